@@ -1,0 +1,757 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement of the reference's bundle-adjustment hot path.  Only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, link or call
+// anything in oracle/.  The product (realsensecalibration_amd/) never does.
+//
+// What is restated, and from where:
+//   * residual functors            /root/reference/Main_Calibration/bundle_adjustment.h:56-343
+//                                  /root/reference/Test1_BundleAdjustment/bundle_adjustmenter.cpp:106-148
+//                                  /root/reference/Test2_BundleAdjustment/bundle_adjustmenter.cpp:217-366
+//   * problem wiring               /root/reference/Main_Calibration/bundle_adjustment_manager.cpp:16-96
+//                                  /root/reference/Test1_BundleAdjustment/main.cpp:63-87
+//                                  /root/reference/Test2_BundleAdjustment/main.cpp:60-104
+//   * corner export / metric       /root/reference/Main_Calibration/bundle_adjustment.cpp:89-130
+//                                  /root/reference/Main_Calibration/reprojection_check.cpp:76-101
+//   * the solver itself lives in a dependency that is NOT vendored in the reference:
+//     Ceres Solver 1.14.0 (README.md:17, PropertySheet.props:6-11).  Its published
+//     algorithm is restated here: Jet-based AutoDiff, AngleAxisRotatePoint (rotation.h),
+//     TrustRegionMinimizer + LevenbergMarquardtStrategy, Schur elimination of the point
+//     blocks and a dense LLT of the reduced camera system, loss-function corrector.
+//
+// Parity pin: the marker-chain model reproduces both input→output pairs the reference
+// commits (hongo/ and test2/ under Common/Correspondence) to <1e-12 (tests/test_oracle_golden.py).
+// The point model (Test1 functor) has no committed output in the reference: it is pinned
+// transitively (same LM driver, same Jet/rotation code, Schur path cross-checked against the
+// dense normal-equation path).
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace oracle {
+
+// ---------------------------------------------------------------------------------------------
+// Jet: forward-mode dual number, the arithmetic Ceres' AutoDiffCostFunction evaluates functors in
+// (ceres/jet.h).  Only the operations the reference functors use.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct Jet {
+  double a;
+  double v[N];
+  Jet() : a(0.0) { for (int i = 0; i < N; ++i) v[i] = 0.0; }
+  explicit Jet(double x) : a(x) { for (int i = 0; i < N; ++i) v[i] = 0.0; }
+  Jet(double x, int k) : a(x) { for (int i = 0; i < N; ++i) v[i] = 0.0; v[k] = 1.0; }
+};
+template <int N> inline Jet<N> operator+(const Jet<N>& f, const Jet<N>& g) {
+  Jet<N> h; h.a = f.a + g.a; for (int i = 0; i < N; ++i) h.v[i] = f.v[i] + g.v[i]; return h; }
+template <int N> inline Jet<N> operator-(const Jet<N>& f, const Jet<N>& g) {
+  Jet<N> h; h.a = f.a - g.a; for (int i = 0; i < N; ++i) h.v[i] = f.v[i] - g.v[i]; return h; }
+template <int N> inline Jet<N> operator-(const Jet<N>& f) {
+  Jet<N> h; h.a = -f.a; for (int i = 0; i < N; ++i) h.v[i] = -f.v[i]; return h; }
+template <int N> inline Jet<N> operator*(const Jet<N>& f, const Jet<N>& g) {
+  Jet<N> h; h.a = f.a * g.a; for (int i = 0; i < N; ++i) h.v[i] = f.a * g.v[i] + f.v[i] * g.a; return h; }
+template <int N> inline Jet<N> operator/(const Jet<N>& f, const Jet<N>& g) {
+  // jet.h: b_inverse = 1/g.a; f_by_g = f.a*b_inverse; v = (f.v - f_by_g*g.v)*b_inverse
+  Jet<N> h; const double gi = 1.0 / g.a; const double fg = f.a * gi; h.a = fg;
+  for (int i = 0; i < N; ++i) h.v[i] = (f.v[i] - fg * g.v[i]) * gi; return h; }
+template <int N> inline Jet<N>& operator+=(Jet<N>& f, const Jet<N>& g) { f = f + g; return f; }
+template <int N> inline bool operator>(const Jet<N>& f, const Jet<N>& g) { return f.a > g.a; }
+template <int N> inline Jet<N> sqrt(const Jet<N>& f) {
+  Jet<N> h; const double t = std::sqrt(f.a); const double s = 1.0 / (2.0 * t); h.a = t;
+  for (int i = 0; i < N; ++i) h.v[i] = f.v[i] * s; return h; }
+template <int N> inline Jet<N> cos(const Jet<N>& f) {
+  Jet<N> h; h.a = std::cos(f.a); const double s = -std::sin(f.a);
+  for (int i = 0; i < N; ++i) h.v[i] = s * f.v[i]; return h; }
+template <int N> inline Jet<N> sin(const Jet<N>& f) {
+  Jet<N> h; h.a = std::sin(f.a); const double c = std::cos(f.a);
+  for (int i = 0; i < N; ++i) h.v[i] = c * f.v[i]; return h; }
+inline double sqrt(double x) { return std::sqrt(x); }
+inline double cos(double x) { return std::cos(x); }
+inline double sin(double x) { return std::sin(x); }
+
+template <typename T> struct Scalar { static double value(const T& t) { return t.a; } };
+template <> struct Scalar<double> { static double value(const double& t) { return t; } };
+
+// ---------------------------------------------------------------------------------------------
+// ceres::AngleAxisRotatePoint (ceres/rotation.h, 1.14).  Call sites in the reference:
+// bundle_adjustment.h:97,103,109,176,182,247,253,320; bundle_adjustment.cpp:114,119;
+// Test1_BundleAdjustment/bundle_adjustmenter.cpp:126.  Safe for result == pt.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+inline void AngleAxisRotatePoint(const T angle_axis[3], const T pt[3], T result[3]) {
+  const T theta2 = angle_axis[0] * angle_axis[0] + angle_axis[1] * angle_axis[1] + angle_axis[2] * angle_axis[2];
+  if (theta2 > T(std::numeric_limits<double>::epsilon())) {
+    const T theta = sqrt(theta2);
+    const T costheta = cos(theta);
+    const T sintheta = sin(theta);
+    const T theta_inverse = T(1.0) / theta;
+    const T w[3] = {angle_axis[0] * theta_inverse, angle_axis[1] * theta_inverse, angle_axis[2] * theta_inverse};
+    const T w_cross_pt[3] = {w[1] * pt[2] - w[2] * pt[1], w[2] * pt[0] - w[0] * pt[2], w[0] * pt[1] - w[1] * pt[0]};
+    const T tmp = (w[0] * pt[0] + w[1] * pt[1] + w[2] * pt[2]) * (T(1.0) - costheta);
+    const T r0 = pt[0] * costheta + w_cross_pt[0] * sintheta + w[0] * tmp;
+    const T r1 = pt[1] * costheta + w_cross_pt[1] * sintheta + w[1] * tmp;
+    const T r2 = pt[2] * costheta + w_cross_pt[2] * sintheta + w[2] * tmp;
+    result[0] = r0; result[1] = r1; result[2] = r2;
+  } else {
+    const T w_cross_pt[3] = {angle_axis[1] * pt[2] - angle_axis[2] * pt[1],
+                             angle_axis[2] * pt[0] - angle_axis[0] * pt[2],
+                             angle_axis[0] * pt[1] - angle_axis[1] * pt[0]};
+    const T r0 = pt[0] + w_cross_pt[0];
+    const T r1 = pt[1] + w_cross_pt[1];
+    const T r2 = pt[2] + w_cross_pt[2];
+    result[0] = r0; result[1] = r1; result[2] = r2;
+  }
+}
+
+struct Intrinsics { double fx, fy, ppx, ppy; };
+
+// Point model: ReprojectionError::operator() — Test1_BundleAdjustment/bundle_adjustmenter.cpp:122-141.
+template <typename T>
+inline void PointReprojectionError(const T* camera, const T* point, const Intrinsics& K,
+                                   double observed_x, double observed_y, T* residuals) {
+  T p[3];
+  AngleAxisRotatePoint(camera, point, p);
+  p[0] = p[0] + camera[3];
+  p[1] = p[1] + camera[4];
+  p[2] = p[2] + camera[5];
+  T xp = T(K.fx) * p[0] / p[2] + T(K.ppx);
+  T yp = T(K.fy) * p[1] / p[2] + T(K.ppy);
+  residuals[0] = xp - T(observed_x);
+  residuals[1] = yp - T(observed_y);
+}
+
+// Marker-chain model.  One body restates the four functors of bundle_adjustment.h:
+//   TargetCameraReprojectionError            :74-125  (camera, time, marker)
+//   BaseCameraReprojectionError              :152-198 (time, marker)            camera == nullptr
+//   TargetCameraBaseMarkerReprojectionError  :225-269 (camera, time)            marker == nullptr
+//   BaseCameraBaseMarkerReprojectionError    :296-336 (time)                    both nullptr
+// Corner order (-h,+h) (+h,+h) (+h,-h) (-h,-h), z = 0 (:77-89).
+template <typename T>
+inline void MarkerChainReprojectionError(const T* camera, const T* time, const T* marker,
+                                         double half_marker_side, const Intrinsics& K,
+                                         const double* observations, T* residuals) {
+  const double h = half_marker_side;
+  const double corner[4][3] = {{-h, h, 0}, {h, h, 0}, {h, -h, 0}, {-h, -h, 0}};
+  for (int i = 0; i < 4; ++i) {
+    T p[3] = {T(corner[i][0]), T(corner[i][1]), T(corner[i][2])};
+    if (marker) {  // coordinate on base marker
+      AngleAxisRotatePoint(marker, p, p);
+      p[0] = p[0] + marker[3]; p[1] = p[1] + marker[4]; p[2] = p[2] + marker[5];
+    }
+    // coordinate on base camera
+    AngleAxisRotatePoint(time, p, p);
+    p[0] = p[0] + time[3]; p[1] = p[1] + time[4]; p[2] = p[2] + time[5];
+    if (camera) {  // coordinate on target camera
+      AngleAxisRotatePoint(camera, p, p);
+      p[0] = p[0] + camera[3]; p[1] = p[1] + camera[4]; p[2] = p[2] + camera[5];
+    }
+    T xp = T(K.fx) * p[0] / p[2] + T(K.ppx);
+    T yp = T(K.fy) * p[1] / p[2] + T(K.ppy);
+    residuals[2 * i] = xp - T(observations[2 * i]);
+    residuals[2 * i + 1] = yp - T(observations[2 * i + 1]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Solver::Options as left by bundle_adjustment_manager.cpp:90-92 (Ceres 1.14 defaults).
+// ---------------------------------------------------------------------------------------------
+struct Options {
+  int max_num_iterations = 50;
+  double initial_trust_region_radius = 1e4;
+  double max_trust_region_radius = 1e16;
+  double min_trust_region_radius = 1e-32;
+  double min_relative_decrease = 1e-3;
+  double min_lm_diagonal = 1e-6;
+  double max_lm_diagonal = 1e32;
+  int max_num_consecutive_invalid_steps = 5;
+  double function_tolerance = 1e-6;
+  double gradient_tolerance = 1e-10;
+  double parameter_tolerance = 1e-8;
+  int jacobi_scaling = 1;
+  double huber_delta = 0.0;  // 0: no loss (the reference passes NULL everywhere)
+  int num_threads = 1;
+};
+
+enum Termination { CONVERGENCE = 0, NO_CONVERGENCE = 1, FAILURE = 2 };
+enum StopReason { STOP_NONE = 0, STOP_GRADIENT = 1, STOP_PARAMETER = 2, STOP_FUNCTION = 3,
+                  STOP_MAX_ITERATIONS = 4, STOP_MIN_RADIUS = 5, STOP_INVALID_STEPS = 6, STOP_INITIAL_FAILURE = 7 };
+
+struct IterationSummary {
+  int iteration = 0;
+  int step_is_valid = 0;
+  int step_is_successful = 0;
+  double cost = 0, cost_change = 0, gradient_max_norm = 0, step_norm = 0, relative_decrease = 0,
+         trust_region_radius = 0;
+};
+
+struct Summary {
+  int termination = NO_CONVERGENCE;
+  int stop_reason = STOP_NONE;
+  int num_successful_steps = 0;
+  int num_unsuccessful_steps = 0;
+  int num_iterations = 0;  // excluding iteration 0
+  double initial_cost = 0, final_cost = 0;
+  std::vector<IterationSummary> iterations;
+};
+
+// Loss (ceres/loss_function.cc HuberLoss, corrector.cc).  rho[0..2] = rho(s), rho'(s), rho''(s).
+inline void HuberEvaluate(double a, double s, double rho[3]) {
+  const double b = a * a;
+  if (s > b) {
+    const double r = std::sqrt(s);
+    rho[0] = 2.0 * a * r - b;
+    rho[1] = std::max(std::numeric_limits<double>::min(), a / r);
+    rho[2] = -rho[1] / (2.0 * s);
+  } else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+}
+
+// Dense symmetric positive definite solve (Eigen LLT in the reference build): in-place lower Cholesky.
+inline bool CholeskyFactor(int n, double* A /* row-major, lower used */) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    d = std::sqrt(d);
+    A[(size_t)j * n + j] = d;
+    const double inv = 1.0 / d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[(size_t)i * n + j];
+      const double* ai = A + (size_t)i * n;
+      const double* aj = A + (size_t)j * n;
+      for (int k = 0; k < j; ++k) s -= ai[k] * aj[k];
+      A[(size_t)i * n + j] = s * inv;
+    }
+  }
+  return true;
+}
+inline void CholeskySolve(int n, const double* L, double* b) {
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[(size_t)i * n + k] * b[k];
+    b[i] = s / L[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int k = i + 1; k < n; ++k) s -= L[(size_t)k * n + i] * b[k];
+    b[i] = s / L[(size_t)i * n + i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TrustRegionMinimizer + LevenbergMarquardtStrategy (Ceres 1.14 trust_region_minimizer.cc,
+// levenberg_marquardt_strategy.cc), generic over a Model that owns r and J.
+//
+// Model concept:
+//   int  num_parameters() const;
+//   bool Evaluate(const double* x, double* cost, bool with_jacobian);  // fills r (+ unscaled J, g = J'r)
+//   const double* gradient() const;
+//   void SquaredColumnNorm(double* out) const;       // of the current (possibly scaled) J
+//   void ScaleColumns(const double* s);
+//   bool Solve(const double* D, double* y);          // (J'J + diag(D)^2) y = J'r
+//   double ModelCostChange(const double* step) const;  // -(J step).(r + J step/2)
+// ---------------------------------------------------------------------------------------------
+template <typename Model>
+inline void TrustRegionMinimize(Model& model, const Options& opt, double* x_inout, Summary* summary) {
+  const int n = model.num_parameters();
+  std::vector<double> x(x_inout, x_inout + n), cand(n), delta(n), step(n), scale(n, 1.0), diag(n), lmd(n);
+  summary->iterations.clear();
+  double x_cost = 0;
+  IterationSummary it;
+  if (!model.Evaluate(x.data(), &x_cost, true)) {
+    summary->termination = FAILURE; summary->stop_reason = STOP_INITIAL_FAILURE; return;
+  }
+  if (opt.jacobi_scaling) {
+    model.SquaredColumnNorm(scale.data());
+    for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(scale[i]));
+    model.ScaleColumns(scale.data());
+  }
+  auto max_norm = [&](const double* g) { double m = 0; for (int i = 0; i < n; ++i) m = std::max(m, std::fabs(g[i])); return m; };
+  auto norm = [&](const double* v) { double s = 0; for (int i = 0; i < n; ++i) s += v[i] * v[i]; return std::sqrt(s); };
+  double x_norm = norm(x.data());
+  double gradient_max_norm = max_norm(model.gradient());
+  double radius = opt.initial_trust_region_radius;
+  double decrease_factor = 2.0;
+  bool reuse_diagonal = false;
+  int num_consecutive_invalid_steps = 0;
+  it.iteration = 0; it.cost = x_cost; it.gradient_max_norm = gradient_max_norm; it.trust_region_radius = radius;
+  it.step_is_valid = 0; it.step_is_successful = 0;
+  summary->initial_cost = x_cost;
+  summary->iterations.push_back(it);
+  summary->termination = NO_CONVERGENCE;
+  auto finish = [&](int term, int reason) {
+    summary->termination = term; summary->stop_reason = reason; summary->final_cost = x_cost;
+    summary->num_iterations = (int)summary->iterations.size() - 1;
+    std::memcpy(x_inout, x.data(), sizeof(double) * n);
+  };
+  if (gradient_max_norm <= opt.gradient_tolerance) { finish(CONVERGENCE, STOP_GRADIENT); return; }
+
+  for (;;) {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue() of the previous iteration.
+    if (summary->iterations.back().iteration >= opt.max_num_iterations) { finish(NO_CONVERGENCE, STOP_MAX_ITERATIONS); return; }
+    if (gradient_max_norm <= opt.gradient_tolerance) { finish(CONVERGENCE, STOP_GRADIENT); return; }
+    if (radius < opt.min_trust_region_radius) { finish(CONVERGENCE, STOP_MIN_RADIUS); return; }
+
+    it = IterationSummary();
+    it.iteration = summary->iterations.back().iteration + 1;
+    // LevenbergMarquardtStrategy::ComputeStep
+    if (!reuse_diagonal) {
+      model.SquaredColumnNorm(diag.data());
+      for (int i = 0; i < n; ++i) diag[i] = std::min(std::max(diag[i], opt.min_lm_diagonal), opt.max_lm_diagonal);
+    }
+    for (int i = 0; i < n; ++i) lmd[i] = std::sqrt(diag[i] / radius);
+    bool ok = model.Solve(lmd.data(), step.data());
+    if (ok) for (int i = 0; i < n; ++i) if (!std::isfinite(step[i])) { ok = false; break; }
+    reuse_diagonal = true;
+    double model_cost_change = 0;
+    if (ok) {
+      for (int i = 0; i < n; ++i) step[i] = -step[i];
+      model_cost_change = model.ModelCostChange(step.data());
+      it.step_is_valid = model_cost_change > 0.0;
+    }
+    if (!it.step_is_valid) {
+      // HandleInvalidStep
+      ++num_consecutive_invalid_steps;
+      it.cost = x_cost; it.gradient_max_norm = gradient_max_norm;
+      if (num_consecutive_invalid_steps >= opt.max_num_consecutive_invalid_steps) {
+        summary->iterations.push_back(it); ++summary->num_unsuccessful_steps;
+        finish(FAILURE, STOP_INVALID_STEPS); return;
+      }
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      it.trust_region_radius = radius;
+      summary->iterations.push_back(it); ++summary->num_unsuccessful_steps;
+      continue;
+    }
+    num_consecutive_invalid_steps = 0;
+    for (int i = 0; i < n; ++i) { delta[i] = step[i] * scale[i]; cand[i] = x[i] + delta[i]; }
+    double cand_cost = 0;
+    if (!model.Evaluate(cand.data(), &cand_cost, false) || !std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    // ParameterToleranceReached
+    { double s = 0; for (int i = 0; i < n; ++i) { const double d = x[i] - cand[i]; s += d * d; } it.step_norm = std::sqrt(s); }
+    it.cost = x_cost; it.gradient_max_norm = gradient_max_norm; it.trust_region_radius = radius;
+    if (it.step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {
+      summary->iterations.push_back(it); finish(CONVERGENCE, STOP_PARAMETER); return;
+    }
+    // FunctionToleranceReached
+    it.cost_change = x_cost - cand_cost;
+    if (std::fabs(it.cost_change) <= opt.function_tolerance * x_cost) {
+      summary->iterations.push_back(it); finish(CONVERGENCE, STOP_FUNCTION); return;
+    }
+    it.relative_decrease = it.cost_change / model_cost_change;
+    if (it.relative_decrease > opt.min_relative_decrease) {
+      // HandleSuccessfulStep
+      x = cand; x_norm = norm(x.data());
+      model.Evaluate(x.data(), &x_cost, true);
+      if (opt.jacobi_scaling) model.ScaleColumns(scale.data());
+      gradient_max_norm = max_norm(model.gradient());
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+      radius = std::min(opt.max_trust_region_radius, radius);
+      decrease_factor = 2.0; reuse_diagonal = false;
+      it.step_is_successful = 1; it.cost = x_cost; it.gradient_max_norm = gradient_max_norm;
+      it.trust_region_radius = radius;
+      ++summary->num_successful_steps;
+    } else {
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      it.trust_region_radius = radius;
+      ++summary->num_unsuccessful_steps;
+    }
+    summary->iterations.push_back(it);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Marker-chain problem (config 1): dense Jacobian, normal equations + LLT.  DENSE_SCHUR with the
+// automatic ordering is the same linear system solved by block elimination; the fixtures agree to
+// 1e-15 either way.
+// ---------------------------------------------------------------------------------------------
+struct MarkerChainProblem {
+  // variant 0: Main_Calibration wiring (bundle_adjustment_manager.cpp:21-88): camera block skipped
+  //            when camera_idx == 0, marker block skipped when marker_idx == 0.
+  // variant 1: Test2_BundleAdjustment wiring (main.cpp:64-96): camera block skipped when
+  //            camera_idx == 0; the marker block is always a parameter.
+  int variant = 0;
+  int T = 0, C = 0, M = 0, N = 0;
+  const int *time_idx = nullptr, *camera_idx = nullptr, *marker_idx = nullptr;
+  const double* observations = nullptr;   // 8 per observation
+  const Intrinsics* intrinsics = nullptr;  // per camera index
+  double marker_side = 0;
+  // parameter layout [C cameras | T times | M markers] x 6 (bundle_adjustment.cpp:64-87)
+  int num_blocks() const { return C + T + M; }
+  bool uses_camera(int i) const { return camera_idx[i] != 0; }
+  bool uses_marker(int i) const { return variant == 1 ? true : marker_idx[i] != 0; }
+  int camera_block(int i) const { return camera_idx[i]; }
+  int time_block(int i) const { return C + time_idx[i]; }
+  int marker_block(int i) const { return C + T + marker_idx[i]; }
+};
+
+class MarkerChainModel {
+ public:
+  MarkerChainModel(const MarkerChainProblem& p, const double* full_params) : p_(p) {
+    full_.assign(full_params, full_params + 6 * p.num_blocks());
+    block_to_active_.assign(p.num_blocks(), -1);
+    std::vector<char> used(p.num_blocks(), 0);
+    for (int i = 0; i < p.N; ++i) {
+      if (p.uses_camera(i)) used[p.camera_block(i)] = 1;
+      used[p.time_block(i)] = 1;
+      if (p.uses_marker(i)) used[p.marker_block(i)] = 1;
+    }
+    for (int b = 0; b < p.num_blocks(); ++b) if (used[b]) { block_to_active_[b] = (int)active_blocks_.size(); active_blocks_.push_back(b); }
+    n_ = 6 * (int)active_blocks_.size();
+    m_ = 8 * p.N;
+    r_.assign(m_, 0.0); J_.assign((size_t)m_ * n_, 0.0); g_.assign(n_, 0.0);
+  }
+  int num_parameters() const { return n_; }
+  int num_residuals() const { return m_; }
+  const std::vector<int>& active_blocks() const { return active_blocks_; }
+  void GetActive(double* x) const { for (size_t k = 0; k < active_blocks_.size(); ++k) std::memcpy(x + 6 * k, &full_[6 * active_blocks_[k]], 48); }
+  void Scatter(const double* x, double* full) const {
+    std::memcpy(full, full_.data(), sizeof(double) * full_.size());
+    for (size_t k = 0; k < active_blocks_.size(); ++k) std::memcpy(full + 6 * active_blocks_[k], x + 6 * k, 48);
+  }
+  bool Evaluate(const double* x, double* cost, bool with_jacobian) {
+    typedef Jet<18> J18;
+    double c = 0;
+    if (with_jacobian) std::fill(J_.begin(), J_.end(), 0.0);
+    for (int i = 0; i < p_.N; ++i) {
+      const bool uc = p_.uses_camera(i), um = p_.uses_marker(i);
+      const int bc = uc ? block_to_active_[p_.camera_block(i)] : -1;
+      const int bt = block_to_active_[p_.time_block(i)];
+      const int bm = um ? block_to_active_[p_.marker_block(i)] : -1;
+      const Intrinsics& K = p_.intrinsics[p_.camera_idx[i]];
+      const double h = p_.marker_side / 2;
+      double res[8];
+      if (!with_jacobian) {
+        MarkerChainReprojectionError<double>(uc ? x + 6 * bc : nullptr, x + 6 * bt, um ? x + 6 * bm : nullptr, h, K,
+                                             p_.observations + 8 * i, res);
+      } else {
+        J18 cam[6], tim[6], mar[6], jr[8];
+        for (int k = 0; k < 6; ++k) {
+          if (uc) cam[k] = J18(x[6 * bc + k], k);
+          tim[k] = J18(x[6 * bt + k], 6 + k);
+          if (um) mar[k] = J18(x[6 * bm + k], 12 + k);
+        }
+        MarkerChainReprojectionError<J18>(uc ? cam : nullptr, tim, um ? mar : nullptr, h, K, p_.observations + 8 * i, jr);
+        for (int r = 0; r < 8; ++r) {
+          res[r] = jr[r].a;
+          double* row = &J_[(size_t)(8 * i + r) * n_];
+          for (int k = 0; k < 6; ++k) {
+            if (uc) row[6 * bc + k] = jr[r].v[k];
+            row[6 * bt + k] = jr[r].v[6 + k];
+            if (um) row[6 * bm + k] = jr[r].v[12 + k];
+          }
+        }
+      }
+      for (int r = 0; r < 8; ++r) {
+        if (!std::isfinite(res[r])) return false;
+        if (with_jacobian) r_[8 * i + r] = res[r];
+        c += res[r] * res[r];
+      }
+    }
+    *cost = 0.5 * c;
+    if (with_jacobian) {
+      std::fill(g_.begin(), g_.end(), 0.0);
+      for (int r = 0; r < m_; ++r) { const double* row = &J_[(size_t)r * n_]; const double rr = r_[r]; for (int k = 0; k < n_; ++k) g_[k] += row[k] * rr; }
+    }
+    return true;
+  }
+  const double* gradient() const { return g_.data(); }
+  const double* residuals() const { return r_.data(); }
+  const double* jacobian() const { return J_.data(); }
+  void SquaredColumnNorm(double* out) const {
+    for (int k = 0; k < n_; ++k) out[k] = 0;
+    for (int r = 0; r < m_; ++r) { const double* row = &J_[(size_t)r * n_]; for (int k = 0; k < n_; ++k) out[k] += row[k] * row[k]; }
+  }
+  void ScaleColumns(const double* s) { for (int r = 0; r < m_; ++r) { double* row = &J_[(size_t)r * n_]; for (int k = 0; k < n_; ++k) row[k] *= s[k]; } }
+  bool Solve(const double* D, double* y) {
+    std::vector<double> A((size_t)n_ * n_, 0.0);
+    for (int r = 0; r < m_; ++r) {
+      const double* row = &J_[(size_t)r * n_];
+      for (int i = 0; i < n_; ++i) { const double ri = row[i]; if (ri == 0.0) continue; double* Ai = &A[(size_t)i * n_]; for (int j = 0; j <= i; ++j) Ai[j] += ri * row[j]; }
+    }
+    for (int i = 0; i < n_; ++i) { A[(size_t)i * n_ + i] += D[i] * D[i]; y[i] = 0; }
+    for (int r = 0; r < m_; ++r) { const double* row = &J_[(size_t)r * n_]; for (int k = 0; k < n_; ++k) y[k] += row[k] * r_[r]; }
+    if (!CholeskyFactor(n_, A.data())) return false;
+    CholeskySolve(n_, A.data(), y);
+    return true;
+  }
+  double ModelCostChange(const double* step) const {
+    double s = 0;
+    for (int r = 0; r < m_; ++r) { const double* row = &J_[(size_t)r * n_]; double mr = 0; for (int k = 0; k < n_; ++k) mr += row[k] * step[k]; s += mr * (r_[r] + mr / 2.0); }
+    return -s;
+  }
+ private:
+  MarkerChainProblem p_;
+  std::vector<double> full_, r_, J_, g_;
+  std::vector<int> block_to_active_, active_blocks_;
+  int n_ = 0, m_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Point model (configs 2-5): block-sparse Jacobian (2x6 camera, 2x3 point per observation),
+// Schur elimination of all point blocks (schur_eliminator_impl.h), dense LLT of the reduced
+// camera system (schur_complement_solver.cc), back-substitution.
+// Parameter layout [C cameras x 6 | P points x 3] (Test1 bundle_adjustmenter.cpp:35-53).
+// ---------------------------------------------------------------------------------------------
+struct PointProblem {
+  int C = 0, P = 0; int64_t N = 0;
+  const int* camera_idx = nullptr; const int* point_idx = nullptr;
+  const double* observations = nullptr;   // 2 per observation
+  const Intrinsics* intrinsics = nullptr;  // per camera
+};
+
+class PointSchurModel {
+ public:
+  PointSchurModel(const PointProblem& p, const Options& opt) : p_(p), opt_(opt) {
+    n_ = 6 * p.C + 3 * p.P;
+    r_.assign(2 * p.N, 0.0); Jc_.assign(12 * p.N, 0.0); Jp_.assign(6 * p.N, 0.0); g_.assign(n_, 0.0);
+    // observations grouped by point (CSR), the order the eliminator walks them in
+    pt_ptr_.assign(p.P + 1, 0);
+    for (int64_t i = 0; i < p.N; ++i) pt_ptr_[p.point_idx[i] + 1]++;
+    for (int j = 0; j < p.P; ++j) pt_ptr_[j + 1] += pt_ptr_[j];
+    pt_obs_.resize(p.N);
+    std::vector<int64_t> fill(pt_ptr_.begin(), pt_ptr_.end() - 1);
+    for (int64_t i = 0; i < p.N; ++i) pt_obs_[fill[p.point_idx[i]]++] = i;
+  }
+  int num_parameters() const { return n_; }
+  // Cost only: operator()<double>; with Jacobian: operator()<Jet<double,9>> (AutoDiff <2,6,3>),
+  // followed by the loss corrector when a loss is set (residual_block.cc / corrector.cc).
+  bool Evaluate(const double* x, double* cost, bool with_jacobian) {
+    typedef Jet<9> J9;
+    const double* cams = x; const double* pts = x + 6 * p_.C;
+    double total = 0; int bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : total) reduction(| : bad) num_threads(opt_.num_threads)
+    for (int64_t i = 0; i < p_.N; ++i) {
+      const int c = p_.camera_idx[i], j = p_.point_idx[i];
+      double res[2], jc[12] = {0}, jp[6] = {0};
+      if (!with_jacobian) {
+        PointReprojectionError<double>(cams + 6 * c, pts + 3 * j, p_.intrinsics[c], p_.observations[2 * i], p_.observations[2 * i + 1], res);
+      } else {
+        J9 cam[6], pt[3], jr[2];
+        for (int k = 0; k < 6; ++k) cam[k] = J9(cams[6 * c + k], k);
+        for (int k = 0; k < 3; ++k) pt[k] = J9(pts[3 * j + k], 6 + k);
+        PointReprojectionError<J9>(cam, pt, p_.intrinsics[c], p_.observations[2 * i], p_.observations[2 * i + 1], jr);
+        for (int r = 0; r < 2; ++r) { res[r] = jr[r].a; for (int k = 0; k < 6; ++k) jc[6 * r + k] = jr[r].v[k]; for (int k = 0; k < 3; ++k) jp[3 * r + k] = jr[r].v[6 + k]; }
+      }
+      if (!std::isfinite(res[0]) || !std::isfinite(res[1])) { bad |= 1; continue; }
+      const double s = res[0] * res[0] + res[1] * res[1];
+      double rho[3] = {s, 1.0, 0.0};
+      if (opt_.huber_delta > 0) HuberEvaluate(opt_.huber_delta, s, rho);
+      total += rho[0];
+      if (with_jacobian) {
+        // Corrector: Huber has rho'' <= 0, so residual and Jacobian are scaled by sqrt(rho').
+        const double sq = std::sqrt(rho[1]);
+        r_[2 * i] = res[0] * sq; r_[2 * i + 1] = res[1] * sq;
+        for (int k = 0; k < 12; ++k) Jc_[12 * i + k] = jc[k] * sq;
+        for (int k = 0; k < 6; ++k) Jp_[6 * i + k] = jp[k] * sq;
+      }
+    }
+    if (bad) return false;
+    *cost = 0.5 * total;
+    if (with_jacobian) {
+      std::fill(g_.begin(), g_.end(), 0.0);
+      for (int64_t i = 0; i < p_.N; ++i) {
+        const int c = p_.camera_idx[i], j = p_.point_idx[i];
+        for (int r = 0; r < 2; ++r) {
+          const double rr = r_[2 * i + r];
+          for (int k = 0; k < 6; ++k) g_[6 * c + k] += Jc_[12 * i + 6 * r + k] * rr;
+          for (int k = 0; k < 3; ++k) g_[6 * p_.C + 3 * j + k] += Jp_[6 * i + 3 * r + k] * rr;
+        }
+      }
+    }
+    return true;
+  }
+  const double* gradient() const { return g_.data(); }
+  void SquaredColumnNorm(double* out) const {
+    std::fill(out, out + n_, 0.0);
+    for (int64_t i = 0; i < p_.N; ++i) {
+      const int c = p_.camera_idx[i], j = p_.point_idx[i];
+      for (int r = 0; r < 2; ++r) {
+        for (int k = 0; k < 6; ++k) { const double v = Jc_[12 * i + 6 * r + k]; out[6 * c + k] += v * v; }
+        for (int k = 0; k < 3; ++k) { const double v = Jp_[6 * i + 3 * r + k]; out[6 * p_.C + 3 * j + k] += v * v; }
+      }
+    }
+  }
+  void ScaleColumns(const double* s) {
+    for (int64_t i = 0; i < p_.N; ++i) {
+      const int c = p_.camera_idx[i], j = p_.point_idx[i];
+      for (int r = 0; r < 2; ++r) {
+        for (int k = 0; k < 6; ++k) Jc_[12 * i + 6 * r + k] *= s[6 * c + k];
+        for (int k = 0; k < 3; ++k) Jp_[6 * i + 3 * r + k] *= s[6 * p_.C + 3 * j + k];
+      }
+    }
+  }
+  // Reduced system only (exposed so tests can compare the HIP Schur kernels stage by stage).
+  // S is (6C)^2 row-major, full symmetric; rhs is 6C.
+  void BuildReducedSystem(const double* D, double* S, double* rhs, std::vector<double>* ete_inv_out) const {
+    const int nc = 6 * p_.C;
+    int nt = std::max(1, opt_.num_threads);
+    std::vector<std::vector<double>> Sl(nt), rl(nt);
+    std::vector<double> ete_inv((size_t)9 * p_.P, 0.0);
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+      const int tid = omp_get_thread_num();
+#else
+      const int tid = 0;
+#endif
+      std::vector<double>& St = Sl[tid]; std::vector<double>& rt = rl[tid];
+      St.assign((size_t)nc * nc, 0.0); rt.assign(nc, 0.0);
+      std::vector<double> W, Y; std::vector<int> cam;
+#pragma omp for schedule(dynamic, 256)
+      for (int j = 0; j < p_.P; ++j) {
+        const int64_t b = pt_ptr_[j], e = pt_ptr_[j + 1];
+        const int k = (int)(e - b);
+        if (k == 0) continue;
+        double ete[9] = {0}, gp[3] = {0};
+        for (int d = 0; d < 3; ++d) { const double dd = D[nc + 3 * j + d]; ete[4 * d] = dd * dd; }
+        W.assign((size_t)18 * k, 0.0); Y.assign((size_t)18 * k, 0.0); cam.resize(k);
+        for (int q = 0; q < k; ++q) {
+          const int64_t i = pt_obs_[b + q];
+          const int c = p_.camera_idx[i]; cam[q] = c;
+          const double* jc = &Jc_[12 * i]; const double* jp = &Jp_[6 * i]; const double* rr = &r_[2 * i];
+          for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) ete[3 * a + bb] += jp[a] * jp[bb] + jp[3 + a] * jp[3 + bb];
+          for (int a = 0; a < 3; ++a) gp[a] += jp[a] * rr[0] + jp[3 + a] * rr[1];
+          double* w = &W[(size_t)18 * q];
+          for (int a = 0; a < 6; ++a) for (int bb = 0; bb < 3; ++bb) w[3 * a + bb] = jc[a] * jp[bb] + jc[6 + a] * jp[3 + bb];
+          // F'F and F'r contributions of this observation to its camera block
+          double* Scc = &St[(size_t)(6 * c) * nc + 6 * c];
+          for (int a = 0; a < 6; ++a) {
+            for (int bb = 0; bb < 6; ++bb) Scc[(size_t)a * nc + bb] += jc[a] * jc[bb] + jc[6 + a] * jc[6 + bb];
+            rt[6 * c + a] += jc[a] * rr[0] + jc[6 + a] * rr[1];
+          }
+        }
+        // (E'E + D_e^2)^-1 via LLT (InvertPSDMatrix<3>)
+        double L[9]; std::memcpy(L, ete, sizeof(L));
+        double inv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (CholeskyFactor(3, L)) {
+          for (int col = 0; col < 3; ++col) { double bcol[3] = {inv[col], inv[3 + col], inv[6 + col]}; CholeskySolve(3, L, bcol); inv[col] = bcol[0]; inv[3 + col] = bcol[1]; inv[6 + col] = bcol[2]; }
+        } else { for (int t = 0; t < 9; ++t) inv[t] = std::numeric_limits<double>::quiet_NaN(); }
+        std::memcpy(&ete_inv[(size_t)9 * j], inv, sizeof(inv));
+        double ig[3]; for (int a = 0; a < 3; ++a) ig[a] = inv[3 * a] * gp[0] + inv[3 * a + 1] * gp[1] + inv[3 * a + 2] * gp[2];
+        for (int q = 0; q < k; ++q) {
+          const double* w = &W[(size_t)18 * q]; double* y = &Y[(size_t)18 * q];
+          for (int a = 0; a < 6; ++a) for (int bb = 0; bb < 3; ++bb) y[3 * a + bb] = w[3 * a] * inv[bb] + w[3 * a + 1] * inv[3 + bb] + w[3 * a + 2] * inv[6 + bb];
+          for (int a = 0; a < 6; ++a) rt[6 * cam[q] + a] -= w[3 * a] * ig[0] + w[3 * a + 1] * ig[1] + w[3 * a + 2] * ig[2];
+        }
+        for (int q1 = 0; q1 < k; ++q1) for (int q2 = 0; q2 < k; ++q2) {
+          const double* y = &Y[(size_t)18 * q1]; const double* w = &W[(size_t)18 * q2];
+          double* Sb = &St[(size_t)(6 * cam[q1]) * nc + 6 * cam[q2]];
+          for (int a = 0; a < 6; ++a) for (int bb = 0; bb < 6; ++bb)
+            Sb[(size_t)a * nc + bb] -= y[3 * a] * w[3 * bb] + y[3 * a + 1] * w[3 * bb + 1] + y[3 * a + 2] * w[3 * bb + 2];
+        }
+      }
+    }
+    std::fill(S, S + (size_t)nc * nc, 0.0); std::fill(rhs, rhs + nc, 0.0);
+    for (int t = 0; t < nt; ++t) { if (Sl[t].empty()) continue; for (size_t q = 0; q < (size_t)nc * nc; ++q) S[q] += Sl[t][q]; for (int q = 0; q < nc; ++q) rhs[q] += rl[t][q]; }
+    for (int q = 0; q < nc; ++q) S[(size_t)q * nc + q] += D[q] * D[q];
+    if (ete_inv_out) ete_inv_out->swap(ete_inv);
+  }
+  bool Solve(const double* D, double* y) {
+    const int nc = 6 * p_.C;
+    std::vector<double> S((size_t)nc * nc), rhs(nc), ete_inv;
+    BuildReducedSystem(D, S.data(), rhs.data(), &ete_inv);
+    for (size_t q = 0; q < ete_inv.size(); ++q) if (!std::isfinite(ete_inv[q])) return false;
+    if (!CholeskyFactor(nc, S.data())) return false;
+    CholeskySolve(nc, S.data(), rhs.data());
+    std::memcpy(y, rhs.data(), sizeof(double) * nc);
+    // back-substitution: y_e = (E'E + D^2)^-1 (E'r - E'F y_f)
+#pragma omp parallel for schedule(static) num_threads(opt_.num_threads)
+    for (int j = 0; j < p_.P; ++j) {
+      double t[3] = {0, 0, 0};
+      for (int64_t q = pt_ptr_[j]; q < pt_ptr_[j + 1]; ++q) {
+        const int64_t i = pt_obs_[q]; const int c = p_.camera_idx[i];
+        const double* jc = &Jc_[12 * i]; const double* jp = &Jp_[6 * i]; const double* rr = &r_[2 * i];
+        double fy0 = 0, fy1 = 0;
+        for (int a = 0; a < 6; ++a) { fy0 += jc[a] * y[6 * c + a]; fy1 += jc[6 + a] * y[6 * c + a]; }
+        for (int a = 0; a < 3; ++a) t[a] += jp[a] * (rr[0] - fy0) + jp[3 + a] * (rr[1] - fy1);
+      }
+      const double* inv = &ete_inv[(size_t)9 * j];
+      for (int a = 0; a < 3; ++a) y[nc + 3 * j + a] = inv[3 * a] * t[0] + inv[3 * a + 1] * t[1] + inv[3 * a + 2] * t[2];
+    }
+    return true;
+  }
+  double ModelCostChange(const double* step) const {
+    double s = 0;
+#pragma omp parallel for schedule(static) reduction(+ : s) num_threads(opt_.num_threads)
+    for (int64_t i = 0; i < p_.N; ++i) {
+      const int c = p_.camera_idx[i], j = p_.point_idx[i];
+      for (int r = 0; r < 2; ++r) {
+        double mr = 0;
+        for (int k = 0; k < 6; ++k) mr += Jc_[12 * i + 6 * r + k] * step[6 * c + k];
+        for (int k = 0; k < 3; ++k) mr += Jp_[6 * i + 3 * r + k] * step[6 * p_.C + 3 * j + k];
+        s += mr * (r_[2 * i + r] + mr / 2.0);
+      }
+    }
+    return -s;
+  }
+  const std::vector<double>& Jc() const { return Jc_; }
+  const std::vector<double>& Jp() const { return Jp_; }
+  const std::vector<double>& residuals() const { return r_; }
+ private:
+  PointProblem p_; Options opt_;
+  int n_ = 0;
+  std::vector<double> r_, Jc_, Jp_, g_;
+  std::vector<int64_t> pt_ptr_, pt_obs_;
+};
+
+// Dense normal-equation twin of PointSchurModel::Solve, used only to cross-check the Schur path.
+inline bool PointDenseSolve(const PointProblem& p, const std::vector<double>& Jc, const std::vector<double>& Jp,
+                            const std::vector<double>& r, const double* D, double* y) {
+  const int n = 6 * p.C + 3 * p.P;
+  std::vector<double> A((size_t)n * n, 0.0);
+  std::fill(y, y + n, 0.0);
+  for (int64_t i = 0; i < p.N; ++i) {
+    const int c = p.camera_idx[i], j = p.point_idx[i];
+    int idx[9]; double row[2][9];
+    for (int k = 0; k < 6; ++k) idx[k] = 6 * c + k;
+    for (int k = 0; k < 3; ++k) idx[6 + k] = 6 * p.C + 3 * j + k;
+    for (int q = 0; q < 2; ++q) { for (int k = 0; k < 6; ++k) row[q][k] = Jc[12 * i + 6 * q + k]; for (int k = 0; k < 3; ++k) row[q][6 + k] = Jp[6 * i + 3 * q + k]; }
+    for (int q = 0; q < 2; ++q) for (int a = 0; a < 9; ++a) {
+      y[idx[a]] += row[q][a] * r[2 * i + q];
+      for (int b = 0; b < 9; ++b) A[(size_t)idx[a] * n + idx[b]] += row[q][a] * row[q][b];
+    }
+  }
+  for (int k = 0; k < n; ++k) A[(size_t)k * n + k] += D[k] * D[k];
+  if (!CholeskyFactor(n, A.data())) return false;
+  CholeskySolve(n, A.data(), y);
+  return true;
+}
+
+// cv::Rodrigues (rvec -> R), used by BAManager::Write (bundle_adjustment_manager.cpp:118-121).
+inline void Rodrigues(const double rvec[3], double R[9]) {
+  const double theta = std::sqrt(rvec[0] * rvec[0] + rvec[1] * rvec[1] + rvec[2] * rvec[2]);
+  if (theta < DBL_EPSILON) { R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1; return; }
+  const double c = std::cos(theta), s = std::sin(theta), c1 = 1.0 - c;
+  const double x = rvec[0] / theta, y = rvec[1] / theta, z = rvec[2] / theta;
+  R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+  R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
+  R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+}
+
+// BALProblem::getPoint3dCoordinates (bundle_adjustment.cpp:89-130): 4 corners per observation through
+// the marker transform (always applied) and the time transform, into the base-camera frame.
+inline void MarkerCorners3d(const MarkerChainProblem& p, const double* params, double* out /* 12 per obs */) {
+  const double h = p.marker_side / 2;
+  const double corner[4][3] = {{-h, h, 0}, {h, h, 0}, {h, -h, 0}, {-h, -h, 0}};
+  for (int i = 0; i < p.N; ++i) {
+    const double* tim = params + 6 * p.time_block(i);
+    const double* mar = params + 6 * p.marker_block(i);
+    for (int j = 0; j < 4; ++j) {
+      double q[3];
+      AngleAxisRotatePoint<double>(mar, corner[j], q);
+      q[0] += mar[3]; q[1] += mar[4]; q[2] += mar[5];
+      AngleAxisRotatePoint<double>(tim, q, q);
+      q[0] += tim[3]; q[1] += tim[4]; q[2] += tim[5];
+      out[12 * i + 3 * j] = q[0]; out[12 * i + 3 * j + 1] = q[1]; out[12 * i + 3 * j + 2] = q[2];
+    }
+  }
+}
+
+}  // namespace oracle
