@@ -1,0 +1,220 @@
+/*
+ * rsba.h — C ABI of the MI355X-native bundle-adjustment path (librsba.so).
+ *
+ * Drop-in boundary for the hot path of ajingu/RealSenseCalibration: everything that
+ * Main_Calibration/bundle_adjustment.h + bundle_adjustment_manager.h hand to Ceres
+ * (problem container, reprojection-error cost, Levenberg-Marquardt + DENSE_SCHUR solve, result
+ * export).  Plain pointers and sizes only; no C++/torch types.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference repository root).
+ *
+ * Parameter layouts are the reference's own:
+ *   point model        [C cameras x (rvec3, tvec3) | P points x xyz]
+ *                      Test1_BundleAdjustment/bundle_adjustmenter.cpp:35-53
+ *   marker-chain model [C cameras | T times | M markers] x (rvec3, tvec3)
+ *                      Main_Calibration/bundle_adjustment.cpp:64-87
+ * Solutions are written in place into the problem's parameter array, exactly as Ceres writes
+ * through the raw pointers BALProblem hands out; blocks that no residual references are untouched.
+ *
+ * All compute runs on the GPU (gfx950).  There is no CPU fallback: every solve entry point returns
+ * RSBA_ERR_NO_DEVICE when no HIP device is present.
+ */
+#ifndef RSBA_H_
+#define RSBA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSBA_VERSION 100
+
+/* ---- return codes (the reference exits the process instead: bundle_adjustment_manager.cpp:8-13) */
+enum {
+  RSBA_OK = 0,
+  RSBA_ERR_IO = 1,        /* file could not be opened (BALProblem::loadFile returns false)   */
+  RSBA_ERR_FORMAT = 2,    /* short or malformed file (reference: fscanfOrDie / unchecked)    */
+  RSBA_ERR_ARG = 3,       /* NULL / out-of-range argument                                    */
+  RSBA_ERR_HIP = 4,       /* a HIP runtime call failed                                       */
+  RSBA_ERR_NO_DEVICE = 5, /* no gfx950 device visible: the product has no CPU path           */
+  RSBA_ERR_COMM = 6,      /* RCCL failure                                                    */
+  RSBA_ERR_UNSUPPORTED = 7
+};
+
+/* ---- models */
+enum {
+  RSBA_MODEL_POINTS = 0,             /* ReprojectionError<2,6,3>, Test1_BundleAdjustment/bundle_adjustmenter.cpp:106-148 */
+  RSBA_MODEL_MARKER_CHAIN = 1,       /* four functors + wiring of Main_Calibration/bundle_adjustment_manager.cpp:21-88  */
+  RSBA_MODEL_MARKER_CHAIN_TEST2 = 2  /* two functors + wiring of Test2_BundleAdjustment/main.cpp:64-96                  */
+};
+
+/* ---- ceres::TerminationType as Summary reports it (bundle_adjustment_manager.cpp:95 FullReport) */
+enum { RSBA_CONVERGENCE = 0, RSBA_NO_CONVERGENCE = 1, RSBA_FAILURE = 2 };
+enum {
+  RSBA_STOP_NONE = 0, RSBA_STOP_GRADIENT = 1, RSBA_STOP_PARAMETER = 2, RSBA_STOP_FUNCTION = 3,
+  RSBA_STOP_MAX_ITERATIONS = 4, RSBA_STOP_MIN_RADIUS = 5, RSBA_STOP_INVALID_STEPS = 6,
+  RSBA_STOP_INITIAL_FAILURE = 7
+};
+
+typedef struct rsba_problem rsba_problem; /* BALProblem (bundle_adjustment.h:18-54) */
+typedef struct rsba_solver rsba_solver;   /* device-resident state of one ceres::Solve call */
+
+/* ceres::Solver::Options as bundle_adjustment_manager.cpp:90-92 leaves it (linear_solver_type =
+ * DENSE_SCHUR, everything else Ceres 1.14 defaults), plus the knobs this implementation adds. */
+typedef struct rsba_options {
+  int32_t max_num_iterations;                /* 50 */
+  int32_t max_num_consecutive_invalid_steps; /* 5 */
+  int32_t jacobi_scaling;                    /* 1 */
+  int32_t minimizer_progress_to_stdout;      /* 0 (the reference sets true, :92) */
+  double initial_trust_region_radius;        /* 1e4 */
+  double max_trust_region_radius;            /* 1e16 */
+  double min_trust_region_radius;            /* 1e-32 */
+  double min_relative_decrease;              /* 1e-3 */
+  double min_lm_diagonal;                    /* 1e-6 */
+  double max_lm_diagonal;                    /* 1e32 */
+  double function_tolerance;                 /* 1e-6 */
+  double gradient_tolerance;                 /* 1e-10 */
+  double parameter_tolerance;                /* 1e-8 */
+  double huber_delta;                        /* 0 = no loss (the reference passes NULL, :38) */
+  /* --- implementation knobs --- */
+  int32_t device;          /* HIP device ordinal, -1 = current                                  */
+  int32_t schur_impl;      /* 0 = reference kernel (global atomics), 1 = tiled (default)         */
+  int32_t profile_kernels; /* 1: bracket every kernel with HIP events (rsba_solver_kernel_stats) */
+  int32_t rank;            /* multi-GPU: this process' rank, 0..world_size-1                     */
+  int32_t world_size;      /* 1 = single GPU.  >1: the problem handed in is this rank's point   */
+                           /* shard (all cameras, its own points); the reduced camera system is */
+                           /* all-reduced over RCCL each iteration                               */
+  int32_t reserved0;
+  const void* comm_unique_id; /* world_size > 1: the 128-byte id from rsba_comm_unique_id (rank 0's) */
+  void* stream;               /* hipStream_t to run on, NULL = a private stream                    */
+} rsba_options;
+
+typedef struct rsba_summary {
+  int32_t termination_type; /* RSBA_CONVERGENCE / NO_CONVERGENCE / FAILURE */
+  int32_t stop_reason;      /* RSBA_STOP_* */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t num_iterations; /* successful + unsuccessful, iteration 0 excluded */
+  int32_t reserved;
+  double initial_cost;
+  double final_cost;
+  double minimizer_seconds; /* wall time of the LM loop only (inputs already on the device) */
+  double setup_seconds;     /* ordering + upload */
+} rsba_summary;
+
+/* one row per iteration (0 = initial evaluation), Ceres' progress table columns */
+typedef struct rsba_iteration {
+  int32_t iteration;
+  int32_t step_is_valid;
+  int32_t step_is_successful;
+  int32_t reserved;
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
+} rsba_iteration;
+
+typedef struct rsba_kernel_stat {
+  char name[48];
+  int64_t launches;
+  double total_ms; /* HIP-event time on the solver stream, profile_kernels = 1 only */
+} rsba_kernel_stat;
+
+int rsba_version(void);
+int rsba_device_count(void);
+const char* rsba_error_string(int code);
+
+/* ------------------------------------------------------------------ problem container */
+/* Point model from arrays (what Test1's BALProblem::LoadFile builds, bundle_adjustmenter.cpp:55-85).
+ * intrinsics: 4 doubles per camera (fx, fy, ppx, ppy) = K(0,0), K(1,1), K(0,2), K(1,2)
+ * (ReprojectionError ctor, :113-120).  Arrays are copied. */
+int rsba_problem_create_points(int32_t num_cameras, int32_t num_points, int64_t num_observations,
+                               const int32_t* camera_index, const int32_t* point_index,
+                               const double* observations /* 2 per observation */,
+                               const double* parameters /* 6C + 3P */,
+                               const double* intrinsics /* 4C */, rsba_problem** out);
+
+/* Test1 file "two_cam_data.txt": `C P`, P rows `cam pt u v` (one observation per point,
+ * bundle_adjustmenter.cpp:62-64), C x (rvec row, tvec row), P rows xyz.  Also accepts the extended
+ * first line `C P N` with N observation rows.  One intrinsics 4-vector is used for every
+ * observation, as Test1_BundleAdjustment/main.cpp:73-74 does. */
+int rsba_problem_load_points_file(const char* path, const double* intrinsics4, rsba_problem** out);
+
+/* BALProblem::loadFile for correspondence.txt (bundle_adjustment.cpp:132-187).
+ * model: RSBA_MODEL_MARKER_CHAIN or RSBA_MODEL_MARKER_CHAIN_TEST2; marker_side: my_const.h:9;
+ * intrinsics: 4 per camera index, in SERIAL_NUMBERS order (my_const.h:15). */
+int rsba_problem_load_correspondence(const char* path, int32_t model, double marker_side,
+                                     const double* intrinsics /* 4C */, rsba_problem** out);
+
+void rsba_problem_free(rsba_problem* p);
+
+/* BALProblem accessors (bundle_adjustment.h:36-53) */
+int32_t rsba_problem_model(const rsba_problem* p);
+int32_t rsba_problem_num_cameras(const rsba_problem* p);
+int32_t rsba_problem_num_points(const rsba_problem* p);  /* point model; 0 otherwise */
+int32_t rsba_problem_num_times(const rsba_problem* p);   /* marker-chain; 0 otherwise */
+int32_t rsba_problem_num_markers(const rsba_problem* p); /* marker-chain; 0 otherwise */
+int64_t rsba_problem_num_observations(const rsba_problem* p);
+int64_t rsba_problem_num_parameters(const rsba_problem* p);
+/* count x 4 corners, as BALProblem::num_observations_per_time_camera returns (bundle_adjustment.cpp:29-32) */
+int32_t rsba_problem_num_observations_per_time_camera(const rsba_problem* p, int32_t time_idx, int32_t camera_idx);
+const double* rsba_problem_observations(const rsba_problem* p);
+double* rsba_problem_parameters(rsba_problem* p); /* mutable: results land here */
+int32_t rsba_problem_camera_idx(const rsba_problem* p, int64_t observation);
+int32_t rsba_problem_point_idx(const rsba_problem* p, int64_t observation);  /* point model */
+int32_t rsba_problem_time_idx(const rsba_problem* p, int64_t observation);   /* marker-chain */
+int32_t rsba_problem_marker_idx(const rsba_problem* p, int64_t observation); /* marker-chain */
+double* rsba_problem_camera_parameters(rsba_problem* p, int32_t camera_idx);
+double* rsba_problem_marker_transform(rsba_problem* p, int32_t marker_idx);
+/* BALProblem::getPoint3dCoordinates (bundle_adjustment.cpp:89-130): 4 corners x xyz per observation */
+int rsba_problem_point3d_coordinates(const rsba_problem* p, double* out /* 12 per observation */);
+
+/* ------------------------------------------------------------------ solve */
+void rsba_options_default(rsba_options* o);
+
+/* BAManager::StartBA / ceres::Solve (bundle_adjustment_manager.cpp:16-96; Test1 main.cpp:63-87):
+ * upload, minimise on the GPU, write the solution back into the problem's parameter array. */
+int rsba_solve(rsba_problem* p, const rsba_options* o, rsba_summary* summary);
+
+/* The same in three steps, so a caller (bench.py) can time the minimiser with inputs resident in HBM. */
+int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out);
+int rsba_solver_run(rsba_solver* s, rsba_summary* summary); /* LM loop; restarts from the uploaded state */
+int rsba_solver_download(rsba_solver* s);                    /* device state -> problem parameters */
+int rsba_solver_iterations(const rsba_solver* s, rsba_iteration* out, int32_t capacity); /* rows written */
+int rsba_solver_kernel_stats(const rsba_solver* s, rsba_kernel_stat* out, int32_t capacity);
+/* final 1/2 sum rho and sum of squared raw residuals of the last run (all ranks' total) */
+int rsba_solver_final_costs(const rsba_solver* s, double* cost, double* sum_sq_residuals);
+void rsba_solver_destroy(rsba_solver* s);
+
+/* Stage-level entry (tests): one linearisation of the point model at the current parameters with a
+ * given trust-region radius.  Any output may be NULL.
+ *   S       (6C)^2 reduced camera matrix, Jacobi-scaled, LM-damped, full symmetric, row-major
+ *   rhs     6C
+ *   delta   6C + 3P: the LM step in parameter space (x_candidate - x)
+ *   scalars [0] cost at x, [1] model cost change, [2] max|gradient|, [3] 1 if the Cholesky succeeded,
+ *           [4] cost at x + delta, [5] |delta|, [6] |x| */
+int rsba_points_linearize_and_step(rsba_problem* p, const rsba_options* o, double radius, double* S,
+                                   double* rhs, double* delta, double* scalars /* 8 */);
+
+/* ------------------------------------------------------------------ multi-GPU bootstrap */
+/* ncclGetUniqueId: rank 0 calls this and ships the 128 bytes to the other ranks (bench.py does it
+ * through torch.distributed); every rank then passes it in rsba_options.comm_unique_id. */
+int rsba_comm_unique_id(void* out128);
+
+/* ------------------------------------------------------------------ files either side of the path */
+/* IO::GetIntrinsics (my_io.cpp:5-31) without OpenCV: reads <intrinsics> 3x3 from an OpenCV
+ * FileStorage XML and returns fx, fy, ppx, ppy. */
+int rsba_read_intrinsics_xml(const char* path, double* out4);
+
+/* BAManager::Write (bundle_adjustment_manager.cpp:98-175).  Any path may be NULL to skip that file.
+ *   camera_transform_xml : R{i} 3x3 (Main) or rvec 3x1 (Test2 variant, main.cpp:128) + t{i}
+ *   extrinsics_dir       : mat{i}.txt = [R^T | -R^T t] one value per line (:135-149)
+ *   point3d_txt          : `4N T C`, count rows, 4N xyz rows (:154-174) */
+int rsba_write_outputs(rsba_problem* p, const char* camera_transform_xml, const char* extrinsics_dir,
+                       const char* point3d_txt);
+
+/* ReprojectionCheck::Reproject's metric (reprojection_check.cpp:76-101) from the current
+ * parameters, evaluated on the GPU: error = sum((du^2+dv^2)/2), rms = sqrt(2 error / (2 n_points)). */
+int rsba_reprojection_error(rsba_problem* p, const rsba_options* o, double* error, double* rms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSBA_H_ */

@@ -1,0 +1,180 @@
+// Per-observation arithmetic of the point model, shared by every HIP kernel.
+//
+// Replaces, on the device, what Ceres' AutoDiffCostFunction<ReprojectionError,2,6,3> computes with
+// Jets for /root/reference/Test1_BundleAdjustment/bundle_adjustmenter.cpp:122-141: the residual and its
+// 2x6 / 2x3 Jacobian blocks, written out analytically.
+//
+//   q = R(w) X,  p = q + t,  r = (fx p0/p2 + ppx - u, fy p1/p2 + ppy - v)
+//   d r / d p    = Pj = [[fx/p2, 0, -fx p0/p2^2], [0, fy/p2, -fy p1/p2^2]]
+//   d r / d X    = Pj R
+//   d r / d t    = Pj
+//   d r / d w    = Pj (-[q]x) Jl(w)         theta^2 >  DBL_EPSILON   (Jl = left Jacobian of SO(3))
+//                = Pj (-[X]x)               theta^2 <= DBL_EPSILON   (AngleAxisRotatePoint's first-order
+//                                            branch: the derivative AutoDiff sees is that of X + w x X)
+// R, Jl and the branch flag depend only on the camera, so they are computed once per camera per
+// linearisation (CameraConstants) instead of once per observation.
+//
+// The header also compiles as plain C++ (g++) so the CPU test-suite can check these formulas against the
+// oracle's dual numbers without a GPU.
+#pragma once
+#include <cfloat>
+#include <cmath>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RSBA_HD __host__ __device__ __forceinline__
+#else
+#define RSBA_HD inline
+#endif
+
+namespace rsba {
+
+// Per-camera constants, 32 doubles (256 B) per camera.
+enum {
+  CC_R = 0,      // 9: rotation matrix, row-major (I + [w]x in the small-angle branch)
+  CC_K = 9,      // 9: left Jacobian Jl(w) (identity in the small-angle branch)
+  CC_T = 18,     // 3: translation
+  CC_FX = 21, CC_FY = 22, CC_PPX = 23, CC_PPY = 24,
+  CC_SMALL = 25, // 1.0 when theta^2 <= DBL_EPSILON
+  CC_STRIDE = 32
+};
+
+RSBA_HD void CameraConstants(const double* cam6, const double* intr4, double* cc) {
+  const double wx = cam6[0], wy = cam6[1], wz = cam6[2];
+  const double theta2 = wx * wx + wy * wy + wz * wz;
+  if (theta2 > DBL_EPSILON) {
+    const double theta = sqrt(theta2);
+    const double c = cos(theta), s = sin(theta);
+    const double it = 1.0 / theta;
+    const double kx = wx * it, ky = wy * it, kz = wz * it;
+    const double sh = sin(0.5 * theta);
+    const double c1 = 2.0 * sh * sh;  // 1 - cos(theta) without cancellation
+    cc[CC_R + 0] = c + c1 * kx * kx;      cc[CC_R + 1] = c1 * kx * ky - s * kz; cc[CC_R + 2] = c1 * kx * kz + s * ky;
+    cc[CC_R + 3] = c1 * kx * ky + s * kz; cc[CC_R + 4] = c + c1 * ky * ky;      cc[CC_R + 5] = c1 * ky * kz - s * kx;
+    cc[CC_R + 6] = c1 * kx * kz - s * ky; cc[CC_R + 7] = c1 * ky * kz + s * kx; cc[CC_R + 8] = c + c1 * kz * kz;
+    const double a = s * it;        // sin(theta)/theta
+    const double b = 1.0 - a;       // 1 - sin(theta)/theta
+    const double d = c1 * it;       // (1 - cos(theta))/theta
+    cc[CC_K + 0] = a + b * kx * kx;      cc[CC_K + 1] = b * kx * ky - d * kz; cc[CC_K + 2] = b * kx * kz + d * ky;
+    cc[CC_K + 3] = b * kx * ky + d * kz; cc[CC_K + 4] = a + b * ky * ky;      cc[CC_K + 5] = b * ky * kz - d * kx;
+    cc[CC_K + 6] = b * kx * kz - d * ky; cc[CC_K + 7] = b * ky * kz + d * kx; cc[CC_K + 8] = a + b * kz * kz;
+    cc[CC_SMALL] = 0.0;
+  } else {
+    cc[CC_R + 0] = 1.0; cc[CC_R + 1] = -wz; cc[CC_R + 2] = wy;
+    cc[CC_R + 3] = wz;  cc[CC_R + 4] = 1.0; cc[CC_R + 5] = -wx;
+    cc[CC_R + 6] = -wy; cc[CC_R + 7] = wx;  cc[CC_R + 8] = 1.0;
+    cc[CC_K + 0] = 1.0; cc[CC_K + 1] = 0.0; cc[CC_K + 2] = 0.0;
+    cc[CC_K + 3] = 0.0; cc[CC_K + 4] = 1.0; cc[CC_K + 5] = 0.0;
+    cc[CC_K + 6] = 0.0; cc[CC_K + 7] = 0.0; cc[CC_K + 8] = 1.0;
+    cc[CC_SMALL] = 1.0;
+  }
+  cc[CC_T + 0] = cam6[3]; cc[CC_T + 1] = cam6[4]; cc[CC_T + 2] = cam6[5];
+  cc[CC_FX] = intr4[0]; cc[CC_FY] = intr4[1]; cc[CC_PPX] = intr4[2]; cc[CC_PPY] = intr4[3];
+  for (int i = CC_SMALL + 1; i < CC_STRIDE; ++i) cc[i] = 0.0;
+}
+
+// Residual only (operator()<double>), used for the candidate cost.
+RSBA_HD void Residual(const double* cc, const double X[3], double u, double v, double r[2]) {
+  const double q0 = cc[CC_R + 0] * X[0] + cc[CC_R + 1] * X[1] + cc[CC_R + 2] * X[2];
+  const double q1 = cc[CC_R + 3] * X[0] + cc[CC_R + 4] * X[1] + cc[CC_R + 5] * X[2];
+  const double q2 = cc[CC_R + 6] * X[0] + cc[CC_R + 7] * X[1] + cc[CC_R + 8] * X[2];
+  const double p0 = q0 + cc[CC_T + 0], p1 = q1 + cc[CC_T + 1], p2 = q2 + cc[CC_T + 2];
+  const double iz = 1.0 / p2;
+  r[0] = cc[CC_FX] * p0 * iz + cc[CC_PPX] - u;
+  r[1] = cc[CC_FY] * p1 * iz + cc[CC_PPY] - v;
+}
+
+// Residual + Jacobian blocks.  jc: 2x6 row-major (d/d rvec, d/d tvec), jp: 2x3 row-major.
+RSBA_HD void ResidualJacobian(const double* cc, const double X[3], double u, double v, double r[2],
+                              double jc[12], double jp[6]) {
+  const double* R = cc + CC_R;
+  const double* K = cc + CC_K;
+  const double q0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
+  const double q1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
+  const double q2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
+  const double p0 = q0 + cc[CC_T + 0], p1 = q1 + cc[CC_T + 1], p2 = q2 + cc[CC_T + 2];
+  const double iz = 1.0 / p2;
+  r[0] = cc[CC_FX] * p0 * iz + cc[CC_PPX] - u;
+  r[1] = cc[CC_FY] * p1 * iz + cc[CC_PPY] - v;
+  const double al = cc[CC_FX] * iz, be = cc[CC_FY] * iz;
+  const double ga = -al * p0 * iz, de = -be * p1 * iz;
+  // d r / d X = Pj R
+  jp[0] = al * R[0] + ga * R[6]; jp[1] = al * R[1] + ga * R[7]; jp[2] = al * R[2] + ga * R[8];
+  jp[3] = be * R[3] + de * R[6]; jp[4] = be * R[4] + de * R[7]; jp[5] = be * R[5] + de * R[8];
+  // rows of -Pj [w]x are w x Pj_i, with w = q (Rodrigues branch) or X (first-order branch)
+  const bool small = cc[CC_SMALL] != 0.0;
+  const double w0 = small ? X[0] : q0, w1 = small ? X[1] : q1, w2 = small ? X[2] : q2;
+  const double a0 = w1 * ga, a1 = w2 * al - w0 * ga, a2 = -w1 * al;
+  const double b0 = w1 * de - w2 * be, b1 = -w0 * de, b2 = w0 * be;
+  jc[0] = a0 * K[0] + a1 * K[3] + a2 * K[6];
+  jc[1] = a0 * K[1] + a1 * K[4] + a2 * K[7];
+  jc[2] = a0 * K[2] + a1 * K[5] + a2 * K[8];
+  jc[3] = al; jc[4] = 0.0; jc[5] = ga;
+  jc[6] = b0 * K[0] + b1 * K[3] + b2 * K[6];
+  jc[7] = b0 * K[1] + b1 * K[4] + b2 * K[7];
+  jc[8] = b0 * K[2] + b1 * K[5] + b2 * K[8];
+  jc[9] = 0.0; jc[10] = be; jc[11] = de;
+}
+
+// ceres::HuberLoss + Corrector for rho'' <= 0: returns rho(s) and the factor sqrt(rho'(s)) that scales
+// the residual and both Jacobian blocks.  delta <= 0 means no loss.
+RSBA_HD double LossAndScale(double delta, double s, double* sqrt_rho1) {
+  if (delta > 0.0 && s > delta * delta) {
+    const double rt = sqrt(s);
+    double rho1 = delta / rt;
+    if (rho1 < DBL_MIN) rho1 = DBL_MIN;
+    *sqrt_rho1 = sqrt(rho1);
+    return 2.0 * delta * rt - delta * delta;
+  }
+  *sqrt_rho1 = 1.0;
+  return s;
+}
+
+// Symmetric 3x3 stored as (00, 01, 02, 11, 12, 22).
+// Effective inverse of a point's damped Hessian block in unscaled coordinates:
+//   Vs = diag(s) V diag(s);  D2 = clamp(diag(Vs), lo, hi) / radius;  Minv = (Vs + D2)^-1 via LLT;
+//   out = diag(s) Minv diag(s)        (so that  W_s (Vs+D2)^-1 W_s' = s_c [W out W'] s_c)
+// Returns false when the block is not positive definite / not finite (Ceres: linear solver failure).
+RSBA_HD bool PointBlockInverse(const double V[6], const double s[3], double lo, double hi, double radius,
+                               double out[6]) {
+  double m00 = s[0] * s[0] * V[0], m01 = s[0] * s[1] * V[1], m02 = s[0] * s[2] * V[2];
+  double m11 = s[1] * s[1] * V[3], m12 = s[1] * s[2] * V[4], m22 = s[2] * s[2] * V[5];
+  const double ir = 1.0 / radius;
+  m00 += fmin(fmax(m00, lo), hi) * ir;
+  m11 += fmin(fmax(m11, lo), hi) * ir;
+  m22 += fmin(fmax(m22, lo), hi) * ir;
+  // LLT
+  if (!(m00 > 0.0)) return false;
+  const double l00 = sqrt(m00), i00 = 1.0 / l00;
+  const double l10 = m01 * i00, l20 = m02 * i00;
+  const double d11 = m11 - l10 * l10;
+  if (!(d11 > 0.0)) return false;
+  const double l11 = sqrt(d11), i11 = 1.0 / l11;
+  const double l21 = (m12 - l20 * l10) * i11;
+  const double d22 = m22 - l20 * l20 - l21 * l21;
+  if (!(d22 > 0.0)) return false;
+  const double l22 = sqrt(d22), i22 = 1.0 / l22;
+  // Linv (lower): rows
+  const double a00 = i00;
+  const double a10 = -l10 * i00 * i11, a11 = i11;
+  const double a20 = -(l20 * a00 + l21 * a10) * i22, a21 = -l21 * a11 * i22, a22 = i22;
+  // Minv = Linv' Linv
+  const double n00 = a00 * a00 + a10 * a10 + a20 * a20;
+  const double n01 = a10 * a11 + a20 * a21;
+  const double n02 = a20 * a22;
+  const double n11 = a11 * a11 + a21 * a21;
+  const double n12 = a21 * a22;
+  const double n22 = a22 * a22;
+  out[0] = s[0] * s[0] * n00; out[1] = s[0] * s[1] * n01; out[2] = s[0] * s[2] * n02;
+  out[3] = s[1] * s[1] * n11; out[4] = s[1] * s[2] * n12; out[5] = s[2] * s[2] * n22;
+  const double chk = out[0] + out[3] + out[5];
+  return chk == chk && fabs(chk) <= DBL_MAX;
+}
+
+RSBA_HD void Sym3MulVec(const double M[6], const double x[3], double y[3]) {
+  y[0] = M[0] * x[0] + M[1] * x[1] + M[2] * x[2];
+  y[1] = M[1] * x[0] + M[3] * x[1] + M[4] * x[2];
+  y[2] = M[2] * x[0] + M[4] * x[1] + M[5] * x[2];
+}
+
+}  // namespace rsba

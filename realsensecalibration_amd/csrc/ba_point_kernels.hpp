@@ -1,0 +1,626 @@
+// HIP kernels of the point-model LM iteration (gfx950, wave64).
+//
+// These are the steps that are implicit inside ceres::Solve for the reference's point model
+// (/root/reference/Test1_BundleAdjustment/main.cpp:63-87 with DENSE_SCHUR): residual + Jacobian
+// evaluation, Schur elimination of the point blocks into the reduced camera system, the dense
+// Cholesky solve, back-substitution and the candidate cost.  Nothing here is a translation of
+// reference code: the reference has no such code (it links Ceres).
+//
+// Data layout in HBM (all fp64 / int32, struct-of-arrays, observations sorted by point then camera):
+//   obs_u[N], obs_v[N], obs_cam[N], pt_ptr[P+1]   20 B per observation + 4 B per point
+//   cam[6C], intr[4C], camc[32C]                  camera blocks and their per-linearisation constants
+//   pts[3P], scale_p[3P], scale_c[6C]             points, Jacobi scales (fixed at iteration 0)
+//   red[]                                         the all-reduce payload: S | gc | corr | diagU | scalars
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ba_math.hpp"
+
+namespace rsba {
+
+// ---- layout of the reduction payload `red` (doubles) for nc = 6C
+//   [0, nc*nc)            S   : U - sum W Vinv W'   (camera-unscaled, undamped; upper blocks valid)
+//   [+0, +nc)             gc  : J_c' r              (camera gradient)
+//   [+nc, +2nc)           corr: -sum W Vinv g_p     (Schur correction of the rhs)
+//   [+2nc, +3nc)          diagU: diag(J_c' J_c)
+//   [+3nc, +3nc+8)        scalars: 0 cost(sum rho, not halved) 1 |X|^2 (points) 2 fail count
+struct RedLayout {
+  int nc;
+  __host__ __device__ size_t S() const { return 0; }
+  __host__ __device__ size_t gc() const { return (size_t)nc * nc; }
+  __host__ __device__ size_t corr() const { return (size_t)nc * nc + nc; }
+  __host__ __device__ size_t diagU() const { return (size_t)nc * nc + 2 * (size_t)nc; }
+  __host__ __device__ size_t scal() const { return (size_t)nc * nc + 3 * (size_t)nc; }
+  __host__ __device__ size_t size() const { return (size_t)nc * nc + 3 * (size_t)nc + 8; }
+};
+
+// Everything the device-side of one iteration reads that is a scalar.
+struct IterParams {
+  double radius;
+  double min_lm_diagonal, max_lm_diagonal;
+  double huber_delta;
+  int first;           // 1: iteration 0 -> compute and store the Jacobi scales
+  int jacobi_scaling;
+};
+
+// Result block the host reads back once per iteration (and RCCL reduces in part).
+enum {
+  RES_COST_X = 0,        // 1/2 sum rho at x
+  RES_GMAX = 1,          // max |gradient|
+  RES_XNORM2 = 2,        // |x|^2
+  RES_CHOL_OK = 3,       // 1.0 when the reduced system factorised
+  RES_MCC = 4,           // model cost change
+  RES_COST_C = 5,        // 1/2 sum rho at the candidate
+  RES_STEP2 = 6,         // |delta|^2
+  RES_XCNORM2 = 7,       // |x + delta|^2
+  RES_POINT_FAIL = 8,    // number of point blocks that were not positive definite
+  RES_SUMSQ_C = 9,       // sum of squared raw residuals at the candidate (for the RMS metric)
+  RES_SIZE = 16
+};
+
+__device__ __forceinline__ double WaveSum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double WaveMax(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ void AtomicMaxNonNeg(double* addr, double v) {
+  atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: per-camera constants (R, left Jacobian, t, intrinsics) for one set of camera blocks.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_camera_constants(int C, const double* __restrict__ cam, const double* __restrict__ intr,
+                                   double* __restrict__ camc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double cc[CC_STRIDE];
+  CameraConstants(cam + 6 * c, intr + 4 * c, cc);
+#pragma unroll
+  for (int i = 0; i < CC_STRIDE; ++i) camc[(size_t)c * CC_STRIDE + i] = cc[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_A (reference Schur kernel, schur_impl = 0): one wavefront per point, one lane per observation.
+//   phase 1: residual + Jacobian blocks per lane; wave reductions give V = sum Jp'Jp, g_p, cost;
+//            camera-side sums (U = Jc'Jc upper 21, g_c 6, corr 6) go to LDS accumulators per block.
+//   phase 2: every lane a holds Y_a = W_a Vinv; W_b is broadcast lane by lane and the 6x6 block
+//            -Y_a W_b' is added to S(cam_a, cam_b) for cam_a <= cam_b with global fp64 atomics.
+// Correct for any problem with at most 64 views per point; slow (atomic-bound): it exists as the
+// on-device cross-check of the tiled kernel and as the first parity-green path.
+// ------------------------------------------------------------------------------------------------
+#define RSBA_ACC_PER_CAM 33  // 21 (U upper) + 6 (gc) + 6 (corr)
+
+template <bool kStageCamc>
+__global__ void __launch_bounds__(256)
+k_linearize_schur_ref(int C, int P, const double* __restrict__ obs_u, const double* __restrict__ obs_v,
+                      const int* __restrict__ obs_cam, const int* __restrict__ pt_ptr,
+                      const double* __restrict__ camc_g, const double* __restrict__ pts,
+                      double* __restrict__ scale_p, double* __restrict__ red, RedLayout L,
+                      double* __restrict__ gmax_out, double* __restrict__ block_scal /* gridDim.x x 4 */,
+                      IterParams ip) {
+  extern __shared__ double lds[];
+  double* acc = lds;                                      // C x 33
+  double* camc_l = lds + (size_t)C * RSBA_ACC_PER_CAM;    // C x 32 when staged
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+  for (int i = tid; i < C * RSBA_ACC_PER_CAM; i += blockDim.x) acc[i] = 0.0;
+  if (kStageCamc) for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) camc_l[i] = camc_g[i];
+  __syncthreads();
+  const double* camc = kStageCamc ? camc_l : camc_g;
+
+  double cost_acc = 0.0, xn_acc = 0.0, fail_acc = 0.0, gmax = 0.0;
+  for (int j = blockIdx.x * nwave + wave; j < P; j += gridDim.x * nwave) {
+    const int b = pt_ptr[j], k = pt_ptr[j + 1] - b;
+    const double X[3] = {pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2]};
+    const bool act = lane < k;
+    int cam = 0;
+    double r[2] = {0, 0}, jc[12], jp[6];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) jc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) jp[i] = 0.0;
+    double rho = 0.0;
+    if (act) {
+      cam = obs_cam[b + lane];
+      ResidualJacobian(camc + (size_t)cam * CC_STRIDE, X, obs_u[b + lane], obs_v[b + lane], r, jc, jp);
+      double sq;
+      rho = LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
+      if (sq != 1.0) {
+        r[0] *= sq; r[1] *= sq;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) jc[i] *= sq;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) jp[i] *= sq;
+      }
+    }
+    // point-side sums over the wave
+    double V[6], gp[3];
+    V[0] = WaveSum(jp[0] * jp[0] + jp[3] * jp[3]);
+    V[1] = WaveSum(jp[0] * jp[1] + jp[3] * jp[4]);
+    V[2] = WaveSum(jp[0] * jp[2] + jp[3] * jp[5]);
+    V[3] = WaveSum(jp[1] * jp[1] + jp[4] * jp[4]);
+    V[4] = WaveSum(jp[1] * jp[2] + jp[4] * jp[5]);
+    V[5] = WaveSum(jp[2] * jp[2] + jp[5] * jp[5]);
+    gp[0] = WaveSum(jp[0] * r[0] + jp[3] * r[1]);
+    gp[1] = WaveSum(jp[1] * r[0] + jp[4] * r[1]);
+    gp[2] = WaveSum(jp[2] * r[0] + jp[5] * r[1]);
+    const double cost_j = WaveSum(rho);
+    double sp[3] = {1.0, 1.0, 1.0};
+    if (ip.jacobi_scaling) {
+      if (ip.first) {
+        sp[0] = 1.0 / (1.0 + sqrt(V[0])); sp[1] = 1.0 / (1.0 + sqrt(V[3])); sp[2] = 1.0 / (1.0 + sqrt(V[5]));
+        if (lane == 0) { scale_p[3 * (size_t)j] = sp[0]; scale_p[3 * (size_t)j + 1] = sp[1]; scale_p[3 * (size_t)j + 2] = sp[2]; }
+      } else {
+        sp[0] = scale_p[3 * (size_t)j]; sp[1] = scale_p[3 * (size_t)j + 1]; sp[2] = scale_p[3 * (size_t)j + 2];
+      }
+    } else if (ip.first && lane == 0) {
+      scale_p[3 * (size_t)j] = 1.0; scale_p[3 * (size_t)j + 1] = 1.0; scale_p[3 * (size_t)j + 2] = 1.0;
+    }
+    double Vi[6];
+    const bool ok = PointBlockInverse(V, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, ip.radius, Vi);
+    if (lane == 0) {
+      cost_acc += cost_j;
+      xn_acc += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+      if (!ok && k > 0) fail_acc += 1.0;
+      gmax = fmax(gmax, fmax(fabs(gp[0]), fmax(fabs(gp[1]), fabs(gp[2]))));
+    }
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Vi[i] = 0.0;
+    }
+    // W = Jc' Jp (6x3), Y = W Vinv (6x3)
+    double W[18], Y[18];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int c3 = 0; c3 < 3; ++c3) W[3 * a + c3] = jc[a] * jp[c3] + jc[6 + a] * jp[3 + c3];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      Y[3 * a + 0] = W[3 * a] * Vi[0] + W[3 * a + 1] * Vi[1] + W[3 * a + 2] * Vi[2];
+      Y[3 * a + 1] = W[3 * a] * Vi[1] + W[3 * a + 1] * Vi[3] + W[3 * a + 2] * Vi[4];
+      Y[3 * a + 2] = W[3 * a] * Vi[2] + W[3 * a + 1] * Vi[4] + W[3 * a + 2] * Vi[5];
+    }
+    if (act) {
+      double* a33 = acc + (size_t)cam * RSBA_ACC_PER_CAM;
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c6 = a; c6 < 6; ++c6) { unsafeAtomicAdd(&a33[t], jc[a] * jc[c6] + jc[6 + a] * jc[6 + c6]); ++t; }
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) unsafeAtomicAdd(&a33[21 + a], jc[a] * r[0] + jc[6 + a] * r[1]);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) unsafeAtomicAdd(&a33[27 + a], -(Y[3 * a] * gp[0] + Y[3 * a + 1] * gp[1] + Y[3 * a + 2] * gp[2]));
+    }
+    // Schur blocks: -Y_a W_b'
+    for (int bb = 0; bb < k; ++bb) {
+      const int camb = __shfl(cam, bb, 64);
+      double Wb[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) Wb[i] = __shfl(W[i], bb, 64);
+      if (act && cam <= camb) {
+        double* Sb = red + L.S() + (size_t)(6 * cam) * L.nc + 6 * camb;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c6 = 0; c6 < 6; ++c6) {
+            const double v = Y[3 * a] * Wb[3 * c6] + Y[3 * a + 1] * Wb[3 * c6 + 1] + Y[3 * a + 2] * Wb[3 * c6 + 2];
+            unsafeAtomicAdd(&Sb[(size_t)a * L.nc + c6], -v);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // flush the camera accumulators: U into the diagonal blocks of S (+ diagU), gc, corr
+  for (int i = tid; i < C * RSBA_ACC_PER_CAM; i += blockDim.x) {
+    const int c = i / RSBA_ACC_PER_CAM, e = i - c * RSBA_ACC_PER_CAM;
+    const double v = acc[i];
+    if (v == 0.0) continue;
+    if (e < 21) {
+      int a = 0, rem = e;
+      while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+      const int c6 = a + rem;
+      unsafeAtomicAdd(&red[L.S() + (size_t)(6 * c + a) * L.nc + 6 * c + c6], v);
+      if (a == c6) unsafeAtomicAdd(&red[L.diagU() + 6 * c + a], v);
+    } else if (e < 27) {
+      unsafeAtomicAdd(&red[L.gc() + 6 * c + (e - 21)], v);
+    } else {
+      unsafeAtomicAdd(&red[L.corr() + 6 * c + (e - 27)], v);
+    }
+  }
+  // per-block scalars (deterministic second stage in k_finish_linearize)
+  __shared__ double sred[4][4];
+  if (lane == 0) { sred[wave][0] = cost_acc; sred[wave][1] = xn_acc; sred[wave][2] = fail_acc; sred[wave][3] = gmax; }
+  __syncthreads();
+  if (tid == 0) {
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int w = 0; w < nwave; ++w) { c0 += sred[w][0]; c1 += sred[w][1]; c2 += sred[w][2]; c3 = fmax(c3, sred[w][3]); }
+    block_scal[4 * blockIdx.x + 0] = c0; block_scal[4 * blockIdx.x + 1] = c1; block_scal[4 * blockIdx.x + 2] = c2;
+    block_scal[4 * blockIdx.x + 3] = c3;
+  }
+  (void)gmax_out;
+}
+
+// Second stage of the scalar reductions of K_A, fixed order -> red scalars (sum part) and gmax (max part).
+__global__ void k_finish_linearize(int nblocks, const double* __restrict__ block_scal, double* __restrict__ red,
+                                   RedLayout L, double* __restrict__ gmax_p) {
+  __shared__ double s[256][4];
+  const int tid = threadIdx.x;
+  double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  for (int i = tid; i < nblocks; i += blockDim.x) {
+    c0 += block_scal[4 * i]; c1 += block_scal[4 * i + 1]; c2 += block_scal[4 * i + 2]; c3 = fmax(c3, block_scal[4 * i + 3]);
+  }
+  s[tid][0] = c0; s[tid][1] = c1; s[tid][2] = c2; s[tid][3] = c3;
+  __syncthreads();
+  for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+    if (tid < off) { s[tid][0] += s[tid + off][0]; s[tid][1] += s[tid + off][1]; s[tid][2] += s[tid + off][2]; s[tid][3] = fmax(s[tid][3], s[tid + off][3]); }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    red[L.scal() + 0] = s[0][0]; red[L.scal() + 1] = s[0][1]; red[L.scal() + 2] = s[0][2];
+    *gmax_p = s[0][3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_C: reduced camera system.  One workgroup (1024 threads).
+//   1. Jacobi scale of the camera columns (iteration 0) from diagU
+//   2. S_s = s_c S s_c + clamp(s_c^2 diagU)/radius, mirrored to a full symmetric matrix; rhs_s = s_c (gc + corr)
+//   3. blocked right-looking Cholesky (32-wide panels, 64x64 trailing tiles through LDS); the rhs rides
+//      along as row n of the panel so the forward substitution is part of the factorisation
+//   4. blocked back-substitution, delta_c = -s_c y, candidate cameras and their constants
+// A is the (n+1) x n row-major work matrix (row n = rhs).
+// ------------------------------------------------------------------------------------------------
+#define RSBA_NB 32
+#define RSBA_TB 64
+
+__device__ void CholeskySolveBlocked(int n, double* __restrict__ A, double* __restrict__ x_out, int* ok_out,
+                                     double* lds /* >= 2*64*33 + 32*33 doubles */) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double* L11 = lds;                       // 32 x 33
+  double* tA = lds + RSBA_NB * (RSBA_NB + 1);     // 64 x 33
+  double* tB = tA + RSBA_TB * (RSBA_NB + 1);      // 64 x 33
+  __shared__ int s_ok;
+  if (tid == 0) s_ok = 1;
+  __syncthreads();
+  const int rows = n + 1;  // including the rhs row
+  for (int kb = 0; kb < n; kb += RSBA_NB) {
+    const int nb = min(RSBA_NB, n - kb);
+    // (a) diagonal block -> LDS, factor with one wave
+    for (int i = tid; i < nb * nb; i += nt) { const int r = i / nb, c = i - r * nb; L11[r * (RSBA_NB + 1) + c] = A[(size_t)(kb + r) * n + kb + c]; }
+    __syncthreads();
+    if (tid < 64) {
+      for (int j = 0; j < nb; ++j) {
+        double d = L11[j * (RSBA_NB + 1) + j];
+        if (!(d > 0.0) || !(d <= DBL_MAX)) { if (tid == 0) s_ok = 0; d = 1.0; }
+        const double l = sqrt(d), il = 1.0 / l;
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) L11[j * (RSBA_NB + 1) + j] = l;
+        double lij = 0.0;
+        if (tid > j && tid < nb) { lij = L11[tid * (RSBA_NB + 1) + j] * il; L11[tid * (RSBA_NB + 1) + j] = lij; }
+        __builtin_amdgcn_wave_barrier();
+        if (tid > j && tid < nb) {
+          for (int c = j + 1; c <= tid; ++c) L11[tid * (RSBA_NB + 1) + c] -= lij * L11[c * (RSBA_NB + 1) + j];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nb * nb; i += nt) { const int r = i / nb, c = i - r * nb; if (c <= r) A[(size_t)(kb + r) * n + kb + c] = L11[r * (RSBA_NB + 1) + c]; }
+    // (b) panel below (rows kb+nb .. n, the rhs row included): row <- row L11^-T, one thread per row
+    for (int r = kb + nb + tid; r < rows; r += nt) {
+      double* row = A + (size_t)r * n + kb;
+      double v[RSBA_NB];
+#pragma unroll
+      for (int c = 0; c < RSBA_NB; ++c) v[c] = c < nb ? row[c] : 0.0;
+#pragma unroll
+      for (int c = 0; c < RSBA_NB; ++c) {
+        if (c < nb) {
+          double s = v[c];
+#pragma unroll
+          for (int q = 0; q < RSBA_NB; ++q) if (q < c) s -= v[q] * L11[c * (RSBA_NB + 1) + q];
+          v[c] = s / L11[c * (RSBA_NB + 1) + c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < RSBA_NB; ++c) if (c < nb) row[c] = v[c];
+    }
+    __threadfence_block();
+    __syncthreads();
+    // (c) trailing update, lower tiles only: A[I, J] -= Lp[I] Lp[J]'  for tiles I >= J over rows kb+nb..n
+    const int t0 = kb + nb;
+    const int m = rows - t0;  // trailing rows incl. rhs row
+    if (m > 0) {
+      const int ntile = (m + RSBA_TB - 1) / RSBA_TB;
+      // 1024 threads: each computes a 2x2 patch of a 64x64 tile
+      const int tr = (tid >> 5), tc = (tid & 31);  // rows 2*tr.., cols 2*tc..
+      for (int ti = 0; ti < ntile; ++ti) {
+        for (int i = tid; i < RSBA_TB * RSBA_NB; i += nt) {
+          const int r = i / RSBA_NB, c = i - r * RSBA_NB; const int gr = t0 + ti * RSBA_TB + r;
+          tA[r * (RSBA_NB + 1) + c] = (gr < rows && c < nb) ? A[(size_t)gr * n + kb + c] : 0.0;
+        }
+        for (int tj = 0; tj <= ti; ++tj) {
+          __syncthreads();
+          for (int i = tid; i < RSBA_TB * RSBA_NB; i += nt) {
+            const int r = i / RSBA_NB, c = i - r * RSBA_NB; const int gr = t0 + tj * RSBA_TB + r;
+            tB[r * (RSBA_NB + 1) + c] = (gr < rows && c < nb) ? A[(size_t)gr * n + kb + c] : 0.0;
+          }
+          __syncthreads();
+          if (nt >= 1024 || tid < 1024) {
+            double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+#pragma unroll 8
+            for (int q = 0; q < RSBA_NB; ++q) {
+              const double a0 = tA[(2 * tr) * (RSBA_NB + 1) + q], a1 = tA[(2 * tr + 1) * (RSBA_NB + 1) + q];
+              const double b0 = tB[(2 * tc) * (RSBA_NB + 1) + q], b1 = tB[(2 * tc + 1) * (RSBA_NB + 1) + q];
+              c00 += a0 * b0; c01 += a0 * b1; c10 += a1 * b0; c11 += a1 * b1;
+            }
+            const int gr0 = t0 + ti * RSBA_TB + 2 * tr, gc0 = t0 + tj * RSBA_TB + 2 * tc;
+            if (gr0 < rows && gc0 < n && gc0 <= gr0) A[(size_t)gr0 * n + gc0] -= c00;
+            if (gr0 < rows && gc0 + 1 < n && gc0 + 1 <= gr0) A[(size_t)gr0 * n + gc0 + 1] -= c01;
+            if (gr0 + 1 < rows && gc0 < n && gc0 <= gr0 + 1) A[(size_t)(gr0 + 1) * n + gc0] -= c10;
+            if (gr0 + 1 < rows && gc0 + 1 < n && gc0 + 1 <= gr0 + 1) A[(size_t)(gr0 + 1) * n + gc0 + 1] -= c11;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  // Row n of A now holds y' with L y = rhs.  Back-substitution L' x = y, blocked from the bottom.
+  double* y = A + (size_t)n * n;
+  double* part = tA;  // 32 x 33 partial dot products
+  for (int kb = ((n - 1) / RSBA_NB) * RSBA_NB; kb >= 0; kb -= RSBA_NB) {
+    const int nb = min(RSBA_NB, n - kb);
+    const int below = n - (kb + nb);
+    // y[kb+c] -= sum_{i >= kb+nb} L[i][kb+c] x[i]     (x already stored in y for those i)
+    {
+      const int c = tid & 31, slice = tid >> 5;  // 32 slices of rows
+      double s = 0.0;
+      if (c < nb) for (int i = kb + nb + slice; i < n; i += 32) s += A[(size_t)i * n + kb + c] * y[i];
+      part[slice * (RSBA_NB + 1) + c] = s;
+    }
+    __syncthreads();
+    if (tid < nb && below > 0) { double s = 0.0; for (int q = 0; q < 32; ++q) s += part[q * (RSBA_NB + 1) + tid]; y[kb + tid] -= s; }
+    __syncthreads();
+    if (tid < 64) {
+      // solve L11' x = y for this block, sequentially from the last row
+      for (int j = nb - 1; j >= 0; --j) {
+        double xj = 0.0;
+        if (tid == 0) { xj = y[kb + j] / A[(size_t)(kb + j) * n + kb + j]; y[kb + j] = xj; }
+        xj = __shfl(xj, 0, 64);
+        if (tid < j) y[kb + tid] -= A[(size_t)(kb + j) * n + kb + tid] * xj;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += nt) x_out[i] = y[i];
+  __syncthreads();
+  if (tid == 0) *ok_out = s_ok;
+}
+
+__global__ void __launch_bounds__(1024)
+k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __restrict__ A /* (nc+1) x nc */,
+                       double* __restrict__ S_copy /* may be null */, double* __restrict__ rhs_copy,
+                       double* __restrict__ scale_c, const double* __restrict__ cam_x, double* __restrict__ cam_c,
+                       const double* __restrict__ intr, double* __restrict__ camc_c, double* __restrict__ dcam,
+                       const double* __restrict__ gmax_p, double* __restrict__ res, IterParams ip) {
+  extern __shared__ double lds[];
+  const int n = L.nc, tid = threadIdx.x, nt = blockDim.x;
+  __shared__ double s_norms[3];
+  __shared__ int s_ok;
+  // 1. camera Jacobi scale
+  for (int i = tid; i < n; i += nt) {
+    if (ip.first) scale_c[i] = ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(red[L.diagU() + i])) : 1.0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // 2. scaled, damped, mirrored system
+  for (size_t e = tid; e < (size_t)n * n; e += nt) {
+    const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
+    const int bi = i / 6, bj = j / 6;
+    // upper blocks are the valid ones; inside a diagonal block the upper triangle
+    const bool upper = (bi < bj) || (bi == bj && i <= j);
+    const double raw = upper ? red[L.S() + (size_t)i * n + j] : red[L.S() + (size_t)j * n + i];
+    double v = raw * scale_c[i] * scale_c[j];
+    if (i == j) {
+      const double d = scale_c[i] * scale_c[i] * red[L.diagU() + i];
+      v += fmin(fmax(d, ip.min_lm_diagonal), ip.max_lm_diagonal) / ip.radius;
+    }
+    A[e] = v;
+    if (S_copy) S_copy[e] = v;
+  }
+  for (int i = tid; i < n; i += nt) {
+    const double v = scale_c[i] * (red[L.gc() + i] + red[L.corr() + i]);
+    A[(size_t)n * n + i] = v;
+    if (rhs_copy) rhs_copy[i] = v;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // 3-4. factor + solve; y = solution of the scaled system, reused from row n of A
+  double* ysol = A + (size_t)n * n;
+  CholeskySolveBlocked(n, A, ysol, &s_ok, lds);
+  __syncthreads();
+  // 5. camera step, candidate cameras, norms, gradient max over the camera part
+  if (tid == 0) { s_norms[0] = 0; s_norms[1] = 0; s_norms[2] = 0; }
+  __syncthreads();
+  double d2 = 0, x2 = 0, xc2 = 0, gm = 0;
+  for (int i = tid; i < n; i += nt) {
+    const double d = -scale_c[i] * ysol[i];
+    dcam[i] = d;
+    const double x = cam_x[i], xc = x + d;
+    cam_c[i] = xc;
+    d2 += d * d; x2 += x * x; xc2 += xc * xc;
+    gm = fmax(gm, fabs(red[L.gc() + i]));
+  }
+  // small fixed-order reduction through LDS
+  double* scr = lds;
+  scr[tid] = d2; scr[nt + tid] = x2; scr[2 * nt + tid] = xc2; scr[3 * nt + tid] = gm;
+  __syncthreads();
+  for (int off = nt / 2; off > 0; off >>= 1) {
+    if (tid < off) { scr[tid] += scr[tid + off]; scr[nt + tid] += scr[nt + tid + off]; scr[2 * nt + tid] += scr[2 * nt + tid + off]; scr[3 * nt + tid] = fmax(scr[3 * nt + tid], scr[3 * nt + tid + off]); }
+    __syncthreads();
+  }
+  for (int c = tid; c < C; c += nt) {
+    double cc[CC_STRIDE];
+    CameraConstants(cam_c + 6 * c, intr + 4 * c, cc);
+    for (int i = 0; i < CC_STRIDE; ++i) camc_c[(size_t)c * CC_STRIDE + i] = cc[i];
+  }
+  if (tid == 0) {
+    res[RES_COST_X] = 0.5 * red[L.scal() + 0];
+    res[RES_GMAX] = fmax(*gmax_p, scr[3 * nt]);
+    res[RES_XNORM2] = red[L.scal() + 1] + scr[nt];
+    res[RES_POINT_FAIL] = red[L.scal() + 2];
+    res[RES_CHOL_OK] = (s_ok && red[L.scal() + 2] == 0.0) ? 1.0 : 0.0;
+    // camera parts of the step / candidate norms; the point parts are added by k_finish_candidate
+    res[RES_STEP2] = scr[0];
+    res[RES_XCNORM2] = scr[2 * nt];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_B: back-substitution + candidate.  One thread per point; a second pass over the observation
+// records.  delta_p = -Vinv (g_p + sum Jp' Jc delta_c); model-cost-change terms accumulate in the same
+// loop; then the cost of the candidate (cameras' constants at x + delta already in camc_c).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_backsub_candidate(int C, int P, const double* __restrict__ obs_u, const double* __restrict__ obs_v,
+                    const int* __restrict__ obs_cam, const int* __restrict__ pt_ptr,
+                    const double* __restrict__ camc_x, const double* __restrict__ camc_c,
+                    const double* __restrict__ dcam, const double* __restrict__ pts_x, double* __restrict__ pts_c,
+                    const double* __restrict__ scale_p, double* __restrict__ block_part /* gridDim.x x 8 */, IterParams ip) {
+  const int tid = threadIdx.x;
+  double mcc = 0, cost_c = 0, dp2 = 0, xc2 = 0, ss_c = 0;
+  for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
+    const int b = pt_ptr[j], e = pt_ptr[j + 1];
+    const double X[3] = {pts_x[3 * (size_t)j], pts_x[3 * (size_t)j + 1], pts_x[3 * (size_t)j + 2]};
+    double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, bv[3] = {0, 0, 0}, a1 = 0, a2 = 0;
+    for (int q = b; q < e; ++q) {
+      const int cam = obs_cam[q];
+      double r[2], jc[12], jp[6];
+      ResidualJacobian(camc_x + (size_t)cam * CC_STRIDE, X, obs_u[q], obs_v[q], r, jc, jp);
+      double sq;
+      LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
+      const double* dc = dcam + 6 * cam;
+      double e0 = 0, e1 = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { e0 += jc[a] * dc[a]; e1 += jc[6 + a] * dc[a]; }
+      if (sq != 1.0) {
+        r[0] *= sq; r[1] *= sq; e0 *= sq; e1 *= sq;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) jp[i] *= sq;
+      }
+      V[0] += jp[0] * jp[0] + jp[3] * jp[3]; V[1] += jp[0] * jp[1] + jp[3] * jp[4]; V[2] += jp[0] * jp[2] + jp[3] * jp[5];
+      V[3] += jp[1] * jp[1] + jp[4] * jp[4]; V[4] += jp[1] * jp[2] + jp[4] * jp[5]; V[5] += jp[2] * jp[2] + jp[5] * jp[5];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { gp[a] += jp[a] * r[0] + jp[3 + a] * r[1]; bv[a] += jp[a] * e0 + jp[3 + a] * e1; }
+      a1 += e0 * r[0] + e1 * r[1];
+      a2 += e0 * e0 + e1 * e1;
+    }
+    const double sp[3] = {scale_p[3 * (size_t)j], scale_p[3 * (size_t)j + 1], scale_p[3 * (size_t)j + 2]};
+    double Vi[6];
+    const bool ok = PointBlockInverse(V, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, ip.radius, Vi);
+    double t[3] = {gp[0] + bv[0], gp[1] + bv[1], gp[2] + bv[2]}, dp[3] = {0, 0, 0};
+    if (ok && e > b) { Sym3MulVec(Vi, t, dp); dp[0] = -dp[0]; dp[1] = -dp[1]; dp[2] = -dp[2]; }
+    const double Xc[3] = {X[0] + dp[0], X[1] + dp[1], X[2] + dp[2]};
+    pts_c[3 * (size_t)j] = Xc[0]; pts_c[3 * (size_t)j + 1] = Xc[1]; pts_c[3 * (size_t)j + 2] = Xc[2];
+    double Vd[3];
+    Sym3MulVec(V, dp, Vd);
+    mcc -= a1 + (dp[0] * gp[0] + dp[1] * gp[1] + dp[2] * gp[2]) + 0.5 * a2 + (dp[0] * bv[0] + dp[1] * bv[1] + dp[2] * bv[2]) +
+           0.5 * (dp[0] * Vd[0] + dp[1] * Vd[1] + dp[2] * Vd[2]);
+    dp2 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
+    xc2 += Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2];
+    for (int q = b; q < e; ++q) {
+      double r[2];
+      Residual(camc_c + (size_t)obs_cam[q] * CC_STRIDE, Xc, obs_u[q], obs_v[q], r);
+      const double s = r[0] * r[0] + r[1] * r[1];
+      double sq;
+      cost_c += LossAndScale(ip.huber_delta, s, &sq);
+      ss_c += s;
+    }
+  }
+  // block reduction in a fixed order
+  __shared__ double s[5][256];
+  s[0][tid] = mcc; s[1][tid] = cost_c; s[2][tid] = dp2; s[3][tid] = xc2; s[4][tid] = ss_c;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) s[q][tid] += s[q][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid < 5) block_part[8 * blockIdx.x + tid] = s[tid][0];
+}
+
+// Second stage: fixed-order sum of the per-block partials into the small reduction payload
+// small[0..4] = {mcc, cost_c (sum rho), |dp|^2, |Xc|^2, sum sq residuals}
+__global__ void k_finish_candidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red) {
+  __shared__ double s[5][256];
+  const int tid = threadIdx.x;
+  double v[5] = {0, 0, 0, 0, 0};
+  for (int i = tid; i < nblocks; i += blockDim.x) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) v[q] += block_part[8 * i + q];
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) s[q][tid] = v[q];
+  __syncthreads();
+  for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) s[q][tid] += s[q][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid < 5) small_red[tid] = s[tid][0];
+}
+
+// Folds the (all-reduced) point-side sums into the result block the host reads.
+__global__ void k_publish_result(const double* __restrict__ small_red, double* __restrict__ res) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    res[RES_MCC] = small_red[0];
+    double c = 0.5 * small_red[1];
+    if (!(c == c) || !(fabs(c) <= DBL_MAX)) c = DBL_MAX;  // Ceres: failed evaluation -> max double
+    res[RES_COST_C] = c;
+    res[RES_STEP2] += small_red[2];
+    res[RES_XCNORM2] += small_red[3];
+    res[RES_SUMSQ_C] = small_red[4];
+  }
+}
+
+// Cost only at the current point-model parameters (used by rsba_reprojection_error).
+__global__ void __launch_bounds__(256)
+k_cost_only(int P, const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
+            const int* __restrict__ pt_ptr, const double* __restrict__ camc, const double* __restrict__ pts,
+            double* __restrict__ block_part, double huber_delta) {
+  const int tid = threadIdx.x;
+  double cost = 0, ss = 0;
+  for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
+    const double X[3] = {pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2]};
+    for (int q = pt_ptr[j]; q < pt_ptr[j + 1]; ++q) {
+      double r[2], sq;
+      Residual(camc + (size_t)obs_cam[q] * CC_STRIDE, X, obs_u[q], obs_v[q], r);
+      const double s = r[0] * r[0] + r[1] * r[1];
+      cost += LossAndScale(huber_delta, s, &sq);
+      ss += s;
+    }
+  }
+  __shared__ double s[2][256];
+  s[0][tid] = cost; s[1][tid] = ss;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (tid < off) { s[0][tid] += s[0][tid + off]; s[1][tid] += s[1][tid + off]; } __syncthreads(); }
+  if (tid == 0) { block_part[8 * blockIdx.x + 1] = s[0][0]; block_part[8 * blockIdx.x + 4] = s[1][0]; block_part[8 * blockIdx.x] = 0; block_part[8 * blockIdx.x + 2] = 0; block_part[8 * blockIdx.x + 3] = 0; }
+}
+
+}  // namespace rsba

@@ -1,0 +1,541 @@
+// Device-resident Levenberg-Marquardt solve of the point model: the replacement for the
+// ceres::Solve call of /root/reference/Test1_BundleAdjustment/main.cpp:82-87 (and, through BAManager,
+// Main_Calibration/bundle_adjustment_manager.cpp:90-95) with DENSE_SCHUR.
+//
+// The trust-region rules are Ceres 1.14's (trust_region_minimizer.cc, levenberg_marquardt_strategy.cc;
+// SURVEY.md Appendix A): accept when rho > 1e-3, radius /= max(1/3, 1-(2rho-1)^3) on success,
+// radius /= decrease_factor (2, 4, 8, ...) on failure, and the three tolerances tested in Ceres' order,
+// with the candidate DISCARDED when the function/parameter tolerance fires.
+//
+// Multi-GPU: each rank holds all cameras and a contiguous block of points with their observations.
+// Per iteration one RCCL all-reduce (sum) of the packed reduced system [S | gc | corr | diagU | scalars],
+// one (max) of the gradient bound, and one tiny (sum) of the candidate scalars.  Every rank then
+// factors the identical system, so no broadcast is needed and all ranks take identical decisions.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ba_marker_kernels.hpp"
+#include "ba_point_kernels.hpp"
+#include "ba_problem.hpp"
+#include "ba_schur_tiled.hpp"
+#include "ba_solver.hpp"
+
+namespace rsba {
+
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      fprintf(stderr, "rsba: HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return RSBA_ERR_HIP;                                                                  \
+    }                                                                                       \
+  } while (0)
+#define NCCLCHK(expr)                                                                       \
+  do {                                                                                      \
+    ncclResult_t _r = (expr);                                                               \
+    if (_r != ncclSuccess) {                                                                \
+      fprintf(stderr, "rsba: RCCL error %s at %s:%d\n", ncclGetErrorString(_r), __FILE__, __LINE__); \
+      return RSBA_ERR_COMM;                                                                 \
+    }                                                                                       \
+  } while (0)
+
+int DeviceCount() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+class KernelTimer {
+ public:
+  void Enable(bool on) { on_ = on; }
+  bool enabled() const { return on_; }
+  void Begin(const char* name, hipStream_t s) {
+    if (!on_) return;
+    Pending p; p.name = name;
+    (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b);
+    (void)hipEventRecord(p.a, s);
+    pending_.push_back(p);
+  }
+  void End(hipStream_t s) { if (!on_) return; (void)hipEventRecord(pending_.back().b, s); }
+  void Collect() {
+    for (auto& p : pending_) {
+      float ms = 0;
+      if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        auto& st = stats_[p.name]; st.first += 1; st.second += ms;
+      }
+      (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+    }
+    pending_.clear();
+  }
+  void Reset() { Collect(); stats_.clear(); }
+  const std::map<std::string, std::pair<int64_t, double>>& stats() const { return stats_; }
+ private:
+  struct Pending { const char* name; hipEvent_t a, b; };
+  bool on_ = false;
+  std::vector<Pending> pending_;
+  std::map<std::string, std::pair<int64_t, double>> stats_;
+};
+
+template <typename T>
+static int DevAlloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess ? RSBA_OK : RSBA_ERR_HIP; }
+
+}  // namespace rsba
+
+using namespace rsba;
+
+struct rsba_solver {
+  rsba_problem* prob = nullptr;
+  rsba_options opt;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  ncclComm_t comm = nullptr;
+  KernelTimer timer;
+  std::vector<rsba_iteration> iters;
+  double final_cost = 0, final_sumsq = 0, setup_seconds = 0;
+
+  // ---- point model
+  int C = 0, P = 0, nc = 0;
+  int64_t N = 0;
+  int max_views = 0;
+  RedLayout L{0};
+  std::vector<int64_t> order;       // sorted position -> original observation index
+  double *obs_u = nullptr, *obs_v = nullptr, *intr = nullptr;
+  int *obs_cam = nullptr, *pt_ptr = nullptr;
+  double *cam[2] = {nullptr, nullptr}, *pts[2] = {nullptr, nullptr}, *camc[2] = {nullptr, nullptr};
+  double *cam0 = nullptr, *pts0 = nullptr;  // uploaded initial state (rsba_solver_run restarts from it)
+  double *scale_c = nullptr, *scale_p = nullptr;
+  double *red = nullptr, *A = nullptr, *S_copy = nullptr, *rhs_copy = nullptr, *dcam = nullptr;
+  double *block_scal = nullptr, *block_part = nullptr, *small_red = nullptr, *gmax = nullptr, *res = nullptr;
+  double* res_host = nullptr;  // pinned
+  int grid_lin = 0, grid_pts = 0;
+  int cur = 0;
+  TiledSchur tiled;
+
+  // ---- marker-chain model
+  MarkerDevice marker;
+};
+
+namespace rsba {
+
+int TiledSchur::Build(int, int, const std::vector<int>&, const std::vector<int>&) { return RSBA_ERR_UNSUPPORTED; }
+int TiledSchur::Launch(rsba_solver*, const IterParams&, KernelTimer&) { return RSBA_ERR_UNSUPPORTED; }
+void TiledSchur::Free() {}
+
+static void FreeSolver(rsba_solver* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  s->timer.Reset();
+  void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
+                  s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
+                  s->block_part, s->small_red, s->gmax, s->res};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  s->tiled.Free();
+  s->marker.Free();
+  if (s->res_host) (void)hipHostFree(s->res_host);
+  if (s->comm) ncclCommDestroy(s->comm);
+  if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+static IterParams MakeIterParams(const rsba_options& o, double radius, bool first) {
+  IterParams ip;
+  ip.radius = radius; ip.min_lm_diagonal = o.min_lm_diagonal; ip.max_lm_diagonal = o.max_lm_diagonal;
+  ip.huber_delta = o.huber_delta; ip.first = first ? 1 : 0; ip.jacobi_scaling = o.jacobi_scaling;
+  return ip;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Upload of the point model: observations are re-ordered by (point, camera) so that one point's
+// records are contiguous; the permutation is kept so nothing the caller sees changes order.
+// ------------------------------------------------------------------------------------------------
+static int UploadPoints(rsba_solver* s) {
+  const rsba_problem& p = *s->prob;
+  s->C = p.num_cameras; s->P = p.num_points; s->N = p.num_observations; s->nc = 6 * s->C; s->L = RedLayout{s->nc};
+  const int C = s->C, P = s->P; const int64_t N = s->N;
+  std::vector<int> ptr(P + 1, 0);
+  for (int64_t i = 0; i < N; ++i) ptr[p.point_index[i] + 1]++;
+  int maxk = 0;
+  for (int j = 0; j < P; ++j) { maxk = std::max(maxk, ptr[j + 1]); ptr[j + 1] += ptr[j]; }
+  s->max_views = maxk;
+  std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+  s->order.resize(N);
+  for (int64_t i = 0; i < N; ++i) s->order[fill[p.point_index[i]]++] = i;
+  for (int j = 0; j < P; ++j)
+    std::stable_sort(s->order.begin() + ptr[j], s->order.begin() + ptr[j + 1],
+                     [&](int64_t a, int64_t b) { return p.camera_index[a] < p.camera_index[b]; });
+  std::vector<double> u(N), v(N);
+  std::vector<int> cam(N);
+  for (int64_t q = 0; q < N; ++q) { const int64_t i = s->order[q]; u[q] = p.observations[2 * i]; v[q] = p.observations[2 * i + 1]; cam[q] = p.camera_index[i]; }
+
+  int rc;
+  if ((rc = DevAlloc(&s->obs_u, N)) || (rc = DevAlloc(&s->obs_v, N)) || (rc = DevAlloc(&s->obs_cam, N)) || (rc = DevAlloc(&s->pt_ptr, P + 1)) ||
+      (rc = DevAlloc(&s->intr, 4 * C)) || (rc = DevAlloc(&s->cam[0], 6 * C)) || (rc = DevAlloc(&s->cam[1], 6 * C)) || (rc = DevAlloc(&s->cam0, 6 * C)) ||
+      (rc = DevAlloc(&s->pts[0], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts[1], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts0, 3 * (size_t)P)) ||
+      (rc = DevAlloc(&s->camc[0], CC_STRIDE * C)) || (rc = DevAlloc(&s->camc[1], CC_STRIDE * C)) || (rc = DevAlloc(&s->scale_c, 6 * C)) ||
+      (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(s->nc + 1) * s->nc)) ||
+      (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
+      (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)))
+    return rc;
+  HIPCHK(hipHostMalloc((void**)&s->res_host, RES_SIZE * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipMemcpy(s->obs_u, u.data(), N * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->obs_v, v.data(), N * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->obs_cam, cam.data(), N * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->pt_ptr, ptr.data(), (P + 1) * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->intr, p.intrinsics.data(), 4 * C * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->cam0, p.parameters.data(), 6 * C * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->pts0, p.parameters.data() + 6 * C, 3 * (size_t)P * sizeof(double), hipMemcpyHostToDevice));
+  // launch geometry: fixed grids (deterministic second-stage reductions depend only on these)
+  s->grid_lin = std::max(1, std::min((P + 3) / 4, 2048));
+  s->grid_pts = std::max(1, std::min((P + 255) / 256, 2048));
+  if ((rc = DevAlloc(&s->block_scal, 4 * (size_t)std::max(s->grid_lin, 4096))) || (rc = DevAlloc(&s->block_part, 8 * (size_t)s->grid_pts))) return rc;
+  if (s->opt.schur_impl != 0) {
+    rc = s->tiled.Build(C, P, ptr, cam);
+    if (rc != RSBA_OK) return rc;
+  } else if (maxk > 64) {
+    fprintf(stderr, "rsba: schur_impl=0 handles at most 64 views per point (problem has %d)\n", maxk);
+    return RSBA_ERR_UNSUPPORTED;
+  }
+  return RSBA_OK;
+}
+
+static int ResetPoints(rsba_solver* s) {
+  HIPCHK(hipMemcpyAsync(s->cam[0], s->cam0, 6 * s->C * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  HIPCHK(hipMemcpyAsync(s->pts[0], s->pts0, 3 * (size_t)s->P * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  s->cur = 0;
+  return RSBA_OK;
+}
+
+// One "solve at radius": linearise at x, reduce, factor, back-substitute, evaluate the candidate.
+// On return res_host holds the RES_* block (host has synchronised).
+static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_system_copy) {
+  const int C = s->C, P = s->P, x = s->cur, c = 1 - s->cur;
+  hipStream_t st = s->stream;
+  const IterParams ip = MakeIterParams(s->opt, radius, first);
+  KernelTimer& T = s->timer;
+
+  T.Begin("k_camera_constants", st);
+  k_camera_constants<<<(C + 63) / 64, 64, 0, st>>>(C, s->cam[x], s->intr, s->camc[x]);
+  T.End(st);
+  HIPCHK(hipMemsetAsync(s->red, 0, s->L.size() * sizeof(double), st));
+
+  if (s->opt.schur_impl == 0) {
+    const bool stage = (size_t)C * (RSBA_ACC_PER_CAM + CC_STRIDE) * sizeof(double) <= 96 * 1024;
+    const size_t lds = (size_t)C * (RSBA_ACC_PER_CAM + (stage ? CC_STRIDE : 0)) * sizeof(double);
+    T.Begin("k_linearize_schur_ref", st);
+    if (stage)
+      k_linearize_schur_ref<true><<<s->grid_lin, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p,
+                                                                 s->red, s->L, s->gmax, s->block_scal, ip);
+    else
+      k_linearize_schur_ref<false><<<s->grid_lin, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p,
+                                                                  s->red, s->L, s->gmax, s->block_scal, ip);
+    T.End(st);
+    T.Begin("k_finish_linearize", st);
+    k_finish_linearize<<<1, 256, 0, st>>>(s->grid_lin, s->block_scal, s->red, s->L, s->gmax);
+    T.End(st);
+  } else {
+    int rc = s->tiled.Launch(s, ip, T);
+    if (rc != RSBA_OK) return rc;
+  }
+  HIPCHK(hipGetLastError());
+
+  if (s->comm) {
+    NCCLCHK(ncclAllReduce(s->red, s->red, s->L.size(), ncclDouble, ncclSum, s->comm, st));
+    NCCLCHK(ncclAllReduce(s->gmax, s->gmax, 1, ncclDouble, ncclMax, s->comm, st));
+  }
+
+  const size_t lds_c = (size_t)std::max(2 * RSBA_TB * (RSBA_NB + 1) + RSBA_NB * (RSBA_NB + 1), 4 * 1024) * sizeof(double);
+  T.Begin("k_reduced_system_solve", st);
+  k_reduced_system_solve<<<1, 1024, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
+                                                 keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
+                                                 s->camc[c], s->dcam, s->gmax, s->res, ip);
+  T.End(st);
+  T.Begin("k_backsub_candidate", st);
+  k_backsub_candidate<<<s->grid_pts, 256, 0, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->camc[c], s->dcam, s->pts[x],
+                                                   s->pts[c], s->scale_p, s->block_part, ip);
+  T.End(st);
+  T.Begin("k_finish_candidate", st);
+  k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red);
+  T.End(st);
+  if (s->comm) NCCLCHK(ncclAllReduce(s->small_red, s->small_red, 8, ncclDouble, ncclSum, s->comm, st));
+  k_publish_result<<<1, 64, 0, st>>>(s->small_red, s->res);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(s->res_host, s->res, RES_SIZE * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return RSBA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TrustRegionMinimizer, host side.  `step(radius, first)` must leave res[] filled.
+// ------------------------------------------------------------------------------------------------
+template <typename StepFn, typename AcceptFn>
+static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn accept) {
+  const rsba_options& o = s->opt;
+  s->iters.clear();
+  double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+  int invalid_run = 0;
+  bool first = true;
+  double x_cost = 0, gmax = 0, x_norm = 0;
+  sum->num_successful_steps = sum->num_unsuccessful_steps = 0;
+  sum->termination_type = RSBA_NO_CONVERGENCE; sum->stop_reason = RSBA_STOP_NONE;
+  auto finish = [&](int term, int reason) {
+    sum->termination_type = term; sum->stop_reason = reason; sum->final_cost = x_cost;
+    sum->num_iterations = (int)s->iters.size() - 1;
+    return RSBA_OK;
+  };
+  for (;;) {
+    // checks of FinalizeIterationAndCheckIfMinimizerCanContinue for the previous iteration
+    if (!first) {
+      if (s->iters.back().iteration >= o.max_num_iterations) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_ITERATIONS);
+      if (gmax <= o.gradient_tolerance) return finish(RSBA_CONVERGENCE, RSBA_STOP_GRADIENT);
+      if (radius < o.min_trust_region_radius) return finish(RSBA_CONVERGENCE, RSBA_STOP_MIN_RADIUS);
+    }
+    int rc = step(radius, first);
+    if (rc != RSBA_OK) return rc;
+    const double* r = s->res_host;
+    x_cost = r[RES_COST_X]; gmax = r[RES_GMAX]; x_norm = std::sqrt(r[RES_XNORM2]);
+    if (first) {
+      // iteration 0: the evaluation at the starting point
+      rsba_iteration it0{}; it0.iteration = 0; it0.cost = x_cost; it0.gradient_max_norm = gmax; it0.trust_region_radius = radius;
+      s->iters.push_back(it0);
+      sum->initial_cost = x_cost;
+      if (!std::isfinite(x_cost)) { sum->final_cost = x_cost; sum->termination_type = RSBA_FAILURE; sum->stop_reason = RSBA_STOP_INITIAL_FAILURE; sum->num_iterations = 0; return RSBA_OK; }
+      if (o.minimizer_progress_to_stdout) printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d % .6e\n", 0, x_cost);
+      first = false;
+      if (gmax <= o.gradient_tolerance) return finish(RSBA_CONVERGENCE, RSBA_STOP_GRADIENT);
+      if (o.max_num_iterations <= 0) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_ITERATIONS);
+    }
+    rsba_iteration it{};
+    it.iteration = s->iters.back().iteration + 1;
+    it.cost = x_cost; it.gradient_max_norm = gmax;
+    const bool solved = r[RES_CHOL_OK] != 0.0 && std::isfinite(r[RES_MCC]) && std::isfinite(r[RES_STEP2]);
+    const double mcc = r[RES_MCC];
+    it.step_is_valid = solved && mcc > 0.0;
+    if (!it.step_is_valid) {
+      ++invalid_run;
+      ++sum->num_unsuccessful_steps;
+      if (invalid_run >= o.max_num_consecutive_invalid_steps) { it.trust_region_radius = radius; s->iters.push_back(it); return finish(RSBA_FAILURE, RSBA_STOP_INVALID_STEPS); }
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      it.trust_region_radius = radius;
+      s->iters.push_back(it);
+      continue;
+    }
+    invalid_run = 0;
+    const double cand_cost = r[RES_COST_C];
+    it.step_norm = std::sqrt(r[RES_STEP2]);
+    it.trust_region_radius = radius;
+    if (it.step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { s->iters.push_back(it); return finish(RSBA_CONVERGENCE, RSBA_STOP_PARAMETER); }
+    it.cost_change = x_cost - cand_cost;
+    if (std::fabs(it.cost_change) <= o.function_tolerance * x_cost) { s->iters.push_back(it); return finish(RSBA_CONVERGENCE, RSBA_STOP_FUNCTION); }
+    it.relative_decrease = it.cost_change / mcc;
+    if (it.relative_decrease > o.min_relative_decrease) {
+      accept();
+      x_cost = cand_cost;  // re-evaluated by the next linearisation; kept for the summary if we stop here
+      s->final_sumsq = r[RES_SUMSQ_C];
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+      radius = std::min(o.max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      it.step_is_successful = 1; it.cost = cand_cost; it.trust_region_radius = radius;
+      ++sum->num_successful_steps;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      it.trust_region_radius = radius;
+      ++sum->num_unsuccessful_steps;
+    }
+    if (o.minimizer_progress_to_stdout)
+      printf("%4d % .6e % .3e % .3e % .3e % .3e % .3e\n", it.iteration, it.cost, it.cost_change, it.gradient_max_norm, it.step_norm, it.relative_decrease, it.trust_region_radius);
+    s->iters.push_back(it);
+  }
+}
+
+}  // namespace rsba
+
+// ================================================================================================
+// C ABI (declared in include/rsba.h)
+// ================================================================================================
+extern "C" {
+
+int rsba_comm_unique_id(void* out128) {
+  if (!out128) return RSBA_ERR_ARG;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return RSBA_ERR_COMM;
+  memcpy(out128, &id, sizeof(id));
+  return RSBA_OK;
+}
+
+int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out) {
+  if (!p || !out) return RSBA_ERR_ARG;
+  if (rsba::DeviceCount() <= 0) return RSBA_ERR_NO_DEVICE;
+  rsba_options opt;
+  if (o) opt = *o; else rsba_options_default(&opt);
+  if (opt.world_size > 1 && (!opt.comm_unique_id || opt.rank < 0 || opt.rank >= opt.world_size)) return RSBA_ERR_ARG;
+  if (opt.world_size > 1 && p->model != RSBA_MODEL_POINTS) return RSBA_ERR_UNSUPPORTED;  // marker-chain: replicas only
+  const auto t0 = std::chrono::steady_clock::now();
+  rsba_solver* s = new rsba_solver();
+  s->prob = p; s->opt = opt;
+  if (opt.device >= 0) { if (hipSetDevice(opt.device) != hipSuccess) { delete s; return RSBA_ERR_HIP; } }
+  if (hipGetDevice(&s->device) != hipSuccess) { delete s; return RSBA_ERR_HIP; }
+  if (opt.stream) s->stream = (hipStream_t)opt.stream;
+  else { if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return RSBA_ERR_HIP; } s->own_stream = true; }
+  s->timer.Enable(opt.profile_kernels != 0);
+  int rc = RSBA_OK;
+  if (opt.world_size > 1) {
+    ncclUniqueId id; memcpy(&id, opt.comm_unique_id, sizeof(id));
+    if (ncclCommInitRank(&s->comm, opt.world_size, id, opt.rank) != ncclSuccess) { rsba::FreeSolver(s); return RSBA_ERR_COMM; }
+  }
+  if (p->model == RSBA_MODEL_POINTS) rc = rsba::UploadPoints(s);
+  else rc = s->marker.Upload(*p);
+  if (rc == RSBA_OK && hipDeviceSynchronize() != hipSuccess) rc = RSBA_ERR_HIP;
+  if (rc != RSBA_OK) { rsba::FreeSolver(s); return rc; }
+  s->setup_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  *out = s;
+  return RSBA_OK;
+}
+
+int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
+  if (!s) return RSBA_ERR_ARG;
+  rsba_summary sum; memset(&sum, 0, sizeof(sum));
+  sum.setup_seconds = s->setup_seconds;
+  if (hipSetDevice(s->device) != hipSuccess) return RSBA_ERR_HIP;
+  int rc;
+  if (s->prob->model == RSBA_MODEL_POINTS) {
+    if ((rc = rsba::ResetPoints(s)) != RSBA_OK) return rc;
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return RSBA_ERR_HIP;
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { return rsba::PointsStep(s, radius, first, false); },
+                            [&]() { s->cur = 1 - s->cur; });
+    sum.minimizer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  } else {
+    if ((rc = s->marker.Reset(s->stream)) != RSBA_OK) return rc;
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return RSBA_ERR_HIP;
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { return s->marker.Step(s->stream, s->opt, radius, first, s->res_host, s->timer); },
+                            [&]() { s->marker.Accept(); });
+    sum.minimizer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  s->timer.Collect();
+  s->final_cost = sum.final_cost;
+  if (sum_out) *sum_out = sum;
+  return rc;
+}
+
+int rsba_solver_download(rsba_solver* s) {
+  if (!s) return RSBA_ERR_ARG;
+  if (hipSetDevice(s->device) != hipSuccess) return RSBA_ERR_HIP;
+  rsba_problem& p = *s->prob;
+  if (p.model == RSBA_MODEL_POINTS) {
+    if (hipMemcpy(p.parameters.data(), s->cam[s->cur], 6 * s->C * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return RSBA_ERR_HIP;
+    if (hipMemcpy(p.parameters.data() + 6 * s->C, s->pts[s->cur], 3 * (size_t)s->P * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return RSBA_ERR_HIP;
+    return RSBA_OK;
+  }
+  return s->marker.Download(&p);
+}
+
+int rsba_solver_iterations(const rsba_solver* s, rsba_iteration* out, int32_t capacity) {
+  if (!s || (!out && capacity > 0)) return 0;
+  const int n = std::min<int>((int)s->iters.size(), capacity);
+  for (int i = 0; i < n; ++i) out[i] = s->iters[i];
+  return n;
+}
+
+int rsba_solver_kernel_stats(const rsba_solver* s, rsba_kernel_stat* out, int32_t capacity) {
+  if (!s) return 0;
+  int n = 0;
+  for (const auto& kv : s->timer.stats()) {
+    if (n >= capacity) break;
+    memset(&out[n], 0, sizeof(out[n]));
+    strncpy(out[n].name, kv.first.c_str(), sizeof(out[n].name) - 1);
+    out[n].launches = kv.second.first; out[n].total_ms = kv.second.second;
+    ++n;
+  }
+  return n;
+}
+
+int rsba_solver_final_costs(const rsba_solver* s, double* cost, double* sum_sq) {
+  if (!s) return RSBA_ERR_ARG;
+  if (cost) *cost = s->final_cost;
+  if (sum_sq) *sum_sq = s->final_sumsq;
+  return RSBA_OK;
+}
+
+void rsba_solver_destroy(rsba_solver* s) { rsba::FreeSolver(s); }
+
+int rsba_solve(rsba_problem* p, const rsba_options* o, rsba_summary* summary) {
+  rsba_solver* s = nullptr;
+  int rc = rsba_solver_create(p, o, &s);
+  if (rc != RSBA_OK) return rc;
+  rc = rsba_solver_run(s, summary);
+  if (rc == RSBA_OK) rc = rsba_solver_download(s);
+  rsba_solver_destroy(s);
+  return rc;
+}
+
+int rsba_points_linearize_and_step(rsba_problem* p, const rsba_options* o, double radius, double* S, double* rhs, double* delta, double* scalars) {
+  if (!p || p->model != RSBA_MODEL_POINTS) return RSBA_ERR_ARG;
+  rsba_solver* s = nullptr;
+  int rc = rsba_solver_create(p, o, &s);
+  if (rc != RSBA_OK) return rc;
+  rc = rsba::ResetPoints(s);
+  if (rc == RSBA_OK) rc = rsba::PointsStep(s, radius, true, true);
+  if (rc == RSBA_OK) {
+    const int nc = s->nc;
+    if (S && hipMemcpy(S, s->S_copy, (size_t)nc * nc * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RSBA_ERR_HIP;
+    if (rhs && hipMemcpy(rhs, s->rhs_copy, nc * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RSBA_ERR_HIP;
+    if (delta) {
+      std::vector<double> xc(6 * s->C + 3 * (size_t)s->P);
+      if (hipMemcpy(xc.data(), s->cam[1 - s->cur], 6 * s->C * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RSBA_ERR_HIP;
+      if (hipMemcpy(xc.data() + 6 * s->C, s->pts[1 - s->cur], 3 * (size_t)s->P * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RSBA_ERR_HIP;
+      for (size_t i = 0; i < xc.size(); ++i) delta[i] = xc[i] - p->parameters[i];
+    }
+    if (scalars) {
+      const double* r = s->res_host;
+      scalars[0] = r[RES_COST_X]; scalars[1] = r[RES_MCC]; scalars[2] = r[RES_GMAX]; scalars[3] = r[RES_CHOL_OK];
+      scalars[4] = r[RES_COST_C]; scalars[5] = std::sqrt(r[RES_STEP2]); scalars[6] = std::sqrt(r[RES_XNORM2]); scalars[7] = r[RES_SUMSQ_C];
+    }
+  }
+  rsba_solver_destroy(s);
+  return rc;
+}
+
+int rsba_reprojection_error(rsba_problem* p, const rsba_options* o, double* error, double* rms) {
+  if (!p) return RSBA_ERR_ARG;
+  rsba_solver* s = nullptr;
+  rsba_options opt; if (o) opt = *o; else rsba_options_default(&opt);
+  opt.world_size = 1; opt.comm_unique_id = nullptr; opt.huber_delta = 0.0;
+  int rc = rsba_solver_create(p, &opt, &s);
+  if (rc != RSBA_OK) return rc;
+  double sumsq = 0; int64_t npts = 0;
+  if (p->model == RSBA_MODEL_POINTS) {
+    rc = rsba::ResetPoints(s);
+    if (rc == RSBA_OK) {
+      k_camera_constants<<<(s->C + 63) / 64, 64, 0, s->stream>>>(s->C, s->cam[0], s->intr, s->camc[0]);
+      k_cost_only<<<s->grid_pts, 256, 0, s->stream>>>(s->P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[0], s->pts[0], s->block_part, 0.0);
+      k_finish_candidate<<<1, 256, 0, s->stream>>>(s->grid_pts, s->block_part, s->small_red);
+      double h[8];
+      if (hipMemcpyAsync(h, s->small_red, 8 * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) rc = RSBA_ERR_HIP;
+      sumsq = h[4]; npts = p->num_observations;
+    }
+  } else {
+    rc = s->marker.SumSquares(s->stream, &sumsq);
+    npts = 4 * p->num_observations;
+  }
+  if (rc == RSBA_OK) {
+    if (error) *error = sumsq / 2.0;                                   // reprojection_check.cpp:81
+    if (rms) *rms = std::sqrt((sumsq / 2.0) * 2.0 / (npts * 2.0));     // reprojection_check.cpp:101
+  }
+  rsba_solver_destroy(s);
+  return rc;
+}
+
+}  // extern "C"

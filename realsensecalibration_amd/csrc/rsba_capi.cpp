@@ -1,0 +1,91 @@
+// C ABI: problem container, options, file formats (no device code here).  Declared in include/rsba.h.
+#include <cstring>
+
+#include "ba_problem.hpp"
+#include "ba_solver.hpp"
+
+extern "C" {
+
+int rsba_version(void) { return RSBA_VERSION; }
+int rsba_device_count(void) { return rsba::DeviceCount(); }
+
+const char* rsba_error_string(int code) {
+  switch (code) {
+    case RSBA_OK: return "ok";
+    case RSBA_ERR_IO: return "unable to open file";
+    case RSBA_ERR_FORMAT: return "malformed file";
+    case RSBA_ERR_ARG: return "bad argument";
+    case RSBA_ERR_HIP: return "HIP runtime error";
+    case RSBA_ERR_NO_DEVICE: return "no HIP device (this library has no CPU path)";
+    case RSBA_ERR_COMM: return "RCCL error";
+    case RSBA_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown error";
+  }
+}
+
+int rsba_problem_create_points(int32_t C, int32_t P, int64_t N, const int32_t* camera_index, const int32_t* point_index,
+                               const double* observations, const double* parameters, const double* intrinsics, rsba_problem** out) {
+  if (C <= 0 || P <= 0 || N < 0 || !camera_index || !point_index || !observations || !parameters || !intrinsics || !out) return RSBA_ERR_ARG;
+  for (int64_t i = 0; i < N; ++i)
+    if (camera_index[i] < 0 || camera_index[i] >= C || point_index[i] < 0 || point_index[i] >= P) return RSBA_ERR_ARG;
+  rsba_problem* p = new rsba_problem();
+  p->model = RSBA_MODEL_POINTS; p->num_cameras = C; p->num_points = P; p->num_observations = N;
+  p->camera_index.assign(camera_index, camera_index + N);
+  p->point_index.assign(point_index, point_index + N);
+  p->observations.assign(observations, observations + 2 * N);
+  p->parameters.assign(parameters, parameters + 6 * (size_t)C + 3 * (size_t)P);
+  p->intrinsics.assign(intrinsics, intrinsics + 4 * (size_t)C);
+  *out = p;
+  return RSBA_OK;
+}
+
+int rsba_problem_load_points_file(const char* path, const double* intrinsics4, rsba_problem** out) { return rsba::LoadPointsFile(path, intrinsics4, out); }
+int rsba_problem_load_correspondence(const char* path, int32_t model, double marker_side, const double* intrinsics, rsba_problem** out) {
+  return rsba::LoadCorrespondence(path, model, marker_side, intrinsics, out);
+}
+void rsba_problem_free(rsba_problem* p) { delete p; }
+
+int32_t rsba_problem_model(const rsba_problem* p) { return p ? p->model : -1; }
+int32_t rsba_problem_num_cameras(const rsba_problem* p) { return p ? p->num_cameras : 0; }
+int32_t rsba_problem_num_points(const rsba_problem* p) { return p ? p->num_points : 0; }
+int32_t rsba_problem_num_times(const rsba_problem* p) { return p ? p->num_times : 0; }
+int32_t rsba_problem_num_markers(const rsba_problem* p) { return p ? p->num_markers : 0; }
+int64_t rsba_problem_num_observations(const rsba_problem* p) { return p ? p->num_observations : 0; }
+int64_t rsba_problem_num_parameters(const rsba_problem* p) { return p ? p->num_parameters() : 0; }
+int32_t rsba_problem_num_observations_per_time_camera(const rsba_problem* p, int32_t t, int32_t c) {
+  if (!p || !p->is_marker_chain() || t < 0 || t >= p->num_times || c < 0 || c >= p->num_cameras) return 0;
+  return p->obs_per_time_camera[t * p->num_cameras + c] * 4;  // bundle_adjustment.cpp:29-32
+}
+const double* rsba_problem_observations(const rsba_problem* p) { return p ? p->observations.data() : nullptr; }
+double* rsba_problem_parameters(rsba_problem* p) { return p ? p->parameters.data() : nullptr; }
+int32_t rsba_problem_camera_idx(const rsba_problem* p, int64_t i) { return (p && i >= 0 && i < p->num_observations) ? p->camera_index[i] : -1; }
+int32_t rsba_problem_point_idx(const rsba_problem* p, int64_t i) { return (p && !p->is_marker_chain() && i >= 0 && i < p->num_observations) ? p->point_index[i] : -1; }
+int32_t rsba_problem_time_idx(const rsba_problem* p, int64_t i) { return (p && p->is_marker_chain() && i >= 0 && i < p->num_observations) ? p->time_index[i] : -1; }
+int32_t rsba_problem_marker_idx(const rsba_problem* p, int64_t i) { return (p && p->is_marker_chain() && i >= 0 && i < p->num_observations) ? p->marker_index[i] : -1; }
+double* rsba_problem_camera_parameters(rsba_problem* p, int32_t c) { return (p && c >= 0 && c < p->num_cameras) ? p->parameters.data() + 6 * c : nullptr; }
+double* rsba_problem_marker_transform(rsba_problem* p, int32_t m) {
+  return (p && p->is_marker_chain() && m >= 0 && m < p->num_markers) ? p->parameters.data() + 6 * (p->num_cameras + p->num_times + m) : nullptr;
+}
+int rsba_problem_point3d_coordinates(const rsba_problem* p, double* out) {
+  if (!p || !out || !p->is_marker_chain()) return RSBA_ERR_ARG;
+  rsba::MarkerCorners3d(*p, out);
+  return RSBA_OK;
+}
+
+void rsba_options_default(rsba_options* o) {
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 50; o->max_num_consecutive_invalid_steps = 5; o->jacobi_scaling = 1; o->minimizer_progress_to_stdout = 0;
+  o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+  o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8; o->huber_delta = 0.0;
+  o->device = -1; o->schur_impl = 0; o->profile_kernels = 0; o->rank = 0; o->world_size = 1; o->comm_unique_id = nullptr; o->stream = nullptr;
+}
+
+int rsba_read_intrinsics_xml(const char* path, double* out4) { return rsba::ReadIntrinsicsXml(path, out4); }
+int rsba_write_outputs(rsba_problem* p, const char* xml, const char* dir, const char* p3d) {
+  if (!p) return RSBA_ERR_ARG;
+  return rsba::WriteOutputs(*p, xml, dir, p3d);
+}
+
+}  // extern "C"
