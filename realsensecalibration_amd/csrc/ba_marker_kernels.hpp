@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -83,7 +84,7 @@ struct MarkerObs {
 };
 
 // Evaluate residual blocks.  with_jacobian: J (8 x 18, columns camera|time|marker) and r (8) are stored.
-__global__ void k_marker_eval(int N, const MarkerObs* __restrict__ mo, const double* __restrict__ obs8,
+__global__ void __launch_bounds__(64) k_marker_eval(int N, const MarkerObs* __restrict__ mo, const double* __restrict__ obs8,
                               const double* __restrict__ params, const double* __restrict__ intr, double half_side,
                               int with_jacobian, double* __restrict__ Jbuf, double* __restrict__ rbuf,
                               double* __restrict__ sumsq_per_obs) {
@@ -174,7 +175,7 @@ k_marker_system(int N, int n, const MarkerObs* __restrict__ mo, const double* __
   __syncthreads();
   for (size_t e = tid; e < (size_t)n * n; e += nt) {
     const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
-    double v = A[e] * scale[i] * scale[j];
+    double v = A[e] * (scale[i] * scale[j]);
     if (i == j) v += fmin(fmax(v, ip.min_lm_diagonal), ip.max_lm_diagonal) / ip.radius;
     A[e] = v;
   }
@@ -305,22 +306,30 @@ struct MarkerDevice {
     const int x = cur, c = 1 - cur;
     // the candidate array must carry the untouched blocks too
     if (hipMemcpyAsync(params[c], params[x], nfull * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return RSBA_ERR_HIP;
+    auto chk = [&](const char* what) {
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) { fprintf(stderr, "rsba: %s launch failed: %s\n", what, hipGetErrorString(e)); return false; }
+      return true;
+    };
+    if (!chk("(before marker step)")) return RSBA_ERR_HIP;
     T.Begin("k_marker_eval", st);
     k_marker_eval<<<(N + 63) / 64, 64, 0, st>>>(N, mo, obs8, params[x], intr, half_side, 1, Jbuf, rbuf, ss_x);
     T.End(st);
+    if (!chk("k_marker_eval")) return RSBA_ERR_HIP;
     const size_t lds = (size_t)std::max(2 * RSBA_TB * (RSBA_NB + 1) + RSBA_NB * (RSBA_NB + 1), 5 * 1024) * sizeof(double);
     T.Begin("k_marker_system", st);
     k_marker_system<<<1, 1024, lds, st>>>(N, n, mo, Jbuf, rbuf, ss_x, A, scale, grad, act_to_full, params[x], params[c], delta, res, ip);
     T.End(st);
+    if (!chk("k_marker_system")) return RSBA_ERR_HIP;
     T.Begin("k_marker_eval", st);
     k_marker_eval<<<(N + 63) / 64, 64, 0, st>>>(N, mo, obs8, params[c], intr, half_side, 0, nullptr, nullptr, ss_c);
     T.End(st);
     T.Begin("k_marker_candidate", st);
     k_marker_candidate<<<1, 256, 0, st>>>(N, mo, Jbuf, rbuf, delta, ss_c, res);
     T.End(st);
-    if (hipGetLastError() != hipSuccess) return RSBA_ERR_HIP;
+    if (!chk("k_marker_candidate")) return RSBA_ERR_HIP;
     if (hipMemcpyAsync(res_host, res, RES_SIZE * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return RSBA_ERR_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return RSBA_ERR_HIP;
+    { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) { fprintf(stderr, "rsba: marker-chain step failed: %s\n", hipGetErrorString(e)); return RSBA_ERR_HIP; } }
     return RSBA_OK;
   }
   int SumSquares(hipStream_t st, double* out) {

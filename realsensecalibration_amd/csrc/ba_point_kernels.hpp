@@ -432,7 +432,7 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
     // upper blocks are the valid ones; inside a diagonal block the upper triangle
     const bool upper = (bi < bj) || (bi == bj && i <= j);
     const double raw = upper ? red[L.S() + (size_t)i * n + j] : red[L.S() + (size_t)j * n + i];
-    double v = raw * scale_c[i] * scale_c[j];
+    double v = raw * (scale_c[i] * scale_c[j]);  // product of the scales first: bitwise symmetric
     if (i == j) {
       const double d = scale_c[i] * scale_c[i] * red[L.diagU() + i];
       v += fmin(fmax(d, ip.min_lm_diagonal), ip.max_lm_diagonal) / ip.radius;

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -148,6 +149,15 @@ static void FreeSolver(rsba_solver* s) {
   delete s;
 }
 
+// RSBA_DEBUG=1: synchronise and report after every launch (bisecting device faults).
+static bool DebugSync(hipStream_t st, const char* what) {
+  static const bool on = getenv("RSBA_DEBUG") != nullptr;
+  if (!on) return true;
+  hipError_t e = hipStreamSynchronize(st);
+  fprintf(stderr, "rsba[debug] %s: %s\n", what, hipGetErrorString(e));
+  return e == hipSuccess;
+}
+
 static IterParams MakeIterParams(const rsba_options& o, double radius, bool first) {
   IterParams ip;
   ip.radius = radius; ip.min_lm_diagonal = o.min_lm_diagonal; ip.max_lm_diagonal = o.max_lm_diagonal;
@@ -187,7 +197,6 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
       (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)))
     return rc;
-  HIPCHK(hipHostMalloc((void**)&s->res_host, RES_SIZE * sizeof(double), hipHostMallocDefault));
   HIPCHK(hipMemcpy(s->obs_u, u.data(), N * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->obs_v, v.data(), N * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->obs_cam, cam.data(), N * sizeof(int), hipMemcpyHostToDevice));
@@ -224,10 +233,13 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   const IterParams ip = MakeIterParams(s->opt, radius, first);
   KernelTimer& T = s->timer;
 
+  DebugSync(st, "enter PointsStep");
   T.Begin("k_camera_constants", st);
   k_camera_constants<<<(C + 63) / 64, 64, 0, st>>>(C, s->cam[x], s->intr, s->camc[x]);
   T.End(st);
+  DebugSync(st, "k_camera_constants");
   HIPCHK(hipMemsetAsync(s->red, 0, s->L.size() * sizeof(double), st));
+  DebugSync(st, "memset red");
 
   if (s->opt.schur_impl == 0) {
     const bool stage = (size_t)C * (RSBA_ACC_PER_CAM + CC_STRIDE) * sizeof(double) <= 96 * 1024;
@@ -248,6 +260,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (rc != RSBA_OK) return rc;
   }
   HIPCHK(hipGetLastError());
+  DebugSync(st, "linearize+schur");
 
   if (s->comm) {
     NCCLCHK(ncclAllReduce(s->red, s->red, s->L.size(), ncclDouble, ncclSum, s->comm, st));
@@ -260,10 +273,12 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
                                                  keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                  s->camc[c], s->dcam, s->gmax, s->res, ip);
   T.End(st);
+  DebugSync(st, "k_reduced_system_solve");
   T.Begin("k_backsub_candidate", st);
   k_backsub_candidate<<<s->grid_pts, 256, 0, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->camc[c], s->dcam, s->pts[x],
                                                    s->pts[c], s->scale_p, s->block_part, ip);
   T.End(st);
+  DebugSync(st, "k_backsub_candidate");
   T.Begin("k_finish_candidate", st);
   k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red);
   T.End(st);
@@ -394,6 +409,7 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
     ncclUniqueId id; memcpy(&id, opt.comm_unique_id, sizeof(id));
     if (ncclCommInitRank(&s->comm, opt.world_size, id, opt.rank) != ncclSuccess) { rsba::FreeSolver(s); return RSBA_ERR_COMM; }
   }
+  if (hipHostMalloc((void**)&s->res_host, RES_SIZE * sizeof(double), hipHostMallocDefault) != hipSuccess) { rsba::FreeSolver(s); return RSBA_ERR_HIP; }
   if (p->model == RSBA_MODEL_POINTS) rc = rsba::UploadPoints(s);
   else rc = s->marker.Upload(*p);
   if (rc == RSBA_OK && hipDeviceSynchronize() != hipSuccess) rc = RSBA_ERR_HIP;

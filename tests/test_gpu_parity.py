@@ -60,7 +60,7 @@ def test_reduced_system_and_step_match_oracle(oracle, impl, C, P, k, radius):
 
 
 # ------------------------------------------------------------------ whole solves
-def _compare_solve(oracle, prob, impl, huber=0.0, **optkw):
+def _compare_solve(oracle, prob, impl, huber=0.0, strict_params=True, iter_cost_tol=1e-7, **optkw):
     o_ref = oracle.options(huber_delta=huber, **optkw)
     ref, s_ref, log_ref = oracle.solve_points(prob, o_ref)
     got, s_got, log_got = capi.solve_points(prob, capi.default_options(schur_impl=impl, huber_delta=huber, **optkw))
@@ -70,7 +70,10 @@ def _compare_solve(oracle, prob, impl, huber=0.0, **optkw):
     assert np.array_equal(log_got[:, 7], log_ref[:, 7])  # same accept / reject sequence
     assert abs(s_got.initial_cost - s_ref.initial_cost) < 1e-11 * s_ref.initial_cost
     assert abs(s_got.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
-    assert _block_rel(got, ref, prob["C"]) < 1e-6
+    # every iterate has the same cost (relative to the largest cost on the trajectory)
+    assert np.abs(log_got[:, 1] - log_ref[:, 1]).max() / log_ref[:, 1].max() < iter_cost_tol
+    if strict_params:
+        assert _block_rel(got, ref, prob["C"]) < 1e-6
     c_ref, ss_ref = oracle.points_cost(prob, ref)
     c_got, ss_got = oracle.points_cost(prob, got)
     rms_ref, rms_got = np.sqrt(ss_ref / (2 * prob["N"])), np.sqrt(ss_got / (2 * prob["N"]))
@@ -96,12 +99,40 @@ def test_config2_full_size(oracle, impl):
 def test_huber_and_rejected_steps(oracle, impl):
     prob = syn.make_problem(8, 1500, 6, seed=9, outlier_frac=0.05)
     _compare_solve(oracle, prob, impl, huber=1.0)
-    # a far-off start forces rejected steps and radius shrinkage
-    rng = np.random.default_rng(3)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("sigma,radius0,seed,min_rejected,strict", [(0.7, 1e4, 2, 2, True), (0.65, 1e6, 2, 5, False)])
+def test_rejected_steps_follow_the_same_trajectory(oracle, impl, sigma, radius0, seed, min_rejected, strict):
+    """A far-off start: rejected steps, radius shrinkage by 2, 4, 8, ... and recovery.
+
+    All cameras and points are free (as in Test1_BundleAdjustment/main.cpp:76-79), so the cost has a
+    7-dof gauge orbit.  On the 20-iteration trajectory with 6 rejections, rounding differences between
+    two correct implementations drift along that orbit: costs, decisions and the RMS still agree, the
+    parameters themselves agree only to ~1e-2 there, so that case checks everything but the parameters."""
+    prob = syn.make_problem(8, 1500, 6, seed=9, outlier_frac=0.05)
+    rng = np.random.default_rng(seed)
     bad = dict(prob)
-    bad["params"] = prob["params"] + np.concatenate([rng.normal(0, 0.15, 48), rng.normal(0, 0.2, 3 * prob["P"])])
-    got, s, log = _compare_solve(oracle, bad, impl)
-    assert s.num_unsuccessful_steps > 0
+    bad["params"] = prob["params"] + np.concatenate([rng.normal(0, sigma, 48), rng.normal(0, sigma, 3 * prob["P"])])
+    # far from the minimum the damped systems are ill-conditioned (cond ~1e12): intermediate costs of two
+    # correct solvers agree to ~1e-5, not 1e-7; the decisions and the end point still coincide
+    got, s, log = _compare_solve(oracle, bad, impl, strict_params=strict, iter_cost_tol=1e-3, initial_trust_region_radius=radius0)
+    assert s.num_unsuccessful_steps >= min_rejected
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_invalid_steps_end_in_failure(oracle, impl):
+    """Five consecutive invalid steps (non-PD reduced system / non-positive model decrease) => FAILURE,
+    parameters left at the starting point (Ceres: max_num_consecutive_invalid_steps)."""
+    prob = syn.make_problem(8, 1500, 6, seed=9, outlier_frac=0.05)
+    rng = np.random.default_rng(2)
+    bad = dict(prob)
+    bad["params"] = prob["params"] + np.concatenate([rng.normal(0, 0.6, 48), rng.normal(0, 0.6, 3 * prob["P"])])
+    ref, s_ref, _ = oracle.solve_points(bad, oracle.options(initial_trust_region_radius=1e12))
+    got, s, log = capi.solve_points(bad, capi.default_options(schur_impl=impl, initial_trust_region_radius=1e12))
+    assert s_ref.termination == 2 and s_ref.stop_reason == 6
+    assert (s.termination_type, s.stop_reason, s.num_iterations) == (2, 6, s_ref.num_iterations)
+    assert np.array_equal(got, bad["params"]) and np.array_equal(ref, bad["params"])
 
 
 @pytest.mark.parametrize("impl", IMPLS)
