@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LM iterations/sec (+ final reprojection RMS) on the 64-camera / 100k-point
+synthetic point-model problem (BASELINE.json configs[2]), one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one Levenberg-Marquardt iteration of the hot path: linearise (residuals + 2x6/2x3 Jacobian
+blocks), eliminate the points into the 6C x 6C reduced camera system, Cholesky-solve it, back-substitute the
+points, evaluate the candidate, decide.  Inputs are resident in HBM before the timed region starts.  The timed
+region runs exactly K iterations from the uploaded start (tolerances off so that the count is exact),
+bracketed by barrier + torch.cuda.synchronize; the maximum over ranks is reported.
+
+N > 1 (launched by torch.distributed.run): weak scaling.  Every rank holds all 64 cameras and its own block
+of 100k points (the global problem has N x 100k points); per iteration the packed reduced camera system is
+all-reduced over RCCL.  `value` is the whole-job rate in units of the N=1 workload:
+    value = LM iterations/s x (total observations / 2,000,000)
+so at N = 1 it is exactly LM iterations/s on BASELINE's 64-cam x 100k-point problem.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz; vector and matrix fp64 share this peak
+                           # (the guide's Matrix-cores table has no fp64 row: AMD datasheet figure)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3", help="cfg2 | cfg3 (default; the metric's config) | cfg5-like via --points")
+    ap.add_argument("--points", type=int, default=None, help="points per rank (default: the config's)")
+    ap.add_argument("--schur-impl", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from realsensecalibration_amd import capi
+    from realsensecalibration_amd import synthetic as syn
+
+    # ---- workload: this rank's shard
+    C, P_cfg, k, seed, outl, huber = syn.CONFIGS[args.config]
+    P_rank = args.points or P_cfg
+    P_total = P_rank * world
+    t0 = time.time()
+    prob = syn.make_problem(C, P_total, k, seed, point_range=(rank * P_rank, (rank + 1) * P_rank), outlier_frac=outl)
+    prob["huber_delta"] = huber
+    gen_s = time.time() - t0
+    N_rank, N_total = prob["N"], prob["N"] * world
+
+    uid = None
+    if world > 1:
+        box = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = ctypes.create_string_buffer(box[0], 128)
+
+    def options(**kw):
+        o = capi.default_options(device=local_rank, huber_delta=huber, rank=rank, world_size=world, **kw)
+        if args.schur_impl is not None:
+            o.schur_impl = args.schur_impl
+        if uid is not None:
+            o.comm_unique_id = ctypes.cast(uid, ctypes.c_void_p)
+        return o
+
+    problem = capi.Problem.points(prob)
+
+    # ---- reference run with the reference's own options (tolerances on): iterations to converge, final RMS
+    sv = capi.Solver(problem, options())
+    s_conv = sv.run()
+    _, sumsq = sv.final_costs()
+    rms = float(np.sqrt(sumsq / (2.0 * N_total))) if sumsq > 0 else float("nan")
+    sv.close()
+
+    # ---- throughput runs: exactly W then exactly K iterations from the uploaded start
+    # negative tolerances: no convergence test can fire (0 would still stop on a bitwise-equal candidate cost)
+    fixed = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
+                 max_num_consecutive_invalid_steps=1 << 30, min_trust_region_radius=0.0)
+    sv_w = capi.Solver(problem, options(max_num_iterations=max(args.warmup, 1), **fixed))
+    sv_w.run()
+    sv_w.close()
+    sv_k = capi.Solver(problem, options(max_num_iterations=args.steps, profile_kernels=0 if args.no_events else 1, **fixed))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    s_k = sv_k.run()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert s_k.num_iterations == args.steps, (s_k.num_iterations, args.steps)
+    stats = sv_k.kernel_stats()
+    sv_k.close()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    iters_per_s = args.steps / elapsed
+    value = iters_per_s * (N_total / 2_000_000.0) if args.config == "cfg3" else iters_per_s
+    out = {
+        "metric": "LM iterations/sec (64 cams x 100k pts point model; + final reprojection RMS px)",
+        "value": value, "unit": "LM iterations/s (of the 2M-observation workload)", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %d cams x %d points, %d observations (%d views/point), point model <2,6,3>, "
+                               "DENSE_SCHUR-equivalent; %d points per GPU" % (args.config, C, P_total, N_total, k, P_rank),
+                   "sharding": "points by contiguous block, cameras replicated, RCCL all-reduce of the reduced system" if world > 1 else "single GPU",
+                   "schur_impl": int(options().schur_impl), "seed": seed},
+        "lm_iterations_per_s": iters_per_s, "observations_per_s": iters_per_s * N_total,
+        "final_reprojection_rms_px": rms, "iterations_to_converge": int(s_conv.num_iterations),
+        "converged_final_cost": s_conv.final_cost, "termination": int(s_conv.termination_type),
+        "problem_generation_s": gen_s, "upload_s": s_k.setup_seconds,
+    }
+
+    # ---- roofline of the dominant kernel, from HIP-event durations recorded in the timed region
+    if stats:
+        per = {n: (c, ms / max(c, 1)) for n, (c, ms) in stats.items()}
+        dom = max(stats.items(), key=lambda kv: kv[1][1])[0]
+        views = np.full(P_rank, k, np.float64)
+        schur_flops = syn.schur_flops_per_iteration(views)
+        b_iter = syn.algorithmic_bytes_per_iteration(C, P_rank, N_rank)
+        dom_ms = per[dom][1]
+        kern = {n: {"launches": int(c), "avg_us": 1e3 * a} for n, (c, a) in sorted(per.items())}
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        if "schur" in dom or "linearize" in dom:
+            ach = schur_flops / (dom_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "avg_launch_us": 1e3 * dom_ms,
+                               "algorithmic_flops_per_launch": schur_flops,
+                               "note": "fp64 FMA-bound point elimination: sum_j k_j(k_j+1)/2 blocks x 216 flop (+rhs); "
+                                       "fp64 vector and MFMA pipes share the 78.6 TF peak"}
+        else:
+            ach = b_iter / (dom_ms * 1e-3) / 1e9
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": 1e3 * dom_ms}
+        it_s = elapsed / args.steps
+        out["roofline"]["iteration_hbm_view"] = {"algorithmic_bytes_per_iteration": b_iter, "achieved_GBps": b_iter / it_s / 1e9,
+                                                 "frac_of_8TBps": b_iter / it_s / 1e9 / HBM_PEAK_GBS}
+        out["kernels"] = kern
+
+    # ---- CPU baseline: the oracle (a port of the Ceres-1.14 path; real Ceres cannot be built here) on this box
+    if not args.no_cpu_baseline and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        o = oracle_lib.load()
+        ncpu = len(os.sched_getaffinity(0))
+        res = {}
+        for nt in sorted({1, ncpu}):
+            oo = o.options(max_num_iterations=args.cpu_iters, num_threads=nt, function_tolerance=-1.0, parameter_tolerance=-1.0,
+                           gradient_tolerance=-1.0, huber_delta=huber)
+            _, s_cpu, _ = o.solve_points(prob, oo)
+            res[nt] = s_cpu.num_iterations / s_cpu.minimizer_seconds
+        best = max(res, key=lambda n: res[n])
+        out["cpu_baseline"] = {"value": res[best], "unit": "LM iterations/s", "cores": int(best), "kind": "port",
+                               "sample": "%d LM iterations of the same %s problem (oracle/: Jet AutoDiff + Schur + dense LLT, "
+                                         "-O3 -march=native, OpenMP over points); single thread = %.4f it/s"
+                                         % (args.cpu_iters, args.config, res[1]),
+                               "single_thread_value": res[1], "all_cores_value": res.get(ncpu), "host_cores": ncpu}
+        out["speedup_vs_cpu_baseline"] = iters_per_s / res[best]
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,31 @@
-// Tiled Schur-complement accumulation (schur_impl = 1).  See DESIGN.md §Kernels.
+// Tiled Schur-complement accumulation (schur_impl = 1): the kernel that dominates an LM iteration.
+//
+//   S = U + D_c^2 - sum_j W_j (V_j + D_pj^2)^-1 W_j'          (schur_eliminator in Ceres' DENSE_SCHUR)
+//
+// A point with k views contributes k(k+1)/2 upper 6x6 blocks of 108 fp64 FMAs each: 4.5 GFLOP per
+// iteration at 64 cameras x 100k points x 20 views — 40x the arithmetic of everything else in the
+// iteration, against 104 MB of algorithmic HBM traffic.  The elimination is fp64-FMA bound, not HBM bound,
+// and the output (1.18 MB) cannot live in one CU's LDS, so scattering per-point products with atomics
+// (schur_impl = 0) runs at the atomic rate.  This kernel keeps every S block in REGISTERS instead:
+//
+//   * cameras are grouped by 16; a workgroup (256 threads) owns one 16 x 16 tile of camera pairs and one
+//     thread owns one pair (a, b): its 6x6 block lives in 36 fp64 registers for the whole launch.
+//   * which points contribute to pair (a, b) is static: camMask[cam] is a bitset over points.  A thread
+//     walks the set bits of camMask[a] & camMask[b] (its own hit list, ~10% of the points), so lanes are
+//     ~fully utilised instead of the 10% a lock-step sweep over points would give.
+//   * per point only X, the damped inverse point block and V^-1 g_p (12 doubles) are staged in LDS, 512
+//     points per chunk; the two observation-side factors of a hit are recomputed from the thread's own
+//     camera constants (R, t, fx, fy in registers).  That doubles the FMA count per hit but keeps the LDS
+//     traffic at 12 gathered doubles per hit and the chunk large enough that hit-count imbalance across the
+//     lanes of a wave stays below ~25%.
+//   * block(a,b) = E_a' (N_a Vinv N_b') E_b with E = [A K | Pj]; the per-camera 3x3 factor K (left Jacobian
+//     of SO(3)) is pulled out of the sum over points and applied once per pair in k_schur_finish.
+//   * every workgroup writes its 256 x 42 partial sums; k_schur_finish adds them in a fixed order (bitwise
+//     reproducible), applies K, and subtracts the result from S.
+//
+// The point-side pass (k_point_pass) that precedes it evaluates residuals and Jacobian blocks once per
+// observation, accumulates U, g_c (LDS fp64 atomics per workgroup), forms the damped inverse point blocks
+// and writes the 12 doubles per point the pair kernel stages.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -12,10 +39,307 @@ namespace rsba {
 
 class KernelTimer;
 
+#define RSBA_TG 16          // cameras per group
+#define RSBA_CHUNK 512      // points per LDS chunk
+#define RSBA_CW (RSBA_CHUNK / 64)
+#define RSBA_PT_STRIDE 12   // X(3) Vinv(6) y(3)
+#define RSBA_PART 42        // 36 block + 6 corr
+
+struct SchurSeg { int ga, gb, chunk_begin, chunk_end; };
+
 struct TiledSchur {
+  int C = 0, P = 0, ngroups = 0, nwords = 0, nchunks = 0, nseg = 0, grid_pp = 0;
+  unsigned long long* cam_mask = nullptr;   // [ngroups*16][nwords]
+  SchurSeg* segs = nullptr;                 // [nseg]
+  int* tile_seg_ptr = nullptr;              // [ntiles+1] segments of a tile are contiguous
+  int* tile_ab = nullptr;                   // [ntiles][2]
+  int ntiles = 0;
+  double* ptdata = nullptr;                 // [P][12]
+  double* partial = nullptr;                // [nseg][42][256]
+  double* block_scal = nullptr;
+  // robust-loss support: sqrt(rho') per observation in camera-major order
+  int* cam_prefix = nullptr;                // [ngroups*16][nwords] set bits of cam_mask before each word
+  int* cam_ptr = nullptr;                   // [ngroups*16+1] start of each camera's observation list
+  int* cm_pos = nullptr;                    // [N] sorted observation -> camera-major position
+  double* sq_cm = nullptr;                  // [N]
   int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam);
   int Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T);
   void Free();
 };
+
+// ------------------------------------------------------------------------------------------------
+// K_A1: point pass, one thread per point.
+// ------------------------------------------------------------------------------------------------
+#define RSBA_PP_ACC 27  // 21 U upper + 6 gc
+
+template <bool kStageCamc>
+__global__ void __launch_bounds__(256)
+k_point_pass(int C, int P, const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
+             const int* __restrict__ pt_ptr, const double* __restrict__ camc_g, const double* __restrict__ pts,
+             double* __restrict__ scale_p, double* __restrict__ ptdata, double* __restrict__ red, RedLayout L,
+             double* __restrict__ block_scal, const int* __restrict__ cm_pos, double* __restrict__ sq_cm, IterParams ip) {
+  extern __shared__ double lds[];
+  double* acc = lds;                                   // C x 27
+  double* camc_l = lds + (size_t)C * RSBA_PP_ACC;      // C x 32 when staged
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C * RSBA_PP_ACC; i += blockDim.x) acc[i] = 0.0;
+  if (kStageCamc) for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) camc_l[i] = camc_g[i];
+  __syncthreads();
+  const double* camc = kStageCamc ? camc_l : camc_g;
+  double cost = 0, xn = 0, fail = 0, gmax = 0;
+  for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
+    const int b = pt_ptr[j], e = pt_ptr[j + 1];
+    const double X[3] = {pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2]};
+    double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
+    for (int q = b; q < e; ++q) {
+      const int cam = obs_cam[q];
+      double r[2], jc[12], jp[6], sq;
+      ResidualJacobian(camc + (size_t)cam * CC_STRIDE, X, obs_u[q], obs_v[q], r, jc, jp);
+      cost += LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
+      if (ip.huber_delta > 0.0) sq_cm[cm_pos[q]] = sq;
+      if (sq != 1.0) {
+        r[0] *= sq; r[1] *= sq;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) jc[i] *= sq;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) jp[i] *= sq;
+      }
+      V[0] += jp[0] * jp[0] + jp[3] * jp[3]; V[1] += jp[0] * jp[1] + jp[3] * jp[4]; V[2] += jp[0] * jp[2] + jp[3] * jp[5];
+      V[3] += jp[1] * jp[1] + jp[4] * jp[4]; V[4] += jp[1] * jp[2] + jp[4] * jp[5]; V[5] += jp[2] * jp[2] + jp[5] * jp[5];
+      gp[0] += jp[0] * r[0] + jp[3] * r[1]; gp[1] += jp[1] * r[0] + jp[4] * r[1]; gp[2] += jp[2] * r[0] + jp[5] * r[1];
+      double* a27 = acc + (size_t)cam * RSBA_PP_ACC;
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c6 = a; c6 < 6; ++c6) { unsafeAtomicAdd(&a27[t], jc[a] * jc[c6] + jc[6 + a] * jc[6 + c6]); ++t; }
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) unsafeAtomicAdd(&a27[21 + a], jc[a] * r[0] + jc[6 + a] * r[1]);
+    }
+    double sp[3] = {1.0, 1.0, 1.0};
+    if (ip.jacobi_scaling) {
+      if (ip.first) { sp[0] = 1.0 / (1.0 + sqrt(V[0])); sp[1] = 1.0 / (1.0 + sqrt(V[3])); sp[2] = 1.0 / (1.0 + sqrt(V[5])); }
+      else { sp[0] = scale_p[3 * (size_t)j]; sp[1] = scale_p[3 * (size_t)j + 1]; sp[2] = scale_p[3 * (size_t)j + 2]; }
+    }
+    if (ip.first) { scale_p[3 * (size_t)j] = sp[0]; scale_p[3 * (size_t)j + 1] = sp[1]; scale_p[3 * (size_t)j + 2] = sp[2]; }
+    double Vi[6];
+    const bool ok = PointBlockInverse(V, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, ip.radius, Vi);
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Vi[i] = 0.0;
+      if (e > b) fail += 1.0;
+    }
+    double y[3];
+    Sym3MulVec(Vi, gp, y);
+    double* pd = ptdata + (size_t)j * RSBA_PT_STRIDE;
+    pd[0] = X[0]; pd[1] = X[1]; pd[2] = X[2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pd[3 + i] = Vi[i];
+    pd[9] = y[0]; pd[10] = y[1]; pd[11] = y[2];
+    xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+    gmax = fmax(gmax, fmax(fabs(gp[0]), fmax(fabs(gp[1]), fabs(gp[2]))));
+  }
+  __syncthreads();
+  for (int i = tid; i < C * RSBA_PP_ACC; i += blockDim.x) {
+    const int c = i / RSBA_PP_ACC, e = i - c * RSBA_PP_ACC;
+    const double v = acc[i];
+    if (v == 0.0) continue;
+    if (e < 21) {
+      int a = 0, rem = e;
+      while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+      const int c6 = a + rem;
+      unsafeAtomicAdd(&red[L.S() + (size_t)(6 * c + a) * L.nc + 6 * c + c6], v);
+      if (a == c6) unsafeAtomicAdd(&red[L.diagU() + 6 * c + a], v);
+    } else {
+      unsafeAtomicAdd(&red[L.gc() + 6 * c + (e - 21)], v);
+    }
+  }
+  __shared__ double s[4][256];
+  s[0][tid] = cost; s[1][tid] = xn; s[2][tid] = fail; s[3][tid] = gmax;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { s[0][tid] += s[0][tid + off]; s[1][tid] += s[1][tid + off]; s[2][tid] += s[2][tid + off]; s[3][tid] = fmax(s[3][tid], s[3][tid + off]); }
+    __syncthreads();
+  }
+  if (tid < 4) block_scal[4 * blockIdx.x + tid] = s[tid][0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_A2: pair kernel.  One workgroup per (tile, segment of chunks); thread (ia, ib) owns camera pair
+// (16 ga + ia, 16 gb + ib).  LDS: point data of the current chunk + the 32 visibility bit-rows.
+// ------------------------------------------------------------------------------------------------
+struct SideConst {
+  double R[9], t[3], fx, fy;
+  bool small;
+};
+
+__device__ __forceinline__ void LoadSide(const double* __restrict__ cc, SideConst& s) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s.R[i] = cc[CC_R + i];
+  s.t[0] = cc[CC_T]; s.t[1] = cc[CC_T + 1]; s.t[2] = cc[CC_T + 2];
+  s.fx = cc[CC_FX]; s.fy = cc[CC_FY];
+  s.small = cc[CC_SMALL] != 0.0;
+}
+
+// Reduced Jacobian rows of one observation: e0/e1 = rows of [A | Pj] (6 each, entries 4 / 3 are zero),
+// n0/n1 = rows of Pj R (2x3).  The camera's K factor is NOT applied here.
+__device__ __forceinline__ void SideRows(const SideConst& s, const double X[3], double sq, double e0[6], double e1[6], double n0[3], double n1[3]) {
+  const double q0 = s.R[0] * X[0] + s.R[1] * X[1] + s.R[2] * X[2];
+  const double q1 = s.R[3] * X[0] + s.R[4] * X[1] + s.R[5] * X[2];
+  const double q2 = s.R[6] * X[0] + s.R[7] * X[1] + s.R[8] * X[2];
+  const double p0 = q0 + s.t[0], p1 = q1 + s.t[1], p2 = q2 + s.t[2];
+  const double iz = 1.0 / p2;
+  const double al = s.fx * iz * sq, be = s.fy * iz * sq;   // sqrt(rho') scales every Jacobian entry of the observation
+  const double ga = -al * p0 * iz, de = -be * p1 * iz;
+  const double w0 = s.small ? X[0] : q0, w1 = s.small ? X[1] : q1, w2 = s.small ? X[2] : q2;
+  e0[0] = w1 * ga; e0[1] = w2 * al - w0 * ga; e0[2] = -w1 * al; e0[3] = al; e0[4] = 0.0; e0[5] = ga;
+  e1[0] = w1 * de - w2 * be; e1[1] = -w0 * de; e1[2] = w0 * be; e1[3] = 0.0; e1[4] = be; e1[5] = de;
+  n0[0] = al * s.R[0] + ga * s.R[6]; n0[1] = al * s.R[1] + ga * s.R[7]; n0[2] = al * s.R[2] + ga * s.R[8];
+  n1[0] = be * s.R[3] + de * s.R[6]; n1[1] = be * s.R[4] + de * s.R[7]; n1[2] = be * s.R[5] + de * s.R[8];
+}
+
+template <bool kLoss>
+__global__ void __launch_bounds__(256, 2)
+k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const SchurSeg* __restrict__ segs,
+              const unsigned long long* __restrict__ cam_mask, const double* __restrict__ ptdata,
+              const int* __restrict__ cam_prefix, const int* __restrict__ cam_ptr, const double* __restrict__ sq_cm,
+              double* __restrict__ partial) {
+  __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];            // 48 KB
+  __shared__ unsigned long long mk[2 * RSBA_TG][RSBA_CW];       // 2 KB
+  const SchurSeg sg = segs[blockIdx.x];
+  const int tid = threadIdx.x, ia = tid >> 4, ib = tid & 15;
+  const int cam_a = RSBA_TG * sg.ga + ia, cam_b = RSBA_TG * sg.gb + ib;
+  const bool diag_tile = sg.ga == sg.gb;
+  const bool live = cam_a < C && cam_b < C && (!diag_tile || ia <= ib);
+  const bool self = live && cam_a == cam_b;
+  SideConst A, B;
+  LoadSide(camc + (size_t)(cam_a < C ? cam_a : 0) * CC_STRIDE, A);
+  LoadSide(camc + (size_t)(cam_b < C ? cam_b : 0) * CC_STRIDE, B);
+  double acc[36], corr[6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) corr[i] = 0.0;
+
+  for (int ch = sg.chunk_begin; ch < sg.chunk_end; ++ch) {
+    const int j0 = ch * RSBA_CHUNK;
+    const int np = min(RSBA_CHUNK, P - j0);
+    __syncthreads();
+    for (int i = tid; i < np * RSBA_PT_STRIDE; i += 256) pt[i] = ptdata[(size_t)j0 * RSBA_PT_STRIDE + i];
+    {
+      const int row = tid >> 3, w = tid & 7;  // 32 rows x 8 words = 256 threads
+      const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
+      mk[row][w] = cam < C ? cam_mask[(size_t)cam * nwords + (size_t)ch * RSBA_CW + w] : 0ull;
+    }
+    __syncthreads();
+    if (!live) continue;
+#pragma unroll 1
+    for (int w = 0; w < RSBA_CW; ++w) {
+      unsigned long long h = mk[ia][w] & mk[RSBA_TG + ib][w];
+#pragma unroll 1
+      while (h) {
+        const int bit = __ffsll((long long)h) - 1;
+        h &= h - 1;
+        const double* pd = pt + (size_t)(w * 64 + bit) * RSBA_PT_STRIDE;
+        const double X[3] = {pd[0], pd[1], pd[2]};
+        const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
+        double ea0[6], ea1[6], na0[3], na1[3], eb0[6], eb1[6], nb0[3], nb1[3];
+        double sqa = 1.0, sqb = 1.0;
+        if (kLoss) {
+          // rank of this point in each camera's own observation list -> its sqrt(rho')
+          const unsigned long long below = (1ull << bit) - 1ull;
+          const int gw = ch * RSBA_CW + w;
+          sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + gw] + __popcll(mk[ia][w] & below)];
+          sqb = sq_cm[cam_ptr[cam_b] + cam_prefix[(size_t)cam_b * nwords + gw] + __popcll(mk[RSBA_TG + ib][w] & below)];
+        }
+        SideRows(A, X, sqa, ea0, ea1, na0, na1);
+        SideRows(B, X, sqb, eb0, eb1, nb0, nb1);
+        // M = Na Vinv Nb'  (2x2)
+        const double t00 = na0[0] * v0 + na0[1] * v1 + na0[2] * v2, t01 = na0[0] * v1 + na0[1] * v3 + na0[2] * v4, t02 = na0[0] * v2 + na0[1] * v4 + na0[2] * v5;
+        const double t10 = na1[0] * v0 + na1[1] * v1 + na1[2] * v2, t11 = na1[0] * v1 + na1[1] * v3 + na1[2] * v4, t12 = na1[0] * v2 + na1[1] * v4 + na1[2] * v5;
+        const double m00 = t00 * nb0[0] + t01 * nb0[1] + t02 * nb0[2], m01 = t00 * nb1[0] + t01 * nb1[1] + t02 * nb1[2];
+        const double m10 = t10 * nb0[0] + t11 * nb0[1] + t12 * nb0[2], m11 = t10 * nb1[0] + t11 * nb1[1] + t12 * nb1[2];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          const double z0 = ea0[p] * m00 + ea1[p] * m10, z1 = ea0[p] * m01 + ea1[p] * m11;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) acc[6 * p + q] += z0 * eb0[q] + z1 * eb1[q];
+        }
+        if (self) {
+          const double f0 = na0[0] * pd[9] + na0[1] * pd[10] + na0[2] * pd[11];
+          const double f1 = na1[0] * pd[9] + na1[1] * pd[10] + na1[2] * pd[11];
+#pragma unroll
+          for (int p = 0; p < 6; ++p) corr[p] += ea0[p] * f0 + ea1[p] * f1;
+        }
+      }
+    }
+  }
+  double* out = partial + (size_t)blockIdx.x * RSBA_PART * 256;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) out[i * 256 + tid] = acc[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out[(36 + i) * 256 + tid] = corr[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_A3: fixed-order sum of the partials of one pair, K factors, S -= block, corr.
+// One thread per (tile, lane).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_schur_finish(int C, int ntiles, const int* __restrict__ tile_ab, const int* __restrict__ tile_seg_ptr,
+               const double* __restrict__ partial, const double* __restrict__ camc, double* __restrict__ red, RedLayout L) {
+  const int tile = blockIdx.x, tid = threadIdx.x, ia = tid >> 4, ib = tid & 15;
+  if (tile >= ntiles) return;
+  const int ga = tile_ab[2 * tile], gb = tile_ab[2 * tile + 1];
+  const int cam_a = RSBA_TG * ga + ia, cam_b = RSBA_TG * gb + ib;
+  if (cam_a >= C || cam_b >= C || (ga == gb && ia > ib)) return;
+  double core[36], cr[6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) core[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) cr[i] = 0.0;
+  for (int sgi = tile_seg_ptr[tile]; sgi < tile_seg_ptr[tile + 1]; ++sgi) {
+    const double* in = partial + (size_t)sgi * RSBA_PART * 256;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) core[i] += in[i * 256 + tid];
+    if (cam_a == cam_b) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) cr[i] += in[(36 + i) * 256 + tid];
+    }
+  }
+  const double* Ka = camc + (size_t)cam_a * CC_STRIDE + CC_K;
+  const double* Kb = camc + (size_t)cam_b * CC_STRIDE + CC_K;
+  // rows: Ta' core  (first three rows mixed by Ka')
+  double tmp[36];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) tmp[6 * p + q] = Ka[0 * 3 + p] * core[0 * 6 + q] + Ka[1 * 3 + p] * core[1 * 6 + q] + Ka[2 * 3 + p] * core[2 * 6 + q];
+#pragma unroll
+    for (int p = 3; p < 6; ++p) tmp[6 * p + q] = core[6 * p + q];
+  }
+  // columns: (.) Tb
+  double blk[36];
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) blk[6 * p + q] = tmp[6 * p + 0] * Kb[0 * 3 + q] + tmp[6 * p + 1] * Kb[1 * 3 + q] + tmp[6 * p + 2] * Kb[2 * 3 + q];
+#pragma unroll
+    for (int q = 3; q < 6; ++q) blk[6 * p + q] = tmp[6 * p + q];
+  }
+  double* Sb = red + L.S() + (size_t)(6 * cam_a) * L.nc + 6 * cam_b;
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) Sb[(size_t)p * L.nc + q] -= blk[6 * p + q];
+  }
+  if (cam_a == cam_b) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) red[L.corr() + 6 * cam_a + p] = -(Ka[0 * 3 + p] * cr[0] + Ka[1 * 3 + p] * cr[1] + Ka[2 * 3 + p] * cr[2]);
+#pragma unroll
+    for (int p = 3; p < 6; ++p) red[L.corr() + 6 * cam_a + p] = -cr[p];
+  }
+}
 
 }  // namespace rsba

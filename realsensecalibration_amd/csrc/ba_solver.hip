@@ -129,9 +129,75 @@ struct rsba_solver {
 
 namespace rsba {
 
-int TiledSchur::Build(int, int, const std::vector<int>&, const std::vector<int>&) { return RSBA_ERR_UNSUPPORTED; }
-int TiledSchur::Launch(rsba_solver*, const IterParams&, KernelTimer&) { return RSBA_ERR_UNSUPPORTED; }
-void TiledSchur::Free() {}
+// ------------------------------------------------------------------------------------------------
+// Static structure of the tiled Schur kernel: visibility bitsets, tiles, segments.
+// ------------------------------------------------------------------------------------------------
+int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam) {
+  C = C_; P = P_;
+  ngroups = (C + RSBA_TG - 1) / RSBA_TG;
+  nwords = ((P + 63) / 64 + RSBA_CW - 1) / RSBA_CW * RSBA_CW;
+  nchunks = nwords / RSBA_CW;
+  const int ncam = ngroups * RSBA_TG;
+  const int64_t N = pt_ptr[P];
+  std::vector<unsigned long long> mask((size_t)ncam * nwords, 0ull);
+  std::vector<int> cptr(ncam + 1, 0);
+  for (int j = 0; j < P; ++j)
+    for (int q = pt_ptr[j]; q < pt_ptr[j + 1]; ++q) { mask[(size_t)obs_cam[q] * nwords + (j >> 6)] |= 1ull << (j & 63); cptr[obs_cam[q] + 1]++; }
+  for (int c = 0; c < ncam; ++c) cptr[c + 1] += cptr[c];
+  std::vector<int> prefix((size_t)ncam * nwords, 0), cmpos(std::max<int64_t>(N, 1), 0);
+  for (int c = 0; c < ncam; ++c) { int run = 0; for (int w = 0; w < nwords; ++w) { prefix[(size_t)c * nwords + w] = run; run += __builtin_popcountll(mask[(size_t)c * nwords + w]); } }
+  {
+    // camera-major position of every (sorted) observation; a camera seeing the same point twice keeps file order
+    std::vector<int> fill(cptr.begin(), cptr.end() - 1);
+    for (int j = 0; j < P; ++j) for (int q = pt_ptr[j]; q < pt_ptr[j + 1]; ++q) cmpos[q] = fill[obs_cam[q]]++;
+  }
+  // tiles (ga <= gb) and their weights (live pairs)
+  std::vector<int> tab; std::vector<double> wt;
+  for (int ga = 0; ga < ngroups; ++ga) for (int gb = ga; gb < ngroups; ++gb) {
+    const int na = std::min(RSBA_TG, C - RSBA_TG * ga), nb = std::min(RSBA_TG, C - RSBA_TG * gb);
+    tab.push_back(ga); tab.push_back(gb);
+    wt.push_back(ga == gb ? na * (na + 1) / 2.0 : (double)na * nb);
+  }
+  ntiles = (int)wt.size();
+  int cus = 256;
+  { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
+  const int target = 2 * cus;
+  double wsum = 0; for (double w : wt) wsum += w;
+  std::vector<SchurSeg> sg; std::vector<int> tsp(ntiles + 1, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    int ns = (int)std::lround(target * wt[t] / wsum);
+    ns = std::max(1, std::min(ns, nchunks));
+    for (int i = 0; i < ns; ++i) {
+      SchurSeg e; e.ga = tab[2 * t]; e.gb = tab[2 * t + 1];
+      e.chunk_begin = (int)((int64_t)nchunks * i / ns); e.chunk_end = (int)((int64_t)nchunks * (i + 1) / ns);
+      sg.push_back(e);
+    }
+    tsp[t + 1] = (int)sg.size();
+  }
+  nseg = (int)sg.size();
+  grid_pp = std::max(1, std::min((P + 255) / 256, 2048));
+  int rc;
+  if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nseg)) || (rc = DevAlloc(&tile_seg_ptr, (size_t)ntiles + 1)) ||
+      (rc = DevAlloc(&tile_ab, (size_t)2 * ntiles)) || (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
+      (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
+      (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, cmpos.size())) ||
+      (rc = DevAlloc(&sq_cm, cmpos.size())))
+    return rc;
+  HIPCHK(hipMemcpy(cam_mask, mask.data(), mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(segs, sg.data(), sg.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(tile_seg_ptr, tsp.data(), tsp.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(tile_ab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cam_prefix, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cam_ptr, cptr.data(), cptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cm_pos, cmpos.data(), cmpos.size() * sizeof(int), hipMemcpyHostToDevice));
+  return RSBA_OK;
+}
+
+void TiledSchur::Free() {
+  void* ptrs[] = {cam_mask, segs, tile_seg_ptr, tile_ab, ptdata, partial, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  cam_mask = nullptr;
+}
 
 static void FreeSolver(rsba_solver* s) {
   if (!s) return;
@@ -144,7 +210,6 @@ static void FreeSolver(rsba_solver* s) {
   s->tiled.Free();
   s->marker.Free();
   if (s->res_host) (void)hipHostFree(s->res_host);
-  if (s->comm) ncclCommDestroy(s->comm);
   if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -209,6 +274,13 @@ static int UploadPoints(rsba_solver* s) {
   s->grid_pts = std::max(1, std::min((P + 255) / 256, 2048));
   if ((rc = DevAlloc(&s->block_scal, 4 * (size_t)std::max(s->grid_lin, 4096))) || (rc = DevAlloc(&s->block_part, 8 * (size_t)s->grid_pts))) return rc;
   if (s->opt.schur_impl != 0) {
+    // the tiled kernel keeps one visibility bit per (camera, point): a camera observing the same point
+    // twice needs the reference kernel (still on the GPU)
+    bool dup = false;
+    for (int j = 0; j < P && !dup; ++j) for (int q = ptr[j] + 1; q < ptr[j + 1]; ++q) if (cam[q] == cam[q - 1]) { dup = true; break; }
+    if (dup) s->opt.schur_impl = 0;
+  }
+  if (s->opt.schur_impl != 0) {
     rc = s->tiled.Build(C, P, ptr, cam);
     if (rc != RSBA_OK) return rc;
   } else if (maxk > 64) {
@@ -222,6 +294,35 @@ static int ResetPoints(rsba_solver* s) {
   HIPCHK(hipMemcpyAsync(s->cam[0], s->cam0, 6 * s->C * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   HIPCHK(hipMemcpyAsync(s->pts[0], s->pts0, 3 * (size_t)s->P * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   s->cur = 0;
+  return RSBA_OK;
+}
+
+
+int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
+  hipStream_t st = s->stream;
+  const int x = s->cur;
+  const bool stage = (size_t)C * (RSBA_PP_ACC + CC_STRIDE) * sizeof(double) <= 56 * 1024;
+  const size_t lds = (size_t)C * (RSBA_PP_ACC + (stage ? CC_STRIDE : 0)) * sizeof(double);
+  T.Begin("k_point_pass", st);
+  if (stage)
+    k_point_pass<true><<<grid_pp, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p, ptdata, s->red,
+                                                  s->L, block_scal, cm_pos, sq_cm, ip);
+  else
+    k_point_pass<false><<<grid_pp, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p, ptdata, s->red,
+                                                   s->L, block_scal, cm_pos, sq_cm, ip);
+  T.End(st);
+  T.Begin("k_finish_linearize", st);
+  k_finish_linearize<<<1, 256, 0, st>>>(grid_pp, block_scal, s->red, s->L, s->gmax);
+  T.End(st);
+  T.Begin("k_schur_pairs", st);
+  if (ip.huber_delta > 0.0)
+    k_schur_pairs<true><<<nseg, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial);
+  else
+    k_schur_pairs<false><<<nseg, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial);
+  T.End(st);
+  T.Begin("k_schur_finish", st);
+  k_schur_finish<<<ntiles, 256, 0, st>>>(C, ntiles, tile_ab, tile_seg_ptr, partial, s->camc[x], s->red, s->L);
+  T.End(st);
   return RSBA_OK;
 }
 
@@ -405,9 +506,22 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
   else { if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return RSBA_ERR_HIP; } s->own_stream = true; }
   s->timer.Enable(opt.profile_kernels != 0);
   int rc = RSBA_OK;
-  if (opt.world_size > 1) {
-    ncclUniqueId id; memcpy(&id, opt.comm_unique_id, sizeof(id));
-    if (ncclCommInitRank(&s->comm, opt.world_size, id, opt.rank) != ncclSuccess) { rsba::FreeSolver(s); return RSBA_ERR_COMM; }
+  if (opt.world_size > 1 || getenv("RSBA_FORCE_COMM")) {
+    // One communicator per unique id and process (an id can be used for one ncclCommInitRank only);
+    // solvers created later with the same id share it.  RSBA_FORCE_COMM=1 builds a 1-rank communicator
+    // so the collective path can be exercised on a single GPU.
+    static std::map<std::string, ncclComm_t> comms;
+    ncclUniqueId id;
+    if (opt.world_size > 1) memcpy(&id, opt.comm_unique_id, sizeof(id));
+    else if (ncclGetUniqueId(&id) != ncclSuccess) { rsba::FreeSolver(s); return RSBA_ERR_COMM; }
+    const std::string key = opt.world_size > 1 ? std::string((const char*)&id, sizeof(id)) : std::string("single");
+    auto it = comms.find(key);
+    if (it == comms.end()) {
+      ncclComm_t c = nullptr;
+      if (ncclCommInitRank(&c, std::max(opt.world_size, 1), id, opt.world_size > 1 ? opt.rank : 0) != ncclSuccess) { rsba::FreeSolver(s); return RSBA_ERR_COMM; }
+      it = comms.emplace(key, c).first;
+    }
+    s->comm = it->second;
   }
   if (hipHostMalloc((void**)&s->res_host, RES_SIZE * sizeof(double), hipHostMallocDefault) != hipSuccess) { rsba::FreeSolver(s); return RSBA_ERR_HIP; }
   if (p->model == RSBA_MODEL_POINTS) rc = rsba::UploadPoints(s);

@@ -79,7 +79,7 @@ void rsba_options_default(rsba_options* o) {
   o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8; o->huber_delta = 0.0;
-  o->device = -1; o->schur_impl = 0; o->profile_kernels = 0; o->rank = 0; o->world_size = 1; o->comm_unique_id = nullptr; o->stream = nullptr;
+  o->device = -1; o->schur_impl = 1; o->profile_kernels = 0; o->rank = 0; o->world_size = 1; o->comm_unique_id = nullptr; o->stream = nullptr;
 }
 
 int rsba_read_intrinsics_xml(const char* path, double* out4) { return rsba::ReadIntrinsicsXml(path, out4); }
