@@ -45,7 +45,7 @@ class KernelTimer;
 #define RSBA_PT_STRIDE 12   // X(3) Vinv(6) y(3)
 #define RSBA_PART 42        // 36 block + 6 corr
 
-struct SchurSeg { int ga, gb, chunk_begin, chunk_end; };
+struct SchurSeg { int ga, gb, chunk_begin, chunk_end, self, pad0, pad1, pad2; };
 
 struct TiledSchur {
   int C = 0, P = 0, ngroups = 0, nwords = 0, nchunks = 0, nseg = 0, grid_pp = 0;
@@ -200,7 +200,7 @@ __device__ __forceinline__ void SideRows(const SideConst& s, const double X[3], 
 }
 
 template <bool kLoss>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 1)
 k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const SchurSeg* __restrict__ segs,
               const unsigned long long* __restrict__ cam_mask, const double* __restrict__ ptdata,
               const int* __restrict__ cam_prefix, const int* __restrict__ cam_ptr, const double* __restrict__ sq_cm,
@@ -209,10 +209,16 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
   __shared__ unsigned long long mk[2 * RSBA_TG][RSBA_CW];       // 2 KB
   const SchurSeg sg = segs[blockIdx.x];
   const int tid = threadIdx.x, ia = tid >> 4, ib = tid & 15;
-  const int cam_a = RSBA_TG * sg.ga + ia, cam_b = RSBA_TG * sg.gb + ib;
-  const bool diag_tile = sg.ga == sg.gb;
-  const bool live = cam_a < C && cam_b < C && (!diag_tile || ia <= ib);
-  const bool self = live && cam_a == cam_b;
+  // Three kinds of tile:
+  //   off-diagonal (ga < gb): thread (ia, ib) owns pair (16 ga + ia, 16 gb + ib)
+  //   diagonal     (ga == gb, self == 0): pairs ia < ib only
+  //   self         (self == 1): the (a, a) blocks.  Camera a sees ~3x the points a pair shares, so its points
+  //                are dealt to 16 lanes: lane (ia, s) takes the bits {s, s+16, s+32, s+48} of every mask word.
+  const bool self_tile = sg.self != 0;
+  const int cam_a = RSBA_TG * sg.ga + ia, cam_b = self_tile ? cam_a : RSBA_TG * sg.gb + ib;
+  const bool live = cam_a < C && cam_b < C && (self_tile || sg.ga != sg.gb || ia < ib);
+  const unsigned long long lane_bits = self_tile ? (0x0001000100010001ull << ib) : ~0ull;
+  const int rowb = self_tile ? ia : RSBA_TG + ib;
   SideConst A, B;
   LoadSide(camc + (size_t)(cam_a < C ? cam_a : 0) * CC_STRIDE, A);
   LoadSide(camc + (size_t)(cam_b < C ? cam_b : 0) * CC_STRIDE, B);
@@ -233,45 +239,46 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
       mk[row][w] = cam < C ? cam_mask[(size_t)cam * nwords + (size_t)ch * RSBA_CW + w] : 0ull;
     }
     __syncthreads();
-    if (!live) continue;
+    // every lane walks ITS OWN hit list through the whole chunk: the word index is per lane, so a wave
+    // runs max-over-lanes(hits in 512 points) trips, not the sum over words of the per-word maxima
+    int w = live ? 0 : RSBA_CW;
+    unsigned long long h = live ? (mk[ia][0] & mk[rowb][0] & lane_bits) : 0ull;
 #pragma unroll 1
-    for (int w = 0; w < RSBA_CW; ++w) {
-      unsigned long long h = mk[ia][w] & mk[RSBA_TG + ib][w];
-#pragma unroll 1
-      while (h) {
-        const int bit = __ffsll((long long)h) - 1;
-        h &= h - 1;
-        const double* pd = pt + (size_t)(w * 64 + bit) * RSBA_PT_STRIDE;
-        const double X[3] = {pd[0], pd[1], pd[2]};
-        const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
-        double ea0[6], ea1[6], na0[3], na1[3], eb0[6], eb1[6], nb0[3], nb1[3];
-        double sqa = 1.0, sqb = 1.0;
-        if (kLoss) {
-          // rank of this point in each camera's own observation list -> its sqrt(rho')
-          const unsigned long long below = (1ull << bit) - 1ull;
-          const int gw = ch * RSBA_CW + w;
-          sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + gw] + __popcll(mk[ia][w] & below)];
-          sqb = sq_cm[cam_ptr[cam_b] + cam_prefix[(size_t)cam_b * nwords + gw] + __popcll(mk[RSBA_TG + ib][w] & below)];
-        }
-        SideRows(A, X, sqa, ea0, ea1, na0, na1);
-        SideRows(B, X, sqb, eb0, eb1, nb0, nb1);
-        // M = Na Vinv Nb'  (2x2)
-        const double t00 = na0[0] * v0 + na0[1] * v1 + na0[2] * v2, t01 = na0[0] * v1 + na0[1] * v3 + na0[2] * v4, t02 = na0[0] * v2 + na0[1] * v4 + na0[2] * v5;
-        const double t10 = na1[0] * v0 + na1[1] * v1 + na1[2] * v2, t11 = na1[0] * v1 + na1[1] * v3 + na1[2] * v4, t12 = na1[0] * v2 + na1[1] * v4 + na1[2] * v5;
-        const double m00 = t00 * nb0[0] + t01 * nb0[1] + t02 * nb0[2], m01 = t00 * nb1[0] + t01 * nb1[1] + t02 * nb1[2];
-        const double m10 = t10 * nb0[0] + t11 * nb0[1] + t12 * nb0[2], m11 = t10 * nb1[0] + t11 * nb1[1] + t12 * nb1[2];
+    for (;;) {
+      while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & mk[rowb][w] & lane_bits; }
+      if (h == 0ull) break;
+      const int bit = __ffsll((long long)h) - 1;
+      h &= h - 1;
+      const double* pd = pt + (size_t)(w * 64 + bit) * RSBA_PT_STRIDE;
+      const double X[3] = {pd[0], pd[1], pd[2]};
+      const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
+      double sqa = 1.0, sqb = 1.0;
+      if (kLoss) {
+        // rank of this point in each camera's own observation list -> its sqrt(rho')
+        const unsigned long long below = (1ull << bit) - 1ull;
+        const int gw = ch * RSBA_CW + w;
+        sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + gw] + __popcll(mk[ia][w] & below)];
+        sqb = self_tile ? sqa : sq_cm[cam_ptr[cam_b] + cam_prefix[(size_t)cam_b * nwords + gw] + __popcll(mk[rowb][w] & below)];
+      }
+      double ea0[6], ea1[6], na0[3], na1[3], eb0[6], eb1[6], nb0[3], nb1[3];
+      SideRows(A, X, sqa, ea0, ea1, na0, na1);
+      SideRows(B, X, sqb, eb0, eb1, nb0, nb1);
+      // M = Na Vinv Nb'  (2x2)
+      const double t00 = na0[0] * v0 + na0[1] * v1 + na0[2] * v2, t01 = na0[0] * v1 + na0[1] * v3 + na0[2] * v4, t02 = na0[0] * v2 + na0[1] * v4 + na0[2] * v5;
+      const double t10 = na1[0] * v0 + na1[1] * v1 + na1[2] * v2, t11 = na1[0] * v1 + na1[1] * v3 + na1[2] * v4, t12 = na1[0] * v2 + na1[1] * v4 + na1[2] * v5;
+      const double m00 = t00 * nb0[0] + t01 * nb0[1] + t02 * nb0[2], m01 = t00 * nb1[0] + t01 * nb1[1] + t02 * nb1[2];
+      const double m10 = t10 * nb0[0] + t11 * nb0[1] + t12 * nb0[2], m11 = t10 * nb1[0] + t11 * nb1[1] + t12 * nb1[2];
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
-          const double z0 = ea0[p] * m00 + ea1[p] * m10, z1 = ea0[p] * m01 + ea1[p] * m11;
+      for (int p = 0; p < 6; ++p) {
+        const double z0 = ea0[p] * m00 + ea1[p] * m10, z1 = ea0[p] * m01 + ea1[p] * m11;
 #pragma unroll
-          for (int q = 0; q < 6; ++q) acc[6 * p + q] += z0 * eb0[q] + z1 * eb1[q];
-        }
-        if (self) {
-          const double f0 = na0[0] * pd[9] + na0[1] * pd[10] + na0[2] * pd[11];
-          const double f1 = na1[0] * pd[9] + na1[1] * pd[10] + na1[2] * pd[11];
+        for (int q = 0; q < 6; ++q) acc[6 * p + q] += z0 * eb0[q] + z1 * eb1[q];
+      }
+      if (self_tile) {
+        const double f0 = na0[0] * pd[9] + na0[1] * pd[10] + na0[2] * pd[11];
+        const double f1 = na1[0] * pd[9] + na1[1] * pd[10] + na1[2] * pd[11];
 #pragma unroll
-          for (int p = 0; p < 6; ++p) corr[p] += ea0[p] * f0 + ea1[p] * f1;
-        }
+        for (int p = 0; p < 6; ++p) corr[p] += ea0[p] * f0 + ea1[p] * f1;
       }
     }
   }
@@ -289,11 +296,15 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
 __global__ void __launch_bounds__(256)
 k_schur_finish(int C, int ntiles, const int* __restrict__ tile_ab, const int* __restrict__ tile_seg_ptr,
                const double* __restrict__ partial, const double* __restrict__ camc, double* __restrict__ red, RedLayout L) {
-  const int tile = blockIdx.x, tid = threadIdx.x, ia = tid >> 4, ib = tid & 15;
+  const int tile = blockIdx.x, tid = threadIdx.x;
   if (tile >= ntiles) return;
-  const int ga = tile_ab[2 * tile], gb = tile_ab[2 * tile + 1];
-  const int cam_a = RSBA_TG * ga + ia, cam_b = RSBA_TG * gb + ib;
-  if (cam_a >= C || cam_b >= C || (ga == gb && ia > ib)) return;
+  const int ga = tile_ab[3 * tile], gb = tile_ab[3 * tile + 1];
+  const bool self_tile = tile_ab[3 * tile + 2] != 0;
+  // pair tiles: one thread per pair.  self tiles: threads 0..15, one per camera, each adds its 16 lane slices.
+  const int ia = self_tile ? tid : tid >> 4, ib = self_tile ? 0 : tid & 15;
+  if (self_tile && tid >= RSBA_TG) return;
+  const int cam_a = RSBA_TG * ga + ia, cam_b = self_tile ? cam_a : RSBA_TG * gb + ib;
+  if (cam_a >= C || cam_b >= C || (!self_tile && ga == gb && ia >= ib)) return;
   double core[36], cr[6];
 #pragma unroll
   for (int i = 0; i < 36; ++i) core[i] = 0.0;
@@ -301,11 +312,16 @@ k_schur_finish(int C, int ntiles, const int* __restrict__ tile_ab, const int* __
   for (int i = 0; i < 6; ++i) cr[i] = 0.0;
   for (int sgi = tile_seg_ptr[tile]; sgi < tile_seg_ptr[tile + 1]; ++sgi) {
     const double* in = partial + (size_t)sgi * RSBA_PART * 256;
+    if (!self_tile) {
 #pragma unroll
-    for (int i = 0; i < 36; ++i) core[i] += in[i * 256 + tid];
-    if (cam_a == cam_b) {
+      for (int i = 0; i < 36; ++i) core[i] += in[i * 256 + tid];
+    } else {
+      for (int sl = 0; sl < 16; ++sl) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) cr[i] += in[(36 + i) * 256 + tid];
+        for (int i = 0; i < 36; ++i) core[i] += in[i * 256 + 16 * ia + sl];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cr[i] += in[(36 + i) * 256 + 16 * ia + sl];
+      }
     }
   }
   const double* Ka = camc + (size_t)cam_a * CC_STRIDE + CC_K;

@@ -151,24 +151,27 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     std::vector<int> fill(cptr.begin(), cptr.end() - 1);
     for (int j = 0; j < P; ++j) for (int q = pt_ptr[j]; q < pt_ptr[j + 1]; ++q) cmpos[q] = fill[obs_cam[q]]++;
   }
-  // tiles (ga <= gb) and their weights (live pairs)
+  // tiles: pair tiles (ga <= gb) and one self tile per group.  A workgroup's time per chunk is set by its
+  // busiest lane, which is the same for diagonal and off-diagonal pair tiles (~10% of the points) and ~1/5 of
+  // that for self tiles (31% of the points dealt to 16 lanes): weights 1 and 1/4.
   std::vector<int> tab; std::vector<double> wt;
   for (int ga = 0; ga < ngroups; ++ga) for (int gb = ga; gb < ngroups; ++gb) {
-    const int na = std::min(RSBA_TG, C - RSBA_TG * ga), nb = std::min(RSBA_TG, C - RSBA_TG * gb);
-    tab.push_back(ga); tab.push_back(gb);
-    wt.push_back(ga == gb ? na * (na + 1) / 2.0 : (double)na * nb);
+    if (ga == gb && std::min(RSBA_TG, C - RSBA_TG * ga) < 2) continue;  // a 1-camera group has no off-diagonal pair
+    tab.push_back(ga); tab.push_back(gb); tab.push_back(0); wt.push_back(1.0);
   }
+  for (int ga = 0; ga < ngroups; ++ga) { tab.push_back(ga); tab.push_back(ga); tab.push_back(1); wt.push_back(0.25); }
   ntiles = (int)wt.size();
   int cus = 256;
   { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
-  const int target = 2 * cus;
+  const int target = (getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : 2) * cus;
   double wsum = 0; for (double w : wt) wsum += w;
   std::vector<SchurSeg> sg; std::vector<int> tsp(ntiles + 1, 0);
   for (int t = 0; t < ntiles; ++t) {
     int ns = (int)std::lround(target * wt[t] / wsum);
     ns = std::max(1, std::min(ns, nchunks));
     for (int i = 0; i < ns; ++i) {
-      SchurSeg e; e.ga = tab[2 * t]; e.gb = tab[2 * t + 1];
+      SchurSeg e; memset(&e, 0, sizeof(e));
+      e.ga = tab[3 * t]; e.gb = tab[3 * t + 1]; e.self = tab[3 * t + 2];
       e.chunk_begin = (int)((int64_t)nchunks * i / ns); e.chunk_end = (int)((int64_t)nchunks * (i + 1) / ns);
       sg.push_back(e);
     }
@@ -178,7 +181,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   grid_pp = std::max(1, std::min((P + 255) / 256, 2048));
   int rc;
   if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nseg)) || (rc = DevAlloc(&tile_seg_ptr, (size_t)ntiles + 1)) ||
-      (rc = DevAlloc(&tile_ab, (size_t)2 * ntiles)) || (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
+      (rc = DevAlloc(&tile_ab, (size_t)3 * ntiles)) || (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, cmpos.size())) ||
       (rc = DevAlloc(&sq_cm, cmpos.size())))
