@@ -1,0 +1,297 @@
+// Dense SPD solve of the reduced camera system on one workgroup (the Eigen LLT of Ceres'
+// DenseSchurComplementSolver), for n <= RSBA_CHOL_MAXN.
+//
+// Left-looking blocked Cholesky, 32-wide panels, 1024 threads (16 waves).  Per panel:
+//   1. the panel rows kb..n (the right-hand side rides along as row n) are loaded into LDS, scaled and
+//      damped on the fly when a raw source matrix is given (PanelSource)
+//   2. update with all previous panels, Pan -= L[rows, 0:kb] * L[kb:kb+32, 0:kb]', on the matrix cores
+//      (v_mfma_f64_16x16x4_f64): the B operand (the panel's own 32 rows of L, all kb columns) is staged in
+//      LDS once — panel + strip together always fit the same (n+1) x 33 doubles — so the k loop runs
+//      without barriers; the A operand streams from L2 one step ahead of the MFMAs
+//   3. 32x32 diagonal block factorised by wave 0 in registers (lane = row; column j goes through LDS once per
+//      step and comes back as broadcast reads; no branches: partial panels are padded with identity),
+//      1/sqrt(pivot) from v_rsq_f64 + two Newton steps; then T = L11^-1 (lane = column)
+//   4. rows below: X = Rows * T' on the matrix cores
+//   5. panel written back (L overwrites A); T is kept in the block's strict upper triangle (+ 1/diag in row n+1)
+// then y = row n (the forward substitution came for free) and a blocked back-substitution that uses the stored
+// T blocks, so no step of it is sequential.
+// Everything latency-critical stays in LDS/registers.  Non-positive pivots clear *ok (Ceres:
+// LINEAR_SOLVER_FAILURE -> invalid step).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+namespace rsba {
+
+#define RSBA_CHOL_MAXN 384
+#define RSBA_PB 32                       // panel width
+#define RSBA_PLD (RSBA_PB + 1)           // LDS leading dimension (bank-conflict padding)
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// Diagnostic build only (-DRSBA_PROFILE_PHASES): cycle totals per phase, read back with hipMemcpyFromSymbol.
+#ifdef RSBA_PROFILE_PHASES
+__device__ long long g_phase_cycles[16];
+#define RSBA_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { long long _t = clock64(); g_phase_cycles[k] += _t - _t0; _t0 = _t; } } while (0)
+#define RSBA_STAMP_INIT long long _t0 = clock64()
+#else
+#define RSBA_STAMP(k) do {} while (0)
+#define RSBA_STAMP_INIT do {} while (0)
+#endif
+
+__device__ __forceinline__ double ReadLaneD(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+// LDS doubles: (n+2) x 33 shared by the panel and the B strip, a 32 x 33 tile for T, 32 inverse pivots, scratch.
+__host__ __device__ inline size_t CholeskyLdsDoubles(int n) {
+  const size_t fact = (size_t)(n + 2) * RSBA_PLD + 2 * RSBA_PB * RSBA_PLD + RSBA_PB + 64;
+  const size_t back = (size_t)((n + 63) & ~63) + 3 * RSBA_PB * RSBA_PLD + 64;
+  return fact > back ? fact : back;
+}
+
+// Optional fused source: when src.S != nullptr the panel rows are not read from A but built on the fly from the
+// raw (unscaled, undamped, full symmetric) matrix: A_ij = S_ij s_i s_j (+ clamp(s_i^2 diagU_i, lo, hi)/radius on the
+// diagonal), which saves a separate pass over the matrix.  Row n (the rhs) is always taken from A.
+struct PanelSource {
+  const double* S;
+  const double* scale;
+  const double* diagU;
+  double lo, hi, inv_radius;
+};
+
+// A: (n+2) x n row-major in global memory; rows 0..n-1 the SPD matrix (lower triangle read), row n the rhs,
+// row n+1 scratch (inverse pivots).  On return the lower triangle holds L, row n holds y = L^-1 rhs, x_out x.
+__device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __restrict__ x_out, int* ok_out, double* lds, PanelSource src) {
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
+  double* T = lds + (size_t)(n + 2) * RSBA_PLD;        // 32 x 33: T = L11^-1
+  double* Lt = T + RSBA_PB * RSBA_PLD;                 // 32 x 33: padded L11
+  double* invd = Lt + RSBA_PB * RSBA_PLD;              // 32
+  double* colb = invd + RSBA_PB;                       // 32 (+32 spare)
+  __shared__ int s_ok;
+  if (tid == 0) s_ok = 1;
+  __syncthreads();
+  RSBA_STAMP_INIT;
+
+  for (int kb = 0; kb < n; kb += RSBA_PB) {
+    const int nb = min(RSBA_PB, n - kb);
+    const int R = n + 1 - kb;  // panel rows, rhs row included (panel-relative row R-1)
+    // LDS split of the shared (n+1) x 33 area: B strip first (kb rows of 33: Bst[q][c] = L[kb+c][q]), panel after
+    double* Bst = lds;
+    double* Pan = lds + (size_t)kb * RSBA_PLD;
+    // 1. load the panel (scaled / damped on the fly) and the B strip
+#pragma unroll 4
+    for (int e = tid; e < R * RSBA_PB; e += nt) {
+      const int r = e >> 5, c = e & 31;
+      double v = 0.0;
+      if (c < nb) {
+        const int gi = kb + r, gj = kb + c;
+        if (src.S != nullptr && gi < n) {
+          const double si = src.scale[gi];
+          v = src.S[(size_t)gi * n + gj] * (si * src.scale[gj]);
+          if (gi == gj) v += fmin(fmax(si * si * src.diagU[gi], src.lo), src.hi) * src.inv_radius;
+        } else {
+          v = A[(size_t)gi * n + gj];
+        }
+      }
+      Pan[r * RSBA_PLD + c] = v;
+    }
+#pragma unroll 4
+    for (int e = tid; e < kb * RSBA_PB; e += nt) {
+      // coalesced along q (row kb+c of L), transposed into Bst[q][c]
+      const int c = e / kb, q = e - c * kb;
+      Bst[q * RSBA_PLD + c] = c < nb ? A[(size_t)(kb + c) * n + q] : 0.0;
+    }
+    __syncthreads();
+    RSBA_STAMP(0);
+    // 2. update with previous panels (MFMA), one wave per 16-row block, no barriers inside
+    if (kb > 0) {
+      const int nrb = (R + 15) >> 4;
+      const int i = lane & 15, kk = lane >> 4;
+      for (int rb = wave; rb < nrb; rb += nwave) {
+        const int prow = rb * 16 + i;  // panel-relative row of this lane's A operand
+        const bool rok = prow < R;
+        const double* arow = A + (size_t)(kb + (rok ? prow : 0)) * n + kk;
+        d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        double an[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) an[u] = rok ? arow[4 * u] : 0.0;
+        for (int q0 = 0; q0 < kb; q0 += RSBA_PB) {
+          double ac[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) ac[u] = an[u];
+          if (q0 + RSBA_PB < kb) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) an[u] = rok ? arow[q0 + RSBA_PB + 4 * u] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double b0 = Bst[(q0 + 4 * u + kk) * RSBA_PLD + i];
+            const double b1 = Bst[(q0 + 4 * u + kk) * RSBA_PLD + 16 + i];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b1, acc1, 0, 0, 0);
+          }
+        }
+        // D layout: col = lane & 15, row = (lane >> 4) + 4 t
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = rb * 16 + kk + 4 * t;
+          if (r < R) {
+            Pan[r * RSBA_PLD + i] -= acc0[t];
+            Pan[r * RSBA_PLD + 16 + i] -= acc1[t];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    RSBA_STAMP(1);
+    // 3. diagonal block + its inverse, wave 0.  Rows/columns >= nb are padded with identity so that all 32
+    //    steps run unconditionally; lanes 32..63 shadow lanes 0..31 (same values, same addresses), so the
+    //    whole sequence is one branch-free basic block.  The empty asm statements pin every updated value at
+    //    its step: without them LLVM sinks the updates towards their uses and spills ~1300 registers.
+    if (wave == 0) {
+      double row[RSBA_PB];
+      const int lr = lane & 31;
+#pragma unroll
+      for (int c = 0; c < RSBA_PB; ++c) row[c] = (lr < nb) ? Pan[lr * RSBA_PLD + c] : (c == lr ? 1.0 : 0.0);
+      bool good = true;
+#pragma unroll
+      for (int j = 0; j < RSBA_PB; ++j) {
+        const double d = ReadLaneD(row[j], j);
+        if (!(d > 0.0) || !(d <= DBL_MAX)) good = false;
+        const double dd = good ? d : 1.0;
+        // il = 1/sqrt(d): hardware estimate + two Newton steps (full fp64); l = d * il
+        double il = __builtin_amdgcn_rsq(dd);
+        il = il * (1.5 - 0.5 * dd * il * il);
+        il = il * (1.5 - 0.5 * dd * il * il);
+        const double lij = (lr == j) ? dd * il : row[j] * il;
+        row[j] = lij;
+        colb[lr] = lij;
+        invd[j] = il;  // wave-uniform value
+        __builtin_amdgcn_wave_barrier();
+        // a_ic -= l_ij l_cj.  Entries above the diagonal (c > row) pick up garbage; they are never read.
+#pragma unroll
+        for (int c = j + 1; c < RSBA_PB; ++c) { row[c] -= lij * colb[c]; asm volatile("" : "+v"(row[c])); }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // padded factor -> Lt (32 x 33); the real rows also back into the panel
+#pragma unroll
+      for (int c = 0; c < RSBA_PB; ++c) {
+        const double v = (c <= lr) ? row[c] : 0.0;
+        Lt[lr * RSBA_PLD + c] = v;
+        if (lr < nb) Pan[lr * RSBA_PLD + c] = v;
+      }
+      if (lane == 0 && !good) s_ok = 0;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // T = L11^-1, column lr: t_i = (delta_i,lr - sum_{q<i} L[i][q] t_q) / L[i][i]   (L11 reads are broadcasts)
+      double t[RSBA_PB];
+#pragma unroll
+      for (int i = 0; i < RSBA_PB; ++i) {
+        double sacc = (i == lr) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < RSBA_PB; ++q) if (q < i) sacc -= Lt[i * RSBA_PLD + q] * t[q];
+        t[i] = sacc * invd[i];
+        asm volatile("" : "+v"(t[i]));
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < RSBA_PB; ++i) T[i * RSBA_PLD + lr] = t[i];
+    }
+    __syncthreads();
+    RSBA_STAMP(2);
+    // 4. rows below the diagonal block (and the rhs row): X = Rows * T' on the matrix cores.
+    //    X[r][j] = sum_k Rows[r][k] T[j][k]:  A-op[i][k] = Pan[r0+i][k],  B-op[k][j] = T[j][k]
+    {
+      const int nrb4 = (R - nb + 15) >> 4;
+      const int i = lane & 15, kk = lane >> 4;
+      for (int rb = wave; rb < nrb4; rb += nwave) {
+        const int prow = nb + rb * 16 + i;
+        d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int qs = 0; qs < RSBA_PB; qs += 4) {
+          const double a = prow < R ? Pan[prow * RSBA_PLD + qs + kk] : 0.0;
+          const double b0 = T[i * RSBA_PLD + qs + kk];
+          const double b1 = T[(16 + i) * RSBA_PLD + qs + kk];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();  // all of this block's rows are read before any is overwritten
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int r = nb + rb * 16 + kk + 4 * tt;
+          if (r < R) {
+            Pan[r * RSBA_PLD + i] = acc0[tt];
+            Pan[r * RSBA_PLD + 16 + i] = acc1[tt];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    RSBA_STAMP(3);
+    // 5. write the panel back; strict upper triangle of the diagonal block <- T (transposed), row n+1 <- 1/pivots
+#pragma unroll 4
+    for (int e = tid; e < R * RSBA_PB; e += nt) {
+      const int r = e >> 5, c = e & 31;
+      if (c < nb) {
+        double v = Pan[r * RSBA_PLD + c];
+        if (r < nb && c > r) v = T[c * RSBA_PLD + r];  // A[kb+r][kb+c] = T[c][r], c > r
+        A[(size_t)(kb + r) * n + kb + c] = v;
+      }
+    }
+    if (tid < nb) A[(size_t)(n + 1) * n + kb + tid] = invd[tid];
+    __threadfence_block();
+    __syncthreads();
+    RSBA_STAMP(4);
+  }
+
+  // Back-substitution L' x = y.  Block kb (from the bottom): b = y_blk - L21' x_below, then x_blk = T' b with
+  // the stored T = L11^-1 (T'[c][i] = T[i][c], nonzero for i >= c): no sequential step.
+  double* y = lds;                                 // n
+  double* part = lds + ((n + 63) & ~63);           // 32 x 33 partial sums
+  double* Tb = part + RSBA_PB * RSBA_PLD;          // 32 x 33: Tb[i][c] = T[i][c]
+  double* bb = Tb + RSBA_PB * RSBA_PLD;            // 32
+  for (int i = tid; i < n; i += nt) y[i] = A[(size_t)n * n + i];
+  __syncthreads();
+  for (int kb = ((n - 1) / RSBA_PB) * RSBA_PB; kb >= 0; kb -= RSBA_PB) {
+    const int nb = min(RSBA_PB, n - kb);
+    const int c = tid & 31;
+    for (int slice = tid >> 5; slice < 32; slice += nt >> 5) {
+      double s = 0.0;
+      if (c < nb) for (int i = kb + nb + slice; i < n; i += 32) s += A[(size_t)i * n + kb + c] * y[i];
+      part[slice * RSBA_PLD + c] = s;
+      // T block: T[i][c] for i > c sits at A[kb+c][kb+i]; the diagonal in row n+1
+      const int i = slice;
+      double tv = 0.0;
+      if (i < nb && c < nb) tv = (i > c) ? A[(size_t)(kb + c) * n + kb + i] : (i == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
+      Tb[i * RSBA_PLD + c] = tv;
+    }
+    __syncthreads();
+    if (tid < RSBA_PB) {
+      double s = 0.0;
+#pragma unroll 8
+      for (int q = 0; q < 32; ++q) s += part[q * RSBA_PLD + tid];
+      bb[tid] = (tid < nb) ? y[kb + tid] - s : 0.0;
+    }
+    __syncthreads();
+    if (tid < RSBA_PB) {
+      double s = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < RSBA_PB; ++i) s += Tb[i * RSBA_PLD + tid] * bb[i];
+      if (tid < nb) y[kb + tid] = s;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += nt) x_out[i] = y[i];
+  __syncthreads();
+  RSBA_STAMP(5);
+  if (tid == 0) *ok_out = s_ok;
+  __syncthreads();
+}
+
+}  // namespace rsba

@@ -131,7 +131,8 @@ __global__ void __launch_bounds__(64) k_marker_eval(int N, const MarkerObs* __re
 
 // One workgroup: normal equations in a fixed order, Jacobi scale, LM damping, Cholesky, step, candidate.
 //   A : (n+1) x n work matrix; H/g accumulated by thread-per-entry loops over the observations in order.
-__global__ void __launch_bounds__(1024)
+template <int kThreads>
+__global__ void __launch_bounds__(kThreads)
 k_marker_system(int N, int n, const MarkerObs* __restrict__ mo, const double* __restrict__ Jbuf, const double* __restrict__ rbuf,
                 const double* __restrict__ sumsq_per_obs, double* __restrict__ A, double* __restrict__ scale,
                 double* __restrict__ grad, const int* __restrict__ act_to_full, const double* __restrict__ params_x,
@@ -183,7 +184,8 @@ k_marker_system(int N, int n, const MarkerObs* __restrict__ mo, const double* __
   __threadfence_block();
   __syncthreads();
   double* ysol = A + (size_t)n * n;
-  CholeskySolveBlocked(n, A, ysol, &s_ok, lds);
+  if (kThreads == 512) CholeskySolvePanelLDS(n, A, ysol, &s_ok, lds, PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0});
+  else CholeskySolveBlocked(n, A, ysol, &s_ok, lds);
   __syncthreads();
   // step, candidate, norms, cost at x
   double* scr = lds;
@@ -281,7 +283,7 @@ struct MarkerDevice {
     if (!al((void**)&mo, N * sizeof(MarkerObs)) || !al((void**)&obs8, 8 * (size_t)N * 8) || !al((void**)&intr, p.intrinsics.size() * 8) ||
         !al((void**)&params[0], nfull * 8) || !al((void**)&params[1], nfull * 8) || !al((void**)&params0, nfull * 8) ||
         !al((void**)&Jbuf, (size_t)N * 8 * 18 * 8) || !al((void**)&rbuf, (size_t)N * 8 * 8) || !al((void**)&ss_x, N * 8) || !al((void**)&ss_c, N * 8) ||
-        !al((void**)&A, (size_t)(n + 1) * n * 8) || !al((void**)&scale, n * 8) || !al((void**)&grad, n * 8) || !al((void**)&delta, n * 8) ||
+        !al((void**)&A, (size_t)(n + 2) * n * 8) || !al((void**)&scale, n * 8) || !al((void**)&grad, n * 8) || !al((void**)&delta, n * 8) ||
         !al((void**)&res, RES_SIZE * 8) || !al((void**)&act_to_full, n * sizeof(int)))
       return RSBA_ERR_HIP;
     if (hipMemcpy(mo, h.data(), N * sizeof(MarkerObs), hipMemcpyHostToDevice) != hipSuccess) return RSBA_ERR_HIP;
@@ -316,9 +318,15 @@ struct MarkerDevice {
     k_marker_eval<<<(N + 63) / 64, 64, 0, st>>>(N, mo, obs8, params[x], intr, half_side, 1, Jbuf, rbuf, ss_x);
     T.End(st);
     if (!chk("k_marker_eval")) return RSBA_ERR_HIP;
-    const size_t lds = (size_t)std::max(2 * RSBA_TB * (RSBA_NB + 1) + RSBA_NB * (RSBA_NB + 1), 5 * 1024) * sizeof(double);
+    size_t lds = (size_t)std::max(2 * RSBA_TB * (RSBA_NB + 1) + RSBA_NB * (RSBA_NB + 1), 5 * 1024) * sizeof(double);
+    if (n <= RSBA_CHOL_MAXN) lds = std::max(lds, CholeskyLdsDoubles(n) * sizeof(double));
     T.Begin("k_marker_system", st);
-    k_marker_system<<<1, 1024, lds, st>>>(N, n, mo, Jbuf, rbuf, ss_x, A, scale, grad, act_to_full, params[x], params[c], delta, res, ip);
+    if (n <= RSBA_CHOL_MAXN) {
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_marker_system<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      k_marker_system<512><<<1, 512, lds, st>>>(N, n, mo, Jbuf, rbuf, ss_x, A, scale, grad, act_to_full, params[x], params[c], delta, res, ip);
+    } else {
+      k_marker_system<1024><<<1, 1024, lds, st>>>(N, n, mo, Jbuf, rbuf, ss_x, A, scale, grad, act_to_full, params[x], params[c], delta, res, ip);
+    }
     T.End(st);
     if (!chk("k_marker_system")) return RSBA_ERR_HIP;
     T.Begin("k_marker_eval", st);

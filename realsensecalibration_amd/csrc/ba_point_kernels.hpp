@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "ba_cholesky.hpp"
 #include "ba_math.hpp"
 
 namespace rsba {
@@ -409,36 +410,48 @@ __device__ void CholeskySolveBlocked(int n, double* __restrict__ A, double* __re
   if (tid == 0) *ok_out = s_ok;
 }
 
-__global__ void __launch_bounds__(1024)
+template <int kThreads>
+__global__ void __launch_bounds__(kThreads)
 k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __restrict__ A /* (nc+1) x nc */,
                        double* __restrict__ S_copy /* may be null */, double* __restrict__ rhs_copy,
                        double* __restrict__ scale_c, const double* __restrict__ cam_x, double* __restrict__ cam_c,
                        const double* __restrict__ intr, double* __restrict__ camc_c, double* __restrict__ dcam,
-                       const double* __restrict__ gmax_p, double* __restrict__ res, IterParams ip) {
+                       const double* __restrict__ gmax_p, double* __restrict__ res, IterParams ip, int sym_full) {
   extern __shared__ double lds[];
   const int n = L.nc, tid = threadIdx.x, nt = blockDim.x;
   __shared__ double s_norms[3];
   __shared__ int s_ok;
+#ifdef RSBA_PROFILE_PHASES
+  long long _k0 = clock64();
+#endif
   // 1. camera Jacobi scale
   for (int i = tid; i < n; i += nt) {
     if (ip.first) scale_c[i] = ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(red[L.diagU() + i])) : 1.0;
   }
   __threadfence_block();
   __syncthreads();
-  // 2. scaled, damped, mirrored system
-  for (size_t e = tid; e < (size_t)n * n; e += nt) {
-    const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
-    const int bi = i / 6, bj = j / 6;
-    // upper blocks are the valid ones; inside a diagonal block the upper triangle
-    const bool upper = (bi < bj) || (bi == bj && i <= j);
-    const double raw = upper ? red[L.S() + (size_t)i * n + j] : red[L.S() + (size_t)j * n + i];
-    double v = raw * (scale_c[i] * scale_c[j]);  // product of the scales first: bitwise symmetric
-    if (i == j) {
-      const double d = scale_c[i] * scale_c[i] * red[L.diagU() + i];
-      v += fmin(fmax(d, ip.min_lm_diagonal), ip.max_lm_diagonal) / ip.radius;
+  // 2. scaled, damped, mirrored system: one wave per row, lanes along the columns.  Skipped when the raw matrix
+  //    is already full symmetric and small enough for the LDS-panel Cholesky, which scales while it loads.
+  const bool fused = sym_full && kThreads == 512 && S_copy == nullptr;
+  if (!fused) {
+    const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    for (int i = wv; i < n; i += nw) {
+      const int bi = i / 6;
+      const double si = scale_c[i];
+      for (int j = lane; j < n; j += 64) {
+        const int bj = j / 6;
+        // upper blocks are the valid ones; inside a diagonal block the upper triangle
+        const bool upper = (bi < bj) || (bi == bj && i <= j);
+        const double raw = upper ? red[L.S() + (size_t)i * n + j] : red[L.S() + (size_t)j * n + i];
+        double v = raw * (si * scale_c[j]);  // product of the scales first: bitwise symmetric
+        if (i == j) {
+          const double d = si * si * red[L.diagU() + i];
+          v += fmin(fmax(d, ip.min_lm_diagonal), ip.max_lm_diagonal) / ip.radius;
+        }
+        A[(size_t)i * n + j] = v;
+        if (S_copy) S_copy[(size_t)i * n + j] = v;
+      }
     }
-    A[e] = v;
-    if (S_copy) S_copy[e] = v;
   }
   for (int i = tid; i < n; i += nt) {
     const double v = scale_c[i] * (red[L.gc() + i] + red[L.corr() + i]);
@@ -447,10 +460,20 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
   }
   __threadfence_block();
   __syncthreads();
+#ifdef RSBA_PROFILE_PHASES
+  if (tid == 0) g_phase_cycles[8] += clock64() - _k0;
+#endif
   // 3-4. factor + solve; y = solution of the scaled system, reused from row n of A
   double* ysol = A + (size_t)n * n;
-  CholeskySolveBlocked(n, A, ysol, &s_ok, lds);
+  if (kThreads == 512)
+    CholeskySolvePanelLDS(n, A, ysol, &s_ok, lds,
+                          fused ? PanelSource{red + L.S(), scale_c, red + L.diagU(), ip.min_lm_diagonal, ip.max_lm_diagonal, 1.0 / ip.radius}
+                                : PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0});
+  else CholeskySolveBlocked(n, A, ysol, &s_ok, lds);
   __syncthreads();
+#ifdef RSBA_PROFILE_PHASES
+  if (tid == 0) { g_phase_cycles[9] += clock64() - _k0; }
+#endif
   // 5. camera step, candidate cameras, norms, gradient max over the camera part
   if (tid == 0) { s_norms[0] = 0; s_norms[1] = 0; s_norms[2] = 0; }
   __syncthreads();

@@ -344,11 +344,27 @@ k_schur_finish(int C, int ntiles, const int* __restrict__ tile_ab, const int* __
 #pragma unroll
     for (int q = 3; q < 6; ++q) blk[6 * p + q] = tmp[6 * p + q];
   }
+  // S is written full symmetric: off-diagonal blocks are touched by nobody else (U lives on the diagonal
+  // blocks only), so block (a,b) = -blk and block (b,a) = -blk'.  The diagonal block holds U (upper triangle,
+  // added by k_point_pass): U - blk there, mirrored into the lower triangle.
   double* Sb = red + L.S() + (size_t)(6 * cam_a) * L.nc + 6 * cam_b;
+  if (cam_a != cam_b) {
+    double* St = red + L.S() + (size_t)(6 * cam_b) * L.nc + 6 * cam_a;
 #pragma unroll
-  for (int p = 0; p < 6; ++p) {
+    for (int p = 0; p < 6; ++p) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) Sb[(size_t)p * L.nc + q] -= blk[6 * p + q];
+      for (int q = 0; q < 6; ++q) { Sb[(size_t)p * L.nc + q] = -blk[6 * p + q]; St[(size_t)q * L.nc + p] = -blk[6 * p + q]; }
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+#pragma unroll
+      for (int q = p; q < 6; ++q) {
+        const double v = Sb[(size_t)p * L.nc + q] - blk[6 * p + q];
+        Sb[(size_t)p * L.nc + q] = v;
+        Sb[(size_t)q * L.nc + p] = v;
+      }
+    }
   }
   if (cam_a == cam_b) {
 #pragma unroll

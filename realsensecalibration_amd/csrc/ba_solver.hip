@@ -261,7 +261,7 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->intr, 4 * C)) || (rc = DevAlloc(&s->cam[0], 6 * C)) || (rc = DevAlloc(&s->cam[1], 6 * C)) || (rc = DevAlloc(&s->cam0, 6 * C)) ||
       (rc = DevAlloc(&s->pts[0], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts[1], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts0, 3 * (size_t)P)) ||
       (rc = DevAlloc(&s->camc[0], CC_STRIDE * C)) || (rc = DevAlloc(&s->camc[1], CC_STRIDE * C)) || (rc = DevAlloc(&s->scale_c, 6 * C)) ||
-      (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(s->nc + 1) * s->nc)) ||
+      (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(s->nc + 2) * s->nc)) ||
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
       (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)))
     return rc;
@@ -371,11 +371,19 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     NCCLCHK(ncclAllReduce(s->gmax, s->gmax, 1, ncclDouble, ncclMax, s->comm, st));
   }
 
-  const size_t lds_c = (size_t)std::max(2 * RSBA_TB * (RSBA_NB + 1) + RSBA_NB * (RSBA_NB + 1), 4 * 1024) * sizeof(double);
+  size_t lds_c = (size_t)std::max(2 * RSBA_TB * (RSBA_NB + 1) + RSBA_NB * (RSBA_NB + 1), 4 * 1024) * sizeof(double);
+  if (s->nc <= RSBA_CHOL_MAXN) lds_c = std::max(lds_c, CholeskyLdsDoubles(s->nc) * sizeof(double));
   T.Begin("k_reduced_system_solve", st);
-  k_reduced_system_solve<<<1, 1024, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
-                                                 keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
-                                                 s->camc[c], s->dcam, s->gmax, s->res, ip);
+  if (s->nc <= RSBA_CHOL_MAXN) {
+    if (lds_c > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+    k_reduced_system_solve<512><<<1, 512, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
+                                                      keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
+                                                      s->camc[c], s->dcam, s->gmax, s->res, ip, s->opt.schur_impl != 0 ? 1 : 0);
+  } else {
+    k_reduced_system_solve<1024><<<1, 1024, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
+                                                        keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
+                                                        s->camc[c], s->dcam, s->gmax, s->res, ip, s->opt.schur_impl != 0 ? 1 : 0);
+  }
   T.End(st);
   DebugSync(st, "k_reduced_system_solve");
   T.Begin("k_backsub_candidate", st);
@@ -602,7 +610,12 @@ int rsba_solver_final_costs(const rsba_solver* s, double* cost, double* sum_sq) 
   return RSBA_OK;
 }
 
-void rsba_solver_destroy(rsba_solver* s) { rsba::FreeSolver(s); }
+void rsba_solver_destroy(rsba_solver* s) {
+#ifdef RSBA_PROFILE_PHASES
+  { long long h[16]; if (hipMemcpyFromSymbol(h, HIP_SYMBOL(rsba::g_phase_cycles), sizeof(h)) == hipSuccess) { fprintf(stderr, "rsba[phases]"); for (int i = 0; i < 16; ++i) fprintf(stderr, " %lld", h[i]); fprintf(stderr, "\n"); } }
+#endif
+  rsba::FreeSolver(s);
+}
 
 int rsba_solve(rsba_problem* p, const rsba_options* o, rsba_summary* summary) {
   rsba_solver* s = nullptr;
