@@ -56,6 +56,7 @@ struct TiledSchur {
   int ntiles = 0;
   double* ptdata = nullptr;                 // [P][12]
   double* partial = nullptr;                // [nseg][42][256]
+  double* tile_sum = nullptr;               // [ntiles][42][256]
   double* block_scal = nullptr;
   // robust-loss support: sqrt(rho') per observation in camera-major order
   int* cam_prefix = nullptr;                // [ngroups*16][nwords] set bits of cam_mask before each word
@@ -293,37 +294,45 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
 // K_A3: fixed-order sum of the partials of one pair, K factors, S -= block, corr.
 // One thread per (tile, lane).
 // ------------------------------------------------------------------------------------------------
+// K_A3a: fixed-order sum over the segments of a tile, one workgroup per (tile, component): 42 x ntiles
+// workgroups instead of ntiles, so the partial sums stream at HBM/L2 rate instead of one CU's.
 __global__ void __launch_bounds__(256)
-k_schur_finish(int C, int ntiles, const int* __restrict__ tile_ab, const int* __restrict__ tile_seg_ptr,
-               const double* __restrict__ partial, const double* __restrict__ camc, double* __restrict__ red, RedLayout L) {
+k_schur_reduce(const int* __restrict__ tile_seg_ptr, const double* __restrict__ partial, double* __restrict__ tile_sum /* [ntiles][42][256] */) {
+  const int tile = blockIdx.x / RSBA_PART, k = blockIdx.x - tile * RSBA_PART, tid = threadIdx.x;
+  double s = 0.0;
+  for (int sgi = tile_seg_ptr[tile]; sgi < tile_seg_ptr[tile + 1]; ++sgi) s += partial[((size_t)sgi * RSBA_PART + k) * 256 + tid];
+  tile_sum[((size_t)tile * RSBA_PART + k) * 256 + tid] = s;
+}
+
+// K_A3b: K factors, S blocks (full symmetric), corr.  One thread per pair; self tiles first add their 16 lane
+// slices with a shuffle reduction inside each 16-lane row.
+__global__ void __launch_bounds__(256)
+k_schur_finish(int C, int ntiles, const int* __restrict__ tile_ab, const double* __restrict__ tile_sum,
+               const double* __restrict__ camc, double* __restrict__ red, RedLayout L) {
   const int tile = blockIdx.x, tid = threadIdx.x;
   if (tile >= ntiles) return;
   const int ga = tile_ab[3 * tile], gb = tile_ab[3 * tile + 1];
   const bool self_tile = tile_ab[3 * tile + 2] != 0;
-  // pair tiles: one thread per pair.  self tiles: threads 0..15, one per camera, each adds its 16 lane slices.
-  const int ia = self_tile ? tid : tid >> 4, ib = self_tile ? 0 : tid & 15;
-  if (self_tile && tid >= RSBA_TG) return;
+  const int ia = tid >> 4, ib = tid & 15;
   const int cam_a = RSBA_TG * ga + ia, cam_b = self_tile ? cam_a : RSBA_TG * gb + ib;
-  if (cam_a >= C || cam_b >= C || (!self_tile && ga == gb && ia >= ib)) return;
+  const double* in = tile_sum + (size_t)tile * RSBA_PART * 256;
   double core[36], cr[6];
 #pragma unroll
-  for (int i = 0; i < 36; ++i) core[i] = 0.0;
+  for (int i = 0; i < 36; ++i) core[i] = in[i * 256 + tid];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) cr[i] = 0.0;
-  for (int sgi = tile_seg_ptr[tile]; sgi < tile_seg_ptr[tile + 1]; ++sgi) {
-    const double* in = partial + (size_t)sgi * RSBA_PART * 256;
-    if (!self_tile) {
+  for (int i = 0; i < 6; ++i) cr[i] = in[(36 + i) * 256 + tid];
+  if (self_tile) {
+    // sum the 16 slices of a row (lanes ia*16 .. ia*16+15 are contiguous inside a wave); fixed tree order
 #pragma unroll
-      for (int i = 0; i < 36; ++i) core[i] += in[i * 256 + tid];
-    } else {
-      for (int sl = 0; sl < 16; ++sl) {
+    for (int off = 8; off > 0; off >>= 1) {
 #pragma unroll
-        for (int i = 0; i < 36; ++i) core[i] += in[i * 256 + 16 * ia + sl];
+      for (int i = 0; i < 36; ++i) core[i] += __shfl_down(core[i], off, 16);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) cr[i] += in[(36 + i) * 256 + 16 * ia + sl];
-      }
+      for (int i = 0; i < 6; ++i) cr[i] += __shfl_down(cr[i], off, 16);
     }
+    if (ib != 0) return;
   }
+  if (cam_a >= C || cam_b >= C || (!self_tile && ga == gb && ia >= ib)) return;
   const double* Ka = camc + (size_t)cam_a * CC_STRIDE + CC_K;
   const double* Kb = camc + (size_t)cam_b * CC_STRIDE + CC_K;
   // rows: Ta' core  (first three rows mixed by Ka')

@@ -163,7 +163,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   ntiles = (int)wt.size();
   int cus = 256;
   { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
-  const int target = (getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : 2) * cus;
+  const int target = (getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : 8) * cus;
   double wsum = 0; for (double w : wt) wsum += w;
   std::vector<SchurSeg> sg; std::vector<int> tsp(ntiles + 1, 0);
   for (int t = 0; t < ntiles; ++t) {
@@ -182,7 +182,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   int rc;
   if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nseg)) || (rc = DevAlloc(&tile_seg_ptr, (size_t)ntiles + 1)) ||
       (rc = DevAlloc(&tile_ab, (size_t)3 * ntiles)) || (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
-      (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
+      (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, cmpos.size())) ||
       (rc = DevAlloc(&sq_cm, cmpos.size())))
     return rc;
@@ -197,7 +197,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, tile_seg_ptr, tile_ab, ptdata, partial, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm};
+  void* ptrs[] = {cam_mask, segs, tile_seg_ptr, tile_ab, ptdata, partial, tile_sum, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   cam_mask = nullptr;
 }
@@ -323,8 +323,11 @@ int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
   else
     k_schur_pairs<false><<<nseg, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial);
   T.End(st);
+  T.Begin("k_schur_reduce", st);
+  k_schur_reduce<<<ntiles * RSBA_PART, 256, 0, st>>>(tile_seg_ptr, partial, tile_sum);
+  T.End(st);
   T.Begin("k_schur_finish", st);
-  k_schur_finish<<<ntiles, 256, 0, st>>>(C, ntiles, tile_ab, tile_seg_ptr, partial, s->camc[x], s->red, s->L);
+  k_schur_finish<<<ntiles, 256, 0, st>>>(C, ntiles, tile_ab, tile_sum, s->camc[x], s->red, s->L);
   T.End(st);
   return RSBA_OK;
 }
