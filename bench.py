@@ -70,6 +70,7 @@ def main():
     if world > 1:
         dist.barrier()
     from realsensecalibration_amd import capi
+    from realsensecalibration_amd import distributed as rd
     from realsensecalibration_amd import synthetic as syn
 
     # ---- workload: this rank's shard
@@ -77,16 +78,14 @@ def main():
     P_rank = args.points or P_cfg
     P_total = P_rank * world
     t0 = time.time()
-    prob = syn.make_problem(C, P_total, k, seed, point_range=(rank * P_rank, (rank + 1) * P_rank), outlier_frac=outl)
+    prob = syn.make_problem(C, P_total, k, seed, point_range=rd.shard_range(P_total, rank, world), outlier_frac=outl)
     prob["huber_delta"] = huber
     gen_s = time.time() - t0
     N_rank, N_total = prob["N"], prob["N"] * world
 
     uid = None
     if world > 1:
-        box = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = ctypes.create_string_buffer(box[0], 128)
+        uid = rd.broadcast_unique_id(dist, capi, rank)
 
     def options(**kw):
         o = capi.default_options(device=local_rank, huber_delta=huber, rank=rank, world_size=world, **kw)

@@ -208,3 +208,23 @@ def test_test2_fixture_on_gpu(oracle):
     assert np.abs(p.params[6:9] - xml["R1"].ravel()).max() < 1e-9
     assert np.abs(p.params[9:12] - xml["t1"].ravel()).max() < 1e-9
     p.close()
+
+
+def test_cpp_bamanager_mirror_end_to_end(tmp_path):
+    """examples/main_calibration.cpp: the reference's BAManager sequence (ctor -> StartBA -> Write) through the
+    C++ mirror headers, compiled with g++ against librsba.so, on the committed hongo input."""
+    import subprocess
+    exe = str(tmp_path / "main_calibration")
+    lib = os.path.join(ol.ROOT, "realsensecalibration_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ol.ROOT, "include"), os.path.join(ol.ROOT, "examples", "main_calibration.cpp"),
+                           "-L" + lib, "-lrsba", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe, G, str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "Termination: CONVERGENCE" in out.stdout and "Iterations: 7 (successful 6, unsuccessful 0)" in out.stdout
+    got, want = ol.read_opencv_xml(str(tmp_path / "Camera_Transform.xml")), ol.read_opencv_xml(os.path.join(G, "hongo", "Camera_Transform.xml"))
+    for k in want:
+        assert np.abs(got[k] - want[k]).max() < 1e-9
+    for i in range(4):
+        assert np.abs(np.loadtxt(str(tmp_path / ("mat%d.txt" % i))) - np.loadtxt(os.path.join(G, "extrinsics", "mat%d.txt" % i))).max() < 2e-6
+    rms = float(out.stdout.split("Average Reprojection Error per One Coordinate:")[1].split()[0])
+    assert abs(rms - 0.726669955) < 1e-6
