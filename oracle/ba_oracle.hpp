@@ -556,29 +556,22 @@ class PointSchurModel {
     *cost = 0.5 * total;
     if (with_jacobian) {
       std::fill(g_.begin(), g_.end(), 0.0);
-      for (int64_t i = 0; i < p_.N; ++i) {
-        const int c = p_.camera_idx[i], j = p_.point_idx[i];
-        for (int r = 0; r < 2; ++r) {
-          const double rr = r_[2 * i + r];
-          for (int k = 0; k < 6; ++k) g_[6 * c + k] += Jc_[12 * i + 6 * r + k] * rr;
-          for (int k = 0; k < 3; ++k) g_[6 * p_.C + 3 * j + k] += Jp_[6 * i + 3 * r + k] * rr;
-        }
-      }
+      AccumulateColumns(g_.data(), [&](int64_t i, int r, int k, bool cam) {
+        return (cam ? Jc_[12 * i + 6 * r + k] : Jp_[6 * i + 3 * r + k]) * r_[2 * i + r];
+      });
     }
     return true;
   }
   const double* gradient() const { return g_.data(); }
   void SquaredColumnNorm(double* out) const {
     std::fill(out, out + n_, 0.0);
-    for (int64_t i = 0; i < p_.N; ++i) {
-      const int c = p_.camera_idx[i], j = p_.point_idx[i];
-      for (int r = 0; r < 2; ++r) {
-        for (int k = 0; k < 6; ++k) { const double v = Jc_[12 * i + 6 * r + k]; out[6 * c + k] += v * v; }
-        for (int k = 0; k < 3; ++k) { const double v = Jp_[6 * i + 3 * r + k]; out[6 * p_.C + 3 * j + k] += v * v; }
-      }
-    }
+    AccumulateColumns(out, [&](int64_t i, int r, int k, bool cam) {
+      const double v = cam ? Jc_[12 * i + 6 * r + k] : Jp_[6 * i + 3 * r + k];
+      return v * v;
+    });
   }
   void ScaleColumns(const double* s) {
+#pragma omp parallel for schedule(static) num_threads(opt_.num_threads)
     for (int64_t i = 0; i < p_.N; ++i) {
       const int c = p_.camera_idx[i], j = p_.point_idx[i];
       for (int r = 0; r < 2; ++r) {
@@ -586,6 +579,38 @@ class PointSchurModel {
         for (int k = 0; k < 3; ++k) Jp_[6 * i + 3 * r + k] *= s[6 * p_.C + 3 * j + k];
       }
     }
+  }
+  // out[column] += sum over observations of f(obs, residual row, local column, is_camera_block); the point part is
+  // walked point by point (no write conflicts), the camera part through per-thread accumulators.
+  template <typename F>
+  void AccumulateColumns(double* out, F f) const {
+    const int nc = 6 * p_.C;
+    const int nt = std::max(1, opt_.num_threads);
+    std::vector<std::vector<double>> cl(nt);
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+      const int tid = omp_get_thread_num();
+#else
+      const int tid = 0;
+#endif
+      std::vector<double>& c = cl[tid];
+      c.assign(nc, 0.0);
+#pragma omp for schedule(static)
+      for (int j = 0; j < p_.P; ++j) {
+        double a[3] = {0, 0, 0};
+        for (int64_t q = pt_ptr_[j]; q < pt_ptr_[j + 1]; ++q) {
+          const int64_t i = pt_obs_[q];
+          const int cam = p_.camera_idx[i];
+          for (int r = 0; r < 2; ++r) {
+            for (int k = 0; k < 6; ++k) c[6 * cam + k] += f(i, r, k, true);
+            for (int k = 0; k < 3; ++k) a[k] += f(i, r, k, false);
+          }
+        }
+        for (int k = 0; k < 3; ++k) out[nc + 3 * j + k] += a[k];
+      }
+    }
+    for (int t = 0; t < nt; ++t) if (!cl[t].empty()) for (int k = 0; k < nc; ++k) out[k] += cl[t][k];
   }
   // Reduced system only (exposed so tests can compare the HIP Schur kernels stage by stage).
   // S is (6C)^2 row-major, full symmetric; rhs is 6C.
@@ -648,8 +673,10 @@ class PointSchurModel {
         }
       }
     }
-    std::fill(S, S + (size_t)nc * nc, 0.0); std::fill(rhs, rhs + nc, 0.0);
-    for (int t = 0; t < nt; ++t) { if (Sl[t].empty()) continue; for (size_t q = 0; q < (size_t)nc * nc; ++q) S[q] += Sl[t][q]; for (int q = 0; q < nc; ++q) rhs[q] += rl[t][q]; }
+    std::fill(rhs, rhs + nc, 0.0);
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int64_t q = 0; q < (int64_t)nc * nc; ++q) { double a = 0; for (int t = 0; t < nt; ++t) if (!Sl[t].empty()) a += Sl[t][q]; S[q] = a; }
+    for (int t = 0; t < nt; ++t) { if (rl[t].empty()) continue; for (int q = 0; q < nc; ++q) rhs[q] += rl[t][q]; }
     for (int q = 0; q < nc; ++q) S[(size_t)q * nc + q] += D[q] * D[q];
     if (ete_inv_out) ete_inv_out->swap(ete_inv);
   }
