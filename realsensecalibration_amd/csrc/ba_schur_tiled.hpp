@@ -48,7 +48,7 @@ class KernelTimer;
 struct SchurSeg { int ga, gb, chunk_begin, chunk_end, self, pad0, pad1, pad2; };
 
 struct TiledSchur {
-  int C = 0, P = 0, ngroups = 0, nwords = 0, nchunks = 0, nseg = 0, grid_pp = 0;
+  int C = 0, P = 0, ngroups = 0, nwords = 0, nchunks = 0, nseg = 0, nseg_pair = 0, grid_pp = 0;
   unsigned long long* cam_mask = nullptr;   // [ngroups*16][nwords]
   SchurSeg* segs = nullptr;                 // [nseg]
   int* tile_seg_ptr = nullptr;              // [ntiles+1] segments of a tile are contiguous
@@ -200,34 +200,61 @@ __device__ __forceinline__ void SideRows(const SideConst& s, const double X[3], 
   n1[0] = be * s.R[3] + de * s.R[6]; n1[1] = be * s.R[4] + de * s.R[7]; n1[2] = be * s.R[5] + de * s.R[8];
 }
 
+// Camera constants the pair kernel keeps in LDS: R(9) t(3) fx fy small + pad = 16 doubles per camera.
+#define RSBA_SC_STRIDE 16
+
+struct SideLds {
+  const double* c;  // LDS pointer to this side's 16 doubles
+  __device__ __forceinline__ double R(int i) const { return c[i]; }
+};
+
+// Reduced Jacobian rows from LDS-resident camera constants (same arithmetic as SideRows).
+__device__ __forceinline__ void SideRowsLds(const double* __restrict__ c, const double X[3], double sq, double e0[6], double e1[6],
+                                            double n0[3], double n1[3]) {
+  const double r0 = c[0], r1 = c[1], r2 = c[2], r3 = c[3], r4 = c[4], r5 = c[5], r6 = c[6], r7 = c[7], r8 = c[8];
+  const double q0 = r0 * X[0] + r1 * X[1] + r2 * X[2];
+  const double q1 = r3 * X[0] + r4 * X[1] + r5 * X[2];
+  const double q2 = r6 * X[0] + r7 * X[1] + r8 * X[2];
+  const double p0 = q0 + c[9], p1 = q1 + c[10], p2 = q2 + c[11];
+  const double iz = 1.0 / p2;
+  const double al = c[12] * iz * sq, be = c[13] * iz * sq;
+  const double ga = -al * p0 * iz, de = -be * p1 * iz;
+  const bool small = c[14] != 0.0;
+  const double w0 = small ? X[0] : q0, w1 = small ? X[1] : q1, w2 = small ? X[2] : q2;
+  e0[0] = w1 * ga; e0[1] = w2 * al - w0 * ga; e0[2] = -w1 * al; e0[3] = al; e0[4] = 0.0; e0[5] = ga;
+  e1[0] = w1 * de - w2 * be; e1[1] = -w0 * de; e1[2] = w0 * be; e1[3] = 0.0; e1[4] = be; e1[5] = de;
+  n0[0] = al * r0 + ga * r6; n0[1] = al * r1 + ga * r7; n0[2] = al * r2 + ga * r8;
+  n1[0] = be * r3 + de * r6; n1[1] = be * r4 + de * r7; n1[2] = be * r5 + de * r8;
+}
+
+// Pair tiles (ga <= gb, a != b).  Two workgroups per CU: the accumulators (72 VGPRs) are the only long-lived
+// per-lane state; camera constants sit in LDS (broadcast within a 16-lane row / replicated across rows).
 template <bool kLoss>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, 2)
 k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const SchurSeg* __restrict__ segs,
               const unsigned long long* __restrict__ cam_mask, const double* __restrict__ ptdata,
               const int* __restrict__ cam_prefix, const int* __restrict__ cam_ptr, const double* __restrict__ sq_cm,
               double* __restrict__ partial) {
   __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];            // 48 KB
   __shared__ unsigned long long mk[2 * RSBA_TG][RSBA_CW];       // 2 KB
+  __shared__ double sc[2 * RSBA_TG * RSBA_SC_STRIDE];           // 4 KB
   const SchurSeg sg = segs[blockIdx.x];
   const int tid = threadIdx.x, ia = tid >> 4, ib = tid & 15;
-  // Three kinds of tile:
-  //   off-diagonal (ga < gb): thread (ia, ib) owns pair (16 ga + ia, 16 gb + ib)
-  //   diagonal     (ga == gb, self == 0): pairs ia < ib only
-  //   self         (self == 1): the (a, a) blocks.  Camera a sees ~3x the points a pair shares, so its points
-  //                are dealt to 16 lanes: lane (ia, s) takes the bits {s, s+16, s+32, s+48} of every mask word.
-  const bool self_tile = sg.self != 0;
-  const int cam_a = RSBA_TG * sg.ga + ia, cam_b = self_tile ? cam_a : RSBA_TG * sg.gb + ib;
-  const bool live = cam_a < C && cam_b < C && (self_tile || sg.ga != sg.gb || ia < ib);
-  const unsigned long long lane_bits = self_tile ? (0x0001000100010001ull << ib) : ~0ull;
-  const int rowb = self_tile ? ia : RSBA_TG + ib;
-  SideConst A, B;
-  LoadSide(camc + (size_t)(cam_a < C ? cam_a : 0) * CC_STRIDE, A);
-  LoadSide(camc + (size_t)(cam_b < C ? cam_b : 0) * CC_STRIDE, B);
-  double acc[36], corr[6];
+  const int cam_a = RSBA_TG * sg.ga + ia, cam_b = RSBA_TG * sg.gb + ib;
+  const bool live = cam_a < C && cam_b < C && (sg.ga != sg.gb || ia < ib);
+  for (int i = tid; i < 2 * RSBA_TG * RSBA_SC_STRIDE; i += 256) {
+    const int row = i / RSBA_SC_STRIDE, e = i - row * RSBA_SC_STRIDE;
+    const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
+    const double* cc = camc + (size_t)(cam < C ? cam : 0) * CC_STRIDE;
+    double v = 0.0;
+    if (e < 9) v = cc[CC_R + e]; else if (e < 12) v = cc[CC_T + e - 9]; else if (e == 12) v = cc[CC_FX]; else if (e == 13) v = cc[CC_FY]; else if (e == 14) v = cc[CC_SMALL];
+    sc[i] = v;
+  }
+  const double* ca = sc + ia * RSBA_SC_STRIDE;
+  const double* cb = sc + (RSBA_TG + ib) * RSBA_SC_STRIDE;
+  double acc[36];
 #pragma unroll
   for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) corr[i] = 0.0;
 
   for (int ch = sg.chunk_begin; ch < sg.chunk_end; ++ch) {
     const int j0 = ch * RSBA_CHUNK;
@@ -243,10 +270,10 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
     // every lane walks ITS OWN hit list through the whole chunk: the word index is per lane, so a wave
     // runs max-over-lanes(hits in 512 points) trips, not the sum over words of the per-word maxima
     int w = live ? 0 : RSBA_CW;
-    unsigned long long h = live ? (mk[ia][0] & mk[rowb][0] & lane_bits) : 0ull;
+    unsigned long long h = live ? (mk[ia][0] & mk[RSBA_TG + ib][0]) : 0ull;
 #pragma unroll 1
     for (;;) {
-      while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & mk[rowb][w] & lane_bits; }
+      while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & mk[RSBA_TG + ib][w]; }
       if (h == 0ull) break;
       const int bit = __ffsll((long long)h) - 1;
       h &= h - 1;
@@ -259,14 +286,15 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
         const unsigned long long below = (1ull << bit) - 1ull;
         const int gw = ch * RSBA_CW + w;
         sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + gw] + __popcll(mk[ia][w] & below)];
-        sqb = self_tile ? sqa : sq_cm[cam_ptr[cam_b] + cam_prefix[(size_t)cam_b * nwords + gw] + __popcll(mk[rowb][w] & below)];
+        sqb = sq_cm[cam_ptr[cam_b] + cam_prefix[(size_t)cam_b * nwords + gw] + __popcll(mk[RSBA_TG + ib][w] & below)];
       }
-      double ea0[6], ea1[6], na0[3], na1[3], eb0[6], eb1[6], nb0[3], nb1[3];
-      SideRows(A, X, sqa, ea0, ea1, na0, na1);
-      SideRows(B, X, sqb, eb0, eb1, nb0, nb1);
-      // M = Na Vinv Nb'  (2x2)
+      double ea0[6], ea1[6], na0[3], na1[3];
+      SideRowsLds(ca, X, sqa, ea0, ea1, na0, na1);
+      // t = Na Vinv (2x3), then the b side, M = t Nb' (2x2), Z = Ea' M (6x2)
       const double t00 = na0[0] * v0 + na0[1] * v1 + na0[2] * v2, t01 = na0[0] * v1 + na0[1] * v3 + na0[2] * v4, t02 = na0[0] * v2 + na0[1] * v4 + na0[2] * v5;
       const double t10 = na1[0] * v0 + na1[1] * v1 + na1[2] * v2, t11 = na1[0] * v1 + na1[1] * v3 + na1[2] * v4, t12 = na1[0] * v2 + na1[1] * v4 + na1[2] * v5;
+      double eb0[6], eb1[6], nb0[3], nb1[3];
+      SideRowsLds(cb, X, sqb, eb0, eb1, nb0, nb1);
       const double m00 = t00 * nb0[0] + t01 * nb0[1] + t02 * nb0[2], m01 = t00 * nb1[0] + t01 * nb1[1] + t02 * nb1[2];
       const double m10 = t10 * nb0[0] + t11 * nb0[1] + t12 * nb0[2], m11 = t10 * nb1[0] + t11 * nb1[1] + t12 * nb1[2];
 #pragma unroll
@@ -275,25 +303,89 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
 #pragma unroll
         for (int q = 0; q < 6; ++q) acc[6 * p + q] += z0 * eb0[q] + z1 * eb1[q];
       }
-      if (self_tile) {
-        const double f0 = na0[0] * pd[9] + na0[1] * pd[10] + na0[2] * pd[11];
-        const double f1 = na1[0] * pd[9] + na1[1] * pd[10] + na1[2] * pd[11];
-#pragma unroll
-        for (int p = 0; p < 6; ++p) corr[p] += ea0[p] * f0 + ea1[p] * f1;
-      }
     }
   }
   double* out = partial + (size_t)blockIdx.x * RSBA_PART * 256;
 #pragma unroll
   for (int i = 0; i < 36; ++i) out[i * 256 + tid] = acc[i];
 #pragma unroll
+  for (int i = 0; i < 6; ++i) out[(36 + i) * 256 + tid] = 0.0;
+}
+
+// Self tiles: the (a, a) blocks and the rhs correction.  Camera a sees ~3x the points a pair shares, so its points are
+// dealt to 16 lanes: lane (ia, s) takes the bits {s, s+16, s+32, s+48} of every mask word.
+template <bool kLoss>
+__global__ void __launch_bounds__(256, 2)
+k_schur_self(int C, int P, int nwords, const double* __restrict__ camc, const SchurSeg* __restrict__ segs,
+             const unsigned long long* __restrict__ cam_mask, const double* __restrict__ ptdata,
+             const int* __restrict__ cam_prefix, const int* __restrict__ cam_ptr, const double* __restrict__ sq_cm,
+             double* __restrict__ partial, int seg0) {
+  __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];
+  __shared__ unsigned long long mk[RSBA_TG][RSBA_CW];
+  const SchurSeg sg = segs[seg0 + blockIdx.x];
+  const int tid = threadIdx.x, ia = tid >> 4, ib = tid & 15;
+  const int cam_a = RSBA_TG * sg.ga + ia;
+  const bool live = cam_a < C;
+  const unsigned long long lane_bits = 0x0001000100010001ull << ib;
+  SideConst A;
+  LoadSide(camc + (size_t)(live ? cam_a : 0) * CC_STRIDE, A);
+  double acc[36], corr[6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) corr[i] = 0.0;
+  for (int ch = sg.chunk_begin; ch < sg.chunk_end; ++ch) {
+    const int j0 = ch * RSBA_CHUNK;
+    const int np = min(RSBA_CHUNK, P - j0);
+    __syncthreads();
+    for (int i = tid; i < np * RSBA_PT_STRIDE; i += 256) pt[i] = ptdata[(size_t)j0 * RSBA_PT_STRIDE + i];
+    if (tid < RSBA_TG * RSBA_CW) {
+      const int row = tid >> 3, w = tid & 7;
+      const int cam = RSBA_TG * sg.ga + row;
+      mk[row][w] = cam < C ? cam_mask[(size_t)cam * nwords + (size_t)ch * RSBA_CW + w] : 0ull;
+    }
+    __syncthreads();
+    int w = live ? 0 : RSBA_CW;
+    unsigned long long h = live ? (mk[ia][0] & lane_bits) : 0ull;
+#pragma unroll 1
+    for (;;) {
+      while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & lane_bits; }
+      if (h == 0ull) break;
+      const int bit = __ffsll((long long)h) - 1;
+      h &= h - 1;
+      const double* pd = pt + (size_t)(w * 64 + bit) * RSBA_PT_STRIDE;
+      const double X[3] = {pd[0], pd[1], pd[2]};
+      const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
+      double sqa = 1.0;
+      if (kLoss) {
+        const unsigned long long below = (1ull << bit) - 1ull;
+        sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + ch * RSBA_CW + w] + __popcll(mk[ia][w] & below)];
+      }
+      double e0[6], e1[6], n0[3], n1[3];
+      SideRows(A, X, sqa, e0, e1, n0, n1);
+      const double t00 = n0[0] * v0 + n0[1] * v1 + n0[2] * v2, t01 = n0[0] * v1 + n0[1] * v3 + n0[2] * v4, t02 = n0[0] * v2 + n0[1] * v4 + n0[2] * v5;
+      const double t10 = n1[0] * v0 + n1[1] * v1 + n1[2] * v2, t11 = n1[0] * v1 + n1[1] * v3 + n1[2] * v4, t12 = n1[0] * v2 + n1[1] * v4 + n1[2] * v5;
+      const double m00 = t00 * n0[0] + t01 * n0[1] + t02 * n0[2], m01 = t00 * n1[0] + t01 * n1[1] + t02 * n1[2];
+      const double m10 = t10 * n0[0] + t11 * n0[1] + t12 * n0[2], m11 = t10 * n1[0] + t11 * n1[1] + t12 * n1[2];
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const double z0 = e0[p] * m00 + e1[p] * m10, z1 = e0[p] * m01 + e1[p] * m11;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[6 * p + q] += z0 * e0[q] + z1 * e1[q];
+      }
+      const double f0 = n0[0] * pd[9] + n0[1] * pd[10] + n0[2] * pd[11];
+      const double f1 = n1[0] * pd[9] + n1[1] * pd[10] + n1[2] * pd[11];
+#pragma unroll
+      for (int p = 0; p < 6; ++p) corr[p] += e0[p] * f0 + e1[p] * f1;
+    }
+  }
+  double* out = partial + (size_t)(seg0 + blockIdx.x) * RSBA_PART * 256;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) out[i * 256 + tid] = acc[i];
+#pragma unroll
   for (int i = 0; i < 6; ++i) out[(36 + i) * 256 + tid] = corr[i];
 }
 
-// ------------------------------------------------------------------------------------------------
-// K_A3: fixed-order sum of the partials of one pair, K factors, S -= block, corr.
-// One thread per (tile, lane).
-// ------------------------------------------------------------------------------------------------
 // K_A3a: fixed-order sum over the segments of a tile, one workgroup per (tile, component): 42 x ntiles
 // workgroups instead of ntiles, so the partial sums stream at HBM/L2 rate instead of one CU's.
 __global__ void __launch_bounds__(256)

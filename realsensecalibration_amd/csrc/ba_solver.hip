@@ -164,10 +164,13 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   int cus = 256;
   { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
   const int target = (getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : 8) * cus;
-  double wsum = 0; for (double w : wt) wsum += w;
+  // pair tiles share `target` workgroups; the self tiles (their own, much lighter launch) get 2 per CU in total
+  int npair_tiles = 0;
+  for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) ++npair_tiles;
   std::vector<SchurSeg> sg; std::vector<int> tsp(ntiles + 1, 0);
   for (int t = 0; t < ntiles; ++t) {
-    int ns = (int)std::lround(target * wt[t] / wsum);
+    const bool self = tab[3 * t + 2] != 0;
+    int ns = self ? (2 * cus + ngroups - 1) / ngroups : (int)std::lround((double)target / std::max(1, npair_tiles));
     ns = std::max(1, std::min(ns, nchunks));
     for (int i = 0; i < ns; ++i) {
       SchurSeg e; memset(&e, 0, sizeof(e));
@@ -178,6 +181,8 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     tsp[t + 1] = (int)sg.size();
   }
   nseg = (int)sg.size();
+  nseg_pair = 0;
+  for (const SchurSeg& e : sg) if (!e.self) ++nseg_pair;  // pair tiles come first, self tiles last
   grid_pp = std::max(1, std::min((P + 255) / 256, 2048));
   int rc;
   if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nseg)) || (rc = DevAlloc(&tile_seg_ptr, (size_t)ntiles + 1)) ||
@@ -318,10 +323,18 @@ int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
   k_finish_linearize<<<1, 256, 0, st>>>(grid_pp, block_scal, s->red, s->L, s->gmax);
   T.End(st);
   T.Begin("k_schur_pairs", st);
+  if (nseg_pair > 0) {
+    if (ip.huber_delta > 0.0)
+      k_schur_pairs<true><<<nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial);
+    else
+      k_schur_pairs<false><<<nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial);
+  }
+  T.End(st);
+  T.Begin("k_schur_self", st);
   if (ip.huber_delta > 0.0)
-    k_schur_pairs<true><<<nseg, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial);
+    k_schur_self<true><<<nseg - nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial, nseg_pair);
   else
-    k_schur_pairs<false><<<nseg, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial);
+    k_schur_self<false><<<nseg - nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial, nseg_pair);
   T.End(st);
   T.Begin("k_schur_reduce", st);
   k_schur_reduce<<<ntiles * RSBA_PART, 256, 0, st>>>(tile_seg_ptr, partial, tile_sum);
