@@ -49,7 +49,7 @@ __device__ __forceinline__ double ReadLaneD(double v, int lane) {
 
 // LDS doubles: (n+2) x 33 shared by the panel and the B strip, a 32 x 33 tile for T, 32 inverse pivots, scratch.
 __host__ __device__ inline size_t CholeskyLdsDoubles(int n) {
-  const size_t fact = (size_t)(n + 2) * RSBA_PLD + 2 * RSBA_PB * RSBA_PLD + RSBA_PB + 64;
+  const size_t fact = (size_t)(n + 2) * RSBA_PLD + 2 * RSBA_PB * RSBA_PLD + RSBA_PB + 64 + (size_t)n;
   const size_t back = (size_t)((n + 63) & ~63) + 3 * RSBA_PB * RSBA_PLD + 64;
   return fact > back ? fact : back;
 }
@@ -72,8 +72,10 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
   double* Lt = T + RSBA_PB * RSBA_PLD;                 // 32 x 33: padded L11
   double* invd = Lt + RSBA_PB * RSBA_PLD;              // 32
   double* colb = invd + RSBA_PB;                       // 32 (+32 spare)
+  double* scl = colb + 64;                             // n: LDS copy of the column scale (fused source only)
   __shared__ int s_ok;
   if (tid == 0) s_ok = 1;
+  if (src.S != nullptr) for (int i = tid; i < n; i += nt) scl[i] = src.scale[i];
   __syncthreads();
   RSBA_STAMP_INIT;
 
@@ -84,15 +86,15 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     double* Bst = lds;
     double* Pan = lds + (size_t)kb * RSBA_PLD;
     // 1. load the panel (scaled / damped on the fly) and the B strip
-#pragma unroll 4
+#pragma unroll 8
     for (int e = tid; e < R * RSBA_PB; e += nt) {
       const int r = e >> 5, c = e & 31;
       double v = 0.0;
       if (c < nb) {
         const int gi = kb + r, gj = kb + c;
         if (src.S != nullptr && gi < n) {
-          const double si = src.scale[gi];
-          v = src.S[(size_t)gi * n + gj] * (si * src.scale[gj]);
+          const double si = scl[gi];
+          v = src.S[(size_t)gi * n + gj] * (si * scl[gj]);
           if (gi == gj) v += fmin(fmax(si * si * src.diagU[gi], src.lo), src.hi) * src.inv_radius;
         } else {
           v = A[(size_t)gi * n + gj];
@@ -100,7 +102,7 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
       }
       Pan[r * RSBA_PLD + c] = v;
     }
-#pragma unroll 4
+#pragma unroll 8
     for (int e = tid; e < kb * RSBA_PB; e += nt) {
       // coalesced along q (row kb+c of L), transposed into Bst[q][c]
       const int c = e / kb, q = e - c * kb;
@@ -109,24 +111,30 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     __syncthreads();
     RSBA_STAMP(0);
     // 2. update with previous panels (MFMA), one wave per 16-row block, no barriers inside
+    // Wave 0 takes the two row blocks of the diagonal block and goes straight on to factor it (step 3) while
+    // the other waves update the rows below: the serial factorisation hides behind the GEMM of the rest.
     if (kb > 0) {
       const int nrb = (R + 15) >> 4;
       const int i = lane & 15, kk = lane >> 4;
-      for (int rb = wave; rb < nrb; rb += nwave) {
+      const int rb_first = wave == 0 ? 0 : 2 + (wave - 1), rb_step = wave == 0 ? 1 : nwave - 1, rb_end = wave == 0 ? min(2, nrb) : nrb;
+      for (int rb = rb_first; rb < rb_end; rb += rb_step) {
         const int prow = rb * 16 + i;  // panel-relative row of this lane's A operand
         const bool rok = prow < R;
         const double* arow = A + (size_t)(kb + (rok ? prow : 0)) * n + kk;
         d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-        double an[8];
+        // rows of the diagonal block ARE the B strip (L[kb+c][q] = Bst[q][c]): wave 0 needs no global loads
+        const bool from_lds = (wave == 0) && (prow < nb);  // rows nb..R-1 of a partial panel (the rhs row) are not in the strip
+        const bool gl = rok && !from_lds;
+        double an[8], an2[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) an[u] = rok ? arow[4 * u] : 0.0;
+        for (int u = 0; u < 8; ++u) { an[u] = gl ? arow[4 * u] : 0.0; an2[u] = (gl && RSBA_PB < kb) ? arow[RSBA_PB + 4 * u] : 0.0; }
         for (int q0 = 0; q0 < kb; q0 += RSBA_PB) {
           double ac[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) ac[u] = an[u];
-          if (q0 + RSBA_PB < kb) {
+          for (int u = 0; u < 8; ++u) { ac[u] = from_lds ? Bst[(q0 + 4 * u + kk) * RSBA_PLD + prow] : an[u]; an[u] = an2[u]; }
+          if (q0 + 2 * RSBA_PB < kb) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) an[u] = rok ? arow[q0 + RSBA_PB + 4 * u] : 0.0;
+            for (int u = 0; u < 8; ++u) an2[u] = gl ? arow[q0 + 2 * RSBA_PB + 4 * u] : 0.0;
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
@@ -147,18 +155,21 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
         }
       }
     }
-    __syncthreads();
-    RSBA_STAMP(1);
+    // (no barrier here: wave 0 wrote the diagonal block's rows itself)
     // 3. diagonal block + its inverse, wave 0.  Rows/columns >= nb are padded with identity so that all 32
     //    steps run unconditionally; lanes 32..63 shadow lanes 0..31 (same values, same addresses), so the
     //    whole sequence is one branch-free basic block.  The empty asm statements pin every updated value at
     //    its step: without them LLVM sinks the updates towards their uses and spills ~1300 registers.
     if (wave == 0) {
+#ifdef RSBA_PROFILE_PHASES
+      long long _w0 = clock64();
+#endif
       double row[RSBA_PB];
       const int lr = lane & 31;
 #pragma unroll
       for (int c = 0; c < RSBA_PB; ++c) row[c] = (lr < nb) ? Pan[lr * RSBA_PLD + c] : (c == lr ? 1.0 : 0.0);
       bool good = true;
+      double ilv = 1.0;  // 1 / L[lr][lr]
 #pragma unroll
       for (int j = 0; j < RSBA_PB; ++j) {
         const double d = ReadLaneD(row[j], j);
@@ -170,13 +181,12 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
         il = il * (1.5 - 0.5 * dd * il * il);
         const double lij = (lr == j) ? dd * il : row[j] * il;
         row[j] = lij;
-        colb[lr] = lij;
+        if (lr == j) ilv = il;
         invd[j] = il;  // wave-uniform value
-        __builtin_amdgcn_wave_barrier();
-        // a_ic -= l_ij l_cj.  Entries above the diagonal (c > row) pick up garbage; they are never read.
+        // a_ic -= l_ij l_cj with l_cj read straight out of lane c's register (v_readlane -> SGPR operand): no LDS
+        // round trip on the critical path.  Entries above the diagonal (c > row) pick up garbage; never read.
 #pragma unroll
-        for (int c = j + 1; c < RSBA_PB; ++c) { row[c] -= lij * colb[c]; asm volatile("" : "+v"(row[c])); }
-        __builtin_amdgcn_wave_barrier();
+        for (int c = j + 1; c < RSBA_PB; ++c) { row[c] -= lij * ReadLaneD(lij, c); asm volatile("" : "+v"(row[c])); }
         __builtin_amdgcn_sched_barrier(0);
       }
       // padded factor -> Lt (32 x 33); the real rows also back into the panel
@@ -189,19 +199,25 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
       if (lane == 0 && !good) s_ok = 0;
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_sched_barrier(0);
+#ifdef RSBA_PROFILE_PHASES
+      if (lane == 0) { long long _w1 = clock64(); g_phase_cycles[10] += _w1 - _w0; _w0 = _w1; }
+#endif
       // T = L11^-1, column lr: t_i = (delta_i,lr - sum_{q<i} L[i][q] t_q) / L[i][i]   (L11 reads are broadcasts)
       double t[RSBA_PB];
 #pragma unroll
       for (int i = 0; i < RSBA_PB; ++i) {
         double sacc = (i == lr) ? 1.0 : 0.0;
 #pragma unroll
-        for (int q = 0; q < RSBA_PB; ++q) if (q < i) sacc -= Lt[i * RSBA_PLD + q] * t[q];
-        t[i] = sacc * invd[i];
+        for (int q = 0; q < RSBA_PB; ++q) if (q < i) sacc -= ReadLaneD(row[q], i) * t[q];  // L[i][q] lives in lane i
+        t[i] = sacc * ReadLaneD(ilv, i);
         asm volatile("" : "+v"(t[i]));
         if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int i = 0; i < RSBA_PB; ++i) T[i * RSBA_PLD + lr] = t[i];
+#ifdef RSBA_PROFILE_PHASES
+      if (lane == 0) g_phase_cycles[11] += clock64() - _w0;
+#endif
     }
     __syncthreads();
     RSBA_STAMP(2);
