@@ -86,27 +86,52 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     double* Bst = lds;
     double* Pan = lds + (size_t)kb * RSBA_PLD;
     // 1. load the panel (scaled / damped on the fly) and the B strip
-#pragma unroll 8
-    for (int e = tid; e < R * RSBA_PB; e += nt) {
-      const int r = e >> 5, c = e & 31;
-      double v = 0.0;
-      if (c < nb) {
-        const int gi = kb + r, gj = kb + c;
-        if (src.S != nullptr && gi < n) {
-          const double si = scl[gi];
-          v = src.S[(size_t)gi * n + gj] * (si * scl[gj]);
-          if (gi == gj) v += fmin(fmax(si * si * src.diagU[gi], src.lo), src.hi) * src.inv_radius;
-        } else {
-          v = A[(size_t)gi * n + gj];
+    // four consecutive doubles of a row per thread and step (two dwordx4 loads): one round of latency per panel
+#pragma unroll 4
+    for (int e = tid; e < R * (RSBA_PB / 4); e += nt) {
+      const int r = e >> 3, c0 = (e & 7) * 4;
+      const int gi = kb + r;
+      double v[4] = {0.0, 0.0, 0.0, 0.0};
+      const bool fused_row = src.S != nullptr && gi < n;
+      const double* srow = (fused_row ? src.S : A) + (size_t)gi * n + kb + c0;
+      if (c0 + 3 < nb && ((((size_t)gi * n + kb + c0) & 1) == 0)) {
+        const double2 a01 = *reinterpret_cast<const double2*>(srow), a23 = *reinterpret_cast<const double2*>(srow + 2);
+        v[0] = a01.x; v[1] = a01.y; v[2] = a23.x; v[3] = a23.y;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (c0 + u < nb) v[u] = srow[u];
+      }
+      if (fused_row) {
+        const double si = scl[gi];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int gj = kb + c0 + u;
+          if (c0 + u < nb) {
+            v[u] *= si * scl[gj];
+            if (gi == gj) v[u] += fmin(fmax(si * si * src.diagU[gi], src.lo), src.hi) * src.inv_radius;
+          }
         }
       }
-      Pan[r * RSBA_PLD + c] = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Pan[r * RSBA_PLD + c0 + u] = v[u];
     }
-#pragma unroll 8
-    for (int e = tid; e < kb * RSBA_PB; e += nt) {
-      // coalesced along q (row kb+c of L), transposed into Bst[q][c]
-      const int c = e / kb, q = e - c * kb;
-      Bst[q * RSBA_PLD + c] = c < nb ? A[(size_t)(kb + c) * n + q] : 0.0;
+    // B strip: row kb+c of L, columns 0..kb, four at a time, transposed into Bst[q][c]
+#pragma unroll 4
+    for (int e = tid; e < (kb >> 2) * RSBA_PB; e += nt) {
+      const int c = e / (kb >> 2), q0 = (e - c * (kb >> 2)) * 4;
+      double v[4] = {0.0, 0.0, 0.0, 0.0};
+      if (c < nb) {
+        const double* lrow = A + (size_t)(kb + c) * n + q0;
+        if (((((size_t)(kb + c) * n + q0)) & 1) == 0) {
+          const double2 a01 = *reinterpret_cast<const double2*>(lrow), a23 = *reinterpret_cast<const double2*>(lrow + 2);
+          v[0] = a01.x; v[1] = a01.y; v[2] = a23.x; v[3] = a23.y;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = lrow[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Bst[(q0 + u) * RSBA_PLD + c] = v[u];
     }
     __syncthreads();
     RSBA_STAMP(0);
@@ -187,7 +212,6 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
         // round trip on the critical path.  Entries above the diagonal (c > row) pick up garbage; never read.
 #pragma unroll
         for (int c = j + 1; c < RSBA_PB; ++c) { row[c] -= lij * ReadLaneD(lij, c); asm volatile("" : "+v"(row[c])); }
-        __builtin_amdgcn_sched_barrier(0);
       }
       // padded factor -> Lt (32 x 33); the real rows also back into the panel
 #pragma unroll
@@ -206,10 +230,10 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
       double t[RSBA_PB];
 #pragma unroll
       for (int i = 0; i < RSBA_PB; ++i) {
-        double sacc = (i == lr) ? 1.0 : 0.0;
+        double sacc = (i == lr) ? 1.0 : 0.0, sacc2 = 0.0;  // two chains: the sum is latency-bound on one wave
 #pragma unroll
-        for (int q = 0; q < RSBA_PB; ++q) if (q < i) sacc -= ReadLaneD(row[q], i) * t[q];  // L[i][q] lives in lane i
-        t[i] = sacc * ReadLaneD(ilv, i);
+        for (int q = 0; q < RSBA_PB; ++q) if (q < i) { if (q & 1) sacc2 -= ReadLaneD(row[q], i) * t[q]; else sacc -= ReadLaneD(row[q], i) * t[q]; }  // L[i][q] lives in lane i
+        t[i] = (sacc + sacc2) * ReadLaneD(ilv, i);
         asm volatile("" : "+v"(t[i]));
         if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
