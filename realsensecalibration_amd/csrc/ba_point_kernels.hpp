@@ -96,6 +96,9 @@ __global__ void k_camera_constants(int C, const double* __restrict__ cam, const 
 // on-device cross-check of the tiled kernel and as the first parity-green path.
 // ------------------------------------------------------------------------------------------------
 #define RSBA_ACC_PER_CAM 33  // 21 (U upper) + 6 (gc) + 6 (corr)
+// LDS copies of the per-camera constants use an odd stride: with the global stride (32 doubles = one full bank row)
+// every lane reading element e of a different camera would hit the same bank.
+#define RSBA_CC_LDS (CC_STRIDE + 1)
 
 template <bool kStageCamc>
 __global__ void __launch_bounds__(256)
@@ -110,9 +113,10 @@ k_linearize_schur_ref(int C, int P, const double* __restrict__ obs_u, const doub
   double* camc_l = lds + (size_t)C * RSBA_ACC_PER_CAM;    // C x 32 when staged
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
   for (int i = tid; i < C * RSBA_ACC_PER_CAM; i += blockDim.x) acc[i] = 0.0;
-  if (kStageCamc) for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) camc_l[i] = camc_g[i];
+  if (kStageCamc) for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; camc_l[c * RSBA_CC_LDS + e] = camc_g[i]; }
   __syncthreads();
   const double* camc = kStageCamc ? camc_l : camc_g;
+  const int ccs = kStageCamc ? RSBA_CC_LDS : CC_STRIDE;
 
   double cost_acc = 0.0, xn_acc = 0.0, fail_acc = 0.0, gmax = 0.0;
   for (int j = blockIdx.x * nwave + wave; j < P; j += gridDim.x * nwave) {
@@ -128,7 +132,7 @@ k_linearize_schur_ref(int C, int P, const double* __restrict__ obs_u, const doub
     double rho = 0.0;
     if (act) {
       cam = obs_cam[b + lane];
-      ResidualJacobian(camc + (size_t)cam * CC_STRIDE, X, obs_u[b + lane], obs_v[b + lane], r, jc, jp);
+      ResidualJacobian(camc + (size_t)cam * ccs, X, obs_u[b + lane], obs_v[b + lane], r, jc, jp);
       double sq;
       rho = LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
       if (sq != 1.0) {
@@ -516,13 +520,28 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
 // records.  delta_p = -Vinv (g_p + sum Jp' Jc delta_c); model-cost-change terms accumulate in the same
 // loop; then the cost of the candidate (cameras' constants at x + delta already in camc_c).
 // ------------------------------------------------------------------------------------------------
+template <bool kStage>
 __global__ void __launch_bounds__(256)
 k_backsub_candidate(int C, int P, const double* __restrict__ obs_u, const double* __restrict__ obs_v,
                     const int* __restrict__ obs_cam, const int* __restrict__ pt_ptr,
-                    const double* __restrict__ camc_x, const double* __restrict__ camc_c,
-                    const double* __restrict__ dcam, const double* __restrict__ pts_x, double* __restrict__ pts_c,
+                    const double* __restrict__ camc_xg, const double* __restrict__ camc_cg,
+                    const double* __restrict__ dcam_g, const double* __restrict__ pts_x, double* __restrict__ pts_c,
                     const double* __restrict__ scale_p, double* __restrict__ block_part /* gridDim.x x 8 */, IterParams ip) {
+  extern __shared__ double lds[];
   const int tid = threadIdx.x;
+  // camera constants at x and at the candidate, and the camera step: 70 doubles per camera, LDS-resident when they fit
+  const double* camc_x = camc_xg;
+  const double* camc_c = camc_cg;
+  const double* dcam = dcam_g;
+  if (kStage) {
+    double* lx = lds;
+    double* lc = lds + (size_t)C * RSBA_CC_LDS;
+    double* ld = lc + (size_t)C * RSBA_CC_LDS;
+    for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; lx[c * RSBA_CC_LDS + e] = camc_xg[i]; lc[c * RSBA_CC_LDS + e] = camc_cg[i]; }
+    for (int i = tid; i < 6 * C; i += blockDim.x) ld[i] = dcam_g[i];
+    __syncthreads();
+    camc_x = lx; camc_c = lc; dcam = ld;
+  }
   double mcc = 0, cost_c = 0, dp2 = 0, xc2 = 0, ss_c = 0;
   for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
     const int b = pt_ptr[j], e = pt_ptr[j + 1];
@@ -531,7 +550,7 @@ k_backsub_candidate(int C, int P, const double* __restrict__ obs_u, const double
     for (int q = b; q < e; ++q) {
       const int cam = obs_cam[q];
       double r[2], jc[12], jp[6];
-      ResidualJacobian(camc_x + (size_t)cam * CC_STRIDE, X, obs_u[q], obs_v[q], r, jc, jp);
+      ResidualJacobian(camc_x + (size_t)cam * (kStage ? RSBA_CC_LDS : CC_STRIDE), X, obs_u[q], obs_v[q], r, jc, jp);
       double sq;
       LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
       const double* dc = dcam + 6 * cam;
@@ -565,7 +584,7 @@ k_backsub_candidate(int C, int P, const double* __restrict__ obs_u, const double
     xc2 += Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2];
     for (int q = b; q < e; ++q) {
       double r[2];
-      Residual(camc_c + (size_t)obs_cam[q] * CC_STRIDE, Xc, obs_u[q], obs_v[q], r);
+      Residual(camc_c + (size_t)obs_cam[q] * (kStage ? RSBA_CC_LDS : CC_STRIDE), Xc, obs_u[q], obs_v[q], r);
       const double s = r[0] * r[0] + r[1] * r[1];
       double sq;
       cost_c += LossAndScale(ip.huber_delta, s, &sq);

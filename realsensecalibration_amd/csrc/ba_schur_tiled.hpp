@@ -84,9 +84,10 @@ k_point_pass(int C, int P, const double* __restrict__ obs_u, const double* __res
   double* camc_l = lds + (size_t)C * RSBA_PP_ACC;      // C x 32 when staged
   const int tid = threadIdx.x;
   for (int i = tid; i < C * RSBA_PP_ACC; i += blockDim.x) acc[i] = 0.0;
-  if (kStageCamc) for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) camc_l[i] = camc_g[i];
+  if (kStageCamc) for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; camc_l[c * RSBA_CC_LDS + e] = camc_g[i]; }
   __syncthreads();
   const double* camc = kStageCamc ? camc_l : camc_g;
+  const int ccs = kStageCamc ? RSBA_CC_LDS : CC_STRIDE;
   double cost = 0, xn = 0, fail = 0, gmax = 0;
   for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
     const int b = pt_ptr[j], e = pt_ptr[j + 1];
@@ -95,7 +96,7 @@ k_point_pass(int C, int P, const double* __restrict__ obs_u, const double* __res
     for (int q = b; q < e; ++q) {
       const int cam = obs_cam[q];
       double r[2], jc[12], jp[6], sq;
-      ResidualJacobian(camc + (size_t)cam * CC_STRIDE, X, obs_u[q], obs_v[q], r, jc, jp);
+      ResidualJacobian(camc + (size_t)cam * ccs, X, obs_u[q], obs_v[q], r, jc, jp);
       cost += LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
       if (ip.huber_delta > 0.0) sq_cm[cm_pos[q]] = sq;
       if (sq != 1.0) {
@@ -297,11 +298,20 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
       SideRowsLds(cb, X, sqb, eb0, eb1, nb0, nb1);
       const double m00 = t00 * nb0[0] + t01 * nb0[1] + t02 * nb0[2], m01 = t00 * nb1[0] + t01 * nb1[1] + t02 * nb1[2];
       const double m10 = t10 * nb0[0] + t11 * nb0[1] + t12 * nb0[2], m11 = t10 * nb1[0] + t11 * nb1[1] + t12 * nb1[2];
+      // Z = Ea' M, acc += Z Eb.  Entries e0[4] and e1[3] are structural zeros ([A | Pj], Pj = [[al,0,ga],[0,be,de]]):
+      // rows 3/4 of Z and columns 3/4 of the update need one product instead of two.
 #pragma unroll
       for (int p = 0; p < 6; ++p) {
-        const double z0 = ea0[p] * m00 + ea1[p] * m10, z1 = ea0[p] * m01 + ea1[p] * m11;
+        double z0, z1;
+        if (p == 3) { z0 = ea0[3] * m00; z1 = ea0[3] * m01; }
+        else if (p == 4) { z0 = ea1[4] * m10; z1 = ea1[4] * m11; }
+        else { z0 = ea0[p] * m00 + ea1[p] * m10; z1 = ea0[p] * m01 + ea1[p] * m11; }
 #pragma unroll
-        for (int q = 0; q < 6; ++q) acc[6 * p + q] += z0 * eb0[q] + z1 * eb1[q];
+        for (int q = 0; q < 6; ++q) {
+          if (q == 3) acc[6 * p + q] += z0 * eb0[3];
+          else if (q == 4) acc[6 * p + q] += z1 * eb1[4];
+          else acc[6 * p + q] += z0 * eb0[q] + z1 * eb1[q];
+        }
       }
     }
   }
@@ -392,6 +402,7 @@ __global__ void __launch_bounds__(256)
 k_schur_reduce(const int* __restrict__ tile_seg_ptr, const double* __restrict__ partial, double* __restrict__ tile_sum /* [ntiles][42][256] */) {
   const int tile = blockIdx.x / RSBA_PART, k = blockIdx.x - tile * RSBA_PART, tid = threadIdx.x;
   double s = 0.0;
+#pragma unroll 8
   for (int sgi = tile_seg_ptr[tile]; sgi < tile_seg_ptr[tile + 1]; ++sgi) s += partial[((size_t)sgi * RSBA_PART + k) * 256 + tid];
   tile_sum[((size_t)tile * RSBA_PART + k) * 256 + tid] = s;
 }

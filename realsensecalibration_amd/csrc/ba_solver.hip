@@ -309,8 +309,8 @@ static int ResetPoints(rsba_solver* s) {
 int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
   hipStream_t st = s->stream;
   const int x = s->cur;
-  const bool stage = (size_t)C * (RSBA_PP_ACC + CC_STRIDE) * sizeof(double) <= 56 * 1024;
-  const size_t lds = (size_t)C * (RSBA_PP_ACC + (stage ? CC_STRIDE : 0)) * sizeof(double);
+  const bool stage = (size_t)C * (RSBA_PP_ACC + RSBA_CC_LDS) * sizeof(double) <= 56 * 1024;
+  const size_t lds = (size_t)C * (RSBA_PP_ACC + (stage ? RSBA_CC_LDS : 0)) * sizeof(double);
   T.Begin("k_point_pass", st);
   if (stage)
     k_point_pass<true><<<grid_pp, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p, ptdata, s->red,
@@ -362,8 +362,8 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   DebugSync(st, "memset red");
 
   if (s->opt.schur_impl == 0) {
-    const bool stage = (size_t)C * (RSBA_ACC_PER_CAM + CC_STRIDE) * sizeof(double) <= 96 * 1024;
-    const size_t lds = (size_t)C * (RSBA_ACC_PER_CAM + (stage ? CC_STRIDE : 0)) * sizeof(double);
+    const bool stage = (size_t)C * (RSBA_ACC_PER_CAM + RSBA_CC_LDS) * sizeof(double) <= 96 * 1024;
+    const size_t lds = (size_t)C * (RSBA_ACC_PER_CAM + (stage ? RSBA_CC_LDS : 0)) * sizeof(double);
     T.Begin("k_linearize_schur_ref", st);
     if (stage)
       k_linearize_schur_ref<true><<<s->grid_lin, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p,
@@ -403,8 +403,15 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   T.End(st);
   DebugSync(st, "k_reduced_system_solve");
   T.Begin("k_backsub_candidate", st);
-  k_backsub_candidate<<<s->grid_pts, 256, 0, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->camc[c], s->dcam, s->pts[x],
-                                                   s->pts[c], s->scale_p, s->block_part, ip);
+  {
+    const size_t lds_b = (size_t)C * (2 * RSBA_CC_LDS + 6) * sizeof(double);
+    if (lds_b <= 60 * 1024)
+      k_backsub_candidate<true><<<s->grid_pts, 256, lds_b, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->camc[c], s->dcam, s->pts[x],
+                                                                 s->pts[c], s->scale_p, s->block_part, ip);
+    else
+      k_backsub_candidate<false><<<s->grid_pts, 256, 0, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->camc[c], s->dcam, s->pts[x],
+                                                              s->pts[c], s->scale_p, s->block_part, ip);
+  }
   T.End(st);
   DebugSync(st, "k_backsub_candidate");
   T.Begin("k_finish_candidate", st);
