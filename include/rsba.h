@@ -79,7 +79,8 @@ typedef struct rsba_options {
   /* --- implementation knobs --- */
   int32_t device;          /* HIP device ordinal, -1 = current                                  */
   int32_t schur_impl;      /* 0 = reference kernel (global atomics), 1 = tiled (default)         */
-  int32_t profile_kernels; /* 1: bracket every kernel with HIP events (rsba_solver_kernel_stats) */
+  int32_t profile_kernels; /* HIP events on the solver stream (rsba_solver_kernel_stats): 1 = around every kernel,
+                              2 = only around the Schur pair kernel and the reduced-system solve */
   int32_t rank;            /* multi-GPU: this process' rank, 0..world_size-1                     */
   int32_t world_size;      /* 1 = single GPU.  >1: the problem handed in is this rank's point   */
                            /* shard (all cameras, its own points); the reduced camera system is */
