@@ -136,27 +136,53 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     __syncthreads();
     RSBA_STAMP(0);
     // 2. update with previous panels (MFMA), one wave per 16-row block, no barriers inside
-    // Wave 0 takes the two row blocks of the diagonal block and goes straight on to factor it (step 3) while
-    // the other waves update the rows below: the serial factorisation hides behind the GEMM of the rest.
+    // 2a. the diagonal block's own 32 rows first, K-split over all waves (both operands come from the LDS strip),
+    //     partial products added into the panel with LDS fp64 atomics;
+    // 2b. then waves 1.. update the rows below while wave 0 goes straight on to factor the diagonal block (step 3):
+    //     the serial factorisation hides behind the GEMM of the rest.
     if (kb > 0) {
-      const int nrb = (R + 15) >> 4;
       const int i = lane & 15, kk = lane >> 4;
-      const int rb_first = wave == 0 ? 0 : 2 + (wave - 1), rb_step = wave == 0 ? 1 : nwave - 1, rb_end = wave == 0 ? min(2, nrb) : nrb;
-      for (int rb = rb_first; rb < rb_end; rb += rb_step) {
+      {
+        d4_t a00 = {0, 0, 0, 0}, a01 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
+        for (int q0 = wave * RSBA_PB; q0 < kb; q0 += nwave * RSBA_PB) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double* bq = Bst + (size_t)(q0 + 4 * u + kk) * RSBA_PLD;
+            const double x0 = bq[i], x1 = bq[16 + i];   // row i / 16+i of the diagonal block, also columns i / 16+i
+            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, a00, 0, 0, 0);
+            a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, a01, 0, 0, 0);
+            a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, a10, 0, 0, 0);
+            a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
+          }
+        }
+        if (wave * RSBA_PB < kb) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int r = kk + 4 * t;
+            unsafeAtomicAdd(&Pan[r * RSBA_PLD + i], -a00[t]);
+            unsafeAtomicAdd(&Pan[r * RSBA_PLD + 16 + i], -a01[t]);
+            unsafeAtomicAdd(&Pan[(16 + r) * RSBA_PLD + i], -a10[t]);
+            unsafeAtomicAdd(&Pan[(16 + r) * RSBA_PLD + 16 + i], -a11[t]);
+          }
+        }
+      }
+      __syncthreads();
+      const int nrb = (R + 15) >> 4;
+      const int nw1 = nwave > 1 ? nwave - 1 : 1;
+      // a partial last panel (nb < 32) keeps its rows nb..R-1 (the rhs row) outside the strip: they are updated here
+      const int rb0 = nb == RSBA_PB ? 2 : (nb >> 4);
+      for (int rb = rb0 + (nwave > 1 ? wave - 1 : 0); rb < nrb && (wave > 0 || nwave == 1); rb += nw1) {
         const int prow = rb * 16 + i;  // panel-relative row of this lane's A operand
-        const bool rok = prow < R;
-        const double* arow = A + (size_t)(kb + (rok ? prow : 0)) * n + kk;
+        const bool gl = prow < R;
+        const double* arow = A + (size_t)(kb + (gl ? prow : 0)) * n + kk;
         d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-        // rows of the diagonal block ARE the B strip (L[kb+c][q] = Bst[q][c]): wave 0 needs no global loads
-        const bool from_lds = (wave == 0) && (prow < nb);  // rows nb..R-1 of a partial panel (the rhs row) are not in the strip
-        const bool gl = rok && !from_lds;
         double an[8], an2[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) { an[u] = gl ? arow[4 * u] : 0.0; an2[u] = (gl && RSBA_PB < kb) ? arow[RSBA_PB + 4 * u] : 0.0; }
         for (int q0 = 0; q0 < kb; q0 += RSBA_PB) {
           double ac[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { ac[u] = from_lds ? Bst[(q0 + 4 * u + kk) * RSBA_PLD + prow] : an[u]; an[u] = an2[u]; }
+          for (int u = 0; u < 8; ++u) { ac[u] = an[u]; an[u] = an2[u]; }
           if (q0 + 2 * RSBA_PB < kb) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) an2[u] = gl ? arow[q0 + 2 * RSBA_PB + 4 * u] : 0.0;
@@ -173,7 +199,7 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int r = rb * 16 + kk + 4 * t;
-          if (r < R) {
+          if (r < R && r >= nb) {
             Pan[r * RSBA_PLD + i] -= acc0[t];
             Pan[r * RSBA_PLD + 16 + i] -= acc1[t];
           }
@@ -290,40 +316,41 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     RSBA_STAMP(4);
   }
 
-  // Back-substitution L' x = y.  Block kb (from the bottom): b = y_blk - L21' x_below, then x_blk = T' b with
-  // the stored T = L11^-1 (T'[c][i] = T[i][c], nonzero for i >= c): no sequential step.
+  // Back-substitution L' x = y, right-looking from the bottom: x_blk = T' y_blk with the stored T = L11^-1
+  // (T'[c][i] = T[i][c], i >= c; no sequential step), then y[0:kb] -= L[kb:kb+nb, 0:kb]' x_blk, which reads the
+  // block's rows of L contiguously (one round of global latency per block).
   double* y = lds;                                 // n
-  double* part = lds + ((n + 63) & ~63);           // 32 x 33 partial sums
-  double* Tb = part + RSBA_PB * RSBA_PLD;          // 32 x 33: Tb[i][c] = T[i][c]
-  double* bb = Tb + RSBA_PB * RSBA_PLD;            // 32
+  double* Tb = lds + ((n + 63) & ~63);             // 32 x 33: Tb[i][c] = T[i][c]
+  double* xb = Tb + RSBA_PB * RSBA_PLD;            // 32
   for (int i = tid; i < n; i += nt) y[i] = A[(size_t)n * n + i];
   __syncthreads();
   for (int kb = ((n - 1) / RSBA_PB) * RSBA_PB; kb >= 0; kb -= RSBA_PB) {
     const int nb = min(RSBA_PB, n - kb);
-    const int c = tid & 31;
-    for (int slice = tid >> 5; slice < 32; slice += nt >> 5) {
-      double s = 0.0;
-      if (c < nb) for (int i = kb + nb + slice; i < n; i += 32) s += A[(size_t)i * n + kb + c] * y[i];
-      part[slice * RSBA_PLD + c] = s;
-      // T block: T[i][c] for i > c sits at A[kb+c][kb+i]; the diagonal in row n+1
-      const int i = slice;
+    for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) {
+      const int i = e >> 5, c = e & 31;
       double tv = 0.0;
+      // T[i][c] for i > c sits at A[kb+c][kb+i]; the diagonal in row n+1
       if (i < nb && c < nb) tv = (i > c) ? A[(size_t)(kb + c) * n + kb + i] : (i == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
       Tb[i * RSBA_PLD + c] = tv;
     }
     __syncthreads();
     if (tid < RSBA_PB) {
-      double s = 0.0;
+      double sacc = 0.0;
 #pragma unroll 8
-      for (int q = 0; q < 32; ++q) s += part[q * RSBA_PLD + tid];
-      bb[tid] = (tid < nb) ? y[kb + tid] - s : 0.0;
+      for (int i = 0; i < RSBA_PB; ++i) sacc += Tb[i * RSBA_PLD + tid] * ((i < nb) ? y[kb + i] : 0.0);
+      xb[tid] = (tid < nb) ? sacc : 0.0;
     }
     __syncthreads();
-    if (tid < RSBA_PB) {
-      double s = 0.0;
-#pragma unroll 8
-      for (int i = 0; i < RSBA_PB; ++i) s += Tb[i * RSBA_PLD + tid] * bb[i];
-      if (tid < nb) y[kb + tid] = s;
+    if (tid < nb) y[kb + tid] = xb[tid];
+    for (int q = tid; q < kb; q += nt) {
+      // 32 independent loads in flight per thread: one round of latency (rows >= nb of a partial block are not read)
+      double lv[RSBA_PB];
+#pragma unroll
+      for (int c = 0; c < RSBA_PB; ++c) lv[c] = (c < nb) ? A[(size_t)(kb + c) * n + q] : 0.0;
+      double sacc = 0.0;
+#pragma unroll
+      for (int c = 0; c < RSBA_PB; ++c) sacc += lv[c] * xb[c];
+      y[q] -= sacc;
     }
     __syncthreads();
   }
