@@ -137,7 +137,7 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     RSBA_STAMP(0);
     // 2. update with previous panels (MFMA), one wave per 16-row block, no barriers inside
     // 2a. the diagonal block's own 32 rows first, K-split over all waves (both operands come from the LDS strip),
-    //     partial products added into the panel with LDS fp64 atomics;
+    //     partial products added into the panel in wave order;
     // 2b. then waves 1.. update the rows below while wave 0 goes straight on to factor the diagonal block (step 3):
     //     the serial factorisation hides behind the GEMM of the rest.
     if (kb > 0) {
@@ -155,15 +155,20 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
             a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
           }
         }
-        if (wave * RSBA_PB < kb) {
+        // the waves add their partial products in wave order (plain read-modify-write, one barrier per wave) so the
+        // factor is bitwise reproducible: every rank of a multi-GPU run must end up with identical cameras
+        for (int wv = 0; wv < nwave && wv * RSBA_PB < kb; ++wv) {
+          if (wave == wv) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int r = kk + 4 * t;
-            unsafeAtomicAdd(&Pan[r * RSBA_PLD + i], -a00[t]);
-            unsafeAtomicAdd(&Pan[r * RSBA_PLD + 16 + i], -a01[t]);
-            unsafeAtomicAdd(&Pan[(16 + r) * RSBA_PLD + i], -a10[t]);
-            unsafeAtomicAdd(&Pan[(16 + r) * RSBA_PLD + 16 + i], -a11[t]);
+            for (int t = 0; t < 4; ++t) {
+              const int r = kk + 4 * t;
+              Pan[r * RSBA_PLD + i] -= a00[t];
+              Pan[r * RSBA_PLD + 16 + i] -= a01[t];
+              Pan[(16 + r) * RSBA_PLD + i] -= a10[t];
+              Pan[(16 + r) * RSBA_PLD + 16 + i] -= a11[t];
+            }
           }
+          __syncthreads();
         }
       }
       __syncthreads();

@@ -228,3 +228,19 @@ def test_cpp_bamanager_mirror_end_to_end(tmp_path):
         assert np.abs(np.loadtxt(str(tmp_path / ("mat%d.txt" % i))) - np.loadtxt(os.path.join(G, "extrinsics", "mat%d.txt" % i))).max() < 2e-6
     rms = float(out.stdout.split("Average Reprojection Error per One Coordinate:")[1].split()[0])
     assert abs(rms - 0.726669955) < 1e-6
+
+
+def test_rccl_collective_path_single_rank(oracle):
+    """RSBA_FORCE_COMM=1 builds a 1-rank RCCL communicator, so the three all-reduces of the multi-GPU path really run
+    (sum of the packed reduced system, max of the gradient bound, sum of the candidate scalars).  With one rank they
+    are identities: the solve must match the oracle exactly as the plain path does."""
+    prob = syn.make_problem(8, 2000, 6, seed=21)
+    ref, s_ref, _ = oracle.solve_points(prob)
+    os.environ["RSBA_FORCE_COMM"] = "1"
+    try:
+        got, s, log = capi.solve_points(prob)
+    finally:
+        del os.environ["RSBA_FORCE_COMM"]
+    assert s.num_iterations == s_ref.num_iterations and s.stop_reason == s_ref.stop_reason
+    assert _block_rel(got, ref, prob["C"]) < 1e-6
+    assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
