@@ -270,24 +270,27 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
     __syncthreads();
     // every lane walks ITS OWN hit list through the whole chunk: the word index is per lane, so a wave
     // runs max-over-lanes(hits in 512 points) trips, not the sum over words of the per-word maxima
-    int w = live ? 0 : RSBA_CW;
+    // one flat loop per lane: (w, h) is the lane's cursor into its hit list; the cursor advance is a tiny inner loop
+    // that does not touch the accumulators
+    int w = 0;
     unsigned long long h = live ? (mk[ia][0] & mk[RSBA_TG + ib][0]) : 0ull;
+    if (live) { while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & mk[RSBA_TG + ib][w]; } }
 #pragma unroll 1
-    for (;;) {
-      while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & mk[RSBA_TG + ib][w]; }
-      if (h == 0ull) break;
+    while (h != 0ull) {
       const int bit = __ffsll((long long)h) - 1;
+      const int wcur = w;
       h &= h - 1;
-      const double* pd = pt + (size_t)(w * 64 + bit) * RSBA_PT_STRIDE;
+      while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & mk[RSBA_TG + ib][w]; }
+      const double* pd = pt + (size_t)(wcur * 64 + bit) * RSBA_PT_STRIDE;
       const double X[3] = {pd[0], pd[1], pd[2]};
       const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
       double sqa = 1.0, sqb = 1.0;
       if (kLoss) {
         // rank of this point in each camera's own observation list -> its sqrt(rho')
         const unsigned long long below = (1ull << bit) - 1ull;
-        const int gw = ch * RSBA_CW + w;
-        sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + gw] + __popcll(mk[ia][w] & below)];
-        sqb = sq_cm[cam_ptr[cam_b] + cam_prefix[(size_t)cam_b * nwords + gw] + __popcll(mk[RSBA_TG + ib][w] & below)];
+        const int gw = ch * RSBA_CW + wcur;
+        sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + gw] + __popcll(mk[ia][wcur] & below)];
+        sqb = sq_cm[cam_ptr[cam_b] + cam_prefix[(size_t)cam_b * nwords + gw] + __popcll(mk[RSBA_TG + ib][wcur] & below)];
       }
       double ea0[6], ea1[6], na0[3], na1[3];
       SideRowsLds(ca, X, sqa, ea0, ea1, na0, na1);
@@ -355,21 +358,22 @@ k_schur_self(int C, int P, int nwords, const double* __restrict__ camc, const Sc
       mk[row][w] = cam < C ? cam_mask[(size_t)cam * nwords + (size_t)ch * RSBA_CW + w] : 0ull;
     }
     __syncthreads();
-    int w = live ? 0 : RSBA_CW;
+    int w = 0;
     unsigned long long h = live ? (mk[ia][0] & lane_bits) : 0ull;
+    if (live) { while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & lane_bits; } }
 #pragma unroll 1
-    for (;;) {
-      while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & lane_bits; }
-      if (h == 0ull) break;
+    while (h != 0ull) {
       const int bit = __ffsll((long long)h) - 1;
+      const int wcur = w;
       h &= h - 1;
-      const double* pd = pt + (size_t)(w * 64 + bit) * RSBA_PT_STRIDE;
+      while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & lane_bits; }
+      const double* pd = pt + (size_t)(wcur * 64 + bit) * RSBA_PT_STRIDE;
       const double X[3] = {pd[0], pd[1], pd[2]};
       const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
       double sqa = 1.0;
       if (kLoss) {
         const unsigned long long below = (1ull << bit) - 1ull;
-        sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + ch * RSBA_CW + w] + __popcll(mk[ia][w] & below)];
+        sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + ch * RSBA_CW + wcur] + __popcll(mk[ia][wcur] & below)];
       }
       double e0[6], e1[6], n0[3], n1[3];
       SideRows(A, X, sqa, e0, e1, n0, n1);
