@@ -329,15 +329,29 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
   double* xb = Tb + RSBA_PB * RSBA_PLD;            // 32
   for (int i = tid; i < n; i += nt) y[i] = A[(size_t)n * n + i];
   __syncthreads();
-  for (int kb = ((n - 1) / RSBA_PB) * RSBA_PB; kb >= 0; kb -= RSBA_PB) {
+  // Global loads are issued a phase early: the T block of the NEXT block row is fetched while this one is solved, and
+  // the strip of L this block multiplies is fetched before x_blk exists (it does not depend on it).
+  const int kb_last = ((n - 1) / RSBA_PB) * RSBA_PB;
+  double tpre[2] = {0.0, 0.0};  // this thread's two entries of the next T block (nt = 512: 1024 entries)
+  auto fetch_T = [&](int kb, int slot) {
+    const int e = tid + slot * nt;
+    const int nbk = min(RSBA_PB, n - kb);
+    const int i = e >> 5, c = e & 31;
+    double tv = 0.0;
+    // T[i][c] for i > c sits at A[kb+c][kb+i]; the diagonal in row n+1
+    if (e < RSBA_PB * RSBA_PB && i < nbk && c < nbk) tv = (i > c) ? A[(size_t)(kb + c) * n + kb + i] : (i == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
+    return tv;
+  };
+  for (int sl = 0; sl < 2; ++sl) tpre[sl] = (tid + sl * nt < RSBA_PB * RSBA_PB) ? fetch_T(kb_last, sl) : 0.0;
+  for (int kb = kb_last; kb >= 0; kb -= RSBA_PB) {
     const int nb = min(RSBA_PB, n - kb);
-    for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) {
-      const int i = e >> 5, c = e & 31;
-      double tv = 0.0;
-      // T[i][c] for i > c sits at A[kb+c][kb+i]; the diagonal in row n+1
-      if (i < nb && c < nb) tv = (i > c) ? A[(size_t)(kb + c) * n + kb + i] : (i == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
-      Tb[i * RSBA_PLD + c] = tv;
-    }
+    for (int sl = 0; sl < 2; ++sl) { const int e = tid + sl * nt; if (e < RSBA_PB * RSBA_PB) Tb[(e >> 5) * RSBA_PLD + (e & 31)] = tpre[sl]; }
+    // strip of L for this block (rows kb..kb+nb, column q = tid): independent of x_blk, so load it now
+    double lv[RSBA_PB];
+    const int q = tid;  // kb <= 352 < nt
+#pragma unroll
+    for (int c = 0; c < RSBA_PB; ++c) lv[c] = (c < nb && q < kb) ? A[(size_t)(kb + c) * n + q] : 0.0;
+    if (kb >= RSBA_PB) { for (int sl = 0; sl < 2; ++sl) tpre[sl] = (tid + sl * nt < RSBA_PB * RSBA_PB) ? fetch_T(kb - RSBA_PB, sl) : 0.0; }
     __syncthreads();
     if (tid < RSBA_PB) {
       double sacc = 0.0;
@@ -347,15 +361,16 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     }
     __syncthreads();
     if (tid < nb) y[kb + tid] = xb[tid];
-    for (int q = tid; q < kb; q += nt) {
-      // 32 independent loads in flight per thread: one round of latency (rows >= nb of a partial block are not read)
-      double lv[RSBA_PB];
-#pragma unroll
-      for (int c = 0; c < RSBA_PB; ++c) lv[c] = (c < nb) ? A[(size_t)(kb + c) * n + q] : 0.0;
+    if (q < kb) {
       double sacc = 0.0;
 #pragma unroll
       for (int c = 0; c < RSBA_PB; ++c) sacc += lv[c] * xb[c];
       y[q] -= sacc;
+    }
+    for (int q2 = tid + nt; q2 < kb; q2 += nt) {  // n > 512 never reaches here (RSBA_CHOL_MAXN), kept for safety
+      double sacc = 0.0;
+      for (int c = 0; c < nb; ++c) sacc += A[(size_t)(kb + c) * n + q2] * xb[c];
+      y[q2] -= sacc;
     }
     __syncthreads();
   }
