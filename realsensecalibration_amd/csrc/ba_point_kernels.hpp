@@ -271,6 +271,7 @@ __global__ void k_finish_linearize(int nblocks, const double* __restrict__ block
   }
   if (tid == 0) {
     red[L.scal() + 0] = s[0][0]; red[L.scal() + 1] = s[0][1]; red[L.scal() + 2] = s[0][2];
+    for (int q = 3; q < 8; ++q) red[L.scal() + q] = 0.0;
     *gmax_p = s[0][3];
   }
 }

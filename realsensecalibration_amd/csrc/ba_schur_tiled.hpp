@@ -63,7 +63,8 @@ struct TiledSchur {
   int* cam_ptr = nullptr;                   // [ngroups*16+1] start of each camera's observation list
   int* cm_pos = nullptr;                    // [N] sorted observation -> camera-major position
   double* sq_cm = nullptr;                  // [N]
-  int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam);
+  double *u_cm = nullptr, *v_cm = nullptr;  // [N] observations in camera-major order (self tiles need the pixel)
+  int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v);
   int Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T);
   void Free();
 };
@@ -71,19 +72,15 @@ struct TiledSchur {
 // ------------------------------------------------------------------------------------------------
 // K_A1: point pass, one thread per point.
 // ------------------------------------------------------------------------------------------------
-#define RSBA_PP_ACC 27  // 21 U upper + 6 gc
-
 template <bool kStageCamc>
 __global__ void __launch_bounds__(256)
 k_point_pass(int C, int P, const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
              const int* __restrict__ pt_ptr, const double* __restrict__ camc_g, const double* __restrict__ pts,
-             double* __restrict__ scale_p, double* __restrict__ ptdata, double* __restrict__ red, RedLayout L,
-             double* __restrict__ block_scal, const int* __restrict__ cm_pos, double* __restrict__ sq_cm, IterParams ip) {
+             double* __restrict__ scale_p, double* __restrict__ ptdata, double* __restrict__ block_scal,
+             const int* __restrict__ cm_pos, double* __restrict__ sq_cm, IterParams ip) {
   extern __shared__ double lds[];
-  double* acc = lds;                                   // C x 27
-  double* camc_l = lds + (size_t)C * RSBA_PP_ACC;      // C x 32 when staged
+  double* camc_l = lds;      // C x 33 when staged
   const int tid = threadIdx.x;
-  for (int i = tid; i < C * RSBA_PP_ACC; i += blockDim.x) acc[i] = 0.0;
   if (kStageCamc) for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; camc_l[c * RSBA_CC_LDS + e] = camc_g[i]; }
   __syncthreads();
   const double* camc = kStageCamc ? camc_l : camc_g;
@@ -102,22 +99,11 @@ k_point_pass(int C, int P, const double* __restrict__ obs_u, const double* __res
       if (sq != 1.0) {
         r[0] *= sq; r[1] *= sq;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) jc[i] *= sq;
-#pragma unroll
         for (int i = 0; i < 6; ++i) jp[i] *= sq;
       }
       V[0] += jp[0] * jp[0] + jp[3] * jp[3]; V[1] += jp[0] * jp[1] + jp[3] * jp[4]; V[2] += jp[0] * jp[2] + jp[3] * jp[5];
       V[3] += jp[1] * jp[1] + jp[4] * jp[4]; V[4] += jp[1] * jp[2] + jp[4] * jp[5]; V[5] += jp[2] * jp[2] + jp[5] * jp[5];
       gp[0] += jp[0] * r[0] + jp[3] * r[1]; gp[1] += jp[1] * r[0] + jp[4] * r[1]; gp[2] += jp[2] * r[0] + jp[5] * r[1];
-      double* a27 = acc + (size_t)cam * RSBA_PP_ACC;
-      int t = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-#pragma unroll
-        for (int c6 = a; c6 < 6; ++c6) { unsafeAtomicAdd(&a27[t], jc[a] * jc[c6] + jc[6 + a] * jc[6 + c6]); ++t; }
-      }
-#pragma unroll
-      for (int a = 0; a < 6; ++a) unsafeAtomicAdd(&a27[21 + a], jc[a] * r[0] + jc[6 + a] * r[1]);
     }
     double sp[3] = {1.0, 1.0, 1.0};
     if (ip.jacobi_scaling) {
@@ -141,21 +127,6 @@ k_point_pass(int C, int P, const double* __restrict__ obs_u, const double* __res
     pd[9] = y[0]; pd[10] = y[1]; pd[11] = y[2];
     xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
     gmax = fmax(gmax, fmax(fabs(gp[0]), fmax(fabs(gp[1]), fabs(gp[2]))));
-  }
-  __syncthreads();
-  for (int i = tid; i < C * RSBA_PP_ACC; i += blockDim.x) {
-    const int c = i / RSBA_PP_ACC, e = i - c * RSBA_PP_ACC;
-    const double v = acc[i];
-    if (v == 0.0) continue;
-    if (e < 21) {
-      int a = 0, rem = e;
-      while (rem >= 6 - a) { rem -= 6 - a; ++a; }
-      const int c6 = a + rem;
-      unsafeAtomicAdd(&red[L.S() + (size_t)(6 * c + a) * L.nc + 6 * c + c6], v);
-      if (a == c6) unsafeAtomicAdd(&red[L.diagU() + 6 * c + a], v);
-    } else {
-      unsafeAtomicAdd(&red[L.gc() + 6 * c + (e - 21)], v);
-    }
   }
   __shared__ double s[4][256];
   s[0][tid] = cost; s[1][tid] = xn; s[2][tid] = fail; s[3][tid] = gmax;
@@ -325,14 +296,22 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
   for (int i = 0; i < 6; ++i) out[(36 + i) * 256 + tid] = 0.0;
 }
 
-// Self tiles: the (a, a) blocks and the rhs correction.  Camera a sees ~3x the points a pair shares, so its points are
-// dealt to 16 lanes: lane (ia, s) takes the bits {s, s+16, s+32, s+48} of every mask word.
+// Self tiles: everything that is a sum over ONE camera's observations — the diagonal block U_a - W V^-1 W' (a, a),
+// diag(U_a) for the LM damping, the camera gradient g_c and the Schur correction of the right-hand side.
+// Camera a sees ~3x the points a pair shares, so its points are dealt to 16 lanes: lane (ia, s) takes the bits
+// {s, s+16, s+32, s+48} of every mask word.  The residual needs this observation's pixel: u/v are kept in a second,
+// camera-major copy (u_cm, v_cm) addressed by the rank of the point in the camera's own list.
+// Per-lane sums (42, the K = J_l factor is applied in k_schur_finish):
+//   [0,21)  upper triangle of  E'(I - N V^-1 N')E   = core of  U_a - W V^-1 W'
+//   [21,27) upper triangle of the top-left 3x3 of E'E, [27,30) diagonal entries 3..5 of E'E   (-> diag U_a)
+//   [30,36) E' r                                           (-> g_c)
+//   [36,42) E' N V^-1 g_p                                  (-> -corr)
 template <bool kLoss>
 __global__ void __launch_bounds__(256, 2)
 k_schur_self(int C, int P, int nwords, const double* __restrict__ camc, const SchurSeg* __restrict__ segs,
              const unsigned long long* __restrict__ cam_mask, const double* __restrict__ ptdata,
              const int* __restrict__ cam_prefix, const int* __restrict__ cam_ptr, const double* __restrict__ sq_cm,
-             double* __restrict__ partial, int seg0) {
+             const double* __restrict__ u_cm, const double* __restrict__ v_cm, double* __restrict__ partial, int seg0) {
   __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];
   __shared__ unsigned long long mk[RSBA_TG][RSBA_CW];
   const SchurSeg sg = segs[seg0 + blockIdx.x];
@@ -340,13 +319,14 @@ k_schur_self(int C, int P, int nwords, const double* __restrict__ camc, const Sc
   const int cam_a = RSBA_TG * sg.ga + ia;
   const bool live = cam_a < C;
   const unsigned long long lane_bits = 0x0001000100010001ull << ib;
+  const double* cca = camc + (size_t)(live ? cam_a : 0) * CC_STRIDE;
   SideConst A;
-  LoadSide(camc + (size_t)(live ? cam_a : 0) * CC_STRIDE, A);
-  double acc[36], corr[6];
+  LoadSide(cca, A);
+  const double ppx = cca[CC_PPX], ppy = cca[CC_PPY];
+  const int obs0 = live ? cam_ptr[cam_a] : 0;
+  double acc[RSBA_PART];
 #pragma unroll
-  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) corr[i] = 0.0;
+  for (int i = 0; i < RSBA_PART; ++i) acc[i] = 0.0;
   for (int ch = sg.chunk_begin; ch < sg.chunk_end; ++ch) {
     const int j0 = ch * RSBA_CHUNK;
     const int np = min(RSBA_CHUNK, P - j0);
@@ -370,34 +350,45 @@ k_schur_self(int C, int P, int nwords, const double* __restrict__ camc, const Sc
       const double* pd = pt + (size_t)(wcur * 64 + bit) * RSBA_PT_STRIDE;
       const double X[3] = {pd[0], pd[1], pd[2]};
       const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
-      double sqa = 1.0;
-      if (kLoss) {
-        const unsigned long long below = (1ull << bit) - 1ull;
-        sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + ch * RSBA_CW + wcur] + __popcll(mk[ia][wcur] & below)];
-      }
+      // rank of this point in the camera's own observation list
+      const int oi = obs0 + cam_prefix[(size_t)cam_a * nwords + ch * RSBA_CW + wcur] + __popcll(mk[ia][wcur] & ((1ull << bit) - 1ull));
+      const double sqa = kLoss ? sq_cm[oi] : 1.0;
+      const double uu = u_cm[oi], vv = v_cm[oi];
       double e0[6], e1[6], n0[3], n1[3];
       SideRows(A, X, sqa, e0, e1, n0, n1);
+      // residual from the rows just built: e0[3] = sq fx / z, e0[5] = -sq fx x / z^2  =>  fx x / z = -e0[5] / e0[3] * fx ... cheaper:
+      // recompute the projection directly (same arithmetic as ba_math.hpp::Residual)
+      const double q0 = A.R[0] * X[0] + A.R[1] * X[1] + A.R[2] * X[2] + A.t[0];
+      const double q1 = A.R[3] * X[0] + A.R[4] * X[1] + A.R[5] * X[2] + A.t[1];
+      const double q2 = A.R[6] * X[0] + A.R[7] * X[1] + A.R[8] * X[2] + A.t[2];
+      const double iz = 1.0 / q2;
+      const double r0 = (A.fx * q0 * iz + ppx - uu) * sqa, r1 = (A.fy * q1 * iz + ppy - vv) * sqa;
+      // M' = I - N Vinv N'  (2x2 symmetric)
       const double t00 = n0[0] * v0 + n0[1] * v1 + n0[2] * v2, t01 = n0[0] * v1 + n0[1] * v3 + n0[2] * v4, t02 = n0[0] * v2 + n0[1] * v4 + n0[2] * v5;
       const double t10 = n1[0] * v0 + n1[1] * v1 + n1[2] * v2, t11 = n1[0] * v1 + n1[1] * v3 + n1[2] * v4, t12 = n1[0] * v2 + n1[1] * v4 + n1[2] * v5;
-      const double m00 = t00 * n0[0] + t01 * n0[1] + t02 * n0[2], m01 = t00 * n1[0] + t01 * n1[1] + t02 * n1[2];
-      const double m10 = t10 * n0[0] + t11 * n0[1] + t12 * n0[2], m11 = t10 * n1[0] + t11 * n1[1] + t12 * n1[2];
+      const double m00 = 1.0 - (t00 * n0[0] + t01 * n0[1] + t02 * n0[2]);
+      const double m01 = -(t00 * n1[0] + t01 * n1[1] + t02 * n1[2]);
+      const double m11 = 1.0 - (t10 * n1[0] + t11 * n1[1] + t12 * n1[2]);
+      int t = 0;
 #pragma unroll
       for (int p = 0; p < 6; ++p) {
-        const double z0 = e0[p] * m00 + e1[p] * m10, z1 = e0[p] * m01 + e1[p] * m11;
+        const double z0 = e0[p] * m00 + e1[p] * m01, z1 = e0[p] * m01 + e1[p] * m11;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) acc[6 * p + q] += z0 * e0[q] + z1 * e1[q];
+        for (int q = p; q < 6; ++q) { acc[t] += z0 * e0[q] + z1 * e1[q]; ++t; }
       }
+      // E'E: top-left 3x3 (upper) and diagonal 3..5
+      acc[21] += e0[0] * e0[0] + e1[0] * e1[0]; acc[22] += e0[0] * e0[1] + e1[0] * e1[1]; acc[23] += e0[0] * e0[2] + e1[0] * e1[2];
+      acc[24] += e0[1] * e0[1] + e1[1] * e1[1]; acc[25] += e0[1] * e0[2] + e1[1] * e1[2]; acc[26] += e0[2] * e0[2] + e1[2] * e1[2];
+      acc[27] += e0[3] * e0[3] + e1[3] * e1[3]; acc[28] += e0[4] * e0[4] + e1[4] * e1[4]; acc[29] += e0[5] * e0[5] + e1[5] * e1[5];
       const double f0 = n0[0] * pd[9] + n0[1] * pd[10] + n0[2] * pd[11];
       const double f1 = n1[0] * pd[9] + n1[1] * pd[10] + n1[2] * pd[11];
 #pragma unroll
-      for (int p = 0; p < 6; ++p) corr[p] += e0[p] * f0 + e1[p] * f1;
+      for (int p = 0; p < 6; ++p) { acc[30 + p] += e0[p] * r0 + e1[p] * r1; acc[36 + p] += e0[p] * f0 + e1[p] * f1; }
     }
   }
   double* out = partial + (size_t)(seg0 + blockIdx.x) * RSBA_PART * 256;
 #pragma unroll
-  for (int i = 0; i < 36; ++i) out[i * 256 + tid] = acc[i];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) out[(36 + i) * 256 + tid] = corr[i];
+  for (int i = 0; i < RSBA_PART; ++i) out[i * 256 + tid] = acc[i];
 }
 
 // K_A3a: fixed-order sum over the segments of a tile, one workgroup per (tile, component): 42 x ntiles
@@ -423,23 +414,68 @@ k_schur_finish(int C, int ntiles, const int* __restrict__ tile_ab, const double*
   const int ia = tid >> 4, ib = tid & 15;
   const int cam_a = RSBA_TG * ga + ia, cam_b = self_tile ? cam_a : RSBA_TG * gb + ib;
   const double* in = tile_sum + (size_t)tile * RSBA_PART * 256;
-  double core[36], cr[6];
-#pragma unroll
-  for (int i = 0; i < 36; ++i) core[i] = in[i * 256 + tid];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) cr[i] = in[(36 + i) * 256 + tid];
   if (self_tile) {
-    // sum the 16 slices of a row (lanes ia*16 .. ia*16+15 are contiguous inside a wave); fixed tree order
+    // sum the 16 slices of a row (lanes ia*16 .. ia*16+15 are contiguous inside a wave) in a fixed tree order
+    double v[RSBA_PART];
+#pragma unroll
+    for (int i = 0; i < RSBA_PART; ++i) v[i] = in[i * 256 + tid];
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) {
 #pragma unroll
-      for (int i = 0; i < 36; ++i) core[i] += __shfl_down(core[i], off, 16);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) cr[i] += __shfl_down(cr[i], off, 16);
+      for (int i = 0; i < RSBA_PART; ++i) v[i] += __shfl_down(v[i], off, 16);
     }
-    if (ib != 0) return;
+    if (ib != 0 || cam_a >= C) return;
+    const double* K = camc + (size_t)cam_a * CC_STRIDE + CC_K;
+    // symmetric core -> full 6x6, then T' core T with T = blkdiag(K, I)
+    double cfull[36];
+    { int t = 0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+#pragma unroll
+        for (int q = p; q < 6; ++q) { cfull[6 * p + q] = v[t]; cfull[6 * q + p] = v[t]; ++t; } } }
+    double tmp[36], blk[36];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) tmp[6 * p + q] = K[0 * 3 + p] * cfull[0 * 6 + q] + K[1 * 3 + p] * cfull[1 * 6 + q] + K[2 * 3 + p] * cfull[2 * 6 + q];
+#pragma unroll
+      for (int p = 3; p < 6; ++p) tmp[6 * p + q] = cfull[6 * p + q];
+    }
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) blk[6 * p + q] = tmp[6 * p + 0] * K[0 * 3 + q] + tmp[6 * p + 1] * K[1 * 3 + q] + tmp[6 * p + 2] * K[2 * 3 + q];
+#pragma unroll
+      for (int q = 3; q < 6; ++q) blk[6 * p + q] = tmp[6 * p + q];
+    }
+    double* Sd = red + L.S() + (size_t)(6 * cam_a) * L.nc + 6 * cam_a;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+#pragma unroll
+      for (int q = p; q < 6; ++q) { const double x = 0.5 * (blk[6 * p + q] + blk[6 * q + p]); Sd[(size_t)p * L.nc + q] = x; Sd[(size_t)q * L.nc + p] = x; }
+    }
+    // diag(U): rows 0..2 through K, rows 3..5 as they are
+    const double u00 = v[21], u01 = v[22], u02 = v[23], u11 = v[24], u12 = v[25], u22 = v[26];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const double k0 = K[0 * 3 + p], k1 = K[1 * 3 + p], k2 = K[2 * 3 + p];
+      red[L.diagU() + 6 * cam_a + p] = k0 * (u00 * k0 + u01 * k1 + u02 * k2) + k1 * (u01 * k0 + u11 * k1 + u12 * k2) + k2 * (u02 * k0 + u12 * k1 + u22 * k2);
+    }
+#pragma unroll
+    for (int p = 3; p < 6; ++p) red[L.diagU() + 6 * cam_a + p] = v[27 + p - 3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      red[L.gc() + 6 * cam_a + p] = K[0 * 3 + p] * v[30] + K[1 * 3 + p] * v[31] + K[2 * 3 + p] * v[32];
+      red[L.corr() + 6 * cam_a + p] = -(K[0 * 3 + p] * v[36] + K[1 * 3 + p] * v[37] + K[2 * 3 + p] * v[38]);
+    }
+#pragma unroll
+    for (int p = 3; p < 6; ++p) { red[L.gc() + 6 * cam_a + p] = v[30 + p]; red[L.corr() + 6 * cam_a + p] = -v[36 + p]; }
+    return;
   }
-  if (cam_a >= C || cam_b >= C || (!self_tile && ga == gb && ia >= ib)) return;
+  double core[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) core[i] = in[i * 256 + tid];
+  if (cam_a >= C || cam_b >= C || (ga == gb && ia >= ib)) return;
   const double* Ka = camc + (size_t)cam_a * CC_STRIDE + CC_K;
   const double* Kb = camc + (size_t)cam_b * CC_STRIDE + CC_K;
   // rows: Ta' core  (first three rows mixed by Ka')
@@ -460,33 +496,13 @@ k_schur_finish(int C, int ntiles, const int* __restrict__ tile_ab, const double*
 #pragma unroll
     for (int q = 3; q < 6; ++q) blk[6 * p + q] = tmp[6 * p + q];
   }
-  // S is written full symmetric: off-diagonal blocks are touched by nobody else (U lives on the diagonal
-  // blocks only), so block (a,b) = -blk and block (b,a) = -blk'.  The diagonal block holds U (upper triangle,
-  // added by k_point_pass): U - blk there, mirrored into the lower triangle.
+  // S is written full symmetric: block (a,b) = -blk, block (b,a) = -blk' (nobody else touches off-diagonal blocks)
   double* Sb = red + L.S() + (size_t)(6 * cam_a) * L.nc + 6 * cam_b;
-  if (cam_a != cam_b) {
-    double* St = red + L.S() + (size_t)(6 * cam_b) * L.nc + 6 * cam_a;
+  double* St = red + L.S() + (size_t)(6 * cam_b) * L.nc + 6 * cam_a;
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {
+  for (int p = 0; p < 6; ++p) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) { Sb[(size_t)p * L.nc + q] = -blk[6 * p + q]; St[(size_t)q * L.nc + p] = -blk[6 * p + q]; }
-    }
-  } else {
-#pragma unroll
-    for (int p = 0; p < 6; ++p) {
-#pragma unroll
-      for (int q = p; q < 6; ++q) {
-        const double v = Sb[(size_t)p * L.nc + q] - blk[6 * p + q];
-        Sb[(size_t)p * L.nc + q] = v;
-        Sb[(size_t)q * L.nc + p] = v;
-      }
-    }
-  }
-  if (cam_a == cam_b) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p) red[L.corr() + 6 * cam_a + p] = -(Ka[0 * 3 + p] * cr[0] + Ka[1 * 3 + p] * cr[1] + Ka[2 * 3 + p] * cr[2]);
-#pragma unroll
-    for (int p = 3; p < 6; ++p) red[L.corr() + 6 * cam_a + p] = -cr[p];
+    for (int q = 0; q < 6; ++q) { Sb[(size_t)p * L.nc + q] = -blk[6 * p + q]; St[(size_t)q * L.nc + p] = -blk[6 * p + q]; }
   }
 }
 

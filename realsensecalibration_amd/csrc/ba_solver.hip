@@ -137,7 +137,7 @@ namespace rsba {
 // ------------------------------------------------------------------------------------------------
 // Static structure of the tiled Schur kernel: visibility bitsets, tiles, segments.
 // ------------------------------------------------------------------------------------------------
-int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam) {
+int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v) {
   C = C_; P = P_;
   ngroups = (C + RSBA_TG - 1) / RSBA_TG;
   nwords = ((P + 63) / 64 + RSBA_CW - 1) / RSBA_CW * RSBA_CW;
@@ -194,8 +194,14 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       (rc = DevAlloc(&tile_ab, (size_t)3 * ntiles)) || (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, cmpos.size())) ||
-      (rc = DevAlloc(&sq_cm, cmpos.size())))
+      (rc = DevAlloc(&sq_cm, cmpos.size())) || (rc = DevAlloc(&u_cm, cmpos.size())) || (rc = DevAlloc(&v_cm, cmpos.size())))
     return rc;
+  {
+    std::vector<double> ucm(cmpos.size(), 0.0), vcm(cmpos.size(), 0.0);
+    for (int64_t q = 0; q < N; ++q) { ucm[cmpos[q]] = u[q]; vcm[cmpos[q]] = v[q]; }
+    HIPCHK(hipMemcpy(u_cm, ucm.data(), ucm.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(v_cm, vcm.data(), vcm.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMemcpy(cam_mask, mask.data(), mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(segs, sg.data(), sg.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(tile_seg_ptr, tsp.data(), tsp.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -207,7 +213,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, tile_seg_ptr, tile_ab, ptdata, partial, tile_sum, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm};
+  void* ptrs[] = {cam_mask, segs, tile_seg_ptr, tile_ab, ptdata, partial, tile_sum, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   cam_mask = nullptr;
 }
@@ -294,7 +300,7 @@ static int UploadPoints(rsba_solver* s) {
     if (dup) s->opt.schur_impl = 0;
   }
   if (s->opt.schur_impl != 0) {
-    rc = s->tiled.Build(C, P, ptr, cam);
+    rc = s->tiled.Build(C, P, ptr, cam, u, v);
     if (rc != RSBA_OK) return rc;
   } else if (maxk > 64) {
     fprintf(stderr, "rsba: schur_impl=0 handles at most 64 views per point (problem has %d)\n", maxk);
@@ -314,15 +320,15 @@ static int ResetPoints(rsba_solver* s) {
 int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
   hipStream_t st = s->stream;
   const int x = s->cur;
-  const bool stage = (size_t)C * (RSBA_PP_ACC + RSBA_CC_LDS) * sizeof(double) <= 56 * 1024;
-  const size_t lds = (size_t)C * (RSBA_PP_ACC + (stage ? RSBA_CC_LDS : 0)) * sizeof(double);
+  const bool stage = (size_t)C * RSBA_CC_LDS * sizeof(double) <= 56 * 1024;
+  const size_t lds = stage ? (size_t)C * RSBA_CC_LDS * sizeof(double) : 0;
   T.Begin("k_point_pass", st);
   if (stage)
-    k_point_pass<true><<<grid_pp, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p, ptdata, s->red,
-                                                  s->L, block_scal, cm_pos, sq_cm, ip);
+    k_point_pass<true><<<grid_pp, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p, ptdata,
+                                                  block_scal, cm_pos, sq_cm, ip);
   else
-    k_point_pass<false><<<grid_pp, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p, ptdata, s->red,
-                                                   s->L, block_scal, cm_pos, sq_cm, ip);
+    k_point_pass<false><<<grid_pp, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p, ptdata,
+                                                   block_scal, cm_pos, sq_cm, ip);
   T.End(st);
   T.Begin("k_finish_linearize", st);
   k_finish_linearize<<<1, 256, 0, st>>>(grid_pp, block_scal, s->red, s->L, s->gmax);
@@ -337,9 +343,9 @@ int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
   T.End(st);
   T.Begin("k_schur_self", st);
   if (ip.huber_delta > 0.0)
-    k_schur_self<true><<<nseg - nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial, nseg_pair);
+    k_schur_self<true><<<nseg - nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, u_cm, v_cm, partial, nseg_pair);
   else
-    k_schur_self<false><<<nseg - nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial, nseg_pair);
+    k_schur_self<false><<<nseg - nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, u_cm, v_cm, partial, nseg_pair);
   T.End(st);
   T.Begin("k_schur_reduce", st);
   k_schur_reduce<<<ntiles * RSBA_PART, 256, 0, st>>>(tile_seg_ptr, partial, tile_sum);
@@ -363,7 +369,8 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   k_camera_constants<<<(C + 63) / 64, 64, 0, st>>>(C, s->cam[x], s->intr, s->camc[x]);
   T.End(st);
   DebugSync(st, "k_camera_constants");
-  HIPCHK(hipMemsetAsync(s->red, 0, s->L.size() * sizeof(double), st));
+  // impl 0 accumulates into `red` with atomics; the tiled path writes every entry of it exactly once
+  if (s->opt.schur_impl == 0) HIPCHK(hipMemsetAsync(s->red, 0, s->L.size() * sizeof(double), st));
   DebugSync(st, "memset red");
 
   if (s->opt.schur_impl == 0) {
