@@ -199,6 +199,29 @@ __device__ __forceinline__ void SideRowsLds(const double* __restrict__ c, const 
   n1[0] = be * r3 + de * r6; n1[1] = be * r4 + de * r7; n1[2] = be * r5 + de * r8;
 }
 
+// The 120 pairs ia < ib of a diagonal tile, packed: lane t of waves 0/1 owns pair (kDiagIa[t], kDiagIb[t]); waves 2/3 of a
+// diagonal-tile workgroup retire right after the chunk is staged, so a diagonal tile costs two waves, not four.
+__device__ __constant__ unsigned char kDiagPair[128] = {
+#define RSBA_P(a, b) (unsigned char)((a) * 16 + (b))
+    RSBA_P(0,1),RSBA_P(0,2),RSBA_P(0,3),RSBA_P(0,4),RSBA_P(0,5),RSBA_P(0,6),RSBA_P(0,7),RSBA_P(0,8),RSBA_P(0,9),RSBA_P(0,10),RSBA_P(0,11),RSBA_P(0,12),RSBA_P(0,13),RSBA_P(0,14),RSBA_P(0,15),
+    RSBA_P(1,2),RSBA_P(1,3),RSBA_P(1,4),RSBA_P(1,5),RSBA_P(1,6),RSBA_P(1,7),RSBA_P(1,8),RSBA_P(1,9),RSBA_P(1,10),RSBA_P(1,11),RSBA_P(1,12),RSBA_P(1,13),RSBA_P(1,14),RSBA_P(1,15),
+    RSBA_P(2,3),RSBA_P(2,4),RSBA_P(2,5),RSBA_P(2,6),RSBA_P(2,7),RSBA_P(2,8),RSBA_P(2,9),RSBA_P(2,10),RSBA_P(2,11),RSBA_P(2,12),RSBA_P(2,13),RSBA_P(2,14),RSBA_P(2,15),
+    RSBA_P(3,4),RSBA_P(3,5),RSBA_P(3,6),RSBA_P(3,7),RSBA_P(3,8),RSBA_P(3,9),RSBA_P(3,10),RSBA_P(3,11),RSBA_P(3,12),RSBA_P(3,13),RSBA_P(3,14),RSBA_P(3,15),
+    RSBA_P(4,5),RSBA_P(4,6),RSBA_P(4,7),RSBA_P(4,8),RSBA_P(4,9),RSBA_P(4,10),RSBA_P(4,11),RSBA_P(4,12),RSBA_P(4,13),RSBA_P(4,14),RSBA_P(4,15),
+    RSBA_P(5,6),RSBA_P(5,7),RSBA_P(5,8),RSBA_P(5,9),RSBA_P(5,10),RSBA_P(5,11),RSBA_P(5,12),RSBA_P(5,13),RSBA_P(5,14),RSBA_P(5,15),
+    RSBA_P(6,7),RSBA_P(6,8),RSBA_P(6,9),RSBA_P(6,10),RSBA_P(6,11),RSBA_P(6,12),RSBA_P(6,13),RSBA_P(6,14),RSBA_P(6,15),
+    RSBA_P(7,8),RSBA_P(7,9),RSBA_P(7,10),RSBA_P(7,11),RSBA_P(7,12),RSBA_P(7,13),RSBA_P(7,14),RSBA_P(7,15),
+    RSBA_P(8,9),RSBA_P(8,10),RSBA_P(8,11),RSBA_P(8,12),RSBA_P(8,13),RSBA_P(8,14),RSBA_P(8,15),
+    RSBA_P(9,10),RSBA_P(9,11),RSBA_P(9,12),RSBA_P(9,13),RSBA_P(9,14),RSBA_P(9,15),
+    RSBA_P(10,11),RSBA_P(10,12),RSBA_P(10,13),RSBA_P(10,14),RSBA_P(10,15),
+    RSBA_P(11,12),RSBA_P(11,13),RSBA_P(11,14),RSBA_P(11,15),
+    RSBA_P(12,13),RSBA_P(12,14),RSBA_P(12,15),
+    RSBA_P(13,14),RSBA_P(13,15),
+    RSBA_P(14,15),
+    0, 0, 0, 0, 0, 0, 0, 0
+#undef RSBA_P
+};
+
 // Pair tiles (ga <= gb, a != b).  Two workgroups per CU: the accumulators (72 VGPRs) are the only long-lived
 // per-lane state; camera constants sit in LDS (broadcast within a 16-lane row / replicated across rows).
 template <bool kLoss>
@@ -211,9 +234,13 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
   __shared__ unsigned long long mk[2 * RSBA_TG][RSBA_CW];       // 2 KB
   __shared__ double sc[2 * RSBA_TG * RSBA_SC_STRIDE];           // 4 KB
   const SchurSeg sg = segs[blockIdx.x];
-  const int tid = threadIdx.x, ia = tid >> 4, ib = tid & 15;
+  const int tid = threadIdx.x;
+  const bool diag_tile = sg.ga == sg.gb;
+  // off-diagonal tile: lane = (ia, ib) directly; diagonal tile: the 120 pairs ia < ib sit in lanes 0..119
+  const int pr = diag_tile ? (tid < 120 ? kDiagPair[tid] : 0) : tid;
+  const int ia = pr >> 4, ib = pr & 15;
   const int cam_a = RSBA_TG * sg.ga + ia, cam_b = RSBA_TG * sg.gb + ib;
-  const bool live = cam_a < C && cam_b < C && (sg.ga != sg.gb || ia < ib);
+  const bool live = cam_a < C && cam_b < C && (!diag_tile || tid < 120);
   for (int i = tid; i < 2 * RSBA_TG * RSBA_SC_STRIDE; i += 256) {
     const int row = i / RSBA_SC_STRIDE, e = i - row * RSBA_SC_STRIDE;
     const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
@@ -289,11 +316,12 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
       }
     }
   }
+  // slot of pair (ia, ib) in the workgroup's partial block is ia*16+ib whatever lane computed it
   double* out = partial + (size_t)blockIdx.x * RSBA_PART * 256;
+  if (!diag_tile || tid < 120) {
 #pragma unroll
-  for (int i = 0; i < 36; ++i) out[i * 256 + tid] = acc[i];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) out[(36 + i) * 256 + tid] = 0.0;
+    for (int i = 0; i < 36; ++i) out[i * 256 + pr] = acc[i];
+  }
 }
 
 // Self tiles: everything that is a sum over ONE camera's observations — the diagonal block U_a - W V^-1 W' (a, a),
