@@ -255,8 +255,8 @@ k_linearize_schur_ref(int C, int P, const double* __restrict__ obs_u, const doub
 }
 
 // Second stage of the scalar reductions of K_A, fixed order -> red scalars (sum part) and gmax (max part).
-__global__ void k_finish_linearize(int nblocks, const double* __restrict__ block_scal, double* __restrict__ red,
-                                   RedLayout L, double* __restrict__ gmax_p) {
+__device__ __forceinline__ void FinishLinearize(int nblocks, const double* __restrict__ block_scal, double* __restrict__ red,
+                                                RedLayout L, double* __restrict__ gmax_p) {
   __shared__ double s[256][4];
   const int tid = threadIdx.x;
   double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -274,6 +274,10 @@ __global__ void k_finish_linearize(int nblocks, const double* __restrict__ block
     for (int q = 3; q < 8; ++q) red[L.scal() + q] = 0.0;
     *gmax_p = s[0][3];
   }
+}
+__global__ void k_finish_linearize(int nblocks, const double* __restrict__ block_scal, double* __restrict__ red,
+                                   RedLayout L, double* __restrict__ gmax_p) {
+  FinishLinearize(nblocks, block_scal, red, L, gmax_p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -608,7 +612,9 @@ k_backsub_candidate(int C, int P, const double* __restrict__ obs_u, const double
 
 // Second stage: fixed-order sum of the per-block partials into the small reduction payload
 // small[0..4] = {mcc, cost_c (sum rho), |dp|^2, |Xc|^2, sum sq residuals}
-__global__ void k_finish_candidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red) {
+__device__ __forceinline__ void PublishResult(const double* __restrict__ small_red, double* __restrict__ res);
+// res != nullptr (single GPU): publish straight away, no separate launch
+__global__ void k_finish_candidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red, double* __restrict__ res) {
   __shared__ double s[5][256];
   const int tid = threadIdx.x;
   double v[5] = {0, 0, 0, 0, 0};
@@ -627,19 +633,24 @@ __global__ void k_finish_candidate(int nblocks, const double* __restrict__ block
     __syncthreads();
   }
   if (tid < 5) small_red[tid] = s[tid][0];
+  if (res != nullptr) {
+    __syncthreads();
+    if (tid == 0) { double sr[5]; for (int q = 0; q < 5; ++q) sr[q] = s[q][0]; PublishResult(sr, res); }
+  }
 }
 
 // Folds the (all-reduced) point-side sums into the result block the host reads.
+__device__ __forceinline__ void PublishResult(const double* __restrict__ small_red, double* __restrict__ res) {
+  res[RES_MCC] = small_red[0];
+  double c = 0.5 * small_red[1];
+  if (!(c == c) || !(fabs(c) <= DBL_MAX)) c = DBL_MAX;  // Ceres: failed evaluation -> max double
+  res[RES_COST_C] = c;
+  res[RES_STEP2] += small_red[2];
+  res[RES_XCNORM2] += small_red[3];
+  res[RES_SUMSQ_C] = small_red[4];
+}
 __global__ void k_publish_result(const double* __restrict__ small_red, double* __restrict__ res) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    res[RES_MCC] = small_red[0];
-    double c = 0.5 * small_red[1];
-    if (!(c == c) || !(fabs(c) <= DBL_MAX)) c = DBL_MAX;  // Ceres: failed evaluation -> max double
-    res[RES_COST_C] = c;
-    res[RES_STEP2] += small_red[2];
-    res[RES_XCNORM2] += small_red[3];
-    res[RES_SUMSQ_C] = small_red[4];
-  }
+  if (threadIdx.x == 0 && blockIdx.x == 0) PublishResult(small_red, res);
 }
 
 // Cost only at the current point-model parameters (used by rsba_reprojection_error).

@@ -434,9 +434,12 @@ k_schur_reduce(const int* __restrict__ tile_seg_ptr, const double* __restrict__ 
 // slices with a shuffle reduction inside each 16-lane row.
 __global__ void __launch_bounds__(256)
 k_schur_finish(int C, int ntiles, const int* __restrict__ tile_ab, const double* __restrict__ tile_sum,
-               const double* __restrict__ camc, double* __restrict__ red, RedLayout L) {
+               const double* __restrict__ camc, double* __restrict__ red, RedLayout L, int nblocks_pp,
+               const double* __restrict__ block_scal, double* __restrict__ gmax_p) {
   const int tile = blockIdx.x, tid = threadIdx.x;
-  if (tile >= ntiles) return;
+  // one extra workgroup folds the point pass' per-block scalars (cost, |X|^2, failures, max|g_p|): saves a launch
+  if (tile == ntiles) { FinishLinearize(nblocks_pp, block_scal, red, L, gmax_p); return; }
+  if (tile > ntiles) return;
   const int ga = tile_ab[3 * tile], gb = tile_ab[3 * tile + 1];
   const bool self_tile = tile_ab[3 * tile + 2] != 0;
   const int ia = tid >> 4, ib = tid & 15;

@@ -330,9 +330,6 @@ int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
     k_point_pass<false><<<grid_pp, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p, ptdata,
                                                    block_scal, cm_pos, sq_cm, ip);
   T.End(st);
-  T.Begin("k_finish_linearize", st);
-  k_finish_linearize<<<1, 256, 0, st>>>(grid_pp, block_scal, s->red, s->L, s->gmax);
-  T.End(st);
   T.Begin("k_schur_pairs", st);
   if (nseg_pair > 0) {
     if (ip.huber_delta > 0.0)
@@ -351,7 +348,7 @@ int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
   k_schur_reduce<<<ntiles * RSBA_PART, 256, 0, st>>>(tile_seg_ptr, partial, tile_sum);
   T.End(st);
   T.Begin("k_schur_finish", st);
-  k_schur_finish<<<ntiles, 256, 0, st>>>(C, ntiles, tile_ab, tile_sum, s->camc[x], s->red, s->L);
+  k_schur_finish<<<ntiles + 1, 256, 0, st>>>(C, ntiles, tile_ab, tile_sum, s->camc[x], s->red, s->L, grid_pp, block_scal, s->gmax);
   T.End(st);
   return RSBA_OK;
 }
@@ -365,9 +362,13 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   KernelTimer& T = s->timer;
 
   DebugSync(st, "enter PointsStep");
-  T.Begin("k_camera_constants", st);
-  k_camera_constants<<<(C + 63) / 64, 64, 0, st>>>(C, s->cam[x], s->intr, s->camc[x]);
-  T.End(st);
+  // camera constants at x: only the first step of a run computes them; afterwards x is either unchanged (rejected step)
+  // or the former candidate, whose constants k_reduced_system_solve already wrote into camc[c] before the swap
+  if (first) {
+    T.Begin("k_camera_constants", st);
+    k_camera_constants<<<(C + 63) / 64, 64, 0, st>>>(C, s->cam[x], s->intr, s->camc[x]);
+    T.End(st);
+  }
   DebugSync(st, "k_camera_constants");
   // impl 0 accumulates into `red` with atomics; the tiled path writes every entry of it exactly once
   if (s->opt.schur_impl == 0) HIPCHK(hipMemsetAsync(s->red, 0, s->L.size() * sizeof(double), st));
@@ -427,10 +428,12 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   T.End(st);
   DebugSync(st, "k_backsub_candidate");
   T.Begin("k_finish_candidate", st);
-  k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red);
+  k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, s->comm ? nullptr : s->res);
   T.End(st);
-  if (s->comm) NCCLCHK(ncclAllReduce(s->small_red, s->small_red, 8, ncclDouble, ncclSum, s->comm, st));
-  k_publish_result<<<1, 64, 0, st>>>(s->small_red, s->res);
+  if (s->comm) {
+    NCCLCHK(ncclAllReduce(s->small_red, s->small_red, 8, ncclDouble, ncclSum, s->comm, st));
+    k_publish_result<<<1, 64, 0, st>>>(s->small_red, s->res);
+  }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(s->res_host, s->res, RES_SIZE * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -702,7 +705,7 @@ int rsba_reprojection_error(rsba_problem* p, const rsba_options* o, double* erro
     if (rc == RSBA_OK) {
       k_camera_constants<<<(s->C + 63) / 64, 64, 0, s->stream>>>(s->C, s->cam[0], s->intr, s->camc[0]);
       k_cost_only<<<s->grid_pts, 256, 0, s->stream>>>(s->P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[0], s->pts[0], s->block_part, 0.0);
-      k_finish_candidate<<<1, 256, 0, s->stream>>>(s->grid_pts, s->block_part, s->small_red);
+      k_finish_candidate<<<1, 256, 0, s->stream>>>(s->grid_pts, s->block_part, s->small_red, nullptr);
       double h[8];
       if (hipMemcpyAsync(h, s->small_red, 8 * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) rc = RSBA_ERR_HIP;
       sumsq = h[4]; npts = p->num_observations;
