@@ -253,3 +253,16 @@ def test_solve_is_bitwise_reproducible():
     a, sa, la = capi.solve_points(prob)
     b, sb, lb = capi.solve_points(prob)
     assert np.array_equal(a, b) and np.array_equal(la, lb) and sa.final_cost == sb.final_cost
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_more_than_64_cameras_and_huber(oracle, impl):
+    """C = 70: reduced system 420 x 420, larger than the LDS-panel Cholesky handles (the global-memory factorisation
+    takes over), 5 camera groups (15 pair tiles + 5 self tiles), camera constants no longer LDS-staged in the
+    back-substitution; with Huber loss and outliers as BASELINE.json configs[4] asks."""
+    prob = syn.make_problem(70, 1500, 10, seed=5, outlier_frac=0.05)
+    _compare_solve(oracle, prob, impl, huber=1.0)
+    a = oracle.points_linearize_and_step(prob, prob["params"], 1e4, opts=oracle.options(huber_delta=1.0))
+    b = capi.points_linearize_and_step(prob, 1e4, capi.default_options(schur_impl=impl, huber_delta=1.0))
+    assert np.abs(b["S"] - a["S"]).max() < 1e-10 * np.abs(a["S"]).max()
+    assert np.abs(b["delta"] - a["delta"]).max() < 1e-7 * np.abs(a["delta"]).max()
