@@ -45,7 +45,9 @@ class KernelTimer;
 #define RSBA_PT_STRIDE 12   // X(3) Vinv(6) y(3)
 #define RSBA_PART 42        // 36 block + 6 corr
 
-struct SchurSeg { int ga, gb, chunk_begin, chunk_end, self, pad0, pad1, pad2; };
+// A segment is a range of 64-point mask words of one tile (not necessarily chunk-aligned: small problems get as many
+// workgroups as they have words).
+struct SchurSeg { int ga, gb, word_begin, word_end, self, pad0, pad1, pad2; };
 
 struct TiledSchur {
   int C = 0, P = 0, ngroups = 0, nwords = 0, nchunks = 0, nseg = 0, nseg_pair = 0, grid_pp = 0;
@@ -255,15 +257,16 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
 #pragma unroll
   for (int i = 0; i < 36; ++i) acc[i] = 0.0;
 
-  for (int ch = sg.chunk_begin; ch < sg.chunk_end; ++ch) {
-    const int j0 = ch * RSBA_CHUNK;
-    const int np = min(RSBA_CHUNK, P - j0);
+  for (int wb = sg.word_begin; wb < sg.word_end; wb += RSBA_CW) {
+    const int nwc = min(RSBA_CW, sg.word_end - wb);  // words of this LDS chunk
+    const int j0 = wb * 64;
+    const int np = max(0, min(nwc * 64, P - j0));
     __syncthreads();
     for (int i = tid; i < np * RSBA_PT_STRIDE; i += 256) pt[i] = ptdata[(size_t)j0 * RSBA_PT_STRIDE + i];
     {
       const int row = tid >> 3, w = tid & 7;  // 32 rows x 8 words = 256 threads
       const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
-      mk[row][w] = cam < C ? cam_mask[(size_t)cam * nwords + (size_t)ch * RSBA_CW + w] : 0ull;
+      mk[row][w] = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
     }
     __syncthreads();
     // every lane walks ITS OWN hit list through the whole chunk: the word index is per lane, so a wave
@@ -286,7 +289,7 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
       if (kLoss) {
         // rank of this point in each camera's own observation list -> its sqrt(rho')
         const unsigned long long below = (1ull << bit) - 1ull;
-        const int gw = ch * RSBA_CW + wcur;
+        const int gw = wb + wcur;
         sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + gw] + __popcll(mk[ia][wcur] & below)];
         sqb = sq_cm[cam_ptr[cam_b] + cam_prefix[(size_t)cam_b * nwords + gw] + __popcll(mk[RSBA_TG + ib][wcur] & below)];
       }
@@ -355,15 +358,16 @@ k_schur_self(int C, int P, int nwords, const double* __restrict__ camc, const Sc
   double acc[RSBA_PART];
 #pragma unroll
   for (int i = 0; i < RSBA_PART; ++i) acc[i] = 0.0;
-  for (int ch = sg.chunk_begin; ch < sg.chunk_end; ++ch) {
-    const int j0 = ch * RSBA_CHUNK;
-    const int np = min(RSBA_CHUNK, P - j0);
+  for (int wb = sg.word_begin; wb < sg.word_end; wb += RSBA_CW) {
+    const int nwc = min(RSBA_CW, sg.word_end - wb);
+    const int j0 = wb * 64;
+    const int np = max(0, min(nwc * 64, P - j0));
     __syncthreads();
     for (int i = tid; i < np * RSBA_PT_STRIDE; i += 256) pt[i] = ptdata[(size_t)j0 * RSBA_PT_STRIDE + i];
     if (tid < RSBA_TG * RSBA_CW) {
       const int row = tid >> 3, w = tid & 7;
       const int cam = RSBA_TG * sg.ga + row;
-      mk[row][w] = cam < C ? cam_mask[(size_t)cam * nwords + (size_t)ch * RSBA_CW + w] : 0ull;
+      mk[row][w] = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
     }
     __syncthreads();
     int w = 0;
@@ -379,7 +383,7 @@ k_schur_self(int C, int P, int nwords, const double* __restrict__ camc, const Sc
       const double X[3] = {pd[0], pd[1], pd[2]};
       const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
       // rank of this point in the camera's own observation list
-      const int oi = obs0 + cam_prefix[(size_t)cam_a * nwords + ch * RSBA_CW + wcur] + __popcll(mk[ia][wcur] & ((1ull << bit) - 1ull));
+      const int oi = obs0 + cam_prefix[(size_t)cam_a * nwords + wb + wcur] + __popcll(mk[ia][wcur] & ((1ull << bit) - 1ull));
       const double sqa = kLoss ? sq_cm[oi] : 1.0;
       const double uu = u_cm[oi], vv = v_cm[oi];
       double e0[6], e1[6], n0[3], n1[3];

@@ -176,11 +176,12 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   for (int t = 0; t < ntiles; ++t) {
     const bool self = tab[3 * t + 2] != 0;
     int ns = self ? (2 * cus + ngroups - 1) / ngroups : (int)std::lround((double)target / std::max(1, npair_tiles));
-    ns = std::max(1, std::min(ns, nchunks));
+    const int nW = (P + 63) / 64;  // mask words that hold points
+    ns = std::max(1, std::min(ns, nW));
     for (int i = 0; i < ns; ++i) {
       SchurSeg e; memset(&e, 0, sizeof(e));
       e.ga = tab[3 * t]; e.gb = tab[3 * t + 1]; e.self = tab[3 * t + 2];
-      e.chunk_begin = (int)((int64_t)nchunks * i / ns); e.chunk_end = (int)((int64_t)nchunks * (i + 1) / ns);
+      e.word_begin = (int)((int64_t)nW * i / ns); e.word_end = (int)((int64_t)nW * (i + 1) / ns);
       sg.push_back(e);
     }
     tsp[t + 1] = (int)sg.size();
