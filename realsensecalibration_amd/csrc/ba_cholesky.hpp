@@ -241,8 +241,18 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
         invd[j] = il;  // wave-uniform value
         // a_ic -= l_ij l_cj with l_cj read straight out of lane c's register (v_readlane -> SGPR operand): no LDS
         // round trip on the critical path.  Entries above the diagonal (c > row) pick up garbage; never read.
+        // groups of four: the eight v_readlane of a group issue back to back, so the SGPR-write -> VALU-read hazard
+        // of one value is covered by the next ones instead of s_nops
 #pragma unroll
-        for (int c = j + 1; c < RSBA_PB; ++c) { row[c] -= lij * ReadLaneD(lij, c); asm volatile("" : "+v"(row[c])); }
+        for (int c0 = j + 1; c0 < RSBA_PB; c0 += 4) {
+          double lc[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) lc[u] = (c0 + u < RSBA_PB) ? ReadLaneD(lij, c0 + u) : 0.0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (c0 + u < RSBA_PB) row[c0 + u] -= lij * lc[u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (c0 + u < RSBA_PB) asm volatile("" : "+v"(row[c0 + u]));
+        }
       }
       // padded factor -> Lt (32 x 33); the real rows also back into the panel
 #pragma unroll
@@ -257,19 +267,51 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
 #ifdef RSBA_PROFILE_PHASES
       if (lane == 0) { long long _w1 = clock64(); g_phase_cycles[10] += _w1 - _w0; _w0 = _w1; }
 #endif
-      // T = L11^-1, column lr: t_i = (delta_i,lr - sum_{q<i} L[i][q] t_q) / L[i][i]   (L11 reads are broadcasts)
-      double t[RSBA_PB];
+      // T = L11^-1 in 16 x 16 blocks: T = [[T11, 0], [-T22 L21 T11, T22]].  Lanes 0..15 invert the top-left block and
+      // lanes 16..31 the bottom-right one at the same time (column lr & 15 each, a 16-step chain instead of 32); the
+      // off-diagonal block is two 16x16x16 products on the matrix cores.
+      {
+        const int hb = lr & 16;          // 0: block (0,0), 16: block (1,1)
+        const int lc = lr & 15;          // column inside the block
+        double t[16];
 #pragma unroll
-      for (int i = 0; i < RSBA_PB; ++i) {
-        double sacc = (i == lr) ? 1.0 : 0.0, sacc2 = 0.0;  // two chains: the sum is latency-bound on one wave
+        for (int i = 0; i < 16; ++i) {
+          double sacc = (i == lc) ? 1.0 : 0.0, sacc2 = 0.0;
 #pragma unroll
-        for (int q = 0; q < RSBA_PB; ++q) if (q < i) { if (q & 1) sacc2 -= ReadLaneD(row[q], i) * t[q]; else sacc -= ReadLaneD(row[q], i) * t[q]; }  // L[i][q] lives in lane i
-        t[i] = (sacc + sacc2) * ReadLaneD(ilv, i);
-        asm volatile("" : "+v"(t[i]));
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          for (int q = 0; q < 16; ++q) {
+            if (q < i) {
+              // L[hb + i][hb + q] lives in lane hb + i, register row[hb + q]
+              const double la = ReadLaneD(row[q], i), lb = ReadLaneD(row[16 + q], 16 + i);
+              const double lv = hb ? lb : la;
+              if (q & 1) sacc2 -= lv * t[q]; else sacc -= lv * t[q];
+            }
+          }
+          const double ia_ = ReadLaneD(ilv, i), ib_ = ReadLaneD(ilv, 16 + i);
+          t[i] = (sacc + sacc2) * (hb ? ib_ : ia_);
+          asm volatile("" : "+v"(t[i]));
+        }
+        // diagonal blocks into the T tile; M1 scratch = T[0..15][16..31]
+        if (lane < RSBA_PB) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) T[(hb + i) * RSBA_PLD + hb + lc] = t[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int mi = lane & 15, mk = lane >> 4;
+        // M1 = L21 T11:  A[i][k] = L[16+i][k] (Lt), B[k][j] = T11[k][j]
+        d4_t m1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 4) m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[(16 + mi) * RSBA_PLD + ks + mk], T[(ks + mk) * RSBA_PLD + mi], m1, 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) T[(mk + 4 * tt) * RSBA_PLD + 16 + mi] = m1[tt];   // M1[row][col] -> scratch quadrant
+        __builtin_amdgcn_wave_barrier();
+        // T21 = -T22 M1:  A[i][k] = T22[i][k] = T[16+i][16+k], B[k][j] = M1[k][j]
+        d4_t t21 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 4) t21 = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(16 + mi) * RSBA_PLD + 16 + ks + mk], T[(ks + mk) * RSBA_PLD + 16 + mi], t21, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) { T[(16 + mk + 4 * tt) * RSBA_PLD + mi] = -t21[tt]; T[(mk + 4 * tt) * RSBA_PLD + 16 + mi] = 0.0; }
       }
-#pragma unroll
-      for (int i = 0; i < RSBA_PB; ++i) T[i * RSBA_PLD + lr] = t[i];
 #ifdef RSBA_PROFILE_PHASES
       if (lane == 0) g_phase_cycles[11] += clock64() - _w0;
 #endif
