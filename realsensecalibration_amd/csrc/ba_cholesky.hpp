@@ -64,6 +64,173 @@ struct PanelSource {
   double lo, hi, inv_radius;
 };
 
+// Factor the padded 32 x 32 diagonal block held in LDS (rows of `Pd`, stride RSBA_PLD) and invert it.  One wavefront.
+// Out: Pd rows < nb = L11 (upper part zeroed), Lt = padded L11, T = L11^-1, invd = 1/diag.  Returns false on a
+// non-positive pivot.  (Rows/columns >= nb are padded with identity so all 32 steps run unconditionally; lanes 32..63
+// shadow lanes 0..31, so the whole sequence is one branch-free basic block.  The empty asm statements pin every updated
+// value at its step: without them LLVM sinks the updates towards their uses and spills ~1300 registers.)
+__device__ __forceinline__ bool DiagFactorInverse(double* __restrict__ Pan, int nb, double* __restrict__ T, double* __restrict__ Lt,
+                                                  double* __restrict__ invd, int lane) {
+#ifdef RSBA_PROFILE_PHASES
+      long long _w0 = clock64();
+#endif
+      double row[RSBA_PB];
+      const int lr = lane & 31;
+#pragma unroll
+      for (int c = 0; c < RSBA_PB; ++c) row[c] = (lr < nb) ? Pan[lr * RSBA_PLD + c] : (c == lr ? 1.0 : 0.0);
+      bool good = true;
+      double ilv = 1.0;  // 1 / L[lr][lr]
+#pragma unroll
+      for (int j = 0; j < RSBA_PB; ++j) {
+        const double d = ReadLaneD(row[j], j);
+        if (!(d > 0.0) || !(d <= DBL_MAX)) good = false;
+        const double dd = good ? d : 1.0;
+        // il = 1/sqrt(d): hardware estimate + two Newton steps (full fp64); l = d * il
+        double il = __builtin_amdgcn_rsq(dd);
+        il = il * (1.5 - 0.5 * dd * il * il);
+        il = il * (1.5 - 0.5 * dd * il * il);
+        const double lij = (lr == j) ? dd * il : row[j] * il;
+        row[j] = lij;
+        if (lr == j) ilv = il;
+        invd[j] = il;  // wave-uniform value
+        // a_ic -= l_ij l_cj with l_cj read straight out of lane c's register (v_readlane -> SGPR operand): no LDS
+        // round trip on the critical path.  Entries above the diagonal (c > row) pick up garbage; never read.
+        // groups of four: the eight v_readlane of a group issue back to back, so the SGPR-write -> VALU-read hazard
+        // of one value is covered by the next ones instead of s_nops
+#pragma unroll
+        for (int c0 = j + 1; c0 < RSBA_PB; c0 += 4) {
+          double lc[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) lc[u] = (c0 + u < RSBA_PB) ? ReadLaneD(lij, c0 + u) : 0.0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (c0 + u < RSBA_PB) row[c0 + u] -= lij * lc[u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (c0 + u < RSBA_PB) asm volatile("" : "+v"(row[c0 + u]));
+        }
+      }
+      // padded factor -> Lt (32 x 33); the real rows also back into the panel
+#pragma unroll
+      for (int c = 0; c < RSBA_PB; ++c) {
+        const double v = (c <= lr) ? row[c] : 0.0;
+        Lt[lr * RSBA_PLD + c] = v;
+        if (lr < nb) Pan[lr * RSBA_PLD + c] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef RSBA_PROFILE_PHASES
+      if (lane == 0) { long long _w1 = clock64(); g_phase_cycles[10] += _w1 - _w0; _w0 = _w1; }
+#endif
+      // T = L11^-1 in 16 x 16 blocks: T = [[T11, 0], [-T22 L21 T11, T22]].  Lanes 0..15 invert the top-left block and
+      // lanes 16..31 the bottom-right one at the same time (column lr & 15 each, a 16-step chain instead of 32); the
+      // off-diagonal block is two 16x16x16 products on the matrix cores.
+      {
+        const int hb = lr & 16;          // 0: block (0,0), 16: block (1,1)
+        const int lc = lr & 15;          // column inside the block
+        double t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          double sacc = (i == lc) ? 1.0 : 0.0, sacc2 = 0.0;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            if (q < i) {
+              // L[hb + i][hb + q] lives in lane hb + i, register row[hb + q]
+              const double la = ReadLaneD(row[q], i), lb = ReadLaneD(row[16 + q], 16 + i);
+              const double lv = hb ? lb : la;
+              if (q & 1) sacc2 -= lv * t[q]; else sacc -= lv * t[q];
+            }
+          }
+          const double ia_ = ReadLaneD(ilv, i), ib_ = ReadLaneD(ilv, 16 + i);
+          t[i] = (sacc + sacc2) * (hb ? ib_ : ia_);
+          asm volatile("" : "+v"(t[i]));
+        }
+        // diagonal blocks into the T tile; M1 scratch = T[0..15][16..31]
+        if (lane < RSBA_PB) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) T[(hb + i) * RSBA_PLD + hb + lc] = t[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int mi = lane & 15, mk = lane >> 4;
+        // M1 = L21 T11:  A[i][k] = L[16+i][k] (Lt), B[k][j] = T11[k][j]
+        d4_t m1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 4) m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[(16 + mi) * RSBA_PLD + ks + mk], T[(ks + mk) * RSBA_PLD + mi], m1, 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) T[(mk + 4 * tt) * RSBA_PLD + 16 + mi] = m1[tt];   // M1[row][col] -> scratch quadrant
+        __builtin_amdgcn_wave_barrier();
+        // T21 = -T22 M1:  A[i][k] = T22[i][k] = T[16+i][16+k], B[k][j] = M1[k][j]
+        d4_t t21 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 4) t21 = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(16 + mi) * RSBA_PLD + 16 + ks + mk], T[(ks + mk) * RSBA_PLD + 16 + mi], t21, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) { T[(16 + mk + 4 * tt) * RSBA_PLD + mi] = -t21[tt]; T[(mk + 4 * tt) * RSBA_PLD + 16 + mi] = 0.0; }
+      }
+#ifdef RSBA_PROFILE_PHASES
+      if (lane == 0) g_phase_cycles[11] += clock64() - _w0;
+#endif
+  return good;
+}
+
+// Blocked back-substitution L' x = y with the stored block inverses; y (row n of A) is copied to LDS and holds x on
+// return (first n doubles of `lds`).  All threads of the workgroup.
+__device__ __forceinline__ double* BackSubstituteBlocks(int n, double* __restrict__ A, double* lds) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // Back-substitution L' x = y, right-looking from the bottom: x_blk = T' y_blk with the stored T = L11^-1
+  // (T'[c][i] = T[i][c], i >= c; no sequential step), then y[0:kb] -= L[kb:kb+nb, 0:kb]' x_blk, which reads the
+  // block's rows of L contiguously (one round of global latency per block).
+  double* y = lds;                                 // n
+  double* Tb = lds + ((n + 63) & ~63);             // 32 x 33: Tb[i][c] = T[i][c]
+  double* xb = Tb + RSBA_PB * RSBA_PLD;            // 32
+  for (int i = tid; i < n; i += nt) y[i] = A[(size_t)n * n + i];
+  __syncthreads();
+  // Global loads are issued a phase early: the T block of the NEXT block row is fetched while this one is solved, and
+  // the strip of L this block multiplies is fetched before x_blk exists (it does not depend on it).
+  const int kb_last = ((n - 1) / RSBA_PB) * RSBA_PB;
+  double tpre[2] = {0.0, 0.0};  // this thread's two entries of the next T block (nt = 512: 1024 entries)
+  auto fetch_T = [&](int kb, int slot) {
+    const int e = tid + slot * nt;
+    const int nbk = min(RSBA_PB, n - kb);
+    const int i = e >> 5, c = e & 31;
+    double tv = 0.0;
+    // T[i][c] for i > c sits at A[kb+c][kb+i]; the diagonal in row n+1
+    if (e < RSBA_PB * RSBA_PB && i < nbk && c < nbk) tv = (i > c) ? A[(size_t)(kb + c) * n + kb + i] : (i == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
+    return tv;
+  };
+  for (int sl = 0; sl < 2; ++sl) tpre[sl] = (tid + sl * nt < RSBA_PB * RSBA_PB) ? fetch_T(kb_last, sl) : 0.0;
+  for (int kb = kb_last; kb >= 0; kb -= RSBA_PB) {
+    const int nb = min(RSBA_PB, n - kb);
+    for (int sl = 0; sl < 2; ++sl) { const int e = tid + sl * nt; if (e < RSBA_PB * RSBA_PB) Tb[(e >> 5) * RSBA_PLD + (e & 31)] = tpre[sl]; }
+    // strip of L for this block (rows kb..kb+nb, column q = tid): independent of x_blk, so load it now
+    double lv[RSBA_PB];
+    const int q = tid;  // kb <= 352 < nt
+#pragma unroll
+    for (int c = 0; c < RSBA_PB; ++c) lv[c] = (c < nb && q < kb) ? A[(size_t)(kb + c) * n + q] : 0.0;
+    if (kb >= RSBA_PB) { for (int sl = 0; sl < 2; ++sl) tpre[sl] = (tid + sl * nt < RSBA_PB * RSBA_PB) ? fetch_T(kb - RSBA_PB, sl) : 0.0; }
+    __syncthreads();
+    if (tid < RSBA_PB) {
+      double sacc = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < RSBA_PB; ++i) sacc += Tb[i * RSBA_PLD + tid] * ((i < nb) ? y[kb + i] : 0.0);
+      xb[tid] = (tid < nb) ? sacc : 0.0;
+    }
+    __syncthreads();
+    if (tid < nb) y[kb + tid] = xb[tid];
+    if (q < kb) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int c = 0; c < RSBA_PB; ++c) sacc += lv[c] * xb[c];
+      y[q] -= sacc;
+    }
+    for (int q2 = tid + nt; q2 < kb; q2 += nt) {  // n > 512 never reaches here (RSBA_CHOL_MAXN), kept for safety
+      double sacc = 0.0;
+      for (int c = 0; c < nb; ++c) sacc += A[(size_t)(kb + c) * n + q2] * xb[c];
+      y[q2] -= sacc;
+    }
+    __syncthreads();
+  }
+  return y;
+}
+
 // A: (n+2) x n row-major in global memory; rows 0..n-1 the SPD matrix (lower triangle read), row n the rhs,
 // row n+1 scratch (inverse pivots).  On return the lower triangle holds L, row n holds y = L^-1 rhs, x_out x.
 __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __restrict__ x_out, int* ok_out, double* lds, PanelSource src) {
@@ -217,104 +384,7 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     //    whole sequence is one branch-free basic block.  The empty asm statements pin every updated value at
     //    its step: without them LLVM sinks the updates towards their uses and spills ~1300 registers.
     if (wave == 0) {
-#ifdef RSBA_PROFILE_PHASES
-      long long _w0 = clock64();
-#endif
-      double row[RSBA_PB];
-      const int lr = lane & 31;
-#pragma unroll
-      for (int c = 0; c < RSBA_PB; ++c) row[c] = (lr < nb) ? Pan[lr * RSBA_PLD + c] : (c == lr ? 1.0 : 0.0);
-      bool good = true;
-      double ilv = 1.0;  // 1 / L[lr][lr]
-#pragma unroll
-      for (int j = 0; j < RSBA_PB; ++j) {
-        const double d = ReadLaneD(row[j], j);
-        if (!(d > 0.0) || !(d <= DBL_MAX)) good = false;
-        const double dd = good ? d : 1.0;
-        // il = 1/sqrt(d): hardware estimate + two Newton steps (full fp64); l = d * il
-        double il = __builtin_amdgcn_rsq(dd);
-        il = il * (1.5 - 0.5 * dd * il * il);
-        il = il * (1.5 - 0.5 * dd * il * il);
-        const double lij = (lr == j) ? dd * il : row[j] * il;
-        row[j] = lij;
-        if (lr == j) ilv = il;
-        invd[j] = il;  // wave-uniform value
-        // a_ic -= l_ij l_cj with l_cj read straight out of lane c's register (v_readlane -> SGPR operand): no LDS
-        // round trip on the critical path.  Entries above the diagonal (c > row) pick up garbage; never read.
-        // groups of four: the eight v_readlane of a group issue back to back, so the SGPR-write -> VALU-read hazard
-        // of one value is covered by the next ones instead of s_nops
-#pragma unroll
-        for (int c0 = j + 1; c0 < RSBA_PB; c0 += 4) {
-          double lc[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) lc[u] = (c0 + u < RSBA_PB) ? ReadLaneD(lij, c0 + u) : 0.0;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) if (c0 + u < RSBA_PB) row[c0 + u] -= lij * lc[u];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) if (c0 + u < RSBA_PB) asm volatile("" : "+v"(row[c0 + u]));
-        }
-      }
-      // padded factor -> Lt (32 x 33); the real rows also back into the panel
-#pragma unroll
-      for (int c = 0; c < RSBA_PB; ++c) {
-        const double v = (c <= lr) ? row[c] : 0.0;
-        Lt[lr * RSBA_PLD + c] = v;
-        if (lr < nb) Pan[lr * RSBA_PLD + c] = v;
-      }
-      if (lane == 0 && !good) s_ok = 0;
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef RSBA_PROFILE_PHASES
-      if (lane == 0) { long long _w1 = clock64(); g_phase_cycles[10] += _w1 - _w0; _w0 = _w1; }
-#endif
-      // T = L11^-1 in 16 x 16 blocks: T = [[T11, 0], [-T22 L21 T11, T22]].  Lanes 0..15 invert the top-left block and
-      // lanes 16..31 the bottom-right one at the same time (column lr & 15 each, a 16-step chain instead of 32); the
-      // off-diagonal block is two 16x16x16 products on the matrix cores.
-      {
-        const int hb = lr & 16;          // 0: block (0,0), 16: block (1,1)
-        const int lc = lr & 15;          // column inside the block
-        double t[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          double sacc = (i == lc) ? 1.0 : 0.0, sacc2 = 0.0;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            if (q < i) {
-              // L[hb + i][hb + q] lives in lane hb + i, register row[hb + q]
-              const double la = ReadLaneD(row[q], i), lb = ReadLaneD(row[16 + q], 16 + i);
-              const double lv = hb ? lb : la;
-              if (q & 1) sacc2 -= lv * t[q]; else sacc -= lv * t[q];
-            }
-          }
-          const double ia_ = ReadLaneD(ilv, i), ib_ = ReadLaneD(ilv, 16 + i);
-          t[i] = (sacc + sacc2) * (hb ? ib_ : ia_);
-          asm volatile("" : "+v"(t[i]));
-        }
-        // diagonal blocks into the T tile; M1 scratch = T[0..15][16..31]
-        if (lane < RSBA_PB) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) T[(hb + i) * RSBA_PLD + hb + lc] = t[i];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int mi = lane & 15, mk = lane >> 4;
-        // M1 = L21 T11:  A[i][k] = L[16+i][k] (Lt), B[k][j] = T11[k][j]
-        d4_t m1 = {0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < 16; ks += 4) m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[(16 + mi) * RSBA_PLD + ks + mk], T[(ks + mk) * RSBA_PLD + mi], m1, 0, 0, 0);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) T[(mk + 4 * tt) * RSBA_PLD + 16 + mi] = m1[tt];   // M1[row][col] -> scratch quadrant
-        __builtin_amdgcn_wave_barrier();
-        // T21 = -T22 M1:  A[i][k] = T22[i][k] = T[16+i][16+k], B[k][j] = M1[k][j]
-        d4_t t21 = {0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < 16; ks += 4) t21 = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(16 + mi) * RSBA_PLD + 16 + ks + mk], T[(ks + mk) * RSBA_PLD + 16 + mi], t21, 0, 0, 0);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) { T[(16 + mk + 4 * tt) * RSBA_PLD + mi] = -t21[tt]; T[(mk + 4 * tt) * RSBA_PLD + 16 + mi] = 0.0; }
-      }
-#ifdef RSBA_PROFILE_PHASES
-      if (lane == 0) g_phase_cycles[11] += clock64() - _w0;
-#endif
+      if (!DiagFactorInverse(Pan, nb, T, Lt, invd, lane) && lane == 0) s_ok = 0;
     }
     __syncthreads();
     RSBA_STAMP(2);
@@ -363,59 +433,7 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     RSBA_STAMP(4);
   }
 
-  // Back-substitution L' x = y, right-looking from the bottom: x_blk = T' y_blk with the stored T = L11^-1
-  // (T'[c][i] = T[i][c], i >= c; no sequential step), then y[0:kb] -= L[kb:kb+nb, 0:kb]' x_blk, which reads the
-  // block's rows of L contiguously (one round of global latency per block).
-  double* y = lds;                                 // n
-  double* Tb = lds + ((n + 63) & ~63);             // 32 x 33: Tb[i][c] = T[i][c]
-  double* xb = Tb + RSBA_PB * RSBA_PLD;            // 32
-  for (int i = tid; i < n; i += nt) y[i] = A[(size_t)n * n + i];
-  __syncthreads();
-  // Global loads are issued a phase early: the T block of the NEXT block row is fetched while this one is solved, and
-  // the strip of L this block multiplies is fetched before x_blk exists (it does not depend on it).
-  const int kb_last = ((n - 1) / RSBA_PB) * RSBA_PB;
-  double tpre[2] = {0.0, 0.0};  // this thread's two entries of the next T block (nt = 512: 1024 entries)
-  auto fetch_T = [&](int kb, int slot) {
-    const int e = tid + slot * nt;
-    const int nbk = min(RSBA_PB, n - kb);
-    const int i = e >> 5, c = e & 31;
-    double tv = 0.0;
-    // T[i][c] for i > c sits at A[kb+c][kb+i]; the diagonal in row n+1
-    if (e < RSBA_PB * RSBA_PB && i < nbk && c < nbk) tv = (i > c) ? A[(size_t)(kb + c) * n + kb + i] : (i == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
-    return tv;
-  };
-  for (int sl = 0; sl < 2; ++sl) tpre[sl] = (tid + sl * nt < RSBA_PB * RSBA_PB) ? fetch_T(kb_last, sl) : 0.0;
-  for (int kb = kb_last; kb >= 0; kb -= RSBA_PB) {
-    const int nb = min(RSBA_PB, n - kb);
-    for (int sl = 0; sl < 2; ++sl) { const int e = tid + sl * nt; if (e < RSBA_PB * RSBA_PB) Tb[(e >> 5) * RSBA_PLD + (e & 31)] = tpre[sl]; }
-    // strip of L for this block (rows kb..kb+nb, column q = tid): independent of x_blk, so load it now
-    double lv[RSBA_PB];
-    const int q = tid;  // kb <= 352 < nt
-#pragma unroll
-    for (int c = 0; c < RSBA_PB; ++c) lv[c] = (c < nb && q < kb) ? A[(size_t)(kb + c) * n + q] : 0.0;
-    if (kb >= RSBA_PB) { for (int sl = 0; sl < 2; ++sl) tpre[sl] = (tid + sl * nt < RSBA_PB * RSBA_PB) ? fetch_T(kb - RSBA_PB, sl) : 0.0; }
-    __syncthreads();
-    if (tid < RSBA_PB) {
-      double sacc = 0.0;
-#pragma unroll 8
-      for (int i = 0; i < RSBA_PB; ++i) sacc += Tb[i * RSBA_PLD + tid] * ((i < nb) ? y[kb + i] : 0.0);
-      xb[tid] = (tid < nb) ? sacc : 0.0;
-    }
-    __syncthreads();
-    if (tid < nb) y[kb + tid] = xb[tid];
-    if (q < kb) {
-      double sacc = 0.0;
-#pragma unroll
-      for (int c = 0; c < RSBA_PB; ++c) sacc += lv[c] * xb[c];
-      y[q] -= sacc;
-    }
-    for (int q2 = tid + nt; q2 < kb; q2 += nt) {  // n > 512 never reaches here (RSBA_CHOL_MAXN), kept for safety
-      double sacc = 0.0;
-      for (int c = 0; c < nb; ++c) sacc += A[(size_t)(kb + c) * n + q2] * xb[c];
-      y[q2] -= sacc;
-    }
-    __syncthreads();
-  }
+  double* y = BackSubstituteBlocks(n, A, lds);
   for (int i = tid; i < n; i += nt) x_out[i] = y[i];
   __syncthreads();
   RSBA_STAMP(5);

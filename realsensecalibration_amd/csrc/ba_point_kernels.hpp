@@ -280,6 +280,49 @@ __global__ void k_finish_linearize(int nblocks, const double* __restrict__ block
   FinishLinearize(nblocks, block_scal, red, L, gmax_p);
 }
 
+// Camera step from the solution of the scaled system: delta_c = -s_c y, candidate cameras and their constants, the
+// camera parts of the norms, gradient max, and the scalars of res[].  One workgroup; `lds` needs 4 * blockDim.x doubles.
+__device__ __forceinline__ void CameraStepEpilogue(int C, const double* __restrict__ red, RedLayout L, const double* __restrict__ scale_c,
+                                                   const double* __restrict__ ysol, const double* __restrict__ cam_x,
+                                                   double* __restrict__ cam_c, const double* __restrict__ intr, double* __restrict__ camc_c,
+                                                   double* __restrict__ dcam, const double* __restrict__ gmax_p, double* __restrict__ res,
+                                                   int ok, double* lds) {
+  const int n = L.nc, tid = threadIdx.x, nt = blockDim.x;
+  // 5. camera step, candidate cameras, norms, gradient max over the camera part
+  double d2 = 0, x2 = 0, xc2 = 0, gm = 0;
+  for (int i = tid; i < n; i += nt) {
+    const double d = -scale_c[i] * ysol[i];
+    dcam[i] = d;
+    const double x = cam_x[i], xc = x + d;
+    cam_c[i] = xc;
+    d2 += d * d; x2 += x * x; xc2 += xc * xc;
+    gm = fmax(gm, fabs(red[L.gc() + i]));
+  }
+  // small fixed-order reduction through LDS
+  double* scr = lds;
+  scr[tid] = d2; scr[nt + tid] = x2; scr[2 * nt + tid] = xc2; scr[3 * nt + tid] = gm;
+  __syncthreads();
+  for (int off = nt / 2; off > 0; off >>= 1) {
+    if (tid < off) { scr[tid] += scr[tid + off]; scr[nt + tid] += scr[nt + tid + off]; scr[2 * nt + tid] += scr[2 * nt + tid + off]; scr[3 * nt + tid] = fmax(scr[3 * nt + tid], scr[3 * nt + tid + off]); }
+    __syncthreads();
+  }
+  for (int c = tid; c < C; c += nt) {
+    double cc[CC_STRIDE];
+    CameraConstants(cam_c + 6 * c, intr + 4 * c, cc);
+    for (int i = 0; i < CC_STRIDE; ++i) camc_c[(size_t)c * CC_STRIDE + i] = cc[i];
+  }
+  if (tid == 0) {
+    res[RES_COST_X] = 0.5 * red[L.scal() + 0];
+    res[RES_GMAX] = fmax(*gmax_p, scr[3 * nt]);
+    res[RES_XNORM2] = red[L.scal() + 1] + scr[nt];
+    res[RES_POINT_FAIL] = red[L.scal() + 2];
+    res[RES_CHOL_OK] = (ok && red[L.scal() + 2] == 0.0) ? 1.0 : 0.0;
+    // camera parts of the step / candidate norms; the point parts are added by k_finish_candidate
+    res[RES_STEP2] = scr[0];
+    res[RES_XCNORM2] = scr[2 * nt];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K_C: reduced camera system.  One workgroup (1024 threads).
 //   1. Jacobi scale of the camera columns (iteration 0) from diagU
@@ -428,7 +471,6 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
                        const double* __restrict__ gmax_p, double* __restrict__ res, IterParams ip, int sym_full) {
   extern __shared__ double lds[];
   const int n = L.nc, tid = threadIdx.x, nt = blockDim.x;
-  __shared__ double s_norms[3];
   __shared__ int s_ok;
 #ifdef RSBA_PROFILE_PHASES
   long long _k0 = clock64();
@@ -484,40 +526,7 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
   if (tid == 0) { g_phase_cycles[9] += clock64() - _k0; }
 #endif
   // 5. camera step, candidate cameras, norms, gradient max over the camera part
-  if (tid == 0) { s_norms[0] = 0; s_norms[1] = 0; s_norms[2] = 0; }
-  __syncthreads();
-  double d2 = 0, x2 = 0, xc2 = 0, gm = 0;
-  for (int i = tid; i < n; i += nt) {
-    const double d = -scale_c[i] * ysol[i];
-    dcam[i] = d;
-    const double x = cam_x[i], xc = x + d;
-    cam_c[i] = xc;
-    d2 += d * d; x2 += x * x; xc2 += xc * xc;
-    gm = fmax(gm, fabs(red[L.gc() + i]));
-  }
-  // small fixed-order reduction through LDS
-  double* scr = lds;
-  scr[tid] = d2; scr[nt + tid] = x2; scr[2 * nt + tid] = xc2; scr[3 * nt + tid] = gm;
-  __syncthreads();
-  for (int off = nt / 2; off > 0; off >>= 1) {
-    if (tid < off) { scr[tid] += scr[tid + off]; scr[nt + tid] += scr[nt + tid + off]; scr[2 * nt + tid] += scr[2 * nt + tid + off]; scr[3 * nt + tid] = fmax(scr[3 * nt + tid], scr[3 * nt + tid + off]); }
-    __syncthreads();
-  }
-  for (int c = tid; c < C; c += nt) {
-    double cc[CC_STRIDE];
-    CameraConstants(cam_c + 6 * c, intr + 4 * c, cc);
-    for (int i = 0; i < CC_STRIDE; ++i) camc_c[(size_t)c * CC_STRIDE + i] = cc[i];
-  }
-  if (tid == 0) {
-    res[RES_COST_X] = 0.5 * red[L.scal() + 0];
-    res[RES_GMAX] = fmax(*gmax_p, scr[3 * nt]);
-    res[RES_XNORM2] = red[L.scal() + 1] + scr[nt];
-    res[RES_POINT_FAIL] = red[L.scal() + 2];
-    res[RES_CHOL_OK] = (s_ok && red[L.scal() + 2] == 0.0) ? 1.0 : 0.0;
-    // camera parts of the step / candidate norms; the point parts are added by k_finish_candidate
-    res[RES_STEP2] = scr[0];
-    res[RES_XCNORM2] = scr[2 * nt];
-  }
+  CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, s_ok, lds);
 }
 
 // ------------------------------------------------------------------------------------------------

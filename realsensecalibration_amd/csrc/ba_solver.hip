@@ -26,6 +26,7 @@
 
 #include "ba_marker_kernels.hpp"
 #include "ba_point_kernels.hpp"
+#include "ba_cholesky_large.hpp"
 #include "ba_problem.hpp"
 #include "ba_schur_tiled.hpp"
 #include "ba_solver.hpp"
@@ -121,6 +122,8 @@ struct rsba_solver {
   double *cam[2] = {nullptr, nullptr}, *pts[2] = {nullptr, nullptr}, *camc[2] = {nullptr, nullptr};
   double *cam0 = nullptr, *pts0 = nullptr;  // uploaded initial state (rsba_solver_run restarts from it)
   double *scale_c = nullptr, *scale_p = nullptr;
+  double *W = nullptr;     // working copy of the reduced system for the multi-launch Cholesky (nc > RSBA_CHOL_MAXN)
+  int* chol_ok = nullptr;
   double *red = nullptr, *A = nullptr, *S_copy = nullptr, *rhs_copy = nullptr, *dcam = nullptr;
   double *block_scal = nullptr, *block_part = nullptr, *small_red = nullptr, *gmax = nullptr, *res = nullptr;
   double* res_host = nullptr;  // pinned
@@ -224,7 +227,7 @@ static void FreeSolver(rsba_solver* s) {
   (void)hipSetDevice(s->device);
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
-                  s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
+                  s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
                   s->block_part, s->small_red, s->gmax, s->res};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
@@ -278,7 +281,8 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->intr, 4 * C)) || (rc = DevAlloc(&s->cam[0], 6 * C)) || (rc = DevAlloc(&s->cam[1], 6 * C)) || (rc = DevAlloc(&s->cam0, 6 * C)) ||
       (rc = DevAlloc(&s->pts[0], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts[1], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts0, 3 * (size_t)P)) ||
       (rc = DevAlloc(&s->camc[0], CC_STRIDE * C)) || (rc = DevAlloc(&s->camc[1], CC_STRIDE * C)) || (rc = DevAlloc(&s->scale_c, 6 * C)) ||
-      (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(s->nc + 2) * s->nc)) ||
+      (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(s->nc + 2) * s->nc)) || (rc = DevAlloc(&s->W, s->nc > RSBA_CHOL_MAXN ? (size_t)(s->nc + 1) * s->nc : 1)) ||
+      (rc = DevAlloc(&s->chol_ok, 1)) ||
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
       (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)))
     return rc;
@@ -401,20 +405,36 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     NCCLCHK(ncclAllReduce(s->gmax, s->gmax, 1, ncclDouble, ncclMax, s->comm, st));
   }
 
-  size_t lds_c = (size_t)std::max(2 * RSBA_TB * (RSBA_NB + 1) + RSBA_NB * (RSBA_NB + 1), 4 * 1024) * sizeof(double);
-  if (s->nc <= RSBA_CHOL_MAXN) lds_c = std::max(lds_c, CholeskyLdsDoubles(s->nc) * sizeof(double));
-  T.Begin("k_reduced_system_solve", st);
   if (s->nc <= RSBA_CHOL_MAXN) {
+    const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(s->nc)) * sizeof(double);
+    T.Begin("k_reduced_system_solve", st);
     if (lds_c > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
     k_reduced_system_solve<512><<<1, 512, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
                                                       keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                       s->camc[c], s->dcam, s->gmax, s->res, ip, s->opt.schur_impl != 0 ? 1 : 0);
+    T.End(st);
   } else {
-    k_reduced_system_solve<1024><<<1, 1024, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
-                                                        keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
-                                                        s->camc[c], s->dcam, s->gmax, s->res, ip, s->opt.schur_impl != 0 ? 1 : 0);
+    // more than 64 cameras: right-looking factorisation over the whole chip, one launch per 32-wide panel
+    const int n = s->nc;
+    T.Begin("k_sys_build", st);
+    k_sys_build<<<n + 1, 256, 0, st>>>(s->red, s->L, s->W, keep_system_copy ? s->S_copy : nullptr, keep_system_copy ? s->rhs_copy : nullptr,
+                                       s->scale_c, ip, s->opt.schur_impl != 0 ? 1 : 0, s->chol_ok);
+    T.End(st);
+    const size_t lds_s = CholStepLdsDoubles() * sizeof(double);
+    HIPCHK(hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    T.Begin("k_chol_step(all panels)", st);
+    for (int kb = 0; kb < n; kb += RSBA_PB) {
+      const int r0 = kb + std::min(RSBA_PB, n - kb);
+      const int nrt = (n + 1 - r0 + RSBA_CT - 1) / RSBA_CT;
+      k_chol_step<<<nrt * (nrt + 1) / 2, 256, lds_s, st>>>(n, kb, s->W, s->A, s->chol_ok);
+    }
+    T.End(st);
+    const size_t lds_f = std::max((size_t)4 * 1024, (size_t)((n + 63) & ~63) + 3 * RSBA_PB * RSBA_PLD + 64) * sizeof(double);
+    T.Begin("k_chol_finish", st);
+    k_chol_finish<<<1, 1024, lds_f, st>>>(C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res,
+                                          s->chol_ok);
+    T.End(st);
   }
-  T.End(st);
   DebugSync(st, "k_reduced_system_solve");
   T.Begin("k_backsub_candidate", st);
   {
