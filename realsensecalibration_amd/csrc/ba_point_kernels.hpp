@@ -529,6 +529,16 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
   CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, s_ok, lds);
 }
 
+// Observations as the point-centric kernels walk them: sliced ELL.  A slice is 64 consecutive points (one wavefront);
+// slot t of lane l sits at (row_ptr[slice] + t) * 64 + l, slots in camera order, cam < 0 pads a point with fewer views
+// than the widest of its slice.  A wavefront's loads are then contiguous (1 KB of pixels, 256 B of camera indices per
+// slot) instead of 64 separate cache lines of the point-major CSR arrays.
+struct ObsSliced {
+  const int* __restrict__ row_ptr;   // [ceil(P/64) + 1]
+  const double2* __restrict__ uv;    // [rows * 64]
+  const int* __restrict__ cam;       // [rows * 64]
+};
+
 // ------------------------------------------------------------------------------------------------
 // K_B: back-substitution + candidate.  One thread per point; a second pass over the observation
 // records.  delta_p = -Vinv (g_p + sum Jp' Jc delta_c); model-cost-change terms accumulate in the same
@@ -536,8 +546,7 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
 // ------------------------------------------------------------------------------------------------
 template <bool kStage>
 __global__ void __launch_bounds__(256)
-k_backsub_candidate(int C, int P, const double* __restrict__ obs_u, const double* __restrict__ obs_v,
-                    const int* __restrict__ obs_cam, const int* __restrict__ pt_ptr,
+k_backsub_candidate(int C, int P, ObsSliced obs,
                     const double* __restrict__ camc_xg, const double* __restrict__ camc_cg,
                     const double* __restrict__ dcam_g, const double* __restrict__ pts_x, double* __restrict__ pts_c,
                     const double* __restrict__ scale_p, double* __restrict__ block_part /* gridDim.x x 8 */, IterParams ip) {
@@ -558,13 +567,18 @@ k_backsub_candidate(int C, int P, const double* __restrict__ obs_u, const double
   }
   double mcc = 0, cost_c = 0, dp2 = 0, xc2 = 0, ss_c = 0;
   for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
-    const int b = pt_ptr[j], e = pt_ptr[j + 1];
+    const int lane = j & 63, tb = obs.row_ptr[j >> 6], te = obs.row_ptr[(j >> 6) + 1];
+    bool any = false;
     const double X[3] = {pts_x[3 * (size_t)j], pts_x[3 * (size_t)j + 1], pts_x[3 * (size_t)j + 2]};
     double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, bv[3] = {0, 0, 0}, a1 = 0, a2 = 0;
-    for (int q = b; q < e; ++q) {
-      const int cam = obs_cam[q];
+    for (int t = tb; t < te; ++t) {
+      const size_t q = (size_t)t * 64 + lane;
+      const int cam = obs.cam[q];
+      if (cam < 0) continue;
+      any = true;
+      const double2 uv = obs.uv[q];
       double r[2], jc[12], jp[6];
-      ResidualJacobian(camc_x + (size_t)cam * (kStage ? RSBA_CC_LDS : CC_STRIDE), X, obs_u[q], obs_v[q], r, jc, jp);
+      ResidualJacobian(camc_x + (size_t)cam * (kStage ? RSBA_CC_LDS : CC_STRIDE), X, uv.x, uv.y, r, jc, jp);
       double sq;
       LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
       const double* dc = dcam + 6 * cam;
@@ -587,7 +601,7 @@ k_backsub_candidate(int C, int P, const double* __restrict__ obs_u, const double
     double Vi[6];
     const bool ok = PointBlockInverse(V, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, ip.radius, Vi);
     double t[3] = {gp[0] + bv[0], gp[1] + bv[1], gp[2] + bv[2]}, dp[3] = {0, 0, 0};
-    if (ok && e > b) { Sym3MulVec(Vi, t, dp); dp[0] = -dp[0]; dp[1] = -dp[1]; dp[2] = -dp[2]; }
+    if (ok && any) { Sym3MulVec(Vi, t, dp); dp[0] = -dp[0]; dp[1] = -dp[1]; dp[2] = -dp[2]; }
     const double Xc[3] = {X[0] + dp[0], X[1] + dp[1], X[2] + dp[2]};
     pts_c[3 * (size_t)j] = Xc[0]; pts_c[3 * (size_t)j + 1] = Xc[1]; pts_c[3 * (size_t)j + 2] = Xc[2];
     double Vd[3];
@@ -596,9 +610,13 @@ k_backsub_candidate(int C, int P, const double* __restrict__ obs_u, const double
            0.5 * (dp[0] * Vd[0] + dp[1] * Vd[1] + dp[2] * Vd[2]);
     dp2 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
     xc2 += Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2];
-    for (int q = b; q < e; ++q) {
+    for (int t = tb; t < te; ++t) {
+      const size_t q = (size_t)t * 64 + lane;
+      const int cam = obs.cam[q];
+      if (cam < 0) continue;
+      const double2 uv = obs.uv[q];
       double r[2];
-      Residual(camc_c + (size_t)obs_cam[q] * (kStage ? RSBA_CC_LDS : CC_STRIDE), Xc, obs_u[q], obs_v[q], r);
+      Residual(camc_c + (size_t)cam * (kStage ? RSBA_CC_LDS : CC_STRIDE), Xc, uv.x, uv.y, r);
       const double s = r[0] * r[0] + r[1] * r[1];
       double sq;
       cost_c += LossAndScale(ip.huber_delta, s, &sq);
@@ -664,16 +682,20 @@ __global__ void k_publish_result(const double* __restrict__ small_red, double* _
 
 // Cost only at the current point-model parameters (used by rsba_reprojection_error).
 __global__ void __launch_bounds__(256)
-k_cost_only(int P, const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
-            const int* __restrict__ pt_ptr, const double* __restrict__ camc, const double* __restrict__ pts,
+k_cost_only(int P, ObsSliced obs, const double* __restrict__ camc, const double* __restrict__ pts,
             double* __restrict__ block_part, double huber_delta) {
   const int tid = threadIdx.x;
   double cost = 0, ss = 0;
   for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
     const double X[3] = {pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2]};
-    for (int q = pt_ptr[j]; q < pt_ptr[j + 1]; ++q) {
+    const int lane = j & 63;
+    for (int t = obs.row_ptr[j >> 6]; t < obs.row_ptr[(j >> 6) + 1]; ++t) {
+      const size_t q = (size_t)t * 64 + lane;
+      const int cam = obs.cam[q];
+      if (cam < 0) continue;
+      const double2 uv = obs.uv[q];
       double r[2], sq;
-      Residual(camc + (size_t)obs_cam[q] * CC_STRIDE, X, obs_u[q], obs_v[q], r);
+      Residual(camc + (size_t)cam * CC_STRIDE, X, uv.x, uv.y, r);
       const double s = r[0] * r[0] + r[1] * r[1];
       cost += LossAndScale(huber_delta, s, &sq);
       ss += s;

@@ -63,10 +63,11 @@ struct TiledSchur {
   // robust-loss support: sqrt(rho') per observation in camera-major order
   int* cam_prefix = nullptr;                // [ngroups*16][nwords] set bits of cam_mask before each word
   int* cam_ptr = nullptr;                   // [ngroups*16+1] start of each camera's observation list
-  int* cm_pos = nullptr;                    // [N] sorted observation -> camera-major position
+  int* cm_pos = nullptr;                    // [rows*64] observation (sliced layout, see ObsSliced) -> camera-major position
   double* sq_cm = nullptr;                  // [N]
   double *u_cm = nullptr, *v_cm = nullptr;  // [N] observations in camera-major order (self tiles need the pixel)
-  int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v);
+  int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
+            const std::vector<int>& sliced_q /* sliced slot -> CSR position, -1 pads */);
   int Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T);
   void Free();
 };
@@ -76,10 +77,9 @@ struct TiledSchur {
 // ------------------------------------------------------------------------------------------------
 template <bool kStageCamc>
 __global__ void __launch_bounds__(256)
-k_point_pass(int C, int P, const double* __restrict__ obs_u, const double* __restrict__ obs_v, const int* __restrict__ obs_cam,
-             const int* __restrict__ pt_ptr, const double* __restrict__ camc_g, const double* __restrict__ pts,
+k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, const double* __restrict__ pts,
              double* __restrict__ scale_p, double* __restrict__ ptdata, double* __restrict__ block_scal,
-             const int* __restrict__ cm_pos, double* __restrict__ sq_cm, IterParams ip) {
+             const int* __restrict__ cm_pos /* sliced like obs */, double* __restrict__ sq_cm, IterParams ip) {
   extern __shared__ double lds[];
   double* camc_l = lds;      // C x 33 when staged
   const int tid = threadIdx.x;
@@ -89,13 +89,18 @@ k_point_pass(int C, int P, const double* __restrict__ obs_u, const double* __res
   const int ccs = kStageCamc ? RSBA_CC_LDS : CC_STRIDE;
   double cost = 0, xn = 0, fail = 0, gmax = 0;
   for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
-    const int b = pt_ptr[j], e = pt_ptr[j + 1];
+    const int lane = j & 63;
+    bool any = false;
     const double X[3] = {pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2]};
     double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
-    for (int q = b; q < e; ++q) {
-      const int cam = obs_cam[q];
+    for (int t = obs.row_ptr[j >> 6]; t < obs.row_ptr[(j >> 6) + 1]; ++t) {
+      const size_t q = (size_t)t * 64 + lane;
+      const int cam = obs.cam[q];
+      if (cam < 0) continue;
+      any = true;
+      const double2 uv = obs.uv[q];
       double r[2], jc[12], jp[6], sq;
-      ResidualJacobian(camc + (size_t)cam * ccs, X, obs_u[q], obs_v[q], r, jc, jp);
+      ResidualJacobian(camc + (size_t)cam * ccs, X, uv.x, uv.y, r, jc, jp);
       cost += LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
       if (ip.huber_delta > 0.0) sq_cm[cm_pos[q]] = sq;
       if (sq != 1.0) {
@@ -118,7 +123,7 @@ k_point_pass(int C, int P, const double* __restrict__ obs_u, const double* __res
     if (!ok) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) Vi[i] = 0.0;
-      if (e > b) fail += 1.0;
+      if (any) fail += 1.0;
     }
     double y[3];
     Sym3MulVec(Vi, gp, y);

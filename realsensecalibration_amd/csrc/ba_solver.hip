@@ -118,6 +118,10 @@ struct rsba_solver {
   RedLayout L{0};
   std::vector<int64_t> order;       // sorted position -> original observation index
   double *obs_u = nullptr, *obs_v = nullptr, *intr = nullptr;
+  // sliced-ELL copy of the observations for the point-centric kernels (ObsSliced)
+  int *sl_row_ptr = nullptr, *sl_cam = nullptr;
+  double2* sl_uv = nullptr;
+  ObsSliced sliced() const { return ObsSliced{sl_row_ptr, sl_uv, sl_cam}; }
   int *obs_cam = nullptr, *pt_ptr = nullptr;
   double *cam[2] = {nullptr, nullptr}, *pts[2] = {nullptr, nullptr}, *camc[2] = {nullptr, nullptr};
   double *cam0 = nullptr, *pts0 = nullptr;  // uploaded initial state (rsba_solver_run restarts from it)
@@ -140,7 +144,8 @@ namespace rsba {
 // ------------------------------------------------------------------------------------------------
 // Static structure of the tiled Schur kernel: visibility bitsets, tiles, segments.
 // ------------------------------------------------------------------------------------------------
-int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v) {
+int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
+                      const std::vector<int>& sliced_q) {
   C = C_; P = P_;
   ngroups = (C + RSBA_TG - 1) / RSBA_TG;
   nwords = ((P + 63) / 64 + RSBA_CW - 1) / RSBA_CW * RSBA_CW;
@@ -171,7 +176,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   ntiles = (int)wt.size();
   int cus = 256;
   { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
-  const int target = (getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : 8) * cus;
+  const int target = (getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : 4) * cus;
   // pair tiles share `target` workgroups; the self tiles (their own, much lighter launch) get 2 per CU in total
   int npair_tiles = 0;
   for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) ++npair_tiles;
@@ -197,7 +202,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nseg)) || (rc = DevAlloc(&tile_seg_ptr, (size_t)ntiles + 1)) ||
       (rc = DevAlloc(&tile_ab, (size_t)3 * ntiles)) || (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
-      (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, cmpos.size())) ||
+      (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm, cmpos.size())) || (rc = DevAlloc(&u_cm, cmpos.size())) || (rc = DevAlloc(&v_cm, cmpos.size())))
     return rc;
   {
@@ -212,7 +217,11 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   HIPCHK(hipMemcpy(tile_ab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_prefix, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_ptr, cptr.data(), cptr.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(cm_pos, cmpos.data(), cmpos.size() * sizeof(int), hipMemcpyHostToDevice));
+  {
+    std::vector<int> cmsl(std::max<size_t>(sliced_q.size(), 1), 0);
+    for (size_t e = 0; e < sliced_q.size(); ++e) cmsl[e] = sliced_q[e] >= 0 ? cmpos[sliced_q[e]] : 0;
+    HIPCHK(hipMemcpy(cm_pos, cmsl.data(), sliced_q.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   return RSBA_OK;
 }
 
@@ -226,7 +235,7 @@ static void FreeSolver(rsba_solver* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   s->timer.Reset();
-  void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
+  void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
                   s->block_part, s->small_red, s->gmax, s->res};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -276,8 +285,26 @@ static int UploadPoints(rsba_solver* s) {
   std::vector<int> cam(N);
   for (int64_t q = 0; q < N; ++q) { const int64_t i = s->order[q]; u[q] = p.observations[2 * i]; v[q] = p.observations[2 * i + 1]; cam[q] = p.camera_index[i]; }
 
+  // sliced-ELL layout: slice = 64 consecutive points, as wide as its widest point
+  const int nslices = (P + 63) / 64;
+  std::vector<int> sl_ptr(nslices + 1, 0);
+  for (int sl = 0; sl < nslices; ++sl) {
+    int w = 0;
+    for (int j = 64 * sl; j < std::min(P, 64 * sl + 64); ++j) w = std::max(w, ptr[j + 1] - ptr[j]);
+    sl_ptr[sl + 1] = sl_ptr[sl] + w;
+  }
+  const size_t sl_elems = (size_t)sl_ptr[nslices] * 64;
+  std::vector<int> sl_q(sl_elems, -1), sl_cam(std::max<size_t>(sl_elems, 1), -1);
+  std::vector<double> sl_uv(std::max<size_t>(2 * sl_elems, 2), 0.0);
+  for (int j = 0; j < P; ++j)
+    for (int q = ptr[j]; q < ptr[j + 1]; ++q) {
+      const size_t e = ((size_t)sl_ptr[j >> 6] + (q - ptr[j])) * 64 + (j & 63);
+      sl_q[e] = q; sl_cam[e] = cam[q]; sl_uv[2 * e] = u[q]; sl_uv[2 * e + 1] = v[q];
+    }
+
   int rc;
   if ((rc = DevAlloc(&s->obs_u, N)) || (rc = DevAlloc(&s->obs_v, N)) || (rc = DevAlloc(&s->obs_cam, N)) || (rc = DevAlloc(&s->pt_ptr, P + 1)) ||
+      (rc = DevAlloc(&s->sl_row_ptr, nslices + 1)) || (rc = DevAlloc(&s->sl_cam, sl_elems)) || (rc = DevAlloc(&s->sl_uv, sl_elems)) ||
       (rc = DevAlloc(&s->intr, 4 * C)) || (rc = DevAlloc(&s->cam[0], 6 * C)) || (rc = DevAlloc(&s->cam[1], 6 * C)) || (rc = DevAlloc(&s->cam0, 6 * C)) ||
       (rc = DevAlloc(&s->pts[0], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts[1], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts0, 3 * (size_t)P)) ||
       (rc = DevAlloc(&s->camc[0], CC_STRIDE * C)) || (rc = DevAlloc(&s->camc[1], CC_STRIDE * C)) || (rc = DevAlloc(&s->scale_c, 6 * C)) ||
@@ -290,6 +317,9 @@ static int UploadPoints(rsba_solver* s) {
   HIPCHK(hipMemcpy(s->obs_v, v.data(), N * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->obs_cam, cam.data(), N * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->pt_ptr, ptr.data(), (P + 1) * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->sl_row_ptr, sl_ptr.data(), (nslices + 1) * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->sl_cam, sl_cam.data(), sl_elems * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->sl_uv, sl_uv.data(), sl_elems * sizeof(double2), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->intr, p.intrinsics.data(), 4 * C * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->cam0, p.parameters.data(), 6 * C * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->pts0, p.parameters.data() + 6 * C, 3 * (size_t)P * sizeof(double), hipMemcpyHostToDevice));
@@ -305,7 +335,7 @@ static int UploadPoints(rsba_solver* s) {
     if (dup) s->opt.schur_impl = 0;
   }
   if (s->opt.schur_impl != 0) {
-    rc = s->tiled.Build(C, P, ptr, cam, u, v);
+    rc = s->tiled.Build(C, P, ptr, cam, u, v, sl_q);
     if (rc != RSBA_OK) return rc;
   } else if (maxk > 64) {
     fprintf(stderr, "rsba: schur_impl=0 handles at most 64 views per point (problem has %d)\n", maxk);
@@ -329,10 +359,10 @@ int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
   const size_t lds = stage ? (size_t)C * RSBA_CC_LDS * sizeof(double) : 0;
   T.Begin("k_point_pass", st);
   if (stage)
-    k_point_pass<true><<<grid_pp, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p, ptdata,
+    k_point_pass<true><<<grid_pp, 256, lds, st>>>(C, P, s->sliced(), s->camc[x], s->pts[x], s->scale_p, ptdata,
                                                   block_scal, cm_pos, sq_cm, ip);
   else
-    k_point_pass<false><<<grid_pp, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p, ptdata,
+    k_point_pass<false><<<grid_pp, 256, lds, st>>>(C, P, s->sliced(), s->camc[x], s->pts[x], s->scale_p, ptdata,
                                                    block_scal, cm_pos, sq_cm, ip);
   T.End(st);
   T.Begin("k_schur_pairs", st);
@@ -440,10 +470,10 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   {
     const size_t lds_b = (size_t)C * (2 * RSBA_CC_LDS + 6) * sizeof(double);
     if (lds_b <= 60 * 1024)
-      k_backsub_candidate<true><<<s->grid_pts, 256, lds_b, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->camc[c], s->dcam, s->pts[x],
+      k_backsub_candidate<true><<<s->grid_pts, 256, lds_b, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
                                                                  s->pts[c], s->scale_p, s->block_part, ip);
     else
-      k_backsub_candidate<false><<<s->grid_pts, 256, 0, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->camc[c], s->dcam, s->pts[x],
+      k_backsub_candidate<false><<<s->grid_pts, 256, 0, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
                                                               s->pts[c], s->scale_p, s->block_part, ip);
   }
   T.End(st);
@@ -725,7 +755,7 @@ int rsba_reprojection_error(rsba_problem* p, const rsba_options* o, double* erro
     rc = rsba::ResetPoints(s);
     if (rc == RSBA_OK) {
       k_camera_constants<<<(s->C + 63) / 64, 64, 0, s->stream>>>(s->C, s->cam[0], s->intr, s->camc[0]);
-      k_cost_only<<<s->grid_pts, 256, 0, s->stream>>>(s->P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[0], s->pts[0], s->block_part, 0.0);
+      k_cost_only<<<s->grid_pts, 256, 0, s->stream>>>(s->P, s->sliced(), s->camc[0], s->pts[0], s->block_part, 0.0);
       k_finish_candidate<<<1, 256, 0, s->stream>>>(s->grid_pts, s->block_part, s->small_red, nullptr);
       double h[8];
       if (hipMemcpyAsync(h, s->small_red, 8 * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) rc = RSBA_ERR_HIP;
