@@ -64,6 +64,37 @@ struct PanelSource {
   double lo, hi, inv_radius;
 };
 
+// Columns of the matrix may still be in production when the factorisation starts (pipelined solve): gate.ready[1 + g]
+// becomes gate.tag when the columns of camera group g (gate.cols wide) are complete; ready == nullptr: no gating.
+struct StageGate {
+  const int* ready;
+  int tag, cols;
+  long long* waited;  // += ticks (100 MHz) spent waiting, by thread 0: the kernel's duration minus this is its own work
+  long long* trace;   // diagnostic (RSBA_TRACE=1): wall-clock stamps of the waits, nullptr otherwise
+};
+
+// Spin (one lane, sleeping between polls) until *flag == tag; false when the producer does not show up in
+// RSBA_STALL_TICKS of the 100 MHz wall clock — the caller gives up instead of hanging the queue.
+#ifndef RSBA_STALL_TICKS
+#define RSBA_STALL_TICKS 5000000LL
+#endif
+__device__ __forceinline__ bool WaitReady(const int* flag, int tag, long long* waited_ticks) {
+  __shared__ int s_wait_ok;
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > RSBA_STALL_TICKS) { ok = 0; break; }
+    }
+    s_wait_ok = ok;
+    if (waited_ticks) *waited_ticks += wall_clock64() - t0;
+  }
+  __syncthreads();
+  __threadfence();  // every thread's later loads see what the producer published before the flag
+  return s_wait_ok != 0;
+}
+
 // Factor the padded 32 x 32 diagonal block held in LDS (rows of `Pd`, stride RSBA_PLD) and invert it.  One wavefront.
 // Out: Pd rows < nb = L11 (upper part zeroed), Lt = padded L11, T = L11^-1, invd = 1/diag.  Returns false on a
 // non-positive pivot.  (Rows/columns >= nb are padded with identity so all 32 steps run unconditionally; lanes 32..63
@@ -233,7 +264,12 @@ __device__ __forceinline__ double* BackSubstituteBlocks(int n, double* __restric
 
 // A: (n+2) x n row-major in global memory; rows 0..n-1 the SPD matrix (lower triangle read), row n the rhs,
 // row n+1 scratch (inverse pivots).  On return the lower triangle holds L, row n holds y = L^-1 rhs, x_out x.
-__device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __restrict__ x_out, int* ok_out, double* lds, PanelSource src) {
+// Only the panels kb_begin <= kb < kb_end are factored, and the back-substitution runs only when `solve` is set: the
+// pipelined solver calls this once per camera group, as soon as that group's columns of the matrix exist, while the
+// rest of the chip is still eliminating points for the later groups.  All state between calls lives in A.
+// With a gate the panels wait for their camera group's columns; a stalled wait returns with *ok_out = -1.
+__device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __restrict__ x_out, int* ok_out, double* lds, PanelSource src,
+                                      int kb_begin, int kb_end, bool solve, StageGate gate = StageGate{nullptr, 0, 0, nullptr, nullptr}) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
   double* T = lds + (size_t)(n + 2) * RSBA_PLD;        // 32 x 33: T = L11^-1
   double* Lt = T + RSBA_PB * RSBA_PLD;                 // 32 x 33: padded L11
@@ -246,7 +282,12 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
   __syncthreads();
   RSBA_STAMP_INIT;
 
-  for (int kb = 0; kb < n; kb += RSBA_PB) {
+  for (int kb = kb_begin; kb < kb_end; kb += RSBA_PB) {
+    if (gate.ready != nullptr && kb % gate.cols == 0) {
+      if (gate.trace && tid == 0) gate.trace[2 + 2 * (kb / gate.cols)] = wall_clock64();
+      if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, gate.waited)) { if (tid == 0) *ok_out = -1; __syncthreads(); return; }
+      if (gate.trace && tid == 0) gate.trace[3 + 2 * (kb / gate.cols)] = wall_clock64();
+    }
     const int nb = min(RSBA_PB, n - kb);
     const int R = n + 1 - kb;  // panel rows, rhs row included (panel-relative row R-1)
     // LDS split of the shared (n+1) x 33 area: B strip first (kb rows of 33: Bst[q][c] = L[kb+c][q]), panel after
@@ -433,9 +474,11 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     RSBA_STAMP(4);
   }
 
-  double* y = BackSubstituteBlocks(n, A, lds);
-  for (int i = tid; i < n; i += nt) x_out[i] = y[i];
-  __syncthreads();
+  if (solve) {
+    double* y = BackSubstituteBlocks(n, A, lds);
+    for (int i = tid; i < n; i += nt) x_out[i] = y[i];
+    __syncthreads();
+  }
   RSBA_STAMP(5);
   if (tid == 0) *ok_out = s_ok;
   __syncthreads();

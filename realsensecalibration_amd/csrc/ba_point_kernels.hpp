@@ -56,6 +56,7 @@ enum {
   RES_XCNORM2 = 7,       // |x + delta|^2
   RES_POINT_FAIL = 8,    // number of point blocks that were not positive definite
   RES_SUMSQ_C = 9,       // sum of squared raw residuals at the candidate (for the RMS metric)
+  RES_STALL = 10,        // pipelined solve only: 1.0 when the Cholesky gave up waiting for its columns
   RES_SIZE = 16
 };
 
@@ -462,71 +463,91 @@ __device__ void CholeskySolveBlocked(int n, double* __restrict__ A, double* __re
   if (tid == 0) *ok_out = s_ok;
 }
 
-template <int kThreads>
-__global__ void __launch_bounds__(kThreads)
-k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __restrict__ A /* (nc+1) x nc */,
+#define RSBA_STAGE_FIRST 1   // builds the scale, the rhs row (and the matrix when it is not fused into the panel loads)
+#define RSBA_STAGE_LAST 2    // back-substitution + camera step
+__global__ void __launch_bounds__(512)
+k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __restrict__ A /* (nc+2) x nc */,
                        double* __restrict__ S_copy /* may be null */, double* __restrict__ rhs_copy,
                        double* __restrict__ scale_c, const double* __restrict__ cam_x, double* __restrict__ cam_c,
                        const double* __restrict__ intr, double* __restrict__ camc_c, double* __restrict__ dcam,
-                       const double* __restrict__ gmax_p, double* __restrict__ res, IterParams ip, int sym_full) {
+                       const double* __restrict__ gmax_p, double* __restrict__ res, IterParams ip, int sym_full,
+                       int kb_begin, int kb_end, int stage_flags, int* __restrict__ chol_ok, StageGate gate) {
   extern __shared__ double lds[];
   const int n = L.nc, tid = threadIdx.x, nt = blockDim.x;
   __shared__ int s_ok;
 #ifdef RSBA_PROFILE_PHASES
   long long _k0 = clock64();
 #endif
-  // 1. camera Jacobi scale
-  for (int i = tid; i < n; i += nt) {
-    if (ip.first) scale_c[i] = ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(red[L.diagU() + i])) : 1.0;
+  // the raw matrix is scaled, damped and mirrored by the panel loads themselves when it is already full symmetric
+  const bool fused = sym_full && S_copy == nullptr;
+  // pipelined: launched ahead of the linearisation; ready[0] says the self tiles (diagonal blocks, damping diagonal,
+  // right-hand sides) and the scalars are in place
+  if (gate.ready != nullptr) {
+    if (gate.trace && tid == 0) gate.trace[0] = wall_clock64();
+    if (!WaitReady(gate.ready, gate.tag, gate.waited)) { if (tid == 0) res[RES_STALL] = 1.0; return; }
+    if (gate.trace && tid == 0) gate.trace[1] = wall_clock64();
   }
-  __threadfence_block();
-  __syncthreads();
-  // 2. scaled, damped, mirrored system: one wave per row, lanes along the columns.  Skipped when the raw matrix
-  //    is already full symmetric and small enough for the LDS-panel Cholesky, which scales while it loads.
-  const bool fused = sym_full && kThreads == 512 && S_copy == nullptr;
-  if (!fused) {
-    const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
-    for (int i = wv; i < n; i += nw) {
-      const int bi = i / 6;
-      const double si = scale_c[i];
-      for (int j = lane; j < n; j += 64) {
-        const int bj = j / 6;
-        // upper blocks are the valid ones; inside a diagonal block the upper triangle
-        const bool upper = (bi < bj) || (bi == bj && i <= j);
-        const double raw = upper ? red[L.S() + (size_t)i * n + j] : red[L.S() + (size_t)j * n + i];
-        double v = raw * (si * scale_c[j]);  // product of the scales first: bitwise symmetric
-        if (i == j) {
-          const double d = si * si * red[L.diagU() + i];
-          v += fmin(fmax(d, ip.min_lm_diagonal), ip.max_lm_diagonal) / ip.radius;
+  if (stage_flags & RSBA_STAGE_FIRST) {
+    // 1. camera Jacobi scale
+    for (int i = tid; i < n; i += nt) {
+      if (ip.first) scale_c[i] = ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(red[L.diagU() + i])) : 1.0;
+    }
+    if (tid == 0) *chol_ok = 1;
+    __threadfence_block();
+    __syncthreads();
+    // 2. scaled, damped, mirrored system: one wave per row, lanes along the columns
+    if (!fused) {
+      const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+      for (int i = wv; i < n; i += nw) {
+        const int bi = i / 6;
+        const double si = scale_c[i];
+        for (int j = lane; j < n; j += 64) {
+          const int bj = j / 6;
+          // upper blocks are the valid ones; inside a diagonal block the upper triangle
+          const bool upper = (bi < bj) || (bi == bj && i <= j);
+          const double raw = upper ? red[L.S() + (size_t)i * n + j] : red[L.S() + (size_t)j * n + i];
+          double v = raw * (si * scale_c[j]);  // product of the scales first: bitwise symmetric
+          if (i == j) {
+            const double d = si * si * red[L.diagU() + i];
+            v += fmin(fmax(d, ip.min_lm_diagonal), ip.max_lm_diagonal) / ip.radius;
+          }
+          A[(size_t)i * n + j] = v;
+          if (S_copy) S_copy[(size_t)i * n + j] = v;
         }
-        A[(size_t)i * n + j] = v;
-        if (S_copy) S_copy[(size_t)i * n + j] = v;
       }
     }
+    for (int i = tid; i < n; i += nt) {
+      const double v = scale_c[i] * (red[L.gc() + i] + red[L.corr() + i]);
+      A[(size_t)n * n + i] = v;
+      if (rhs_copy) rhs_copy[i] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
   }
-  for (int i = tid; i < n; i += nt) {
-    const double v = scale_c[i] * (red[L.gc() + i] + red[L.corr() + i]);
-    A[(size_t)n * n + i] = v;
-    if (rhs_copy) rhs_copy[i] = v;
-  }
-  __threadfence_block();
-  __syncthreads();
 #ifdef RSBA_PROFILE_PHASES
   if (tid == 0) g_phase_cycles[8] += clock64() - _k0;
 #endif
-  // 3-4. factor + solve; y = solution of the scaled system, reused from row n of A
+  // 3-4. factor (this stage's panels) + solve; y = solution of the scaled system, reused from row n of A
   double* ysol = A + (size_t)n * n;
-  if (kThreads == 512)
-    CholeskySolvePanelLDS(n, A, ysol, &s_ok, lds,
-                          fused ? PanelSource{red + L.S(), scale_c, red + L.diagU(), ip.min_lm_diagonal, ip.max_lm_diagonal, 1.0 / ip.radius}
-                                : PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0});
-  else CholeskySolveBlocked(n, A, ysol, &s_ok, lds);
+  const bool last = (stage_flags & RSBA_STAGE_LAST) != 0;
+  CholeskySolvePanelLDS(n, A, ysol, &s_ok, lds,
+                        fused ? PanelSource{red + L.S(), scale_c, red + L.diagU(), ip.min_lm_diagonal, ip.max_lm_diagonal, 1.0 / ip.radius}
+                              : PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0},
+                        kb_begin, kb_end, last, gate);
   __syncthreads();
+  if (s_ok < 0) { if (tid == 0) res[RES_STALL] = 1.0; return; }
+  int ok = 1;
+  if (tid == 0) {
+    res[RES_STALL] = 0.0;
+    if (!s_ok) *chol_ok = 0;
+    ok = *chol_ok;
+  }
 #ifdef RSBA_PROFILE_PHASES
   if (tid == 0) { g_phase_cycles[9] += clock64() - _k0; }
 #endif
   // 5. camera step, candidate cameras, norms, gradient max over the camera part
-  CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, s_ok, lds);
+  if (last) CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, ok, lds);
+  if (gate.trace && tid == 0) gate.trace[15] = wall_clock64();
 }
 
 // Observations as the point-centric kernels walk them: sliced ELL.  A slice is 64 consecutive points (one wavefront);

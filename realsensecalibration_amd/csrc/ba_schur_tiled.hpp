@@ -47,7 +47,12 @@ class KernelTimer;
 
 // A segment is a range of 64-point mask words of one tile (not necessarily chunk-aligned: small problems get as many
 // workgroups as they have words).
-struct SchurSeg { int ga, gb, word_begin, word_end, self, pad0, pad1, pad2; };
+struct SchurSeg {
+  int ga, gb, word_begin, word_end, self;
+  // in-kernel reduction tree of the pair tiles: segment -> group of RSBA_GRP consecutive segments -> tile -> stage
+  int tile, grp, grp_seg0, grp_nseg, tile_grp0, tile_ngrp, stage, stage_ntiles, pad0, pad1, pad2;
+};
+#define RSBA_GRP 8          // segments per reduction group
 
 struct TiledSchur {
   int C = 0, P = 0, ngroups = 0, nwords = 0, nchunks = 0, nseg = 0, nseg_pair = 0, grid_pp = 0;
@@ -58,7 +63,10 @@ struct TiledSchur {
   int ntiles = 0;
   double* ptdata = nullptr;                 // [P][12]
   double* partial = nullptr;                // [nseg][42][256]
-  double* tile_sum = nullptr;               // [ntiles][42][256]
+  double* grp_sum = nullptr;                // [ngrp][42][256] sums of RSBA_GRP consecutive segments
+  int* sync_cnt = nullptr;                  // [ngrp + ntiles + nstages] arrival counters, self-resetting
+  int* ready = nullptr;                     // [1 + nstages] ready[0]: self tiles + scalars, ready[1+g]: pair tiles of stage g; = step tag
+  int ngrp = 0;
   double* block_scal = nullptr;
   // robust-loss support: sqrt(rho') per observation in camera-major order
   int* cam_prefix = nullptr;                // [ngroups*16][nwords] set bits of cam_mask before each word
@@ -67,8 +75,14 @@ struct TiledSchur {
   double* sq_cm = nullptr;                  // [N]
   double *u_cm = nullptr, *v_cm = nullptr;  // [N] observations in camera-major order (self tiles need the pixel)
   int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
-            const std::vector<int>& sliced_q /* sliced slot -> CSR position, -1 pads */);
+            const std::vector<int>& sliced_q /* sliced slot -> CSR position, -1 pads */, bool staged);
+  // stages of the pipelined solve: pair tiles with ga == g are contiguous (tiles [stage_tile[g], stage_tile[g+1])), the
+  // self tiles follow ([stage_tile[nstages], ntiles)); segments follow their tiles
+  int nstages = 0;
+  std::vector<int> stage_tile, stage_seg;
   int Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T);
+  void LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
+  void LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag);
   void Free();
 };
 
@@ -229,18 +243,215 @@ __device__ __constant__ unsigned char kDiagPair[128] = {
 #undef RSBA_P
 };
 
+// v[i] = sum over q < n of block q's entry i (this thread's slot), blocks RSBA_PART*256 doubles apart, in block order.
+// Agent-scope loads (see TileTreeReduce); two blocks are in flight at a time when the registers allow it (the sums
+// sit at the tail of a tile, where only memory-level parallelism shortens them).
+template <int NV>
+__device__ __forceinline__ void TreeSum(const double* __restrict__ in, int n, double* v) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = 0.0;
+  int q = 0;
+  if (NV <= 36) {
+    for (; q + 1 < n; q += 2) {
+      const double* p0 = in + (size_t)q * RSBA_PART * 256;
+      const double* p1 = p0 + (size_t)RSBA_PART * 256;
+      double x0[NV], x1[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) x0[i] = __hip_atomic_load(&p0[i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) x1[i] = __hip_atomic_load(&p1[i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = (v[i] + x0[i]) + x1[i];
+    }
+  }
+  for (; q < n; ++q) {
+    const double* p0 = in + (size_t)q * RSBA_PART * 256;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] += __hip_atomic_load(&p0[i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Reduction tree of a tile without further launches.  Every workgroup has written its partial block (agent-scope
+// stores); the last workgroup of a group of RSBA_GRP segments to arrive adds the group's blocks in segment order (the
+// sums do not depend on who arrives last) and the last group of a tile adds the group sums: that workgroup returns
+// true with the tile's sums in v[] (slot = thread).  Counters reset themselves.
+// The eight XCDs' L2s are not coherent with each other inside a kernel, and an agent-scope fence costs a write-back /
+// invalidate of a whole L2 (measured: 2x on the pair kernel, 8x on a kernel running beside it, when every workgroup
+// fenced).  So the tree's data moves with agent-scope (sc1) stores and loads that go through to memory, ordered by
+// waiting for the stores' acknowledgements before a counter is bumped; only the tile finishers, whose results are
+// written with ordinary stores, pay for a real fence.
+template <int NV>
+__device__ __forceinline__ bool TileTreeReduce(const SchurSeg& sg, const double* __restrict__ partial, double* __restrict__ grp_sum,
+                                               int* __restrict__ sync_cnt, int ngrp, double* v) {
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0) s_last = __hip_atomic_fetch_add(&sync_cnt[sg.grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.grp_nseg - 1;
+  __syncthreads();
+  if (!s_last) return false;
+  TreeSum<NV>(partial + (size_t)sg.grp_seg0 * RSBA_PART * 256 + tid, sg.grp_nseg, v);
+  {
+    double* gs = grp_sum + (size_t)sg.grp * RSBA_PART * 256 + tid;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) __hip_atomic_store(&gs[i * 256], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid == 0) __hip_atomic_store(&sync_cnt[sg.grp], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0) s_last = __hip_atomic_fetch_add(&sync_cnt[ngrp + sg.tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.tile_ngrp - 1;
+  __syncthreads();
+  if (!s_last) return false;
+  TreeSum<NV>(grp_sum + (size_t)sg.tile_grp0 * RSBA_PART * 256 + tid, sg.tile_ngrp, v);
+  if (tid == 0) __hip_atomic_store(&sync_cnt[ngrp + sg.tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+// The tile's results are written: one arrival at the stage counter; true (whole workgroup) for the last tile of the stage.
+__device__ __forceinline__ bool StageArrive(const SchurSeg& sg, int* __restrict__ sync_cnt, int ngrp, int ntiles) {
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_last = __hip_atomic_fetch_add(&sync_cnt[ngrp + ntiles + sg.stage], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.stage_ntiles - 1;
+    if (s_last) __hip_atomic_store(&sync_cnt[ngrp + ntiles + sg.stage], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+// Self tile: lane (ia, s) holds slice s of camera 16 ga + ia's 42 sums in v[]; called by the whole workgroup (shuffles).
+// Adds the 16 slices in a fixed tree order, then K factors, diagonal S block, diag(U), g_c and the rhs correction.
+__device__ __forceinline__ void FinishSelfSlot(int C, int ga, double* v, const double* __restrict__ camc, double* __restrict__ red, RedLayout L) {
+  const int tid = threadIdx.x, ia = tid >> 4, ib = tid & 15, cam_a = RSBA_TG * ga + ia;
+  // sum the 16 slices of a row (lanes ia*16 .. ia*16+15 are contiguous inside a wave) in a fixed tree order
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+#pragma unroll
+    for (int i = 0; i < RSBA_PART; ++i) v[i] += __shfl_down(v[i], off, 16);
+  }
+  if (ib != 0 || cam_a >= C) return;
+  const double* K = camc + (size_t)cam_a * CC_STRIDE + CC_K;
+  // symmetric core -> full 6x6, then T' core T with T = blkdiag(K, I)
+  double cfull[36];
+  { int t = 0;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+#pragma unroll
+      for (int q = p; q < 6; ++q) { cfull[6 * p + q] = v[t]; cfull[6 * q + p] = v[t]; ++t; } } }
+  double tmp[36], blk[36];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) tmp[6 * p + q] = K[0 * 3 + p] * cfull[0 * 6 + q] + K[1 * 3 + p] * cfull[1 * 6 + q] + K[2 * 3 + p] * cfull[2 * 6 + q];
+#pragma unroll
+    for (int p = 3; p < 6; ++p) tmp[6 * p + q] = cfull[6 * p + q];
+  }
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) blk[6 * p + q] = tmp[6 * p + 0] * K[0 * 3 + q] + tmp[6 * p + 1] * K[1 * 3 + q] + tmp[6 * p + 2] * K[2 * 3 + q];
+#pragma unroll
+    for (int q = 3; q < 6; ++q) blk[6 * p + q] = tmp[6 * p + q];
+  }
+  double* Sd = red + L.S() + (size_t)(6 * cam_a) * L.nc + 6 * cam_a;
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+#pragma unroll
+    for (int q = p; q < 6; ++q) { const double x = 0.5 * (blk[6 * p + q] + blk[6 * q + p]); Sd[(size_t)p * L.nc + q] = x; Sd[(size_t)q * L.nc + p] = x; }
+  }
+  // diag(U): rows 0..2 through K, rows 3..5 as they are
+  const double u00 = v[21], u01 = v[22], u02 = v[23], u11 = v[24], u12 = v[25], u22 = v[26];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const double k0 = K[0 * 3 + p], k1 = K[1 * 3 + p], k2 = K[2 * 3 + p];
+    red[L.diagU() + 6 * cam_a + p] = k0 * (u00 * k0 + u01 * k1 + u02 * k2) + k1 * (u01 * k0 + u11 * k1 + u12 * k2) + k2 * (u02 * k0 + u12 * k1 + u22 * k2);
+  }
+#pragma unroll
+  for (int p = 3; p < 6; ++p) red[L.diagU() + 6 * cam_a + p] = v[27 + p - 3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    red[L.gc() + 6 * cam_a + p] = K[0 * 3 + p] * v[30] + K[1 * 3 + p] * v[31] + K[2 * 3 + p] * v[32];
+    red[L.corr() + 6 * cam_a + p] = -(K[0 * 3 + p] * v[36] + K[1 * 3 + p] * v[37] + K[2 * 3 + p] * v[38]);
+  }
+#pragma unroll
+  for (int p = 3; p < 6; ++p) { red[L.gc() + 6 * cam_a + p] = v[30 + p]; red[L.corr() + 6 * cam_a + p] = -v[36 + p]; }
+}
+
+// K factors and the S blocks of one camera pair: slot (ia, ib) of tile (ga, gb) with its 36 reduced sums in `core`.
+__device__ __forceinline__ void FinishPairSlot(int C, int ga, int gb, int slot, const double* core, const double* __restrict__ camc,
+                                               double* __restrict__ red, RedLayout L) {
+  const int ia = slot >> 4, ib = slot & 15;
+  const int cam_a = RSBA_TG * ga + ia, cam_b = RSBA_TG * gb + ib;
+  if (cam_a >= C || cam_b >= C || (ga == gb && ia >= ib)) return;
+  const double* Ka = camc + (size_t)cam_a * CC_STRIDE + CC_K;
+  const double* Kb = camc + (size_t)cam_b * CC_STRIDE + CC_K;
+  // rows: Ta' core  (first three rows mixed by Ka')
+  double tmp[36];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) tmp[6 * p + q] = Ka[0 * 3 + p] * core[0 * 6 + q] + Ka[1 * 3 + p] * core[1 * 6 + q] + Ka[2 * 3 + p] * core[2 * 6 + q];
+#pragma unroll
+    for (int p = 3; p < 6; ++p) tmp[6 * p + q] = core[6 * p + q];
+  }
+  // columns: (.) Tb
+  double blk[36];
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) blk[6 * p + q] = tmp[6 * p + 0] * Kb[0 * 3 + q] + tmp[6 * p + 1] * Kb[1 * 3 + q] + tmp[6 * p + 2] * Kb[2 * 3 + q];
+#pragma unroll
+    for (int q = 3; q < 6; ++q) blk[6 * p + q] = tmp[6 * p + q];
+  }
+  // S is written full symmetric: block (a,b) = -blk, block (b,a) = -blk' (nobody else touches off-diagonal blocks)
+  double* Sb = red + L.S() + (size_t)(6 * cam_a) * L.nc + 6 * cam_b;
+  double* St = red + L.S() + (size_t)(6 * cam_b) * L.nc + 6 * cam_a;
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { Sb[(size_t)p * L.nc + q] = -blk[6 * p + q]; St[(size_t)q * L.nc + p] = -blk[6 * p + q]; }
+  }
+}
+
 // Pair tiles (ga <= gb, a != b).  Two workgroups per CU: the accumulators (72 VGPRs) are the only long-lived
 // per-lane state; camera constants sit in LDS (broadcast within a 16-lane row / replicated across rows).
+struct SchurArgs {
+  int C, P, nwords;
+  const double* __restrict__ camc;
+  const SchurSeg* __restrict__ segs;
+  const unsigned long long* __restrict__ cam_mask;
+  const double* __restrict__ ptdata;
+  const int* __restrict__ cam_prefix;
+  const int* __restrict__ cam_ptr;
+  const double* __restrict__ sq_cm;
+  const double* __restrict__ u_cm;
+  const double* __restrict__ v_cm;
+  double* __restrict__ partial;
+  double* __restrict__ grp_sum;
+  int* __restrict__ sync_cnt;
+  int ngrp, ntiles, nself_seg, npair_seg;
+  int* __restrict__ ready;
+  unsigned publish;   // ready[] bits the last self tile publishes: bit 0 + the stages without any pair tile
+  int tag;            // 0: nobody is waiting (sequential schedule)
+  double* __restrict__ red;
+  RedLayout L;
+  int nblocks_pp;
+  const double* __restrict__ block_scal;
+  double* __restrict__ gmax_p;
+  long long* trace;   // diagnostic (RSBA_TRACE=1)
+};
+
 template <bool kLoss>
-__global__ void __launch_bounds__(256, 2)
-k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const SchurSeg* __restrict__ segs,
-              const unsigned long long* __restrict__ cam_mask, const double* __restrict__ ptdata,
-              const int* __restrict__ cam_prefix, const int* __restrict__ cam_ptr, const double* __restrict__ sq_cm,
-              double* __restrict__ partial) {
-  __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];            // 48 KB
-  __shared__ unsigned long long mk[2 * RSBA_TG][RSBA_CW];       // 2 KB
-  __shared__ double sc[2 * RSBA_TG * RSBA_SC_STRIDE];           // 4 KB
-  const SchurSeg sg = segs[blockIdx.x];
+__device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& sg, int seg_index, double* pt, unsigned long long (*mk)[RSBA_CW], double* sc) {
+  const int C = a.C, P = a.P, nwords = a.nwords;
+  const double* __restrict__ camc = a.camc;
+  const unsigned long long* __restrict__ cam_mask = a.cam_mask;
+  const double* __restrict__ ptdata = a.ptdata;
+  const int* __restrict__ cam_prefix = a.cam_prefix;
+  const int* __restrict__ cam_ptr = a.cam_ptr;
+  const double* __restrict__ sq_cm = a.sq_cm;
+  double* __restrict__ partial = a.partial;
   const int tid = threadIdx.x;
   const bool diag_tile = sg.ga == sg.gb;
   // off-diagonal tile: lane = (ia, ib) directly; diagonal tile: the 120 pairs ia < ib sit in lanes 0..119
@@ -325,11 +536,19 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
     }
   }
   // slot of pair (ia, ib) in the workgroup's partial block is ia*16+ib whatever lane computed it
-  double* out = partial + (size_t)blockIdx.x * RSBA_PART * 256;
+  double* out = partial + (size_t)seg_index * RSBA_PART * 256;
   if (!diag_tile || tid < 120) {
 #pragma unroll
-    for (int i = 0; i < 36; ++i) out[i * 256 + pr] = acc[i];
+    for (int i = 0; i < 36; ++i) __hip_atomic_store(&out[i * 256 + pr], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // the tile's last workgroup applies the K factors and writes the S blocks; the stage's last tile publishes the stage
+  // for the Cholesky that may be waiting for these columns
+  double v[36];
+  if (!TileTreeReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
+  FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L);
+  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles)) return;
+  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.trace && tid == 0) a.trace[17 + sg.stage] = wall_clock64();
 }
 
 // Self tiles: everything that is a sum over ONE camera's observations — the diagonal block U_a - W V^-1 W' (a, a),
@@ -343,14 +562,17 @@ k_schur_pairs(int C, int P, int nwords, const double* __restrict__ camc, const S
 //   [30,36) E' r                                           (-> g_c)
 //   [36,42) E' N V^-1 g_p                                  (-> -corr)
 template <bool kLoss>
-__global__ void __launch_bounds__(256, 2)
-k_schur_self(int C, int P, int nwords, const double* __restrict__ camc, const SchurSeg* __restrict__ segs,
-             const unsigned long long* __restrict__ cam_mask, const double* __restrict__ ptdata,
-             const int* __restrict__ cam_prefix, const int* __restrict__ cam_ptr, const double* __restrict__ sq_cm,
-             const double* __restrict__ u_cm, const double* __restrict__ v_cm, double* __restrict__ partial, int seg0) {
-  __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];
-  __shared__ unsigned long long mk[RSBA_TG][RSBA_CW];
-  const SchurSeg sg = segs[seg0 + blockIdx.x];
+__device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& sg, int seg_index, double* pt, unsigned long long (*mk)[RSBA_CW]) {
+  const int C = a.C, P = a.P, nwords = a.nwords;
+  const double* __restrict__ camc = a.camc;
+  const unsigned long long* __restrict__ cam_mask = a.cam_mask;
+  const double* __restrict__ ptdata = a.ptdata;
+  const int* __restrict__ cam_prefix = a.cam_prefix;
+  const int* __restrict__ cam_ptr = a.cam_ptr;
+  const double* __restrict__ sq_cm = a.sq_cm;
+  const double* __restrict__ u_cm = a.u_cm;
+  const double* __restrict__ v_cm = a.v_cm;
+  double* __restrict__ partial = a.partial;
   const int tid = threadIdx.x, ia = tid >> 4, ib = tid & 15;
   const int cam_a = RSBA_TG * sg.ga + ia;
   const bool live = cam_a < C;
@@ -423,127 +645,42 @@ k_schur_self(int C, int P, int nwords, const double* __restrict__ camc, const Sc
       for (int p = 0; p < 6; ++p) { acc[30 + p] += e0[p] * r0 + e1[p] * r1; acc[36 + p] += e0[p] * f0 + e1[p] * f1; }
     }
   }
-  double* out = partial + (size_t)(seg0 + blockIdx.x) * RSBA_PART * 256;
+  double* out = partial + (size_t)seg_index * RSBA_PART * 256;
 #pragma unroll
-  for (int i = 0; i < RSBA_PART; ++i) out[i * 256 + tid] = acc[i];
+  for (int i = 0; i < RSBA_PART; ++i) __hip_atomic_store(&out[i * 256 + tid], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // same tree as the pair tiles; the last self tile also folds the point pass' per-block scalars (cost, |X|^2,
+  // failures, max|g_p|) and publishes ready[0] (+ the stages that have no pair tile at all)
+  double v[RSBA_PART];
+  if (!TileTreeReduce<RSBA_PART>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
+  FinishSelfSlot(C, sg.ga, v, camc, a.red, a.L);
+  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles)) return;
+  FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
+  __threadfence();
+  __syncthreads();
+  if (tid == 0 && a.tag) {
+    for (int i = 0; i < 16; ++i) if (a.publish >> i & 1u) __hip_atomic_store(&a.ready[i], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (a.trace && tid == 0) a.trace[16] = wall_clock64();
 }
 
-// K_A3a: fixed-order sum over the segments of a tile, one workgroup per (tile, component): 42 x ntiles
-// workgroups instead of ntiles, so the partial sums stream at HBM/L2 rate instead of one CU's.
-__global__ void __launch_bounds__(256)
-k_schur_reduce(const int* __restrict__ tile_seg_ptr, const double* __restrict__ partial, double* __restrict__ tile_sum /* [ntiles][42][256] */) {
-  const int tile = blockIdx.x / RSBA_PART, k = blockIdx.x - tile * RSBA_PART, tid = threadIdx.x;
-  double s = 0.0;
-#pragma unroll 8
-  for (int sgi = tile_seg_ptr[tile]; sgi < tile_seg_ptr[tile + 1]; ++sgi) s += partial[((size_t)sgi * RSBA_PART + k) * 256 + tid];
-  tile_sum[((size_t)tile * RSBA_PART + k) * 256 + tid] = s;
+// K_A2: the Schur elimination kernel.  One workgroup per segment (a range of 64-point words of one tile); the self
+// segments come first in block order (the Cholesky's first gate), then the pair tiles stage by stage.  Two workgroups
+// per CU: the accumulators are the only long-lived per-lane state; point data, visibility rows and camera constants sit
+// in LDS.
+template <bool kLoss>
+__global__ void __launch_bounds__(256, 2)
+k_schur_tiles(SchurArgs a) {
+  __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];            // 48 KB
+  __shared__ unsigned long long mk[2 * RSBA_TG][RSBA_CW];       // 2 KB
+  __shared__ double sc[2 * RSBA_TG * RSBA_SC_STRIDE];           // 4 KB
+  // segs[] holds the pair segments first ([0, npair_seg)), the self segments after them
+  const int seg_index = (int)blockIdx.x < a.nself_seg ? a.npair_seg + (int)blockIdx.x : (int)blockIdx.x - a.nself_seg;
+  const SchurSeg sg = a.segs[seg_index];
+  if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
+  if (a.trace && (int)blockIdx.x == a.nself_seg && threadIdx.x == 0) a.trace[25] = wall_clock64();
+  if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, pt, mk);
+  else PairSegment<kLoss>(a, sg, seg_index, pt, mk, sc);
 }
 
-// K_A3b: K factors, S blocks (full symmetric), corr.  One thread per pair; self tiles first add their 16 lane
-// slices with a shuffle reduction inside each 16-lane row.
-__global__ void __launch_bounds__(256)
-k_schur_finish(int C, int ntiles, const int* __restrict__ tile_ab, const double* __restrict__ tile_sum,
-               const double* __restrict__ camc, double* __restrict__ red, RedLayout L, int nblocks_pp,
-               const double* __restrict__ block_scal, double* __restrict__ gmax_p) {
-  const int tile = blockIdx.x, tid = threadIdx.x;
-  // one extra workgroup folds the point pass' per-block scalars (cost, |X|^2, failures, max|g_p|): saves a launch
-  if (tile == ntiles) { FinishLinearize(nblocks_pp, block_scal, red, L, gmax_p); return; }
-  if (tile > ntiles) return;
-  const int ga = tile_ab[3 * tile], gb = tile_ab[3 * tile + 1];
-  const bool self_tile = tile_ab[3 * tile + 2] != 0;
-  const int ia = tid >> 4, ib = tid & 15;
-  const int cam_a = RSBA_TG * ga + ia, cam_b = self_tile ? cam_a : RSBA_TG * gb + ib;
-  const double* in = tile_sum + (size_t)tile * RSBA_PART * 256;
-  if (self_tile) {
-    // sum the 16 slices of a row (lanes ia*16 .. ia*16+15 are contiguous inside a wave) in a fixed tree order
-    double v[RSBA_PART];
-#pragma unroll
-    for (int i = 0; i < RSBA_PART; ++i) v[i] = in[i * 256 + tid];
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
-#pragma unroll
-      for (int i = 0; i < RSBA_PART; ++i) v[i] += __shfl_down(v[i], off, 16);
-    }
-    if (ib != 0 || cam_a >= C) return;
-    const double* K = camc + (size_t)cam_a * CC_STRIDE + CC_K;
-    // symmetric core -> full 6x6, then T' core T with T = blkdiag(K, I)
-    double cfull[36];
-    { int t = 0;
-#pragma unroll
-      for (int p = 0; p < 6; ++p) {
-#pragma unroll
-        for (int q = p; q < 6; ++q) { cfull[6 * p + q] = v[t]; cfull[6 * q + p] = v[t]; ++t; } } }
-    double tmp[36], blk[36];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) tmp[6 * p + q] = K[0 * 3 + p] * cfull[0 * 6 + q] + K[1 * 3 + p] * cfull[1 * 6 + q] + K[2 * 3 + p] * cfull[2 * 6 + q];
-#pragma unroll
-      for (int p = 3; p < 6; ++p) tmp[6 * p + q] = cfull[6 * p + q];
-    }
-#pragma unroll
-    for (int p = 0; p < 6; ++p) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) blk[6 * p + q] = tmp[6 * p + 0] * K[0 * 3 + q] + tmp[6 * p + 1] * K[1 * 3 + q] + tmp[6 * p + 2] * K[2 * 3 + q];
-#pragma unroll
-      for (int q = 3; q < 6; ++q) blk[6 * p + q] = tmp[6 * p + q];
-    }
-    double* Sd = red + L.S() + (size_t)(6 * cam_a) * L.nc + 6 * cam_a;
-#pragma unroll
-    for (int p = 0; p < 6; ++p) {
-#pragma unroll
-      for (int q = p; q < 6; ++q) { const double x = 0.5 * (blk[6 * p + q] + blk[6 * q + p]); Sd[(size_t)p * L.nc + q] = x; Sd[(size_t)q * L.nc + p] = x; }
-    }
-    // diag(U): rows 0..2 through K, rows 3..5 as they are
-    const double u00 = v[21], u01 = v[22], u02 = v[23], u11 = v[24], u12 = v[25], u22 = v[26];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      const double k0 = K[0 * 3 + p], k1 = K[1 * 3 + p], k2 = K[2 * 3 + p];
-      red[L.diagU() + 6 * cam_a + p] = k0 * (u00 * k0 + u01 * k1 + u02 * k2) + k1 * (u01 * k0 + u11 * k1 + u12 * k2) + k2 * (u02 * k0 + u12 * k1 + u22 * k2);
-    }
-#pragma unroll
-    for (int p = 3; p < 6; ++p) red[L.diagU() + 6 * cam_a + p] = v[27 + p - 3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      red[L.gc() + 6 * cam_a + p] = K[0 * 3 + p] * v[30] + K[1 * 3 + p] * v[31] + K[2 * 3 + p] * v[32];
-      red[L.corr() + 6 * cam_a + p] = -(K[0 * 3 + p] * v[36] + K[1 * 3 + p] * v[37] + K[2 * 3 + p] * v[38]);
-    }
-#pragma unroll
-    for (int p = 3; p < 6; ++p) { red[L.gc() + 6 * cam_a + p] = v[30 + p]; red[L.corr() + 6 * cam_a + p] = -v[36 + p]; }
-    return;
-  }
-  double core[36];
-#pragma unroll
-  for (int i = 0; i < 36; ++i) core[i] = in[i * 256 + tid];
-  if (cam_a >= C || cam_b >= C || (ga == gb && ia >= ib)) return;
-  const double* Ka = camc + (size_t)cam_a * CC_STRIDE + CC_K;
-  const double* Kb = camc + (size_t)cam_b * CC_STRIDE + CC_K;
-  // rows: Ta' core  (first three rows mixed by Ka')
-  double tmp[36];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p) tmp[6 * p + q] = Ka[0 * 3 + p] * core[0 * 6 + q] + Ka[1 * 3 + p] * core[1 * 6 + q] + Ka[2 * 3 + p] * core[2 * 6 + q];
-#pragma unroll
-    for (int p = 3; p < 6; ++p) tmp[6 * p + q] = core[6 * p + q];
-  }
-  // columns: (.) Tb
-  double blk[36];
-#pragma unroll
-  for (int p = 0; p < 6; ++p) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) blk[6 * p + q] = tmp[6 * p + 0] * Kb[0 * 3 + q] + tmp[6 * p + 1] * Kb[1 * 3 + q] + tmp[6 * p + 2] * Kb[2 * 3 + q];
-#pragma unroll
-    for (int q = 3; q < 6; ++q) blk[6 * p + q] = tmp[6 * p + q];
-  }
-  // S is written full symmetric: block (a,b) = -blk, block (b,a) = -blk' (nobody else touches off-diagonal blocks)
-  double* Sb = red + L.S() + (size_t)(6 * cam_a) * L.nc + 6 * cam_b;
-  double* St = red + L.S() + (size_t)(6 * cam_b) * L.nc + 6 * cam_a;
-#pragma unroll
-  for (int p = 0; p < 6; ++p) {
-#pragma unroll
-    for (int q = 0; q < 6; ++q) { Sb[(size_t)p * L.nc + q] = -blk[6 * p + q]; St[(size_t)q * L.nc + p] = -blk[6 * p + q]; }
-  }
-}
 
 }  // namespace rsba

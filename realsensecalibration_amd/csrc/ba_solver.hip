@@ -63,7 +63,7 @@ class KernelTimer {
   // timed region to four records per iteration)
   void Enable(int mode) { mode_ = mode; on_ = false; }
   bool enabled() const { return mode_ != 0; }
-  static bool Major(const char* n) { return strcmp(n, "k_schur_pairs") == 0 || strcmp(n, "k_reduced_system_solve") == 0 || strcmp(n, "k_linearize_schur_ref") == 0; }
+  static bool Major(const char* n) { return strcmp(n, "k_schur_tiles") == 0 || strcmp(n, "k_reduced_system_solve") == 0 || strcmp(n, "k_linearize_schur_ref") == 0; }
   void Begin(const char* name, hipStream_t s) {
     on_ = mode_ == 1 || (mode_ == 2 && Major(name));
     if (!on_) return;
@@ -83,6 +83,7 @@ class KernelTimer {
     }
     pending_.clear();
   }
+  void Add(const char* name, double ms) { auto& st = stats_[name]; st.first += 1; st.second += ms; }
   void Reset() { Collect(); stats_.clear(); }
   const std::map<std::string, std::pair<int64_t, double>>& stats() const { return stats_; }
  private:
@@ -106,6 +107,17 @@ struct rsba_solver {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // Pipelined solve (single GPU, 17..64 cameras): the one-workgroup Cholesky is launched FIRST, on its own hardware
+  // queue restricted to one CU (sB), and waits inside the kernel for ready flags; the pair kernel (on the main stream)
+  // publishes each camera group's columns as its last workgroups reduce them, the self tiles are the first blocks of the same launch.
+  bool pipelined = false;
+  bool test_stall = false;   // RSBA_TEST_STALL=1: the Cholesky waits for a tag nobody publishes (exercises the fallback)
+  int step_tag = 0;
+  hipStream_t sB = nullptr;
+  hipEvent_t ev_chol = nullptr;
+  long long* chol_waited = nullptr;   // device: ticks the pipelined Cholesky spent waiting for its columns (cumulative)
+  long long chol_waited_seen = 0;
+  long long* trace = nullptr;   // RSBA_TRACE=1: 32 wall-clock stamps of the pipelined step
   ncclComm_t comm = nullptr;
   KernelTimer timer;
   std::vector<rsba_iteration> iters;
@@ -145,7 +157,8 @@ namespace rsba {
 // Static structure of the tiled Schur kernel: visibility bitsets, tiles, segments.
 // ------------------------------------------------------------------------------------------------
 int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
-                      const std::vector<int>& sliced_q) {
+                      const std::vector<int>& sliced_q, bool staged) {
+  (void)staged;
   C = C_; P = P_;
   ngroups = (C + RSBA_TG - 1) / RSBA_TG;
   nwords = ((P + 63) / 64 + RSBA_CW - 1) / RSBA_CW * RSBA_CW;
@@ -176,11 +189,17 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   ntiles = (int)wt.size();
   int cus = 256;
   { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
-  const int target = (getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : 4) * cus;
-  // pair tiles share `target` workgroups; the self tiles (their own, much lighter launch) get 2 per CU in total
+  const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : 4;
+  const int target = seg_per_cu * cus;
+  // the pair tiles share `target` workgroups, same number for every tile (the pipelined solve launches them stage
+  // by stage, ga == g: the later, smaller stages need not fill the chip, they only have to finish before the
+  // Cholesky of the previous stage does); the self tiles (their own, much lighter launch) get 2 per CU in total
   int npair_tiles = 0;
-  for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) ++npair_tiles;
+  std::vector<int> tiles_of_stage(ngroups, 0);
+  for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) { ++npair_tiles; ++tiles_of_stage[tab[3 * t]]; }
   std::vector<SchurSeg> sg; std::vector<int> tsp(ntiles + 1, 0);
+  nstages = ngroups; ngrp = 0;
+  stage_tile.assign(nstages + 1, 0); stage_seg.assign(nstages + 1, 0);
   for (int t = 0; t < ntiles; ++t) {
     const bool self = tab[3 * t + 2] != 0;
     int ns = self ? (2 * cus + ngroups - 1) / ngroups : (int)std::lround((double)target / std::max(1, npair_tiles));
@@ -193,6 +212,20 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       sg.push_back(e);
     }
     tsp[t + 1] = (int)sg.size();
+    // pair tiles are ordered by ga: stage g ends after its last tile
+    if (!self) for (int g = tab[3 * t]; g < nstages; ++g) { stage_tile[g + 1] = t + 1; stage_seg[g + 1] = tsp[t + 1]; }
+    {
+      // reduction tree of this tile: groups of RSBA_GRP consecutive segments; the self tiles form one more "stage"
+      const int s0 = tsp[t], ns_t = tsp[t + 1] - tsp[t], g0 = ngrp, ng = (ns_t + RSBA_GRP - 1) / RSBA_GRP;
+      for (int i = 0; i < ns_t; ++i) {
+        SchurSeg& e = sg[s0 + i];
+        e.tile = t; e.grp = g0 + i / RSBA_GRP; e.grp_seg0 = s0 + (i / RSBA_GRP) * RSBA_GRP;
+        e.grp_nseg = std::min(RSBA_GRP, ns_t - (i / RSBA_GRP) * RSBA_GRP);
+        e.tile_grp0 = g0; e.tile_ngrp = ng;
+        e.stage = self ? nstages : tab[3 * t]; e.stage_ntiles = self ? ngroups : tiles_of_stage[tab[3 * t]];
+      }
+      ngrp += ng;
+    }
   }
   nseg = (int)sg.size();
   nseg_pair = 0;
@@ -201,7 +234,8 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   int rc;
   if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nseg)) || (rc = DevAlloc(&tile_seg_ptr, (size_t)ntiles + 1)) ||
       (rc = DevAlloc(&tile_ab, (size_t)3 * ntiles)) || (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
-      (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
+      (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
+      (rc = DevAlloc(&sync_cnt, (size_t)ngrp + ntiles + nstages + 1)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm, cmpos.size())) || (rc = DevAlloc(&u_cm, cmpos.size())) || (rc = DevAlloc(&v_cm, cmpos.size())))
     return rc;
@@ -211,6 +245,8 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     HIPCHK(hipMemcpy(u_cm, ucm.data(), ucm.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(v_cm, vcm.data(), vcm.size() * sizeof(double), hipMemcpyHostToDevice));
   }
+  HIPCHK(hipMemset(sync_cnt, 0, ((size_t)ngrp + ntiles + nstages + 1) * sizeof(int)));
+  HIPCHK(hipMemset(ready, 0, 16 * sizeof(int)));
   HIPCHK(hipMemcpy(cam_mask, mask.data(), mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(segs, sg.data(), sg.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(tile_seg_ptr, tsp.data(), tsp.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -226,7 +262,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, tile_seg_ptr, tile_ab, ptdata, partial, tile_sum, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
+  void* ptrs[] = {cam_mask, segs, tile_seg_ptr, tile_ab, ptdata, partial, grp_sum, sync_cnt, ready, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   cam_mask = nullptr;
 }
@@ -242,6 +278,10 @@ static void FreeSolver(rsba_solver* s) {
   s->tiled.Free();
   s->marker.Free();
   if (s->res_host) (void)hipHostFree(s->res_host);
+  if (s->trace) (void)hipFree(s->trace);
+  if (s->chol_waited) (void)hipFree(s->chol_waited);
+  if (s->sB) (void)hipStreamDestroy(s->sB);
+  if (s->ev_chol) (void)hipEventDestroy(s->ev_chol);
   if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -266,6 +306,30 @@ static IterParams MakeIterParams(const rsba_options& o, double radius, bool firs
 // Upload of the point model: observations are re-ordered by (point, camera) so that one point's
 // records are contiguous; the permutation is kept so nothing the caller sees changes order.
 // ------------------------------------------------------------------------------------------------
+// Streams and events of the pipelined solve.  The Cholesky stream is created with a CU mask: that gives it a hardware
+// queue of its own (a waiting kernel must never sit in front of its producers in a shared queue) and one CU that the
+// chip-filling kernels launched after it cannot take (without the reservation a one-workgroup kernel that needs a whole
+// CU was measured to start 4.5 ms late).  RSBA_PIPELINE=0 switches the pipeline off, =2 gives sB all CUs.
+static bool SetupPipeline(rsba_solver* s) {
+  const char* env = getenv("RSBA_PIPELINE");
+  const int mode = env ? atoi(env) : 1;
+  if (mode == 0) return false;
+  s->test_stall = getenv("RSBA_TEST_STALL") != nullptr;
+  if (s->comm || s->opt.world_size > 1) return false;               // multi-GPU keeps the one-all-reduce schedule
+  if (s->nc > RSBA_CHOL_MAXN || s->C <= RSBA_TG) return false;        // one camera group: nothing to overlap
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) return false;
+  const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
+  std::vector<uint32_t> mask(words, mode == 2 ? 0xffffffffu : 0u);
+  if (mode != 2) mask[0] = 1u;
+  bool ok = hipExtStreamCreateWithCUMask(&s->sB, words, mask.data()) == hipSuccess &&
+            hipEventCreateWithFlags(&s->ev_chol, hipEventDisableTiming) == hipSuccess &&
+            hipMalloc((void**)&s->chol_waited, sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, sizeof(long long)) == hipSuccess;
+  if (ok && getenv("RSBA_TRACE")) ok = hipMalloc((void**)&s->trace, 32 * sizeof(long long)) == hipSuccess && hipMemset(s->trace, 0, 32 * sizeof(long long)) == hipSuccess;
+  if (!ok) { (void)hipGetLastError(); if (getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: CU-masked stream unavailable, solve not pipelined\n"); }
+  return ok;
+}
+
 static int UploadPoints(rsba_solver* s) {
   const rsba_problem& p = *s->prob;
   s->C = p.num_cameras; s->P = p.num_points; s->N = p.num_observations; s->nc = 6 * s->C; s->L = RedLayout{s->nc};
@@ -335,7 +399,8 @@ static int UploadPoints(rsba_solver* s) {
     if (dup) s->opt.schur_impl = 0;
   }
   if (s->opt.schur_impl != 0) {
-    rc = s->tiled.Build(C, P, ptr, cam, u, v, sl_q);
+    s->pipelined = SetupPipeline(s);
+    rc = s->tiled.Build(C, P, ptr, cam, u, v, sl_q, s->pipelined);
     if (rc != RSBA_OK) return rc;
   } else if (maxk > 64) {
     fprintf(stderr, "rsba: schur_impl=0 handles at most 64 views per point (problem has %d)\n", maxk);
@@ -352,8 +417,7 @@ static int ResetPoints(rsba_solver* s) {
 }
 
 
-int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
-  hipStream_t st = s->stream;
+void TiledSchur::LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st) {
   const int x = s->cur;
   const bool stage = (size_t)C * RSBA_CC_LDS * sizeof(double) <= 56 * 1024;
   const size_t lds = stage ? (size_t)C * RSBA_CC_LDS * sizeof(double) : 0;
@@ -365,26 +429,30 @@ int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
     k_point_pass<false><<<grid_pp, 256, lds, st>>>(C, P, s->sliced(), s->camc[x], s->pts[x], s->scale_p, ptdata,
                                                    block_scal, cm_pos, sq_cm, ip);
   T.End(st);
-  T.Begin("k_schur_pairs", st);
-  if (nseg_pair > 0) {
-    if (ip.huber_delta > 0.0)
-      k_schur_pairs<true><<<nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial);
-    else
-      k_schur_pairs<false><<<nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, partial);
-  }
+}
+
+// The Schur elimination launch: self segments first, then the pair tiles stage by stage; results land in s->red.
+// tag != 0: the ready flags are published for a Cholesky that is already waiting (pipelined schedule).
+void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag) {
+  const int x = s->cur;
+  SchurArgs a;
+  a.C = C; a.P = P; a.nwords = nwords; a.camc = s->camc[x]; a.segs = segs; a.cam_mask = cam_mask; a.ptdata = ptdata;
+  a.cam_prefix = cam_prefix; a.cam_ptr = cam_ptr; a.sq_cm = sq_cm; a.u_cm = u_cm; a.v_cm = v_cm; a.partial = partial;
+  a.grp_sum = grp_sum; a.sync_cnt = sync_cnt; a.ngrp = ngrp; a.ntiles = ntiles; a.nself_seg = nseg - nseg_pair; a.npair_seg = nseg_pair;
+  a.ready = ready; a.tag = tag; a.red = s->red; a.L = s->L; a.nblocks_pp = grid_pp; a.block_scal = block_scal; a.gmax_p = s->gmax;
+  a.trace = s->trace;
+  a.publish = 1u;  // ready[0]; plus the stages that have no pair tile at all (a last group of one camera)
+  for (int g = 0; g < nstages; ++g) if (stage_tile[g + 1] == stage_tile[g]) a.publish |= 1u << (1 + g);
+  T.Begin("k_schur_tiles", st);
+  if (ip.huber_delta > 0.0) k_schur_tiles<true><<<nseg, 256, 0, st>>>(a);
+  else k_schur_tiles<false><<<nseg, 256, 0, st>>>(a);
   T.End(st);
-  T.Begin("k_schur_self", st);
-  if (ip.huber_delta > 0.0)
-    k_schur_self<true><<<nseg - nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, u_cm, v_cm, partial, nseg_pair);
-  else
-    k_schur_self<false><<<nseg - nseg_pair, 256, 0, st>>>(C, P, nwords, s->camc[x], segs, cam_mask, ptdata, cam_prefix, cam_ptr, sq_cm, u_cm, v_cm, partial, nseg_pair);
-  T.End(st);
-  T.Begin("k_schur_reduce", st);
-  k_schur_reduce<<<ntiles * RSBA_PART, 256, 0, st>>>(tile_seg_ptr, partial, tile_sum);
-  T.End(st);
-  T.Begin("k_schur_finish", st);
-  k_schur_finish<<<ntiles + 1, 256, 0, st>>>(C, ntiles, tile_ab, tile_sum, s->camc[x], s->red, s->L, grid_pp, block_scal, s->gmax);
-  T.End(st);
+}
+
+int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
+  hipStream_t st = s->stream;
+  LaunchPointPass(s, ip, T, st);
+  LaunchTiles(s, ip, T, st, 0);
   return RSBA_OK;
 }
 
@@ -405,6 +473,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     T.End(st);
   }
   DebugSync(st, "k_camera_constants");
+  const bool pipe = s->pipelined && s->opt.schur_impl != 0 && !keep_system_copy;
   // impl 0 accumulates into `red` with atomics; the tiled path writes every entry of it exactly once
   if (s->opt.schur_impl == 0) HIPCHK(hipMemsetAsync(s->red, 0, s->L.size() * sizeof(double), st));
   DebugSync(st, "memset red");
@@ -423,9 +492,27 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     T.Begin("k_finish_linearize", st);
     k_finish_linearize<<<1, 256, 0, st>>>(s->grid_lin, s->block_scal, s->red, s->L, s->gmax);
     T.End(st);
-  } else {
+  } else if (!pipe) {
     int rc = s->tiled.Launch(s, ip, T);
     if (rc != RSBA_OK) return rc;
+  } else {
+    // Pipelined.  Camera group g's columns of the reduced system are complete once the pair tiles (g, g' >= g) are
+    // reduced, and the left-looking Cholesky needs nothing else for its panels 3g..3g+2.  The Cholesky kernel goes out
+    // first (it takes the reserved CU while the chip is idle and sleeps on the ready flags), then the point pass, then
+    // the pair kernel (stage by stage in block order) with the self tiles beside it.
+    TiledSchur& ts = s->tiled;
+    const int n = s->nc, tag = ++s->step_tag;
+    const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(n)) * sizeof(double);
+    if (lds_c > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+    T.Begin("k_reduced_system_solve", s->sB);
+    k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
+                                                     s->camc[c], s->dcam, s->gmax, s->res, ip, 1, 0, n, RSBA_STAGE_FIRST | RSBA_STAGE_LAST,
+                                                     s->chol_ok, StageGate{ts.ready, s->test_stall ? tag + 1 : tag, 6 * RSBA_TG, s->chol_waited, s->trace});
+    T.End(s->sB);
+    HIPCHK(hipEventRecord(s->ev_chol, s->sB));
+    ts.LaunchPointPass(s, ip, T, st);
+    ts.LaunchTiles(s, ip, T, st, tag);
+    HIPCHK(hipStreamWaitEvent(st, s->ev_chol, 0));
   }
   HIPCHK(hipGetLastError());
   DebugSync(st, "linearize+schur");
@@ -435,13 +522,16 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     NCCLCHK(ncclAllReduce(s->gmax, s->gmax, 1, ncclDouble, ncclMax, s->comm, st));
   }
 
-  if (s->nc <= RSBA_CHOL_MAXN) {
+  if (pipe) {
+    // issued at the top of the step (see below): nothing left to launch here
+  } else if (s->nc <= RSBA_CHOL_MAXN) {
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(s->nc)) * sizeof(double);
     T.Begin("k_reduced_system_solve", st);
-    if (lds_c > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-    k_reduced_system_solve<512><<<1, 512, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
-                                                      keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
-                                                      s->camc[c], s->dcam, s->gmax, s->res, ip, s->opt.schur_impl != 0 ? 1 : 0);
+    if (lds_c > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+    k_reduced_system_solve<<<1, 512, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
+                                                  keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
+                                                  s->camc[c], s->dcam, s->gmax, s->res, ip, s->opt.schur_impl != 0 ? 1 : 0, 0, s->nc,
+                                                  RSBA_STAGE_FIRST | RSBA_STAGE_LAST, s->chol_ok, StageGate{nullptr, 0, 0, nullptr, nullptr});
     T.End(st);
   } else {
     // more than 64 cameras: right-looking factorisation over the whole chip, one launch per 32-wide panel
@@ -488,6 +578,32 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(s->res_host, s->res, RES_SIZE * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if (pipe && T.enabled()) {
+    // the Cholesky's event span includes the time it slept on the ready flags: record that separately
+    long long w = 0;
+    HIPCHK(hipMemcpy(&w, s->chol_waited, sizeof(w), hipMemcpyDeviceToHost));
+    T.Add("k_reduced_system_solve:waiting", (w - s->chol_waited_seen) * 1e-5);
+    s->chol_waited_seen = w;
+  }
+  if (pipe && s->trace) {
+    long long h[32];
+    HIPCHK(hipMemcpy(h, s->trace, sizeof(h), hipMemcpyDeviceToHost));
+    const long long t0 = h[24];
+    fprintf(stderr, "rsba[trace] us since first tile block: chol start %.1f ready0 seen %.1f | gates (wait..pass)", (h[0] - t0) * 0.01, (h[1] - t0) * 0.01);
+    for (int g = 0; g < s->tiled.nstages; ++g) fprintf(stderr, " %.1f..%.1f", (h[2 + 2 * g] - t0) * 0.01, (h[3 + 2 * g] - t0) * 0.01);
+    fprintf(stderr, " end %.1f | published: self %.1f stages", (h[15] - t0) * 0.01, (h[16] - t0) * 0.01);
+    for (int g = 0; g < s->tiled.nstages; ++g) fprintf(stderr, " %.1f", (h[17 + g] - t0) * 0.01);
+    fprintf(stderr, " | first pair block %.1f\n", (h[25] - t0) * 0.01);
+  }
+  if (pipe && s->res_host[RES_STALL] != 0.0) {
+    // the waiting Cholesky never saw its columns (its producers were not running beside it): nothing of x has been
+    // touched, so repeat the step with the plain schedule and stay there
+    fprintf(stderr, "rsba: pipelined solve stalled; falling back to the sequential schedule\n");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(s->tiled.sync_cnt, 0, ((size_t)s->tiled.ngrp + s->tiled.ntiles + s->tiled.nstages + 1) * sizeof(int)));
+    s->pipelined = false;
+    return PointsStep(s, radius, first, keep_system_copy);
+  }
   return RSBA_OK;
 }
 

@@ -266,3 +266,38 @@ def test_more_than_64_cameras_and_huber(oracle, impl):
     b = capi.points_linearize_and_step(prob, 1e4, capi.default_options(schur_impl=impl, huber_delta=1.0))
     assert np.abs(b["S"] - a["S"]).max() < 1e-10 * np.abs(a["S"]).max()
     assert np.abs(b["delta"] - a["delta"]).max() < 1e-7 * np.abs(a["delta"]).max()
+
+
+# ------------------------------------------------------------------ pipelined solve (17..64 cameras on one GPU)
+@pytest.mark.parametrize("C,P,k,huber", [(17, 1200, 6, 0.0), (33, 2500, 8, 0.0), (40, 3000, 9, 0.0), (64, 4000, 12, 1.0)])
+def test_pipelined_solve_matches_oracle_and_sequential_schedule(oracle, C, P, k, huber):
+    """With 17..64 cameras the Cholesky of the reduced system is launched first and factors camera group g's
+    columns as soon as the Schur kernel has published them (ready flags), while the later groups are still being
+    eliminated.  Same kernels, same summation orders: the result must equal the oracle's within the usual tolerances
+    and the sequential schedule's (RSBA_PIPELINE=0) bit for bit.  C = 17 leaves a last group of one camera (a stage
+    without any pair tile), C = 64 is the benchmark's shape, with Huber loss and outliers."""
+    prob = syn.make_problem(C, P, k, seed=300 + C, outlier_frac=0.05 if huber else 0.0)
+    got, s, log = _compare_solve(oracle, prob, 1, huber=huber)
+    os.environ["RSBA_PIPELINE"] = "0"
+    try:
+        seq, s_seq, log_seq = capi.solve_points(prob, capi.default_options(schur_impl=1, huber_delta=huber))
+    finally:
+        del os.environ["RSBA_PIPELINE"]
+    assert np.array_equal(got, seq) and np.array_equal(log, log_seq) and s.final_cost == s_seq.final_cost
+    again, s2, log2 = capi.solve_points(prob, capi.default_options(schur_impl=1, huber_delta=huber))
+    assert np.array_equal(got, again) and np.array_equal(log, log2)
+
+
+def test_pipeline_stall_falls_back_to_sequential_schedule(oracle, capfd):
+    """RSBA_TEST_STALL=1 makes the waiting Cholesky look for a tag nobody publishes: it must give up after its 50 ms
+    budget (never hang the queue), the step must be repeated with the sequential schedule, and the result must not
+    change."""
+    prob = syn.make_problem(24, 1500, 7, seed=77)
+    ref, s_ref, log_ref = capi.solve_points(prob)
+    os.environ["RSBA_TEST_STALL"] = "1"
+    try:
+        got, s, log = capi.solve_points(prob)
+    finally:
+        del os.environ["RSBA_TEST_STALL"]
+    assert "falling back" in capfd.readouterr().err
+    assert np.array_equal(got, ref) and np.array_equal(log, log_ref) and s.num_iterations == s_ref.num_iterations
