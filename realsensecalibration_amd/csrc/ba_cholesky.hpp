@@ -62,6 +62,8 @@ struct PanelSource {
   const double* scale;
   const double* diagU;
   double lo, hi, inv_radius;
+  const double* gc;     // gated solve only: the rhs entries of a camera group, s_i (gc_i + corr_i), are written into
+  const double* corr;   // row n of A when the group's gate opens (they come from the same stage of the Schur kernel)
 };
 
 // Columns of the matrix may still be in production when the factorisation starts (pipelined solve): gate.ready[1 + g]
@@ -287,6 +289,11 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
       if (gate.trace && tid == 0) gate.trace[2 + 2 * (kb / gate.cols)] = wall_clock64();
       if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, gate.waited)) { if (tid == 0) *ok_out = -1; __syncthreads(); return; }
       if (gate.trace && tid == 0) gate.trace[3 + 2 * (kb / gate.cols)] = wall_clock64();
+      if (src.gc != nullptr) {
+        for (int i = kb + tid; i < min(kb + gate.cols, n); i += nt) A[(size_t)n * n + i] = src.scale[i] * (src.gc[i] + src.corr[i]);
+        __threadfence_block();
+        __syncthreads();
+      }
     }
     const int nb = min(RSBA_PB, n - kb);
     const int R = n + 1 - kb;  // panel rows, rhs row included (panel-relative row R-1)

@@ -480,11 +480,16 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
 #endif
   // the raw matrix is scaled, damped and mirrored by the panel loads themselves when it is already full symmetric
   const bool fused = sym_full && S_copy == nullptr;
-  // pipelined: launched ahead of the linearisation; ready[0] says the self tiles (diagonal blocks, damping diagonal,
-  // right-hand sides) and the scalars are in place
-  if (gate.ready != nullptr) {
+  // pipelined: launched ahead of the linearisation.  Camera group g's gate (ready[1 + g]) says its diagonal blocks,
+  // damping diagonal, right-hand side and pair blocks are in place.  The first iteration defines the Jacobi scale from
+  // the whole damping diagonal, so it waits for every group before it starts; later iterations start with group 0.
+  const bool gated = gate.ready != nullptr;
+  if (gated) {
     if (gate.trace && tid == 0) gate.trace[0] = wall_clock64();
-    if (!WaitReady(gate.ready, gate.tag, gate.waited)) { if (tid == 0) res[RES_STALL] = 1.0; return; }
+    if (ip.first) {
+      for (int g = 0; g * gate.cols < n; ++g)
+        if (!WaitReady(gate.ready + 1 + g, gate.tag, gate.waited)) { if (tid == 0) res[RES_STALL] = 1.0; return; }
+    }
     if (gate.trace && tid == 0) gate.trace[1] = wall_clock64();
   }
   if (stage_flags & RSBA_STAGE_FIRST) {
@@ -516,10 +521,13 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
         }
       }
     }
-    for (int i = tid; i < n; i += nt) {
-      const double v = scale_c[i] * (red[L.gc() + i] + red[L.corr() + i]);
-      A[(size_t)n * n + i] = v;
-      if (rhs_copy) rhs_copy[i] = v;
+    // right-hand side; the gated solve writes each group's entries when the group's gate opens
+    if (!gated) {
+      for (int i = tid; i < n; i += nt) {
+        const double v = scale_c[i] * (red[L.gc() + i] + red[L.corr() + i]);
+        A[(size_t)n * n + i] = v;
+        if (rhs_copy) rhs_copy[i] = v;
+      }
     }
     __threadfence_block();
     __syncthreads();
@@ -531,8 +539,9 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
   double* ysol = A + (size_t)n * n;
   const bool last = (stage_flags & RSBA_STAGE_LAST) != 0;
   CholeskySolvePanelLDS(n, A, ysol, &s_ok, lds,
-                        fused ? PanelSource{red + L.S(), scale_c, red + L.diagU(), ip.min_lm_diagonal, ip.max_lm_diagonal, 1.0 / ip.radius}
-                              : PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0},
+                        fused ? PanelSource{red + L.S(), scale_c, red + L.diagU(), ip.min_lm_diagonal, ip.max_lm_diagonal, 1.0 / ip.radius,
+                                            gated ? red + L.gc() : nullptr, gated ? red + L.corr() : nullptr}
+                              : PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr, nullptr},
                         kb_begin, kb_end, last, gate);
   __syncthreads();
   if (s_ok < 0) { if (tid == 0) res[RES_STALL] = 1.0; return; }

@@ -50,9 +50,11 @@ class KernelTimer;
 struct SchurSeg {
   int ga, gb, word_begin, word_end, self;
   // in-kernel reduction tree of the pair tiles: segment -> group of RSBA_GRP consecutive segments -> tile -> stage
-  int tile, grp, grp_seg0, grp_nseg, tile_grp0, tile_ngrp, stage, stage_ntiles, pad0, pad1, pad2;
+  int tile, grp, grp_seg0, grp_nseg, tile_grp0, tile_ngrp, stage, stage_ntiles, nred, pad1, pad2;
+  // self: 0 pair segment, 1 self segment, 2 / 3 reducer of a pair / self tile (word_begin..word_end = its components)
 };
 #define RSBA_GRP 8          // segments per reduction group
+#define RSBA_RED_COMPS 6     // components per reducer workgroup: 6 reducers per pair tile (36), 7 per self tile (42)
 
 struct TiledSchur {
   int C = 0, P = 0, ngroups = 0, nwords = 0, nchunks = 0, nseg = 0, nseg_pair = 0, grid_pp = 0;
@@ -64,8 +66,12 @@ struct TiledSchur {
   double* ptdata = nullptr;                 // [P][12]
   double* partial = nullptr;                // [nseg][42][256]
   double* grp_sum = nullptr;                // [ngrp][42][256] sums of RSBA_GRP consecutive segments
-  int* sync_cnt = nullptr;                  // [ngrp + ntiles + nstages] arrival counters, self-resetting
-  int* ready = nullptr;                     // [1 + nstages] ready[0]: self tiles + scalars, ready[1+g]: pair tiles of stage g; = step tag
+  double* tile_sum = nullptr;               // [ntiles][42][256]
+  int* tree_error = nullptr;
+  int* sync_cnt = nullptr;                  // arrival counters, self-resetting: [ngrp] group members, [ntiles] groups done, [16] stage tiles, [ntiles] reducers done
+  int nsync = 0, nblocks = 0;               // counters; blocks of the launch (segments + reducers)
+  int* ready = nullptr;                     // ready[1 + g] = step tag once stage g (self tile g + pair tiles (g, g' >= g)) is in S
+  int* block_seg = nullptr;                 // [nseg] launch order: block -> segment
   int ngrp = 0;
   double* block_scal = nullptr;
   // robust-loss support: sqrt(rho') per observation in camera-major order
@@ -244,8 +250,8 @@ __device__ __constant__ unsigned char kDiagPair[128] = {
 };
 
 // v[i] = sum over q < n of block q's entry i (this thread's slot), blocks RSBA_PART*256 doubles apart, in block order.
-// Agent-scope loads (see TileTreeReduce); two blocks are in flight at a time when the registers allow it (the sums
-// sit at the tail of a tile, where only memory-level parallelism shortens them).
+// Plain loads after the caller's acquire (see TileTreeReduce); two blocks are in flight at a time when the registers
+// allow it (the sums sit at the tail of a tile, where only memory-level parallelism shortens them).
 template <int NV>
 __device__ __forceinline__ void TreeSum(const double* __restrict__ in, int n, double* v) {
 #pragma unroll
@@ -257,9 +263,9 @@ __device__ __forceinline__ void TreeSum(const double* __restrict__ in, int n, do
       const double* p1 = p0 + (size_t)RSBA_PART * 256;
       double x0[NV], x1[NV];
 #pragma unroll
-      for (int i = 0; i < NV; ++i) x0[i] = __hip_atomic_load(&p0[i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < NV; ++i) x0[i] = p0[i * 256];
 #pragma unroll
-      for (int i = 0; i < NV; ++i) x1[i] = __hip_atomic_load(&p1[i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < NV; ++i) x1[i] = p1[i * 256];
 #pragma unroll
       for (int i = 0; i < NV; ++i) v[i] = (v[i] + x0[i]) + x1[i];
     }
@@ -267,44 +273,44 @@ __device__ __forceinline__ void TreeSum(const double* __restrict__ in, int n, do
   for (; q < n; ++q) {
     const double* p0 = in + (size_t)q * RSBA_PART * 256;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] += __hip_atomic_load(&p0[i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < NV; ++i) v[i] += p0[i * 256];
   }
 }
 
-// Reduction tree of a tile without further launches.  Every workgroup has written its partial block (agent-scope
-// stores); the last workgroup of a group of RSBA_GRP segments to arrive adds the group's blocks in segment order (the
-// sums do not depend on who arrives last) and the last group of a tile adds the group sums: that workgroup returns
-// true with the tile's sums in v[] (slot = thread).  Counters reset themselves.
+// Reduction of a tile without further launches, in two levels.
+//  1. Every compute workgroup writes its partial block; the last workgroup of a group of RSBA_GRP consecutive segments
+//     to arrive adds the group's blocks in segment order (the sums do not depend on who arrives last) into grp_sum and
+//     counts the group as done.
+//  2. One CU pulls ~30 GB/s out of memory, so a single workgroup adding a tile's 30-40 group sums (2-3 MB) was measured
+//     at 65-105 us, at the tail of every stage.  Instead each tile has RSBA_NRED reducer workgroups, placed in block order
+//     right behind the stage's compute blocks (so everything they wait for has been dispatched before them: they can
+//     spin without deadlock).  Each waits for the tile's groups, adds a slice of the components over all groups into
+//     tile_sum, and the last reducer to finish applies the K factors and writes the tile's blocks of S.
 // The eight XCDs' L2s are not coherent with each other inside a kernel, and an agent-scope fence costs a write-back /
-// invalidate of a whole L2 (measured: 2x on the pair kernel, 8x on a kernel running beside it, when every workgroup
-// fenced).  So the tree's data moves with agent-scope (sc1) stores and loads that go through to memory, ordered by
-// waiting for the stores' acknowledgements before a counter is bumped; only the tile finishers, whose results are
-// written with ordinary stores, pay for a real fence.
+// invalidate of a whole L2 (measured: 2x on this kernel when every workgroup fenced).  So partial sums are written with
+// agent-scope (sc1) stores that go through to memory, ordered by waiting for the stores' acknowledgements before a
+// counter is bumped; only the workgroups that read other workgroups' sums invalidate their L2 first, and only the tile
+// finishers, whose results are written with ordinary stores, write theirs back.
 template <int NV>
-__device__ __forceinline__ bool TileTreeReduce(const SchurSeg& sg, const double* __restrict__ partial, double* __restrict__ grp_sum,
-                                               int* __restrict__ sync_cnt, int ngrp, double* v) {
+__device__ __forceinline__ void GroupReduce(const SchurSeg& sg, const double* __restrict__ partial, double* __restrict__ grp_sum,
+                                            int* __restrict__ sync_cnt, int ngrp) {
   __shared__ int s_last;
   const int tid = threadIdx.x;
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0) s_last = __hip_atomic_fetch_add(&sync_cnt[sg.grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.grp_nseg - 1;
   __syncthreads();
-  if (!s_last) return false;
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  double v[NV];
   TreeSum<NV>(partial + (size_t)sg.grp_seg0 * RSBA_PART * 256 + tid, sg.grp_nseg, v);
-  {
-    double* gs = grp_sum + (size_t)sg.grp * RSBA_PART * 256 + tid;
+  double* gs = grp_sum + (size_t)sg.grp * RSBA_PART * 256 + tid;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) __hip_atomic_store(&gs[i * 256], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  for (int i = 0; i < NV; ++i) __hip_atomic_store(&gs[i * 256], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid == 0) __hip_atomic_store(&sync_cnt[sg.grp], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  if (tid == 0) s_last = __hip_atomic_fetch_add(&sync_cnt[ngrp + sg.tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.tile_ngrp - 1;
-  __syncthreads();
-  if (!s_last) return false;
-  TreeSum<NV>(grp_sum + (size_t)sg.tile_grp0 * RSBA_PART * 256 + tid, sg.tile_ngrp, v);
-  if (tid == 0) __hip_atomic_store(&sync_cnt[ngrp + sg.tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return true;
+  if (tid == 0) __hip_atomic_fetch_add(&sync_cnt[ngrp + sg.tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The tile's results are written: one arrival at the stage counter; true (whole workgroup) for the last tile of the stage.
@@ -430,16 +436,19 @@ struct SchurArgs {
   double* __restrict__ partial;
   double* __restrict__ grp_sum;
   int* __restrict__ sync_cnt;
-  int ngrp, ntiles, nself_seg, npair_seg;
+  int ngrp, ntiles, last_group;
+  const int* __restrict__ block_seg;
   int* __restrict__ ready;
-  unsigned publish;   // ready[] bits the last self tile publishes: bit 0 + the stages without any pair tile
   int tag;            // 0: nobody is waiting (sequential schedule)
   double* __restrict__ red;
   RedLayout L;
   int nblocks_pp;
   const double* __restrict__ block_scal;
   double* __restrict__ gmax_p;
+  double* __restrict__ tile_sum;   // [ntiles][42][256]
+  int* tree_error;                 // set when a reducer gave up waiting (cannot happen; never hang)
   long long* trace;   // diagnostic (RSBA_TRACE=1)
+  long long* wg_trace;  // diagnostic (RSBA_TRACE=2): start / end / compute-end stamp of every block
 };
 
 template <bool kLoss>
@@ -541,14 +550,8 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
 #pragma unroll
     for (int i = 0; i < 36; ++i) __hip_atomic_store(&out[i * 256 + pr], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // the tile's last workgroup applies the K factors and writes the S blocks; the stage's last tile publishes the stage
-  // for the Cholesky that may be waiting for these columns
-  double v[36];
-  if (!TileTreeReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
-  FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L);
-  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles)) return;
-  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.trace && tid == 0) a.trace[17 + sg.stage] = wall_clock64();
+  if (a.wg_trace && tid == 0) a.wg_trace[3 * blockIdx.x + 2] = wall_clock64();
+  GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp);
 }
 
 // Self tiles: everything that is a sum over ONE camera's observations — the diagonal block U_a - W V^-1 W' (a, a),
@@ -648,23 +651,85 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   double* out = partial + (size_t)seg_index * RSBA_PART * 256;
 #pragma unroll
   for (int i = 0; i < RSBA_PART; ++i) __hip_atomic_store(&out[i * 256 + tid], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // same tree as the pair tiles; the last self tile also folds the point pass' per-block scalars (cost, |X|^2,
-  // failures, max|g_p|) and publishes ready[0] (+ the stages that have no pair tile at all)
-  double v[RSBA_PART];
-  if (!TileTreeReduce<RSBA_PART>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
-  FinishSelfSlot(C, sg.ga, v, camc, a.red, a.L);
-  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles)) return;
-  FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
-  __threadfence();
-  __syncthreads();
-  if (tid == 0 && a.tag) {
-    for (int i = 0; i < 16; ++i) if (a.publish >> i & 1u) __hip_atomic_store(&a.ready[i], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (a.trace && tid == 0) a.trace[16] = wall_clock64();
+  if (a.wg_trace && tid == 0) a.wg_trace[3 * blockIdx.x + 2] = wall_clock64();
+  GroupReduce<RSBA_PART>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp);
 }
 
-// K_A2: the Schur elimination kernel.  One workgroup per segment (a range of 64-point words of one tile); the self
-// segments come first in block order (the Cholesky's first gate), then the pair tiles stage by stage.  Two workgroups
+// Reducer workgroup `part` of tile sg.tile (see GroupReduce): components [word_begin, word_end) of the tile sums; the
+// last reducer finishes the tile, the last tile of a stage publishes it for the Cholesky that may be waiting for these
+// columns.  The self tile of the last group also folds the point pass' per-block scalars (cost, |X|^2, failures, max|g_p|).
+__device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSeg& sg) {
+  __shared__ int s_flag;
+  const int tid = threadIdx.x;
+  int* cnt_groups = a.sync_cnt + a.ngrp + sg.tile;
+  int* cnt_red = a.sync_cnt + a.ngrp + a.ntiles + 16 + sg.tile;
+  if (tid == 0) {
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(cnt_groups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sg.tile_ngrp) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > RSBA_STALL_TICKS) { ok = 0; break; }   // cannot happen (see GroupReduce); never hang
+    }
+    s_flag = ok;
+  }
+  __syncthreads();
+  if (!s_flag) { if (tid == 0) __hip_atomic_store(a.tree_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const int c0 = sg.word_begin, c1 = sg.word_end;
+  double* ts = a.tile_sum + (size_t)sg.tile * RSBA_PART * 256 + tid;
+  {
+    // up to RSBA_RED_COMPS components of this slot over all groups, in group order, four groups in flight
+    double v[RSBA_RED_COMPS];
+#pragma unroll
+    for (int i = 0; i < RSBA_RED_COMPS; ++i) v[i] = 0.0;
+    const double* in = a.grp_sum + (size_t)sg.tile_grp0 * RSBA_PART * 256 + (size_t)c0 * 256 + tid;
+    int q = 0;
+    for (; q + 3 < sg.tile_ngrp; q += 4) {
+      double x[4][RSBA_RED_COMPS];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < RSBA_RED_COMPS; ++i) x[u][i] = (c0 + i < c1) ? in[(size_t)(q + u) * RSBA_PART * 256 + i * 256] : 0.0;
+#pragma unroll
+      for (int i = 0; i < RSBA_RED_COMPS; ++i) v[i] = (((v[i] + x[0][i]) + x[1][i]) + x[2][i]) + x[3][i];
+    }
+    for (; q < sg.tile_ngrp; ++q)
+#pragma unroll
+      for (int i = 0; i < RSBA_RED_COMPS; ++i) if (c0 + i < c1) v[i] += in[(size_t)q * RSBA_PART * 256 + i * 256];
+#pragma unroll
+    for (int i = 0; i < RSBA_RED_COMPS; ++i) if (c0 + i < c1) __hip_atomic_store(&ts[(c0 + i) * 256], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0) s_flag = __hip_atomic_fetch_add(cnt_red, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.nred - 1;
+  __syncthreads();
+  if (!s_flag) return;
+  // last reducer of the tile: every other reducer is past its wait, so both counters can go back to zero
+  if (tid == 0) {
+    __hip_atomic_store(cnt_groups, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cnt_red, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (sg.self == 3) {
+    double v[RSBA_PART];
+#pragma unroll
+    for (int i = 0; i < RSBA_PART; ++i) v[i] = ts[i * 256];
+    FinishSelfSlot(a.C, sg.ga, v, a.camc, a.red, a.L);
+    if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
+  } else {
+    double v[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) v[i] = ts[i * 256];
+    FinishPairSlot(a.C, sg.ga, sg.gb, tid, v, a.camc, a.red, a.L);
+  }
+  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles)) return;
+  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.trace && tid == 0) a.trace[17 + sg.stage] = wall_clock64();
+}
+
+// K_A2: the Schur elimination kernel.  One workgroup per segment (a range of 64-point words of one tile), in block order
+// stage by stage: the self tile of camera group g, then the pair tiles (g, g' >= g) — what the Cholesky needs for group
+// g's columns.  Two workgroups
 // per CU: the accumulators are the only long-lived per-lane state; point data, visibility rows and camera constants sit
 // in LDS.
 template <bool kLoss>
@@ -673,13 +738,14 @@ k_schur_tiles(SchurArgs a) {
   __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];            // 48 KB
   __shared__ unsigned long long mk[2 * RSBA_TG][RSBA_CW];       // 2 KB
   __shared__ double sc[2 * RSBA_TG * RSBA_SC_STRIDE];           // 4 KB
-  // segs[] holds the pair segments first ([0, npair_seg)), the self segments after them
-  const int seg_index = (int)blockIdx.x < a.nself_seg ? a.npair_seg + (int)blockIdx.x : (int)blockIdx.x - a.nself_seg;
+  const int seg_index = a.block_seg[blockIdx.x];
   const SchurSeg sg = a.segs[seg_index];
   if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
-  if (a.trace && (int)blockIdx.x == a.nself_seg && threadIdx.x == 0) a.trace[25] = wall_clock64();
-  if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, pt, mk);
+  if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * blockIdx.x] = wall_clock64();
+  if (sg.self >= 2) ReducerSegment(a, sg);
+  else if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, pt, mk);
   else PairSegment<kLoss>(a, sg, seg_index, pt, mk, sc);
+  if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * blockIdx.x + 1] = wall_clock64();
 }
 
 

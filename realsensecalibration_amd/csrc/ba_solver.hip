@@ -118,6 +118,7 @@ struct rsba_solver {
   long long* chol_waited = nullptr;   // device: ticks the pipelined Cholesky spent waiting for its columns (cumulative)
   long long chol_waited_seen = 0;
   long long* trace = nullptr;   // RSBA_TRACE=1: 32 wall-clock stamps of the pipelined step
+  long long* wg_trace = nullptr;  // RSBA_TRACE=2: per-block stamps of the Schur kernel, dumped to RSBA_TRACE_FILE
   ncclComm_t comm = nullptr;
   KernelTimer timer;
   std::vector<rsba_iteration> iters;
@@ -191,9 +192,9 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
   const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : 4;
   const int target = seg_per_cu * cus;
-  // the pair tiles share `target` workgroups, same number for every tile (the pipelined solve launches them stage
-  // by stage, ga == g: the later, smaller stages need not fill the chip, they only have to finish before the
-  // Cholesky of the previous stage does); the self tiles (their own, much lighter launch) get 2 per CU in total
+  // the pair tiles share `target` workgroups, same number for every tile; the self tiles (much lighter) get 2 per CU in
+  // total.  (Sizing each stage's workgroups to whole rounds of slots was tried for the pipelined schedule: no gain, and
+  // the two schedules would no longer add in the same order.)
   int npair_tiles = 0;
   std::vector<int> tiles_of_stage(ngroups, 0);
   for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) { ++npair_tiles; ++tiles_of_stage[tab[3 * t]]; }
@@ -216,26 +217,52 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     if (!self) for (int g = tab[3 * t]; g < nstages; ++g) { stage_tile[g + 1] = t + 1; stage_seg[g + 1] = tsp[t + 1]; }
     {
       // reduction tree of this tile: groups of RSBA_GRP consecutive segments; the self tiles form one more "stage"
-      const int s0 = tsp[t], ns_t = tsp[t + 1] - tsp[t], g0 = ngrp, ng = (ns_t + RSBA_GRP - 1) / RSBA_GRP;
+      const int GRP = std::max(1, getenv("RSBA_GRP") ? atoi(getenv("RSBA_GRP")) : RSBA_GRP);
+      const int s0 = tsp[t], ns_t = tsp[t + 1] - tsp[t], g0 = ngrp, ng = (ns_t + GRP - 1) / GRP;
       for (int i = 0; i < ns_t; ++i) {
         SchurSeg& e = sg[s0 + i];
-        e.tile = t; e.grp = g0 + i / RSBA_GRP; e.grp_seg0 = s0 + (i / RSBA_GRP) * RSBA_GRP;
-        e.grp_nseg = std::min(RSBA_GRP, ns_t - (i / RSBA_GRP) * RSBA_GRP);
+        e.tile = t; e.grp = g0 + i / GRP; e.grp_seg0 = s0 + (i / GRP) * GRP;
+        e.grp_nseg = std::min(GRP, ns_t - (i / GRP) * GRP);
         e.tile_grp0 = g0; e.tile_ngrp = ng;
-        e.stage = self ? nstages : tab[3 * t]; e.stage_ntiles = self ? ngroups : tiles_of_stage[tab[3 * t]];
+        e.stage = tab[3 * t]; e.stage_ntiles = tiles_of_stage[tab[3 * t]] + 1;   // the stage's pair tiles + its self tile
       }
       ngrp += ng;
     }
   }
   nseg = (int)sg.size();
+  // reducer workgroups (see GroupReduce in ba_schur_tiled.hpp): entries behind the compute segments
+  std::vector<std::vector<int>> red_of_tile(ntiles);
+  for (int t = 0; t < ntiles; ++t) {
+    const bool self = tab[3 * t + 2] != 0;
+    const int nv = self ? RSBA_PART : 36, nred = (nv + RSBA_RED_COMPS - 1) / RSBA_RED_COMPS;
+    const SchurSeg first = sg[tsp[t]];
+    for (int r = 0; r < nred; ++r) {
+      SchurSeg e = first;
+      e.self = self ? 3 : 2; e.word_begin = r * RSBA_RED_COMPS; e.word_end = std::min(nv, (r + 1) * RSBA_RED_COMPS); e.nred = nred;
+      red_of_tile[t].push_back((int)sg.size());
+      sg.push_back(e);
+    }
+  }
+  nblocks = (int)sg.size();
+  nsync = ngrp + 2 * ntiles + 16;
+  // block order of the launch: stage by stage, the stage's self tile first, then its pair tiles, then their reducers
+  std::vector<int> border; border.reserve(nblocks);
+  for (int g = 0; g < nstages; ++g) {
+    std::vector<int> tiles_g;
+    for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2] && tab[3 * t] == g) tiles_g.push_back(t);
+    for (int t = stage_tile[g]; t < stage_tile[g + 1]; ++t) tiles_g.push_back(t);
+    for (int t : tiles_g) for (int q = tsp[t]; q < tsp[t + 1]; ++q) border.push_back(q);
+    for (int t : tiles_g) for (int q : red_of_tile[t]) border.push_back(q);
+  }
   nseg_pair = 0;
-  for (const SchurSeg& e : sg) if (!e.self) ++nseg_pair;  // pair tiles come first, self tiles last
+  for (int q = 0; q < nseg; ++q) if (!sg[q].self) ++nseg_pair;  // pair tiles come first, self tiles after them, reducers last
   grid_pp = std::max(1, std::min((P + 255) / 256, 2048));
   int rc;
-  if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nseg)) || (rc = DevAlloc(&tile_seg_ptr, (size_t)ntiles + 1)) ||
+  if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nblocks)) || (rc = DevAlloc(&tile_seg_ptr, (size_t)ntiles + 1)) ||
       (rc = DevAlloc(&tile_ab, (size_t)3 * ntiles)) || (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
-      (rc = DevAlloc(&sync_cnt, (size_t)ngrp + ntiles + nstages + 1)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
+      (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) ||
+      (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 1)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm, cmpos.size())) || (rc = DevAlloc(&u_cm, cmpos.size())) || (rc = DevAlloc(&v_cm, cmpos.size())))
     return rc;
@@ -245,8 +272,10 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     HIPCHK(hipMemcpy(u_cm, ucm.data(), ucm.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(v_cm, vcm.data(), vcm.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  HIPCHK(hipMemset(sync_cnt, 0, ((size_t)ngrp + ntiles + nstages + 1) * sizeof(int)));
+  HIPCHK(hipMemset(sync_cnt, 0, (size_t)nsync * sizeof(int)));
+  HIPCHK(hipMemset(tree_error, 0, sizeof(int)));
   HIPCHK(hipMemset(ready, 0, 16 * sizeof(int)));
+  HIPCHK(hipMemcpy(block_seg, border.data(), border.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_mask, mask.data(), mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(segs, sg.data(), sg.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(tile_seg_ptr, tsp.data(), tsp.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -262,7 +291,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, tile_seg_ptr, tile_ab, ptdata, partial, grp_sum, sync_cnt, ready, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
+  void* ptrs[] = {cam_mask, segs, tile_seg_ptr, tile_ab, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, ready, block_seg, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   cam_mask = nullptr;
 }
@@ -279,6 +308,7 @@ static void FreeSolver(rsba_solver* s) {
   s->marker.Free();
   if (s->res_host) (void)hipHostFree(s->res_host);
   if (s->trace) (void)hipFree(s->trace);
+  if (s->wg_trace) (void)hipFree(s->wg_trace);
   if (s->chol_waited) (void)hipFree(s->chol_waited);
   if (s->sB) (void)hipStreamDestroy(s->sB);
   if (s->ev_chol) (void)hipEventDestroy(s->ev_chol);
@@ -326,6 +356,7 @@ static bool SetupPipeline(rsba_solver* s) {
             hipEventCreateWithFlags(&s->ev_chol, hipEventDisableTiming) == hipSuccess &&
             hipMalloc((void**)&s->chol_waited, sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, sizeof(long long)) == hipSuccess;
   if (ok && getenv("RSBA_TRACE")) ok = hipMalloc((void**)&s->trace, 32 * sizeof(long long)) == hipSuccess && hipMemset(s->trace, 0, 32 * sizeof(long long)) == hipSuccess;
+  if (ok && getenv("RSBA_TRACE") && atoi(getenv("RSBA_TRACE")) == 2) ok = hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) == hipSuccess;
   if (!ok) { (void)hipGetLastError(); if (getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: CU-masked stream unavailable, solve not pipelined\n"); }
   return ok;
 }
@@ -438,14 +469,12 @@ void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& 
   SchurArgs a;
   a.C = C; a.P = P; a.nwords = nwords; a.camc = s->camc[x]; a.segs = segs; a.cam_mask = cam_mask; a.ptdata = ptdata;
   a.cam_prefix = cam_prefix; a.cam_ptr = cam_ptr; a.sq_cm = sq_cm; a.u_cm = u_cm; a.v_cm = v_cm; a.partial = partial;
-  a.grp_sum = grp_sum; a.sync_cnt = sync_cnt; a.ngrp = ngrp; a.ntiles = ntiles; a.nself_seg = nseg - nseg_pair; a.npair_seg = nseg_pair;
+  a.grp_sum = grp_sum; a.sync_cnt = sync_cnt; a.ngrp = ngrp; a.ntiles = ntiles; a.block_seg = block_seg; a.last_group = ngroups - 1; a.tile_sum = tile_sum; a.tree_error = tree_error;
   a.ready = ready; a.tag = tag; a.red = s->red; a.L = s->L; a.nblocks_pp = grid_pp; a.block_scal = block_scal; a.gmax_p = s->gmax;
-  a.trace = s->trace;
-  a.publish = 1u;  // ready[0]; plus the stages that have no pair tile at all (a last group of one camera)
-  for (int g = 0; g < nstages; ++g) if (stage_tile[g + 1] == stage_tile[g]) a.publish |= 1u << (1 + g);
+  a.trace = s->trace; a.wg_trace = s->wg_trace;
   T.Begin("k_schur_tiles", st);
-  if (ip.huber_delta > 0.0) k_schur_tiles<true><<<nseg, 256, 0, st>>>(a);
-  else k_schur_tiles<false><<<nseg, 256, 0, st>>>(a);
+  if (ip.huber_delta > 0.0) k_schur_tiles<true><<<nblocks, 256, 0, st>>>(a);
+  else k_schur_tiles<false><<<nblocks, 256, 0, st>>>(a);
   T.End(st);
 }
 
@@ -593,14 +622,31 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     for (int g = 0; g < s->tiled.nstages; ++g) fprintf(stderr, " %.1f..%.1f", (h[2 + 2 * g] - t0) * 0.01, (h[3 + 2 * g] - t0) * 0.01);
     fprintf(stderr, " end %.1f | published: self %.1f stages", (h[15] - t0) * 0.01, (h[16] - t0) * 0.01);
     for (int g = 0; g < s->tiled.nstages; ++g) fprintf(stderr, " %.1f", (h[17 + g] - t0) * 0.01);
-    fprintf(stderr, " | first pair block %.1f\n", (h[25] - t0) * 0.01);
+    fprintf(stderr, "\n");
+    if (s->wg_trace && s->step_tag == 5) {
+      // one step's block timeline: block, segment, tile, self, stage, words, start, compute end, end (us)
+      const int nb = s->tiled.nblocks;
+      std::vector<long long> w((size_t)3 * nb);
+      std::vector<SchurSeg> hs(nb); std::vector<int> bs(nb);
+      HIPCHK(hipMemcpy(w.data(), s->wg_trace, w.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(hs.data(), s->tiled.segs, nb * sizeof(SchurSeg), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(bs.data(), s->tiled.block_seg, nb * sizeof(int), hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(getenv("RSBA_TRACE_FILE") ? getenv("RSBA_TRACE_FILE") : "wgtrace.txt", "w")) {
+        for (int b = 0; b < nb; ++b) {
+          const SchurSeg& e = hs[bs[b]];
+          fprintf(f, "%d %d %d %d %d %d %.2f %.2f %.2f\n", b, bs[b], e.tile, e.self, e.stage, e.word_end - e.word_begin, (w[3 * b] - t0) * 0.01,
+                  (w[3 * b + 2] - t0) * 0.01, (w[3 * b + 1] - t0) * 0.01);
+        }
+        fclose(f);
+      }
+    }
   }
   if (pipe && s->res_host[RES_STALL] != 0.0) {
     // the waiting Cholesky never saw its columns (its producers were not running beside it): nothing of x has been
     // touched, so repeat the step with the plain schedule and stay there
     fprintf(stderr, "rsba: pipelined solve stalled; falling back to the sequential schedule\n");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemset(s->tiled.sync_cnt, 0, ((size_t)s->tiled.ngrp + s->tiled.ntiles + s->tiled.nstages + 1) * sizeof(int)));
+    HIPCHK(hipMemset(s->tiled.sync_cnt, 0, (size_t)s->tiled.nsync * sizeof(int)));
     s->pipelined = false;
     return PointsStep(s, radius, first, keep_system_copy);
   }
@@ -762,6 +808,15 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
     rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { return rsba::PointsStep(s, radius, first, false); },
                             [&]() { s->cur = 1 - s->cur; });
     sum.minimizer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc == RSBA_OK && s->tiled.tree_error) {
+      // a reducer workgroup of the Schur kernel gave up waiting for its tile (cannot happen by construction): the sums
+      // it produced are garbage, so is the result
+      int bad = 0;
+      if (hipMemcpy(&bad, s->tiled.tree_error, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || bad) {
+        fprintf(stderr, "rsba: in-kernel reduction timed out\n");
+        rc = RSBA_ERR_HIP;
+      }
+    }
   } else {
     if ((rc = s->marker.Reset(s->stream)) != RSBA_OK) return rc;
     if (hipStreamSynchronize(s->stream) != hipSuccess) return RSBA_ERR_HIP;
