@@ -55,6 +55,7 @@ struct SchurSeg {
 };
 #define RSBA_GRP 8          // segments per reduction group
 #define RSBA_RED_COMPS 6     // components per reducer workgroup: 6 reducers per pair tile (36), 7 per self tile (42)
+#define RSBA_DIRECT_GROUPS 4  // tiles with at most this many groups are finished by their last group, without reducers
 
 struct TiledSchur {
   int C = 0, P = 0, ngroups = 0, nwords = 0, nchunks = 0, nseg = 0, nseg_pair = 0, grid_pp = 0;
@@ -292,17 +293,16 @@ __device__ __forceinline__ void TreeSum(const double* __restrict__ in, int n, do
 // counter is bumped; only the workgroups that read other workgroups' sums invalidate their L2 first, and only the tile
 // finishers, whose results are written with ordinary stores, write theirs back.
 template <int NV>
-__device__ __forceinline__ void GroupReduce(const SchurSeg& sg, const double* __restrict__ partial, double* __restrict__ grp_sum,
-                                            int* __restrict__ sync_cnt, int ngrp) {
+__device__ __forceinline__ bool GroupReduce(const SchurSeg& sg, const double* __restrict__ partial, double* __restrict__ grp_sum,
+                                            int* __restrict__ sync_cnt, int ngrp, double* v) {
   __shared__ int s_last;
   const int tid = threadIdx.x;
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0) s_last = __hip_atomic_fetch_add(&sync_cnt[sg.grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.grp_nseg - 1;
   __syncthreads();
-  if (!s_last) return;
+  if (!s_last) return false;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  double v[NV];
   TreeSum<NV>(partial + (size_t)sg.grp_seg0 * RSBA_PART * 256 + tid, sg.grp_nseg, v);
   double* gs = grp_sum + (size_t)sg.grp * RSBA_PART * 256 + tid;
 #pragma unroll
@@ -310,13 +310,23 @@ __device__ __forceinline__ void GroupReduce(const SchurSeg& sg, const double* __
   if (tid == 0) __hip_atomic_store(&sync_cnt[sg.grp], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(&sync_cnt[ngrp + sg.tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) s_last = __hip_atomic_fetch_add(&sync_cnt[ngrp + sg.tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.tile_ngrp - 1;
+  __syncthreads();
+  // tiles of a few groups only (many cameras: 136 pair tiles at 256 cameras) have no reducers: the workgroup that
+  // completes the last group adds the group sums itself
+  if (sg.nred != 0 || !s_last) return false;
+  if (tid == 0) __hip_atomic_store(&sync_cnt[ngrp + sg.tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  TreeSum<NV>(grp_sum + (size_t)sg.tile_grp0 * RSBA_PART * 256 + tid, sg.tile_ngrp, v);
+  return true;
 }
 
 // The tile's results are written: one arrival at the stage counter; true (whole workgroup) for the last tile of the stage.
-__device__ __forceinline__ bool StageArrive(const SchurSeg& sg, int* __restrict__ sync_cnt, int ngrp, int ntiles) {
+__device__ __forceinline__ bool StageArrive(const SchurSeg& sg, int* __restrict__ sync_cnt, int ngrp, int ntiles, bool publish) {
   __shared__ int s_last;
-  __threadfence();
+  // the tile's blocks of S must be visible to the waiting Cholesky (another XCD) before the stage is published; with
+  // the sequential schedule the kernel boundary does that, and 152 L2 write-backs (256 cameras) are not free
+  if (publish) __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
     s_last = __hip_atomic_fetch_add(&sync_cnt[ngrp + ntiles + sg.stage], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.stage_ntiles - 1;
@@ -551,7 +561,12 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
     for (int i = 0; i < 36; ++i) __hip_atomic_store(&out[i * 256 + pr], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (a.wg_trace && tid == 0) a.wg_trace[3 * blockIdx.x + 2] = wall_clock64();
-  GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp);
+  double v[36];
+  if (!GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
+  FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L);
+  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
+  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.trace && tid == 0) a.trace[17 + sg.stage] = wall_clock64();
 }
 
 // Self tiles: everything that is a sum over ONE camera's observations — the diagonal block U_a - W V^-1 W' (a, a),
@@ -652,7 +667,13 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
 #pragma unroll
   for (int i = 0; i < RSBA_PART; ++i) __hip_atomic_store(&out[i * 256 + tid], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.wg_trace && tid == 0) a.wg_trace[3 * blockIdx.x + 2] = wall_clock64();
-  GroupReduce<RSBA_PART>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp);
+  double v[RSBA_PART];
+  if (!GroupReduce<RSBA_PART>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
+  FinishSelfSlot(C, sg.ga, v, camc, a.red, a.L);
+  if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
+  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
+  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.trace && tid == 0) a.trace[17 + sg.stage] = wall_clock64();
 }
 
 // Reducer workgroup `part` of tile sg.tile (see GroupReduce): components [word_begin, word_end) of the tile sums; the
@@ -722,7 +743,7 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
     for (int i = 0; i < 36; ++i) v[i] = ts[i * 256];
     FinishPairSlot(a.C, sg.ga, sg.gb, tid, v, a.camc, a.red, a.L);
   }
-  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles)) return;
+  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (a.trace && tid == 0) a.trace[17 + sg.stage] = wall_clock64();
 }

@@ -159,7 +159,6 @@ namespace rsba {
 // ------------------------------------------------------------------------------------------------
 int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
                       const std::vector<int>& sliced_q, bool staged) {
-  (void)staged;
   C = C_; P = P_;
   ngroups = (C + RSBA_TG - 1) / RSBA_TG;
   nwords = ((P + 63) / 64 + RSBA_CW - 1) / RSBA_CW * RSBA_CW;
@@ -234,8 +233,9 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   std::vector<std::vector<int>> red_of_tile(ntiles);
   for (int t = 0; t < ntiles; ++t) {
     const bool self = tab[3 * t + 2] != 0;
-    const int nv = self ? RSBA_PART : 36, nred = (nv + RSBA_RED_COMPS - 1) / RSBA_RED_COMPS;
     const SchurSeg first = sg[tsp[t]];
+    const int nv = self ? RSBA_PART : 36, nred = first.tile_ngrp <= RSBA_DIRECT_GROUPS ? 0 : (nv + RSBA_RED_COMPS - 1) / RSBA_RED_COMPS;
+    for (int q = tsp[t]; q < tsp[t + 1]; ++q) sg[q].nred = nred;
     for (int r = 0; r < nred; ++r) {
       SchurSeg e = first;
       e.self = self ? 3 : 2; e.word_begin = r * RSBA_RED_COMPS; e.word_end = std::min(nv, (r + 1) * RSBA_RED_COMPS); e.nred = nred;
@@ -245,14 +245,22 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   }
   nblocks = (int)sg.size();
   nsync = ngrp + 2 * ntiles + 16;
-  // block order of the launch: stage by stage, the stage's self tile first, then its pair tiles, then their reducers
+  // Block order of the launch.  Pipelined: stage by stage — the stage's self tile, its pair tiles, then their reducers —
+  // so that camera group g's columns are complete as early as possible.  Sequential schedule: every pair tile first and
+  // the (much shorter) self workgroups last, where they fill the tail of the last round of pair workgroups (at 256
+  // cameras a pair workgroup runs 220 us and the launch is ~3 rounds deep), reducers behind everything.
   std::vector<int> border; border.reserve(nblocks);
-  for (int g = 0; g < nstages; ++g) {
-    std::vector<int> tiles_g;
-    for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2] && tab[3 * t] == g) tiles_g.push_back(t);
-    for (int t = stage_tile[g]; t < stage_tile[g + 1]; ++t) tiles_g.push_back(t);
-    for (int t : tiles_g) for (int q = tsp[t]; q < tsp[t + 1]; ++q) border.push_back(q);
-    for (int t : tiles_g) for (int q : red_of_tile[t]) border.push_back(q);
+  if (staged) {
+    for (int g = 0; g < nstages; ++g) {
+      std::vector<int> tiles_g;
+      for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2] && tab[3 * t] == g) tiles_g.push_back(t);
+      for (int t = stage_tile[g]; t < stage_tile[g + 1]; ++t) tiles_g.push_back(t);
+      for (int t : tiles_g) for (int q = tsp[t]; q < tsp[t + 1]; ++q) border.push_back(q);
+      for (int t : tiles_g) for (int q : red_of_tile[t]) border.push_back(q);
+    }
+  } else {
+    for (int q = 0; q < nseg; ++q) border.push_back(q);   // segments are stored pair tiles first, self tiles after them
+    for (int t = 0; t < ntiles; ++t) for (int q : red_of_tile[t]) border.push_back(q);
   }
   nseg_pair = 0;
   for (int q = 0; q < nseg; ++q) if (!sg[q].self) ++nseg_pair;  // pair tiles come first, self tiles after them, reducers last
@@ -355,8 +363,6 @@ static bool SetupPipeline(rsba_solver* s) {
   bool ok = hipExtStreamCreateWithCUMask(&s->sB, words, mask.data()) == hipSuccess &&
             hipEventCreateWithFlags(&s->ev_chol, hipEventDisableTiming) == hipSuccess &&
             hipMalloc((void**)&s->chol_waited, sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, sizeof(long long)) == hipSuccess;
-  if (ok && getenv("RSBA_TRACE")) ok = hipMalloc((void**)&s->trace, 32 * sizeof(long long)) == hipSuccess && hipMemset(s->trace, 0, 32 * sizeof(long long)) == hipSuccess;
-  if (ok && getenv("RSBA_TRACE") && atoi(getenv("RSBA_TRACE")) == 2) ok = hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) == hipSuccess;
   if (!ok) { (void)hipGetLastError(); if (getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: CU-masked stream unavailable, solve not pipelined\n"); }
   return ok;
 }
@@ -430,6 +436,11 @@ static int UploadPoints(rsba_solver* s) {
     if (dup) s->opt.schur_impl = 0;
   }
   if (s->opt.schur_impl != 0) {
+    if (getenv("RSBA_TRACE")) {
+      // diagnostics: wall-clock stamps of the step (1) and of every block of the Schur kernel (2)
+      if (hipMalloc((void**)&s->trace, 32 * sizeof(long long)) != hipSuccess || hipMemset(s->trace, 0, 32 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
+      if (atoi(getenv("RSBA_TRACE")) == 2 && hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
+    }
     s->pipelined = SetupPipeline(s);
     rc = s->tiled.Build(C, P, ptr, cam, u, v, sl_q, s->pipelined);
     if (rc != RSBA_OK) return rc;
@@ -503,6 +514,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   }
   DebugSync(st, "k_camera_constants");
   const bool pipe = s->pipelined && s->opt.schur_impl != 0 && !keep_system_copy;
+  ++s->step_tag;
   // impl 0 accumulates into `red` with atomics; the tiled path writes every entry of it exactly once
   if (s->opt.schur_impl == 0) HIPCHK(hipMemsetAsync(s->red, 0, s->L.size() * sizeof(double), st));
   DebugSync(st, "memset red");
@@ -530,7 +542,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // first (it takes the reserved CU while the chip is idle and sleeps on the ready flags), then the point pass, then
     // the pair kernel (stage by stage in block order) with the self tiles beside it.
     TiledSchur& ts = s->tiled;
-    const int n = s->nc, tag = ++s->step_tag;
+    const int n = s->nc, tag = s->step_tag;
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(n)) * sizeof(double);
     if (lds_c > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
     T.Begin("k_reduced_system_solve", s->sB);
@@ -614,7 +626,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     T.Add("k_reduced_system_solve:waiting", (w - s->chol_waited_seen) * 1e-5);
     s->chol_waited_seen = w;
   }
-  if (pipe && s->trace) {
+  if (s->trace && s->opt.schur_impl != 0) {
     long long h[32];
     HIPCHK(hipMemcpy(h, s->trace, sizeof(h), hipMemcpyDeviceToHost));
     const long long t0 = h[24];
