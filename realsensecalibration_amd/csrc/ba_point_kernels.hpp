@@ -670,8 +670,10 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
 // Second stage: fixed-order sum of the per-block partials into the small reduction payload
 // small[0..4] = {mcc, cost_c (sum rho), |dp|^2, |Xc|^2, sum sq residuals}
 __device__ __forceinline__ void PublishResult(const double* __restrict__ small_red, double* __restrict__ res);
+__device__ __forceinline__ void PostToHost(const double* __restrict__ res, double* host, double seq);
 // res != nullptr (single GPU): publish straight away, no separate launch
-__global__ void k_finish_candidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red, double* __restrict__ res) {
+__global__ void k_finish_candidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red, double* __restrict__ res,
+                                   double* host, double seq) {
   __shared__ double s[5][256];
   const int tid = threadIdx.x;
   double v[5] = {0, 0, 0, 0, 0};
@@ -692,7 +694,7 @@ __global__ void k_finish_candidate(int nblocks, const double* __restrict__ block
   if (tid < 5) small_red[tid] = s[tid][0];
   if (res != nullptr) {
     __syncthreads();
-    if (tid == 0) { double sr[5]; for (int q = 0; q < 5; ++q) sr[q] = s[q][0]; PublishResult(sr, res); }
+    if (tid == 0) { double sr[5]; for (int q = 0; q < 5; ++q) sr[q] = s[q][0]; PublishResult(sr, res); PostToHost(res, host, seq); }
   }
 }
 
@@ -706,8 +708,15 @@ __device__ __forceinline__ void PublishResult(const double* __restrict__ small_r
   res[RES_XCNORM2] += small_red[3];
   res[RES_SUMSQ_C] = small_red[4];
 }
-__global__ void k_publish_result(const double* __restrict__ small_red, double* __restrict__ res) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) PublishResult(small_red, res);
+// The step's result block goes straight into the host's pinned, coherent buffer, sequence number last: the host polls
+// that word instead of paying for a copy kernel and a stream synchronisation per LM iteration.  One thread.
+__device__ __forceinline__ void PostToHost(const double* __restrict__ res, double* host, double seq) {
+  if (host == nullptr) return;
+  for (int i = 0; i < RES_SIZE - 1; ++i) __hip_atomic_store(&host[i], res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&host[RES_SIZE - 1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_publish_result(const double* __restrict__ small_red, double* __restrict__ res, double* host, double seq) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { PublishResult(small_red, res); PostToHost(res, host, seq); }
 }
 
 // Cost only at the current point-model parameters (used by rsba_reprojection_error).

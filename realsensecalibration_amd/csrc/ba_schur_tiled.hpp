@@ -457,12 +457,13 @@ struct SchurArgs {
   double* __restrict__ gmax_p;
   double* __restrict__ tile_sum;   // [ntiles][42][256]
   int* tree_error;                 // set when a reducer gave up waiting (cannot happen; never hang)
+  int* ticket;                     // next entry of the work list (block_seg)
   long long* trace;   // diagnostic (RSBA_TRACE=1)
   long long* wg_trace;  // diagnostic (RSBA_TRACE=2): start / end / compute-end stamp of every block
 };
 
 template <bool kLoss>
-__device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& sg, int seg_index, double* pt, unsigned long long (*mk)[RSBA_CW], double* sc) {
+__device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& sg, int seg_index, int ticket, double* pt, unsigned long long (*mk)[RSBA_CW], double* sc) {
   const int C = a.C, P = a.P, nwords = a.nwords;
   const double* __restrict__ camc = a.camc;
   const unsigned long long* __restrict__ cam_mask = a.cam_mask;
@@ -560,7 +561,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
 #pragma unroll
     for (int i = 0; i < 36; ++i) __hip_atomic_store(&out[i * 256 + pr], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (a.wg_trace && tid == 0) a.wg_trace[3 * blockIdx.x + 2] = wall_clock64();
+  if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();
   double v[36];
   if (!GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
   FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L);
@@ -580,7 +581,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
 //   [30,36) E' r                                           (-> g_c)
 //   [36,42) E' N V^-1 g_p                                  (-> -corr)
 template <bool kLoss>
-__device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& sg, int seg_index, double* pt, unsigned long long (*mk)[RSBA_CW]) {
+__device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& sg, int seg_index, int ticket, double* pt, unsigned long long (*mk)[RSBA_CW]) {
   const int C = a.C, P = a.P, nwords = a.nwords;
   const double* __restrict__ camc = a.camc;
   const unsigned long long* __restrict__ cam_mask = a.cam_mask;
@@ -666,7 +667,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   double* out = partial + (size_t)seg_index * RSBA_PART * 256;
 #pragma unroll
   for (int i = 0; i < RSBA_PART; ++i) __hip_atomic_store(&out[i * 256 + tid], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.wg_trace && tid == 0) a.wg_trace[3 * blockIdx.x + 2] = wall_clock64();
+  if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();
   double v[RSBA_PART];
   if (!GroupReduce<RSBA_PART>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
   FinishSelfSlot(C, sg.ga, v, camc, a.red, a.L);
@@ -759,14 +760,26 @@ k_schur_tiles(SchurArgs a) {
   __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];            // 48 KB
   __shared__ unsigned long long mk[2 * RSBA_TG][RSBA_CW];       // 2 KB
   __shared__ double sc[2 * RSBA_TG * RSBA_SC_STRIDE];           // 4 KB
-  const int seg_index = a.block_seg[blockIdx.x];
+  // Work is handed out by ticket, not by block index: blocks are assigned to the 8 XCDs round-robin and each XCD
+  // dispatches its own in order, so an XCD that is a little slower (the one that lends a CU to the Cholesky has 62 slots
+  // instead of 64) starts the last blocks of a stage tens of microseconds late, and the stage ends with them.  With
+  // tickets the order of the work list is the order in which slots take it up, whoever they are.  (The sums do not
+  // depend on who does which segment.)  The last ticket resets the counter for the next launch.
+  __shared__ int s_ticket;
+  if (threadIdx.x == 0) {
+    s_ticket = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s_ticket == (int)gridDim.x - 1) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int b = s_ticket;
+  const int seg_index = a.block_seg[b];
   const SchurSeg sg = a.segs[seg_index];
-  if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
-  if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * blockIdx.x] = wall_clock64();
+  if (a.trace && b == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
+  if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b] = wall_clock64();
   if (sg.self >= 2) ReducerSegment(a, sg);
-  else if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, pt, mk);
-  else PairSegment<kLoss>(a, sg, seg_index, pt, mk, sc);
-  if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * blockIdx.x + 1] = wall_clock64();
+  else if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, b, pt, mk);
+  else PairSegment<kLoss>(a, sg, seg_index, b, pt, mk, sc);
+  if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b + 1] = wall_clock64();
 }
 
 

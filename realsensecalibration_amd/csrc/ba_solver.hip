@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -59,16 +60,17 @@ int DeviceCount() {
 // ------------------------------------------------------------------------------------------------
 class KernelTimer {
  public:
-  // mode 0: off, 1: every kernel, 2: only the two kernels the roofline is quoted on (keeps the event overhead in a
-  // timed region to four records per iteration)
+  // mode 0: off, 1: every kernel, 2: only the two kernels the roofline is quoted on, and only every other LM step (the
+  // host-side cost of the event records sits on the critical path between two launches: ~40 us per step when every
+  // step was recorded, 5% of the step).  Events come from a pool: creating one per record costs more than recording it.
   void Enable(int mode) { mode_ = mode; on_ = false; }
-  bool enabled() const { return mode_ != 0; }
+  bool enabled() const { return mode_ != 0 && sampled_; }
+  void NextStep() { ++step_; sampled_ = mode_ == 1 || (mode_ == 2 && (step_ & 1) == 0); }
   static bool Major(const char* n) { return strcmp(n, "k_schur_tiles") == 0 || strcmp(n, "k_reduced_system_solve") == 0 || strcmp(n, "k_linearize_schur_ref") == 0; }
   void Begin(const char* name, hipStream_t s) {
-    on_ = mode_ == 1 || (mode_ == 2 && Major(name));
+    on_ = sampled_ && (mode_ == 1 || (mode_ == 2 && Major(name)));
     if (!on_) return;
-    Pending p; p.name = name;
-    (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b);
+    Pending p; p.name = name; p.a = Get(); p.b = Get();
     (void)hipEventRecord(p.a, s);
     pending_.push_back(p);
   }
@@ -79,18 +81,26 @@ class KernelTimer {
       if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
         auto& st = stats_[p.name]; st.first += 1; st.second += ms;
       }
-      (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+      pool_.push_back(p.a); pool_.push_back(p.b);
     }
     pending_.clear();
   }
   void Add(const char* name, double ms) { auto& st = stats_[name]; st.first += 1; st.second += ms; }
-  void Reset() { Collect(); stats_.clear(); }
+  void Reset() { Collect(); stats_.clear(); for (hipEvent_t e : pool_) (void)hipEventDestroy(e); pool_.clear(); }
+  void Reserve(int n) { while ((int)pool_.size() < n) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; pool_.push_back(e); } }
   const std::map<std::string, std::pair<int64_t, double>>& stats() const { return stats_; }
  private:
+  hipEvent_t Get() {
+    if (pool_.empty()) Reserve(64);
+    hipEvent_t e = pool_.back(); pool_.pop_back();
+    return e;
+  }
   struct Pending { const char* name; hipEvent_t a, b; };
-  bool on_ = false;
+  bool on_ = false, sampled_ = true;
   int mode_ = 0;
+  int64_t step_ = -1;
   std::vector<Pending> pending_;
+  std::vector<hipEvent_t> pool_;
   std::map<std::string, std::pair<int64_t, double>> stats_;
 };
 
@@ -118,6 +128,7 @@ struct rsba_solver {
   long long* chol_waited = nullptr;   // device: ticks the pipelined Cholesky spent waiting for its columns (cumulative)
   long long chol_waited_seen = 0;
   long long* trace = nullptr;   // RSBA_TRACE=1: 32 wall-clock stamps of the pipelined step
+  std::chrono::steady_clock::time_point host_t[4];
   long long* wg_trace = nullptr;  // RSBA_TRACE=2: per-block stamps of the Schur kernel, dumped to RSBA_TRACE_FILE
   ncclComm_t comm = nullptr;
   KernelTimer timer;
@@ -143,7 +154,8 @@ struct rsba_solver {
   int* chol_ok = nullptr;
   double *red = nullptr, *A = nullptr, *S_copy = nullptr, *rhs_copy = nullptr, *dcam = nullptr;
   double *block_scal = nullptr, *block_part = nullptr, *small_red = nullptr, *gmax = nullptr, *res = nullptr;
-  double* res_host = nullptr;  // pinned
+  double* res_host = nullptr;  // pinned, coherent: the last kernel of a step posts res[] here, sequence number in the last slot
+  double res_seq = 0.0;
   int grid_lin = 0, grid_pts = 0;
   int cur = 0;
   TiledSchur tiled;
@@ -189,7 +201,9 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   ntiles = (int)wt.size();
   int cus = 256;
   { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
-  const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : 4;
+  // measured at 64 cameras: the pipelined schedule likes shorter workgroups (a stage ends with its last one), the
+  // sequential one fewer partial sums
+  const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : (staged ? 8 : 4);
   const int target = seg_per_cu * cus;
   // the pair tiles share `target` workgroups, same number for every tile; the self tiles (much lighter) get 2 per CU in
   // total.  (Sizing each stage's workgroups to whole rounds of slots was tried for the pipelined schedule: no gain, and
@@ -205,10 +219,25 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     int ns = self ? (2 * cus + ngroups - 1) / ngroups : (int)std::lround((double)target / std::max(1, npair_tiles));
     const int nW = (P + 63) / 64;  // mask words that hold points
     ns = std::max(1, std::min(ns, nW));
+    // Optional tapered segments (RSBA_TAPER > 1: the first of a tile is that many times as long as the last).  A stage is
+    // over when its last block is, so long-blocks-first should end it earlier; measured, it does not (a stage is only
+    // ~1-2 "rounds" of slots deep and two blocks share a CU's VALU, so a block's duration follows its CU-mate more than
+    // its own length).  Default off.
+    const double taper = getenv("RSBA_TAPER") ? atof(getenv("RSBA_TAPER")) : 1.0;
+    std::vector<int> bound(ns + 1, 0);
+    {
+      const double hi = 2.0 * taper / (taper + 1.0), lo = 2.0 - hi;
+      double cum = 0.0;
+      for (int i = 0; i < ns; ++i) { cum += ns > 1 ? hi - (hi - lo) * i / (ns - 1) : 1.0; bound[i + 1] = (int)std::llround(nW * cum / ns); }
+      bound[ns] = nW;
+      bool ok = true;
+      for (int i = 0; i < ns; ++i) ok = ok && bound[i + 1] > bound[i];
+      if (!ok) for (int i = 0; i <= ns; ++i) bound[i] = (int)((int64_t)nW * i / ns);
+    }
     for (int i = 0; i < ns; ++i) {
       SchurSeg e; memset(&e, 0, sizeof(e));
       e.ga = tab[3 * t]; e.gb = tab[3 * t + 1]; e.self = tab[3 * t + 2];
-      e.word_begin = (int)((int64_t)nW * i / ns); e.word_end = (int)((int64_t)nW * (i + 1) / ns);
+      e.word_begin = bound[i]; e.word_end = bound[i + 1];
       sg.push_back(e);
     }
     tsp[t + 1] = (int)sg.size();
@@ -234,11 +263,13 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   for (int t = 0; t < ntiles; ++t) {
     const bool self = tab[3 * t + 2] != 0;
     const SchurSeg first = sg[tsp[t]];
-    const int nv = self ? RSBA_PART : 36, nred = first.tile_ngrp <= RSBA_DIRECT_GROUPS ? 0 : (nv + RSBA_RED_COMPS - 1) / RSBA_RED_COMPS;
+    const int rc_env = getenv("RSBA_RED_COMPS") ? atoi(getenv("RSBA_RED_COMPS")) : RSBA_RED_COMPS;
+    const int red_comps = std::max(1, std::min(rc_env, RSBA_RED_COMPS));
+    const int nv = self ? RSBA_PART : 36, nred = first.tile_ngrp <= RSBA_DIRECT_GROUPS ? 0 : (nv + red_comps - 1) / red_comps;
     for (int q = tsp[t]; q < tsp[t + 1]; ++q) sg[q].nred = nred;
     for (int r = 0; r < nred; ++r) {
       SchurSeg e = first;
-      e.self = self ? 3 : 2; e.word_begin = r * RSBA_RED_COMPS; e.word_end = std::min(nv, (r + 1) * RSBA_RED_COMPS); e.nred = nred;
+      e.self = self ? 3 : 2; e.word_begin = r * red_comps; e.word_end = std::min(nv, (r + 1) * red_comps); e.nred = nred;
       red_of_tile[t].push_back((int)sg.size());
       sg.push_back(e);
     }
@@ -255,7 +286,12 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       std::vector<int> tiles_g;
       for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2] && tab[3 * t] == g) tiles_g.push_back(t);
       for (int t = stage_tile[g]; t < stage_tile[g + 1]; ++t) tiles_g.push_back(t);
-      for (int t : tiles_g) for (int q = tsp[t]; q < tsp[t + 1]; ++q) border.push_back(q);
+      // the stage's tiles interleaved by position, so that the stage as a whole runs long blocks first, short ones last
+      // and all its tiles end together
+      std::vector<std::pair<double, int>> ord;
+      for (int t : tiles_g) for (int q = tsp[t]; q < tsp[t + 1]; ++q) ord.push_back({(q - tsp[t] + 0.5) / (tsp[t + 1] - tsp[t]), q});
+      std::stable_sort(ord.begin(), ord.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+      for (const auto& o : ord) border.push_back(o.second);
       for (int t : tiles_g) for (int q : red_of_tile[t]) border.push_back(q);
     }
   } else {
@@ -270,7 +306,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       (rc = DevAlloc(&tile_ab, (size_t)3 * ntiles)) || (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
       (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) ||
-      (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 1)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
+      (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm, cmpos.size())) || (rc = DevAlloc(&u_cm, cmpos.size())) || (rc = DevAlloc(&v_cm, cmpos.size())))
     return rc;
@@ -281,7 +317,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     HIPCHK(hipMemcpy(v_cm, vcm.data(), vcm.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   HIPCHK(hipMemset(sync_cnt, 0, (size_t)nsync * sizeof(int)));
-  HIPCHK(hipMemset(tree_error, 0, sizeof(int)));
+  HIPCHK(hipMemset(tree_error, 0, 2 * sizeof(int)));   // [0] error flag, [1] ticket counter of the Schur kernel
   HIPCHK(hipMemset(ready, 0, 16 * sizeof(int)));
   HIPCHK(hipMemcpy(block_seg, border.data(), border.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_mask, mask.data(), mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
@@ -435,6 +471,13 @@ static int UploadPoints(rsba_solver* s) {
     for (int j = 0; j < P && !dup; ++j) for (int q = ptr[j] + 1; q < ptr[j + 1]; ++q) if (cam[q] == cam[q - 1]) { dup = true; break; }
     if (dup) s->opt.schur_impl = 0;
   }
+  // dynamic LDS above 48 KB has to be asked for, once
+  if (s->nc <= RSBA_CHOL_MAXN) {
+    const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(s->nc)) * sizeof(double);
+    if (lds_c > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+  } else {
+    HIPCHK(hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CholStepLdsDoubles() * sizeof(double))));
+  }
   if (s->opt.schur_impl != 0) {
     if (getenv("RSBA_TRACE")) {
       // diagnostics: wall-clock stamps of the step (1) and of every block of the Schur kernel (2)
@@ -480,7 +523,7 @@ void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& 
   SchurArgs a;
   a.C = C; a.P = P; a.nwords = nwords; a.camc = s->camc[x]; a.segs = segs; a.cam_mask = cam_mask; a.ptdata = ptdata;
   a.cam_prefix = cam_prefix; a.cam_ptr = cam_ptr; a.sq_cm = sq_cm; a.u_cm = u_cm; a.v_cm = v_cm; a.partial = partial;
-  a.grp_sum = grp_sum; a.sync_cnt = sync_cnt; a.ngrp = ngrp; a.ntiles = ntiles; a.block_seg = block_seg; a.last_group = ngroups - 1; a.tile_sum = tile_sum; a.tree_error = tree_error;
+  a.grp_sum = grp_sum; a.sync_cnt = sync_cnt; a.ngrp = ngrp; a.ntiles = ntiles; a.block_seg = block_seg; a.last_group = ngroups - 1; a.tile_sum = tile_sum; a.tree_error = tree_error; a.ticket = tree_error + 1;
   a.ready = ready; a.tag = tag; a.red = s->red; a.L = s->L; a.nblocks_pp = grid_pp; a.block_scal = block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
   T.Begin("k_schur_tiles", st);
@@ -504,6 +547,8 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   const IterParams ip = MakeIterParams(s->opt, radius, first);
   KernelTimer& T = s->timer;
 
+  if (s->trace) s->host_t[0] = std::chrono::steady_clock::now();
+  T.NextStep();
   DebugSync(st, "enter PointsStep");
   // camera constants at x: only the first step of a run computes them; afterwards x is either unchanged (rejected step)
   // or the former candidate, whose constants k_reduced_system_solve already wrote into camc[c] before the swap
@@ -544,14 +589,16 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     TiledSchur& ts = s->tiled;
     const int n = s->nc, tag = s->step_tag;
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(n)) * sizeof(double);
-    if (lds_c > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+    // the point pass first: it is the head of the critical path; the Cholesky (which must be resident before the
+    // Schur kernel fills the chip) goes out while it runs
+    ts.LaunchPointPass(s, ip, T, st);
+    if (s->trace) s->host_t[1] = std::chrono::steady_clock::now();
     T.Begin("k_reduced_system_solve", s->sB);
     k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                      s->camc[c], s->dcam, s->gmax, s->res, ip, 1, 0, n, RSBA_STAGE_FIRST | RSBA_STAGE_LAST,
-                                                     s->chol_ok, StageGate{ts.ready, s->test_stall ? tag + 1 : tag, 6 * RSBA_TG, s->chol_waited, s->trace});
+                                                     s->chol_ok, StageGate{ts.ready, s->test_stall ? tag + 1 : tag, 6 * RSBA_TG, T.enabled() ? s->chol_waited : nullptr, s->trace});
     T.End(s->sB);
     HIPCHK(hipEventRecord(s->ev_chol, s->sB));
-    ts.LaunchPointPass(s, ip, T, st);
     ts.LaunchTiles(s, ip, T, st, tag);
     HIPCHK(hipStreamWaitEvent(st, s->ev_chol, 0));
   }
@@ -568,7 +615,6 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   } else if (s->nc <= RSBA_CHOL_MAXN) {
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(s->nc)) * sizeof(double);
     T.Begin("k_reduced_system_solve", st);
-    if (lds_c > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
     k_reduced_system_solve<<<1, 512, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
                                                   keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                   s->camc[c], s->dcam, s->gmax, s->res, ip, s->opt.schur_impl != 0 ? 1 : 0, 0, s->nc,
@@ -582,7 +628,6 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
                                        s->scale_c, ip, s->opt.schur_impl != 0 ? 1 : 0, s->chol_ok);
     T.End(st);
     const size_t lds_s = CholStepLdsDoubles() * sizeof(double);
-    HIPCHK(hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
     T.Begin("k_chol_step(all panels)", st);
     for (int kb = 0; kb < n; kb += RSBA_PB) {
       const int r0 = kb + std::min(RSBA_PB, n - kb);
@@ -610,15 +655,36 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   T.End(st);
   DebugSync(st, "k_backsub_candidate");
   T.Begin("k_finish_candidate", st);
-  k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, s->comm ? nullptr : s->res);
+  k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, s->comm ? nullptr : s->res, s->res_host, s->res_seq + 1.0);
   T.End(st);
   if (s->comm) {
     NCCLCHK(ncclAllReduce(s->small_red, s->small_red, 8, ncclDouble, ncclSum, s->comm, st));
-    k_publish_result<<<1, 64, 0, st>>>(s->small_red, s->res);
+    k_publish_result<<<1, 64, 0, st>>>(s->small_red, s->res, s->res_host, s->res_seq + 1.0);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(s->res_host, s->res, RES_SIZE * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  if (s->trace) s->host_t[2] = std::chrono::steady_clock::now();
+  {
+    // wait for the step's result block: poll the sequence word the last kernel posts (see PostToHost); a stream
+    // synchronisation every 2 s of polling keeps a dead queue from spinning us forever
+    s->res_seq += 1.0;
+    volatile double* seq = s->res_host + (RES_SIZE - 1);
+    auto t_poll = std::chrono::steady_clock::now();
+    while (*seq != s->res_seq) {
+      __builtin_ia32_pause();
+      if (std::chrono::steady_clock::now() - t_poll > std::chrono::seconds(2)) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (*seq != s->res_seq) { fprintf(stderr, "rsba: step finished without posting its result\n"); return RSBA_ERR_HIP; }
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (s->trace) {
+    const auto now = std::chrono::steady_clock::now();
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "rsba[host] since previous result %.1f us | enter -> point pass launched %.1f -> all launched %.1f -> result %.1f\n",
+            us(s->host_t[3], s->host_t[0]), us(s->host_t[0], s->host_t[1]), us(s->host_t[1], s->host_t[2]), us(s->host_t[2], now));
+    s->host_t[3] = now;
+  }
   if (pipe && T.enabled()) {
     // the Cholesky's event span includes the time it slept on the ready flags: record that separately
     long long w = 0;
@@ -659,6 +725,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     fprintf(stderr, "rsba: pipelined solve stalled; falling back to the sequential schedule\n");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(s->tiled.sync_cnt, 0, (size_t)s->tiled.nsync * sizeof(int)));
+    HIPCHK(hipMemset(s->tiled.tree_error + 1, 0, sizeof(int)));
     s->pipelined = false;
     return PointsStep(s, radius, first, keep_system_copy);
   }
@@ -779,6 +846,7 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
   if (opt.stream) s->stream = (hipStream_t)opt.stream;
   else { if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return RSBA_ERR_HIP; } s->own_stream = true; }
   s->timer.Enable(opt.profile_kernels);
+  if (opt.profile_kernels) s->timer.Reserve(256);
   int rc = RSBA_OK;
   if (opt.world_size > 1 || getenv("RSBA_FORCE_COMM")) {
     // One communicator per unique id and process (an id can be used for one ncclCommInitRank only);
@@ -797,7 +865,7 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
     }
     s->comm = it->second;
   }
-  if (hipHostMalloc((void**)&s->res_host, RES_SIZE * sizeof(double), hipHostMallocDefault) != hipSuccess) { rsba::FreeSolver(s); return RSBA_ERR_HIP; }
+  if (hipHostMalloc((void**)&s->res_host, RES_SIZE * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { rsba::FreeSolver(s); return RSBA_ERR_HIP; }
   if (p->model == RSBA_MODEL_POINTS) rc = rsba::UploadPoints(s);
   else rc = s->marker.Upload(*p);
   if (rc == RSBA_OK && hipDeviceSynchronize() != hipSuccess) rc = RSBA_ERR_HIP;
@@ -939,7 +1007,7 @@ int rsba_reprojection_error(rsba_problem* p, const rsba_options* o, double* erro
     if (rc == RSBA_OK) {
       k_camera_constants<<<(s->C + 63) / 64, 64, 0, s->stream>>>(s->C, s->cam[0], s->intr, s->camc[0]);
       k_cost_only<<<s->grid_pts, 256, 0, s->stream>>>(s->P, s->sliced(), s->camc[0], s->pts[0], s->block_part, 0.0);
-      k_finish_candidate<<<1, 256, 0, s->stream>>>(s->grid_pts, s->block_part, s->small_red, nullptr);
+      k_finish_candidate<<<1, 256, 0, s->stream>>>(s->grid_pts, s->block_part, s->small_red, nullptr, nullptr, 0.0);
       double h[8];
       if (hipMemcpyAsync(h, s->small_red, 8 * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) rc = RSBA_ERR_HIP;
       sumsq = h[4]; npts = p->num_observations;

@@ -274,15 +274,17 @@ def test_pipelined_solve_matches_oracle_and_sequential_schedule(oracle, C, P, k,
     """With 17..64 cameras the Cholesky of the reduced system is launched first and factors camera group g's
     columns as soon as the Schur kernel has published them (ready flags), while the later groups are still being
     eliminated.  Same kernels, same summation orders: the result must equal the oracle's within the usual tolerances
-    and the sequential schedule's (RSBA_PIPELINE=0) bit for bit.  C = 17 leaves a last group of one camera (a stage
+    and the sequential schedule's (RSBA_PIPELINE=0, same segment size) bit for bit.  C = 17 leaves a last group of one camera (a stage
     without any pair tile), C = 64 is the benchmark's shape, with Huber loss and outliers."""
     prob = syn.make_problem(C, P, k, seed=300 + C, outlier_frac=0.05 if huber else 0.0)
     got, s, log = _compare_solve(oracle, prob, 1, huber=huber)
     os.environ["RSBA_PIPELINE"] = "0"
+    os.environ["RSBA_SEG_PER_CU"] = "8"   # the pipelined default: same segments, same summation order
     try:
         seq, s_seq, log_seq = capi.solve_points(prob, capi.default_options(schur_impl=1, huber_delta=huber))
     finally:
         del os.environ["RSBA_PIPELINE"]
+        del os.environ["RSBA_SEG_PER_CU"]
     assert np.array_equal(got, seq) and np.array_equal(log, log_seq) and s.final_cost == s_seq.final_cost
     again, s2, log2 = capi.solve_points(prob, capi.default_options(schur_impl=1, huber_delta=huber))
     assert np.array_equal(got, again) and np.array_equal(log, log2)
