@@ -47,9 +47,10 @@ __device__ __forceinline__ double ReadLaneD(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// LDS doubles: (n+2) x 33 shared by the panel and the B strip, a 32 x 33 tile for T, 32 inverse pivots, scratch.
+// LDS doubles: (n+2) x 33 shared by the panel and the B strip, 32 x 33 tiles for T and the padded L11, 32 inverse
+// pivots, scratch, the column scale, four 32 x 33 tiles for the look-ahead products of the next diagonal block.
 __host__ __device__ inline size_t CholeskyLdsDoubles(int n) {
-  const size_t fact = (size_t)(n + 2) * RSBA_PLD + 2 * RSBA_PB * RSBA_PLD + RSBA_PB + 64 + (size_t)n;
+  const size_t fact = (size_t)(n + 2) * RSBA_PLD + 2 * RSBA_PB * RSBA_PLD + RSBA_PB + 64 + (size_t)n + 4 * RSBA_PB * RSBA_PLD;
   const size_t back = (size_t)((n + 63) & ~63) + 3 * RSBA_PB * RSBA_PLD + 64;
   return fact > back ? fact : back;
 }
@@ -204,6 +205,15 @@ __device__ __forceinline__ bool DiagFactorInverse(double* __restrict__ Pan, int 
   return good;
 }
 
+// Out-of-line copy for the one-workgroup solver: that kernel sits at the 256-VGPR cap of a 512-thread workgroup, and with
+// the factorisation inlined the register allocator spills into this loop (the critical path) whenever the code of the
+// other waves grows.  As a separate function it gets its own allocation and the caller saves what it needs around one
+// call per panel.  The LDS pointers keep their address space across the call (ds_read, not flat loads).
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __noinline__ bool DiagFactorInverseCall(lds_double* Pan, int nb, lds_double* T, lds_double* Lt, lds_double* invd, int lane) {
+  return DiagFactorInverse((double*)Pan, nb, (double*)T, (double*)Lt, (double*)invd, lane);
+}
+
 // Blocked back-substitution L' x = y with the stored block inverses; y (row n of A) is copied to LDS and holds x on
 // return (first n doubles of `lds`).  All threads of the workgroup.
 __device__ __forceinline__ double* BackSubstituteBlocks(int n, double* __restrict__ A, double* lds) {
@@ -278,8 +288,11 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
   double* invd = Lt + RSBA_PB * RSBA_PLD;              // 32
   double* colb = invd + RSBA_PB;                       // 32 (+32 spare)
   double* scl = colb + 64;                             // n: LDS copy of the column scale (fused source only)
+  double* ahead = scl + n;                             // 4 x (32 x 33): look-ahead products for the next diagonal block
   __shared__ int s_ok;
-  if (tid == 0) s_ok = 1;
+  __shared__ int s_ahead_read;   // the panel whose look-ahead tiles wave 0 has consumed (waves 1..4 may overwrite them)
+  __shared__ int s_rb_next;      // next pair of 16-row blocks of the update (2b): the waves take them as they get free
+  if (tid == 0) { s_ok = 1; s_ahead_read = -1; s_rb_next = 0; }
   if (src.S != nullptr) for (int i = tid; i < n; i += nt) scl[i] = src.scale[i];
   __syncthreads();
   RSBA_STAMP_INIT;
@@ -348,69 +361,152 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
 #pragma unroll
       for (int u = 0; u < 4; ++u) Bst[(q0 + u) * RSBA_PLD + c] = v[u];
     }
+    if (tid == 0) s_rb_next = 0;
     __syncthreads();
     RSBA_STAMP(0);
+#ifdef RSBA_PROFILE_PHASES
+    long long _x0 = 0;
+    const long long _x00 = clock64();
+#endif
     // 2. update with previous panels (MFMA), one wave per 16-row block, no barriers inside
-    // 2a. the diagonal block's own 32 rows first, K-split over all waves (both operands come from the LDS strip),
-    //     partial products added into the panel in wave order;
-    // 2b. then waves 1.. update the rows below while wave 0 goes straight on to factor the diagonal block (step 3):
-    //     the serial factorisation hides behind the GEMM of the rest.
+    // 2a. the diagonal block's own 32 rows, by wave 0 alone: a rank-32 update with the previous panel from the LDS
+    //     strip + the look-ahead products over all earlier columns that waves 1..4 computed during the previous panel
+    //     (2c), so nothing but ~0.5 us of wave 0 stands between the panel load and the factorisation;
+    // 2b. waves 1.. update the rows below while wave 0 factors the diagonal block (step 3): the serial factorisation
+    //     hides behind the GEMM of the rest;
+    // 2c. waves 1..4 also form, for the NEXT diagonal block, L[kb+32.., 0:kb] L[kb+32.., 0:kb]' from global memory
+    //     (final entries of L, written back by the earlier panels), K-split four ways into `ahead`.
     if (kb > 0) {
       const int i = lane & 15, kk = lane >> 4;
-      {
+      if (wave == 0) {
+        // the previous panel's 32 columns: rank-32 update straight from the strip
         d4_t a00 = {0, 0, 0, 0}, a01 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
-        for (int q0 = wave * RSBA_PB; q0 < kb; q0 += nwave * RSBA_PB) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const double* bq = Bst + (size_t)(q0 + 4 * u + kk) * RSBA_PLD;
-            const double x0 = bq[i], x1 = bq[16 + i];   // row i / 16+i of the diagonal block, also columns i / 16+i
-            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, a00, 0, 0, 0);
-            a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, a01, 0, 0, 0);
-            a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, a10, 0, 0, 0);
-            a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
-          }
+        for (int u = 0; u < 8; ++u) {
+          const double* bq = Bst + (size_t)(kb - RSBA_PB + 4 * u + kk) * RSBA_PLD;
+          const double x0 = bq[i], x1 = bq[16 + i];   // row i / 16+i of the diagonal block, also columns i / 16+i
+          a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, a00, 0, 0, 0);
+          a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, a01, 0, 0, 0);
+          a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, a10, 0, 0, 0);
+          a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
         }
-        // the waves add their partial products in wave order (plain read-modify-write, one barrier per wave) so the
-        // factor is bitwise reproducible: every rank of a multi-GPU run must end up with identical cameras
-        for (int wv = 0; wv < nwave && wv * RSBA_PB < kb; ++wv) {
-          if (wave == wv) {
+#ifdef RSBA_PROFILE_PHASES
+        if (lane == 0) g_phase_cycles[1] += clock64() - _x00;
+#endif
+        // all earlier columns: the four partial products waves 1..4 left in `ahead` during the previous panel, added
+        // in a fixed order (bitwise reproducible: every rank of a multi-GPU run must end up with identical cameras)
+        const bool have_ahead = kb > RSBA_PB;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const int r = kk + 4 * t;
-              Pan[r * RSBA_PLD + i] -= a00[t];
-              Pan[r * RSBA_PLD + 16 + i] -= a01[t];
-              Pan[(16 + r) * RSBA_PLD + i] -= a10[t];
-              Pan[(16 + r) * RSBA_PLD + 16 + i] -= a11[t];
+        for (int t = 0; t < 4; ++t) {
+          const int r = kk + 4 * t;
+          const int e00 = r * RSBA_PLD + i, e01 = e00 + 16, e10 = (16 + r) * RSBA_PLD + i, e11 = e10 + 16;
+          double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
+          if (have_ahead) {
+            const double *h0 = ahead, *h1 = ahead + RSBA_PB * RSBA_PLD, *h2 = h1 + RSBA_PB * RSBA_PLD, *h3 = h2 + RSBA_PB * RSBA_PLD;
+            s00 = (h0[e00] + h1[e00]) + (h2[e00] + h3[e00]); s01 = (h0[e01] + h1[e01]) + (h2[e01] + h3[e01]);
+            s10 = (h0[e10] + h1[e10]) + (h2[e10] + h3[e10]); s11 = (h0[e11] + h1[e11]) + (h2[e11] + h3[e11]);
+          }
+          // rows >= nb of a partial last panel are not the diagonal block's (the rhs row sits there): the waves of 2b
+          // own them, and a read-modify-write of "minus zero" from here would race with their update
+          if (r < nb) { Pan[e00] -= s00 + a00[t]; Pan[e01] -= s01 + a01[t]; }
+          if (16 + r < nb) { Pan[e10] -= s10 + a10[t]; Pan[e11] -= s11 + a11[t]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&s_ahead_read, kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      // (no barrier: only wave 0 touches the diagonal block between the panel load and its factorisation)
+#ifdef RSBA_PROFILE_PHASES
+      _x0 = clock64();
+#endif
+      if (wave >= 1 && wave <= 4 && kb + RSBA_PB < n) {
+        const int kbn = kb + RSBA_PB;
+        const int r0g = kbn + i, r1g = kbn + 16 + i;
+        const double* p0 = A + (size_t)(r0g < n ? r0g : 0) * n + 8 * kk;   // k order 8 kk + u, as in 2b
+        const double* p1 = A + (size_t)(r1g < n ? r1g : 0) * n + 8 * kk;
+        d4_t a00 = {0, 0, 0, 0}, a01 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
+        {
+          // this wave's column blocks qf, qf+128, qf+256 (kb <= 352: at most three): all loads first, one round trip
+          const int qf = (wave - 1) * RSBA_PB;
+          double x0[3][8], x1[3][8];
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            const int q = qf + b * 4 * RSBA_PB;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { x0[b][u] = (r0g < n && q < kb) ? p0[q + u] : 0.0; x1[b][u] = (r1g < n && q < kb) ? p1[q + u] : 0.0; }
+          }
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            if (qf + b * 4 * RSBA_PB < kb) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[b][u], x0[b][u], a00, 0, 0, 0);
+                a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[b][u], x1[b][u], a01, 0, 0, 0);
+                a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[b][u], x0[b][u], a10, 0, 0, 0);
+                a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[b][u], x1[b][u], a11, 0, 0, 0);
+              }
             }
           }
-          __syncthreads();
+          for (int q0 = qf + 12 * RSBA_PB; q0 < kb; q0 += 4 * RSBA_PB) {   // n > 416 only (never with RSBA_CHOL_MAXN = 384)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const double z0 = r0g < n ? p0[q0 + u] : 0.0, z1 = r1g < n ? p1[q0 + u] : 0.0;
+              a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, z0, a00, 0, 0, 0);
+              a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, z1, a01, 0, 0, 0);
+              a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, z0, a10, 0, 0, 0);
+              a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, z1, a11, 0, 0, 0);
+            }
+          }
+        }
+        // wave 0 may still be reading the tiles of THIS panel (2a, a microsecond at the start of the phase)
+        while (__hip_atomic_load(&s_ahead_read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != kb) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        double* h = ahead + (size_t)(wave - 1) * RSBA_PB * RSBA_PLD;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = kk + 4 * t;
+          h[r * RSBA_PLD + i] = a00[t]; h[r * RSBA_PLD + 16 + i] = a01[t];
+          h[(16 + r) * RSBA_PLD + i] = a10[t]; h[(16 + r) * RSBA_PLD + 16 + i] = a11[t];
         }
       }
-      __syncthreads();
+#ifdef RSBA_PROFILE_PHASES
+      if (tid == 64) { long long _x1 = clock64(); g_phase_cycles[12] += _x1 - _x0; _x0 = _x1; }
+#endif
       const int nrb = (R + 15) >> 4;
-      const int nw1 = nwave > 1 ? nwave - 1 : 1;
       // a partial last panel (nb < 32) keeps its rows nb..R-1 (the rhs row) outside the strip: they are updated here
       const int rb0 = nb == RSBA_PB ? 2 : (nb >> 4);
-      for (int rb = rb0 + (nwave > 1 ? wave - 1 : 0); rb < nrb && (wave > 0 || nwave == 1); rb += nw1) {
+      // 16-row blocks handed out through an LDS counter (waves 1..4 arrive late from 2c and take fewer); the A operand
+      // two steps ahead of the MFMAs
+      for (;;) {
+        if (!(wave > 0 || nwave == 1)) break;
+        int blk = 0;
+        if (lane == 0) blk = __hip_atomic_fetch_add(&s_rb_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        blk = __builtin_amdgcn_readfirstlane(blk);
+        const int rb = rb0 + blk;
+        if (rb >= nrb) break;
         const int prow = rb * 16 + i;  // panel-relative row of this lane's A operand
         const bool gl = prow < R;
-        const double* arow = A + (size_t)(kb + (gl ? prow : 0)) * n + kk;
+        // k index of MFMA step u in lane group kk is 8 kk + u (for both operands): a lane's eight A values are then 64
+        // contiguous bytes, four lanes cover 256 B of a row — every sector fetched is used (one CU only pulls a few
+        // tens of GB/s; with the natural k = 4 u + kk order each load touched 16 rows x 32 B)
+        const double* arow = A + (size_t)(kb + (gl ? prow : 0)) * n + 8 * kk;
         d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         double an[8], an2[8];
+        auto fetch = [&](double (&d)[8], int q) {
+          const double2* pa = reinterpret_cast<const double2*>(arow + q);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { an[u] = gl ? arow[4 * u] : 0.0; an2[u] = (gl && RSBA_PB < kb) ? arow[RSBA_PB + 4 * u] : 0.0; }
+          for (int v = 0; v < 4; ++v) { const double2 t = pa[v]; d[2 * v] = gl ? t.x : 0.0; d[2 * v + 1] = gl ? t.y : 0.0; }
+        };
+        fetch(an, 0);
+        if (RSBA_PB < kb) fetch(an2, RSBA_PB);
         for (int q0 = 0; q0 < kb; q0 += RSBA_PB) {
           double ac[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) { ac[u] = an[u]; an[u] = an2[u]; }
-          if (q0 + 2 * RSBA_PB < kb) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) an2[u] = gl ? arow[q0 + 2 * RSBA_PB + 4 * u] : 0.0;
-          }
+          if (q0 + 2 * RSBA_PB < kb) fetch(an2, q0 + 2 * RSBA_PB);
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const double b0 = Bst[(q0 + 4 * u + kk) * RSBA_PLD + i];
-            const double b1 = Bst[(q0 + 4 * u + kk) * RSBA_PLD + 16 + i];
+            const double b0 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + i];
+            const double b1 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + 16 + i];
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b1, acc1, 0, 0, 0);
           }
@@ -426,13 +522,24 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
         }
       }
     }
+#ifdef RSBA_PROFILE_PHASES
+    if (kb > 0 && tid == 64) g_phase_cycles[13] += clock64() - _x0;
+    if (kb > 0 && tid == 448) g_phase_cycles[14] += clock64() - _x0;
+#endif
     // (no barrier here: wave 0 wrote the diagonal block's rows itself)
     // 3. diagonal block + its inverse, wave 0.  Rows/columns >= nb are padded with identity so that all 32
     //    steps run unconditionally; lanes 32..63 shadow lanes 0..31 (same values, same addresses), so the
     //    whole sequence is one branch-free basic block.  The empty asm statements pin every updated value at
     //    its step: without them LLVM sinks the updates towards their uses and spills ~1300 registers.
     if (wave == 0) {
-      if (!DiagFactorInverse(Pan, nb, T, Lt, invd, lane) && lane == 0) s_ok = 0;
+#ifdef RSBA_PROFILE_PHASES
+      if (lane == 0) g_phase_cycles[6] += clock64() - _x00;
+      long long _c0 = clock64();
+#endif
+      if (!DiagFactorInverseCall((lds_double*)Pan, nb, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane) && lane == 0) s_ok = 0;
+#ifdef RSBA_PROFILE_PHASES
+      if (lane == 0) g_phase_cycles[7] += clock64() - _c0;
+#endif
     }
     __syncthreads();
     RSBA_STAMP(2);
