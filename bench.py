@@ -249,7 +249,15 @@ def main():
                                          % (args.cpu_iters, args.config, res[1]),
                                "single_thread_value": res[1], "multi_thread_value": res.get(min(ncpu, 64)), "multi_threads": min(ncpu, 64), "host_cores": ncpu}
         out["speedup_vs_cpu_baseline"] = iters_per_s / res[best]
-    print(json.dumps(out))
+    # RCCL prints a version banner through C stdio, which sits in libc's buffer until exit when stdout is a pipe and
+    # would land AFTER the JSON line: push it out first so that the JSON is the last line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

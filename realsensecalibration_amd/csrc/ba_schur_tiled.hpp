@@ -19,13 +19,18 @@
 //     traffic at 12 gathered doubles per hit and the chunk large enough that hit-count imbalance across the
 //     lanes of a wave stays below ~25%.
 //   * block(a,b) = E_a' (N_a Vinv N_b') E_b with E = [A K | Pj]; the per-camera 3x3 factor K (left Jacobian
-//     of SO(3)) is pulled out of the sum over points and applied once per pair in k_schur_finish.
-//   * every workgroup writes its 256 x 42 partial sums; k_schur_finish adds them in a fixed order (bitwise
-//     reproducible), applies K, and subtracts the result from S.
+//     of SO(3)) is pulled out of the sum over points and applied once per pair by the tile's finisher.
+//   * every workgroup writes its 256 x 42 partial sums; they are added inside the same launch, in a fixed order
+//     (bitwise reproducible): groups of RSBA_GRP segments by their last arriver, tiles by reducer workgroups, whose
+//     last one applies K and writes the tile's blocks of S (GroupReduce / ReducerSegment below).
+//   * everything that is a sum over ONE camera's observations (diagonal blocks, damping diagonal, g_c, rhs
+//     correction) is a "self" segment of the same launch (SelfSegment).
+//   * the launch works through a list ordered by camera group ("stage") and publishes ready[1 + g] when group g's
+//     columns of S are complete: the Cholesky may already be waiting for them (pipelined schedule, ba_solver.hip).
 //
 // The point-side pass (k_point_pass) that precedes it evaluates residuals and Jacobian blocks once per
-// observation, accumulates U, g_c (LDS fp64 atomics per workgroup), forms the damped inverse point blocks
-// and writes the 12 doubles per point the pair kernel stages.
+// observation (point side only), forms the damped inverse point blocks and writes the 12 doubles per point the
+// Schur kernel stages.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -61,8 +66,6 @@ struct TiledSchur {
   int C = 0, P = 0, ngroups = 0, nwords = 0, nchunks = 0, nseg = 0, nseg_pair = 0, grid_pp = 0;
   unsigned long long* cam_mask = nullptr;   // [ngroups*16][nwords]
   SchurSeg* segs = nullptr;                 // [nseg]
-  int* tile_seg_ptr = nullptr;              // [ntiles+1] segments of a tile are contiguous
-  int* tile_ab = nullptr;                   // [ntiles][2]
   int ntiles = 0;
   double* ptdata = nullptr;                 // [P][12]
   double* partial = nullptr;                // [nseg][42][256]
@@ -575,7 +578,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
 // Camera a sees ~3x the points a pair shares, so its points are dealt to 16 lanes: lane (ia, s) takes the bits
 // {s, s+16, s+32, s+48} of every mask word.  The residual needs this observation's pixel: u/v are kept in a second,
 // camera-major copy (u_cm, v_cm) addressed by the rank of the point in the camera's own list.
-// Per-lane sums (42, the K = J_l factor is applied in k_schur_finish):
+// Per-lane sums (42, the K = J_l factor is applied by the tile's finisher, FinishSelfSlot):
 //   [0,21)  upper triangle of  E'(I - N V^-1 N')E   = core of  U_a - W V^-1 W'
 //   [21,27) upper triangle of the top-left 3x3 of E'E, [27,30) diagonal entries 3..5 of E'E   (-> diag U_a)
 //   [30,36) E' r                                           (-> g_c)

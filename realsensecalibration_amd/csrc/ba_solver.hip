@@ -302,8 +302,8 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   for (int q = 0; q < nseg; ++q) if (!sg[q].self) ++nseg_pair;  // pair tiles come first, self tiles after them, reducers last
   grid_pp = std::max(1, std::min((P + 255) / 256, 2048));
   int rc;
-  if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nblocks)) || (rc = DevAlloc(&tile_seg_ptr, (size_t)ntiles + 1)) ||
-      (rc = DevAlloc(&tile_ab, (size_t)3 * ntiles)) || (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
+  if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nblocks)) ||
+      (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
       (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) ||
       (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
@@ -322,8 +322,6 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   HIPCHK(hipMemcpy(block_seg, border.data(), border.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_mask, mask.data(), mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(segs, sg.data(), sg.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(tile_seg_ptr, tsp.data(), tsp.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(tile_ab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_prefix, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_ptr, cptr.data(), cptr.size() * sizeof(int), hipMemcpyHostToDevice));
   {
@@ -335,7 +333,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, tile_seg_ptr, tile_ab, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, ready, block_seg, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
+  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, ready, block_seg, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   cam_mask = nullptr;
 }

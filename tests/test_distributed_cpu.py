@@ -33,7 +33,7 @@ def _rank_step(rank, world, port, out):
     nc, Pl = 6 * C, prob["P"]
     cams, pts = prob["params"][:nc].reshape(C, 6), prob["params"][nc:].reshape(Pl, 3)
     intr = prob["intr"].reshape(C, 4)
-    # ---- local linearisation: the payload of k_point_pass + k_schur_pairs
+    # ---- local linearisation: the payload of k_point_pass + k_schur_tiles
     S, gc, corr, diagU = np.zeros((nc, nc)), np.zeros(nc), np.zeros(nc), np.zeros(nc)
     cost = xn2 = gmax = 0.0
     per_point = []
