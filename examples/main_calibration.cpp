@@ -33,6 +33,10 @@ int main(int argc, char** argv) {
     double err = 0;
     const double rms = ba_manager.ReprojectionRms(&err);
     printf("Reprojection Error (After BA): %.9g\nAverage Reprojection Error per One Coordinate: %.9g\n", err, rms);
+    // the reference's own check re-reads what Write() produced (6-digit text): main.cpp:41-43
+    double err_files = 0;
+    const double rms_files = ba_manager.ReprojectionRmsFromFiles(K, &err_files);
+    printf("From the written files: %.9g %.9g\n", err_files, rms_files);
   } catch (const std::exception& e) {
     fprintf(stderr, "%s\n", e.what());
     return 1;

@@ -215,6 +215,14 @@ int rsba_write_outputs(rsba_problem* p, const char* camera_transform_xml, const 
  * parameters, evaluated on the GPU: error = sum((du^2+dv^2)/2), rms = sqrt(2 error / (2 n_points)). */
 int rsba_reprojection_error(rsba_problem* p, const rsba_options* o, double* error, double* rms);
 
+/* ReprojectionCheck::Reproject end to end from the files it reads (reprojection_check.cpp:5-101): the 6-digit 3D
+ * corners of point3d.txt, R{i} (3x3, or the 3x1 rvec of the Test2 variant) and t{i} of Camera_Transform.xml, and the
+ * detected corners — taken from correspondence.txt and rounded to float32 as the reference holds them (Point2f,
+ * :78) — projected on the GPU with zero distortion (:69).  intrinsics: fx, fy, ppx, ppy per camera.  On the
+ * committed hongo files this prints the reference's 143.64 / 0.726696 (vs 0.726670 from the unrounded parameters). */
+int rsba_reprojection_check_files(const char* correspondence_txt, const char* point3d_txt, const char* camera_transform_xml,
+                                  const double* intrinsics, double* error, double* rms);
+
 #ifdef __cplusplus
 }
 #endif

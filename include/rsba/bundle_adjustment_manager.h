@@ -64,6 +64,19 @@ class BAManager {
     return rms;
   }
 
+  // ReprojectionCheck::Reproject as main.cpp:41-43 runs it after Write(): from the files just written
+  // (reprojection_check.cpp:5-101: 6-digit point3d.txt, Camera_Transform.xml, float32 corners)
+  double ReprojectionRmsFromFiles(const std::vector<Intrinsics>& camera_intrinsics, double* error = nullptr) {
+    std::vector<double> k;
+    for (const Intrinsics& i : camera_intrinsics) k.insert(k.end(), i.begin(), i.end());
+    double e = 0, rms = 0;
+    const int rc = rsba_reprojection_check_files(paths_.correspondence.c_str(), paths_.point3d.c_str(), paths_.camera_transform_xml.c_str(),
+                                                 k.data(), &e, &rms);
+    if (rc != RSBA_OK) throw std::runtime_error(std::string("ReprojectionCheck: ") + rsba_error_string(rc));
+    if (error) *error = e;
+    return rms;
+  }
+
   BALProblem bal_problem;
   rsba_options options;
   rsba_summary summary{};

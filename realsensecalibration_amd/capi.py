@@ -22,7 +22,7 @@ EXPORTS = [
     "rsba_problem_point3d_coordinates", "rsba_options_default", "rsba_solve", "rsba_solver_create", "rsba_solver_run",
     "rsba_solver_download", "rsba_solver_iterations", "rsba_solver_kernel_stats", "rsba_solver_final_costs",
     "rsba_solver_destroy", "rsba_points_linearize_and_step", "rsba_comm_unique_id", "rsba_read_intrinsics_xml",
-    "rsba_write_outputs", "rsba_reprojection_error",
+    "rsba_write_outputs", "rsba_reprojection_error", "rsba_reprojection_check_files",
 ]
 
 
@@ -110,6 +110,7 @@ def load():
     lib.rsba_read_intrinsics_xml.argtypes = [C.c_char_p, C.c_void_p]
     lib.rsba_write_outputs.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.rsba_reprojection_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rsba_reprojection_check_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _LIB = lib
     return lib
 
@@ -298,3 +299,13 @@ def read_intrinsics_xml(path):
     out = np.zeros(4)
     _chk(load().rsba_read_intrinsics_xml(path.encode(), _vp(out)), "rsba_read_intrinsics_xml")
     return out
+
+
+def reprojection_check_files(correspondence_txt, point3d_txt, camera_transform_xml, intrinsics):
+    """ReprojectionCheck::Reproject from its files (reprojection_check.cpp:5-101); returns (error, rms)."""
+    intr = np.ascontiguousarray(intrinsics, dtype=np.float64)
+    err, rms = C.c_double(), C.c_double()
+    _chk(load().rsba_reprojection_check_files(str(correspondence_txt).encode(), str(point3d_txt).encode(),
+                                               str(camera_transform_xml).encode(), _vp(intr), C.byref(err), C.byref(rms)),
+         "rsba_reprojection_check_files")
+    return err.value, rms.value

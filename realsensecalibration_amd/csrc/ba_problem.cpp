@@ -14,6 +14,8 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <vector>
+#include <algorithm>
 
 namespace rsba {
 
@@ -127,6 +129,99 @@ int ReadIntrinsicsXml(const char* path, double* out4) {
   double k[9];
   for (int i = 0; i < 9; ++i) if (!tk.NextDouble(&k[i])) return RSBA_ERR_FORMAT;
   out4[0] = k[0]; out4[1] = k[4]; out4[2] = k[2]; out4[3] = k[5];  // bundle_adjustment.h:66-69
+  return RSBA_OK;
+}
+
+// One <name type_id="opencv-matrix"> node of an OpenCV FileStorage XML: rows, cols and the doubles of <data>.
+static int ReadXmlMatrix(const std::string& text, const std::string& name, int* rows, int* cols, std::vector<double>* data) {
+  const size_t a = text.find("<" + name + " ");
+  if (a == std::string::npos) return RSBA_ERR_FORMAT;
+  const size_t end = text.find("</" + name + ">", a);
+  if (end == std::string::npos) return RSBA_ERR_FORMAT;
+  auto field = [&](const char* open, const char* close, std::string* out) {
+    const size_t b = text.find(open, a), e = text.find(close, a);
+    if (b == std::string::npos || e == std::string::npos || e < b || e > end) return false;
+    *out = text.substr(b + strlen(open), e - b - strlen(open));
+    return true;
+  };
+  std::string r, c, d;
+  if (!field("<rows>", "</rows>", &r) || !field("<cols>", "</cols>", &c) || !field("<data>", "</data>", &d)) return RSBA_ERR_FORMAT;
+  *rows = atoi(r.c_str()); *cols = atoi(c.c_str());
+  if (*rows <= 0 || *cols <= 0 || *rows * *cols > 64) return RSBA_ERR_FORMAT;
+  Tokens tk(d);
+  data->resize((size_t)*rows * *cols);
+  for (double& v : *data) if (!tk.NextDouble(&v)) return RSBA_ERR_FORMAT;
+  return RSBA_OK;
+}
+
+// Rotation matrix (row-major) -> angle-axis, the inverse of Rodrigues above (what cv::projectPoints does with the 3x3
+// "rvec" reprojection_check.cpp:65-69 hands it).
+void RotationToAngleAxis(const double R[9], double aa[3]) {
+  const double tr = R[0] + R[4] + R[8];
+  double c = 0.5 * (tr - 1.0);
+  c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+  const double ax = R[7] - R[5], ay = R[2] - R[6], az = R[3] - R[1];   // 2 sin(theta) * axis
+  const double s2 = std::sqrt(ax * ax + ay * ay + az * az);
+  const double theta = std::atan2(0.5 * s2, c);
+  if (s2 < 1e-12) {
+    if (c > 0.0) { aa[0] = 0.5 * ax; aa[1] = 0.5 * ay; aa[2] = 0.5 * az; return; }
+    // theta ~ pi: axis from the diagonal of (R + I) / 2
+    double v[3] = {std::sqrt(std::max(0.0, 0.5 * (R[0] + 1.0))), std::sqrt(std::max(0.0, 0.5 * (R[4] + 1.0))), std::sqrt(std::max(0.0, 0.5 * (R[8] + 1.0)))};
+    if (R[1] + R[3] < 0.0) v[1] = -v[1];
+    if (R[2] + R[6] < 0.0) v[2] = -v[2];
+    for (int k = 0; k < 3; ++k) aa[k] = theta * v[k];
+    return;
+  }
+  const double f = theta / s2;
+  aa[0] = f * ax; aa[1] = f * ay; aa[2] = f * az;
+}
+
+// ReprojectionCheck::Reproject's inputs (reprojection_check.cpp:5-66) as a point-model problem: cameras from
+// Camera_Transform.xml (R{i} 3x3 as Main writes it, or the 3x1 rvec of the Test2 variant, and t{i}), one point per
+// row of point3d.txt (the 6-digit 3D corners, `4N T C` header and T count rows first), one observation per point: the
+// corner of correspondence.txt rounded to float32 as the reference holds it (Point2f), camera from the same row.
+int LoadReprojectionCheck(const char* correspondence_txt, const char* point3d_txt, const char* camera_transform_xml,
+                          const double* intrinsics /* 4 per camera */, rsba_problem** out) {
+  if (!correspondence_txt || !point3d_txt || !camera_transform_xml || !intrinsics || !out) return RSBA_ERR_ARG;
+  rsba_problem* corr = nullptr;
+  // the wiring model does not matter here: only the observation rows are used
+  std::string text;
+  if (!ReadAll(correspondence_txt, &text)) return RSBA_ERR_IO;
+  int64_t T = 0, C = 0, M = 0, N = 0;
+  { Tokens tk(text); if (!tk.NextInt(&T) || !tk.NextInt(&C) || !tk.NextInt(&M) || !tk.NextInt(&N)) return RSBA_ERR_FORMAT; }
+  if (C <= 0 || N <= 0) return RSBA_ERR_FORMAT;
+  int rc = LoadCorrespondence(correspondence_txt, RSBA_MODEL_MARKER_CHAIN, 0.0, intrinsics, &corr);
+  if (rc != RSBA_OK) return rc;
+  std::string p3, xml;
+  if (!ReadAll(point3d_txt, &p3) || !ReadAll(camera_transform_xml, &xml)) { delete corr; return RSBA_ERR_IO; }
+  Tokens tk(p3);
+  int64_t npts = 0, t3 = 0, c3 = 0;
+  if (!tk.NextInt(&npts) || !tk.NextInt(&t3) || !tk.NextInt(&c3) || npts != 4 * N || c3 != C) { delete corr; return RSBA_ERR_FORMAT; }
+  for (int64_t t = 0; t < t3; ++t) for (int64_t k = 0; k <= C; ++k) { int64_t v; if (!tk.NextInt(&v)) { delete corr; return RSBA_ERR_FORMAT; } }
+  rsba_problem* p = new rsba_problem();
+  p->model = RSBA_MODEL_POINTS;
+  p->num_cameras = (int32_t)C; p->num_points = (int32_t)npts; p->num_observations = npts;
+  p->parameters.assign(6 * C + 3 * npts, 0.0);
+  for (int64_t c = 0; c < C; ++c) {
+    int rr, cc; std::vector<double> Rm, tv;
+    if (ReadXmlMatrix(xml, "R" + std::to_string(c), &rr, &cc, &Rm) != RSBA_OK || ReadXmlMatrix(xml, "t" + std::to_string(c), &rr, &cc, &tv) != RSBA_OK ||
+        tv.size() != 3 || (Rm.size() != 9 && Rm.size() != 3)) { delete corr; delete p; return RSBA_ERR_FORMAT; }
+    double aa[3];
+    if (Rm.size() == 9) RotationToAngleAxis(Rm.data(), aa); else { aa[0] = Rm[0]; aa[1] = Rm[1]; aa[2] = Rm[2]; }
+    for (int k = 0; k < 3; ++k) { p->parameters[6 * c + k] = aa[k]; p->parameters[6 * c + 3 + k] = tv[k]; }
+  }
+  for (int64_t j = 0; j < 3 * npts; ++j) if (!tk.NextDouble(&p->parameters[6 * C + j])) { delete corr; delete p; return RSBA_ERR_FORMAT; }
+  p->camera_index.resize(npts); p->point_index.resize(npts); p->observations.resize(2 * npts);
+  for (int64_t i = 0; i < N; ++i)
+    for (int k = 0; k < 4; ++k) {
+      const int64_t j = 4 * i + k;
+      p->camera_index[j] = corr->camera_index[i]; p->point_index[j] = (int32_t)j;
+      p->observations[2 * j] = (double)(float)corr->observations[8 * i + 2 * k];          // Point2f
+      p->observations[2 * j + 1] = (double)(float)corr->observations[8 * i + 2 * k + 1];
+    }
+  p->intrinsics.assign(intrinsics, intrinsics + 4 * C);
+  delete corr;
+  *out = p;
   return RSBA_OK;
 }
 

@@ -44,6 +44,9 @@ int LoadCorrespondence(const char* path, int32_t model, double marker_side, cons
                        rsba_problem** out);
 int ReadIntrinsicsXml(const char* path, double* out4);
 void Rodrigues(const double rvec[3], double R[9]);
+void RotationToAngleAxis(const double R[9], double aa[3]);
+int LoadReprojectionCheck(const char* correspondence_txt, const char* point3d_txt, const char* camera_transform_xml,
+                          const double* intrinsics, rsba_problem** out);
 void AngleAxisRotatePointHost(const double aa[3], const double pt[3], double out[3]);
 void MarkerCorners3d(const rsba_problem& p, double* out /* 12 per observation */);
 int WriteOutputs(const rsba_problem& p, const char* camera_transform_xml, const char* extrinsics_dir,

@@ -1022,4 +1022,14 @@ int rsba_reprojection_error(rsba_problem* p, const rsba_options* o, double* erro
   return rc;
 }
 
+int rsba_reprojection_check_files(const char* correspondence_txt, const char* point3d_txt, const char* camera_transform_xml,
+                                  const double* intrinsics, double* error, double* rms) {
+  rsba_problem* p = nullptr;
+  int rc = rsba::LoadReprojectionCheck(correspondence_txt, point3d_txt, camera_transform_xml, intrinsics, &p);
+  if (rc != RSBA_OK) return rc;
+  rc = rsba_reprojection_error(p, nullptr, error, rms);
+  delete p;
+  return rc;
+}
+
 }  // extern "C"

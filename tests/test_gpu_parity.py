@@ -228,6 +228,9 @@ def test_cpp_bamanager_mirror_end_to_end(tmp_path):
         assert np.abs(np.loadtxt(str(tmp_path / ("mat%d.txt" % i))) - np.loadtxt(os.path.join(G, "extrinsics", "mat%d.txt" % i))).max() < 2e-6
     rms = float(out.stdout.split("Average Reprojection Error per One Coordinate:")[1].split()[0])
     assert abs(rms - 0.726669955) < 1e-6
+    # ... and the reference's own file-driven check on what was just written (6-digit text): 0.726696
+    rms_files = float(out.stdout.split("From the written files:")[1].split()[1])
+    assert abs(rms_files - 0.726696372) < 2e-6
 
 
 def test_rccl_collective_path_single_rank(oracle):
@@ -303,3 +306,32 @@ def test_pipeline_stall_falls_back_to_sequential_schedule(oracle, capfd):
         del os.environ["RSBA_TEST_STALL"]
     assert "falling back" in capfd.readouterr().err
     assert np.array_equal(got, ref) and np.array_equal(log, log_ref) and s.num_iterations == s_ref.num_iterations
+
+
+def test_file_driven_reprojection_check_matches_reference_numbers(oracle):
+    """reprojection_check.cpp:5-101 from the committed files: 6-digit point3d.txt, R/t from Camera_Transform.xml,
+    float32 corners.  The hongo numbers are the ones the oracle's restatement of that text path gives
+    (tests/test_oracle_golden.py::test_hongo_reference_text_path_rms); test2's XML holds rvecs instead of matrices."""
+    intr = ol.read_intrinsics(ol.SERIALS_MAIN)
+    err, rms = capi.reprojection_check_files(os.path.join(G, "hongo", "correspondence.txt"), os.path.join(G, "hongo", "point3d.txt"),
+                                             os.path.join(G, "hongo", "Camera_Transform.xml"), intr)
+    assert abs(err - 143.639831820) < 1e-6 and abs(rms - 0.726696372) < 1e-8
+    intr2 = ol.read_intrinsics(ol.SERIALS_TEST2)
+    err2, rms2 = capi.reprojection_check_files(os.path.join(G, "test2", "correspondence_test.txt"), os.path.join(G, "test2", "point3d.txt"),
+                                               os.path.join(G, "test2", "Camera_Transform.xml"), intr2)
+    # same computation in numpy
+    prob = ol.read_correspondence(os.path.join(G, "test2", "correspondence_test.txt"))
+    xml = ol.read_opencv_xml(os.path.join(G, "test2", "Camera_Transform.xml"))
+    n, counts, pts = ol.read_point3d(os.path.join(G, "test2", "point3d.txt"))
+    ref = 0.0
+    for i in range(prob["N"]):
+        c = prob["c"][i]
+        R = oracle.rodrigues(xml["R%d" % c].ravel())
+        t = xml["t%d" % c].ravel()
+        fx, fy, px, py = intr2[c]
+        for j in range(4):
+            q = R @ pts[4 * i + j] + t
+            u, v = fx * q[0] / q[2] + px, fy * q[1] / q[2] + py
+            ou, ov = np.float32(prob["obs"][8 * i + 2 * j]), np.float32(prob["obs"][8 * i + 2 * j + 1])
+            ref += ((float(ou) - u) ** 2 + (float(ov) - v) ** 2) / 2
+    assert abs(err2 - ref) < 1e-9 * max(ref, 1.0) and abs(rms2 - np.sqrt(ref * 2.0 / (n * 2.0))) < 1e-10
