@@ -604,8 +604,11 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   DebugSync(st, "linearize+schur");
 
   if (s->comm) {
+    // one group: the sum of the packed reduced system and the max of the point-gradient bound go out as one launch
+    NCCLCHK(ncclGroupStart());
     NCCLCHK(ncclAllReduce(s->red, s->red, s->L.size(), ncclDouble, ncclSum, s->comm, st));
     NCCLCHK(ncclAllReduce(s->gmax, s->gmax, 1, ncclDouble, ncclMax, s->comm, st));
+    NCCLCHK(ncclGroupEnd());
   }
 
   if (pipe) {
