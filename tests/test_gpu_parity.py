@@ -335,3 +335,45 @@ def test_file_driven_reprojection_check_matches_reference_numbers(oracle):
             ou, ov = np.float32(prob["obs"][8 * i + 2 * j]), np.float32(prob["obs"][8 * i + 2 * j + 1])
             ref += ((float(ou) - u) ** 2 + (float(ov) - v) ** 2) / 2
     assert abs(err2 - ref) < 1e-9 * max(ref, 1.0) and abs(rms2 - np.sqrt(ref * 2.0 / (n * 2.0))) < 1e-10
+
+
+# ------------------------------------------------------------------ edge cases of the input
+def test_duplicate_observations_and_unobserved_points(oracle):
+    """A camera that observes the same point twice (two residual blocks on the same parameter pair, as Ceres allows)
+    cannot use one visibility bit per (camera, point): the solver must notice and take the atomic kernel, still on
+    the GPU.  Points nobody observes must stay where they are."""
+    prob = syn.make_problem(6, 300, 4, seed=41)
+    rng = np.random.default_rng(1)
+    dup = rng.choice(prob["N"], 40, replace=False)
+    drop_pts = np.array([3, 77, 299])
+    keep = ~np.isin(prob["pt_idx"], drop_pts)
+    cam = np.concatenate([prob["cam_idx"][keep], prob["cam_idx"][dup][~np.isin(prob["pt_idx"][dup], drop_pts)]])
+    pt = np.concatenate([prob["pt_idx"][keep], prob["pt_idx"][dup][~np.isin(prob["pt_idx"][dup], drop_pts)]])
+    obs2 = prob["obs"].reshape(-1, 2)
+    dup_obs = obs2[dup][~np.isin(prob["pt_idx"][dup], drop_pts)] + rng.normal(0, 0.3, (len(cam) - int(keep.sum()), 2))
+    q = dict(prob)
+    q["cam_idx"] = np.ascontiguousarray(cam.astype(np.int32)); q["pt_idx"] = np.ascontiguousarray(pt.astype(np.int32))
+    q["obs"] = np.ascontiguousarray(np.concatenate([obs2[keep], dup_obs]).reshape(-1)); q["N"] = len(cam)
+    got, s, log = _compare_solve(oracle, q, 1)
+    C = q["C"]
+    for j in drop_pts:
+        assert np.array_equal(got[6 * C + 3 * j: 6 * C + 3 * j + 3], q["params"][6 * C + 3 * j: 6 * C + 3 * j + 3])
+
+
+def test_every_camera_sees_every_point_more_than_64_views(oracle):
+    """k = C = 66 views per point: more than one 64-bit word of cameras per point, 5 camera groups, the multi-launch
+    Cholesky (396 x 396)."""
+    prob = syn.make_problem(66, 400, 66, seed=43)
+    assert prob["N"] == 66 * 400
+    _compare_solve(oracle, prob, 1)
+
+
+def test_problem_without_observations(oracle):
+    """No residual blocks: cost 0, gradient 0 — Ceres converges at iteration 0 on the gradient tolerance and leaves
+    the parameters alone."""
+    prob = syn.make_problem(3, 20, 2, seed=44)
+    q = dict(prob)
+    q["cam_idx"] = np.zeros(0, np.int32); q["pt_idx"] = np.zeros(0, np.int32); q["obs"] = np.zeros(0); q["N"] = 0
+    got, s, log = capi.solve_points(q)
+    assert s.termination_type == 0 and s.num_iterations == 0 and s.initial_cost == 0.0 and s.final_cost == 0.0
+    assert np.array_equal(got, q["params"])
