@@ -167,14 +167,13 @@ __device__ __forceinline__ bool DiagFactorInverse(double* __restrict__ Pan, int 
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             if (q < i) {
-              // L[hb + i][hb + q] lives in lane hb + i, register row[hb + q]
-              const double la = ReadLaneD(row[q], i), lb = ReadLaneD(row[16 + q], 16 + i);
-              const double lv = hb ? lb : la;
+              // L[hb + i][hb + q] from the tile just written: an LDS read with two distinct addresses per wave (one per
+              // block) instead of two v_readlane pairs and a select; the reads of a step are independent of the chain
+              const double lv = Lt[(hb + i) * RSBA_PLD + hb + q];
               if (q & 1) sacc2 -= lv * t[q]; else sacc -= lv * t[q];
             }
           }
-          const double ia_ = ReadLaneD(ilv, i), ib_ = ReadLaneD(ilv, 16 + i);
-          t[i] = (sacc + sacc2) * (hb ? ib_ : ia_);
+          t[i] = (sacc + sacc2) * invd[hb + i];
           asm volatile("" : "+v"(t[i]));
         }
         // diagonal blocks into the T tile; M1 scratch = T[0..15][16..31]
