@@ -683,7 +683,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
 // Reducer workgroup `part` of tile sg.tile (see GroupReduce): components [word_begin, word_end) of the tile sums; the
 // last reducer finishes the tile, the last tile of a stage publishes it for the Cholesky that may be waiting for these
 // columns.  The self tile of the last group also folds the point pass' per-block scalars (cost, |X|^2, failures, max|g_p|).
-__device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSeg& sg) {
+__device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSeg& sg, int ticket) {
   __shared__ int s_flag;
   const int tid = threadIdx.x;
   int* cnt_groups = a.sync_cnt + a.ngrp + sg.tile;
@@ -699,6 +699,7 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
   }
   __syncthreads();
   if (!s_flag) { if (tid == 0) __hip_atomic_store(a.tree_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();   // the tile's groups are complete
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   const int c0 = sg.word_begin, c1 = sg.word_end;
   double* ts = a.tile_sum + (size_t)sg.tile * RSBA_PART * 256 + tid;
@@ -779,7 +780,7 @@ k_schur_tiles(SchurArgs a) {
   const SchurSeg sg = a.segs[seg_index];
   if (a.trace && b == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
   if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b] = wall_clock64();
-  if (sg.self >= 2) ReducerSegment(a, sg);
+  if (sg.self >= 2) ReducerSegment(a, sg, b);
   else if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, b, pt, mk);
   else PairSegment<kLoss>(a, sg, seg_index, b, pt, mk, sc);
   if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b + 1] = wall_clock64();
