@@ -79,7 +79,7 @@ struct StageGate {
 // Spin (one lane, sleeping between polls) until *flag == tag; false when the producer does not show up in
 // RSBA_STALL_TICKS of the 100 MHz wall clock — the caller gives up instead of hanging the queue.
 #ifndef RSBA_STALL_TICKS
-#define RSBA_STALL_TICKS 5000000LL
+#define RSBA_STALL_TICKS 50000000LL
 #endif
 __device__ __forceinline__ bool WaitReady(const int* flag, int tag, long long* waited_ticks) {
   __shared__ int s_wait_ok;

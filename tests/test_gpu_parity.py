@@ -294,7 +294,7 @@ def test_pipelined_solve_matches_oracle_and_sequential_schedule(oracle, C, P, k,
 
 
 def test_pipeline_stall_falls_back_to_sequential_schedule(oracle, capfd):
-    """RSBA_TEST_STALL=1 makes the waiting Cholesky look for a tag nobody publishes: it must give up after its 50 ms
+    """RSBA_TEST_STALL=1 makes the waiting Cholesky look for a tag nobody publishes: it must give up after its 0.5 s
     budget (never hang the queue), the step must be repeated with the sequential schedule, and the result must not
     change."""
     prob = syn.make_problem(24, 1500, 7, seed=77)
