@@ -275,12 +275,11 @@ __device__ __forceinline__ double* BackSubstituteBlocks(int n, double* __restric
 
 // A: (n+2) x n row-major in global memory; rows 0..n-1 the SPD matrix (lower triangle read), row n the rhs,
 // row n+1 scratch (inverse pivots).  On return the lower triangle holds L, row n holds y = L^-1 rhs, x_out x.
-// Only the panels kb_begin <= kb < kb_end are factored, and the back-substitution runs only when `solve` is set: the
-// pipelined solver calls this once per camera group, as soon as that group's columns of the matrix exist, while the
-// rest of the chip is still eliminating points for the later groups.  All state between calls lives in A.
-// With a gate the panels wait for their camera group's columns; a stalled wait returns with *ok_out = -1.
+// With a gate (pipelined solver: the kernel is launched before the matrix exists) the first panel of every camera
+// group waits until that group's columns have been published by the Schur kernel, which is still eliminating points
+// for the later groups on the rest of the chip; a stalled wait returns with *ok_out = -1.
 __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __restrict__ x_out, int* ok_out, double* lds, PanelSource src,
-                                      int kb_begin, int kb_end, bool solve, StageGate gate = StageGate{nullptr, 0, 0, nullptr, nullptr}) {
+                                      StageGate gate = StageGate{nullptr, 0, 0, nullptr, nullptr}) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
   double* T = lds + (size_t)(n + 2) * RSBA_PLD;        // 32 x 33: T = L11^-1
   double* Lt = T + RSBA_PB * RSBA_PLD;                 // 32 x 33: padded L11
@@ -296,7 +295,7 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
   __syncthreads();
   RSBA_STAMP_INIT;
 
-  for (int kb = kb_begin; kb < kb_end; kb += RSBA_PB) {
+  for (int kb = 0; kb < n; kb += RSBA_PB) {
     if (gate.ready != nullptr && kb % gate.cols == 0) {
       if (gate.trace && tid == 0) gate.trace[2 + 2 * (kb / gate.cols)] = wall_clock64();
       if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, gate.waited)) { if (tid == 0) *ok_out = -1; __syncthreads(); return; }
@@ -587,11 +586,9 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     RSBA_STAMP(4);
   }
 
-  if (solve) {
-    double* y = BackSubstituteBlocks(n, A, lds);
-    for (int i = tid; i < n; i += nt) x_out[i] = y[i];
-    __syncthreads();
-  }
+  double* y = BackSubstituteBlocks(n, A, lds);
+  for (int i = tid; i < n; i += nt) x_out[i] = y[i];
+  __syncthreads();
   RSBA_STAMP(5);
   if (tid == 0) *ok_out = s_ok;
   __syncthreads();

@@ -463,15 +463,13 @@ __device__ void CholeskySolveBlocked(int n, double* __restrict__ A, double* __re
   if (tid == 0) *ok_out = s_ok;
 }
 
-#define RSBA_STAGE_FIRST 1   // builds the scale, the rhs row (and the matrix when it is not fused into the panel loads)
-#define RSBA_STAGE_LAST 2    // back-substitution + camera step
 __global__ void __launch_bounds__(512)
 k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __restrict__ A /* (nc+2) x nc */,
                        double* __restrict__ S_copy /* may be null */, double* __restrict__ rhs_copy,
                        double* __restrict__ scale_c, const double* __restrict__ cam_x, double* __restrict__ cam_c,
                        const double* __restrict__ intr, double* __restrict__ camc_c, double* __restrict__ dcam,
                        const double* __restrict__ gmax_p, double* __restrict__ res, IterParams ip, int sym_full,
-                       int kb_begin, int kb_end, int stage_flags, int* __restrict__ chol_ok, StageGate gate) {
+                       int* __restrict__ chol_ok, StageGate gate) {
   extern __shared__ double lds[];
   const int n = L.nc, tid = threadIdx.x, nt = blockDim.x;
   __shared__ int s_ok;
@@ -492,7 +490,7 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
     }
     if (gate.trace && tid == 0) gate.trace[1] = wall_clock64();
   }
-  if (stage_flags & RSBA_STAGE_FIRST) {
+  {
     // 1. camera Jacobi scale
     for (int i = tid; i < n; i += nt) {
       if (ip.first) scale_c[i] = ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(red[L.diagU() + i])) : 1.0;
@@ -535,14 +533,13 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
 #ifdef RSBA_PROFILE_PHASES
   if (tid == 0) g_phase_cycles[8] += clock64() - _k0;
 #endif
-  // 3-4. factor (this stage's panels) + solve; y = solution of the scaled system, reused from row n of A
+  // 3-4. factor + solve; y = solution of the scaled system, reused from row n of A
   double* ysol = A + (size_t)n * n;
-  const bool last = (stage_flags & RSBA_STAGE_LAST) != 0;
   CholeskySolvePanelLDS(n, A, ysol, &s_ok, lds,
                         fused ? PanelSource{red + L.S(), scale_c, red + L.diagU(), ip.min_lm_diagonal, ip.max_lm_diagonal, 1.0 / ip.radius,
                                             gated ? red + L.gc() : nullptr, gated ? red + L.corr() : nullptr}
                               : PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr, nullptr},
-                        kb_begin, kb_end, last, gate);
+                        gate);
   __syncthreads();
   if (s_ok < 0) { if (tid == 0) res[RES_STALL] = 1.0; return; }
   int ok = 1;
@@ -555,7 +552,7 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
   if (tid == 0) { g_phase_cycles[9] += clock64() - _k0; }
 #endif
   // 5. camera step, candidate cameras, norms, gradient max over the camera part
-  if (last) CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, ok, lds);
+  CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, ok, lds);
   if (gate.trace && tid == 0) gate.trace[15] = wall_clock64();
 }
 

@@ -607,7 +607,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (s->trace) s->host_t[1] = std::chrono::steady_clock::now();
     T.Begin("k_reduced_system_solve", s->sB);
     k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
-                                                     s->camc[c], s->dcam, s->gmax, s->res, ip, 1, 0, n, RSBA_STAGE_FIRST | RSBA_STAGE_LAST,
+                                                     s->camc[c], s->dcam, s->gmax, s->res, ip, 1,
                                                      s->chol_ok, StageGate{ts.ready, s->test_stall ? tag + 1 : tag, 6 * RSBA_TG, T.enabled() ? s->chol_waited : nullptr, s->trace});
     T.End(s->sB);
     HIPCHK(hipEventRecord(s->ev_chol, s->sB));
@@ -632,8 +632,8 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     T.Begin("k_reduced_system_solve", st);
     k_reduced_system_solve<<<1, 512, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
                                                   keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
-                                                  s->camc[c], s->dcam, s->gmax, s->res, ip, s->opt.schur_impl != 0 ? 1 : 0, 0, s->nc,
-                                                  RSBA_STAGE_FIRST | RSBA_STAGE_LAST, s->chol_ok, StageGate{nullptr, 0, 0, nullptr, nullptr});
+                                                  s->camc[c], s->dcam, s->gmax, s->res, ip, s->opt.schur_impl != 0 ? 1 : 0,
+                                                  s->chol_ok, StageGate{nullptr, 0, 0, nullptr, nullptr});
     T.End(st);
   } else {
     // more than 64 cameras: right-looking factorisation over the whole chip, one launch per 32-wide panel
