@@ -223,7 +223,7 @@ def main():
         out["kernels"] = {n: {"launches": int(c), "avg_us": 1e3 * a, "measured": "timed region" if n in stats_timed else "repeat pass"}
                           for n, (c, a) in sorted(per.items())}
         out["kernel_timing"] = ("HIP events on the launching stream; in the timed region only k_schur_tiles and k_reduced_system_solve are "
-                                "recorded, on every other LM step (recording every step costs ~40 us of host time per step between "
+                                "recorded, on every fourth LM step (recording every step costs ~40 us of host time per step between "
                                 "two launches); the other kernels come from an identical repeat pass with every launch recorded")
         for n, (c, ms) in waiting.items():
             out["kernels"][n]["avg_span_us"] = 1e3 * spans[n][1] / max(spans[n][0], 1)

@@ -60,12 +60,12 @@ int DeviceCount() {
 // ------------------------------------------------------------------------------------------------
 class KernelTimer {
  public:
-  // mode 0: off, 1: every kernel, 2: only the two kernels the roofline is quoted on, and only every other LM step (the
+  // mode 0: off, 1: every kernel, 2: only the two kernels the roofline is quoted on, and only every fourth LM step (the
   // host-side cost of the event records sits on the critical path between two launches: ~40 us per step when every
   // step was recorded, 5% of the step).  Events come from a pool: creating one per record costs more than recording it.
   void Enable(int mode) { mode_ = mode; on_ = false; }
   bool enabled() const { return mode_ != 0 && sampled_; }
-  void NextStep() { ++step_; sampled_ = mode_ == 1 || (mode_ == 2 && (step_ & 1) == 0); }
+  void NextStep() { ++step_; sampled_ = mode_ == 1 || (mode_ == 2 && (step_ & 3) == 0); }
   static bool Major(const char* n) { return strcmp(n, "k_schur_tiles") == 0 || strcmp(n, "k_reduced_system_solve") == 0 || strcmp(n, "k_linearize_schur_ref") == 0; }
   void Begin(const char* name, hipStream_t s) {
     on_ = sampled_ && (mode_ == 1 || (mode_ == 2 && Major(name)));
