@@ -571,12 +571,16 @@ struct ObsSliced {
 // records.  delta_p = -Vinv (g_p + sum Jp' Jc delta_c); model-cost-change terms accumulate in the same
 // loop; then the cost of the candidate (cameras' constants at x + delta already in camc_c).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void FinishCandidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
+                                                double* __restrict__ res, double* host, double seq);
+
 template <bool kStage>
 __global__ void __launch_bounds__(256)
 k_backsub_candidate(int C, int P, ObsSliced obs,
                     const double* __restrict__ camc_xg, const double* __restrict__ camc_cg,
                     const double* __restrict__ dcam_g, const double* __restrict__ pts_x, double* __restrict__ pts_c,
-                    const double* __restrict__ scale_p, double* __restrict__ block_part /* gridDim.x x 8 */, IterParams ip) {
+                    const double* __restrict__ scale_p, double* __restrict__ block_part /* gridDim.x x 8 */, IterParams ip,
+                    int* __restrict__ done_cnt, double* __restrict__ small_red, double* __restrict__ res, double* host, double seq) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   // camera constants at x and at the candidate, and the camera step: 70 doubles per camera, LDS-resident when they fit
@@ -661,27 +665,48 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
     }
     __syncthreads();
   }
-  if (tid < 5) block_part[8 * blockIdx.x + tid] = s[tid][0];
+  // (agent-scope store: the last workgroup may sit on another XCD, and a full fence per workgroup costs an L2 write-back)
+  if (tid < 5) __hip_atomic_store(&block_part[8 * blockIdx.x + tid], s[tid][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // Single GPU (done_cnt != nullptr): the last workgroup to arrive adds the per-block partials (in block order, so the
+  // sums do not depend on who is last) and posts the result: no second launch.  With RCCL the sums have to be
+  // all-reduced first, and k_finish_candidate / k_publish_result do it.
+  if (done_cnt != nullptr) {
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+      s_last = __hip_atomic_fetch_add(done_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+      if (s_last) __hip_atomic_store(done_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      FinishCandidate((int)gridDim.x, block_part, small_red, res, host, seq);
+    }
+  }
 }
 
 // Second stage: fixed-order sum of the per-block partials into the small reduction payload
 // small[0..4] = {mcc, cost_c (sum rho), |dp|^2, |Xc|^2, sum sq residuals}
 __device__ __forceinline__ void PublishResult(const double* __restrict__ small_red, double* __restrict__ res);
 __device__ __forceinline__ void PostToHost(const double* __restrict__ res, double* host, double seq);
-// res != nullptr (single GPU): publish straight away, no separate launch
-__global__ void k_finish_candidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red, double* __restrict__ res,
-                                   double* host, double seq) {
+// One workgroup: small_red[0..4] = fixed-order sums of the per-block partials; with res != nullptr (single GPU) the
+// result block is completed and posted to the host straight away.
+__device__ __forceinline__ void FinishCandidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
+                                                double* __restrict__ res, double* host, double seq) {
   __shared__ double s[5][256];
   const int tid = threadIdx.x;
   double v[5] = {0, 0, 0, 0, 0};
-  for (int i = tid; i < nblocks; i += blockDim.x) {
+  if (tid < 256) {
+    for (int i = tid; i < nblocks; i += 256) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) v[q] += block_part[8 * i + q];
+      for (int q = 0; q < 5; ++q) v[q] += block_part[8 * i + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) s[q][tid] = v[q];
   }
-#pragma unroll
-  for (int q = 0; q < 5; ++q) s[q][tid] = v[q];
   __syncthreads();
-  for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+  for (int off = 128; off > 0; off >>= 1) {
     if (tid < off) {
 #pragma unroll
       for (int q = 0; q < 5; ++q) s[q][tid] += s[q][tid + off];
@@ -691,8 +716,15 @@ __global__ void k_finish_candidate(int nblocks, const double* __restrict__ block
   if (tid < 5) small_red[tid] = s[tid][0];
   if (res != nullptr) {
     __syncthreads();
-    if (tid == 0) { double sr[5]; for (int q = 0; q < 5; ++q) sr[q] = s[q][0]; PublishResult(sr, res); PostToHost(res, host, seq); }
+    if (tid == 0) { double sr[5]; for (int q = 0; q < 5; ++q) sr[q] = s[q][0]; PublishResult(sr, res); }
+    __syncthreads();
+    PostToHost(res, host, seq);
   }
+}
+__global__ void __launch_bounds__(256)
+k_finish_candidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red, double* __restrict__ res,
+                   double* host, double seq) {
+  FinishCandidate(nblocks, block_part, small_red, res, host, seq);
 }
 
 // Folds the (all-reduced) point-side sums into the result block the host reads.
@@ -706,14 +738,23 @@ __device__ __forceinline__ void PublishResult(const double* __restrict__ small_r
   res[RES_SUMSQ_C] = small_red[4];
 }
 // The step's result block goes straight into the host's pinned, coherent buffer, sequence number last: the host polls
-// that word instead of paying for a copy kernel and a stream synchronisation per LM iteration.  One thread.
+// that word instead of paying for a copy kernel and a stream synchronisation per LM iteration.  Called by a whole
+// wavefront or workgroup: fifteen lanes write one value each (serially they cost ~5 us of PCIe round trips), lane 0 the
+// sequence number after them.
 __device__ __forceinline__ void PostToHost(const double* __restrict__ res, double* host, double seq) {
   if (host == nullptr) return;
-  for (int i = 0; i < RES_SIZE - 1; ++i) __hip_atomic_store(&host[i], res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(&host[RES_SIZE - 1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    if (tid < RES_SIZE - 1) __hip_atomic_store(&host[tid], res[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: the values before the sequence number
+    if (tid == 0) __hip_atomic_store(&host[RES_SIZE - 1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 __global__ void k_publish_result(const double* __restrict__ small_red, double* __restrict__ res, double* host, double seq) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { PublishResult(small_red, res); PostToHost(res, host, seq); }
+  if (blockIdx.x != 0) return;
+  if (threadIdx.x == 0) PublishResult(small_red, res);
+  __syncthreads();
+  PostToHost(res, host, seq);
 }
 
 // Cost only at the current point-model parameters (used by rsba_reprojection_error).

@@ -458,10 +458,11 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->pts[0], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts[1], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts0, 3 * (size_t)P)) ||
       (rc = DevAlloc(&s->camc[0], CC_STRIDE * C)) || (rc = DevAlloc(&s->camc[1], CC_STRIDE * C)) || (rc = DevAlloc(&s->scale_c, 6 * C)) ||
       (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(s->nc + 2) * s->nc)) || (rc = DevAlloc(&s->W, s->nc > RSBA_CHOL_MAXN ? (size_t)(s->nc + 1) * s->nc : 1)) ||
-      (rc = DevAlloc(&s->chol_ok, 1)) ||
+      (rc = DevAlloc(&s->chol_ok, 2)) ||
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
       (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)))
     return rc;
+  HIPCHK(hipMemset(s->chol_ok, 0, 2 * sizeof(int)));   // [0] Cholesky status, [1] arrival counter of the back-substitution's blocks
   HIPCHK(hipMemcpy(s->obs_u, u.data(), N * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->obs_v, v.data(), N * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->obs_cam, cam.data(), N * sizeof(int), hipMemcpyHostToDevice));
@@ -658,20 +659,24 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   }
   DebugSync(st, "k_reduced_system_solve");
   T.Begin("k_backsub_candidate", st);
+  // single GPU: the kernel's last workgroup finishes the step (sums, result block, post to the host)
+  int* fin_cnt = s->comm ? nullptr : s->chol_ok + 1;
   {
     const size_t lds_b = (size_t)C * (2 * RSBA_CC_LDS + 6) * sizeof(double);
     if (lds_b <= 60 * 1024)
       k_backsub_candidate<true><<<s->grid_pts, 256, lds_b, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
-                                                                 s->pts[c], s->scale_p, s->block_part, ip);
+                                                                 s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0);
     else
       k_backsub_candidate<false><<<s->grid_pts, 256, 0, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
-                                                              s->pts[c], s->scale_p, s->block_part, ip);
+                                                              s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0);
   }
   T.End(st);
   DebugSync(st, "k_backsub_candidate");
-  T.Begin("k_finish_candidate", st);
-  k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, s->comm ? nullptr : s->res, s->res_host, s->res_seq + 1.0);
-  T.End(st);
+  if (s->comm) {
+    T.Begin("k_finish_candidate", st);
+    k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, nullptr, nullptr, 0.0);
+    T.End(st);
+  }
   if (s->comm) {
     NCCLCHK(ncclAllReduce(s->small_red, s->small_red, 8, ncclDouble, ncclSum, s->comm, st));
     k_publish_result<<<1, 64, 0, st>>>(s->small_red, s->res, s->res_host, s->res_seq + 1.0);
