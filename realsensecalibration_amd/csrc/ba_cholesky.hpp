@@ -72,6 +72,8 @@ struct PanelSource {
 struct StageGate {
   const int* ready;
   int tag, cols;
+  int* done;          // = tag when the kernel has finished (or given up): the back-substitution, launched behind the Schur
+                      // kernel on the main stream, waits for it inside the kernel instead of behind a cross-stream event
   long long* waited;  // += ticks (100 MHz) spent waiting, by thread 0: the kernel's duration minus this is its own work
   long long* trace;   // diagnostic (RSBA_TRACE=1): wall-clock stamps of the waits, nullptr otherwise
 };
@@ -86,8 +88,10 @@ __device__ __forceinline__ bool WaitReady(const int* flag, int tag, long long* w
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();
     int ok = 1;
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) {
-      __builtin_amdgcn_s_sleep(8);
+    // relaxed polls: an acquire load invalidates this XCD's L2 every time (measured: 391 workgroups polling with acquire
+    // doubled the duration of a latency-bound kernel next to them); the fence below acquires once
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+      __builtin_amdgcn_s_sleep(16);
       if (wall_clock64() - t0 > RSBA_STALL_TICKS) { ok = 0; break; }
     }
     s_wait_ok = ok;
@@ -279,7 +283,7 @@ __device__ __forceinline__ double* BackSubstituteBlocks(int n, double* __restric
 // group waits until that group's columns have been published by the Schur kernel, which is still eliminating points
 // for the later groups on the rest of the chip; a stalled wait returns with *ok_out = -1.
 __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __restrict__ x_out, int* ok_out, double* lds, PanelSource src,
-                                      StageGate gate = StageGate{nullptr, 0, 0, nullptr, nullptr}) {
+                                      StageGate gate = StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr}) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
   double* T = lds + (size_t)(n + 2) * RSBA_PLD;        // 32 x 33: T = L11^-1
   double* Lt = T + RSBA_PB * RSBA_PLD;                 // 32 x 33: padded L11

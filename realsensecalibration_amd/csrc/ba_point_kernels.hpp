@@ -463,6 +463,15 @@ __device__ void CholeskySolveBlocked(int n, double* __restrict__ A, double* __re
   if (tid == 0) *ok_out = s_ok;
 }
 
+// Whole workgroup: everything the kernel wrote (camera step, candidate cameras and their constants, res[]) is made
+// visible, then gate.done = tag releases the back-substitution that is waiting for it (pipelined schedule).
+__device__ __forceinline__ void SolveDone(const StageGate& gate) {
+  if (gate.done == nullptr) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(gate.done, gate.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void __launch_bounds__(512)
 k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __restrict__ A /* (nc+2) x nc */,
                        double* __restrict__ S_copy /* may be null */, double* __restrict__ rhs_copy,
@@ -486,7 +495,7 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
     if (gate.trace && tid == 0) gate.trace[0] = wall_clock64();
     if (ip.first) {
       for (int g = 0; g * gate.cols < n; ++g)
-        if (!WaitReady(gate.ready + 1 + g, gate.tag, gate.waited)) { if (tid == 0) res[RES_STALL] = 1.0; return; }
+        if (!WaitReady(gate.ready + 1 + g, gate.tag, gate.waited)) { if (tid == 0) res[RES_STALL] = 1.0; SolveDone(gate); return; }
     }
     if (gate.trace && tid == 0) gate.trace[1] = wall_clock64();
   }
@@ -541,7 +550,7 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
                               : PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr, nullptr},
                         gate);
   __syncthreads();
-  if (s_ok < 0) { if (tid == 0) res[RES_STALL] = 1.0; return; }
+  if (s_ok < 0) { if (tid == 0) res[RES_STALL] = 1.0; SolveDone(gate); return; }
   int ok = 1;
   if (tid == 0) {
     res[RES_STALL] = 0.0;
@@ -554,6 +563,7 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
   // 5. camera step, candidate cameras, norms, gradient max over the camera part
   CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, ok, lds);
   if (gate.trace && tid == 0) gate.trace[15] = wall_clock64();
+  SolveDone(gate);
 }
 
 // Observations as the point-centric kernels walk them: sliced ELL.  A slice is 64 consecutive points (one wavefront);
@@ -580,21 +590,42 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
                     const double* __restrict__ camc_xg, const double* __restrict__ camc_cg,
                     const double* __restrict__ dcam_g, const double* __restrict__ pts_x, double* __restrict__ pts_c,
                     const double* __restrict__ scale_p, double* __restrict__ block_part /* gridDim.x x 8 */, IterParams ip,
-                    int* __restrict__ done_cnt, double* __restrict__ small_red, double* __restrict__ res, double* host, double seq) {
+                    int* __restrict__ done_cnt, double* __restrict__ small_red, double* __restrict__ res, double* host, double seq,
+                    const int* __restrict__ solve_done, int solve_tag, long long* __restrict__ waited) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   // camera constants at x and at the candidate, and the camera step: 70 doubles per camera, LDS-resident when they fit
   const double* camc_x = camc_xg;
   const double* camc_c = camc_cg;
   const double* dcam = dcam_g;
+  // Pipelined schedule: the kernel is launched behind the Schur kernel, while the Cholesky is still running on its own
+  // CU and stream; the chip is idle by then, so the workgroups just sit here (camera constants at x already staged) until
+  // the solve publishes its tag — no cross-stream event, no launch latency after the solve.  0.5 s budget: never hang.
+  auto wait_solve = [&]() {
+    if (solve_done == nullptr) return;
+    if (tid == 0) {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(solve_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != solve_tag) {
+        __builtin_amdgcn_s_sleep(127);
+        if (wall_clock64() - t0 > RSBA_STALL_TICKS) break;
+      }
+      if (waited != nullptr && blockIdx.x == 0) *waited += wall_clock64() - t0;   // the kernel's span minus this is its own work
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  };
   if (kStage) {
     double* lx = lds;
     double* lc = lds + (size_t)C * RSBA_CC_LDS;
     double* ld = lc + (size_t)C * RSBA_CC_LDS;
-    for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; lx[c * RSBA_CC_LDS + e] = camc_xg[i]; lc[c * RSBA_CC_LDS + e] = camc_cg[i]; }
+    for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; lx[c * RSBA_CC_LDS + e] = camc_xg[i]; }
+    wait_solve();
+    for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; lc[c * RSBA_CC_LDS + e] = camc_cg[i]; }
     for (int i = tid; i < 6 * C; i += blockDim.x) ld[i] = dcam_g[i];
     __syncthreads();
     camc_x = lx; camc_c = lc; dcam = ld;
+  } else {
+    wait_solve();
   }
   double mcc = 0, cost_c = 0, dp2 = 0, xc2 = 0, ss_c = 0;
   for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {

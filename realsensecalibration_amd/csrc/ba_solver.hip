@@ -126,7 +126,7 @@ struct rsba_solver {
   hipStream_t sB = nullptr;
   hipEvent_t ev_chol = nullptr;
   long long* chol_waited = nullptr;   // device: ticks the pipelined Cholesky spent waiting for its columns (cumulative)
-  long long chol_waited_seen = 0;
+  long long chol_waited_seen = 0, backsub_waited_seen = 0;   // [1]: the back-substitution's wait for the solve
   long long* trace = nullptr;   // RSBA_TRACE=1: 32 wall-clock stamps of the pipelined step
   std::chrono::steady_clock::time_point host_t[4];
   long long* wg_trace = nullptr;  // RSBA_TRACE=2: per-block stamps of the Schur kernel, dumped to RSBA_TRACE_FILE
@@ -410,7 +410,7 @@ static bool SetupPipeline(rsba_solver* s) {
   if (mode != 2) mask[0] = 1u;
   bool ok = hipExtStreamCreateWithCUMask(&s->sB, words, mask.data()) == hipSuccess &&
             hipEventCreateWithFlags(&s->ev_chol, hipEventDisableTiming) == hipSuccess &&
-            hipMalloc((void**)&s->chol_waited, sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, sizeof(long long)) == hipSuccess;
+            hipMalloc((void**)&s->chol_waited, 2 * sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, 2 * sizeof(long long)) == hipSuccess;
   if (!ok) { (void)hipGetLastError(); if (getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: CU-masked stream unavailable, solve not pipelined\n"); }
   return ok;
 }
@@ -609,11 +609,9 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     T.Begin("k_reduced_system_solve", s->sB);
     k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                      s->camc[c], s->dcam, s->gmax, s->res, ip, 1,
-                                                     s->chol_ok, StageGate{ts.ready, s->test_stall ? tag + 1 : tag, 6 * RSBA_TG, T.enabled() ? s->chol_waited : nullptr, s->trace});
+                                                     s->chol_ok, StageGate{ts.ready, s->test_stall ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15, T.enabled() ? s->chol_waited : nullptr, s->trace});
     T.End(s->sB);
-    HIPCHK(hipEventRecord(s->ev_chol, s->sB));
     ts.LaunchTiles(s, ip, T, st, tag);
-    HIPCHK(hipStreamWaitEvent(st, s->ev_chol, 0));
   }
   HIPCHK(hipGetLastError());
   DebugSync(st, "linearize+schur");
@@ -634,7 +632,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     k_reduced_system_solve<<<1, 512, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
                                                   keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                   s->camc[c], s->dcam, s->gmax, s->res, ip, s->opt.schur_impl != 0 ? 1 : 0,
-                                                  s->chol_ok, StageGate{nullptr, 0, 0, nullptr, nullptr});
+                                                  s->chol_ok, StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr});
     T.End(st);
   } else {
     // more than 64 cameras: right-looking factorisation over the whole chip, one launch per 32-wide panel
@@ -665,10 +663,12 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const size_t lds_b = (size_t)C * (2 * RSBA_CC_LDS + 6) * sizeof(double);
     if (lds_b <= 60 * 1024)
       k_backsub_candidate<true><<<s->grid_pts, 256, lds_b, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
-                                                                 s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0);
+                                                                 s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0,
+        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + 1 : s->step_tag, pipe && T.enabled() ? s->chol_waited + 1 : nullptr);
     else
       k_backsub_candidate<false><<<s->grid_pts, 256, 0, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
-                                                              s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0);
+                                                              s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0,
+        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + 1 : s->step_tag, pipe && T.enabled() ? s->chol_waited + 1 : nullptr);
   }
   T.End(st);
   DebugSync(st, "k_backsub_candidate");
@@ -707,10 +707,11 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   }
   if (pipe && T.enabled()) {
     // the Cholesky's event span includes the time it slept on the ready flags: record that separately
-    long long w = 0;
-    HIPCHK(hipMemcpy(&w, s->chol_waited, sizeof(w), hipMemcpyDeviceToHost));
-    T.Add("k_reduced_system_solve:waiting", (w - s->chol_waited_seen) * 1e-5);
-    s->chol_waited_seen = w;
+    long long w[2] = {0, 0};
+    HIPCHK(hipMemcpy(w, s->chol_waited, sizeof(w), hipMemcpyDeviceToHost));
+    T.Add("k_reduced_system_solve:waiting", (w[0] - s->chol_waited_seen) * 1e-5);
+    T.Add("k_backsub_candidate:waiting", (w[1] - s->backsub_waited_seen) * 1e-5);
+    s->chol_waited_seen = w[0]; s->backsub_waited_seen = w[1];
   }
   if (s->trace && s->opt.schur_impl != 0) {
     long long h[32];
