@@ -56,6 +56,8 @@ enum {
   RSBA_STOP_INITIAL_FAILURE = 7
 };
 
+enum rsba_loss { RSBA_LOSS_HUBER = 0, RSBA_LOSS_CAUCHY = 1 };
+
 typedef struct rsba_problem rsba_problem; /* BALProblem (bundle_adjustment.h:18-54) */
 typedef struct rsba_solver rsba_solver;   /* device-resident state of one ceres::Solve call */
 
@@ -75,7 +77,7 @@ typedef struct rsba_options {
   double function_tolerance;                 /* 1e-6 */
   double gradient_tolerance;                 /* 1e-10 */
   double parameter_tolerance;                /* 1e-8 */
-  double huber_delta;                        /* 0 = no loss (the reference passes NULL, :38) */
+  double huber_delta;                        /* the loss function's parameter a; 0 = no loss (the reference passes NULL, :38) */
   /* --- implementation knobs --- */
   int32_t device;          /* HIP device ordinal, -1 = current                                  */
   int32_t schur_impl;      /* 0 = reference kernel (global atomics), 1 = tiled (default)         */
@@ -85,7 +87,9 @@ typedef struct rsba_options {
   int32_t world_size;      /* 1 = single GPU.  >1: the problem handed in is this rank's point   */
                            /* shard (all cameras, its own points); the reduced camera system is */
                            /* all-reduced over RCCL each iteration                               */
-  int32_t reserved0;
+  int32_t loss_type;       /* with huber_delta = a > 0: RSBA_LOSS_HUBER (0) = ceres::HuberLoss(a),       */
+                           /* RSBA_LOSS_CAUCHY (1) = ceres::CauchyLoss(a); both have rho'' <= 0, so the  */
+                           /* corrector scales residual and Jacobians by sqrt(rho') (corrector.cc)      */
   const void* comm_unique_id; /* world_size > 1: the 128-byte id from rsba_comm_unique_id (rank 0's) */
   void* stream;               /* hipStream_t to run on, NULL = a private stream                    */
 } rsba_options;

@@ -176,7 +176,7 @@ struct Options {
   double gradient_tolerance = 1e-10;
   double parameter_tolerance = 1e-8;
   int jacobi_scaling = 1;
-  double huber_delta = 0.0;  // 0: no loss (the reference passes NULL everywhere)
+  double huber_delta = 0.0;  // 0: no loss (the reference passes NULL everywhere); > 0: HuberLoss(a); < 0: CauchyLoss(-a)
   int num_threads = 1;
 };
 
@@ -211,6 +211,14 @@ inline void HuberEvaluate(double a, double s, double rho[3]) {
     rho[1] = std::max(std::numeric_limits<double>::min(), a / r);
     rho[2] = -rho[1] / (2.0 * s);
   } else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+}
+
+// ceres/loss_function.cc CauchyLoss(a): b = a^2, c = 1 / b.
+inline void CauchyEvaluate(double a, double s, double rho[3]) {
+  const double b = a * a, c = 1.0 / b, sum = s * c + 1.0, inv = 1.0 / sum;
+  rho[0] = b * std::log(sum);
+  rho[1] = std::max(std::numeric_limits<double>::min(), inv);
+  rho[2] = -c * (inv * inv);
 }
 
 // Dense symmetric positive definite solve (Eigen LLT in the reference build): in-place lower Cholesky.
@@ -543,9 +551,10 @@ class PointSchurModel {
       const double s = res[0] * res[0] + res[1] * res[1];
       double rho[3] = {s, 1.0, 0.0};
       if (opt_.huber_delta > 0) HuberEvaluate(opt_.huber_delta, s, rho);
+      else if (opt_.huber_delta < 0) CauchyEvaluate(-opt_.huber_delta, s, rho);
       total += rho[0];
       if (with_jacobian) {
-        // Corrector: Huber has rho'' <= 0, so residual and Jacobian are scaled by sqrt(rho').
+        // Corrector: Huber and Cauchy have rho'' <= 0, so residual and Jacobian are scaled by sqrt(rho').
         const double sq = std::sqrt(rho[1]);
         r_[2 * i] = res[0] * sq; r_[2 * i + 1] = res[1] * sq;
         for (int k = 0; k < 12; ++k) Jc_[12 * i + k] = jc[k] * sq;

@@ -210,6 +210,7 @@ void oracle_points_cost(int C, int P, int64_t N, const int* camera_idx, const in
     const double s = r[0] * r[0] + r[1] * r[1];
     double rho[3] = {s, 1, 0};
     if (huber_delta > 0) HuberEvaluate(huber_delta, s, rho);
+    else if (huber_delta < 0) CauchyEvaluate(-huber_delta, s, rho);
     total += rho[0]; ss += s;
   }
   *cost = 0.5 * total; *sum_sq = ss;

@@ -116,15 +116,25 @@ RSBA_HD void ResidualJacobian(const double* cc, const double X[3], double u, dou
   jc[9] = 0.0; jc[10] = be; jc[11] = de;
 }
 
-// ceres::HuberLoss + Corrector for rho'' <= 0: returns rho(s) and the factor sqrt(rho'(s)) that scales
-// the residual and both Jacobian blocks.  delta <= 0 means no loss.
+// ceres::HuberLoss / CauchyLoss + Corrector for rho'' <= 0 (both): returns rho(s) and the factor sqrt(rho'(s)) that
+// scales the residual and both Jacobian blocks.  delta > 0: Huber with a = delta; delta < 0: Cauchy with a = -delta
+// (the sign is this implementation's internal encoding of rsba_options::loss_type); 0: no loss.
 RSBA_HD double LossAndScale(double delta, double s, double* sqrt_rho1) {
-  if (delta > 0.0 && s > delta * delta) {
-    const double rt = sqrt(s);
-    double rho1 = delta / rt;
+  if (delta > 0.0) {
+    if (s > delta * delta) {
+      const double rt = sqrt(s);
+      double rho1 = delta / rt;
+      if (rho1 < DBL_MIN) rho1 = DBL_MIN;
+      *sqrt_rho1 = sqrt(rho1);
+      return 2.0 * delta * rt - delta * delta;
+    }
+  } else if (delta < 0.0) {
+    // loss_function.cc CauchyLoss: b = a^2, c = 1 / b; rho = b log(1 + s c), rho' = max(min, 1 / (1 + s c))
+    const double b = delta * delta, sum = s * (1.0 / b) + 1.0;
+    double rho1 = 1.0 / sum;
     if (rho1 < DBL_MIN) rho1 = DBL_MIN;
     *sqrt_rho1 = sqrt(rho1);
-    return 2.0 * delta * rt - delta * delta;
+    return b * log(sum);
   }
   *sqrt_rho1 = 1.0;
   return s;

@@ -126,7 +126,7 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
       double r[2], jc[12], jp[6], sq;
       ResidualJacobian(camc + (size_t)cam * ccs, X, uv.x, uv.y, r, jc, jp);
       cost += LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
-      if (ip.huber_delta > 0.0) sq_cm[cm_pos[q]] = sq;
+      if (ip.huber_delta != 0.0) sq_cm[cm_pos[q]] = sq;
       if (sq != 1.0) {
         r[0] *= sq; r[1] *= sq;
 #pragma unroll

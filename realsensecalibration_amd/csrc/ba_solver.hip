@@ -384,7 +384,8 @@ static bool DebugSync(hipStream_t st, const char* what) {
 static IterParams MakeIterParams(const rsba_options& o, double radius, bool first) {
   IterParams ip;
   ip.radius = radius; ip.min_lm_diagonal = o.min_lm_diagonal; ip.max_lm_diagonal = o.max_lm_diagonal;
-  ip.huber_delta = o.huber_delta; ip.first = first ? 1 : 0; ip.jacobi_scaling = o.jacobi_scaling;
+  ip.huber_delta = o.huber_delta > 0.0 ? (o.loss_type == RSBA_LOSS_CAUCHY ? -o.huber_delta : o.huber_delta) : 0.0;   // signed: see LossAndScale
+  ip.first = first ? 1 : 0; ip.jacobi_scaling = o.jacobi_scaling;
   return ip;
 }
 
@@ -540,7 +541,7 @@ void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& 
   a.ready = ready; a.tag = tag; a.red = s->red; a.L = s->L; a.nblocks_pp = grid_pp; a.block_scal = block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
   T.Begin("k_schur_tiles", st);
-  if (ip.huber_delta > 0.0) k_schur_tiles<true><<<nblocks, 256, 0, st>>>(a);
+  if (ip.huber_delta != 0.0) k_schur_tiles<true><<<nblocks, 256, 0, st>>>(a);
   else k_schur_tiles<false><<<nblocks, 256, 0, st>>>(a);
   T.End(st);
 }

@@ -377,3 +377,21 @@ def test_problem_without_observations(oracle):
     got, s, log = capi.solve_points(q)
     assert s.termination_type == 0 and s.num_iterations == 0 and s.initial_cost == 0.0 and s.final_cost == 0.0
     assert np.array_equal(got, q["params"])
+
+
+def test_cauchy_loss_matches_oracle(oracle):
+    """ceres::CauchyLoss(a) (rho = a^2 log(1 + s / a^2), rho'' < 0: the corrector scales residual and Jacobians by
+    sqrt(rho')), SURVEY 8(f) rank 4.  Outliers as in config 5; the oracle takes the Cauchy scale as a negative
+    huber_delta (its own convention)."""
+    prob = syn.make_problem(20, 1500, 8, seed=51, outlier_frac=0.05)
+    o_ref = oracle.options(huber_delta=-2.0)
+    ref, s_ref, log_ref = oracle.solve_points(prob, o_ref)
+    got, s, log = capi.solve_points(prob, capi.default_options(huber_delta=2.0, loss_type=1))
+    assert (s.termination_type, s.stop_reason, s.num_iterations) == (s_ref.termination, s_ref.stop_reason, s_ref.num_iterations)
+    assert np.array_equal(log[:, 7], log_ref[:, 7])
+    assert abs(s.initial_cost - s_ref.initial_cost) < 1e-11 * s_ref.initial_cost
+    assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
+    assert _block_rel(got, ref, prob["C"]) < 1e-6
+    # and it is a different problem from Huber with the same parameter
+    _, s_h, _ = capi.solve_points(prob, capi.default_options(huber_delta=2.0))
+    assert abs(s_h.final_cost - s.final_cost) > 1e-3 * s.final_cost
