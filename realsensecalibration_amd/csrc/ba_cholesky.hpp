@@ -293,7 +293,7 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
   double* ahead = scl + n;                             // 4 x (32 x 33): look-ahead products for the next diagonal block
   __shared__ int s_ok;
   __shared__ int s_ahead_read;   // the panel whose look-ahead tiles wave 0 has consumed (waves 1..4 may overwrite them)
-  __shared__ int s_rb_next;      // next pair of 16-row blocks of the update (2b): the waves take them as they get free
+  __shared__ int s_rb_next;      // next 16-row block of the update (2b): the waves take them as they get free
   if (tid == 0) { s_ok = 1; s_ahead_read = -1; s_rb_next = 0; }
   if (src.S != nullptr) for (int i = tid; i < n; i += nt) scl[i] = src.scale[i];
   __syncthreads();

@@ -124,7 +124,6 @@ struct rsba_solver {
   bool test_stall = false;   // RSBA_TEST_STALL=1: the Cholesky waits for a tag nobody publishes (exercises the fallback)
   int step_tag = 0;
   hipStream_t sB = nullptr;
-  hipEvent_t ev_chol = nullptr;
   long long* chol_waited = nullptr;   // device: ticks the pipelined Cholesky spent waiting for its columns (cumulative)
   long long chol_waited_seen = 0, backsub_waited_seen = 0;   // [1]: the back-substitution's wait for the solve
   long long* trace = nullptr;   // RSBA_TRACE=1: 32 wall-clock stamps of the pipelined step
@@ -367,7 +366,6 @@ static void FreeSolver(rsba_solver* s) {
   if (s->wg_trace) (void)hipFree(s->wg_trace);
   if (s->chol_waited) (void)hipFree(s->chol_waited);
   if (s->sB) (void)hipStreamDestroy(s->sB);
-  if (s->ev_chol) (void)hipEventDestroy(s->ev_chol);
   if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -410,7 +408,6 @@ static bool SetupPipeline(rsba_solver* s) {
   std::vector<uint32_t> mask(words, mode == 2 ? 0xffffffffu : 0u);
   if (mode != 2) mask[0] = 1u;
   bool ok = hipExtStreamCreateWithCUMask(&s->sB, words, mask.data()) == hipSuccess &&
-            hipEventCreateWithFlags(&s->ev_chol, hipEventDisableTiming) == hipSuccess &&
             hipMalloc((void**)&s->chol_waited, 2 * sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, 2 * sizeof(long long)) == hipSuccess;
   if (!ok) { (void)hipGetLastError(); if (getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: CU-masked stream unavailable, solve not pipelined\n"); }
   return ok;
