@@ -395,3 +395,47 @@ def test_cauchy_loss_matches_oracle(oracle):
     # and it is a different problem from Huber with the same parameter
     _, s_h, _ = capi.solve_points(prob, capi.default_options(huber_delta=2.0))
     assert abs(s_h.final_cost - s.final_cost) > 1e-3 * s.final_cost
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[2] at full size
+def test_config3_full_size_properties():
+    """64 cameras x 100k points x 2M observations, the configuration the metric is quoted on.  The oracle needs ~1 s per
+    iteration here (bench.py replays three of them in its cpu_baseline leg: `full_size_parity`), so this test checks
+    what does not need it: the cost falls monotonically over accepted steps to the RMS of the synthetic noise
+    (0.5 px sigma in both coordinates, 2M x 2 residuals), two solves are bit-identical, the pipelined and the sequential
+    schedule agree bit for bit, and solving again from the solution stops at once (idempotence)."""
+    prob = syn.make_config("cfg3")
+    assert (prob["C"], prob["P"], prob["N"]) == (64, 100_000, 2_000_000)
+    problem = capi.Problem.points(prob)
+    sv = capi.Solver(problem, capi.default_options())
+    s = sv.run()
+    log = sv.iterations()
+    _, sumsq = sv.final_costs()
+    sv.close()
+    assert s.termination_type == 0 and 2 <= s.num_iterations <= 6
+    costs = log[:, 1]
+    assert np.all(np.diff(costs[log[:, 7] >= 2]) < 0)                     # accepted steps only go down
+    rms = np.sqrt(sumsq / (2.0 * prob["N"]))
+    assert abs(rms - 0.5) < 0.03                                          # the noise floor of the generator
+    sv2 = capi.Solver(problem, capi.default_options())
+    s2 = sv2.run()
+    log2 = sv2.iterations()
+    os.environ["RSBA_PIPELINE"] = "0"
+    os.environ["RSBA_SEG_PER_CU"] = "8"
+    try:
+        sv3 = capi.Solver(problem, capi.default_options())
+        s3 = sv3.run()
+        log3 = sv3.iterations()
+        sv3.close()
+    finally:
+        del os.environ["RSBA_PIPELINE"]
+        del os.environ["RSBA_SEG_PER_CU"]
+    assert np.array_equal(log, log2) and s.final_cost == s2.final_cost
+    assert np.array_equal(log, log3) and s.final_cost == s3.final_cost
+    sv2.download()                                                        # the solution becomes the problem's start
+    sv2.close()
+    sv4 = capi.Solver(problem, capi.default_options())
+    s4 = sv4.run()
+    sv4.close()
+    assert s4.num_iterations <= 1 and abs(s4.final_cost - s.final_cost) < 1e-6 * s.final_cost
+    problem.close()
