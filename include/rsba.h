@@ -198,6 +198,14 @@ void rsba_solver_destroy(rsba_solver* s);
 int rsba_points_linearize_and_step(rsba_problem* p, const rsba_options* o, double radius, double* S,
                                    double* rhs, double* delta, double* scalars /* 8 */);
 
+/* Stage-level entry (tests): the payload the multi-GPU path all-reduces after one linearisation of this problem
+ * (a rank's point shard, or the whole problem): S (6C)^2 unscaled / undamped, full symmetric | g_c (6C) | rhs
+ * correction (6C) | diag U (6C) | 8 scalars (cost sum, |points|^2, failed point blocks, ...), followed by the one value
+ * that is max-reduced (max |g_p|).  Additive over disjoint point shards: the sum of the shards' payloads is the
+ * payload of the union.  payload == NULL: only *count (doubles needed) is returned. */
+int rsba_points_linearize_payload(rsba_problem* p, const rsba_options* o, double radius, double* payload, int64_t capacity,
+                                  int64_t* count);
+
 /* ------------------------------------------------------------------ multi-GPU bootstrap */
 /* ncclGetUniqueId: rank 0 calls this and ships the 128 bytes to the other ranks (bench.py does it
  * through torch.distributed); every rank then passes it in rsba_options.comm_unique_id. */

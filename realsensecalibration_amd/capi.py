@@ -21,7 +21,7 @@ EXPORTS = [
     "rsba_problem_marker_idx", "rsba_problem_camera_parameters", "rsba_problem_marker_transform",
     "rsba_problem_point3d_coordinates", "rsba_options_default", "rsba_solve", "rsba_solver_create", "rsba_solver_run",
     "rsba_solver_download", "rsba_solver_iterations", "rsba_solver_kernel_stats", "rsba_solver_final_costs",
-    "rsba_solver_destroy", "rsba_points_linearize_and_step", "rsba_comm_unique_id", "rsba_read_intrinsics_xml",
+    "rsba_solver_destroy", "rsba_points_linearize_and_step", "rsba_points_linearize_payload", "rsba_comm_unique_id", "rsba_read_intrinsics_xml",
     "rsba_write_outputs", "rsba_reprojection_error", "rsba_reprojection_check_files",
 ]
 
@@ -106,6 +106,7 @@ def load():
     lib.rsba_solver_final_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rsba_solver_destroy.argtypes = [C.c_void_p]
     lib.rsba_points_linearize_and_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 4
+    lib.rsba_points_linearize_payload.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]
     lib.rsba_comm_unique_id.argtypes = [C.c_void_p]
     lib.rsba_read_intrinsics_xml.argtypes = [C.c_char_p, C.c_void_p]
     lib.rsba_write_outputs.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
@@ -287,6 +288,18 @@ def points_linearize_and_step(prob, radius, opts=None):
         p.close()
     return dict(S=S, rhs=rhs, delta=delta, cost=scal[0], model_cost_change=scal[1], gradient_max_norm=scal[2],
                 solve_ok=bool(scal[3]), cost_candidate=scal[4], step_norm=scal[5], x_norm=scal[6])
+
+
+def points_linearize_payload(prob, radius, opts=None):
+    """The all-reduce payload of one linearisation (see rsba.h); returns (payload without the last value, max |g_p|)."""
+    problem = Problem.points(prob)
+    o = opts or default_options()
+    n = C.c_int64()
+    _chk(load().rsba_points_linearize_payload(problem.h, C.byref(o), C.c_double(radius), None, 0, C.byref(n)), "rsba_points_linearize_payload")
+    buf = np.zeros(n.value)
+    _chk(load().rsba_points_linearize_payload(problem.h, C.byref(o), C.c_double(radius), _vp(buf), n.value, C.byref(n)), "rsba_points_linearize_payload")
+    problem.close()
+    return buf[:-1], buf[-1]
 
 
 def comm_unique_id():

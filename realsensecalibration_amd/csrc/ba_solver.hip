@@ -1013,6 +1013,23 @@ int rsba_points_linearize_and_step(rsba_problem* p, const rsba_options* o, doubl
   return rc;
 }
 
+int rsba_points_linearize_payload(rsba_problem* p, const rsba_options* o, double radius, double* payload, int64_t capacity, int64_t* count) {
+  if (!p || p->model != RSBA_MODEL_POINTS || !count) return RSBA_ERR_ARG;
+  rsba_solver* s = nullptr;
+  int rc = rsba_solver_create(p, o, &s);
+  if (rc != RSBA_OK) return rc;
+  *count = (int64_t)s->L.size() + 1;
+  if (payload) {
+    if (capacity < *count) rc = RSBA_ERR_ARG;
+    if (rc == RSBA_OK) rc = rsba::ResetPoints(s);
+    if (rc == RSBA_OK) rc = rsba::PointsStep(s, radius, true, true);   // keeps `red` as the linearisation left it
+    if (rc == RSBA_OK && hipMemcpy(payload, s->red, s->L.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RSBA_ERR_HIP;
+    if (rc == RSBA_OK && hipMemcpy(payload + s->L.size(), s->gmax, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RSBA_ERR_HIP;
+  }
+  rsba_solver_destroy(s);
+  return rc;
+}
+
 int rsba_reprojection_error(rsba_problem* p, const rsba_options* o, double* error, double* rms) {
   if (!p) return RSBA_ERR_ARG;
   rsba_solver* s = nullptr;

@@ -439,3 +439,30 @@ def test_config3_full_size_properties():
     sv4.close()
     assert s4.num_iterations <= 1 and abs(s4.final_cost - s.final_cost) < 1e-6 * s.final_cost
     problem.close()
+
+
+# ------------------------------------------------------------------ what the multi-GPU path relies on
+@pytest.mark.parametrize("huber", [0.0, 1.0])
+def test_shard_payloads_add_up_to_the_payload_of_the_whole(huber):
+    """Linearity: the payload a rank contributes to the all-reduce (S | g_c | rhs correction | diag U | scalars, and
+    max |g_p| for the max-reduce) is a sum over that rank's points, so the payloads of disjoint point shards, computed
+    by the same HIP kernels on each shard alone, must add up to the payload of the whole problem — which is all the
+    RCCL sum all-reduce assumes.  (The shards come from the generator exactly as bench.py hands them to the ranks.)"""
+    C, P, k, seed = 40, 16384, 10, 61
+    opts = lambda: capi.default_options(huber_delta=huber)
+    whole = syn.make_problem(C, P, k, seed=seed, outlier_frac=0.05 if huber else 0.0)
+    full, gmax_full = capi.points_linearize_payload(whole, 1e4, opts())
+    parts, gmaxs = [], []
+    for lo, hi in [(0, 4096), (4096, 12288), (12288, 16384)]:
+        shard = syn.make_problem(C, P, k, seed=seed, point_range=(lo, hi), outlier_frac=0.05 if huber else 0.0)
+        pay, gm = capi.points_linearize_payload(shard, 1e4, opts())
+        parts.append(pay); gmaxs.append(gm)
+    total = parts[0] + parts[1] + parts[2]
+    n = 6 * C
+    S, Sf = total[:n * n].reshape(n, n), full[:n * n].reshape(n, n)
+    assert np.abs(S - Sf).max() < 1e-11 * np.abs(Sf).max()
+    vec, vecf = total[n * n:n * n + 3 * n], full[n * n:n * n + 3 * n]
+    assert np.abs(vec - vecf).max() < 1e-11 * np.abs(vecf).max()
+    sc, scf = total[n * n + 3 * n:], full[n * n + 3 * n:]
+    assert np.abs(sc - scf).max() < 1e-11 * max(np.abs(scf).max(), 1.0)
+    assert max(gmaxs) == gmax_full
