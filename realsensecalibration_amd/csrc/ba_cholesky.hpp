@@ -65,6 +65,8 @@ struct PanelSource {
   double lo, hi, inv_radius;
   const double* gc;     // gated solve only: the rhs entries of a camera group, s_i (gc_i + corr_i), are written into
   const double* corr;   // row n of A when the group's gate opens (they come from the same stage of the Schur kernel)
+  int transposed;       // read entry (i, j), i >= j, as S[j][i]: the panel of camera group g then only touches the row slab
+                        // of group g, which is what has been all-reduced when the multi-GPU pipeline opens the group's gate
 };
 
 // Columns of the matrix may still be in production when the factorisation starts (pipelined solve): gate.ready[1 + g]
@@ -317,6 +319,25 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
     double* Pan = lds + (size_t)kb * RSBA_PLD;
     // 1. load the panel (scaled / damped on the fly) and the B strip
     // four consecutive doubles of a row per thread and step (two dwordx4 loads): one round of latency per panel
+    if (src.S != nullptr && src.transposed) {
+      // column c of the panel = row kb + c of S, read along the row: lanes along r, stride-33 LDS stores
+      const int nrow = n - kb;
+      for (int r = tid & 127; r < nrow; r += 128) {
+        const int gi = kb + r;
+        const double si = scl[gi];
+#pragma unroll
+        for (int c = tid >> 7; c < RSBA_PB; c += 4) {   // nt = 512: four column classes
+          const int gj = kb + c;
+          double v = 0.0;
+          if (c < nb) {
+            v = src.S[(size_t)gj * n + gi] * (si * scl[gj]);
+            if (gi == gj) v += fmin(fmax(si * si * src.diagU[gi], src.lo), src.hi) * src.inv_radius;
+          }
+          Pan[r * RSBA_PLD + c] = v;
+        }
+      }
+      for (int c = tid; c < RSBA_PB; c += nt) Pan[(R - 1) * RSBA_PLD + c] = c < nb ? A[(size_t)n * n + kb + c] : 0.0;   // rhs row
+    } else
 #pragma unroll 4
     for (int e = tid; e < R * (RSBA_PB / 4); e += nt) {
       const int r = e >> 3, c0 = (e & 7) * 4;

@@ -184,7 +184,7 @@ k_marker_system(int N, int n, const MarkerObs* __restrict__ mo, const double* __
   __threadfence_block();
   __syncthreads();
   double* ysol = A + (size_t)n * n;
-  if (kThreads == 512) CholeskySolvePanelLDS(n, A, ysol, &s_ok, lds, PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr, nullptr});
+  if (kThreads == 512) CholeskySolvePanelLDS(n, A, ysol, &s_ok, lds, PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr, nullptr, 0});
   else CholeskySolveBlocked(n, A, ysol, &s_ok, lds);
   __syncthreads();
   // step, candidate, norms, cost at x

@@ -546,8 +546,8 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
   double* ysol = A + (size_t)n * n;
   CholeskySolvePanelLDS(n, A, ysol, &s_ok, lds,
                         fused ? PanelSource{red + L.S(), scale_c, red + L.diagU(), ip.min_lm_diagonal, ip.max_lm_diagonal, 1.0 / ip.radius,
-                                            gated ? red + L.gc() : nullptr, gated ? red + L.corr() : nullptr}
-                              : PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr, nullptr},
+                                            gated ? red + L.gc() : nullptr, gated ? red + L.corr() : nullptr, sym_full == 2 ? 1 : 0}
+                              : PanelSource{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr, nullptr, 0},
                         gate);
   __syncthreads();
   if (s_ok < 0) { if (tid == 0) res[RES_STALL] = 1.0; SolveDone(gate); return; }

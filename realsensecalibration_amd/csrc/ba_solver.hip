@@ -606,7 +606,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (s->trace) s->host_t[1] = std::chrono::steady_clock::now();
     T.Begin("k_reduced_system_solve", s->sB);
     k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
-                                                     s->camc[c], s->dcam, s->gmax, s->res, ip, 1,
+                                                     s->camc[c], s->dcam, s->gmax, s->res, ip, getenv("RSBA_TRANSPOSED_SOURCE") ? 2 : 1,
                                                      s->chol_ok, StageGate{ts.ready, s->test_stall ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15, T.enabled() ? s->chol_waited : nullptr, s->trace});
     T.End(s->sB);
     ts.LaunchTiles(s, ip, T, st, tag);
