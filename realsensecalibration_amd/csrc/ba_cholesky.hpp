@@ -78,6 +78,8 @@ struct StageGate {
                       // kernel on the main stream, waits for it inside the kernel instead of behind a cross-stream event
   long long* waited;  // += ticks (100 MHz) spent waiting, by thread 0: the kernel's duration minus this is its own work
   long long* trace;   // diagnostic (RSBA_TRACE=1): wall-clock stamps of the waits, nullptr otherwise
+  long long budget;   // ticks a wait may last before the kernel gives up (0: RSBA_STALL_TICKS); the multi-GPU pipeline waits
+                      // for other ranks' collectives and gets ten times as long
 };
 
 // Spin (one lane, sleeping between polls) until *flag == tag; false when the producer does not show up in
@@ -85,7 +87,7 @@ struct StageGate {
 #ifndef RSBA_STALL_TICKS
 #define RSBA_STALL_TICKS 50000000LL
 #endif
-__device__ __forceinline__ bool WaitReady(const int* flag, int tag, long long* waited_ticks) {
+__device__ __forceinline__ bool WaitReady(const int* flag, int tag, long long* waited_ticks, long long budget = 0) {
   __shared__ int s_wait_ok;
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();
@@ -94,7 +96,7 @@ __device__ __forceinline__ bool WaitReady(const int* flag, int tag, long long* w
     // doubled the duration of a latency-bound kernel next to them); the fence below acquires once
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
       __builtin_amdgcn_s_sleep(16);
-      if (wall_clock64() - t0 > RSBA_STALL_TICKS) { ok = 0; break; }
+      if (wall_clock64() - t0 > (budget > 0 ? budget : RSBA_STALL_TICKS)) { ok = 0; break; }
     }
     s_wait_ok = ok;
     if (waited_ticks) *waited_ticks += wall_clock64() - t0;
@@ -285,7 +287,7 @@ __device__ __forceinline__ double* BackSubstituteBlocks(int n, double* __restric
 // group waits until that group's columns have been published by the Schur kernel, which is still eliminating points
 // for the later groups on the rest of the chip; a stalled wait returns with *ok_out = -1.
 __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __restrict__ x_out, int* ok_out, double* lds, PanelSource src,
-                                      StageGate gate = StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr}) {
+                                      StageGate gate = StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0}) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
   double* T = lds + (size_t)(n + 2) * RSBA_PLD;        // 32 x 33: T = L11^-1
   double* Lt = T + RSBA_PB * RSBA_PLD;                 // 32 x 33: padded L11
@@ -304,7 +306,7 @@ __device__ void CholeskySolvePanelLDS(int n, double* __restrict__ A, double* __r
   for (int kb = 0; kb < n; kb += RSBA_PB) {
     if (gate.ready != nullptr && kb % gate.cols == 0) {
       if (gate.trace && tid == 0) gate.trace[2 + 2 * (kb / gate.cols)] = wall_clock64();
-      if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, gate.waited)) { if (tid == 0) *ok_out = -1; __syncthreads(); return; }
+      if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, gate.waited, gate.budget)) { if (tid == 0) *ok_out = -1; __syncthreads(); return; }
       if (gate.trace && tid == 0) gate.trace[3 + 2 * (kb / gate.cols)] = wall_clock64();
       if (src.gc != nullptr) {
         for (int i = kb + tid; i < min(kb + gate.cols, n); i += nt) A[(size_t)n * n + i] = src.scale[i] * (src.gc[i] + src.corr[i]);

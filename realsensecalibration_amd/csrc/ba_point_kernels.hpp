@@ -495,7 +495,7 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
     if (gate.trace && tid == 0) gate.trace[0] = wall_clock64();
     if (ip.first) {
       for (int g = 0; g * gate.cols < n; ++g)
-        if (!WaitReady(gate.ready + 1 + g, gate.tag, gate.waited)) { if (tid == 0) res[RES_STALL] = 1.0; SolveDone(gate); return; }
+        if (!WaitReady(gate.ready + 1 + g, gate.tag, gate.waited, gate.budget)) { if (tid == 0) res[RES_STALL] = 1.0; SolveDone(gate); return; }
     }
     if (gate.trace && tid == 0) gate.trace[1] = wall_clock64();
   }
@@ -582,7 +582,7 @@ struct ObsSliced {
 // loop; then the cost of the candidate (cameras' constants at x + delta already in camc_c).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void FinishCandidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
-                                                double* __restrict__ res, double* host, double seq);
+                                                double* __restrict__ res, double* host, double seq, const double* res_stall = nullptr);
 
 template <bool kStage>
 __global__ void __launch_bounds__(256)
@@ -724,7 +724,7 @@ __device__ __forceinline__ void PostToHost(const double* __restrict__ res, doubl
 // One workgroup: small_red[0..4] = fixed-order sums of the per-block partials; with res != nullptr (single GPU) the
 // result block is completed and posted to the host straight away.
 __device__ __forceinline__ void FinishCandidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
-                                                double* __restrict__ res, double* host, double seq) {
+                                                double* __restrict__ res, double* host, double seq, const double* res_stall) {
   __shared__ double s[5][256];
   const int tid = threadIdx.x;
   double v[5] = {0, 0, 0, 0, 0};
@@ -745,6 +745,7 @@ __device__ __forceinline__ void FinishCandidate(int nblocks, const double* __res
     __syncthreads();
   }
   if (tid < 5) small_red[tid] = s[tid][0];
+  if (tid == 5 && res_stall != nullptr) small_red[5] = res_stall[RES_STALL];   // summed over the ranks: a stall anywhere is everybody's
   if (res != nullptr) {
     __syncthreads();
     if (tid == 0) { double sr[5]; for (int q = 0; q < 5; ++q) sr[q] = s[q][0]; PublishResult(sr, res); }
@@ -754,8 +755,9 @@ __device__ __forceinline__ void FinishCandidate(int nblocks, const double* __res
 }
 __global__ void __launch_bounds__(256)
 k_finish_candidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red, double* __restrict__ res,
-                   double* host, double seq) {
-  FinishCandidate(nblocks, block_part, small_red, res, host, seq);
+                   double* host, double seq, const double* res_stall, long long* trace = nullptr) {
+  if (trace && threadIdx.x == 0) trace[26] = wall_clock64();
+  FinishCandidate(nblocks, block_part, small_red, res, host, seq, res_stall);
 }
 
 // Folds the (all-reduced) point-side sums into the result block the host reads.
@@ -781,9 +783,11 @@ __device__ __forceinline__ void PostToHost(const double* __restrict__ res, doubl
     if (tid == 0) __hip_atomic_store(&host[RES_SIZE - 1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-__global__ void k_publish_result(const double* __restrict__ small_red, double* __restrict__ res, double* host, double seq) {
+__global__ void k_publish_result(const double* __restrict__ small_red, double* __restrict__ res, double* host, double seq, int stall_summed,
+                                 long long* trace = nullptr) {
+  if (trace && threadIdx.x == 0 && blockIdx.x == 0) trace[27] = wall_clock64();
   if (blockIdx.x != 0) return;
-  if (threadIdx.x == 0) PublishResult(small_red, res);
+  if (threadIdx.x == 0) { PublishResult(small_red, res); if (stall_summed) res[RES_STALL] = small_red[5]; }
   __syncthreads();
   PostToHost(res, host, seq);
 }

@@ -787,4 +787,23 @@ k_schur_tiles(SchurArgs a) {
 }
 
 
+// Multi-GPU pipeline, communication stream: k_wait_stage holds the stream until the Schur kernel has published stage g
+// locally (then RCCL all-reduces the stage's row slab of S and its vector ranges), k_set_flag publishes the reduced stage
+// to the Cholesky.  One wavefront, a handful of registers: it fits beside the chip-filling kernel.
+__global__ void __launch_bounds__(64) k_wait_stage(const int* __restrict__ flag, int tag, int* __restrict__ error) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+      __builtin_amdgcn_s_sleep(32);
+      if (wall_clock64() - t0 > 10 * RSBA_STALL_TICKS) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  __syncthreads();
+  __threadfence();
+}
+__global__ void __launch_bounds__(64) k_set_flag(int* __restrict__ flag, int tag) {
+  __threadfence();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace rsba

@@ -124,6 +124,12 @@ struct rsba_solver {
   bool test_stall = false;   // RSBA_TEST_STALL=1: the Cholesky waits for a tag nobody publishes (exercises the fallback)
   int step_tag = 0;
   hipStream_t sB = nullptr;
+  // Multi-GPU pipeline: the stage flags the Cholesky waits on are published on the communication stream sR, each after
+  // the RCCL all-reduce of that stage's row slab of S (k_wait_stage / k_set_flag, ba_schur_tiled.hpp)
+  bool pipelined_mg = false;
+  hipStream_t sR = nullptr;
+  hipEvent_t ev_bs = nullptr;
+  int* ready_global = nullptr;
   long long* chol_waited = nullptr;   // device: ticks the pipelined Cholesky spent waiting for its columns (cumulative)
   long long chol_waited_seen = 0, backsub_waited_seen = 0;   // [1]: the back-substitution's wait for the solve
   long long* trace = nullptr;   // RSBA_TRACE=1: 32 wall-clock stamps of the pipelined step
@@ -366,6 +372,9 @@ static void FreeSolver(rsba_solver* s) {
   if (s->wg_trace) (void)hipFree(s->wg_trace);
   if (s->chol_waited) (void)hipFree(s->chol_waited);
   if (s->sB) (void)hipStreamDestroy(s->sB);
+  if (s->sR) (void)hipStreamDestroy(s->sR);
+  if (s->ev_bs) (void)hipEventDestroy(s->ev_bs);
+  if (s->ready_global) (void)hipFree(s->ready_global);
   if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -400,7 +409,12 @@ static bool SetupPipeline(rsba_solver* s) {
   const int mode = env ? atoi(env) : 1;
   if (mode == 0) return false;
   s->test_stall = getenv("RSBA_TEST_STALL") != nullptr;
-  if (s->comm || s->opt.world_size > 1) return false;               // multi-GPU keeps the one-all-reduce schedule
+  const bool mg = s->comm != nullptr;
+  // Multi-GPU pipeline: opt-in (RSBA_PIPELINE_MG=1).  With a 1-rank communicator on one GPU it is correct (the whole GPU
+  // suite passes) but not faster than the sequential multi-GPU schedule (0.89 vs 0.81 ms: the tail of the step —
+  // back-substitution, sums, hop to the communication stream, all-reduce, publish — costs what the overlap gains), and it
+  // could not be run on several GPUs in this environment.
+  if (mg && !(getenv("RSBA_PIPELINE_MG") && atoi(getenv("RSBA_PIPELINE_MG")) == 1)) return false;
   if (s->nc > RSBA_CHOL_MAXN || s->C <= RSBA_TG) return false;        // one camera group: nothing to overlap
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) return false;
@@ -409,6 +423,14 @@ static bool SetupPipeline(rsba_solver* s) {
   if (mode != 2) mask[0] = 1u;
   bool ok = hipExtStreamCreateWithCUMask(&s->sB, words, mask.data()) == hipSuccess &&
             hipMalloc((void**)&s->chol_waited, 2 * sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, 2 * sizeof(long long)) == hipSuccess;
+  if (ok && mg) {
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    ok = hipStreamCreateWithPriority(&s->sR, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+         hipEventCreateWithFlags(&s->ev_bs, hipEventDisableTiming) == hipSuccess &&
+         hipMalloc((void**)&s->ready_global, 16 * sizeof(int)) == hipSuccess && hipMemset(s->ready_global, 0, 16 * sizeof(int)) == hipSuccess;
+    s->pipelined_mg = ok;
+  }
   if (!ok) { (void)hipGetLastError(); if (getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: CU-masked stream unavailable, solve not pipelined\n"); }
   return ok;
 }
@@ -496,6 +518,26 @@ static int UploadPoints(rsba_solver* s) {
       if (atoi(getenv("RSBA_TRACE")) == 2 && hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
     }
     s->pipelined = SetupPipeline(s);
+  }
+  {
+    // Multi-GPU: the pipelined schedule issues other collectives than the sequential one, so the ranks have to agree.
+    // Every rank with a communicator takes part in this one all-reduce (min), whatever its own answer was (a shard
+    // with duplicate observations runs schur_impl 0 and cannot pipeline); it is also the communicator's first
+    // collective, so connection set-up happens here and not inside a step.
+    const char* e1 = getenv("RSBA_PIPELINE"); const char* e2 = getenv("RSBA_PIPELINE_MG");
+    const bool mg_possible = s->comm && !(e1 && atoi(e1) == 0) && (e2 && atoi(e2) == 1);
+    if (mg_possible) {
+      int h = s->pipelined ? 1 : 0, *d = nullptr;
+      if ((rc = DevAlloc(&d, 1))) return rc;
+      HIPCHK(hipMemcpy(d, &h, sizeof(int), hipMemcpyHostToDevice));
+      NCCLCHK(ncclAllReduce(d, d, 1, ncclInt32, ncclMin, s->comm, s->stream));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      HIPCHK(hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost));
+      (void)hipFree(d);
+      if (!h) { s->pipelined = false; s->pipelined_mg = false; }
+    }
+  }
+  if (s->opt.schur_impl != 0) {
     rc = s->tiled.Build(C, P, ptr, cam, u, v, sl_q, s->pipelined);
     if (rc != RSBA_OK) return rc;
   } else if (maxk > 64) {
@@ -604,17 +646,42 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // Schur kernel fills the chip) goes out while it runs
     ts.LaunchPointPass(s, ip, T, st);
     if (s->trace) s->host_t[1] = std::chrono::steady_clock::now();
+    const bool mg = s->pipelined_mg;
+    // multi-GPU: the gates open on the flags the communication stream publishes after each stage's all-reduce, the
+    // panels are read from the (all-reduced) row slab of their own group, and the waits may last as long as the slowest rank
     T.Begin("k_reduced_system_solve", s->sB);
     k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
-                                                     s->camc[c], s->dcam, s->gmax, s->res, ip, getenv("RSBA_TRANSPOSED_SOURCE") ? 2 : 1,
-                                                     s->chol_ok, StageGate{ts.ready, s->test_stall ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15, T.enabled() ? s->chol_waited : nullptr, s->trace});
+                                                     s->camc[c], s->dcam, s->gmax, s->res, ip, (mg || getenv("RSBA_TRANSPOSED_SOURCE")) ? 2 : 1,
+                                                     s->chol_ok, StageGate{mg ? s->ready_global : ts.ready, s->test_stall ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15,
+                                                                           T.enabled() ? s->chol_waited : nullptr, s->trace, mg ? 10 * RSBA_STALL_TICKS : 0});
     T.End(s->sB);
     ts.LaunchTiles(s, ip, T, st, tag);
+    if (mg) {
+      // communication stream: stage by stage, as the Schur kernel publishes them locally — the row slab of S of the
+      // stage's camera group (complete once the stage is: the mirror blocks in it were written by earlier stages) and
+      // the group's ranges of g_c, rhs correction and diag U; the scalars and max |g_p| ride with the last stage
+      const RedLayout& L = s->L;
+      for (int g = 0; g < ts.nstages; ++g) {
+        const int r0 = 6 * RSBA_TG * g, r1 = std::min(6 * RSBA_TG * (g + 1), n), rows = r1 - r0;
+        k_wait_stage<<<1, 64, 0, s->sR>>>(ts.ready + 1 + g, tag, ts.tree_error);
+        NCCLCHK(ncclGroupStart());
+        NCCLCHK(ncclAllReduce(s->red + L.S() + (size_t)r0 * n, s->red + L.S() + (size_t)r0 * n, (size_t)rows * n, ncclDouble, ncclSum, s->comm, s->sR));
+        NCCLCHK(ncclAllReduce(s->red + L.gc() + r0, s->red + L.gc() + r0, rows, ncclDouble, ncclSum, s->comm, s->sR));
+        NCCLCHK(ncclAllReduce(s->red + L.corr() + r0, s->red + L.corr() + r0, rows, ncclDouble, ncclSum, s->comm, s->sR));
+        NCCLCHK(ncclAllReduce(s->red + L.diagU() + r0, s->red + L.diagU() + r0, rows, ncclDouble, ncclSum, s->comm, s->sR));
+        if (g == ts.nstages - 1) {
+          NCCLCHK(ncclAllReduce(s->red + L.scal(), s->red + L.scal(), 8, ncclDouble, ncclSum, s->comm, s->sR));
+          NCCLCHK(ncclAllReduce(s->gmax, s->gmax, 1, ncclDouble, ncclMax, s->comm, s->sR));
+        }
+        NCCLCHK(ncclGroupEnd());
+        k_set_flag<<<1, 64, 0, s->sR>>>(s->ready_global + 1 + g, tag);
+      }
+    }
   }
   HIPCHK(hipGetLastError());
   DebugSync(st, "linearize+schur");
 
-  if (s->comm) {
+  if (s->comm && !(pipe && s->pipelined_mg)) {
     // one group: the sum of the packed reduced system and the max of the point-gradient bound go out as one launch
     NCCLCHK(ncclGroupStart());
     NCCLCHK(ncclAllReduce(s->red, s->red, s->L.size(), ncclDouble, ncclSum, s->comm, st));
@@ -671,13 +738,20 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   T.End(st);
   DebugSync(st, "k_backsub_candidate");
   if (s->comm) {
+    const bool mg = pipe && s->pipelined_mg;
     T.Begin("k_finish_candidate", st);
-    k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, nullptr, nullptr, 0.0);
+    k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, nullptr, nullptr, 0.0, mg ? s->res : nullptr, s->trace);
     T.End(st);
-  }
-  if (s->comm) {
-    NCCLCHK(ncclAllReduce(s->small_red, s->small_red, 8, ncclDouble, ncclSum, s->comm, st));
-    k_publish_result<<<1, 64, 0, st>>>(s->small_red, s->res, s->res_host, s->res_seq + 1.0);
+    // the candidate's sums (and, pipelined, the stall flags: a stall on one rank must send every rank back to the
+    // sequential schedule together); pipelined, all RCCL traffic stays on the communication stream
+    hipStream_t sc = st;
+    if (mg) {
+      HIPCHK(hipEventRecord(s->ev_bs, st));
+      HIPCHK(hipStreamWaitEvent(s->sR, s->ev_bs, 0));
+      sc = s->sR;
+    }
+    NCCLCHK(ncclAllReduce(s->small_red, s->small_red, 8, ncclDouble, ncclSum, s->comm, sc));
+    k_publish_result<<<1, 64, 0, sc>>>(s->small_red, s->res, s->res_host, s->res_seq + 1.0, mg ? 1 : 0, s->trace);
   }
   HIPCHK(hipGetLastError());
   if (s->trace) s->host_t[2] = std::chrono::steady_clock::now();
@@ -719,6 +793,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     for (int g = 0; g < s->tiled.nstages; ++g) fprintf(stderr, " %.1f..%.1f", (h[2 + 2 * g] - t0) * 0.01, (h[3 + 2 * g] - t0) * 0.01);
     fprintf(stderr, " end %.1f | published: self %.1f stages", (h[15] - t0) * 0.01, (h[16] - t0) * 0.01);
     for (int g = 0; g < s->tiled.nstages; ++g) fprintf(stderr, " %.1f", (h[17 + g] - t0) * 0.01);
+    if (s->comm) fprintf(stderr, " | after the solve: candidate sums start +%.1f, publish +%.1f", (h[26] - h[15]) * 0.01, (h[27] - h[15]) * 0.01);
     fprintf(stderr, "\n");
     if (s->wg_trace && s->step_tag == 5) {
       // one step's block timeline: block, segment, tile, self, stage, words, start, compute end, end (us)
@@ -745,7 +820,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(s->tiled.sync_cnt, 0, (size_t)s->tiled.nsync * sizeof(int)));
     HIPCHK(hipMemset(s->tiled.tree_error + 1, 0, sizeof(int)));
-    s->pipelined = false;
+    s->pipelined = false; s->pipelined_mg = false;
     return PointsStep(s, radius, first, keep_system_copy);
   }
   return RSBA_OK;
@@ -1043,7 +1118,7 @@ int rsba_reprojection_error(rsba_problem* p, const rsba_options* o, double* erro
     if (rc == RSBA_OK) {
       k_camera_constants<<<(s->C + 63) / 64, 64, 0, s->stream>>>(s->C, s->cam[0], s->intr, s->camc[0]);
       k_cost_only<<<s->grid_pts, 256, 0, s->stream>>>(s->P, s->sliced(), s->camc[0], s->pts[0], s->block_part, 0.0);
-      k_finish_candidate<<<1, 256, 0, s->stream>>>(s->grid_pts, s->block_part, s->small_red, nullptr, nullptr, 0.0);
+      k_finish_candidate<<<1, 256, 0, s->stream>>>(s->grid_pts, s->block_part, s->small_red, nullptr, nullptr, 0.0, nullptr);
       double h[8];
       if (hipMemcpyAsync(h, s->small_red, 8 * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) rc = RSBA_ERR_HIP;
       sumsq = h[4]; npts = p->num_observations;

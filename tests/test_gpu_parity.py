@@ -466,3 +466,22 @@ def test_shard_payloads_add_up_to_the_payload_of_the_whole(huber):
     sc, scf = total[n * n + 3 * n:], full[n * n + 3 * n:]
     assert np.abs(sc - scf).max() < 1e-11 * max(np.abs(scf).max(), 1.0)
     assert max(gmaxs) == gmax_full
+
+
+def test_multi_gpu_pipeline_opt_in_single_rank(oracle):
+    """RSBA_PIPELINE_MG=1 (opt-in): the pipelined schedule with RCCL in it — per-stage all-reduces of the row slabs of S
+    on a communication stream, the Cholesky gated on the flags published after them and reading its panels from the
+    reduced slabs (transposed source), the ranks agreeing on the schedule and on stalls through all-reduces.  One rank
+    here (RSBA_FORCE_COMM): the collectives are identities, everything around them runs."""
+    prob = syn.make_problem(40, 3000, 9, seed=340)
+    ref, s_ref, log_ref = capi.solve_points(prob)
+    os.environ["RSBA_FORCE_COMM"] = "1"
+    os.environ["RSBA_PIPELINE_MG"] = "1"
+    try:
+        got, s, log = capi.solve_points(prob)
+    finally:
+        del os.environ["RSBA_FORCE_COMM"]
+        del os.environ["RSBA_PIPELINE_MG"]
+    assert s.num_iterations == s_ref.num_iterations and s.stop_reason == s_ref.stop_reason
+    assert np.array_equal(log[:, 7], log_ref[:, 7])
+    assert _block_rel(got, ref, prob["C"]) < 1e-9 and abs(s.final_cost - s_ref.final_cost) < 1e-12 * s_ref.final_cost
