@@ -57,6 +57,7 @@ enum {
   RES_POINT_FAIL = 8,    // number of point blocks that were not positive definite
   RES_SUMSQ_C = 9,       // sum of squared raw residuals at the candidate (for the RMS metric)
   RES_STALL = 10,        // pipelined solve only: 1.0 when the Cholesky gave up waiting for its columns
+  RES_WAIT_TIMEOUT = 11, // pipelined solve only: 1.0 when the back-substitution gave up waiting for the solve
   RES_SIZE = 16
 };
 
@@ -591,7 +592,7 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
                     const double* __restrict__ dcam_g, const double* __restrict__ pts_x, double* __restrict__ pts_c,
                     const double* __restrict__ scale_p, double* __restrict__ block_part /* gridDim.x x 8 */, IterParams ip,
                     int* __restrict__ done_cnt, double* __restrict__ small_red, double* __restrict__ res, double* host, double seq,
-                    const int* __restrict__ solve_done, int solve_tag, long long* __restrict__ waited) {
+                    const int* __restrict__ solve_done, int solve_tag, long long* __restrict__ waited, int* __restrict__ wait_timeout) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   // camera constants at x and at the candidate, and the camera step: 70 doubles per camera, LDS-resident when they fit
@@ -607,7 +608,9 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
       const long long t0 = wall_clock64();
       while (__hip_atomic_load(solve_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != solve_tag) {
         __builtin_amdgcn_s_sleep(127);
-        if (wall_clock64() - t0 > RSBA_STALL_TICKS) break;
+        // (the solve was not running beside us — e.g. its CU was taken: what follows is computed from stale data, and the
+        //  host must repeat the step with the sequential schedule)
+        if (wall_clock64() - t0 > RSBA_STALL_TICKS) { __hip_atomic_store(wait_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
       if (waited != nullptr && blockIdx.x == 0) *waited += wall_clock64() - t0;   // the kernel's span minus this is its own work
     }
@@ -712,6 +715,11 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
     __syncthreads();
     if (s_last) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (tid == 0 && wait_timeout != nullptr) {
+        res[RES_WAIT_TIMEOUT] = (double)__hip_atomic_load(wait_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(wait_timeout, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
       FinishCandidate((int)gridDim.x, block_part, small_red, res, host, seq);
     }
   }
@@ -755,9 +763,13 @@ __device__ __forceinline__ void FinishCandidate(int nblocks, const double* __res
 }
 __global__ void __launch_bounds__(256)
 k_finish_candidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red, double* __restrict__ res,
-                   double* host, double seq, const double* res_stall, long long* trace = nullptr) {
+                   double* host, double seq, const double* res_stall, long long* trace = nullptr, int* wait_timeout = nullptr) {
   if (trace && threadIdx.x == 0) trace[26] = wall_clock64();
   FinishCandidate(nblocks, block_part, small_red, res, host, seq, res_stall);
+  if (threadIdx.x == 5 && res_stall != nullptr && wait_timeout != nullptr) {   // multi-GPU pipeline: a timed-out wait counts as a stall
+    small_red[5] += (double)__hip_atomic_load(wait_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(wait_timeout, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // Folds the (all-reduced) point-side sums into the result block the host reads.

@@ -121,7 +121,8 @@ struct rsba_solver {
   // queue restricted to one CU (sB), and waits inside the kernel for ready flags; the pair kernel (on the main stream)
   // publishes each camera group's columns as its last workgroups reduce them, the self tiles are the first blocks of the same launch.
   bool pipelined = false;
-  bool test_stall = false;   // RSBA_TEST_STALL=1: the Cholesky waits for a tag nobody publishes (exercises the fallback)
+  int test_stall = 0;        // RSBA_TEST_STALL=1: the Cholesky waits for a tag nobody publishes, =2: the back-substitution does
+                             // (both exercise the fallback to the sequential schedule)
   int step_tag = 0;
   hipStream_t sB = nullptr;
   // Multi-GPU pipeline: the stage flags the Cholesky waits on are published on the communication stream sR, each after
@@ -408,7 +409,7 @@ static bool SetupPipeline(rsba_solver* s) {
   const char* env = getenv("RSBA_PIPELINE");
   const int mode = env ? atoi(env) : 1;
   if (mode == 0) return false;
-  s->test_stall = getenv("RSBA_TEST_STALL") != nullptr;
+  s->test_stall = getenv("RSBA_TEST_STALL") ? std::max(1, atoi(getenv("RSBA_TEST_STALL"))) : 0;
   const bool mg = s->comm != nullptr;
   // Multi-GPU pipeline: opt-in (RSBA_PIPELINE_MG=1).  With a 1-rank communicator on one GPU it is correct (the whole GPU
   // suite passes) but not faster than the sequential multi-GPU schedule (0.89 vs 0.81 ms: the tail of the step —
@@ -478,11 +479,11 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->pts[0], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts[1], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts0, 3 * (size_t)P)) ||
       (rc = DevAlloc(&s->camc[0], CC_STRIDE * C)) || (rc = DevAlloc(&s->camc[1], CC_STRIDE * C)) || (rc = DevAlloc(&s->scale_c, 6 * C)) ||
       (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(s->nc + 2) * s->nc)) || (rc = DevAlloc(&s->W, s->nc > RSBA_CHOL_MAXN ? (size_t)(s->nc + 1) * s->nc : 1)) ||
-      (rc = DevAlloc(&s->chol_ok, 2)) ||
+      (rc = DevAlloc(&s->chol_ok, 3)) ||
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
       (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)))
     return rc;
-  HIPCHK(hipMemset(s->chol_ok, 0, 2 * sizeof(int)));   // [0] Cholesky status, [1] arrival counter of the back-substitution's blocks
+  HIPCHK(hipMemset(s->chol_ok, 0, 3 * sizeof(int)));   // [0] Cholesky status, [1] arrival counter of the back-substitution's blocks, [2] its wait timed out
   HIPCHK(hipMemcpy(s->obs_u, u.data(), N * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->obs_v, v.data(), N * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->obs_cam, cam.data(), N * sizeof(int), hipMemcpyHostToDevice));
@@ -652,7 +653,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     T.Begin("k_reduced_system_solve", s->sB);
     k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                      s->camc[c], s->dcam, s->gmax, s->res, ip, (mg || getenv("RSBA_TRANSPOSED_SOURCE")) ? 2 : 1,
-                                                     s->chol_ok, StageGate{mg ? s->ready_global : ts.ready, s->test_stall ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15,
+                                                     s->chol_ok, StageGate{mg ? s->ready_global : ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15,
                                                                            T.enabled() ? s->chol_waited : nullptr, s->trace, mg ? 10 * RSBA_STALL_TICKS : 0});
     T.End(s->sB);
     ts.LaunchTiles(s, ip, T, st, tag);
@@ -729,18 +730,18 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (lds_b <= 60 * 1024)
       k_backsub_candidate<true><<<s->grid_pts, 256, lds_b, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
                                                                  s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0,
-        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + 1 : s->step_tag, pipe && T.enabled() ? s->chol_waited + 1 : nullptr);
+        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag, pipe && T.enabled() ? s->chol_waited + 1 : nullptr, s->chol_ok + 2);
     else
       k_backsub_candidate<false><<<s->grid_pts, 256, 0, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
                                                               s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0,
-        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + 1 : s->step_tag, pipe && T.enabled() ? s->chol_waited + 1 : nullptr);
+        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag, pipe && T.enabled() ? s->chol_waited + 1 : nullptr, s->chol_ok + 2);
   }
   T.End(st);
   DebugSync(st, "k_backsub_candidate");
   if (s->comm) {
     const bool mg = pipe && s->pipelined_mg;
     T.Begin("k_finish_candidate", st);
-    k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, nullptr, nullptr, 0.0, mg ? s->res : nullptr, s->trace);
+    k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, nullptr, nullptr, 0.0, mg ? s->res : nullptr, s->trace, s->chol_ok + 2);
     T.End(st);
     // the candidate's sums (and, pipelined, the stall flags: a stall on one rank must send every rank back to the
     // sequential schedule together); pipelined, all RCCL traffic stays on the communication stream
@@ -813,7 +814,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       }
     }
   }
-  if (pipe && s->res_host[RES_STALL] != 0.0) {
+  if (pipe && (s->res_host[RES_STALL] != 0.0 || s->res_host[RES_WAIT_TIMEOUT] != 0.0)) {
     // the waiting Cholesky never saw its columns (its producers were not running beside it): nothing of x has been
     // touched, so repeat the step with the plain schedule and stay there
     fprintf(stderr, "rsba: pipelined solve stalled; falling back to the sequential schedule\n");

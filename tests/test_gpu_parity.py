@@ -293,13 +293,14 @@ def test_pipelined_solve_matches_oracle_and_sequential_schedule(oracle, C, P, k,
     assert np.array_equal(got, again) and np.array_equal(log, log2)
 
 
-def test_pipeline_stall_falls_back_to_sequential_schedule(oracle, capfd):
+@pytest.mark.parametrize("who", ["1", "2"])
+def test_pipeline_stall_falls_back_to_sequential_schedule(oracle, capfd, who):
     """RSBA_TEST_STALL=1 makes the waiting Cholesky look for a tag nobody publishes: it must give up after its 0.5 s
     budget (never hang the queue), the step must be repeated with the sequential schedule, and the result must not
     change."""
     prob = syn.make_problem(24, 1500, 7, seed=77)
     ref, s_ref, log_ref = capi.solve_points(prob)
-    os.environ["RSBA_TEST_STALL"] = "1"
+    os.environ["RSBA_TEST_STALL"] = who   # 1: the Cholesky's wait, 2: the back-substitution's wait for the solve
     try:
         got, s, log = capi.solve_points(prob)
     finally:
