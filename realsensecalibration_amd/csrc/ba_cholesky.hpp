@@ -122,34 +122,64 @@ __device__ __forceinline__ bool DiagFactorInverse(double* __restrict__ Pan, int 
       for (int c = 0; c < RSBA_PB; ++c) row[c] = (lr < nb) ? Pan[lr * RSBA_PLD + c] : (c == lr ? 1.0 : 0.0);
       bool good = true;
       double ilv = 1.0;  // 1 / L[lr][lr]
-#pragma unroll
-      for (int j = 0; j < RSBA_PB; ++j) {
-        const double d = ReadLaneD(row[j], j);
-        if (!(d > 0.0) || !(d <= DBL_MAX)) good = false;
-        const double dd = good ? d : 1.0;
-        // il = 1/sqrt(d): hardware estimate + two Newton steps (full fp64); l = d * il
-        double il = __builtin_amdgcn_rsq(dd);
-        il = il * (1.5 - 0.5 * dd * il * il);
-        il = il * (1.5 - 0.5 * dd * il * il);
-        const double lij = (lr == j) ? dd * il : row[j] * il;
-        row[j] = lij;
-        if (lr == j) ilv = il;
-        invd[j] = il;  // wave-uniform value
-        // a_ic -= l_ij l_cj with l_cj read straight out of lane c's register (v_readlane -> SGPR operand): no LDS
-        // round trip on the critical path.  Entries above the diagonal (c > row) pick up garbage; never read.
-        // groups of four: the eight v_readlane of a group issue back to back, so the SGPR-write -> VALU-read hazard
-        // of one value is covered by the next ones instead of s_nops
-#pragma unroll
-        for (int c0 = j + 1; c0 < RSBA_PB; c0 += 4) {
-          double lc[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) lc[u] = (c0 + u < RSBA_PB) ? ReadLaneD(lij, c0 + u) : 0.0;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) if (c0 + u < RSBA_PB) row[c0 + u] -= lij * lc[u];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) if (c0 + u < RSBA_PB) asm volatile("" : "+v"(row[c0 + u]));
-        }
+      // Two 16-column halves: the steps j < 16 only update the columns up to 15 (for all 32 rows: that gives L11 of the
+      // top-left block and L21 below it), the bottom-right block then takes its rank-16 update L21 L21' from the matrix
+      // cores in one go, and the steps j >= 16 work on it alone.  The v_readlane broadcasts are what a step costs (~430 of
+      // ~610 cycles): 240 pairs instead of 496.  (Two loops, not one with a conditional bound: with the bound and the
+      // rank-16 block inside one loop body LLVM stopped unrolling fully and put row[] into scratch memory.)
+#define RSBA_FACTOR_STEP(CEND)                                                                                          \
+      {                                                                                                                 \
+        const double d = ReadLaneD(row[j], j);                                                                          \
+        if (!(d > 0.0) || !(d <= DBL_MAX)) good = false;                                                                \
+        const double dd = good ? d : 1.0;                                                                               \
+        /* il = 1/sqrt(d): hardware estimate + two Newton steps (full fp64); l = d * il */                              \
+        double il = __builtin_amdgcn_rsq(dd);                                                                           \
+        il = il * (1.5 - 0.5 * dd * il * il);                                                                           \
+        il = il * (1.5 - 0.5 * dd * il * il);                                                                           \
+        const double lij = (lr == j) ? dd * il : row[j] * il;                                                           \
+        row[j] = lij;                                                                                                   \
+        if (lr == j) ilv = il;                                                                                          \
+        invd[j] = il; /* wave-uniform value */                                                                          \
+        /* a_ic -= l_ij l_cj with l_cj read straight out of lane c's register (v_readlane -> SGPR operand): no LDS  */  \
+        /* round trip on the critical path.  Entries above the diagonal (c > row) pick up garbage; never read.       */  \
+        /* groups of four: the eight v_readlane of a group issue back to back, so the SGPR-write -> VALU-read       */  \
+        /* hazard of one value is covered by the next ones instead of s_nops                                         */  \
+        _Pragma("unroll") for (int c0 = j + 1; c0 < (CEND); c0 += 4) {                                                  \
+          double lc[4];                                                                                                 \
+          _Pragma("unroll") for (int u = 0; u < 4; ++u) lc[u] = (c0 + u < (CEND)) ? ReadLaneD(lij, c0 + u) : 0.0;       \
+          _Pragma("unroll") for (int u = 0; u < 4; ++u) if (c0 + u < (CEND)) row[c0 + u] -= lij * lc[u];                \
+          _Pragma("unroll") for (int u = 0; u < 4; ++u) if (c0 + u < (CEND)) asm volatile("" : "+v"(row[c0 + u]));      \
+        }                                                                                                               \
       }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) RSBA_FACTOR_STEP(16)
+      {
+        // A22 -= L21 L21': L21 (rows 16..31, columns 0..15) through the Lt tile into MFMA operand layout, the product
+        // back through the (still unused) T tile into the rows' registers
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Lt[lr * RSBA_PLD + c] = row[c];
+        __builtin_amdgcn_wave_barrier();
+        const int mi = lane & 15, mk = lane >> 4;
+        d4_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 4) {
+          const double a = Lt[(16 + mi) * RSBA_PLD + ks + mk];   // A[i][k] = L21[i][k]; B[k][j] = L21[j][k]: the same value
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) T[(mk + 4 * tt) * RSBA_PLD + mi] = acc[tt];   // D[row][col]
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const double upd = T[(lr & 15) * RSBA_PLD + c];
+          if (lr >= 16) row[16 + c] -= upd;
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(row[16 + c]));
+      }
+#pragma unroll
+      for (int j = 16; j < RSBA_PB; ++j) RSBA_FACTOR_STEP(RSBA_PB)
+#undef RSBA_FACTOR_STEP
       // padded factor -> Lt (32 x 33); the real rows also back into the panel
 #pragma unroll
       for (int c = 0; c < RSBA_PB; ++c) {
