@@ -80,7 +80,9 @@ typedef struct rsba_options {
   double huber_delta;                        /* the loss function's parameter a; 0 = no loss (the reference passes NULL, :38) */
   /* --- implementation knobs --- */
   int32_t device;          /* HIP device ordinal, -1 = current                                  */
-  int32_t schur_impl;      /* 0 = reference kernel (global atomics), 1 = tiled (default)         */
+  int32_t schur_impl;      /* point model: 0 = reference kernel (global atomics), 1 = tiled (default).          */
+                           /* marker-chain: 0 = dense normal equations in one workgroup, 1 = eliminate the time */
+                           /* blocks when the dense system has more than 384 unknowns, 2 = always eliminate     */
   int32_t profile_kernels; /* HIP events on the solver stream (rsba_solver_kernel_stats): 1 = around every kernel,
                               2 = only around the Schur pair kernel and the reduced-system solve */
   int32_t rank;            /* multi-GPU: this process' rank, 0..world_size-1                     */
@@ -135,6 +137,14 @@ int rsba_problem_create_points(int32_t num_cameras, int32_t num_points, int64_t 
                                const double* observations /* 2 per observation */,
                                const double* parameters /* 6C + 3P */,
                                const double* intrinsics /* 4C */, rsba_problem** out);
+
+/* Marker-chain problem from arrays (what BALProblem::loadFile, bundle_adjustment.cpp:132-187, leaves in memory): one row
+ * per detected marker = residual block; observations 8 per row (4 corners x (u, v)); parameters [C | T | M] x 6
+ * (rvec, tvec), camera 0 / marker 0 being the fixed base blocks of RSBA_MODEL_MARKER_CHAIN. */
+int rsba_problem_create_marker_chain(int32_t model, int32_t num_cameras, int32_t num_times, int32_t num_markers,
+                                     int64_t num_observations, const int32_t* time_index, const int32_t* camera_index,
+                                     const int32_t* marker_index, const double* observations, const double* parameters,
+                                     const double* intrinsics, double marker_side, rsba_problem** out);
 
 /* Test1 file "two_cam_data.txt": `C P`, P rows `cam pt u v` (one observation per point,
  * bundle_adjustmenter.cpp:62-64), C x (rvec row, tvec row), P rows xyz.  Also accepts the extended

@@ -13,7 +13,8 @@ MODEL_POINTS, MODEL_MARKER_CHAIN, MODEL_MARKER_CHAIN_TEST2 = 0, 1, 2
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 
 EXPORTS = [
-    "rsba_version", "rsba_device_count", "rsba_error_string", "rsba_problem_create_points", "rsba_problem_load_points_file",
+    "rsba_version", "rsba_device_count", "rsba_error_string", "rsba_problem_create_points", "rsba_problem_create_marker_chain",
+    "rsba_problem_load_points_file",
     "rsba_problem_load_correspondence", "rsba_problem_free", "rsba_problem_model", "rsba_problem_num_cameras",
     "rsba_problem_num_points", "rsba_problem_num_times", "rsba_problem_num_markers", "rsba_problem_num_observations",
     "rsba_problem_num_parameters", "rsba_problem_num_observations_per_time_camera", "rsba_problem_observations",
@@ -84,6 +85,7 @@ def load():
     lib.rsba_problem_num_observations.restype = C.c_int64
     lib.rsba_problem_num_parameters.restype = C.c_int64
     lib.rsba_problem_create_points.argtypes = [C.c_int32, C.c_int32, C.c_int64] + [C.c_void_p] * 6
+    lib.rsba_problem_create_marker_chain.argtypes = [C.c_int32] * 4 + [C.c_int64] + [C.c_void_p] * 6 + [C.c_double, C.c_void_p]
     lib.rsba_problem_load_points_file.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
     lib.rsba_problem_load_correspondence.argtypes = [C.c_char_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]
     lib.rsba_problem_free.argtypes = [C.c_void_p]
@@ -156,6 +158,19 @@ class Problem:
         intr = np.ascontiguousarray(prob["intr"], np.float64)
         _chk(load().rsba_problem_create_points(prob["C"], prob["P"], prob["N"], _vp(cam), _vp(pt), _vp(obs), _vp(par), _vp(intr),
                                                C.byref(h)), "rsba_problem_create_points")
+        return cls(h)
+
+    @classmethod
+    def marker_chain(cls, prob, model=MODEL_MARKER_CHAIN):
+        """prob: dict with T, C, M, N, t, c, m (int32 per row), obs (N x 8), params (6 (C + T + M)), intr (C x 4), marker_side."""
+        h = C.c_void_p()
+        t, c, m = (np.ascontiguousarray(prob[k], np.int32) for k in ("t", "c", "m"))
+        obs = np.ascontiguousarray(prob["obs"], np.float64)
+        par = np.ascontiguousarray(prob["params"], np.float64)
+        intr = np.ascontiguousarray(prob["intr"], np.float64)
+        _chk(load().rsba_problem_create_marker_chain(model, prob["C"], prob["T"], prob["M"], prob["N"], _vp(t), _vp(c), _vp(m), _vp(obs),
+                                                     _vp(par), _vp(intr), C.c_double(prob["marker_side"]), C.byref(h)),
+             "rsba_problem_create_marker_chain")
         return cls(h)
 
     @classmethod

@@ -1,0 +1,671 @@
+// Marker-chain model at scale: many times x markers x cameras.
+//
+// The residual blocks of /root/reference/Main_Calibration/bundle_adjustment.h:56-343 touch up to three 6-dof blocks:
+// a camera transform, a marker transform and the pose of the base marker at one TIME.  Every residual block has
+// exactly one time block, and no residual couples two times: given the cameras and markers the time blocks are
+// mutually independent, the same structure the 3-D points have in the point model (and the reason Ceres' DENSE_SCHUR
+// ordering would eliminate them first).  So the time blocks are eliminated,
+//
+//     S = U - sum_t W_t' (V_t + D_t)^-1 W_t        rhs = g_r - sum_t W_t' (V_t + D_t)^-1 g_t
+//
+// leaving a dense system over the (cameras + markers) only, which goes through the same Cholesky kernels as the
+// reduced camera system of the point model, and the time steps come from back-substitution.  The one-workgroup dense
+// solver of ba_marker_kernels.hpp stays for the committed 114-parameter data; this path takes over when the normal
+// equations no longer fit it (rsba_options.schur_impl: 0 dense, 1 automatic, 2 always eliminate).
+//
+//   k_marker_eval        thread per residual block: r (8), J (8 x 18) by forward-mode duals      [ba_marker_kernels.hpp]
+//   k_time_eliminate     workgroup per chunk of consecutive times, one time after the other: V, g, W and the reduced
+//                        gradient from the staged Jacobians, E = (V + D)^-1, Y = E W, then every entry of the time's
+//                        local block of U - W'Y is added to the workgroup's PRIVATE partial system (fixed order:
+//                        bitwise reproducible, no atomics)
+//   k_marker_reduce      thread per entry: the partial systems summed in chunk order, mirrored to full symmetric
+//   k_marker_reduced_solve / k_sys_build + k_chol_step + k_marker_chol_finish     (n_r <= 384 / larger)
+//   k_time_backsub       thread per time: delta_t = -E (g_t + W_t delta_r), candidate time poses
+//   k_marker_obs_terms   thread per residual block: model cost change, candidate cost
+//   k_marker_schur_finish   ordered final sums -> the 16-double result block
+//
+// Scaling and damping follow the point model's formulation: the elimination runs in unscaled coordinates with the
+// effective damping D_t = clamp(s^2 V_ii) / (radius s^2), the Jacobi scale and the LM diagonal of the reduced blocks
+// are applied by the Cholesky's panel loads (PanelSource).
+#pragma once
+#include "ba_cholesky_large.hpp"
+#include "ba_marker_kernels.hpp"
+
+namespace rsba {
+
+#define RSBA_MT_TILE 32        // residual blocks staged per tile (32 x 152 doubles of LDS)
+#define RSBA_MT_MAXD 1020      // widest local system of one time: 170 camera + marker blocks
+
+struct TimeSlots {  // per residual block, in time order: where its camera / marker block sits
+  int slot_cam, slot_marker;   // index in its time's slot list (-1: block not part of the residual)
+  int col_cam, col_marker;     // first column in the reduced system (-1)
+};
+
+// 6 x 6 SPD inverse through Cholesky; false when a pivot is not positive and finite.
+__device__ inline bool InvertSpd6(const double* A, double* E) {
+  double L[6][6], M[6][6];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double s = A[j * 6 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+    if (!(s > 0.0) || !(s <= DBL_MAX)) { ok = false; s = 1.0; }
+    const double l = sqrt(s), inv = 1.0 / l;
+    L[j][j] = l;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double t = A[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+      L[i][j] = t * inv;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    M[j][j] = 1.0 / L[j][j];
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = j; k < i; ++k) s -= L[i][k] * M[k][j];
+      M[i][j] = s / L[i][i];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = a; k < 6; ++k) s += M[k][a] * M[k][b];
+      E[a * 6 + b] = s; E[b * 6 + a] = s;
+    }
+  return ok;
+}
+
+struct ElimArgs {
+  int nr, dmax;
+  const int* __restrict__ chunk_ptr;   // [G + 1] times of each workgroup
+  const int* __restrict__ time_ptr;    // [T + 1] residual blocks of each time
+  const int* __restrict__ slot_ptr;    // [T + 1] slots (distinct camera / marker blocks) of each time
+  const int* __restrict__ slot_col;    // first reduced column of each slot, ascending inside a time
+  const int* __restrict__ time_full;   // offset of the time block in the full parameter array
+  const TimeSlots* __restrict__ ts;
+  const double* __restrict__ J;        // [N][8][18]
+  const double* __restrict__ r;        // [N][8]
+  const double* __restrict__ sumsq;    // [N]
+  const double* __restrict__ params_x;
+  double* __restrict__ scale_t;        // [6 T]
+  double* __restrict__ tdata;          // [T][48]: E (36), g_t (6)
+  double* __restrict__ part;           // [G][RedLayout(nr).size()]; S lower triangle only
+  IterParams ip;
+};
+
+__device__ __forceinline__ int LocalColumn(int slot, int q, int sc, int sm) { return slot == sc ? q : (slot == sm ? 12 + q : -1); }
+
+__global__ void __launch_bounds__(256)
+k_time_eliminate(ElimArgs a) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nr = a.nr, dmax = a.dmax;
+  const RedLayout RL{nr};
+  double* W = lds;                        // [6][d]
+  double* Y = W + 6 * dmax;               // [6][d]
+  double* Gr = Y + 6 * dmax;              // [d]
+  double* Vs = Gr + dmax;                 // V 36 | g 6 | (pad 6) | E 36 | Eg 6
+  double* Jt = Vs + 96;                   // [TILE][144]
+  double* rt = Jt + RSBA_MT_TILE * 144;   // [TILE][8]
+  int* sl = (int*)(rt + RSBA_MT_TILE * 8);  // [TILE][2] slots, then the time's slot columns [d / 6]
+  int* scol = sl + 2 * RSBA_MT_TILE;
+  double* P = a.part + (size_t)blockIdx.x * RL.size();
+  for (size_t e = tid; e < RL.size(); e += 256) P[e] = 0.0;
+  double cost = 0.0, xn2 = 0.0, gmax = 0.0, fail = 0.0;   // thread 0's running sums over the chunk's times
+  __threadfence_block();
+  __syncthreads();
+
+  for (int t = a.chunk_ptr[blockIdx.x]; t < a.chunk_ptr[blockIdx.x + 1]; ++t) {
+    const int o0 = a.time_ptr[t], nobs = a.time_ptr[t + 1] - o0;
+    const int s0 = a.slot_ptr[t], nslot = a.slot_ptr[t + 1] - s0, d = 6 * nslot;
+    for (int e = tid; e < 6 * d; e += 256) W[e] = 0.0;
+    for (int e = tid; e < d; e += 256) Gr[e] = 0.0;
+    if (tid < 42) Vs[tid] = 0.0;
+    for (int e = tid; e < nslot; e += 256) scol[e] = a.slot_col[s0 + e];
+    const int ntile = (nobs + RSBA_MT_TILE - 1) / RSBA_MT_TILE;
+    auto stage = [&](int tile) {
+      const int b0 = o0 + tile * RSBA_MT_TILE, nb = min(RSBA_MT_TILE, nobs - tile * RSBA_MT_TILE);
+      __syncthreads();   // the previous tile has been consumed
+      for (int e = tid; e < nb * 144; e += 256) Jt[e] = a.J[(size_t)b0 * 144 + e];
+      for (int e = tid; e < nb * 8; e += 256) rt[e] = a.r[(size_t)b0 * 8 + e];
+      for (int e = tid; e < nb; e += 256) { sl[2 * e] = a.ts[b0 + e].slot_cam; sl[2 * e + 1] = a.ts[b0 + e].slot_marker; }
+      __syncthreads();
+      return nb;
+    };
+    // ---- pass 1: V, g_t, W = J_t' J_r, reduced gradient
+    for (int tile = 0; tile < ntile; ++tile) {
+      const int nb = stage(tile);
+      for (int e = tid; e < 42 + 7 * d; e += 256) {
+        double acc = 0.0;
+        if (e < 36) {
+          const int x = e / 6, y = e - 6 * x;
+          for (int i = 0; i < nb; ++i)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += Jt[i * 144 + q * 18 + 6 + x] * Jt[i * 144 + q * 18 + 6 + y];
+          Vs[e] += acc;
+        } else if (e < 42) {
+          const int x = e - 36;
+          for (int i = 0; i < nb; ++i)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += Jt[i * 144 + q * 18 + 6 + x] * rt[i * 8 + q];
+          Vs[e] += acc;
+        } else if (e < 42 + 6 * d) {
+          const int k = e - 42, x = k / d, col = k - x * d, s = col / 6, cq = col - 6 * s;
+          for (int i = 0; i < nb; ++i) {
+            const int jc = LocalColumn(s, cq, sl[2 * i], sl[2 * i + 1]);
+            if (jc < 0) continue;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += Jt[i * 144 + q * 18 + 6 + x] * Jt[i * 144 + q * 18 + jc];
+          }
+          W[k] += acc;
+        } else {
+          const int col = e - 42 - 6 * d, s = col / 6, cq = col - 6 * s;
+          for (int i = 0; i < nb; ++i) {
+            const int jc = LocalColumn(s, cq, sl[2 * i], sl[2 * i + 1]);
+            if (jc < 0) continue;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += Jt[i * 144 + q * 18 + jc] * rt[i * 8 + q];
+          }
+          Gr[col] += acc;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- E = (V + D)^-1, E g_t
+    if (tid == 0) {
+      double Vd[36], E[36];
+      const int tf = a.time_full[t];
+      for (int x = 0; x < 6; ++x) {
+        double s;
+        if (a.ip.first) { s = a.ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(Vs[7 * x])) : 1.0; a.scale_t[6 * t + x] = s; }
+        else s = a.scale_t[6 * t + x];
+        for (int y = 0; y < 6; ++y) Vd[6 * x + y] = Vs[6 * x + y];
+        const double s2 = s * s;
+        Vd[7 * x] += fmin(fmax(s2 * Vs[7 * x], a.ip.min_lm_diagonal), a.ip.max_lm_diagonal) / (a.ip.radius * s2);
+        gmax = fmax(gmax, fabs(Vs[36 + x]));
+        const double xv = a.params_x[tf + x];
+        xn2 += xv * xv;
+      }
+      if (!InvertSpd6(Vd, E)) fail += 1.0;
+      for (int e = 0; e < 36; ++e) { Vs[48 + e] = E[e]; a.tdata[(size_t)t * 48 + e] = E[e]; }
+      for (int x = 0; x < 6; ++x) {
+        double s = 0.0;
+        for (int y = 0; y < 6; ++y) s += E[6 * x + y] * Vs[36 + y];
+        Vs[84 + x] = s;
+        a.tdata[(size_t)t * 48 + 36 + x] = Vs[36 + x];
+      }
+      for (int i = 0; i < nobs; ++i) cost += a.sumsq[o0 + i];
+    }
+    __syncthreads();
+    for (int e = tid; e < 6 * d; e += 256) {
+      const int x = e / d, col = e - x * d;
+      double s = 0.0;
+#pragma unroll
+      for (int y = 0; y < 6; ++y) s += Vs[48 + 6 * x + y] * W[y * d + col];
+      Y[e] = s;
+    }
+    __syncthreads();
+    // ---- pass 2: the time's block of U - W'Y into the private partial system (lower triangle: slots ascend)
+    for (int tile = 0; tile < ntile; ++tile) {
+      const int nb = ntile == 1 ? nobs : stage(tile);   // a single tile is still staged
+      const bool last = tile == ntile - 1;
+      for (int e = tid; e < d * d; e += 256) {
+        const int row = e / d, col = e - row * d;
+        if (col > row) continue;
+        const int rs = row / 6, rq = row - 6 * rs, cs = col / 6, cq = col - 6 * cs;
+        double u = 0.0;
+        for (int i = 0; i < nb; ++i) {
+          const int jr = LocalColumn(rs, rq, sl[2 * i], sl[2 * i + 1]);
+          const int jc = LocalColumn(cs, cq, sl[2 * i], sl[2 * i + 1]);
+          if (jr < 0 || jc < 0) continue;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) u += Jt[i * 144 + q * 18 + jr] * Jt[i * 144 + q * 18 + jc];
+        }
+        const int gr = scol[rs] + rq, gc = scol[cs] + cq;
+        if (row == col) P[RL.diagU() + gr] += u;
+        if (last) {
+          double wy = 0.0;
+#pragma unroll
+          for (int x = 0; x < 6; ++x) wy += W[x * d + row] * Y[x * d + col];
+          u -= wy;
+        }
+        P[RL.S() + (size_t)gr * nr + gc] += u;
+      }
+    }
+    for (int e = tid; e < d; e += 256) {
+      const int s = e / 6, gcol = scol[s] + (e - 6 * s);
+      double c = 0.0;
+#pragma unroll
+      for (int x = 0; x < 6; ++x) c += W[x * d + e] * Vs[84 + x];
+      P[RL.gc() + gcol] += Gr[e];
+      P[RL.corr() + gcol] -= c;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (tid == 0) { P[RL.scal() + 0] = cost; P[RL.scal() + 1] = xn2; P[RL.scal() + 2] = fail; P[RL.scal() + 3] = gmax; }
+}
+
+// Partial systems -> red (full symmetric S | gc | corr | diagU | scal), chunk order.
+__global__ void __launch_bounds__(256)
+k_marker_reduce(int nr, int G, const double* __restrict__ part, double* __restrict__ red) {
+  const RedLayout RL{nr};
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= RL.size()) return;
+  size_t src = idx;
+  if (idx < (size_t)nr * nr) { const size_t i = idx / nr, j = idx - i * nr; src = i >= j ? idx : j * nr + i; }
+  const bool is_max = idx == RL.scal() + 3;
+  double s = 0.0;
+  for (int g = 0; g < G; ++g) { const double v = part[(size_t)g * RL.size() + src]; s = is_max ? fmax(s, v) : s + v; }
+  red[idx] = s;
+}
+
+// Step of the reduced blocks from the solution y of the scaled system; candidate parameters; norms.
+//   out[0..4] = |delta_r|^2, |x_r|^2, |x_r + delta_r|^2, max |g_r|, factorisation ok
+__device__ __forceinline__ void ReducedStepEpilogue(int nr, const double* __restrict__ red, RedLayout RL, const double* __restrict__ scale_r,
+                                                    const double* __restrict__ ysol, const int* __restrict__ col_full,
+                                                    const double* __restrict__ params_x, double* __restrict__ params_c,
+                                                    double* __restrict__ delta_r, double* __restrict__ out, int ok, double* scr) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double d2 = 0, x2 = 0, xc2 = 0, gm = 0;
+  for (int i = tid; i < nr; i += nt) {
+    const double dd = -scale_r[i] * ysol[i];
+    delta_r[i] = dd;
+    const double x = params_x[col_full[i]], xc = x + dd;
+    params_c[col_full[i]] = xc;
+    d2 += dd * dd; x2 += x * x; xc2 += xc * xc; gm = fmax(gm, fabs(red[RL.gc() + i]));
+  }
+  __syncthreads();
+  scr[tid] = d2; scr[nt + tid] = x2; scr[2 * nt + tid] = xc2; scr[3 * nt + tid] = gm;
+  __syncthreads();
+  for (int off = nt / 2; off > 0; off >>= 1) {
+    if (tid < off) {
+      scr[tid] += scr[tid + off]; scr[nt + tid] += scr[nt + tid + off]; scr[2 * nt + tid] += scr[2 * nt + tid + off];
+      scr[3 * nt + tid] = fmax(scr[3 * nt + tid], scr[3 * nt + tid + off]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { out[0] = scr[0]; out[1] = scr[nt]; out[2] = scr[2 * nt]; out[3] = scr[3 * nt]; out[4] = ok ? 1.0 : 0.0; }
+}
+
+__global__ void __launch_bounds__(512)
+k_marker_reduced_solve(int nr, const double* __restrict__ red, double* __restrict__ A, double* __restrict__ scale_r,
+                       const int* __restrict__ col_full, const double* __restrict__ params_x, double* __restrict__ params_c,
+                       double* __restrict__ delta_r, double* __restrict__ out, IterParams ip) {
+  extern __shared__ double lds[];
+  const RedLayout RL{nr};
+  const int tid = threadIdx.x, nt = blockDim.x;
+  __shared__ int s_ok;
+  for (int i = tid; i < nr; i += nt)
+    if (ip.first) scale_r[i] = ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(red[RL.diagU() + i])) : 1.0;
+  __threadfence_block();
+  __syncthreads();
+  for (int i = tid; i < nr; i += nt) A[(size_t)nr * nr + i] = scale_r[i] * (red[RL.gc() + i] + red[RL.corr() + i]);
+  __threadfence_block();
+  __syncthreads();
+  double* ysol = A + (size_t)nr * nr;
+  CholeskySolvePanelLDS(nr, A, ysol, &s_ok, lds,
+                        PanelSource{red + RL.S(), scale_r, red + RL.diagU(), ip.min_lm_diagonal, ip.max_lm_diagonal, 1.0 / ip.radius, nullptr, nullptr, 0},
+                        StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0});
+  __syncthreads();
+  ReducedStepEpilogue(nr, red, RL, scale_r, ysol, col_full, params_x, params_c, delta_r, out, s_ok > 0, lds);
+}
+
+__global__ void __launch_bounds__(1024)
+k_marker_chol_finish(int nr, const double* __restrict__ red, double* __restrict__ F, const double* __restrict__ scale_r,
+                     const int* __restrict__ col_full, const double* __restrict__ params_x, double* __restrict__ params_c,
+                     double* __restrict__ delta_r, double* __restrict__ out, const int* __restrict__ ok_flag) {
+  extern __shared__ double lds[];
+  const RedLayout RL{nr};
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double* y = BackSubstituteBlocks(nr, F, lds);
+  double* ysol = F + (size_t)nr * nr;
+  for (int i = tid; i < nr; i += nt) ysol[i] = y[i];
+  __threadfence_block();
+  __syncthreads();
+  ReducedStepEpilogue(nr, red, RL, scale_r, ysol, col_full, params_x, params_c, delta_r, out, *ok_flag, lds);
+}
+
+// delta_t = -E (g_t + sum J_t' (J_c delta_c + J_m delta_m)); candidate time poses; per-workgroup norms.
+__global__ void __launch_bounds__(64)
+k_time_backsub(int T, const int* __restrict__ time_ptr, const int* __restrict__ time_full, const TimeSlots* __restrict__ ts,
+               const double* __restrict__ J, const double* __restrict__ tdata, const double* __restrict__ delta_r,
+               const double* __restrict__ params_x, double* __restrict__ params_c, double* __restrict__ delta_t,
+               double* __restrict__ bpart /* gridDim.x x 4 */) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  double d2 = 0, xc2 = 0;
+  if (t < T) {
+    double h[6];
+    for (int x = 0; x < 6; ++x) h[x] = tdata[(size_t)t * 48 + 36 + x];
+    for (int i = time_ptr[t]; i < time_ptr[t + 1]; ++i) {
+      const TimeSlots s = ts[i];
+      double dc[6], dm[6];
+      for (int x = 0; x < 6; ++x) { dc[x] = s.col_cam >= 0 ? delta_r[s.col_cam + x] : 0.0; dm[x] = s.col_marker >= 0 ? delta_r[s.col_marker + x] : 0.0; }
+      const double* Ji = J + (size_t)i * 144;
+      for (int q = 0; q < 8; ++q) {
+        double m = 0.0;
+        for (int x = 0; x < 6; ++x) m += Ji[q * 18 + x] * dc[x] + Ji[q * 18 + 12 + x] * dm[x];
+        for (int x = 0; x < 6; ++x) h[x] += Ji[q * 18 + 6 + x] * m;
+      }
+    }
+    const int tf = time_full[t];
+    for (int x = 0; x < 6; ++x) {
+      double s = 0.0;
+      for (int y = 0; y < 6; ++y) s += tdata[(size_t)t * 48 + 6 * x + y] * h[y];
+      const double dd = -s, xv = params_x[tf + x], xc = xv + dd;
+      delta_t[6 * t + x] = dd;
+      params_c[tf + x] = xc;
+      d2 += dd * dd; xc2 += xc * xc;
+    }
+  }
+  // fixed-order sums inside the wavefront, then per workgroup
+  for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_down(d2, off, 64); xc2 += __shfl_down(xc2, off, 64); }
+  if (threadIdx.x == 0) { bpart[4 * blockIdx.x] = d2; bpart[4 * blockIdx.x + 1] = xc2; }
+}
+
+// Per residual block: model cost change -(J d).(r + J d / 2) and the candidate's squared residuals.
+__global__ void __launch_bounds__(256)
+k_marker_obs_terms(int N, const int* __restrict__ obs_time, const TimeSlots* __restrict__ ts, const double* __restrict__ J,
+                   const double* __restrict__ r, const double* __restrict__ delta_r, const double* __restrict__ delta_t,
+                   const double* __restrict__ sumsq_c, double* __restrict__ bpart /* gridDim.x x 2 */) {
+  __shared__ double s[2][256];
+  const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+  double mcc = 0, cc = 0;
+  if (i < N) {
+    const TimeSlots o = ts[i];
+    const int t = obs_time[i];
+    double dl[18];
+    for (int x = 0; x < 6; ++x) {
+      dl[x] = o.col_cam >= 0 ? delta_r[o.col_cam + x] : 0.0;
+      dl[6 + x] = delta_t[6 * t + x];
+      dl[12 + x] = o.col_marker >= 0 ? delta_r[o.col_marker + x] : 0.0;
+    }
+    const double* Ji = J + (size_t)i * 144;
+    for (int q = 0; q < 8; ++q) {
+      double m = 0.0;
+#pragma unroll
+      for (int x = 0; x < 18; ++x) m += Ji[q * 18 + x] * dl[x];
+      mcc -= m * (r[(size_t)i * 8 + q] + 0.5 * m);
+    }
+    cc = sumsq_c[i];
+  }
+  s[0][tid] = mcc; s[1][tid] = cc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (tid < off) { s[0][tid] += s[0][tid + off]; s[1][tid] += s[1][tid + off]; } __syncthreads(); }
+  if (tid == 0) { bpart[2 * blockIdx.x] = s[0][0]; bpart[2 * blockIdx.x + 1] = s[1][0]; }
+}
+
+__global__ void __launch_bounds__(256)
+k_marker_schur_finish(int nb_time, const double* __restrict__ bp_time, int nb_obs, const double* __restrict__ bp_obs,
+                      const double* __restrict__ red_scal, const double* __restrict__ solve_out, double* __restrict__ res) {
+  __shared__ double s[4][256];
+  const int tid = threadIdx.x;
+  double v[4] = {0, 0, 0, 0};
+  for (int b = tid; b < nb_time; b += 256) { v[0] += bp_time[4 * b]; v[1] += bp_time[4 * b + 1]; }
+  for (int b = tid; b < nb_obs; b += 256) { v[2] += bp_obs[2 * b]; v[3] += bp_obs[2 * b + 1]; }
+  for (int k = 0; k < 4; ++k) s[k][tid] = v[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (tid < off) for (int k = 0; k < 4; ++k) s[k][tid] += s[k][tid + off]; __syncthreads(); }
+  if (tid == 0) {
+    res[RES_COST_X] = 0.5 * red_scal[0];
+    res[RES_GMAX] = fmax(red_scal[3], solve_out[3]);
+    res[RES_XNORM2] = red_scal[1] + solve_out[1];
+    res[RES_POINT_FAIL] = red_scal[2];
+    res[RES_CHOL_OK] = (solve_out[4] != 0.0 && red_scal[2] == 0.0) ? 1.0 : 0.0;
+    res[RES_STEP2] = solve_out[0] + s[0][0];
+    res[RES_XCNORM2] = solve_out[2] + s[1][0];
+    res[RES_MCC] = s[2][0];
+    double c = 0.5 * s[3][0];
+    if (!(c == c) || !(fabs(c) <= DBL_MAX)) c = DBL_MAX;
+    res[RES_COST_C] = c;
+    res[RES_SUMSQ_C] = s[3][0];
+    res[RES_STALL] = 0.0; res[RES_WAIT_TIMEOUT] = 0.0;
+  }
+}
+
+struct MarkerSchurDevice {
+  int N = 0, T = 0, nr = 0, nfull = 0, G = 0, dmax = 0, nb_time = 0, nb_obs = 0;
+  double half_side = 0;
+  MarkerObs* mo = nullptr;
+  TimeSlots* ts = nullptr;
+  int *chunk_ptr = nullptr, *time_ptr = nullptr, *slot_ptr = nullptr, *slot_col = nullptr, *time_full = nullptr, *col_full = nullptr,
+      *obs_time = nullptr, *ok_flag = nullptr;
+  double *obs8 = nullptr, *intr = nullptr, *params[2] = {nullptr, nullptr}, *params0 = nullptr;
+  double *Jbuf = nullptr, *rbuf = nullptr, *ss_x = nullptr, *ss_c = nullptr, *scale_t = nullptr, *scale_r = nullptr, *tdata = nullptr,
+         *part = nullptr, *red = nullptr, *A = nullptr, *Wm = nullptr, *delta_r = nullptr, *delta_t = nullptr, *bp_time = nullptr,
+         *bp_obs = nullptr, *solve_out = nullptr, *res = nullptr;
+  int cur = 0;
+  size_t lds_elim = 0;
+
+  void Free() {
+    void* ptrs[] = {mo, ts, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, obs_time, ok_flag, obs8, intr, params[0], params[1],
+                    params0, Jbuf, rbuf, ss_x, ss_c, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, bp_obs, solve_out, res};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    mo = nullptr; ts = nullptr;
+  }
+
+  // true when the problem should take this path (schur_impl: 0 never, 1 when the dense system outgrows one workgroup, 2 always)
+  static bool Wanted(const rsba_problem& p, int schur_impl) {
+    if (schur_impl == 0) return false;
+    if (schur_impl >= 2) return true;
+    const int nblocks = p.num_cameras + p.num_times + p.num_markers;
+    return 6 * nblocks > RSBA_CHOL_MAXN;
+  }
+
+  int Upload(const rsba_problem& p) {
+    N = (int)p.num_observations; nfull = (int)p.parameters.size(); half_side = p.marker_side / 2;
+    if (N <= 0) return RSBA_ERR_ARG;
+    const int C = p.num_cameras, Tn = p.num_times, M = p.num_markers;
+    // reduced blocks: the cameras and markers some residual uses, cameras first
+    std::vector<int> red_col(C + M, -1);
+    std::vector<char> used(C + M, 0), tused(Tn, 0);
+    for (int i = 0; i < N; ++i) {
+      if (p.uses_camera(i)) used[p.camera_index[i]] = 1;
+      if (p.uses_marker(i)) used[C + p.marker_index[i]] = 1;
+      tused[p.time_index[i]] = 1;
+    }
+    std::vector<int> cf;
+    int K = 0;
+    for (int b = 0; b < C + M; ++b) if (used[b]) {
+      red_col[b] = 6 * K++;
+      const int full = 6 * (b < C ? b : Tn + b);   // [C | T | M] x 6
+      for (int q = 0; q < 6; ++q) cf.push_back(full + q);
+    }
+    nr = 6 * K;
+    if (nr == 0) return RSBA_ERR_UNSUPPORTED;   // nothing but time blocks: the dense path handles it
+    std::vector<int> tid_of(Tn, -1), tfull;
+    T = 0;
+    for (int t = 0; t < Tn; ++t) if (tused[t]) { tid_of[t] = T++; tfull.push_back(6 * (C + t)); }
+    // residual blocks in time order (stable)
+    std::vector<int> order(N);
+    for (int i = 0; i < N; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return p.time_index[x] < p.time_index[y]; });
+    std::vector<int> tptr(T + 1, 0), sptr(T + 1, 0), scol, otime(N);
+    std::vector<MarkerObs> hmo(N);
+    std::vector<TimeSlots> hts(N);
+    std::vector<double> hobs(8 * (size_t)N);
+    for (int k = 0; k < N; ++k) tptr[tid_of[p.time_index[order[k]]] + 1]++;
+    for (int t = 0; t < T; ++t) tptr[t + 1] += tptr[t];
+    dmax = 0;
+    std::vector<double> work(T);
+    for (int t = 0; t < T; ++t) {
+      std::vector<int> cols;
+      for (int k = tptr[t]; k < tptr[t + 1]; ++k) {
+        const int i = order[k];
+        if (p.uses_camera(i)) cols.push_back(red_col[p.camera_index[i]]);
+        if (p.uses_marker(i)) cols.push_back(red_col[C + p.marker_index[i]]);
+      }
+      std::sort(cols.begin(), cols.end());
+      cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+      for (int k = tptr[t]; k < tptr[t + 1]; ++k) {
+        const int i = order[k];
+        MarkerObs& o = hmo[k];
+        o.full_cam = p.uses_camera(i) ? 6 * p.camera_block(i) : -1; o.full_time = 6 * p.time_block(i);
+        o.full_marker = p.uses_marker(i) ? 6 * p.marker_block(i) : -1;
+        o.act_cam = o.act_time = o.act_marker = -1; o.camera = p.camera_index[i]; o.pad = 0;
+        TimeSlots& s = hts[k];
+        s.col_cam = p.uses_camera(i) ? red_col[p.camera_index[i]] : -1;
+        s.col_marker = p.uses_marker(i) ? red_col[C + p.marker_index[i]] : -1;
+        s.slot_cam = s.col_cam >= 0 ? (int)(std::lower_bound(cols.begin(), cols.end(), s.col_cam) - cols.begin()) : -1;
+        s.slot_marker = s.col_marker >= 0 ? (int)(std::lower_bound(cols.begin(), cols.end(), s.col_marker) - cols.begin()) : -1;
+        otime[k] = t;
+        memcpy(&hobs[8 * (size_t)k], &p.observations[8 * (size_t)i], 8 * sizeof(double));
+      }
+      sptr[t + 1] = sptr[t] + (int)cols.size();
+      scol.insert(scol.end(), cols.begin(), cols.end());
+      const int d = 6 * (int)cols.size();
+      dmax = std::max(dmax, d);
+      work[t] = (double)d * d * (1.0 + 0.25 * (tptr[t + 1] - tptr[t])) + 2000.0;
+    }
+    if (dmax > RSBA_MT_MAXD) return RSBA_ERR_UNSUPPORTED;
+    // chunks of consecutive times, balanced by work; the partial systems together stay below 2 GB
+    const RedLayout RL{nr};
+    const size_t cap = std::max<size_t>(1, ((size_t)2 << 30) / (RL.size() * sizeof(double)));
+    G = (int)std::min<size_t>(std::min<size_t>((size_t)T, 1024), cap);
+    std::vector<int> cptr(G + 1, 0);
+    {
+      double total = 0; for (double w : work) total += w;
+      double acc = 0; int g = 0;
+      for (int t = 0; t < T; ++t) {
+        acc += work[t];
+        // close chunk g when it has its share and enough times remain for the others
+        while (g < G - 1 && acc >= total * (g + 1) / G && T - (t + 1) >= G - 1 - g) cptr[++g] = t + 1;
+      }
+      while (g < G) cptr[++g] = T;
+      // chunks may not be empty in the middle: compact
+      std::vector<int> c2; c2.push_back(0);
+      for (int k = 1; k <= G; ++k) if (cptr[k] > c2.back()) c2.push_back(cptr[k]);
+      G = (int)c2.size() - 1; cptr = c2;
+    }
+    nb_time = (T + 63) / 64; nb_obs = (N + 255) / 256;
+    lds_elim = (size_t)(13 * dmax + 96 + RSBA_MT_TILE * 152) * sizeof(double) + (size_t)(2 * RSBA_MT_TILE + dmax / 6 + 2) * sizeof(int);
+    auto al = [](void** q, size_t bytes) { return hipMalloc(q, std::max<size_t>(bytes, 8)) == hipSuccess; };
+    const size_t nA = (size_t)(nr + 2) * nr;
+    if (!al((void**)&mo, N * sizeof(MarkerObs)) || !al((void**)&ts, N * sizeof(TimeSlots)) || !al((void**)&chunk_ptr, (G + 1) * 4) ||
+        !al((void**)&time_ptr, (T + 1) * 4) || !al((void**)&slot_ptr, (T + 1) * 4) || !al((void**)&slot_col, scol.size() * 4) ||
+        !al((void**)&time_full, T * 4) || !al((void**)&col_full, nr * 4) || !al((void**)&obs_time, N * 4) || !al((void**)&ok_flag, 4) ||
+        !al((void**)&obs8, 8 * (size_t)N * 8) || !al((void**)&intr, p.intrinsics.size() * 8) || !al((void**)&params[0], nfull * 8) ||
+        !al((void**)&params[1], nfull * 8) || !al((void**)&params0, nfull * 8) || !al((void**)&Jbuf, (size_t)N * 144 * 8) ||
+        !al((void**)&rbuf, (size_t)N * 8 * 8) || !al((void**)&ss_x, N * 8) || !al((void**)&ss_c, N * 8) || !al((void**)&scale_t, 6 * (size_t)T * 8) ||
+        !al((void**)&scale_r, nr * 8) || !al((void**)&tdata, 48 * (size_t)T * 8) || !al((void**)&part, (size_t)G * RL.size() * 8) ||
+        !al((void**)&red, RL.size() * 8) || !al((void**)&A, nA * 8) || (nr > RSBA_CHOL_MAXN && !al((void**)&Wm, nA * 8)) ||
+        !al((void**)&delta_r, nr * 8) || !al((void**)&delta_t, 6 * (size_t)T * 8) || !al((void**)&bp_time, 4 * (size_t)nb_time * 8) ||
+        !al((void**)&bp_obs, 2 * (size_t)nb_obs * 8) || !al((void**)&solve_out, 8 * 8) || !al((void**)&res, RES_SIZE * 8))
+      return RSBA_ERR_HIP;
+    auto up = [](void* d, const void* h, size_t bytes) { return bytes == 0 || hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) == hipSuccess; };
+    if (!up(mo, hmo.data(), N * sizeof(MarkerObs)) || !up(ts, hts.data(), N * sizeof(TimeSlots)) || !up(chunk_ptr, cptr.data(), (G + 1) * 4) ||
+        !up(time_ptr, tptr.data(), (T + 1) * 4) || !up(slot_ptr, sptr.data(), (T + 1) * 4) || !up(slot_col, scol.data(), scol.size() * 4) ||
+        !up(time_full, tfull.data(), T * 4) || !up(col_full, cf.data(), nr * 4) || !up(obs_time, otime.data(), N * 4) ||
+        !up(obs8, hobs.data(), 8 * (size_t)N * 8) || !up(intr, p.intrinsics.data(), p.intrinsics.size() * 8) ||
+        !up(params0, p.parameters.data(), nfull * 8))
+      return RSBA_ERR_HIP;
+    if (hipMemset(res, 0, RES_SIZE * 8) != hipSuccess) return RSBA_ERR_HIP;
+    if (lds_elim > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)k_time_eliminate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_elim) != hipSuccess) return RSBA_ERR_HIP;
+    if (nr <= RSBA_CHOL_MAXN) {
+      const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(nr)) * sizeof(double);
+      if (lds_c > 48 * 1024 &&
+          hipFuncSetAttribute((const void*)k_marker_reduced_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return RSBA_ERR_HIP;
+    } else {
+      if (hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CholStepLdsDoubles() * sizeof(double))) != hipSuccess)
+        return RSBA_ERR_HIP;
+    }
+    return RSBA_OK;
+  }
+  int Reset(hipStream_t st) {
+    if (hipMemcpyAsync(params[0], params0, nfull * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return RSBA_ERR_HIP;
+    if (hipMemcpyAsync(params[1], params0, nfull * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return RSBA_ERR_HIP;
+    cur = 0;
+    return RSBA_OK;
+  }
+  void Accept() { cur = 1 - cur; }
+
+  template <typename Timer>
+  int Step(hipStream_t st, const rsba_options& o, double radius, bool first, double* res_host, Timer& Tm) {
+    IterParams ip;
+    ip.radius = radius; ip.min_lm_diagonal = o.min_lm_diagonal; ip.max_lm_diagonal = o.max_lm_diagonal; ip.huber_delta = 0.0;
+    ip.first = first ? 1 : 0; ip.jacobi_scaling = o.jacobi_scaling;
+    const int x = cur, c = 1 - cur;
+    if (hipMemcpyAsync(params[c], params[x], nfull * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return RSBA_ERR_HIP;
+    auto chk = [&](const char* what) {
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) { fprintf(stderr, "rsba: %s launch failed: %s\n", what, hipGetErrorString(e)); return false; }
+      return true;
+    };
+    if (!chk("(before marker step)")) return RSBA_ERR_HIP;
+    const RedLayout RL{nr};
+    Tm.Begin("k_marker_eval", st);
+    k_marker_eval<<<(N + 63) / 64, 64, 0, st>>>(N, mo, obs8, params[x], intr, half_side, 1, Jbuf, rbuf, ss_x);
+    Tm.End(st);
+    ElimArgs ea{nr, dmax, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, ts, Jbuf, rbuf, ss_x, params[x], scale_t, tdata, part, ip};
+    Tm.Begin("k_time_eliminate", st);
+    k_time_eliminate<<<G, 256, lds_elim, st>>>(ea);
+    Tm.End(st);
+    if (!chk("k_time_eliminate")) return RSBA_ERR_HIP;
+    Tm.Begin("k_marker_reduce", st);
+    k_marker_reduce<<<(unsigned)((RL.size() + 255) / 256), 256, 0, st>>>(nr, G, part, red);
+    Tm.End(st);
+    if (nr <= RSBA_CHOL_MAXN) {
+      const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(nr)) * sizeof(double);
+      Tm.Begin("k_marker_reduced_solve", st);
+      k_marker_reduced_solve<<<1, 512, lds_c, st>>>(nr, red, A, scale_r, col_full, params[x], params[c], delta_r, solve_out, ip);
+      Tm.End(st);
+    } else {
+      Tm.Begin("k_sys_build", st);
+      k_sys_build<<<nr + 1, 256, 0, st>>>(red, RL, Wm, nullptr, nullptr, scale_r, ip, 1, ok_flag);
+      Tm.End(st);
+      const size_t lds_s = CholStepLdsDoubles() * sizeof(double);
+      Tm.Begin("k_chol_step(all panels)", st);
+      for (int kb = 0; kb < nr; kb += RSBA_PB) {
+        const int r0 = kb + std::min(RSBA_PB, nr - kb);
+        const int nrt = (nr + 1 - r0 + RSBA_CT - 1) / RSBA_CT;
+        k_chol_step<<<nrt * (nrt + 1) / 2, 256, lds_s, st>>>(nr, kb, Wm, A, ok_flag);
+      }
+      Tm.End(st);
+      const size_t lds_f = std::max((size_t)4 * 1024, (size_t)((nr + 63) & ~63) + 3 * RSBA_PB * RSBA_PLD + 64) * sizeof(double);
+      Tm.Begin("k_marker_chol_finish", st);
+      k_marker_chol_finish<<<1, 1024, lds_f, st>>>(nr, red, A, scale_r, col_full, params[x], params[c], delta_r, solve_out, ok_flag);
+      Tm.End(st);
+    }
+    if (!chk("reduced solve")) return RSBA_ERR_HIP;
+    Tm.Begin("k_time_backsub", st);
+    k_time_backsub<<<nb_time, 64, 0, st>>>(T, time_ptr, time_full, ts, Jbuf, tdata, delta_r, params[x], params[c], delta_t, bp_time);
+    Tm.End(st);
+    Tm.Begin("k_marker_eval", st);
+    k_marker_eval<<<(N + 63) / 64, 64, 0, st>>>(N, mo, obs8, params[c], intr, half_side, 0, nullptr, nullptr, ss_c);
+    Tm.End(st);
+    Tm.Begin("k_marker_obs_terms", st);
+    k_marker_obs_terms<<<nb_obs, 256, 0, st>>>(N, obs_time, ts, Jbuf, rbuf, delta_r, delta_t, ss_c, bp_obs);
+    Tm.End(st);
+    Tm.Begin("k_marker_schur_finish", st);
+    k_marker_schur_finish<<<1, 256, 0, st>>>(nb_time, bp_time, nb_obs, bp_obs, red + RL.scal(), solve_out, res);
+    Tm.End(st);
+    if (!chk("k_marker_schur_finish")) return RSBA_ERR_HIP;
+    if (hipMemcpyAsync(res_host, res, RES_SIZE * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return RSBA_ERR_HIP;
+    { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) { fprintf(stderr, "rsba: marker-chain step failed: %s\n", hipGetErrorString(e)); return RSBA_ERR_HIP; } }
+    return RSBA_OK;
+  }
+  int SumSquares(hipStream_t st, double* out) {
+    if (Reset(st) != RSBA_OK) return RSBA_ERR_HIP;
+    k_marker_eval<<<(N + 63) / 64, 64, 0, st>>>(N, mo, obs8, params[0], intr, half_side, 0, nullptr, nullptr, ss_x);
+    std::vector<double> h(N);
+    if (hipMemcpyAsync(h.data(), ss_x, N * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return RSBA_ERR_HIP;
+    double s = 0; for (double v : h) s += v;
+    *out = s;
+    return RSBA_OK;
+  }
+  int Download(rsba_problem* p) {
+    if (hipMemcpy(p->parameters.data(), params[cur], nfull * 8, hipMemcpyDeviceToHost) != hipSuccess) return RSBA_ERR_HIP;
+    return RSBA_OK;
+  }
+};
+
+}  // namespace rsba

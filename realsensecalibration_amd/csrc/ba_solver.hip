@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "ba_marker_kernels.hpp"
+#include "ba_marker_schur.hpp"
 #include "ba_point_kernels.hpp"
 #include "ba_cholesky_large.hpp"
 #include "ba_problem.hpp"
@@ -168,6 +169,8 @@ struct rsba_solver {
 
   // ---- marker-chain model
   MarkerDevice marker;
+  MarkerSchurDevice marker_schur;   // time blocks eliminated: the marker-chain model at scale
+  bool eliminate_times = false;
 };
 
 namespace rsba {
@@ -368,6 +371,7 @@ static void FreeSolver(rsba_solver* s) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
+  s->marker_schur.Free();
   if (s->res_host) (void)hipHostFree(s->res_host);
   if (s->trace) (void)hipFree(s->trace);
   if (s->wg_trace) (void)hipFree(s->wg_trace);
@@ -962,7 +966,10 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
   }
   if (hipHostMalloc((void**)&s->res_host, RES_SIZE * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { rsba::FreeSolver(s); return RSBA_ERR_HIP; }
   if (p->model == RSBA_MODEL_POINTS) rc = rsba::UploadPoints(s);
-  else rc = s->marker.Upload(*p);
+  else {
+    s->eliminate_times = rsba::MarkerSchurDevice::Wanted(*p, opt.schur_impl);
+    rc = s->eliminate_times ? s->marker_schur.Upload(*p) : s->marker.Upload(*p);
+  }
   if (rc == RSBA_OK && hipDeviceSynchronize() != hipSuccess) rc = RSBA_ERR_HIP;
   if (rc != RSBA_OK) { rsba::FreeSolver(s); return rc; }
   s->setup_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -993,11 +1000,15 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
       }
     }
   } else {
-    if ((rc = s->marker.Reset(s->stream)) != RSBA_OK) return rc;
+    if ((rc = s->eliminate_times ? s->marker_schur.Reset(s->stream) : s->marker.Reset(s->stream)) != RSBA_OK) return rc;
     if (hipStreamSynchronize(s->stream) != hipSuccess) return RSBA_ERR_HIP;
     const auto t0 = std::chrono::steady_clock::now();
-    rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { return s->marker.Step(s->stream, s->opt, radius, first, s->res_host, s->timer); },
-                            [&]() { s->marker.Accept(); });
+    if (s->eliminate_times)
+      rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { return s->marker_schur.Step(s->stream, s->opt, radius, first, s->res_host, s->timer); },
+                              [&]() { s->marker_schur.Accept(); });
+    else
+      rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { return s->marker.Step(s->stream, s->opt, radius, first, s->res_host, s->timer); },
+                              [&]() { s->marker.Accept(); });
     sum.minimizer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
   s->timer.Collect();
@@ -1015,7 +1026,7 @@ int rsba_solver_download(rsba_solver* s) {
     if (hipMemcpy(p.parameters.data() + 6 * s->C, s->pts[s->cur], 3 * (size_t)s->P * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return RSBA_ERR_HIP;
     return RSBA_OK;
   }
-  return s->marker.Download(&p);
+  return s->eliminate_times ? s->marker_schur.Download(&p) : s->marker.Download(&p);
 }
 
 int rsba_solver_iterations(const rsba_solver* s, rsba_iteration* out, int32_t capacity) {
@@ -1125,7 +1136,7 @@ int rsba_reprojection_error(rsba_problem* p, const rsba_options* o, double* erro
       sumsq = h[4]; npts = p->num_observations;
     }
   } else {
-    rc = s->marker.SumSquares(s->stream, &sumsq);
+    rc = s->eliminate_times ? s->marker_schur.SumSquares(s->stream, &sumsq) : s->marker.SumSquares(s->stream, &sumsq);
     npts = 4 * p->num_observations;
   }
   if (rc == RSBA_OK) {

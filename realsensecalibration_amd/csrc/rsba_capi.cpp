@@ -1,4 +1,6 @@
 // C ABI: problem container, options, file formats (no device code here).  Declared in include/rsba.h.
+#include <climits>
+#include <cstdint>
 #include <cstring>
 
 #include "ba_problem.hpp"
@@ -35,6 +37,29 @@ int rsba_problem_create_points(int32_t C, int32_t P, int64_t N, const int32_t* c
   p->observations.assign(observations, observations + 2 * N);
   p->parameters.assign(parameters, parameters + 6 * (size_t)C + 3 * (size_t)P);
   p->intrinsics.assign(intrinsics, intrinsics + 4 * (size_t)C);
+  *out = p;
+  return RSBA_OK;
+}
+
+int rsba_problem_create_marker_chain(int32_t model, int32_t C, int32_t T, int32_t M, int64_t N, const int32_t* time_index,
+                                     const int32_t* camera_index, const int32_t* marker_index, const double* observations,
+                                     const double* parameters, const double* intrinsics, double marker_side, rsba_problem** out) {
+  if ((model != RSBA_MODEL_MARKER_CHAIN && model != RSBA_MODEL_MARKER_CHAIN_TEST2) || C <= 0 || T <= 0 || M <= 0 || N < 0 || N > INT32_MAX ||
+      !time_index || !camera_index || !marker_index || !observations || !parameters || !intrinsics || !(marker_side > 0.0) || !out)
+    return RSBA_ERR_ARG;
+  for (int64_t i = 0; i < N; ++i)
+    if (time_index[i] < 0 || time_index[i] >= T || camera_index[i] < 0 || camera_index[i] >= C || marker_index[i] < 0 || marker_index[i] >= M)
+      return RSBA_ERR_ARG;
+  rsba_problem* p = new rsba_problem();
+  p->model = model; p->num_cameras = C; p->num_times = T; p->num_markers = M; p->num_observations = N; p->marker_side = marker_side;
+  p->time_index.assign(time_index, time_index + N);
+  p->camera_index.assign(camera_index, camera_index + N);
+  p->marker_index.assign(marker_index, marker_index + N);
+  p->observations.assign(observations, observations + 8 * N);
+  p->parameters.assign(parameters, parameters + 6 * ((size_t)C + T + M));
+  p->intrinsics.assign(intrinsics, intrinsics + 4 * (size_t)C);
+  p->obs_per_time_camera.assign((size_t)T * C, 0);
+  for (int64_t i = 0; i < N; ++i) p->obs_per_time_camera[(size_t)time_index[i] * C + camera_index[i]]++;
   *out = p;
   return RSBA_OK;
 }

@@ -134,3 +134,64 @@ def schur_flops_per_iteration(views_per_point_counts):
     (6x3)(3x6) products (108 FMA each) + k 6x3 mat-vecs for the right-hand side."""
     k = np.asarray(views_per_point_counts, np.float64)
     return float(np.sum(k * (k + 1) / 2 * 216 + k * 36))
+
+
+# ------------------------------------------------------------------------------------------------
+# Marker-chain model (BASELINE config 1's model at larger sizes): C cameras rigidly mounted around a
+# main camera, a board carrying M ArUco markers, T shots of the board.  Layout of the reference's
+# BALProblem (Main_Calibration/bundle_adjustment.h:18-54): parameters [C | T | M] x (rvec, tvec), one
+# residual block per detected marker = row (time, camera, marker, 4 corners x (u, v)).
+def _rotate(rvec, p):
+    return np.einsum("...ij,...j->...i", _matrix_from_rotvec(rvec), p)
+
+
+def make_marker_chain(C, T, M, seed, marker_side=0.08, keep=0.9, noise_px=0.3, sigma_rvec=0.02, sigma_tvec=0.02):
+    """Returns the arrays `rsba_problem_create_marker_chain` takes (rows sorted by time, camera, marker) and the truth.
+    Camera 0 / marker 0 are the base blocks (identity, not part of the problem)."""
+    rng = np.random.default_rng([seed, 0xA2C0])
+    f = rng.uniform(600, 640, C)
+    intr = np.stack([f, f, rng.uniform(305, 335, C), rng.uniform(225, 255, C)], -1)
+    cams = np.zeros((C, 6))
+    cams[1:, :3] = rng.normal(0, 0.12, (C - 1, 3))
+    cams[1:, 3:5] = rng.uniform(-0.4, 0.4, (C - 1, 2))
+    cams[1:, 5] = rng.normal(0, 0.08, C - 1)
+    side = int(np.ceil(np.sqrt(M)))
+    marks = np.zeros((M, 6))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    cells = np.stack([gx.ravel(), gy.ravel()], -1)[:M].astype(float)
+    marks[:, 3:5] = (cells - cells[0]) * (1.6 * marker_side)
+    marks[1:, 5] = rng.normal(0, 0.01, M - 1)
+    marks[1:, :3] = rng.normal(0, 0.05, (M - 1, 3))
+    centre = marks[:, 3:].mean(0)
+    times = np.zeros((T, 6))
+    times[:, :3] = rng.normal(0, 0.25, (T, 3))
+    times[:, 3] = rng.uniform(-0.3, 0.3, T)
+    times[:, 4] = rng.uniform(-0.2, 0.2, T)
+    times[:, 5] = rng.uniform(1.2, 2.4, T)
+    times[:, 3:] -= _rotate(times[:, :3], np.broadcast_to(centre, (T, 3)))  # the board's middle, not marker 0, sits there
+    h = marker_side / 2
+    corners = np.array([[-h, h, 0.0], [h, h, 0.0], [h, -h, 0.0], [-h, -h, 0.0]])  # bundle_adjustment.h:92-101
+    rows_t, rows_c, rows_m, obs = [], [], [], []
+    # corners of every marker in the board frame: (M, 4, 3)
+    in_board = _rotate(marks[:, None, :3], corners[None]) + marks[:, None, 3:]
+    for t in range(T):
+        in_base = _rotate(times[t, :3], in_board) + times[t, 3:]  # (M, 4, 3)
+        for c in range(C):
+            pc = _rotate(cams[c, :3], in_base) + cams[c, 3:]
+            u = intr[c, 0] * pc[..., 0] / pc[..., 2] + intr[c, 2]
+            v = intr[c, 1] * pc[..., 1] / pc[..., 2] + intr[c, 3]
+            ok = (pc[..., 2] > 0.3).all(1) & (u > 0).all(1) & (u < 640).all(1) & (v > 0).all(1) & (v < 480).all(1)
+            ok &= rng.random(M) < keep
+            for m in np.nonzero(ok)[0]:
+                rows_t.append(t); rows_c.append(c); rows_m.append(m)
+                obs.append(np.stack([u[m], v[m]], -1).ravel() + rng.normal(0, noise_px, 8))
+    N = len(rows_t)
+    truth = np.concatenate([cams.ravel(), times.ravel(), marks.ravel()])
+    start = truth.reshape(-1, 6).copy()
+    jitter = np.hstack([rng.normal(0, sigma_rvec, (C + T + M, 3)), rng.normal(0, sigma_tvec, (C + T + M, 3))])
+    jitter[0] = 0.0          # base camera
+    jitter[C + T] = 0.0      # base marker
+    start += jitter
+    return {"T": T, "C": C, "M": M, "N": N, "t": np.array(rows_t, np.int32), "c": np.array(rows_c, np.int32),
+            "m": np.array(rows_m, np.int32), "obs": np.array(obs, float).reshape(N, 8), "params": start.ravel(), "truth": truth,
+            "intr": intr, "marker_side": marker_side}

@@ -486,3 +486,82 @@ def test_multi_gpu_pipeline_opt_in_single_rank(oracle):
     assert s.num_iterations == s_ref.num_iterations and s.stop_reason == s_ref.stop_reason
     assert np.array_equal(log[:, 7], log_ref[:, 7])
     assert _block_rel(got, ref, prob["C"]) < 1e-9 and abs(s.final_cost - s_ref.final_cost) < 1e-12 * s_ref.final_cost
+
+
+# ------------------------------------------------------------------ marker-chain model at scale
+# The time blocks are eliminated on the GPU (ba_marker_schur.hpp); the oracle solves the dense normal equations of all
+# blocks.  Same LM sequence, parameters to 1e-6 relative.
+def _solve_marker_chain_both(oracle, prob, schur_impl, model=capi.MODEL_MARKER_CHAIN):
+    variant = 0 if model == capi.MODEL_MARKER_CHAIN else 1
+    ref, s_ref, log = oracle.solve_marker_chain(prob, variant, prob["marker_side"], prob["intr"])
+    p = capi.Problem.marker_chain(prob, model)
+    s = p.solve(capi.default_options(schur_impl=schur_impl))
+    got = p.params.copy()
+    p.close()
+    return ref, s_ref, got, s
+
+
+@pytest.mark.parametrize("shape", [(4, 40, 6), (8, 120, 12), (3, 300, 4)])
+def test_marker_chain_time_elimination_matches_oracle(oracle, shape):
+    C_, T_, M_ = shape
+    prob = syn.make_marker_chain(C_, T_, M_, seed=sum(shape))
+    ref, s_ref, got, s = _solve_marker_chain_both(oracle, prob, 2)
+    assert s.num_iterations == s_ref.num_iterations and s.num_successful_steps == s_ref.num_successful_steps
+    assert abs(s.initial_cost - s_ref.initial_cost) < 1e-9 * s_ref.initial_cost
+    assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
+    assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
+    # the base blocks are not part of the problem
+    assert np.all(got[:6] == prob["params"][:6]) and np.all(got[6 * (C_ + T_):6 * (C_ + T_) + 6] == prob["params"][6 * (C_ + T_):6 * (C_ + T_) + 6])
+
+
+def test_marker_chain_automatic_choice_and_dense_cross_check(oracle):
+    """schur_impl 1 (default) eliminates once the dense system outgrows one workgroup's solver; the one-workgroup dense
+    path (schur_impl 0) on the same problem is the on-device cross-check."""
+    prob = syn.make_marker_chain(5, 80, 8, seed=77)   # 6 (5 + 80 + 8) = 558 unknowns > 384
+    p = capi.Problem.marker_chain(prob)
+    s1 = p.solve()
+    a = p.params.copy(); p.close()
+    p = capi.Problem.marker_chain(prob)
+    s0 = p.solve(capi.default_options(schur_impl=0))
+    b = p.params.copy(); p.close()
+    assert s1.num_iterations == s0.num_iterations
+    assert abs(s1.final_cost - s0.final_cost) < 1e-10 * s0.final_cost
+    assert np.abs(a - b).max() < 1e-7
+    # and the run is bitwise reproducible
+    p = capi.Problem.marker_chain(prob)
+    p.solve()
+    assert np.array_equal(p.params, a)
+    p.close()
+
+
+def test_marker_chain_large_reduced_system(oracle):
+    """More than 64 camera + marker blocks: the reduced system goes through the multi-launch Cholesky."""
+    prob = syn.make_marker_chain(36, 24, 36, seed=5, keep=0.5)
+    assert 6 * (35 + 35) > 384
+    ref, s_ref, got, s = _solve_marker_chain_both(oracle, prob, 1)
+    assert s.num_iterations == s_ref.num_iterations
+    assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
+    assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_golden_fixtures_through_time_elimination(oracle, tmp_path):
+    """The committed hongo / test2 inputs with schur_impl = 2: same iteration counts and the reference's own outputs."""
+    intr = ol.read_intrinsics(ol.SERIALS_MAIN)
+    p = capi.Problem.correspondence(os.path.join(G, "hongo", "correspondence.txt"), capi.MODEL_MARKER_CHAIN, ol.MARKER_SIDE_MAIN, intr)
+    s = p.solve(capi.default_options(schur_impl=2))
+    assert s.termination_type == capi.CONVERGENCE and s.num_iterations == 7 and s.num_successful_steps == 6
+    assert abs(s.initial_cost - 138796.696054) < 1e-5 and abs(s.final_cost - 143.629388852) < 1e-7
+    xml = str(tmp_path / "Camera_Transform.xml")
+    p.write_outputs(xml, None, None)
+    got, want = ol.read_opencv_xml(xml), ol.read_opencv_xml(os.path.join(G, "hongo", "Camera_Transform.xml"))
+    for k in want:
+        assert np.abs(got[k] - want[k]).max() < 1e-9, k
+    p.close()
+    intr = ol.read_intrinsics(ol.SERIALS_TEST2)
+    p = capi.Problem.correspondence(os.path.join(G, "test2", "correspondence_test.txt"), capi.MODEL_MARKER_CHAIN_TEST2, ol.MARKER_SIDE_TEST2, intr)
+    s = p.solve(capi.default_options(schur_impl=2))
+    xmlv = ol.read_opencv_xml(os.path.join(G, "test2", "Camera_Transform.xml"))
+    assert s.num_iterations == 4 and s.stop_reason == 3
+    assert np.abs(p.params[6:9] - xmlv["R1"].ravel()).max() < 1e-9
+    assert np.abs(p.params[9:12] - xmlv["t1"].ravel()).max() < 1e-9
+    p.close()
