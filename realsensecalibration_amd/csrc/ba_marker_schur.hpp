@@ -36,6 +36,21 @@ namespace rsba {
 #define RSBA_MT_TILE 32        // residual blocks staged per tile (32 x 152 doubles of LDS)
 #define RSBA_MT_MAXD 1020      // widest local system of one time: 170 camera + marker blocks
 
+#define RSBA_MT_THREADS 1024
+#define RSBA_MT_JLD 145        // LDS stride of a staged 8 x 18 Jacobian
+
+// A workgroup's partial system: S as packed lower triangle (row i, column j <= i at i (i + 1) / 2 + j), then the vectors.
+struct PartLayout {
+  int nr;
+  __host__ __device__ size_t packed() const { return (size_t)nr * (nr + 1) / 2; }
+  __host__ __device__ size_t S() const { return 0; }
+  __host__ __device__ size_t gc() const { return packed(); }
+  __host__ __device__ size_t corr() const { return packed() + nr; }
+  __host__ __device__ size_t diagU() const { return packed() + 2 * (size_t)nr; }
+  __host__ __device__ size_t scal() const { return packed() + 3 * (size_t)nr; }
+  __host__ __device__ size_t size() const { return packed() + 3 * (size_t)nr + 8; }
+};
+
 struct TimeSlots {  // per residual block, in time order: where its camera / marker block sits
   int slot_cam, slot_marker;   // index in its time's slot list (-1: block not part of the residual)
   int col_cam, col_marker;     // first column in the reduced system (-1)
@@ -102,83 +117,154 @@ struct ElimArgs {
   IterParams ip;
 };
 
+#ifdef RSBA_PROFILE_PHASES
+#define RSBA_MT_STAMP(k) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { long long _t = clock64(); g_phase_cycles[k] += _t - _t0; _t0 = _t; } } while (0)
+#else
+#define RSBA_MT_STAMP(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ int LocalColumn(int slot, int q, int sc, int sm) { return slot == sc ? q : (slot == sm ? 12 + q : -1); }
 
-__global__ void __launch_bounds__(256)
+template <bool kLdsS>
+__global__ void __launch_bounds__(RSBA_MT_THREADS)
 k_time_eliminate(ElimArgs a) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nr = a.nr, dmax = a.dmax;
-  const RedLayout RL{nr};
+  const PartLayout RL{nr};
   double* W = lds;                        // [6][d]
   double* Y = W + 6 * dmax;               // [6][d]
   double* Gr = Y + 6 * dmax;              // [d]
   double* Vs = Gr + dmax;                 // V 36 | g 6 | (pad 6) | E 36 | Eg 6
-  double* Jt = Vs + 96;                   // [TILE][144]
-  double* rt = Jt + RSBA_MT_TILE * 144;   // [TILE][8]
-  int* sl = (int*)(rt + RSBA_MT_TILE * 8);  // [TILE][2] slots, then the time's slot columns [d / 6]
-  int* scol = sl + 2 * RSBA_MT_TILE;
+  double* Jt = Vs + 96;                   // [TILE][145]: odd stride, the lanes of pass 2 read different residual blocks
+  double* rt = Jt + RSBA_MT_TILE * RSBA_MT_JLD;   // [TILE][8]
+  double* sqv = rt + RSBA_MT_TILE * 8;    // [TILE] squared residual norms
+  int* sl = (int*)(sqv + RSBA_MT_TILE);   // [TILE][2] slots, then per slot of the time [dmax / 6 + 1] each:
+  int* scol = sl + 2 * RSBA_MT_TILE;      //   first reduced column
+  int* mk = scol + dmax / 6 + 1;          //   bit i: staged residual block i has the slot
+  int* kb = mk + dmax / 6 + 1;            //   where the slot's block sits in a residual's Jacobian: column 0 (camera) or 12 (marker)
+  // the chunk's sum of S (packed lower triangle): in LDS when it fits, else straight in the workgroup's partial system
+  double* Sl = (double*)(sl + ((2 * RSBA_MT_TILE + 3 * (dmax / 6 + 1) + 1) & ~1));
   double* P = a.part + (size_t)blockIdx.x * RL.size();
-  for (size_t e = tid; e < RL.size(); e += 256) P[e] = 0.0;
+  double* Sacc = kLdsS ? Sl : P + RL.S();
+  for (size_t e = tid; e < RL.packed(); e += RSBA_MT_THREADS) Sacc[e] = 0.0;
+  for (size_t e = RL.packed() + tid; e < RL.size(); e += RSBA_MT_THREADS) P[e] = 0.0;
   double cost = 0.0, xn2 = 0.0, gmax = 0.0, fail = 0.0;   // thread 0's running sums over the chunk's times
+#ifdef RSBA_PROFILE_PHASES
+  long long _t0 = clock64();
+#endif
   __threadfence_block();
   __syncthreads();
 
+  RSBA_MT_STAMP(0);
   for (int t = a.chunk_ptr[blockIdx.x]; t < a.chunk_ptr[blockIdx.x + 1]; ++t) {
     const int o0 = a.time_ptr[t], nobs = a.time_ptr[t + 1] - o0;
     const int s0 = a.slot_ptr[t], nslot = a.slot_ptr[t + 1] - s0, d = 6 * nslot;
-    for (int e = tid; e < 6 * d; e += 256) W[e] = 0.0;
-    for (int e = tid; e < d; e += 256) Gr[e] = 0.0;
-    if (tid < 42) Vs[tid] = 0.0;
-    for (int e = tid; e < nslot; e += 256) scol[e] = a.slot_col[s0 + e];
+    for (int e = tid; e < 6 * d; e += RSBA_MT_THREADS) W[e] = 0.0;
+    for (int e = tid; e < d; e += RSBA_MT_THREADS) Gr[e] = 0.0;
+    if (tid < 43) Vs[tid] = 0.0;
+    for (int e = tid; e < nslot; e += RSBA_MT_THREADS) scol[e] = a.slot_col[s0 + e];
     const int ntile = (nobs + RSBA_MT_TILE - 1) / RSBA_MT_TILE;
     auto stage = [&](int tile) {
       const int b0 = o0 + tile * RSBA_MT_TILE, nb = min(RSBA_MT_TILE, nobs - tile * RSBA_MT_TILE);
       __syncthreads();   // the previous tile has been consumed
-      for (int e = tid; e < nb * 144; e += 256) Jt[e] = a.J[(size_t)b0 * 144 + e];
-      for (int e = tid; e < nb * 8; e += 256) rt[e] = a.r[(size_t)b0 * 8 + e];
-      for (int e = tid; e < nb; e += 256) { sl[2 * e] = a.ts[b0 + e].slot_cam; sl[2 * e + 1] = a.ts[b0 + e].slot_marker; }
+      {
+        // all loads of the tile in flight before the first LDS store (a loop with an unknown bound waits for each)
+        constexpr int kIter = (RSBA_MT_TILE * 144 + RSBA_MT_THREADS - 1) / RSBA_MT_THREADS;
+        double v[kIter];
+#pragma unroll
+        for (int k = 0; k < kIter; ++k) { const int e = tid + k * RSBA_MT_THREADS; v[k] = e < nb * 144 ? a.J[(size_t)b0 * 144 + e] : 0.0; }
+        const double rv = tid < nb * 8 ? a.r[(size_t)b0 * 8 + tid] : 0.0;
+#pragma unroll
+        for (int k = 0; k < kIter; ++k) { const int e = tid + k * RSBA_MT_THREADS; if (e < nb * 144) Jt[(e / 144) * RSBA_MT_JLD + e % 144] = v[k]; }
+        if (tid < nb * 8) rt[tid] = rv;
+      }
+      for (int e = tid; e < nb; e += RSBA_MT_THREADS) { sl[2 * e] = a.ts[b0 + e].slot_cam; sl[2 * e + 1] = a.ts[b0 + e].slot_marker; sqv[e] = a.sumsq[b0 + e]; }
+      for (int e = tid; e < nslot; e += RSBA_MT_THREADS) mk[e] = 0;
+      __syncthreads();
+      // which staged residual blocks belong to a slot (bit order = block order: the sums below run in a fixed order)
+      if (tid < nb) {
+        const int sc = sl[2 * tid], sm = sl[2 * tid + 1];
+        if (sc >= 0) { atomicOr(&mk[sc], 1 << tid); kb[sc] = 0; }
+        if (sm >= 0) { atomicOr(&mk[sm], 1 << tid); kb[sm] = 12; }
+      }
       __syncthreads();
       return nb;
     };
-    // ---- pass 1: V, g_t, W = J_t' J_r, reduced gradient
+    RSBA_MT_STAMP(1);
+    // ---- pass 1 (the only one over the Jacobians): V, g_t, W = J_t' J_r, reduced gradient, U
     for (int tile = 0; tile < ntile; ++tile) {
       const int nb = stage(tile);
-      for (int e = tid; e < 42 + 7 * d; e += 256) {
+      for (int e = tid; e < 7 * d; e += RSBA_MT_THREADS) {
         double acc = 0.0;
-        if (e < 36) {
-          const int x = e / 6, y = e - 6 * x;
-          for (int i = 0; i < nb; ++i)
+        if (e < 6 * d) {
+          const int x = e / d, col = e - x * d, s = col / 6, jc = kb[s] + col - 6 * s;
+          for (unsigned m = (unsigned)mk[s]; m; m &= m - 1) {
+            const int i = __ffs(m) - 1;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += Jt[i * 144 + q * 18 + 6 + x] * Jt[i * 144 + q * 18 + 6 + y];
-          Vs[e] += acc;
-        } else if (e < 42) {
-          const int x = e - 36;
-          for (int i = 0; i < nb; ++i)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc += Jt[i * 144 + q * 18 + 6 + x] * rt[i * 8 + q];
-          Vs[e] += acc;
-        } else if (e < 42 + 6 * d) {
-          const int k = e - 42, x = k / d, col = k - x * d, s = col / 6, cq = col - 6 * s;
-          for (int i = 0; i < nb; ++i) {
-            const int jc = LocalColumn(s, cq, sl[2 * i], sl[2 * i + 1]);
-            if (jc < 0) continue;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc += Jt[i * 144 + q * 18 + 6 + x] * Jt[i * 144 + q * 18 + jc];
+            for (int q = 0; q < 8; ++q) acc += Jt[i * RSBA_MT_JLD + q * 18 + 6 + x] * Jt[i * RSBA_MT_JLD + q * 18 + jc];
           }
-          W[k] += acc;
+          W[e] += acc;
         } else {
-          const int col = e - 42 - 6 * d, s = col / 6, cq = col - 6 * s;
-          for (int i = 0; i < nb; ++i) {
-            const int jc = LocalColumn(s, cq, sl[2 * i], sl[2 * i + 1]);
-            if (jc < 0) continue;
+          const int col = e - 6 * d, s = col / 6, jc = kb[s] + col - 6 * s;
+          for (unsigned m = (unsigned)mk[s]; m; m &= m - 1) {
+            const int i = __ffs(m) - 1;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += Jt[i * 144 + q * 18 + jc] * rt[i * 8 + q];
+            for (int q = 0; q < 8; ++q) acc += Jt[i * RSBA_MT_JLD + q * 18 + jc] * rt[i * 8 + q];
           }
           Gr[col] += acc;
         }
       }
+      // U: a diagonal block per slot (sum over the slot's residual blocks) and one (marker, camera) block per residual block
+      // that has both (cameras have the lower columns); two different cameras (or markers) never meet in a residual.
+      // Every (time, camera, marker) occurs once, so the cross blocks of different residual blocks never overlap.
+      for (int e = tid; e < nslot * 36; e += RSBA_MT_THREADS) {
+        const int sidx = e / 36, rq = (e - 36 * sidx) / 6, cq = e - 36 * sidx - 6 * rq;
+        if (cq > rq) continue;
+        double u = 0.0;
+        const int jb = kb[sidx];
+        for (unsigned m = (unsigned)mk[sidx]; m; m &= m - 1) {
+          const int i = __ffs(m) - 1;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) u += Jt[i * RSBA_MT_JLD + q * 18 + jb + rq] * Jt[i * RSBA_MT_JLD + q * 18 + jb + cq];
+        }
+        const int gr = scol[sidx] + rq, gc = scol[sidx] + cq;
+        if (rq == cq) P[RL.diagU() + gr] += u;
+        Sacc[(size_t)gr * (gr + 1) / 2 + gc] += u;
+      }
+      for (int e = tid; e < nb * 36; e += RSBA_MT_THREADS) {
+        const int i = e / 36, rq = (e - 36 * i) / 6, cq = e - 36 * i - 6 * rq;
+        const int sc = sl[2 * i], sm = sl[2 * i + 1];
+        if (sc < 0 || sm < 0) continue;
+        double u = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u += Jt[i * RSBA_MT_JLD + q * 18 + 12 + rq] * Jt[i * RSBA_MT_JLD + q * 18 + cq];
+        const int gr = scol[sm] + rq, gc = scol[sc] + cq;
+        Sacc[(size_t)gr * (gr + 1) / 2 + gc] += u;
+      }
+      // V (36), g_t (6), cost (1): every staged residual block contributes; eight lanes per entry take every eighth block,
+      // a fixed shuffle tree adds them
+      if (tid < 43 * 8) {
+        const int ent = tid >> 3, k = tid & 7;
+        double acc = 0.0;
+        if (ent < 36) {
+          const int x = ent / 6, y = ent - 6 * x;
+          for (int i = k; i < nb; i += 8)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += Jt[i * RSBA_MT_JLD + q * 18 + 6 + x] * Jt[i * RSBA_MT_JLD + q * 18 + 6 + y];
+        } else if (ent < 42) {
+          const int x = ent - 36;
+          for (int i = k; i < nb; i += 8)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += Jt[i * RSBA_MT_JLD + q * 18 + 6 + x] * rt[i * 8 + q];
+        } else {
+          for (int i = k; i < nb; i += 8) acc += sqv[i];
+        }
+        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+        if (k == 0) Vs[ent] += acc;
+      }
     }
     __syncthreads();
+    RSBA_MT_STAMP(2);
     // ---- E = (V + D)^-1, E g_t
     if (tid == 0) {
       double Vd[36], E[36];
@@ -202,10 +288,11 @@ k_time_eliminate(ElimArgs a) {
         Vs[84 + x] = s;
         a.tdata[(size_t)t * 48 + 36 + x] = Vs[36 + x];
       }
-      for (int i = 0; i < nobs; ++i) cost += a.sumsq[o0 + i];
+      cost += Vs[42];
     }
     __syncthreads();
-    for (int e = tid; e < 6 * d; e += 256) {
+    RSBA_MT_STAMP(3);
+    for (int e = tid; e < 6 * d; e += RSBA_MT_THREADS) {
       const int x = e / d, col = e - x * d;
       double s = 0.0;
 #pragma unroll
@@ -213,34 +300,21 @@ k_time_eliminate(ElimArgs a) {
       Y[e] = s;
     }
     __syncthreads();
-    // ---- pass 2: the time's block of U - W'Y into the private partial system (lower triangle: slots ascend)
-    for (int tile = 0; tile < ntile; ++tile) {
-      const int nb = ntile == 1 ? nobs : stage(tile);   // a single tile is still staged
-      const bool last = tile == ntile - 1;
-      for (int e = tid; e < d * d; e += 256) {
-        const int row = e / d, col = e - row * d;
-        if (col > row) continue;
-        const int rs = row / 6, rq = row - 6 * rs, cs = col / 6, cq = col - 6 * cs;
-        double u = 0.0;
-        for (int i = 0; i < nb; ++i) {
-          const int jr = LocalColumn(rs, rq, sl[2 * i], sl[2 * i + 1]);
-          const int jc = LocalColumn(cs, cq, sl[2 * i], sl[2 * i + 1]);
-          if (jr < 0 || jc < 0) continue;
+    RSBA_MT_STAMP(4);
+    // ---- pass 2: minus W'Y, the dense part of the time's block (lower triangle: slots ascend)
+    __syncthreads();
+    for (int e = tid; e < d * d; e += RSBA_MT_THREADS) {
+      const int row = e / d, col = e - row * d;
+      if (col > row) continue;
+      double wy = 0.0;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) u += Jt[i * 144 + q * 18 + jr] * Jt[i * 144 + q * 18 + jc];
-        }
-        const int gr = scol[rs] + rq, gc = scol[cs] + cq;
-        if (row == col) P[RL.diagU() + gr] += u;
-        if (last) {
-          double wy = 0.0;
-#pragma unroll
-          for (int x = 0; x < 6; ++x) wy += W[x * d + row] * Y[x * d + col];
-          u -= wy;
-        }
-        P[RL.S() + (size_t)gr * nr + gc] += u;
-      }
+      for (int x = 0; x < 6; ++x) wy += W[x * d + row] * Y[x * d + col];
+      const int rs = row / 6, cs = col / 6;
+      const int gr = scol[rs] + (row - 6 * rs), gc = scol[cs] + (col - 6 * cs);
+      Sacc[(size_t)gr * (gr + 1) / 2 + gc] -= wy;
     }
-    for (int e = tid; e < d; e += 256) {
+    RSBA_MT_STAMP(5);
+    for (int e = tid; e < d; e += RSBA_MT_THREADS) {
       const int s = e / 6, gcol = scol[s] + (e - 6 * s);
       double c = 0.0;
 #pragma unroll
@@ -250,7 +324,9 @@ k_time_eliminate(ElimArgs a) {
     }
     __threadfence_block();
     __syncthreads();
+    RSBA_MT_STAMP(6);
   }
+  if (kLdsS) for (size_t e = tid; e < RL.packed(); e += RSBA_MT_THREADS) P[RL.S() + e] = Sl[e];
   if (tid == 0) { P[RL.scal() + 0] = cost; P[RL.scal() + 1] = xn2; P[RL.scal() + 2] = fail; P[RL.scal() + 3] = gmax; }
 }
 
@@ -258,14 +334,32 @@ k_time_eliminate(ElimArgs a) {
 __global__ void __launch_bounds__(256)
 k_marker_reduce(int nr, int G, const double* __restrict__ part, double* __restrict__ red) {
   const RedLayout RL{nr};
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= RL.size()) return;
-  size_t src = idx;
-  if (idx < (size_t)nr * nr) { const size_t i = idx / nr, j = idx - i * nr; src = i >= j ? idx : j * nr + i; }
+  const PartLayout PL{nr};
+  // eight lanes per entry: lane k takes the chunks g = k (mod 8) in ascending order, eight loads in flight, then a fixed
+  // shuffle tree (a single thread per entry is a dependent chain of G cache misses)
+  const int k = threadIdx.x & 7;
+  const size_t idx = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool live = idx < RL.size();
+  size_t src = 0;
+  if (live) {
+    if (idx < (size_t)nr * nr) { const size_t i = idx / nr, j = idx - i * nr; src = i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+    else src = PL.packed() + (idx - (size_t)nr * nr);
+  }
   const bool is_max = idx == RL.scal() + 3;
   double s = 0.0;
-  for (int g = 0; g < G; ++g) { const double v = part[(size_t)g * RL.size() + src]; s = is_max ? fmax(s, v) : s + v; }
-  red[idx] = s;
+  if (live) {
+    int g = k;
+    for (; g + 56 < G; g += 64) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(g + 8 * u) * PL.size() + src];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s = is_max ? fmax(s, v[u]) : s + v[u];
+    }
+    for (; g < G; g += 8) { const double v = part[(size_t)g * PL.size() + src]; s = is_max ? fmax(s, v) : s + v; }
+  }
+  for (int off = 1; off < 8; off <<= 1) { const double o = __shfl_xor(s, off, 64); s = is_max ? fmax(s, o) : s + o; }
+  if (live && k == 0) red[idx] = s;
 }
 
 // Step of the reduced blocks from the solution y of the scaled system; candidate parameters; norms.
@@ -335,40 +429,57 @@ k_marker_chol_finish(int nr, const double* __restrict__ red, double* __restrict_
 }
 
 // delta_t = -E (g_t + sum J_t' (J_c delta_c + J_m delta_m)); candidate time poses; per-workgroup norms.
-__global__ void __launch_bounds__(64)
+// One wavefront per time: the lanes take the time's residual blocks, a fixed shuffle tree adds their six sums.
+__global__ void __launch_bounds__(256)
 k_time_backsub(int T, const int* __restrict__ time_ptr, const int* __restrict__ time_full, const TimeSlots* __restrict__ ts,
                const double* __restrict__ J, const double* __restrict__ tdata, const double* __restrict__ delta_r,
                const double* __restrict__ params_x, double* __restrict__ params_c, double* __restrict__ delta_t,
                double* __restrict__ bpart /* gridDim.x x 4 */) {
-  const int t = blockIdx.x * 64 + threadIdx.x;
+  __shared__ double s_part[4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * 4 + wave;
   double d2 = 0, xc2 = 0;
   if (t < T) {
-    double h[6];
-    for (int x = 0; x < 6; ++x) h[x] = tdata[(size_t)t * 48 + 36 + x];
-    for (int i = time_ptr[t]; i < time_ptr[t + 1]; ++i) {
+    double h[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = time_ptr[t] + lane; i < time_ptr[t + 1]; i += 64) {
       const TimeSlots s = ts[i];
       double dc[6], dm[6];
+#pragma unroll
       for (int x = 0; x < 6; ++x) { dc[x] = s.col_cam >= 0 ? delta_r[s.col_cam + x] : 0.0; dm[x] = s.col_marker >= 0 ? delta_r[s.col_marker + x] : 0.0; }
       const double* Ji = J + (size_t)i * 144;
       for (int q = 0; q < 8; ++q) {
         double m = 0.0;
+#pragma unroll
         for (int x = 0; x < 6; ++x) m += Ji[q * 18 + x] * dc[x] + Ji[q * 18 + 12 + x] * dm[x];
+#pragma unroll
         for (int x = 0; x < 6; ++x) h[x] += Ji[q * 18 + 6 + x] * m;
       }
     }
-    const int tf = time_full[t];
+#pragma unroll
     for (int x = 0; x < 6; ++x) {
+      for (int off = 32; off > 0; off >>= 1) h[x] += __shfl_down(h[x], off, 64);
+      h[x] = __shfl(h[x], 0, 64) + tdata[(size_t)t * 48 + 36 + x];
+    }
+    if (lane < 6) {
+      const int tf = time_full[t];
       double s = 0.0;
-      for (int y = 0; y < 6; ++y) s += tdata[(size_t)t * 48 + 6 * x + y] * h[y];
-      const double dd = -s, xv = params_x[tf + x], xc = xv + dd;
-      delta_t[6 * t + x] = dd;
-      params_c[tf + x] = xc;
-      d2 += dd * dd; xc2 += xc * xc;
+#pragma unroll
+      for (int y = 0; y < 6; ++y) s += tdata[(size_t)t * 48 + 6 * lane + y] * h[y];
+      const double dd = -s, xv = params_x[tf + lane], xc = xv + dd;
+      delta_t[6 * t + lane] = dd;
+      params_c[tf + lane] = xc;
+      d2 = dd * dd; xc2 = xc * xc;
     }
   }
-  // fixed-order sums inside the wavefront, then per workgroup
-  for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_down(d2, off, 64); xc2 += __shfl_down(xc2, off, 64); }
-  if (threadIdx.x == 0) { bpart[4 * blockIdx.x] = d2; bpart[4 * blockIdx.x + 1] = xc2; }
+  // the six entries in lane order, then the four times of the workgroup in wave order
+  double a2 = 0, b2 = 0;
+  for (int x = 0; x < 6; ++x) { a2 += __shfl(d2, x, 64); b2 += __shfl(xc2, x, 64); }
+  if (lane == 0) { s_part[wave][0] = a2; s_part[wave][1] = b2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bpart[4 * blockIdx.x] = ((s_part[0][0] + s_part[1][0]) + s_part[2][0]) + s_part[3][0];
+    bpart[4 * blockIdx.x + 1] = ((s_part[0][1] + s_part[1][1]) + s_part[2][1]) + s_part[3][1];
+  }
 }
 
 // Per residual block: model cost change -(J d).(r + J d / 2) and the candidate's squared residuals.
@@ -444,6 +555,7 @@ struct MarkerSchurDevice {
          *bp_obs = nullptr, *solve_out = nullptr, *res = nullptr;
   int cur = 0;
   size_t lds_elim = 0;
+  bool lds_s = false;   // the chunk sums of S live in LDS
 
   void Free() {
     void* ptrs[] = {mo, ts, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, obs_time, ok_flag, obs8, intr, params[0], params[1],
@@ -505,6 +617,14 @@ struct MarkerSchurDevice {
       }
       std::sort(cols.begin(), cols.end());
       cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+      {
+        // the kernel relies on one residual block per (time, camera, marker); the same detection listed twice goes to
+        // the dense path
+        std::vector<std::pair<int, int>> cm;
+        for (int k = tptr[t]; k < tptr[t + 1]; ++k) cm.emplace_back(p.camera_index[order[k]], p.marker_index[order[k]]);
+        std::sort(cm.begin(), cm.end());
+        if (std::adjacent_find(cm.begin(), cm.end()) != cm.end()) return RSBA_ERR_UNSUPPORTED;
+      }
       for (int k = tptr[t]; k < tptr[t + 1]; ++k) {
         const int i = order[k];
         MarkerObs& o = hmo[k];
@@ -528,8 +648,14 @@ struct MarkerSchurDevice {
     if (dmax > RSBA_MT_MAXD) return RSBA_ERR_UNSUPPORTED;
     // chunks of consecutive times, balanced by work; the partial systems together stay below 2 GB
     const RedLayout RL{nr};
-    const size_t cap = std::max<size_t>(1, ((size_t)2 << 30) / (RL.size() * sizeof(double)));
-    G = (int)std::min<size_t>(std::min<size_t>((size_t)T, 1024), cap);
+    const PartLayout PL{nr};
+    lds_elim = (size_t)(13 * dmax + 96 + RSBA_MT_TILE * (RSBA_MT_JLD + 9)) * sizeof(double) + (size_t)(2 * RSBA_MT_TILE + 3 * (dmax / 6 + 1) + 2) * sizeof(int);
+    lds_s = lds_elim + PL.packed() * sizeof(double) <= 156 * 1024;
+    if (lds_s) lds_elim += PL.packed() * sizeof(double);
+    // Without the LDS accumulators every entry is a read-modify-write in the partial system: few enough workgroups that
+    // their partial systems stay in the L2s (8 x 4 MB) then, as many as there are times otherwise (at most 1024).
+    const size_t cap = lds_s ? 1024 : std::min<size_t>(1024, std::max<size_t>(64, ((size_t)24 << 20) / (PL.size() * sizeof(double))));
+    G = (int)std::min<size_t>((size_t)T, cap);
     std::vector<int> cptr(G + 1, 0);
     {
       double total = 0; for (double w : work) total += w;
@@ -545,8 +671,7 @@ struct MarkerSchurDevice {
       for (int k = 1; k <= G; ++k) if (cptr[k] > c2.back()) c2.push_back(cptr[k]);
       G = (int)c2.size() - 1; cptr = c2;
     }
-    nb_time = (T + 63) / 64; nb_obs = (N + 255) / 256;
-    lds_elim = (size_t)(13 * dmax + 96 + RSBA_MT_TILE * 152) * sizeof(double) + (size_t)(2 * RSBA_MT_TILE + dmax / 6 + 2) * sizeof(int);
+    nb_time = (T + 3) / 4; nb_obs = (N + 255) / 256;
     auto al = [](void** q, size_t bytes) { return hipMalloc(q, std::max<size_t>(bytes, 8)) == hipSuccess; };
     const size_t nA = (size_t)(nr + 2) * nr;
     if (!al((void**)&mo, N * sizeof(MarkerObs)) || !al((void**)&ts, N * sizeof(TimeSlots)) || !al((void**)&chunk_ptr, (G + 1) * 4) ||
@@ -555,7 +680,7 @@ struct MarkerSchurDevice {
         !al((void**)&obs8, 8 * (size_t)N * 8) || !al((void**)&intr, p.intrinsics.size() * 8) || !al((void**)&params[0], nfull * 8) ||
         !al((void**)&params[1], nfull * 8) || !al((void**)&params0, nfull * 8) || !al((void**)&Jbuf, (size_t)N * 144 * 8) ||
         !al((void**)&rbuf, (size_t)N * 8 * 8) || !al((void**)&ss_x, N * 8) || !al((void**)&ss_c, N * 8) || !al((void**)&scale_t, 6 * (size_t)T * 8) ||
-        !al((void**)&scale_r, nr * 8) || !al((void**)&tdata, 48 * (size_t)T * 8) || !al((void**)&part, (size_t)G * RL.size() * 8) ||
+        !al((void**)&scale_r, nr * 8) || !al((void**)&tdata, 48 * (size_t)T * 8) || !al((void**)&part, (size_t)G * PL.size() * 8) ||
         !al((void**)&red, RL.size() * 8) || !al((void**)&A, nA * 8) || (nr > RSBA_CHOL_MAXN && !al((void**)&Wm, nA * 8)) ||
         !al((void**)&delta_r, nr * 8) || !al((void**)&delta_t, 6 * (size_t)T * 8) || !al((void**)&bp_time, 4 * (size_t)nb_time * 8) ||
         !al((void**)&bp_obs, 2 * (size_t)nb_obs * 8) || !al((void**)&solve_out, 8 * 8) || !al((void**)&res, RES_SIZE * 8))
@@ -569,7 +694,8 @@ struct MarkerSchurDevice {
       return RSBA_ERR_HIP;
     if (hipMemset(res, 0, RES_SIZE * 8) != hipSuccess) return RSBA_ERR_HIP;
     if (lds_elim > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)k_time_eliminate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_elim) != hipSuccess) return RSBA_ERR_HIP;
+        hipFuncSetAttribute(lds_s ? (const void*)k_time_eliminate<true> : (const void*)k_time_eliminate<false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_elim) != hipSuccess) return RSBA_ERR_HIP;
     if (nr <= RSBA_CHOL_MAXN) {
       const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(nr)) * sizeof(double);
       if (lds_c > 48 * 1024 &&
@@ -607,11 +733,12 @@ struct MarkerSchurDevice {
     Tm.End(st);
     ElimArgs ea{nr, dmax, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, ts, Jbuf, rbuf, ss_x, params[x], scale_t, tdata, part, ip};
     Tm.Begin("k_time_eliminate", st);
-    k_time_eliminate<<<G, 256, lds_elim, st>>>(ea);
+    if (lds_s) k_time_eliminate<true><<<G, RSBA_MT_THREADS, lds_elim, st>>>(ea);
+    else k_time_eliminate<false><<<G, RSBA_MT_THREADS, lds_elim, st>>>(ea);
     Tm.End(st);
     if (!chk("k_time_eliminate")) return RSBA_ERR_HIP;
     Tm.Begin("k_marker_reduce", st);
-    k_marker_reduce<<<(unsigned)((RL.size() + 255) / 256), 256, 0, st>>>(nr, G, part, red);
+    k_marker_reduce<<<(unsigned)((RL.size() + 31) / 32), 256, 0, st>>>(nr, G, part, red);
     Tm.End(st);
     if (nr <= RSBA_CHOL_MAXN) {
       const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(nr)) * sizeof(double);
@@ -637,7 +764,7 @@ struct MarkerSchurDevice {
     }
     if (!chk("reduced solve")) return RSBA_ERR_HIP;
     Tm.Begin("k_time_backsub", st);
-    k_time_backsub<<<nb_time, 64, 0, st>>>(T, time_ptr, time_full, ts, Jbuf, tdata, delta_r, params[x], params[c], delta_t, bp_time);
+    k_time_backsub<<<nb_time, 256, 0, st>>>(T, time_ptr, time_full, ts, Jbuf, tdata, delta_r, params[x], params[c], delta_t, bp_time);
     Tm.End(st);
     Tm.Begin("k_marker_eval", st);
     k_marker_eval<<<(N + 63) / 64, 64, 0, st>>>(N, mo, obs8, params[c], intr, half_side, 0, nullptr, nullptr, ss_c);

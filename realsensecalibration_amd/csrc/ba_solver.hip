@@ -969,6 +969,12 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
   else {
     s->eliminate_times = rsba::MarkerSchurDevice::Wanted(*p, opt.schur_impl);
     rc = s->eliminate_times ? s->marker_schur.Upload(*p) : s->marker.Upload(*p);
+    if (s->eliminate_times && rc == RSBA_ERR_UNSUPPORTED) {
+      // duplicate detections, no camera / marker block at all, or a time wider than the kernel's LDS: the dense path is general
+      s->marker_schur.Free();
+      s->eliminate_times = false;
+      rc = s->marker.Upload(*p);
+    }
   }
   if (rc == RSBA_OK && hipDeviceSynchronize() != hipSuccess) rc = RSBA_ERR_HIP;
   if (rc != RSBA_OK) { rsba::FreeSolver(s); return rc; }

@@ -171,20 +171,23 @@ def make_marker_chain(C, T, M, seed, marker_side=0.08, keep=0.9, noise_px=0.3, s
     times[:, 3:] -= _rotate(times[:, :3], np.broadcast_to(centre, (T, 3)))  # the board's middle, not marker 0, sits there
     h = marker_side / 2
     corners = np.array([[-h, h, 0.0], [h, h, 0.0], [h, -h, 0.0], [-h, -h, 0.0]])  # bundle_adjustment.h:92-101
-    rows_t, rows_c, rows_m, obs = [], [], [], []
-    # corners of every marker in the board frame: (M, 4, 3)
+    # corners of every marker in the board frame (M, 4, 3), then in the base camera's frame at every time (T, M, 4, 3)
     in_board = _rotate(marks[:, None, :3], corners[None]) + marks[:, None, 3:]
-    for t in range(T):
-        in_base = _rotate(times[t, :3], in_board) + times[t, 3:]  # (M, 4, 3)
-        for c in range(C):
-            pc = _rotate(cams[c, :3], in_base) + cams[c, 3:]
-            u = intr[c, 0] * pc[..., 0] / pc[..., 2] + intr[c, 2]
-            v = intr[c, 1] * pc[..., 1] / pc[..., 2] + intr[c, 3]
-            ok = (pc[..., 2] > 0.3).all(1) & (u > 0).all(1) & (u < 640).all(1) & (v > 0).all(1) & (v < 480).all(1)
-            ok &= rng.random(M) < keep
-            for m in np.nonzero(ok)[0]:
-                rows_t.append(t); rows_c.append(c); rows_m.append(m)
-                obs.append(np.stack([u[m], v[m]], -1).ravel() + rng.normal(0, noise_px, 8))
+    in_base = _rotate(times[:, None, None, :3], in_board[None]) + times[:, None, None, 3:]
+    rows, obs = [], []
+    for c in range(C):
+        pc = _rotate(cams[c, :3], in_base) + cams[c, 3:]
+        u = intr[c, 0] * pc[..., 0] / pc[..., 2] + intr[c, 2]
+        v = intr[c, 1] * pc[..., 1] / pc[..., 2] + intr[c, 3]
+        ok = (pc[..., 2] > 0.3).all(-1) & (u > 0).all(-1) & (u < 640).all(-1) & (v > 0).all(-1) & (v < 480).all(-1)
+        ok &= rng.random((T, M)) < keep
+        tt, mm = np.nonzero(ok)
+        rows.append(np.stack([tt, np.full_like(tt, c), mm], -1))
+        obs.append(np.stack([u[tt, mm], v[tt, mm]], -1).reshape(-1, 8) + rng.normal(0, noise_px, (len(tt), 8)))
+    rows, obs = np.concatenate(rows), np.concatenate(obs)
+    order = np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0]))   # by time, camera, marker: the reference file's order
+    rows, obs = rows[order], obs[order]
+    rows_t, rows_c, rows_m = rows[:, 0], rows[:, 1], rows[:, 2]
     N = len(rows_t)
     truth = np.concatenate([cams.ravel(), times.ravel(), marks.ravel()])
     start = truth.reshape(-1, 6).copy()
