@@ -301,17 +301,29 @@ k_time_eliminate(ElimArgs a) {
     }
     __syncthreads();
     RSBA_MT_STAMP(4);
-    // ---- pass 2: minus W'Y, the dense part of the time's block (lower triangle: slots ascend)
-    __syncthreads();
-    for (int e = tid; e < d * d; e += RSBA_MT_THREADS) {
-      const int row = e / d, col = e - row * d;
-      if (col > row) continue;
-      double wy = 0.0;
+    // ---- pass 2: minus W'Y, the dense part of the time's block.  One item = a row of a 6 x 6 block (rs, cs <= rs):
+    // lower triangle only (slots ascend, so does the reduced column), six outputs per six + 36 loads
+    {
+      const int nbp = nslot * (nslot + 1) / 2;
+      for (int it = tid; it < 6 * nbp; it += RSBA_MT_THREADS) {
+        const int bp = it / 6, rq = it - 6 * bp;
+        int rs = (int)((sqrtf(8.0f * (float)bp + 1.0f) - 1.0f) * 0.5f);
+        while (rs * (rs + 1) / 2 > bp) --rs;
+        while ((rs + 1) * (rs + 2) / 2 <= bp) ++rs;
+        const int cs = bp - rs * (rs + 1) / 2;
+        double wr[6];
 #pragma unroll
-      for (int x = 0; x < 6; ++x) wy += W[x * d + row] * Y[x * d + col];
-      const int rs = row / 6, cs = col / 6;
-      const int gr = scol[rs] + (row - 6 * rs), gc = scol[cs] + (col - 6 * cs);
-      Sacc[(size_t)gr * (gr + 1) / 2 + gc] -= wy;
+        for (int x = 0; x < 6; ++x) wr[x] = W[x * d + 6 * rs + rq];
+        const int gr = scol[rs] + rq;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          if (rs == cs && c > rq) continue;
+          double wy = 0.0;
+#pragma unroll
+          for (int x = 0; x < 6; ++x) wy += wr[x] * Y[x * d + 6 * cs + c];
+          Sacc[(size_t)gr * (gr + 1) / 2 + scol[cs] + c] -= wy;
+        }
+      }
     }
     RSBA_MT_STAMP(5);
     for (int e = tid; e < d; e += RSBA_MT_THREADS) {
