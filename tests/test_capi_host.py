@@ -45,6 +45,45 @@ def test_load_correspondence_matches_reference_reader():
     p.close()
 
 
+def test_marker_chain_from_arrays_equals_the_file_reader():
+    """rsba_problem_create_marker_chain on the arrays of the committed file = the file reader; bad indices are refused."""
+    intr = ol.read_intrinsics(ol.SERIALS_MAIN)
+    path = os.path.join(G, "hongo", "correspondence.txt")
+    ref = ol.read_correspondence(path)
+    ref = dict(ref, intr=intr, marker_side=ol.MARKER_SIDE_MAIN)
+    a = capi.Problem.correspondence(path, capi.MODEL_MARKER_CHAIN, ol.MARKER_SIDE_MAIN, intr)
+    b = capi.Problem.marker_chain(ref)
+    assert (b.num_times, b.num_cameras, b.num_markers, b.num_observations, b.num_parameters) == (6, 4, 11, 68, 126)
+    assert np.array_equal(a.params, b.params)
+    lib = capi.load()
+    obs_a = np.ctypeslib.as_array(lib.rsba_problem_observations(a.h), shape=(68 * 8,))
+    obs_b = np.ctypeslib.as_array(lib.rsba_problem_observations(b.h), shape=(68 * 8,))
+    assert np.array_equal(obs_a, obs_b)
+    for t in range(6):
+        for c in range(4):
+            assert a.num_observations_per_time_camera(t, c) == b.num_observations_per_time_camera(t, c)
+    assert np.array_equal(a.point3d(), b.point3d())
+    a.close(); b.close()
+    bad = dict(ref, m=ref["m"].copy())
+    bad["m"][3] = 11
+    with pytest.raises(capi.RsbaError):
+        capi.Problem.marker_chain(bad)
+    with pytest.raises(capi.RsbaError):
+        capi.Problem.marker_chain(ref, model=capi.MODEL_POINTS)
+
+
+def test_synthetic_marker_chain_is_consistent(oracle):
+    """The generator's truth reprojects to the noise level and the rows come in the reference file's order."""
+    from realsensecalibration_amd import synthetic as syn
+    p = syn.make_marker_chain(4, 30, 6, seed=3)
+    assert p["obs"].shape == (p["N"], 8) and p["params"].shape == (6 * (4 + 30 + 6),)
+    key = p["t"].astype(np.int64) * 10_000 + p["c"] * 100 + p["m"]
+    assert np.all(np.diff(key) > 0)          # sorted, no detection twice
+    cost = oracle.marker_chain_cost(p, 0, p["marker_side"], p["intr"], p["truth"])
+    assert abs(cost / (0.5 * 8 * p["N"] * 0.3 ** 2) - 1.0) < 0.15
+    assert np.all(p["params"][:6] == 0) and np.all(p["params"][6 * 34:6 * 35] == 0)
+
+
 def test_intrinsics_xml_reader():
     for sn, ref in zip(ol.SERIALS_MAIN, ol.read_intrinsics(ol.SERIALS_MAIN)):
         assert np.array_equal(capi.read_intrinsics_xml(os.path.join(G, "intrinsics", sn + ".xml")), ref)
