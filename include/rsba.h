@@ -158,6 +158,25 @@ int rsba_problem_load_points_file(const char* path, const double* intrinsics4, r
 int rsba_problem_load_correspondence(const char* path, int32_t model, double marker_side,
                                      const double* intrinsics /* 4C */, rsba_problem** out);
 
+/* ------------------------------------------------------------------ initial guesses (the reference's front end)
+ * What Correspondencer computes between the ArUco detections and correspondence.txt, without OpenCV.  Poses are
+ * 6 doubles (rvec, tvec), p_out = R(rvec) p_in + tvec.  Host code; zero lens distortion (the committed intrinsics). */
+/* correspondencer.cpp:119-127: the base marker's pose in the main camera from the detection of another marker and
+ * that marker's pose in the base marker's frame (my_io GetMarkerGeometry). */
+int rsba_base_pose_from_marker_detection(const double* marker_from_camera, const double* marker_from_base,
+                                         double* base_from_camera);
+/* correspondencer.cpp:137-147: marker i in the main camera = base pose o (marker i in the base marker's frame). */
+int rsba_marker_pose_in_camera(const double* base_from_camera, const double* marker_from_base, double* marker_from_camera);
+/* Correspondencer::GetCornersInCameraWorld (correspondencer.cpp:5-39): top-left, top-right, bottom-right, bottom-left. */
+int rsba_marker_corners_in_camera(const double* pose, double marker_side, double* out12);
+/* cv::solvePnP(object, image, K, dist = 0, rvec, tvec, false, SOLVEPNP_EPNP) as correspondencer.cpp:192-195 calls it.
+ * n >= 4 points (the reference exits below 4, :185-190); RSBA_ERR_UNSUPPORTED for a coplanar point set. */
+int rsba_solve_pnp_epnp(int32_t n, const double* object_points /* 3n */, const double* image_points /* 2n */,
+                        const double* intrinsics4, double* pose);
+/* Correspondencer::CalculateTransforms (correspondencer.cpp:178-205) on a marker-chain problem whose time and marker
+ * blocks are filled: camera 0 := identity, every other camera := EPnP over the corners of all markers it detected. */
+int rsba_problem_initial_camera_poses(rsba_problem* p);
+
 void rsba_problem_free(rsba_problem* p);
 
 /* BALProblem accessors (bundle_adjustment.h:36-53) */

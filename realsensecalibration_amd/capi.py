@@ -24,6 +24,8 @@ EXPORTS = [
     "rsba_solver_download", "rsba_solver_iterations", "rsba_solver_kernel_stats", "rsba_solver_final_costs",
     "rsba_solver_destroy", "rsba_points_linearize_and_step", "rsba_points_linearize_payload", "rsba_comm_unique_id", "rsba_read_intrinsics_xml",
     "rsba_write_outputs", "rsba_reprojection_error", "rsba_reprojection_check_files",
+    "rsba_base_pose_from_marker_detection", "rsba_marker_pose_in_camera", "rsba_marker_corners_in_camera", "rsba_solve_pnp_epnp",
+    "rsba_problem_initial_camera_poses",
 ]
 
 
@@ -114,6 +116,11 @@ def load():
     lib.rsba_write_outputs.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.rsba_reprojection_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rsba_reprojection_check_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rsba_base_pose_from_marker_detection.argtypes = [C.c_void_p] * 3
+    lib.rsba_marker_pose_in_camera.argtypes = [C.c_void_p] * 3
+    lib.rsba_marker_corners_in_camera.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+    lib.rsba_solve_pnp_epnp.argtypes = [C.c_int32] + [C.c_void_p] * 4
+    lib.rsba_problem_initial_camera_poses.argtypes = [C.c_void_p]
     _LIB = lib
     return lib
 
@@ -213,6 +220,9 @@ class Problem:
         o = opts or default_options()
         _chk(load().rsba_reprojection_error(self.h, C.byref(o), C.byref(err), C.byref(rms)), "rsba_reprojection_error")
         return err.value, rms.value
+
+    def initial_camera_poses(self):
+        _chk(load().rsba_problem_initial_camera_poses(self.h), "rsba_problem_initial_camera_poses")
 
     def solve(self, opts=None):
         s = Summary()
@@ -337,3 +347,31 @@ def reprojection_check_files(correspondence_txt, point3d_txt, camera_transform_x
                                                str(camera_transform_xml).encode(), _vp(intr), C.byref(err), C.byref(rms)),
          "rsba_reprojection_check_files")
     return err.value, rms.value
+
+
+def _pose_op(fn, a, b):
+    a, b, out = np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64), np.zeros(6)
+    _chk(fn(_vp(a), _vp(b), _vp(out)), "pose composition")
+    return out
+
+
+def base_pose_from_marker_detection(marker_from_camera, marker_from_base):
+    return _pose_op(load().rsba_base_pose_from_marker_detection, marker_from_camera, marker_from_base)
+
+
+def marker_pose_in_camera(base_from_camera, marker_from_base):
+    return _pose_op(load().rsba_marker_pose_in_camera, base_from_camera, marker_from_base)
+
+
+def marker_corners_in_camera(pose, marker_side):
+    pose, out = np.ascontiguousarray(pose, np.float64), np.zeros((4, 3))
+    _chk(load().rsba_marker_corners_in_camera(_vp(pose), C.c_double(marker_side), _vp(out)), "rsba_marker_corners_in_camera")
+    return out
+
+
+def solve_pnp_epnp(object_points, image_points, intrinsics4):
+    obj = np.ascontiguousarray(object_points, np.float64).reshape(-1, 3)
+    img = np.ascontiguousarray(image_points, np.float64).reshape(-1, 2)
+    k, out = np.ascontiguousarray(intrinsics4, np.float64), np.zeros(6)
+    _chk(load().rsba_solve_pnp_epnp(len(obj), _vp(obj), _vp(img), _vp(k), _vp(out)), "rsba_solve_pnp_epnp")
+    return out

@@ -49,6 +49,12 @@ int LoadReprojectionCheck(const char* correspondence_txt, const char* point3d_tx
                           const double* intrinsics, rsba_problem** out);
 void AngleAxisRotatePointHost(const double aa[3], const double pt[3], double out[3]);
 void MarkerCorners3d(const rsba_problem& p, double* out /* 12 per observation */);
+// ba_initial_guess.cpp: the front end's math between the detections and correspondence.txt (correspondencer.cpp)
+void BaseFromMarkerDetection(const double marker_from_camera[6], const double marker_from_base[6], double base_from_camera[6]);
+void MarkerFromCamera(const double base_from_camera[6], const double marker_from_base[6], double marker_from_camera[6]);
+void MarkerCornersInCamera(const double pose[6], double marker_side, double out12[12]);
+int SolvePnPEPnP(int n, const double* object_points, const double* image_points, const double intrinsics4[4], double pose[6]);
+int InitialCameraPoses(rsba_problem* p);
 int WriteOutputs(const rsba_problem& p, const char* camera_transform_xml, const char* extrinsics_dir,
                  const char* point3d_txt);
 

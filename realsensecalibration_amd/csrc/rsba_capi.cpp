@@ -70,6 +70,26 @@ int rsba_problem_load_correspondence(const char* path, int32_t model, double mar
 }
 void rsba_problem_free(rsba_problem* p) { delete p; }
 
+int rsba_base_pose_from_marker_detection(const double* marker_from_camera, const double* marker_from_base, double* base_from_camera) {
+  if (!marker_from_camera || !marker_from_base || !base_from_camera) return RSBA_ERR_ARG;
+  rsba::BaseFromMarkerDetection(marker_from_camera, marker_from_base, base_from_camera);
+  return RSBA_OK;
+}
+int rsba_marker_pose_in_camera(const double* base_from_camera, const double* marker_from_base, double* marker_from_camera) {
+  if (!base_from_camera || !marker_from_base || !marker_from_camera) return RSBA_ERR_ARG;
+  rsba::MarkerFromCamera(base_from_camera, marker_from_base, marker_from_camera);
+  return RSBA_OK;
+}
+int rsba_marker_corners_in_camera(const double* pose, double marker_side, double* out12) {
+  if (!pose || !out12 || !(marker_side > 0.0)) return RSBA_ERR_ARG;
+  rsba::MarkerCornersInCamera(pose, marker_side, out12);
+  return RSBA_OK;
+}
+int rsba_solve_pnp_epnp(int32_t n, const double* object_points, const double* image_points, const double* intrinsics4, double* pose) {
+  return rsba::SolvePnPEPnP(n, object_points, image_points, intrinsics4, pose);
+}
+int rsba_problem_initial_camera_poses(rsba_problem* p) { return rsba::InitialCameraPoses(p); }
+
 int32_t rsba_problem_model(const rsba_problem* p) { return p ? p->model : -1; }
 int32_t rsba_problem_num_cameras(const rsba_problem* p) { return p ? p->num_cameras : 0; }
 int32_t rsba_problem_num_points(const rsba_problem* p) { return p ? p->num_points : 0; }

@@ -1,0 +1,145 @@
+"""Initial-guess math of the reference's front end: csrc/ba_initial_guess.cpp through the C ABI against
+the numpy restatement in oracle/initial_guess_oracle.py, and against what the reference itself committed:
+Common/Correspondence/hongo/correspondence.txt carries the EPnP camera poses Correspondencer::CalculateTransforms wrote.
+
+EPnP's result depends on the SIGN of the principal axes that define its control points as soon as the data are noisy;
+OpenCV leaves that sign to cvSVD, so the committed poses (reprojection error ~20-37 px: the single-marker poses they
+are built from are rough) cannot be reproduced digit by digit by anything but OpenCV's own SVD.  What is checked
+instead: exact recovery on exact data, agreement with the independent numpy restatement to 1e-9 on noisy data, a
+reprojection error no worse than the committed guess's, and that bundle adjustment from this guess lands on the
+reference's committed Camera_Transform.xml."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from realsensecalibration_amd import capi
+
+sys.path.insert(0, os.path.join(ol.ROOT, "oracle"))
+import initial_guess_oracle as ig  # noqa: E402
+
+G = ol.GOLDEN
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__
+    __graft_entry__.build()
+
+
+def _random_pose(rng, z=0.5):
+    return np.concatenate([rng.normal(0, 0.4, 3), rng.uniform(-0.3, 0.3, 2), [z]])
+
+
+def test_pose_composition_and_corners_match_the_restatement():
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        a, b = _random_pose(rng), _random_pose(rng, 0.1)
+        assert np.abs(capi.base_pose_from_marker_detection(a, b) - ig.base_pose_from_marker_detection(a, b)).max() < 1e-12
+        assert np.abs(capi.marker_pose_in_camera(a, b) - ig.marker_pose_in_camera(a, b)).max() < 1e-12
+        assert np.abs(capi.marker_corners_in_camera(a, 0.048) - ig.marker_corners_in_camera(a, 0.048)).max() < 1e-14
+    # the two compositions are inverse to each other (correspondencer.cpp:119-127 undoes :137-147)
+    base, geo = _random_pose(rng), _random_pose(rng, 0.05)
+    seen = capi.marker_pose_in_camera(base, geo)
+    assert np.abs(capi.base_pose_from_marker_detection(seen, geo) - base).max() < 1e-12
+    # corner order: top-left, top-right, bottom-right, bottom-left of an unrotated marker (image y grows downwards in the
+    # camera frame, the marker's y axis points up: top = +F)
+    c = capi.marker_corners_in_camera(np.array([0, 0, 0, 0, 0, 1.0]), 2.0)
+    assert np.array_equal(c, [[-1, 1, 1], [1, 1, 1], [1, -1, 1], [-1, -1, 1]])
+
+
+def _project(pose, obj, k4):
+    pc = obj @ ig.rodrigues(pose[:3]).T + pose[3:]
+    return np.stack([k4[0] * pc[:, 0] / pc[:, 2] + k4[2], k4[1] * pc[:, 1] / pc[:, 2] + k4[3]], 1)
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.5, 5.0, 20.0])
+def test_epnp_against_the_restatement(noise):
+    rng = np.random.default_rng(int(10 * noise) + 3)
+    k4 = np.array([620.0, 615.0, 320.0, 240.0])
+    for n in (6, 60, 300):   # below six points M'M has more than one null vector even for exact data: basis-dependent
+        pose = _random_pose(rng)
+        obj = rng.uniform(-0.5, 0.5, (n, 3)) + [0, 0, 2.5]
+        img = _project(pose, obj, k4) + rng.normal(0, noise, (n, 2))
+        got = capi.solve_pnp_epnp(obj, img, k4)
+        want, err = ig.epnp(obj, img, k4)
+        assert np.abs(got - want).max() < 1e-9, (n, noise)
+        if noise == 0.0:
+            assert np.abs(got - pose).max() < 1e-8     # exact data: the exact pose
+        elif n >= 60:
+            assert np.abs(_project(got, obj, k4) - img).std() < 2.0 * noise
+
+
+def test_epnp_argument_checks():
+    k4 = np.array([620.0, 615.0, 320.0, 240.0])
+    with pytest.raises(capi.RsbaError):        # the reference exits below four points (correspondencer.cpp:185-190)
+        capi.solve_pnp_epnp(np.zeros((3, 3)), np.zeros((3, 2)), k4)
+    flat = np.array([[0, 0, 2.0], [1, 0, 2], [0, 1, 2], [1, 1, 2], [0.5, 0.2, 2]])
+    with pytest.raises(capi.RsbaError):        # coplanar: the control tetrahedron is flat
+        capi.solve_pnp_epnp(flat, flat[:, :2] * 100, k4)
+
+
+def _hongo():
+    intr = ol.read_intrinsics(ol.SERIALS_MAIN)
+    path = os.path.join(G, "hongo", "correspondence.txt")
+    return path, intr, ol.read_correspondence(path)
+
+
+def _initial_cost(oracle, ref, intr, params):
+    return oracle.marker_chain_cost(ref, 0, ol.MARKER_SIDE_MAIN, intr, params)
+
+
+def test_epnp_reproduces_the_committed_initial_guesses(oracle):
+    """CalculateTransforms on the committed detections: no worse a fit than the poses the reference wrote, camera by
+    camera the same rotation to within the noise of the problem, and the same optimum after bundle adjustment."""
+    path, intr, ref = _hongo()
+    p = capi.Problem.correspondence(path, capi.MODEL_MARKER_CHAIN, ol.MARKER_SIDE_MAIN, intr)
+    committed = p.params.copy()
+    p.initial_camera_poses()
+    ours = p.params.copy()
+    p.close()
+    assert np.all(ours[:6] == 0)                                   # :180-181
+    assert np.array_equal(ours[24:], committed[24:])               # time and marker blocks untouched
+    # numpy restatement on the same inputs
+    P, O = committed.reshape(-1, 6), ref["obs"].reshape(-1, 8)
+    Cn, T = ref["C"], ref["T"]
+    for c in range(1, Cn):
+        rows = np.nonzero(ref["c"] == c)[0]
+        obj = np.concatenate([ig.marker_corners_in_camera(ig.marker_pose_in_camera(P[Cn + ref["t"][i]], P[Cn + T + ref["m"][i]]),
+                                                          ol.MARKER_SIDE_MAIN) for i in rows])
+        img = np.concatenate([O[i].reshape(4, 2) for i in rows])
+        want, _ = ig.epnp(obj, img, intr[c])
+        assert np.abs(ours[6 * c:6 * c + 6] - want).max() < 1e-9
+        # same camera as the committed guess: rotation within 0.3 rad, position within 8 cm (the fit is ~25 px either way)
+        dR = ig.rodrigues(ours[6 * c:6 * c + 3]) @ ig.rodrigues(committed[6 * c:6 * c + 3]).T
+        assert np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)) < 0.3
+        assert np.abs(ours[6 * c + 3:6 * c + 6] - committed[6 * c + 3:6 * c + 6]).max() < 0.08
+    # the cost bundle adjustment starts from: 138796.7 with the committed poses
+    c_committed, c_ours = _initial_cost(oracle, ref, intr, committed), _initial_cost(oracle, ref, intr, ours)
+    assert abs(c_committed - 138796.696054) < 1e-5
+    assert c_ours < 1.05 * c_committed
+    # ... and ends at: the committed Camera_Transform.xml
+    got, s, _ = oracle.solve_marker_chain(dict(ref, params=ours), 0, ol.MARKER_SIDE_MAIN, intr)
+    assert abs(s.final_cost - 143.629388852) < 1e-4
+    xml = ol.read_opencv_xml(os.path.join(G, "hongo", "Camera_Transform.xml"))
+    for c in range(1, Cn):
+        assert np.abs(ig.rodrigues(got[6 * c:6 * c + 3]) - xml["R%d" % c].reshape(3, 3)).max() < 2e-5
+        assert np.abs(got[6 * c + 3:6 * c + 6] - xml["t%d" % c].ravel()).max() < 2e-5
+
+
+@pytest.mark.gpu
+def test_front_end_to_bundle_adjustment_on_the_gpu(tmp_path):
+    """detections -> EPnP initial guess -> GPU bundle adjustment -> Camera_Transform.xml, against the committed file."""
+    path, intr, ref = _hongo()
+    p = capi.Problem.correspondence(path, capi.MODEL_MARKER_CHAIN, ol.MARKER_SIDE_MAIN, intr)
+    p.initial_camera_poses()
+    s = p.solve()
+    assert s.termination_type == capi.CONVERGENCE and abs(s.final_cost - 143.629388852) < 1e-4
+    out = str(tmp_path / "Camera_Transform.xml")
+    p.write_outputs(out, None, None)
+    got, want = ol.read_opencv_xml(out), ol.read_opencv_xml(os.path.join(G, "hongo", "Camera_Transform.xml"))
+    for k in want:
+        assert np.abs(got[k] - want[k]).max() < 2e-5, k
+    p.close()
