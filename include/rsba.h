@@ -146,6 +146,11 @@ int rsba_problem_create_marker_chain(int32_t model, int32_t num_cameras, int32_t
                                      const int32_t* marker_index, const double* observations, const double* parameters,
                                      const double* intrinsics, double marker_side, rsba_problem** out);
 
+/* ceres::Problem::SetParameterBlockConstant on a camera block of the point model (not used by the reference; SURVEY
+ * §8f rank 4): the camera keeps its value, has no columns in the linear system and does not count in the norms of the
+ * convergence tests.  Fixing one camera removes the gauge freedom of a free network. */
+int rsba_problem_set_camera_constant(rsba_problem* p, int32_t camera_idx, int32_t constant);
+
 /* Test1 file "two_cam_data.txt": `C P`, P rows `cam pt u v` (one observation per point,
  * bundle_adjustmenter.cpp:62-64), C x (rvec row, tvec row), P rows xyz.  Also accepts the extended
  * first line `C P N` with N observation rows.  One intrinsics 4-vector is used for every
@@ -214,6 +219,9 @@ int rsba_solver_download(rsba_solver* s);                    /* device state -> 
 int rsba_solver_iterations(const rsba_solver* s, rsba_iteration* out, int32_t capacity); /* rows written */
 int rsba_solver_kernel_stats(const rsba_solver* s, rsba_kernel_stat* out, int32_t capacity);
 /* final 1/2 sum rho and sum of squared raw residuals of the last run (all ranks' total) */
+/* Summary::FullReport() of the latest run (the reference prints it, bundle_adjustment_manager.cpp:95): problem sizes,
+ * costs, iteration counts, times and the termination message.  snprintf semantics: returns the length needed. */
+int rsba_solver_full_report(const rsba_solver* s, char* buf, int32_t capacity);
 int rsba_solver_final_costs(const rsba_solver* s, double* cost, double* sum_sq_residuals);
 void rsba_solver_destroy(rsba_solver* s);
 

@@ -178,6 +178,10 @@ struct Options {
   int jacobi_scaling = 1;
   double huber_delta = 0.0;  // 0: no loss (the reference passes NULL everywhere); > 0: HuberLoss(a); < 0: CauchyLoss(-a)
   int num_threads = 1;
+  // Problem::SetParameterBlockConstant (not used by the reference): per PARAMETER, 1 = not part of the reduced program;
+  // such parameters have no Jacobian columns (the model zeroes them) and are left out of |x| and |step|.
+  const unsigned char* constant_parameter = nullptr;
+  const unsigned char* constant_camera = nullptr;   // point model: per camera
 };
 
 enum Termination { CONVERGENCE = 0, NO_CONVERGENCE = 1, FAILURE = 2 };
@@ -282,7 +286,7 @@ inline void TrustRegionMinimize(Model& model, const Options& opt, double* x_inou
     model.ScaleColumns(scale.data());
   }
   auto max_norm = [&](const double* g) { double m = 0; for (int i = 0; i < n; ++i) m = std::max(m, std::fabs(g[i])); return m; };
-  auto norm = [&](const double* v) { double s = 0; for (int i = 0; i < n; ++i) s += v[i] * v[i]; return std::sqrt(s); };
+  auto norm = [&](const double* v) { double s = 0; for (int i = 0; i < n; ++i) if (!opt.constant_parameter || !opt.constant_parameter[i]) s += v[i] * v[i]; return std::sqrt(s); };
   double x_norm = norm(x.data());
   double gradient_max_norm = max_norm(model.gradient());
   double radius = opt.initial_trust_region_radius;
@@ -546,6 +550,7 @@ class PointSchurModel {
         for (int k = 0; k < 3; ++k) pt[k] = J9(pts[3 * j + k], 6 + k);
         PointReprojectionError<J9>(cam, pt, p_.intrinsics[c], p_.observations[2 * i], p_.observations[2 * i + 1], jr);
         for (int r = 0; r < 2; ++r) { res[r] = jr[r].a; for (int k = 0; k < 6; ++k) jc[6 * r + k] = jr[r].v[k]; for (int k = 0; k < 3; ++k) jp[3 * r + k] = jr[r].v[6 + k]; }
+        if (opt_.constant_camera && opt_.constant_camera[c]) for (int k = 0; k < 12; ++k) jc[k] = 0.0;   // constant block: no columns
       }
       if (!std::isfinite(res[0]) || !std::isfinite(res[1])) { bad |= 1; continue; }
       const double s = res[0] * res[0] + res[1] * res[1];

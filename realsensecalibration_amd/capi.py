@@ -25,7 +25,7 @@ EXPORTS = [
     "rsba_solver_destroy", "rsba_points_linearize_and_step", "rsba_points_linearize_payload", "rsba_comm_unique_id", "rsba_read_intrinsics_xml",
     "rsba_write_outputs", "rsba_reprojection_error", "rsba_reprojection_check_files",
     "rsba_base_pose_from_marker_detection", "rsba_marker_pose_in_camera", "rsba_marker_corners_in_camera", "rsba_solve_pnp_epnp",
-    "rsba_problem_initial_camera_poses",
+    "rsba_problem_initial_camera_poses", "rsba_problem_set_camera_constant", "rsba_solver_full_report",
 ]
 
 
@@ -107,6 +107,7 @@ def load():
     lib.rsba_solver_download.argtypes = [C.c_void_p]
     lib.rsba_solver_iterations.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.rsba_solver_kernel_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.rsba_solver_full_report.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     lib.rsba_solver_final_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rsba_solver_destroy.argtypes = [C.c_void_p]
     lib.rsba_points_linearize_and_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 4
@@ -121,6 +122,7 @@ def load():
     lib.rsba_marker_corners_in_camera.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
     lib.rsba_solve_pnp_epnp.argtypes = [C.c_int32] + [C.c_void_p] * 4
     lib.rsba_problem_initial_camera_poses.argtypes = [C.c_void_p]
+    lib.rsba_problem_set_camera_constant.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     _LIB = lib
     return lib
 
@@ -221,6 +223,9 @@ class Problem:
         _chk(load().rsba_reprojection_error(self.h, C.byref(o), C.byref(err), C.byref(rms)), "rsba_reprojection_error")
         return err.value, rms.value
 
+    def set_camera_constant(self, camera_idx, constant=True):
+        _chk(load().rsba_problem_set_camera_constant(self.h, camera_idx, 1 if constant else 0), "rsba_problem_set_camera_constant")
+
     def initial_camera_poses(self):
         _chk(load().rsba_problem_initial_camera_poses(self.h), "rsba_problem_initial_camera_poses")
 
@@ -268,6 +273,14 @@ class Solver:
         arr = (KernelStat * cap)()
         n = load().rsba_solver_kernel_stats(self.h, arr, cap)
         return {a.name.decode(): (a.launches, a.total_ms) for a in arr[:n]}
+
+    def full_report(self):
+        n = load().rsba_solver_full_report(self.h, None, 0)
+        if n < 0:
+            raise RsbaError(3, "rsba_solver_full_report")
+        buf = C.create_string_buffer(n + 1)
+        load().rsba_solver_full_report(self.h, buf, n + 1)
+        return buf.value.decode()
 
     def final_costs(self):
         c, ss = C.c_double(), C.c_double()

@@ -147,7 +147,8 @@ k_chol_step(int n, int kb, double* __restrict__ W, double* __restrict__ F, int* 
 __global__ void __launch_bounds__(1024)
 k_chol_finish(int C, const double* __restrict__ red, RedLayout L, double* __restrict__ F, const double* __restrict__ scale_c,
               const double* __restrict__ cam_x, double* __restrict__ cam_c, const double* __restrict__ intr, double* __restrict__ camc_c,
-              double* __restrict__ dcam, const double* __restrict__ gmax_p, double* __restrict__ res, const int* __restrict__ ok_flag) {
+              double* __restrict__ dcam, const double* __restrict__ gmax_p, double* __restrict__ res, const int* __restrict__ ok_flag,
+              const double* __restrict__ cam_free) {
   extern __shared__ double lds[];
   const int n = L.nc, tid = threadIdx.x, nt = blockDim.x;
   double* y = BackSubstituteBlocks(n, F, lds);
@@ -155,7 +156,7 @@ k_chol_finish(int C, const double* __restrict__ red, RedLayout L, double* __rest
   for (int i = tid; i < n; i += nt) ysol[i] = y[i];
   __threadfence_block();
   __syncthreads();
-  CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, *ok_flag, lds);
+  CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, *ok_flag, lds, cam_free);
 }
 
 }  // namespace rsba

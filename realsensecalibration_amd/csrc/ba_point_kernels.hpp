@@ -42,6 +42,7 @@ struct IterParams {
   double huber_delta;
   int first;           // 1: iteration 0 -> compute and store the Jacobi scales
   int jacobi_scaling;
+  const double* cam_free = nullptr;   // per camera 1.0 / 0.0 (constant block: SetParameterBlockConstant); nullptr: all free
 };
 
 // Result block the host reads back once per iteration (and RCCL reduces in part).
@@ -135,6 +136,10 @@ k_linearize_schur_ref(int C, int P, const double* __restrict__ obs_u, const doub
     if (act) {
       cam = obs_cam[b + lane];
       ResidualJacobian(camc + (size_t)cam * ccs, X, obs_u[b + lane], obs_v[b + lane], r, jc, jp);
+      if (ip.cam_free != nullptr && ip.cam_free[cam] == 0.0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) jc[i] = 0.0;   // a constant camera has no columns
+      }
       double sq;
       rho = LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
       if (sq != 1.0) {
@@ -288,7 +293,7 @@ __device__ __forceinline__ void CameraStepEpilogue(int C, const double* __restri
                                                    const double* __restrict__ ysol, const double* __restrict__ cam_x,
                                                    double* __restrict__ cam_c, const double* __restrict__ intr, double* __restrict__ camc_c,
                                                    double* __restrict__ dcam, const double* __restrict__ gmax_p, double* __restrict__ res,
-                                                   int ok, double* lds) {
+                                                   int ok, double* lds, const double* __restrict__ cam_free = nullptr) {
   const int n = L.nc, tid = threadIdx.x, nt = blockDim.x;
   // 5. camera step, candidate cameras, norms, gradient max over the camera part
   double d2 = 0, x2 = 0, xc2 = 0, gm = 0;
@@ -297,7 +302,8 @@ __device__ __forceinline__ void CameraStepEpilogue(int C, const double* __restri
     dcam[i] = d;
     const double x = cam_x[i], xc = x + d;
     cam_c[i] = xc;
-    d2 += d * d; x2 += x * x; xc2 += xc * xc;
+    // a constant camera is not a parameter of the reduced program: Ceres' norms do not see it (its step is 0 anyway)
+    if (cam_free == nullptr || cam_free[i / 6] != 0.0) { d2 += d * d; x2 += x * x; xc2 += xc * xc; }
     gm = fmax(gm, fabs(red[L.gc() + i]));
   }
   // small fixed-order reduction through LDS
@@ -562,7 +568,7 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
   if (tid == 0) { g_phase_cycles[9] += clock64() - _k0; }
 #endif
   // 5. camera step, candidate cameras, norms, gradient max over the camera part
-  CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, ok, lds);
+  CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, ok, lds, ip.cam_free);
   if (gate.trace && tid == 0) gate.trace[15] = wall_clock64();
   SolveDone(gate);
 }

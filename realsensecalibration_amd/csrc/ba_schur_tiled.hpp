@@ -341,7 +341,8 @@ __device__ __forceinline__ bool StageArrive(const SchurSeg& sg, int* __restrict_
 
 // Self tile: lane (ia, s) holds slice s of camera 16 ga + ia's 42 sums in v[]; called by the whole workgroup (shuffles).
 // Adds the 16 slices in a fixed tree order, then K factors, diagonal S block, diag(U), g_c and the rhs correction.
-__device__ __forceinline__ void FinishSelfSlot(int C, int ga, double* v, const double* __restrict__ camc, double* __restrict__ red, RedLayout L) {
+__device__ __forceinline__ void FinishSelfSlot(int C, int ga, double* v, const double* __restrict__ camc, double* __restrict__ red, RedLayout L,
+                                               const double* __restrict__ cam_free) {
   const int tid = threadIdx.x, ia = tid >> 4, ib = tid & 15, cam_a = RSBA_TG * ga + ia;
   // sum the 16 slices of a row (lanes ia*16 .. ia*16+15 are contiguous inside a wave) in a fixed tree order
 #pragma unroll
@@ -350,6 +351,12 @@ __device__ __forceinline__ void FinishSelfSlot(int C, int ga, double* v, const d
     for (int i = 0; i < RSBA_PART; ++i) v[i] += __shfl_down(v[i], off, 16);
   }
   if (ib != 0 || cam_a >= C) return;
+  if (cam_free != nullptr && cam_free[cam_a] == 0.0) {
+    // constant camera: no columns in the reduced program -> zero block, gradient and damping diagonal; the LM floor
+    // (min_lm_diagonal / radius) keeps the factorisation positive and its step is exactly zero
+#pragma unroll
+    for (int i = 0; i < RSBA_PART; ++i) v[i] = 0.0;
+  }
   const double* K = camc + (size_t)cam_a * CC_STRIDE + CC_K;
   // symmetric core -> full 6x6, then T' core T with T = blkdiag(K, I)
   double cfull[36];
@@ -399,7 +406,7 @@ __device__ __forceinline__ void FinishSelfSlot(int C, int ga, double* v, const d
 
 // K factors and the S blocks of one camera pair: slot (ia, ib) of tile (ga, gb) with its 36 reduced sums in `core`.
 __device__ __forceinline__ void FinishPairSlot(int C, int ga, int gb, int slot, const double* core, const double* __restrict__ camc,
-                                               double* __restrict__ red, RedLayout L) {
+                                               double* __restrict__ red, RedLayout L, const double* __restrict__ cam_free) {
   const int ia = slot >> 4, ib = slot & 15;
   const int cam_a = RSBA_TG * ga + ia, cam_b = RSBA_TG * gb + ib;
   if (cam_a >= C || cam_b >= C || (ga == gb && ia >= ib)) return;
@@ -423,6 +430,10 @@ __device__ __forceinline__ void FinishPairSlot(int C, int ga, int gb, int slot, 
 #pragma unroll
     for (int q = 3; q < 6; ++q) blk[6 * p + q] = tmp[6 * p + q];
   }
+  if (cam_free != nullptr && cam_free[cam_a] * cam_free[cam_b] == 0.0) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) blk[i] = 0.0;   // a constant camera couples to nobody
+  }
   // S is written full symmetric: block (a,b) = -blk, block (b,a) = -blk' (nobody else touches off-diagonal blocks)
   double* Sb = red + L.S() + (size_t)(6 * cam_a) * L.nc + 6 * cam_b;
   double* St = red + L.S() + (size_t)(6 * cam_b) * L.nc + 6 * cam_a;
@@ -438,6 +449,7 @@ __device__ __forceinline__ void FinishPairSlot(int C, int ga, int gb, int slot, 
 struct SchurArgs {
   int C, P, nwords;
   const double* __restrict__ camc;
+  const double* __restrict__ cam_free;   // per camera 1.0 / 0.0 (constant), nullptr: all free
   const SchurSeg* __restrict__ segs;
   const unsigned long long* __restrict__ cam_mask;
   const double* __restrict__ ptdata;
@@ -567,7 +579,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
   if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();
   double v[36];
   if (!GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
-  FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L);
+  FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L, a.cam_free);
   if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (a.trace && tid == 0) a.trace[17 + sg.stage] = wall_clock64();
@@ -673,7 +685,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();
   double v[RSBA_PART];
   if (!GroupReduce<RSBA_PART>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
-  FinishSelfSlot(C, sg.ga, v, camc, a.red, a.L);
+  FinishSelfSlot(C, sg.ga, v, camc, a.red, a.L, a.cam_free);
   if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
   if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -740,13 +752,13 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
     double v[RSBA_PART];
 #pragma unroll
     for (int i = 0; i < RSBA_PART; ++i) v[i] = ts[i * 256];
-    FinishSelfSlot(a.C, sg.ga, v, a.camc, a.red, a.L);
+    FinishSelfSlot(a.C, sg.ga, v, a.camc, a.red, a.L, a.cam_free);
     if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
   } else {
     double v[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) v[i] = ts[i * 256];
-    FinishPairSlot(a.C, sg.ga, sg.gb, tid, v, a.camc, a.red, a.L);
+    FinishPairSlot(a.C, sg.ga, sg.gb, tid, v, a.camc, a.red, a.L, a.cam_free);
   }
   if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -141,6 +141,8 @@ struct rsba_solver {
   KernelTimer timer;
   std::vector<rsba_iteration> iters;
   double final_cost = 0, final_sumsq = 0, setup_seconds = 0;
+  rsba_summary last_summary{};   // of the latest rsba_solver_run (rsba_solver_full_report)
+  bool has_run = false;
 
   // ---- point model
   int C = 0, P = 0, nc = 0;
@@ -155,6 +157,7 @@ struct rsba_solver {
   ObsSliced sliced() const { return ObsSliced{sl_row_ptr, sl_uv, sl_cam}; }
   int *obs_cam = nullptr, *pt_ptr = nullptr;
   double *cam[2] = {nullptr, nullptr}, *pts[2] = {nullptr, nullptr}, *camc[2] = {nullptr, nullptr};
+  double* cam_free = nullptr;   // [C] 1.0 / 0.0: constant cameras (nullptr when there are none)
   double *cam0 = nullptr, *pts0 = nullptr;  // uploaded initial state (rsba_solver_run restarts from it)
   double *scale_c = nullptr, *scale_p = nullptr;
   double *W = nullptr;     // working copy of the reduced system for the multi-launch Cholesky (nc > RSBA_CHOL_MAXN)
@@ -367,7 +370,7 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res};
+                  s->block_part, s->small_red, s->gmax, s->res, s->cam_free};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
@@ -444,6 +447,12 @@ static int UploadPoints(rsba_solver* s) {
   const rsba_problem& p = *s->prob;
   s->C = p.num_cameras; s->P = p.num_points; s->N = p.num_observations; s->nc = 6 * s->C; s->L = RedLayout{s->nc};
   const int C = s->C, P = s->P; const int64_t N = s->N;
+  if (std::find(p.camera_constant.begin(), p.camera_constant.end(), (uint8_t)1) != p.camera_constant.end()) {
+    std::vector<double> fr(C, 1.0);
+    for (int c = 0; c < C && c < (int)p.camera_constant.size(); ++c) if (p.camera_constant[c]) fr[c] = 0.0;
+    if (hipMalloc((void**)&s->cam_free, C * sizeof(double)) != hipSuccess ||
+        hipMemcpy(s->cam_free, fr.data(), C * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return RSBA_ERR_HIP;
+  }
   std::vector<int> ptr(P + 1, 0);
   for (int64_t i = 0; i < N; ++i) ptr[p.point_index[i] + 1]++;
   int maxk = 0;
@@ -579,7 +588,7 @@ void TiledSchur::LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTim
 void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag) {
   const int x = s->cur;
   SchurArgs a;
-  a.C = C; a.P = P; a.nwords = nwords; a.camc = s->camc[x]; a.segs = segs; a.cam_mask = cam_mask; a.ptdata = ptdata;
+  a.C = C; a.P = P; a.nwords = nwords; a.camc = s->camc[x]; a.cam_free = s->cam_free; a.segs = segs; a.cam_mask = cam_mask; a.ptdata = ptdata;
   a.cam_prefix = cam_prefix; a.cam_ptr = cam_ptr; a.sq_cm = sq_cm; a.u_cm = u_cm; a.v_cm = v_cm; a.partial = partial;
   a.grp_sum = grp_sum; a.sync_cnt = sync_cnt; a.ngrp = ngrp; a.ntiles = ntiles; a.block_seg = block_seg; a.last_group = ngroups - 1; a.tile_sum = tile_sum; a.tree_error = tree_error; a.ticket = tree_error + 1;
   a.ready = ready; a.tag = tag; a.red = s->red; a.L = s->L; a.nblocks_pp = grid_pp; a.block_scal = block_scal; a.gmax_p = s->gmax;
@@ -602,7 +611,8 @@ int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
 static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_system_copy) {
   const int C = s->C, P = s->P, x = s->cur, c = 1 - s->cur;
   hipStream_t st = s->stream;
-  const IterParams ip = MakeIterParams(s->opt, radius, first);
+  IterParams ip = MakeIterParams(s->opt, radius, first);
+  ip.cam_free = s->cam_free;
   KernelTimer& T = s->timer;
 
   if (s->trace) s->host_t[0] = std::chrono::steady_clock::now();
@@ -722,7 +732,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const size_t lds_f = std::max((size_t)4 * 1024, (size_t)((n + 63) & ~63) + 3 * RSBA_PB * RSBA_PLD + 64) * sizeof(double);
     T.Begin("k_chol_finish", st);
     k_chol_finish<<<1, 1024, lds_f, st>>>(C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res,
-                                          s->chol_ok);
+                                          s->chol_ok, s->cam_free);
     T.End(st);
   }
   DebugSync(st, "k_reduced_system_solve");
@@ -1019,6 +1029,7 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
   }
   s->timer.Collect();
   s->final_cost = sum.final_cost;
+  s->last_summary = sum; s->has_run = true;
   if (sum_out) *sum_out = sum;
   return rc;
 }
@@ -1052,6 +1063,73 @@ int rsba_solver_kernel_stats(const rsba_solver* s, rsba_kernel_stat* out, int32_
     out[n].launches = kv.second.first; out[n].total_ms = kv.second.second;
     ++n;
   }
+  return n;
+}
+
+// ceres::Solver::Summary::FullReport() (printed by bundle_adjustment_manager.cpp:95): same sections, the values this
+// solver has.  Returns the length the full text needs (snprintf semantics); buf may be NULL with capacity 0.
+int rsba_solver_full_report(const rsba_solver* s, char* buf, int32_t capacity) {
+  if (!s || !s->has_run || capacity < 0 || (!buf && capacity > 0)) return -1;
+  const rsba_problem& p = *s->prob;
+  const rsba_summary& m = s->last_summary;
+  long long blocks0, params0, blocks1, params1, rblocks, residuals;
+  if (p.model == RSBA_MODEL_POINTS) {
+    int nconst = 0;
+    for (uint8_t c : p.camera_constant) nconst += c ? 1 : 0;
+    blocks0 = (long long)p.num_cameras + p.num_points; params0 = 6LL * p.num_cameras + 3LL * p.num_points;
+    blocks1 = blocks0 - nconst; params1 = params0 - 6LL * nconst;
+    rblocks = p.num_observations; residuals = 2 * rblocks;
+  } else {
+    const int nb = p.num_cameras + p.num_times + p.num_markers;
+    std::vector<char> used(nb, 0);
+    for (int64_t i = 0; i < p.num_observations; ++i) {
+      if (p.uses_camera(i)) used[p.camera_block(i)] = 1;
+      used[p.time_block(i)] = 1;
+      if (p.uses_marker(i)) used[p.marker_block(i)] = 1;
+    }
+    int nu = 0; for (char u : used) nu += u;
+    // blocks no residual touches never enter the ceres::Problem (camera 0 / marker 0 of the reference's wiring)
+    blocks0 = blocks1 = nu; params0 = params1 = 6LL * nu;
+    rblocks = p.num_observations; residuals = 8 * rblocks;
+  }
+  static const char* kTerm[] = {"CONVERGENCE", "NO_CONVERGENCE", "FAILURE"};
+  char why[192] = "";
+  const rsba_iteration* last = s->iters.empty() ? nullptr : &s->iters.back();
+  switch (m.stop_reason) {
+    case RSBA_STOP_FUNCTION:
+      if (last) snprintf(why, sizeof(why), "Function tolerance reached. |cost_change|/cost: %e <= %e", std::fabs(last->cost_change) / std::max(last->cost + last->cost_change, 1e-300), s->opt.function_tolerance);
+      break;
+    case RSBA_STOP_PARAMETER: snprintf(why, sizeof(why), "Parameter tolerance reached. Relative step_norm <= %e", s->opt.parameter_tolerance); break;
+    case RSBA_STOP_GRADIENT:
+      if (last) snprintf(why, sizeof(why), "Gradient tolerance reached. Gradient max norm: %e <= %e", last->gradient_max_norm, s->opt.gradient_tolerance);
+      break;
+    case RSBA_STOP_MAX_ITERATIONS: snprintf(why, sizeof(why), "Maximum number of iterations reached. Number of iterations: %d.", m.num_iterations); break;
+    case RSBA_STOP_MIN_RADIUS: snprintf(why, sizeof(why), "Minimum trust region radius reached. Trust region radius <= %e", s->opt.min_trust_region_radius); break;
+    case RSBA_STOP_INVALID_STEPS: snprintf(why, sizeof(why), "Number of successive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d", s->opt.max_num_consecutive_invalid_steps); break;
+    case RSBA_STOP_INITIAL_FAILURE: snprintf(why, sizeof(why), "Residual and Jacobian evaluation failed."); break;
+    default: break;
+  }
+  hipDeviceProp_t prop; memset(&prop, 0, sizeof(prop));
+  (void)hipGetDeviceProperties(&prop, s->device);
+  const int n = snprintf(buf, (size_t)capacity,
+      "\nSolver Summary (rsba %d.%02d, %s)\n\n"
+      "%-32s%12s%25s\n"
+      "%-32s%12lld%25lld\n%-32s%12lld%25lld\n%-32s%12lld%25lld\n%-32s%12lld%25lld\n\n"
+      "%-25s%19s\n%-25s%19s\n%-25s%19s\n\n"
+      "%-32s%12s%25s\n%-32s%12s%25s\n%-32s%12d%25d\n\n"
+      "Cost:\n%-25s%19.6e\n%-25s%19.6e\n%-25s%19.6e\n\n"
+      "%-32s%12d\n%-32s%12d\n%-32s%12d\n\n"
+      "Time (in seconds):\n%-25s%19.6f\n%-25s%19.6f\n%-25s%19.6f\n\n"
+      "Termination: %25s (%s)\n",
+      RSBA_VERSION / 100, RSBA_VERSION % 100, prop.gcnArchName[0] ? prop.gcnArchName : "HIP device",
+      "", "Original", "Reduced",
+      "Parameter blocks", blocks0, blocks1, "Parameters", params0, params1, "Residual blocks", rblocks, rblocks, "Residuals", residuals, residuals,
+      "Minimizer", "TRUST_REGION", "Dense linear algebra library", "HIP", "Trust region strategy", "LEVENBERG_MARQUARDT",
+      "", "Given", "Used", "Linear solver", "DENSE_SCHUR", "DENSE_SCHUR", "GPUs", std::max(s->opt.world_size, 1), std::max(s->opt.world_size, 1),
+      "Initial", m.initial_cost, "Final", m.final_cost, "Change", m.initial_cost - m.final_cost,
+      "Minimizer iterations", m.num_successful_steps + m.num_unsuccessful_steps + 1, "Successful steps", m.num_successful_steps + 1, "Unsuccessful steps", m.num_unsuccessful_steps,
+      "Preprocessor", m.setup_seconds, "Minimizer", m.minimizer_seconds, "Total", m.setup_seconds + m.minimizer_seconds,
+      kTerm[std::min(std::max(m.termination_type, 0), 2)], why);
   return n;
 }
 

@@ -68,6 +68,13 @@ int rsba_problem_load_points_file(const char* path, const double* intrinsics4, r
 int rsba_problem_load_correspondence(const char* path, int32_t model, double marker_side, const double* intrinsics, rsba_problem** out) {
   return rsba::LoadCorrespondence(path, model, marker_side, intrinsics, out);
 }
+int rsba_problem_set_camera_constant(rsba_problem* p, int32_t camera_idx, int32_t constant) {
+  if (!p || camera_idx < 0 || camera_idx >= p->num_cameras) return RSBA_ERR_ARG;
+  if (p->model != RSBA_MODEL_POINTS) return RSBA_ERR_UNSUPPORTED;   // the marker-chain wiring already fixes camera 0 / marker 0
+  if (p->camera_constant.empty()) p->camera_constant.assign(p->num_cameras, 0);
+  p->camera_constant[camera_idx] = constant ? 1 : 0;
+  return RSBA_OK;
+}
 void rsba_problem_free(rsba_problem* p) { delete p; }
 
 int rsba_base_pose_from_marker_detection(const double* marker_from_camera, const double* marker_from_base, double* base_from_camera) {

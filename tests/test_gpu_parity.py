@@ -565,3 +565,57 @@ def test_golden_fixtures_through_time_elimination(oracle, tmp_path):
     assert np.abs(p.params[6:9] - xmlv["R1"].ravel()).max() < 1e-9
     assert np.abs(p.params[9:12] - xmlv["t1"].ravel()).max() < 1e-9
     p.close()
+
+
+# ------------------------------------------------------------------ constant camera blocks
+@pytest.mark.parametrize("shape,const,impl", [((8, 2000, 6), (0,), 1), ((24, 3000, 8), (0, 17), 1), ((8, 1500, 6), (3,), 0),
+                                              ((70, 1500, 10), (0, 69), 1)])
+def test_constant_cameras_match_oracle(oracle, shape, const, impl):
+    """Problem::SetParameterBlockConstant on camera blocks: the cameras keep their bits, the rest follows the oracle's
+    trajectory (Jacobian columns dropped, norms without the constant blocks)."""
+    C_, P_, k_ = shape
+    prob = syn.make_problem(C_, P_, k_, seed=C_ + P_)
+    ref, s_ref, _ = oracle.solve_points_constant(prob, const)
+    p = capi.Problem.points(prob)
+    for c in const:
+        p.set_camera_constant(c)
+    s = p.solve(capi.default_options(schur_impl=impl))
+    got = p.params.copy()
+    p.close()
+    assert s.num_iterations == s_ref.num_iterations and s.num_successful_steps == s_ref.num_successful_steps
+    assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
+    for c in const:
+        assert np.array_equal(got[6 * c:6 * c + 6], prob["params"][6 * c:6 * c + 6])
+    assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
+    # and it is a different problem from the free one
+    free, s_free, _ = oracle.solve_points(prob)
+    assert np.abs(free[:6 * C_] - ref[:6 * C_]).max() > 1e-6
+
+
+def test_constant_camera_is_refused_for_the_marker_chain_model():
+    prob = syn.make_marker_chain(3, 10, 4, seed=2)
+    p = capi.Problem.marker_chain(prob)
+    with pytest.raises(capi.RsbaError):
+        p.set_camera_constant(1)
+    p.close()
+
+
+def test_full_report_of_the_committed_problem():
+    """Summary::FullReport() (bundle_adjustment_manager.cpp:95): sizes of the reduced program as Ceres counts them (camera 0
+    and marker 0 never enter the problem: 19 blocks / 114 parameters, 68 residual blocks / 544 residuals), Ceres' step
+    counts (iteration 0 counts as a successful step) and its termination message."""
+    intr = ol.read_intrinsics(ol.SERIALS_MAIN)
+    p = capi.Problem.correspondence(os.path.join(G, "hongo", "correspondence.txt"), capi.MODEL_MARKER_CHAIN, ol.MARKER_SIDE_MAIN, intr)
+    sv = capi.Solver(p)
+    with pytest.raises(capi.RsbaError):
+        sv.full_report()          # nothing has run yet
+    sv.run()
+    rep = sv.full_report()
+    sv.close(); p.close()
+    lines = {ln[:25].strip(): ln.split() for ln in rep.splitlines() if ln.strip()}
+    assert lines["Parameter blocks"][-2:] == ["19", "19"] and lines["Parameters"][-2:] == ["114", "114"]
+    assert lines["Residual blocks"][-2:] == ["68", "68"] and lines["Residuals"][-2:] == ["544", "544"]
+    assert lines["Linear solver"][-2:] == ["DENSE_SCHUR", "DENSE_SCHUR"]
+    assert lines["Minimizer iterations"][-1] == "7" and lines["Successful steps"][-1] == "7" and lines["Unsuccessful steps"][-1] == "0"
+    assert abs(float(lines["Initial"][-1]) - 1.387967e5) < 1 and abs(float(lines["Final"][-1]) - 1.436294e2) < 1e-3
+    assert "CONVERGENCE (Function tolerance reached. |cost_change|/cost:" in rep and "gfx950" in rep
