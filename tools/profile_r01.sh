@@ -16,3 +16,7 @@ python3 tools/pmc_to_json.py gpurun_out/prof_pmc_fetch gpurun_out/prof_pmc_write
 python3 tools/pmc_summary.py gpurun_out/prof_pmc_fetch gpurun_out/prof_pmc_write gpurun_out/prof_pmc_sq gpurun_out/prof_pmc_sq2 > gpurun_out/r01_pmc_summary.txt
 cp $(ls gpurun_out/prof_kt/*/*kernel_stats.csv | head -1) gpurun_out/r01_kernel_stats.csv
 tail -1 gpurun_out/prof_kt.json > gpurun_out/r01_bench_under_rocprof.json
+# marker-chain model at scale (time-block elimination): kernel trace of tools/marker_chain_scale.py
+rm -rf gpurun_out/prof_mc
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_mc -- python3 tools/marker_chain_scale.py 8 5000 16 > gpurun_out/r01_marker_chain_scale.json 2> gpurun_out/prof_mc.err
+cp $(ls gpurun_out/prof_mc/*/*kernel_stats.csv | head -1) gpurun_out/r01_marker_chain_kernel_stats.csv
