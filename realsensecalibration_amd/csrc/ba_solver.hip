@@ -29,6 +29,7 @@
 #include "ba_marker_schur.hpp"
 #include "ba_point_kernels.hpp"
 #include "ba_cholesky_large.hpp"
+#include "ba_cholesky_multi.hpp"
 #include "ba_problem.hpp"
 #include "ba_schur_tiled.hpp"
 #include "ba_solver.hpp"
@@ -125,6 +126,9 @@ struct rsba_solver {
   int test_stall = 0;        // RSBA_TEST_STALL=1: the Cholesky waits for a tag nobody publishes, =2: the back-substitution does
                              // (both exercise the fallback to the sequential schedule)
   int step_tag = 0;
+  int chol_wgs = 1;          // > 1: the reduced system is factored by this many workgroups (ba_cholesky_multi.hpp)
+  int* mc_flags = nullptr;   // tdone[16] | strip_ready[16] | wg_done[8] | error
+  long long* mc_trace = nullptr;   // RSBA_MC_TRACE=1: stamps of the latest multi-workgroup factorisation
   hipStream_t sB = nullptr;
   // Multi-GPU pipeline: the stage flags the Cholesky waits on are published on the communication stream sR, each after
   // the RCCL all-reduce of that stage's row slab of S (k_wait_stage / k_set_flag, ba_schur_tiled.hpp)
@@ -370,7 +374,7 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res, s->cam_free};
+                  s->block_part, s->small_red, s->gmax, s->res, s->cam_free, s->mc_flags};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
@@ -534,6 +538,19 @@ static int UploadPoints(rsba_solver* s) {
     s->pipelined = SetupPipeline(s);
   }
   {
+    // several workgroups for the reduced system: 32, 48 or 64 cameras (whole 32-wide panels), full symmetric S
+    const char* e = getenv("RSBA_CHOL_WGS");
+    const int want = e ? atoi(e) : 4;
+    if (want > 1 && s->opt.schur_impl != 0 && s->nc % RSBA_PB == 0 && s->nc >= 6 * RSBA_PB && s->nc <= RSBA_CHOL_MAXN && !s->pipelined_mg) {
+      s->chol_wgs = std::min(want, RSBA_MC_MAXG);
+      if ((rc = DevAlloc(&s->mc_flags, 48))) return rc;
+      HIPCHK(hipMemset(s->mc_flags, 0, 48 * sizeof(int)));
+      if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, RSBA_MC_MAXG * 16 * 8))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, RSBA_MC_MAXG * 16 * 8 * sizeof(long long))); }
+      HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(MultiCholLdsDoubles(s->nc) * sizeof(double))));
+    }
+  }
+  {
     // Multi-GPU: the pipelined schedule issues other collectives than the sequential one, so the ranks have to agree.
     // Every rank with a communicator takes part in this one all-reduce (min), whatever its own answer was (a shard
     // with duplicate observations runs schur_impl 0 and cannot pipeline); it is also the communicator's first
@@ -665,6 +682,12 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // multi-GPU: the gates open on the flags the communication stream publishes after each stage's all-reduce, the
     // panels are read from the (all-reduced) row slab of their own group, and the waits may last as long as the slowest rank
     T.Begin("k_reduced_system_solve", s->sB);
+    if (s->chol_wgs > 1 && !mg)
+      k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
+          C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
+          StageGate{ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15, T.enabled() ? s->chol_waited : nullptr, s->trace, 0},
+          MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 40}, tag, s->mc_trace);
+    else
     k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                      s->camc[c], s->dcam, s->gmax, s->res, ip, (mg || getenv("RSBA_TRANSPOSED_SOURCE")) ? 2 : 1,
                                                      s->chol_ok, StageGate{mg ? s->ready_global : ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15,
@@ -709,6 +732,12 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   } else if (s->nc <= RSBA_CHOL_MAXN) {
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(s->nc)) * sizeof(double);
     T.Begin("k_reduced_system_solve", st);
+    if (s->chol_wgs > 1 && !keep_system_copy)
+      k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(s->nc) * sizeof(double), st>>>(
+          C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
+          StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0}, MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 40},
+          s->step_tag, s->mc_trace);
+    else
     k_reduced_system_solve<<<1, 512, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
                                                   keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                   s->camc[c], s->dcam, s->gmax, s->res, ip, s->opt.schur_impl != 0 ? 1 : 0,
@@ -828,6 +857,14 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       }
     }
   }
+  if (!pipe && s->chol_wgs > 1 && s->res_host[RES_STALL] != 0.0) {
+    // the workgroups of the factorisation did not run side by side (cannot happen on an idle stream): one workgroup then
+    fprintf(stderr, "rsba: multi-workgroup Cholesky stalled; using one workgroup\n");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(s->mc_flags, 0, 48 * sizeof(int)));
+    s->chol_wgs = 1;
+    return PointsStep(s, radius, first, keep_system_copy);
+  }
   if (pipe && (s->res_host[RES_STALL] != 0.0 || s->res_host[RES_WAIT_TIMEOUT] != 0.0)) {
     // the waiting Cholesky never saw its columns (its producers were not running beside it): nothing of x has been
     // touched, so repeat the step with the plain schedule and stay there
@@ -835,6 +872,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(s->tiled.sync_cnt, 0, (size_t)s->tiled.nsync * sizeof(int)));
     HIPCHK(hipMemset(s->tiled.tree_error + 1, 0, sizeof(int)));
+    if (s->mc_flags) HIPCHK(hipMemset(s->mc_flags, 0, 48 * sizeof(int)));
     s->pipelined = false; s->pipelined_mg = false;
     return PointsStep(s, radius, first, keep_system_copy);
   }
@@ -1141,6 +1179,19 @@ int rsba_solver_final_costs(const rsba_solver* s, double* cost, double* sum_sq) 
 }
 
 void rsba_solver_destroy(rsba_solver* s) {
+  if (s && s->mc_trace) {
+    // diagnostic: per workgroup and panel, microseconds since the kernel's first stamp
+    std::vector<long long> h(RSBA_MC_MAXG * 16 * 8);
+    if (hipMemcpy(h.data(), s->mc_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+      long long t0 = 0; for (long long v : h) if (v && (!t0 || v < t0)) t0 = v;
+      for (int w = 0; w < s->chol_wgs; ++w) for (int p = 0; p < s->nc / 32; ++p) {
+        fprintf(stderr, "rsba[mc] wg %d panel %2d:", w, p);
+        for (int k = 0; k < 8; ++k) { const long long v = h[((size_t)w * 16 + p) * 8 + k]; fprintf(stderr, " %7.2f", v ? (v - t0) / 100.0 : -1.0); }
+        fprintf(stderr, "\n");
+      }
+    }
+    (void)hipFree(s->mc_trace);
+  }
 #ifdef RSBA_PROFILE_PHASES
   { long long h[16]; if (hipMemcpyFromSymbol(h, HIP_SYMBOL(rsba::g_phase_cycles), sizeof(h)) == hipSuccess) { fprintf(stderr, "rsba[phases]"); for (int i = 0; i < 16; ++i) fprintf(stderr, " %lld", h[i]); fprintf(stderr, "\n"); } }
 #endif
