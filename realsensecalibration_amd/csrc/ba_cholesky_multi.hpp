@@ -69,19 +69,30 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
   const int np = n / RSBA_PB;              // column panels; blocks 0 .. np (block np: the rhs row alone)
   const long long budget = gate.budget > 0 ? gate.budget : RSBA_STALL_TICKS;
   __shared__ int s_ok;
-  // LDS: strip (32 p rows of 33) | this workgroup's blocks of the panel (32 x 33 each) | T | Lt | invd | scale
+  __shared__ int s_wb;     // arrivals at the working waves' own barrier
+  int wb_gen = 0;
+  // LDS: strip (32 p rows of 33) | this workgroup's blocks of the panel (32 x 33 each) | T | Lt | invd | scale | Pre | Xl
   const int max_rows = n + RSBA_PB;       // strip + panel blocks never exceed (p + ceil((np + 1 - p) / G)) * 32 <= n + 32 rows
   double* T = lds + (size_t)max_rows * RSBA_PLD;
   double* Lt = T + RSBA_PB * RSBA_PLD;
-  double* invd = Lt + RSBA_PB * RSBA_PLD;
+  double* Xl = Lt + RSBA_PB * RSBA_PLD;    // X of the next diagonal block in the current panel (rank-32 update, last rows of its strip)
+  double* invd = Xl + RSBA_PB * RSBA_PLD;
   double* scl = invd + 64;
-  if (tid == 0) s_ok = 1;
+  double* Pre = scl + n;                   // the NEXT diagonal block of this workgroup, updated ahead of its panel
+  double* part = T;                        // T | Lt | Xl are idle before T(p) arrives: partial tiles of the K-split update
+                                           // (up to six 16 x 32) and of the look-ahead product (eight 16 x 16)
+  if (tid == 0) { s_ok = 1; s_wb = 0; }
   bool stalled = false;
+  const double* S = red + L.S();
+  const double inv_radius = 1.0 / ip.radius;
+  const int mi = lane & 15, kk = lane >> 4;
 
   // pipelined first iteration: the Jacobi scale needs the whole damping diagonal
   if (gate.ready != nullptr && ip.first) {
     for (int g = 0; g * gate.cols < n; ++g)
       if (!WaitReady(gate.ready + 1 + g, gate.tag, w == 0 ? gate.waited : nullptr, gate.budget)) { stalled = true; break; }
+  } else if (gate.ready != nullptr && w == 0) {
+    if (!WaitReady(gate.ready + 1, gate.tag, gate.waited, gate.budget)) stalled = true;   // workgroup 0 starts with S(0, 0)
   }
   if (!stalled) {
     for (int i = tid; i < n; i += nt) {
@@ -92,152 +103,265 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
     if (w == 0 && tid == 0) __hip_atomic_store(chol_ok, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  const double* S = red + L.S();
-  const double inv_radius = 1.0 / ip.radius;
+  // scaled, damped entry (gi, gj) of the system, gi < n; the rhs row (gi == n) from gc + corr
+  auto sys = [&](int gi, int gj, double raw) {
+    if (gi == n) return scl[gj] * (red[L.gc() + gj] + red[L.corr() + gj]);
+    double v = raw * (scl[gi] * scl[gj]);
+    if (gi == gj) v += fmin(fmax(scl[gi] * scl[gi] * red[L.diagU() + gi], ip.min_lm_diagonal), ip.max_lm_diagonal) * inv_radius;
+    return v;
+  };
+  if (w == 0 && !stalled) {   // the first diagonal block
+    for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) { const int r = e >> 5, c = e & 31; Pre[r * RSBA_PLD + c] = sys(r, c, S[(size_t)r * n + c]); }
+    __syncthreads();
+  }
 
 #define RSBA_MC_STAMP(k) do { if (mtrace && tid == 0) mtrace[((size_t)w * 16 + p) * 8 + (k)] = wall_clock64(); } while (0)
   for (int p = 0; p < np && !stalled; ++p) {
     const int kb = p * RSBA_PB;
     RSBA_MC_STAMP(0);
-    if (gate.ready != nullptr && kb % gate.cols == 0 && !ip.first) {
-      if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, w == 0 ? gate.waited : nullptr, gate.budget)) { stalled = true; break; }
-    }
     // this workgroup's blocks b >= p: b = first, first + G, ...
     const int first = p + ((w - p % G) + G) % G;
     const int nown = first > np ? 0 : (np - first) / G + 1;
     const bool owner = first == p;
+    const bool next_owner = p + 1 < np && (p + 1) % G == w;    // then first == p + 1: slot 0 is the next diagonal block
+    if (nown == 0) continue;
     double* Bst = lds;
     double* Pan = lds + (size_t)kb * RSBA_PLD;    // slot j: rows of block first + j G
-    // 1. panel columns of the owned blocks, scaled and damped on the fly; the rhs row from gc + corr
-    for (int e = tid; e < nown * RSBA_PB * (RSBA_PB / 4); e += nt) {
-      const int j = e / (RSBA_PB * (RSBA_PB / 4)), rr = (e >> 3) & 31, c0 = (e & 7) * 4;
-      const int b = first + j * G, gi = b * RSBA_PB + rr;
-      double v[4] = {0.0, 0.0, 0.0, 0.0};
-      if (b < np) {
-        const double* srow = S + (size_t)gi * n + kb + c0;
-        const double2 a01 = *reinterpret_cast<const double2*>(srow), a23 = *reinterpret_cast<const double2*>(srow + 2);
-        v[0] = a01.x; v[1] = a01.y; v[2] = a23.x; v[3] = a23.y;
-        const double si = scl[gi];
+    // One 16-row half of an owned block: its columns of the panel (scaled, damped) into Pan, then minus A[rows, 0:kb] Bst'.
+    // A wave loads what it updates itself: no workgroup barrier in between.
+    // (ks, nsplit): this wave's slice of the K range; slice 0 owns the rows in Pan, the others leave their products in
+    // `part` (slot pslot) for slice 0 to add in a fixed order after the barrier.
+    auto load_update_half = [&](int hb, int ks, int nsplit, int pslot) {
+      const int j = hb >> 1, b = first + j * G;
+      const int prow = j * RSBA_PB + (hb & 1) * 16;
+      if (ks == 0) {
+        const int r = lane >> 2, c0 = (lane & 3) * 8;
+        const int gi = b * RSBA_PB + (hb & 1) * 16 + r;
+        double v[8];
+        if (gi < n) {
+          const double2* sp = reinterpret_cast<const double2*>(S + (size_t)gi * n + kb + c0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int gj = kb + c0 + u;
-          v[u] *= si * scl[gj];
-          if (gi == gj) v[u] += fmin(fmax(si * si * red[L.diagU() + gi], ip.min_lm_diagonal), ip.max_lm_diagonal) * inv_radius;
-        }
-      } else if (rr == 0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int gj = kb + c0 + u; v[u] = scl[gj] * (red[L.gc() + gj] + red[L.corr() + gj]); }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) Pan[(j * RSBA_PB + rr) * RSBA_PLD + c0 + u] = v[u];
-    }
-    RSBA_MC_STAMP(1);
-    // 2. strip: rows of block p, columns 0 .. kb, transposed into Bst[q][c]
-    if (p > 0) {
-      if (!owner && !WaitFlagWG(f.strip_ready + p, tag, f.error, budget)) { stalled = true; break; }
-      if (owner) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // its own agent-scope stores of the last panel, not a stale L1 line
-      RSBA_MC_STAMP(2);
-      for (int e = tid; e < (kb >> 2) * RSBA_PB; e += nt) {
-        const int c = e / (kb >> 2), q0 = (e - c * (kb >> 2)) * 4;
-        const double* lrow = A + (size_t)(kb + c) * n + q0;
-        const double2 a01 = *reinterpret_cast<const double2*>(lrow), a23 = *reinterpret_cast<const double2*>(lrow + 2);
-        Bst[(q0 + 0) * RSBA_PLD + c] = a01.x; Bst[(q0 + 1) * RSBA_PLD + c] = a01.y;
-        Bst[(q0 + 2) * RSBA_PLD + c] = a23.x; Bst[(q0 + 3) * RSBA_PLD + c] = a23.y;
-      }
-    }
-    __syncthreads();
-    RSBA_MC_STAMP(3);
-    // 3. update: Pan[block] -= A[block rows, 0:kb] Bst', one wave per 16-row half, the diagonal block's halves first
-    if (p > 0) {
-      const int i = lane & 15, kk = lane >> 4;
-      for (int hb = wave; hb < 2 * nown; hb += nwave) {
-        const int j = hb >> 1, b = first + j * G;
-        const int prow = j * RSBA_PB + (hb & 1) * 16;          // first Pan row of this half
-        const int grow = b * RSBA_PB + (hb & 1) * 16 + i;      // global row of this lane's A operand
-        const bool gl = grow <= n && (b < np || (hb & 1) == 0 && i == 0);
-        const double* arow = A + (size_t)(gl ? grow : 0) * n + 8 * kk;
-        d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-        double an[8], an2[8];
-        auto fetch = [&](double (&d)[8], int q) {
-          const double2* pa = reinterpret_cast<const double2*>(arow + q);
-#pragma unroll
-          for (int v = 0; v < 4; ++v) { const double2 t = pa[v]; d[2 * v] = gl ? t.x : 0.0; d[2 * v + 1] = gl ? t.y : 0.0; }
-        };
-        fetch(an, 0);
-        if (RSBA_PB < kb) fetch(an2, RSBA_PB);
-        for (int q0 = 0; q0 < kb; q0 += RSBA_PB) {
-          double ac[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { ac[u] = an[u]; an[u] = an2[u]; }
-          if (q0 + 2 * RSBA_PB < kb) fetch(an2, q0 + 2 * RSBA_PB);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const double b0 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + i];
-            const double b1 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + 16 + i];
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b1, acc1, 0, 0, 0);
-          }
+          for (int u = 0; u < 4; ++u) { const double2 t = sp[u]; v[2 * u] = t.x; v[2 * u + 1] = t.y; }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int u = 0; u < 8; ++u) Pan[(prow + r) * RSBA_PLD + c0 + u] = gi <= n ? sys(gi, kb + c0 + u, gi < n ? v[u] : 0.0) : 0.0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (p == 0) return;
+      const int nq = kb / RSBA_PB, qper = (nq + nsplit - 1) / nsplit;
+      const int qa = ks * qper * RSBA_PB, qb = min(kb, (ks + 1) * qper * RSBA_PB);   // this slice's columns
+      const int grow = b * RSBA_PB + (hb & 1) * 16 + mi;
+      const bool gl = grow <= n;
+      const double* arow = A + (size_t)(gl ? grow : 0) * n + 8 * kk;
+      d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      double an[8], an2[8];
+      auto fetch = [&](double (&d)[8], int q) {
+        const double2* pa = reinterpret_cast<const double2*>(arow + q);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const double2 t = pa[v]; d[2 * v] = gl ? t.x : 0.0; d[2 * v + 1] = gl ? t.y : 0.0; }
+      };
+      if (qa < qb) fetch(an, qa);
+      if (qa + RSBA_PB < qb) fetch(an2, qa + RSBA_PB);
+      for (int q0 = qa; q0 < qb; q0 += RSBA_PB) {
+        double ac[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ac[u] = an[u]; an[u] = an2[u]; }
+        if (q0 + 2 * RSBA_PB < qb) fetch(an2, q0 + 2 * RSBA_PB);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double b0 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + mi];
+          const double b1 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + 16 + mi];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b1, acc1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (ks == 0) {
           const int r = prow + kk + 4 * t;
-          Pan[r * RSBA_PLD + i] -= acc0[t];
-          Pan[r * RSBA_PLD + 16 + i] -= acc1[t];
+          Pan[r * RSBA_PLD + mi] -= acc0[t];
+          Pan[r * RSBA_PLD + 16 + mi] -= acc1[t];
+        } else {
+          part[pslot * 512 + (kk + 4 * t) * 32 + mi] = acc0[t];
+          part[pslot * 512 + (kk + 4 * t) * 32 + 16 + mi] = acc1[t];
         }
       }
-      __syncthreads();
-    }
-    RSBA_MC_STAMP(4);
-    // 4. the diagonal block: factor + inverse by the owner's wave 0, published; the others fetch T
+    };
+
     if (owner) {
-      if (wave == 0 && !DiagFactorInverseCall((lds_double*)Pan, RSBA_PB, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane) && lane == 0) s_ok = 0;
+      // Pre = this panel's diagonal block, fully updated during the previous panel.
+      // Wave 0 factors at once; the other waves bring the remaining blocks up to date meanwhile.
+      if (wave == 0) {
+        if (!DiagFactorInverseCall((lds_double*)Pre, RSBA_PB, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane) && lane == 0) s_ok = 0;
+      } else if (nown > 1) {
+        if (p > 0) {
+          // the strip of block p: this workgroup's own rows (the last 32 columns stored a moment ago), by the seven working
+          // waves alone, with a barrier of their own (wave 0 is in the factorisation)
+          for (int e = tid - 64; e < (kb >> 2) * RSBA_PB; e += nt - 64) {
+            const int c = e / (kb >> 2), q0 = (e - c * (kb >> 2)) * 4;
+            const double* lrow = A + (size_t)(kb + c) * n + q0;
+            const double2 a01 = *reinterpret_cast<const double2*>(lrow), a23 = *reinterpret_cast<const double2*>(lrow + 2);
+            Bst[(q0 + 0) * RSBA_PLD + c] = a01.x; Bst[(q0 + 1) * RSBA_PLD + c] = a01.y;
+            Bst[(q0 + 2) * RSBA_PLD + c] = a23.x; Bst[(q0 + 3) * RSBA_PLD + c] = a23.y;
+          }
+          ++wb_gen;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) {
+            __hip_atomic_fetch_add(&s_wb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(&s_wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (nwave - 1) * wb_gen) __builtin_amdgcn_s_sleep(1);
+          }
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        for (int hb = 2 + (wave - 1); hb < 2 * nown; hb += nwave - 1) load_update_half(hb, 0, 1, 0);
+      }
       __syncthreads();
+      RSBA_MC_STAMP(4);
       // L11 in the lower triangle, T transposed into the strict upper one, inverse pivots into row n + 1 (the layout
       // BackSubstituteBlocks reads)
       for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) {
         const int r = e >> 5, c = e & 31;
-        StoreShared(&A[(size_t)(kb + r) * n + kb + c], c > r ? T[c * RSBA_PLD + r] : Pan[r * RSBA_PLD + c]);
+        StoreShared(&A[(size_t)(kb + r) * n + kb + c], c > r ? T[c * RSBA_PLD + r] : Pre[r * RSBA_PLD + c]);
       }
       if (tid < RSBA_PB) StoreShared(&A[(size_t)(n + 1) * n + kb + tid], invd[tid]);
       if (tid == 0 && !s_ok) __hip_atomic_store(chol_ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       PublishFlagWG(f.tdone + p, tag);
-    } else if (nown > 0) {
+      RSBA_MC_STAMP(5);
+    } else {
+      if (gate.ready != nullptr && kb % gate.cols == 0 && !ip.first) {
+        if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
+      }
+      if (next_owner) {
+        // Look-ahead, before anything of this panel is needed: the NEXT diagonal block's entries of the system minus
+        // L[block p+1, 0:kb] L[block p+1, 0:kb]' — this workgroup's own rows, final since the last panel — so that only the
+        // X X' of this panel stands between T(p) and the next factorisation.  Wave = (tile row, tile column, half of K).
+        const int nb0 = kb + RSBA_PB;   // first row / column of block p + 1
+        if (gate.ready != nullptr && nb0 % gate.cols == 0 && !ip.first) {
+          if (!WaitReady(gate.ready + 1 + nb0 / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
+        }
+        double sv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; sv[u] = S[(size_t)(nb0 + r) * n + nb0 + c]; }
+        {
+          const int ti = wave >> 2, tj = (wave >> 1) & 1, h = wave & 1;
+          const int nq = kb / RSBA_PB, qh = (nq + 1) >> 1;
+          const int qa = h * qh * RSBA_PB, qb = h ? kb : min(kb, qh * RSBA_PB);
+          const double* ra = A + (size_t)(nb0 + 16 * ti + mi) * n + 8 * kk;
+          const double* rb = A + (size_t)(nb0 + 16 * tj + mi) * n + 8 * kk;
+          d4_t acc = {0, 0, 0, 0};
+          double xa[8], xb[8], ya[8], yb[8];
+          auto fetch2 = [&](double (&da)[8], double (&db)[8], int q) {
+            const double2* pa = reinterpret_cast<const double2*>(ra + q);
+            const double2* pb = reinterpret_cast<const double2*>(rb + q);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { const double2 t = pa[v], t2 = pb[v]; da[2 * v] = t.x; da[2 * v + 1] = t.y; db[2 * v] = t2.x; db[2 * v + 1] = t2.y; }
+          };
+          if (qa < qb) fetch2(xa, xb, qa);
+          if (qa + RSBA_PB < qb) fetch2(ya, yb, qa + RSBA_PB);
+          for (int q0 = qa; q0 < qb; q0 += RSBA_PB) {
+            double ca[8], cb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { ca[u] = xa[u]; cb[u] = xb[u]; xa[u] = ya[u]; xb[u] = yb[u]; }
+            if (q0 + 2 * RSBA_PB < qb) fetch2(ya, yb, q0 + 2 * RSBA_PB);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[u], cb[u], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) part[wave * 256 + (kk + 4 * t) * 16 + mi] = acc[t];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = tid + u * nt, r = e >> 5, c = e & 31;
+          const int pw = ((r >> 4) << 2) | ((c >> 4) << 1);
+          const double d = part[pw * 256 + (r & 15) * 16 + (c & 15)] + part[(pw + 1) * 256 + (r & 15) * 16 + (c & 15)];
+          Pre[r * RSBA_PLD + c] = sys(nb0 + r, nb0 + c, sv[u]) - d;
+        }
+        __syncthreads();
+      }
+      RSBA_MC_STAMP(1);
+      // strip: rows of block p, columns 0 .. kb, transposed into Bst[q][c]
+      if (p > 0) {
+        if (!WaitFlagWG(f.strip_ready + p, tag, f.error, budget)) { stalled = true; break; }
+        RSBA_MC_STAMP(2);
+        for (int e = tid; e < (kb >> 2) * RSBA_PB; e += nt) {
+          const int c = e / (kb >> 2), q0 = (e - c * (kb >> 2)) * 4;
+          const double* lrow = A + (size_t)(kb + c) * n + q0;
+          const double2 a01 = *reinterpret_cast<const double2*>(lrow), a23 = *reinterpret_cast<const double2*>(lrow + 2);
+          Bst[(q0 + 0) * RSBA_PLD + c] = a01.x; Bst[(q0 + 1) * RSBA_PLD + c] = a01.y;
+          Bst[(q0 + 2) * RSBA_PLD + c] = a23.x; Bst[(q0 + 3) * RSBA_PLD + c] = a23.y;
+        }
+        __syncthreads();
+      }
+      RSBA_MC_STAMP(3);
+      {
+        // few 16-row halves (late panels): several waves share one, each a slice of the K range — the update is a chain
+        // of dependent load latencies per wave, so its length is what counts
+        const int nh = 2 * nown, nsplit = (p > 0 && nh <= 2) ? 4 : ((p > 0 && nh <= 4) ? 2 : 1);
+        for (int it = wave; it < nh * nsplit; it += nwave) {
+          const int hb = it / nsplit, ks = it - hb * nsplit;
+          load_update_half(hb, ks, nsplit, hb * (nsplit - 1) + ks - 1);
+        }
+        __syncthreads();
+        if (nsplit > 1) {
+          for (int e = tid; e < nh * 512; e += nt) {
+            const int hb = e >> 9, r = (e >> 5) & 15, c = e & 31;
+            double sum = part[(hb * (nsplit - 1)) * 512 + r * 32 + c];
+            for (int k2 = 1; k2 < nsplit - 1; ++k2) sum += part[(hb * (nsplit - 1) + k2) * 512 + r * 32 + c];
+            Pan[((hb >> 1) * RSBA_PB + (hb & 1) * 16 + r) * RSBA_PLD + c] -= sum;
+          }
+          __syncthreads();
+        }
+      }
+      RSBA_MC_STAMP(4);
       if (!WaitFlagWG(f.tdone + p, tag, f.error, budget)) { stalled = true; break; }
       for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) {
         const int r = e >> 5, c = e & 31;   // T[r][c], r >= c: stored at A[kb + c][kb + r] for r > c, the diagonal in row n + 1
         T[r * RSBA_PLD + c] = r > c ? A[(size_t)(kb + c) * n + kb + r] : (r == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
       }
       __syncthreads();
+      RSBA_MC_STAMP(5);
     }
-    RSBA_MC_STAMP(5);
-    // 5. X = Rows T' for the blocks below the diagonal, stored as L
+    // X = Rows T' for the blocks below the diagonal, stored as L; the next diagonal block's X also stays in LDS
     {
-      const int j0 = owner ? 1 : 0;
-      const int i = lane & 15, kk = lane >> 4;
-      for (int hb = 2 * j0 + wave; hb < 2 * nown; hb += nwave) {
+      const int hb0 = owner ? 2 : 0;
+      for (int hb = hb0 + wave; hb < 2 * nown; hb += nwave) {
         const int j = hb >> 1, b = first + j * G;
         const int prow = j * RSBA_PB + (hb & 1) * 16;
         d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
         for (int qs = 0; qs < RSBA_PB; qs += 4) {
-          const double a = Pan[(prow + i) * RSBA_PLD + qs + kk];
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[i * RSBA_PLD + qs + kk], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[(16 + i) * RSBA_PLD + qs + kk], acc1, 0, 0, 0);
+          const double a = Pan[(prow + mi) * RSBA_PLD + qs + kk];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[mi * RSBA_PLD + qs + kk], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[(16 + mi) * RSBA_PLD + qs + kk], acc1, 0, 0, 0);
         }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-          const int grow = b * RSBA_PB + (hb & 1) * 16 + kk + 4 * tt;
-          if (grow <= n && (b < np || grow == n)) {
-            StoreShared(&A[(size_t)grow * n + kb + i], acc0[tt]);
-            StoreShared(&A[(size_t)grow * n + kb + 16 + i], acc1[tt]);
+          const int lr = (hb & 1) * 16 + kk + 4 * tt, grow = b * RSBA_PB + lr;
+          if (grow <= n) {
+            StoreShared(&A[(size_t)grow * n + kb + mi], acc0[tt]);
+            StoreShared(&A[(size_t)grow * n + kb + 16 + mi], acc1[tt]);
           }
+          if (next_owner && j == 0) { Xl[lr * RSBA_PLD + mi] = acc0[tt]; Xl[lr * RSBA_PLD + 16 + mi] = acc1[tt]; }
         }
       }
     }
     RSBA_MC_STAMP(6);
-    // 6. the owner of the next diagonal block: its rows are complete through this panel
-    if (p + 1 < np && (p + 1) % G == w) PublishFlagWG(f.strip_ready + p + 1, tag);
-    else { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }
+    if (next_owner) {
+      __syncthreads();
+      // Pre -= X X' (one 16 x 16 tile per wave 0..3); block p + 1's rows in global memory are complete through this panel:
+      // the others may read them as the next strip
+      if (wave < 4) {
+        const int ti = wave >> 1, tj = wave & 1;
+        d4_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int qs = 0; qs < RSBA_PB; qs += 4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xl[(16 * ti + mi) * RSBA_PLD + qs + kk], Xl[(16 * tj + mi) * RSBA_PLD + qs + kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Pre[(16 * ti + kk + 4 * t) * RSBA_PLD + 16 * tj + mi] -= acc[t];
+      }
+      PublishFlagWG(f.strip_ready + p + 1, tag);
+    } else { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }
     RSBA_MC_STAMP(7);
   }
 
@@ -261,6 +385,6 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
   SolveDone(gate);
 }
 
-__host__ __device__ inline size_t MultiCholLdsDoubles(int n) { return (size_t)(n + RSBA_PB) * RSBA_PLD + 2 * RSBA_PB * RSBA_PLD + 64 + n; }
+__host__ __device__ inline size_t MultiCholLdsDoubles(int n) { return (size_t)(n + RSBA_PB) * RSBA_PLD + 4 * RSBA_PB * RSBA_PLD + 64 + n; }
 
 }  // namespace rsba
