@@ -243,18 +243,30 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
 #pragma unroll
         for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; sv[u] = S[(size_t)(nb0 + r) * n + nb0 + c]; }
         {
-          const int ti = wave >> 2, tj = (wave >> 1) & 1, h = wave & 1;
-          const int nq = kb / RSBA_PB, qh = (nq + 1) >> 1;
-          const int qa = h * qh * RSBA_PB, qb = h ? kb : min(kb, qh * RSBA_PB);
+          // The product is symmetric: tiles (0,0) and (1,1) take two waves each (halves of the K range, one operand to
+          // load), tile (1,0) four (quarters, two operands), tile (0,1) is its mirror.  One CU pulls ~30 GB/s of such rows:
+          // the bytes are what this phase costs.
+          const bool cross = wave >= 4;
+          const int ti = wave >= 2 ? 1 : 0, tj = (wave >= 2 && wave < 4) ? 1 : 0;
+          const int nsl = cross ? 4 : 2, sl = cross ? wave - 4 : (wave & 1);
+          const int nq = kb / RSBA_PB, qper = (nq + nsl - 1) / nsl;
+          const int qa = sl * qper * RSBA_PB, qb = min(kb, (sl + 1) * qper * RSBA_PB);
           const double* ra = A + (size_t)(nb0 + 16 * ti + mi) * n + 8 * kk;
           const double* rb = A + (size_t)(nb0 + 16 * tj + mi) * n + 8 * kk;
           d4_t acc = {0, 0, 0, 0};
           double xa[8], xb[8], ya[8], yb[8];
           auto fetch2 = [&](double (&da)[8], double (&db)[8], int q) {
             const double2* pa = reinterpret_cast<const double2*>(ra + q);
-            const double2* pb = reinterpret_cast<const double2*>(rb + q);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) { const double2 t = pa[v], t2 = pb[v]; da[2 * v] = t.x; da[2 * v + 1] = t.y; db[2 * v] = t2.x; db[2 * v + 1] = t2.y; }
+            for (int v = 0; v < 4; ++v) { const double2 t = pa[v]; da[2 * v] = t.x; da[2 * v + 1] = t.y; }
+            if (cross) {
+              const double2* pb = reinterpret_cast<const double2*>(rb + q);
+#pragma unroll
+              for (int v = 0; v < 4; ++v) { const double2 t2 = pb[v]; db[2 * v] = t2.x; db[2 * v + 1] = t2.y; }
+            } else {
+#pragma unroll
+              for (int v = 0; v < 8; ++v) db[v] = da[v];
+            }
           };
           if (qa < qb) fetch2(xa, xb, qa);
           if (qa + RSBA_PB < qb) fetch2(ya, yb, qa + RSBA_PB);
@@ -273,8 +285,14 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int e = tid + u * nt, r = e >> 5, c = e & 31;
-          const int pw = ((r >> 4) << 2) | ((c >> 4) << 1);
-          const double d = part[pw * 256 + (r & 15) * 16 + (c & 15)] + part[(pw + 1) * 256 + (r & 15) * 16 + (c & 15)];
+          double d;
+          if ((r >> 4) == (c >> 4)) {
+            const int pw = (r >> 4) * 2, o = (r & 15) * 16 + (c & 15);
+            d = part[pw * 256 + o] + part[(pw + 1) * 256 + o];
+          } else {
+            const int o = r >= 16 ? (r & 15) * 16 + (c & 15) : (c & 15) * 16 + (r & 15);   // tile (1,0), or its mirror
+            d = ((part[4 * 256 + o] + part[5 * 256 + o]) + part[6 * 256 + o]) + part[7 * 256 + o];
+          }
           Pre[r * RSBA_PLD + c] = sys(nb0 + r, nb0 + c, sv[u]) - d;
         }
         __syncthreads();
