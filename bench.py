@@ -207,7 +207,7 @@ def main():
                 return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "avg_launch_us": 1e3 * ms,
                         "algorithmic_flops_per_launch": chol_flops / lpi, "launches_per_iteration": lpi,
-                        "note": "dense (6C)^3/3 + 2(6C)^2 Cholesky solve on ONE workgroup (latency-bound by construction)"}
+                        "note": "dense (6C)^3/3 + 2(6C)^2 Cholesky solve on four workgroups (a chain of 32 x 32 factorisations: latency-bound by construction)"}
             share = {"k_point_pass": 24 * N_rank + 48 * P_rank, "k_backsub_candidate": 24 * N_rank + 48 * P_rank}.get(name, b_iter)
             ach = share / lpi / (ms * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -226,9 +226,10 @@ def main():
         out["roofline_other_kernels"] = [roof(n) for n, _ in rest[:3]]
         out["kernels"] = {n: {"launches": int(c), "avg_us": 1e3 * a, "measured": "timed region" if n in stats_timed else "repeat pass"}
                           for n, (c, a) in sorted(per.items())}
-        out["kernel_timing"] = ("HIP events on the launching stream; in the timed region only k_schur_tiles and k_reduced_system_solve are "
-                                "recorded, on every fourth LM step (recording every step costs ~40 us of host time per step between "
-                                "two launches); the other kernels come from an identical repeat pass with every launch recorded")
+        out["kernel_timing"] = ("HIP events on the launching stream; in the timed region only the dominant kernel (k_schur_tiles) is "
+                                "recorded, on every fourth LM step (an event record costs ~10 us of host time between two launches, "
+                                "which is on the critical path of a 0.66 ms step); the other kernels come from an identical repeat pass "
+                                "with every launch recorded")
         for n, (c, ms) in waiting.items():
             if n not in out["kernels"]:
                 continue

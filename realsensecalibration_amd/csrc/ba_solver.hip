@@ -68,7 +68,7 @@ class KernelTimer {
   void Enable(int mode) { mode_ = mode; on_ = false; }
   bool enabled() const { return mode_ != 0 && sampled_; }
   void NextStep() { ++step_; sampled_ = mode_ == 1 || (mode_ == 2 && (step_ & 3) == 0); }
-  static bool Major(const char* n) { return strcmp(n, "k_schur_tiles") == 0 || strcmp(n, "k_reduced_system_solve") == 0 || strcmp(n, "k_linearize_schur_ref") == 0; }
+  static bool Major(const char* n) { return strcmp(n, "k_schur_tiles") == 0 || strcmp(n, "k_linearize_schur_ref") == 0; }
   void Begin(const char* name, hipStream_t s) {
     on_ = sampled_ && (mode_ == 1 || (mode_ == 2 && Major(name)));
     if (!on_) return;
