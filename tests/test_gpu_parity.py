@@ -619,3 +619,45 @@ def test_full_report_of_the_committed_problem():
     assert lines["Minimizer iterations"][-1] == "7" and lines["Successful steps"][-1] == "7" and lines["Unsuccessful steps"][-1] == "0"
     assert abs(float(lines["Initial"][-1]) - 1.387967e5) < 1 and abs(float(lines["Final"][-1]) - 1.436294e2) < 1e-3
     assert "CONVERGENCE (Function tolerance reached. |cost_change|/cost:" in rep and "gfx950" in rep
+
+
+# ------------------------------------------------------------------ reduced system on several workgroups
+@pytest.mark.parametrize("C,P,k", [(32, 2400, 8), (48, 3000, 10), (64, 3600, 12)])
+def test_multi_workgroup_cholesky_matches_oracle_and_single_workgroup(oracle, C, P, k):
+    """32 / 48 / 64 cameras: the reduced system is factored by four workgroups handing the diagonal factors to each other
+    (ba_cholesky_multi.hpp).  Oracle parity, bitwise reproducibility, the same answer (to rounding) from 1, 2, 3 and 6
+    workgroups, and from the sequential schedule bit for bit."""
+    prob = syn.make_problem(C, P, k, seed=500 + C)
+    got, s, log = _compare_solve(oracle, prob, 1)
+    again, s2, log2 = capi.solve_points(prob)
+    assert np.array_equal(got, again) and np.array_equal(log, log2)
+    for g in ("1", "2", "3", "6"):
+        os.environ["RSBA_CHOL_WGS"] = g
+        try:
+            other, so, _ = capi.solve_points(prob)
+        finally:
+            del os.environ["RSBA_CHOL_WGS"]
+        assert so.num_iterations == s.num_iterations
+        assert np.abs(other - got).max() < 1e-9 * max(1.0, np.abs(got).max()), g
+    os.environ["RSBA_PIPELINE"] = "0"
+    os.environ["RSBA_SEG_PER_CU"] = "8"
+    try:
+        seq, s_seq, log_seq = capi.solve_points(prob)
+    finally:
+        del os.environ["RSBA_PIPELINE"]
+        del os.environ["RSBA_SEG_PER_CU"]
+    assert np.array_equal(got, seq) and np.array_equal(log, log_seq)
+
+
+def test_multi_workgroup_cholesky_stall_falls_back(oracle, capfd):
+    """The gates of the four-workgroup factorisation never open (RSBA_TEST_STALL=1): every workgroup gives up inside its
+    budget, the step is repeated with the sequential schedule, the result does not change."""
+    prob = syn.make_problem(32, 2000, 8, seed=91)
+    ref, s_ref, log_ref = capi.solve_points(prob)
+    os.environ["RSBA_TEST_STALL"] = "1"
+    try:
+        got, s, log = capi.solve_points(prob)
+    finally:
+        del os.environ["RSBA_TEST_STALL"]
+    assert "falling back" in capfd.readouterr().err
+    assert np.array_equal(got, ref) and np.array_equal(log, log_ref)
