@@ -67,6 +67,7 @@ class KernelTimer {
   // step was recorded, 5% of the step).  Events come from a pool: creating one per record costs more than recording it.
   void Enable(int mode) { mode_ = mode; on_ = false; }
   bool enabled() const { return mode_ != 0 && sampled_; }
+  bool all_kernels() const { return mode_ == 1; }   // the kernels that wait inside (solve, back-substitution) are only timed then
   void NextStep() { ++step_; sampled_ = mode_ == 1 || (mode_ == 2 && (step_ & 3) == 0); }
   static bool Major(const char* n) { return strcmp(n, "k_schur_tiles") == 0 || strcmp(n, "k_linearize_schur_ref") == 0; }
   void Begin(const char* name, hipStream_t s) {
@@ -685,13 +686,13 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (s->chol_wgs > 1 && !mg)
       k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
-          StageGate{ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15, T.enabled() ? s->chol_waited : nullptr, s->trace, 0},
+          StageGate{ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0},
           MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 40}, tag, s->mc_trace);
     else
     k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                      s->camc[c], s->dcam, s->gmax, s->res, ip, (mg || getenv("RSBA_TRANSPOSED_SOURCE")) ? 2 : 1,
                                                      s->chol_ok, StageGate{mg ? s->ready_global : ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15,
-                                                                           T.enabled() ? s->chol_waited : nullptr, s->trace, mg ? 10 * RSBA_STALL_TICKS : 0});
+                                                                           T.all_kernels() ? s->chol_waited : nullptr, s->trace, mg ? 10 * RSBA_STALL_TICKS : 0});
     T.End(s->sB);
     ts.LaunchTiles(s, ip, T, st, tag);
     if (mg) {
@@ -773,11 +774,11 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (lds_b <= 60 * 1024)
       k_backsub_candidate<true><<<s->grid_pts, 256, lds_b, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
                                                                  s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0,
-        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag, pipe && T.enabled() ? s->chol_waited + 1 : nullptr, s->chol_ok + 2);
+        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag, pipe && T.all_kernels() ? s->chol_waited + 1 : nullptr, s->chol_ok + 2);
     else
       k_backsub_candidate<false><<<s->grid_pts, 256, 0, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
                                                               s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0,
-        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag, pipe && T.enabled() ? s->chol_waited + 1 : nullptr, s->chol_ok + 2);
+        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag, pipe && T.all_kernels() ? s->chol_waited + 1 : nullptr, s->chol_ok + 2);
   }
   T.End(st);
   DebugSync(st, "k_backsub_candidate");
@@ -821,7 +822,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
             us(s->host_t[3], s->host_t[0]), us(s->host_t[0], s->host_t[1]), us(s->host_t[1], s->host_t[2]), us(s->host_t[2], now));
     s->host_t[3] = now;
   }
-  if (pipe && T.enabled()) {
+  if (pipe && T.all_kernels()) {
     // the Cholesky's event span includes the time it slept on the ready flags: record that separately
     long long w[2] = {0, 0};
     HIPCHK(hipMemcpy(w, s->chol_waited, sizeof(w), hipMemcpyDeviceToHost));
