@@ -57,6 +57,57 @@ __device__ __forceinline__ void PublishFlagWG(int* flag, int tag) {
 
 __device__ __forceinline__ void StoreShared(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// BackSubstituteBlocks (ba_cholesky.hpp) with the strip of the NEXT block row in flight while this one is applied: the
+// twelve strips of L come back from memory one dependent round trip each (~2.5 us), which was all this phase cost.
+// 512 threads, n a multiple of 32 (the kernel below); same arithmetic, same order.
+__device__ __forceinline__ double* BackSubstituteBlocksPrefetch(int n, double* __restrict__ A, double* lds) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double* y = lds;                                 // n
+  double* Tb = lds + ((n + 63) & ~63);             // 32 x 33: Tb[i][c] = T[i][c]
+  double* xb = Tb + RSBA_PB * RSBA_PLD;            // 32
+  for (int i = tid; i < n; i += nt) y[i] = A[(size_t)n * n + i];
+  __syncthreads();
+  const int kb_last = n - RSBA_PB;
+  auto fetch_T = [&](int kb, int slot) {
+    const int e = tid + slot * nt, i = e >> 5, c = e & 31;
+    // T[i][c] for i > c sits at A[kb+c][kb+i]; the diagonal in row n+1
+    return (i > c) ? A[(size_t)(kb + c) * n + kb + i] : (i == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
+  };
+  const int q = tid;  // kb <= 352 < nt
+  double tpre[2], lv[RSBA_PB], ln[RSBA_PB];
+  for (int sl = 0; sl < 2; ++sl) tpre[sl] = fetch_T(kb_last, sl);
+#pragma unroll
+  for (int c = 0; c < RSBA_PB; ++c) lv[c] = q < kb_last ? A[(size_t)(kb_last + c) * n + q] : 0.0;
+  for (int kb = kb_last; kb >= 0; kb -= RSBA_PB) {
+    for (int sl = 0; sl < 2; ++sl) { const int e = tid + sl * nt; Tb[(e >> 5) * RSBA_PLD + (e & 31)] = tpre[sl]; }
+    if (kb >= RSBA_PB) {
+      const int kn = kb - RSBA_PB;
+#pragma unroll
+      for (int c = 0; c < RSBA_PB; ++c) ln[c] = q < kn ? A[(size_t)(kn + c) * n + q] : 0.0;
+      for (int sl = 0; sl < 2; ++sl) tpre[sl] = fetch_T(kn, sl);
+    }
+    __syncthreads();
+    if (tid < RSBA_PB) {
+      double sacc = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < RSBA_PB; ++i) sacc += Tb[i * RSBA_PLD + tid] * y[kb + i];
+      xb[tid] = sacc;
+    }
+    __syncthreads();
+    if (tid < RSBA_PB) y[kb + tid] = xb[tid];
+    if (q < kb) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int c = 0; c < RSBA_PB; ++c) sacc += lv[c] * xb[c];
+      y[q] -= sacc;
+    }
+#pragma unroll
+    for (int c = 0; c < RSBA_PB; ++c) lv[c] = ln[c];
+    __syncthreads();
+  }
+  return y;
+}
+
 __global__ void __launch_bounds__(512)
 k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, double* __restrict__ A, double* __restrict__ scale_c,
                              const double* __restrict__ cam_x, double* __restrict__ cam_c, const double* __restrict__ intr,
@@ -393,7 +444,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
   for (int o = 1; o < G; ++o)
     if (!WaitFlagWG(f.wg_done + o, tag, f.error, budget)) { if (tid == 0) res[RES_STALL] = 1.0; SolveDone(gate); return; }
   double* ysol = A + (size_t)n * n;
-  double* y = BackSubstituteBlocks(n, A, lds);
+  double* y = BackSubstituteBlocksPrefetch(n, A, lds);
   for (int i = tid; i < n; i += nt) ysol[i] = y[i];
   __threadfence_block();
   __syncthreads();
