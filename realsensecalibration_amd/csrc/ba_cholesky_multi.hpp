@@ -133,6 +133,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
   double* part = T;                        // T | Lt | Xl are idle before T(p) arrives: partial tiles of the K-split update
                                            // (up to six 16 x 32) and of the look-ahead product (eight 16 x 16)
   if (tid == 0) { s_ok = 1; s_wb = 0; }
+  if (gate.trace && tid == 0 && w == 0) gate.trace[0] = wall_clock64();
   bool stalled = false;
   const double* S = red + L.S();
   const double inv_radius = 1.0 / ip.radius;
@@ -287,12 +288,14 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
         // L[block p+1, 0:kb] L[block p+1, 0:kb]' — this workgroup's own rows, final since the last panel — so that only the
         // X X' of this panel stands between T(p) and the next factorisation.  Wave = (tile row, tile column, half of K).
         const int nb0 = kb + RSBA_PB;   // first row / column of block p + 1
-        if (gate.ready != nullptr && nb0 % gate.cols == 0 && !ip.first) {
-          if (!WaitReady(gate.ready + 1 + nb0 / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
-        }
-        double sv[2];
+        // block p + 1 opens a new camera group whose columns may not be published yet: its entries of S are added after
+        // this panel's X instead (the product below only needs L) — waiting here would hold up this panel for everybody
+        const bool s_late = gate.ready != nullptr && nb0 % gate.cols == 0 && !ip.first;
+        double sv[2] = {0.0, 0.0};
+        if (!s_late) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; sv[u] = S[(size_t)(nb0 + r) * n + nb0 + c]; }
+          for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; sv[u] = S[(size_t)(nb0 + r) * n + nb0 + c]; }
+        }
         {
           // The product is symmetric: tiles (0,0) and (1,1) take two waves each (halves of the K range, one operand to
           // load), tile (1,0) four (quarters, two operands), tile (0,1) is its mirror.  One CU pulls ~30 GB/s of such rows:
@@ -344,7 +347,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
             const int o = r >= 16 ? (r & 15) * 16 + (c & 15) : (c & 15) * 16 + (r & 15);   // tile (1,0), or its mirror
             d = ((part[4 * 256 + o] + part[5 * 256 + o]) + part[6 * 256 + o]) + part[7 * 256 + o];
           }
-          Pre[r * RSBA_PLD + c] = sys(nb0 + r, nb0 + c, sv[u]) - d;
+          Pre[r * RSBA_PLD + c] = (s_late ? 0.0 : sys(nb0 + r, nb0 + c, sv[u])) - d;
         }
         __syncthreads();
       }
@@ -418,6 +421,16 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
     RSBA_MC_STAMP(6);
     if (next_owner) {
       __syncthreads();
+      const int nb0 = kb + RSBA_PB;
+      if (gate.ready != nullptr && nb0 % gate.cols == 0 && !ip.first) {   // the deferred entries of S (see the look-ahead)
+        if (!WaitReady(gate.ready + 1 + nb0 / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = tid + u * nt, r = e >> 5, c = e & 31;
+          Pre[r * RSBA_PLD + c] += sys(nb0 + r, nb0 + c, S[(size_t)(nb0 + r) * n + nb0 + c]);
+        }
+        __syncthreads();
+      }
       // Pre -= X X' (one 16 x 16 tile per wave 0..3); block p + 1's rows in global memory are complete through this panel:
       // the others may read them as the next strip
       if (wave < 4) {
@@ -443,6 +456,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
   // workgroup 0: everybody's rows, then L' x = y and the camera step
   for (int o = 1; o < G; ++o)
     if (!WaitFlagWG(f.wg_done + o, tag, f.error, budget)) { if (tid == 0) res[RES_STALL] = 1.0; SolveDone(gate); return; }
+  if (gate.trace && tid == 0) gate.trace[13] = wall_clock64();   // factorisation complete on every workgroup
   double* ysol = A + (size_t)n * n;
   double* y = BackSubstituteBlocksPrefetch(n, A, lds);
   for (int i = tid; i < n; i += nt) ysol[i] = y[i];
@@ -450,7 +464,9 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
   __syncthreads();
   int ok = 1;
   if (tid == 0) { res[RES_STALL] = 0.0; ok = __hip_atomic_load(chol_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (gate.trace && tid == 0) gate.trace[14] = wall_clock64();   // back-substitution done
   CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, ok, lds, ip.cam_free);
+  if (gate.trace && tid == 0) gate.trace[15] = wall_clock64();
   SolveDone(gate);
 }
 

@@ -836,7 +836,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const long long t0 = h[24];
     fprintf(stderr, "rsba[trace] us since first tile block: chol start %.1f ready0 seen %.1f | gates (wait..pass)", (h[0] - t0) * 0.01, (h[1] - t0) * 0.01);
     for (int g = 0; g < s->tiled.nstages; ++g) fprintf(stderr, " %.1f..%.1f", (h[2 + 2 * g] - t0) * 0.01, (h[3 + 2 * g] - t0) * 0.01);
-    fprintf(stderr, " end %.1f | published: self %.1f stages", (h[15] - t0) * 0.01, (h[16] - t0) * 0.01);
+    fprintf(stderr, " factored %.1f back-substituted %.1f end %.1f | published: self %.1f stages", (h[13] - t0) * 0.01, (h[14] - t0) * 0.01, (h[15] - t0) * 0.01, (h[16] - t0) * 0.01);
     for (int g = 0; g < s->tiled.nstages; ++g) fprintf(stderr, " %.1f", (h[17 + g] - t0) * 0.01);
     if (s->comm) fprintf(stderr, " | after the solve: candidate sums start +%.1f, publish +%.1f", (h[26] - h[15]) * 0.01, (h[27] - h[15]) * 0.01);
     fprintf(stderr, "\n");
