@@ -280,9 +280,6 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
       PublishFlagWG(f.tdone + p, tag);
       RSBA_MC_STAMP(5);
     } else {
-      if (gate.ready != nullptr && kb % gate.cols == 0 && !ip.first) {
-        if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
-      }
       if (next_owner) {
         // Look-ahead, before anything of this panel is needed: the NEXT diagonal block's entries of the system minus
         // L[block p+1, 0:kb] L[block p+1, 0:kb]' — this workgroup's own rows, final since the last panel — so that only the
@@ -290,7 +287,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
         const int nb0 = kb + RSBA_PB;   // first row / column of block p + 1
         // block p + 1 opens a new camera group whose columns may not be published yet: its entries of S are added after
         // this panel's X instead (the product below only needs L) — waiting here would hold up this panel for everybody
-        const bool s_late = gate.ready != nullptr && nb0 % gate.cols == 0 && !ip.first;
+        const bool s_late = gate.ready != nullptr && !ip.first && (nb0 % gate.cols == 0 || kb % gate.cols == 0);   // (this panel's own gate is passed further down)
         double sv[2] = {0.0, 0.0};
         if (!s_late) {
 #pragma unroll
@@ -366,6 +363,11 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
         __syncthreads();
       }
       RSBA_MC_STAMP(3);
+      // the panel's own columns of S are first needed here: everything above (look-ahead product, strip) ran while the
+      // Schur kernel was still producing this camera group
+      if (gate.ready != nullptr && kb % gate.cols == 0 && !ip.first) {
+        if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
+      }
       {
         // few 16-row halves (late panels): several waves share one, each a slice of the K range — the update is a chain
         // of dependent load latencies per wave, so its length is what counts
@@ -420,9 +422,11 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
     }
     RSBA_MC_STAMP(6);
     if (next_owner) {
-      __syncthreads();
+      // block p + 1's rows in global memory are complete through this panel: the others may read them as the next strip
+      // (before anything that may wait for the Schur kernel)
+      PublishFlagWG(f.strip_ready + p + 1, tag);
       const int nb0 = kb + RSBA_PB;
-      if (gate.ready != nullptr && nb0 % gate.cols == 0 && !ip.first) {   // the deferred entries of S (see the look-ahead)
+      if (gate.ready != nullptr && !ip.first && (nb0 % gate.cols == 0 || kb % gate.cols == 0)) {   // the deferred entries of S (see the look-ahead)
         if (!WaitReady(gate.ready + 1 + nb0 / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -431,8 +435,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
         }
         __syncthreads();
       }
-      // Pre -= X X' (one 16 x 16 tile per wave 0..3); block p + 1's rows in global memory are complete through this panel:
-      // the others may read them as the next strip
+      // Pre -= X X' (one 16 x 16 tile per wave 0..3)
       if (wave < 4) {
         const int ti = wave >> 1, tj = wave & 1;
         d4_t acc = {0, 0, 0, 0};
@@ -442,7 +445,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
 #pragma unroll
         for (int t = 0; t < 4; ++t) Pre[(16 * ti + kk + 4 * t) * RSBA_PLD + 16 * tj + mi] -= acc[t];
       }
-      PublishFlagWG(f.strip_ready + p + 1, tag);
+      __syncthreads();
     } else { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }
     RSBA_MC_STAMP(7);
   }
