@@ -20,8 +20,8 @@
 //                        bitwise reproducible, no atomics)
 //   k_marker_reduce      thread per entry: the partial systems summed in chunk order, mirrored to full symmetric
 //   k_marker_reduced_solve / k_sys_build + k_chol_step + k_marker_chol_finish     (n_r <= 384 / larger)
-//   k_time_backsub       thread per time: delta_t = -E (g_t + W_t delta_r), candidate time poses
-//   k_marker_obs_terms   thread per residual block: model cost change, candidate cost
+//   k_time_backsub_terms wavefront per time: delta_t = -E (g_t + W_t delta_r), candidate time pose, then the model cost
+//                        change and the candidate's residuals of the time's residual blocks
 //   k_marker_schur_finish   ordered final sums -> the 16-double result block
 //
 // Scaling and damping follow the point model's formulation: the elimination runs in unscaled coordinates with the
@@ -440,20 +440,26 @@ k_marker_chol_finish(int nr, const double* __restrict__ red, double* __restrict_
   ReducedStepEpilogue(nr, red, RL, scale_r, ysol, col_full, params_x, params_c, delta_r, out, *ok_flag, lds);
 }
 
-// delta_t = -E (g_t + sum J_t' (J_c delta_c + J_m delta_m)); candidate time poses; per-workgroup norms.
-// One wavefront per time: the lanes take the time's residual blocks, a fixed shuffle tree adds their six sums.
+// Back-substitution of one time and everything that follows from its step, one wavefront per time:
+//   pass 1  lanes over the time's residual blocks: delta_t = -E (g_t + sum J_t' (J_c delta_c + J_m delta_m)) (fixed
+//           shuffle tree), candidate time pose;
+//   pass 2  the same residual blocks again (their Jacobians are still in the L2): the model cost change
+//           -(J d).(r + J d / 2) and the squared residuals of the candidate (four corners through the three candidate poses).
+// Per workgroup (four times): |delta_t|^2, |x_t + delta_t|^2, model cost change, candidate sum of squares.
 __global__ void __launch_bounds__(256)
-k_time_backsub(int T, const int* __restrict__ time_ptr, const int* __restrict__ time_full, const TimeSlots* __restrict__ ts,
-               const double* __restrict__ J, const double* __restrict__ tdata, const double* __restrict__ delta_r,
-               const double* __restrict__ params_x, double* __restrict__ params_c, double* __restrict__ delta_t,
-               double* __restrict__ bpart /* gridDim.x x 4 */) {
-  __shared__ double s_part[4][2];
+k_time_backsub_terms(int T, const int* __restrict__ time_ptr, const int* __restrict__ time_full, const TimeSlots* __restrict__ ts,
+                     const MarkerObs* __restrict__ mo, const double* __restrict__ obs8, const double* __restrict__ intr, double half_side,
+                     const double* __restrict__ J, const double* __restrict__ rres, const double* __restrict__ tdata,
+                     const double* __restrict__ delta_r, const double* __restrict__ params_x, double* __restrict__ params_c,
+                     double* __restrict__ delta_t, double* __restrict__ bpart /* gridDim.x x 4 */) {
+  __shared__ double s_part[4][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.x * 4 + wave;
-  double d2 = 0, xc2 = 0;
+  double d2 = 0, xc2 = 0, mcc = 0, cc = 0;
   if (t < T) {
+    const int o0 = time_ptr[t], o1 = time_ptr[t + 1], tf = time_full[t];
     double h[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = time_ptr[t] + lane; i < time_ptr[t + 1]; i += 64) {
+    for (int i = o0 + lane; i < o1; i += 64) {
       const TimeSlots s = ts[i];
       double dc[6], dm[6];
 #pragma unroll
@@ -472,68 +478,73 @@ k_time_backsub(int T, const int* __restrict__ time_ptr, const int* __restrict__ 
       for (int off = 32; off > 0; off >>= 1) h[x] += __shfl_down(h[x], off, 64);
       h[x] = __shfl(h[x], 0, 64) + tdata[(size_t)t * 48 + 36 + x];
     }
+    double dt[6], tc[6];   // the time's step and candidate pose, in every lane
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double sum = 0.0;
+#pragma unroll
+      for (int y = 0; y < 6; ++y) sum += tdata[(size_t)t * 48 + 6 * a + y] * h[y];
+      dt[a] = -sum;
+      tc[a] = params_x[tf + a] + dt[a];
+      d2 += dt[a] * dt[a]; xc2 += tc[a] * tc[a];   // identical in every lane; lane 0's copy is used
+    }
     if (lane < 6) {
-      const int tf = time_full[t];
-      double s = 0.0;
+      double dsel = dt[0], csel = tc[0];
 #pragma unroll
-      for (int y = 0; y < 6; ++y) s += tdata[(size_t)t * 48 + 6 * lane + y] * h[y];
-      const double dd = -s, xv = params_x[tf + lane], xc = xv + dd;
-      delta_t[6 * t + lane] = dd;
-      params_c[tf + lane] = xc;
-      d2 = dd * dd; xc2 = xc * xc;
+      for (int a = 1; a < 6; ++a) if (lane == a) { dsel = dt[a]; csel = tc[a]; }
+      delta_t[6 * t + lane] = dsel;
+      params_c[tf + lane] = csel;
+    }
+    // pass 2
+    const double cx[4] = {-half_side, half_side, half_side, -half_side};
+    const double cy[4] = {half_side, half_side, -half_side, -half_side};
+    for (int i = o0 + lane; i < o1; i += 64) {
+      const TimeSlots s = ts[i];
+      const MarkerObs o = mo[i];
+      double dl[18];
+#pragma unroll
+      for (int x = 0; x < 6; ++x) {
+        dl[x] = s.col_cam >= 0 ? delta_r[s.col_cam + x] : 0.0;
+        dl[6 + x] = dt[x];
+        dl[12 + x] = s.col_marker >= 0 ? delta_r[s.col_marker + x] : 0.0;
+      }
+      const double* Ji = J + (size_t)i * 144;
+      for (int q = 0; q < 8; ++q) {
+        double m = 0.0;
+#pragma unroll
+        for (int x = 0; x < 18; ++x) m += Ji[q * 18 + x] * dl[x];
+        mcc -= m * (rres[(size_t)i * 8 + q] + 0.5 * m);
+      }
+      // candidate residuals: cameras and markers of the candidate are in params_c already (reduced solve), the time here
+      const double fx = intr[4 * o.camera], fy = intr[4 * o.camera + 1], ppx = intr[4 * o.camera + 2], ppy = intr[4 * o.camera + 3];
+      for (int k = 0; k < 4; ++k) {
+        double pt[3] = {cx[k], cy[k], 0.0};
+        if (o.full_marker >= 0) { const double* m = params_c + o.full_marker; RotateD(m, pt); pt[0] += m[3]; pt[1] += m[4]; pt[2] += m[5]; }
+        RotateD(tc, pt); pt[0] += tc[3]; pt[1] += tc[4]; pt[2] += tc[5];
+        if (o.full_cam >= 0) { const double* c = params_c + o.full_cam; RotateD(c, pt); pt[0] += c[3]; pt[1] += c[4]; pt[2] += c[5]; }
+        const double r0 = fx * pt[0] / pt[2] + ppx - obs8[8 * (size_t)i + 2 * k];
+        const double r1 = fy * pt[1] / pt[2] + ppy - obs8[8 * (size_t)i + 2 * k + 1];
+        cc += r0 * r0 + r1 * r1;
+      }
     }
   }
-  // the six entries in lane order, then the four times of the workgroup in wave order
-  double a2 = 0, b2 = 0;
-  for (int x = 0; x < 6; ++x) { a2 += __shfl(d2, x, 64); b2 += __shfl(xc2, x, 64); }
-  if (lane == 0) { s_part[wave][0] = a2; s_part[wave][1] = b2; }
+  // the lanes' sums in a fixed tree, then the four times of the workgroup in wave order
+  for (int off = 32; off > 0; off >>= 1) { mcc += __shfl_down(mcc, off, 64); cc += __shfl_down(cc, off, 64); }
+  if (lane == 0) { s_part[wave][0] = d2; s_part[wave][1] = xc2; s_part[wave][2] = mcc; s_part[wave][3] = cc; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    bpart[4 * blockIdx.x] = ((s_part[0][0] + s_part[1][0]) + s_part[2][0]) + s_part[3][0];
-    bpart[4 * blockIdx.x + 1] = ((s_part[0][1] + s_part[1][1]) + s_part[2][1]) + s_part[3][1];
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    bpart[4 * blockIdx.x + k] = ((s_part[0][k] + s_part[1][k]) + s_part[2][k]) + s_part[3][k];
   }
 }
 
-// Per residual block: model cost change -(J d).(r + J d / 2) and the candidate's squared residuals.
 __global__ void __launch_bounds__(256)
-k_marker_obs_terms(int N, const int* __restrict__ obs_time, const TimeSlots* __restrict__ ts, const double* __restrict__ J,
-                   const double* __restrict__ r, const double* __restrict__ delta_r, const double* __restrict__ delta_t,
-                   const double* __restrict__ sumsq_c, double* __restrict__ bpart /* gridDim.x x 2 */) {
-  __shared__ double s[2][256];
-  const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
-  double mcc = 0, cc = 0;
-  if (i < N) {
-    const TimeSlots o = ts[i];
-    const int t = obs_time[i];
-    double dl[18];
-    for (int x = 0; x < 6; ++x) {
-      dl[x] = o.col_cam >= 0 ? delta_r[o.col_cam + x] : 0.0;
-      dl[6 + x] = delta_t[6 * t + x];
-      dl[12 + x] = o.col_marker >= 0 ? delta_r[o.col_marker + x] : 0.0;
-    }
-    const double* Ji = J + (size_t)i * 144;
-    for (int q = 0; q < 8; ++q) {
-      double m = 0.0;
-#pragma unroll
-      for (int x = 0; x < 18; ++x) m += Ji[q * 18 + x] * dl[x];
-      mcc -= m * (r[(size_t)i * 8 + q] + 0.5 * m);
-    }
-    cc = sumsq_c[i];
-  }
-  s[0][tid] = mcc; s[1][tid] = cc;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) { if (tid < off) { s[0][tid] += s[0][tid + off]; s[1][tid] += s[1][tid + off]; } __syncthreads(); }
-  if (tid == 0) { bpart[2 * blockIdx.x] = s[0][0]; bpart[2 * blockIdx.x + 1] = s[1][0]; }
-}
-
-__global__ void __launch_bounds__(256)
-k_marker_schur_finish(int nb_time, const double* __restrict__ bp_time, int nb_obs, const double* __restrict__ bp_obs,
-                      const double* __restrict__ red_scal, const double* __restrict__ solve_out, double* __restrict__ res) {
+k_marker_schur_finish(int nb_time, const double* __restrict__ bp_time, const double* __restrict__ red_scal,
+                      const double* __restrict__ solve_out, double* __restrict__ res) {
   __shared__ double s[4][256];
   const int tid = threadIdx.x;
   double v[4] = {0, 0, 0, 0};
-  for (int b = tid; b < nb_time; b += 256) { v[0] += bp_time[4 * b]; v[1] += bp_time[4 * b + 1]; }
-  for (int b = tid; b < nb_obs; b += 256) { v[2] += bp_obs[2 * b]; v[3] += bp_obs[2 * b + 1]; }
+  for (int b = tid; b < nb_time; b += 256) for (int k = 0; k < 4; ++k) v[k] += bp_time[4 * b + k];
   for (int k = 0; k < 4; ++k) s[k][tid] = v[k];
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) { if (tid < off) for (int k = 0; k < 4; ++k) s[k][tid] += s[k][tid + off]; __syncthreads(); }
@@ -775,17 +786,12 @@ struct MarkerSchurDevice {
       Tm.End(st);
     }
     if (!chk("reduced solve")) return RSBA_ERR_HIP;
-    Tm.Begin("k_time_backsub", st);
-    k_time_backsub<<<nb_time, 256, 0, st>>>(T, time_ptr, time_full, ts, Jbuf, tdata, delta_r, params[x], params[c], delta_t, bp_time);
-    Tm.End(st);
-    Tm.Begin("k_marker_eval", st);
-    k_marker_eval<<<(N + 63) / 64, 64, 0, st>>>(N, mo, obs8, params[c], intr, half_side, 0, nullptr, nullptr, ss_c);
-    Tm.End(st);
-    Tm.Begin("k_marker_obs_terms", st);
-    k_marker_obs_terms<<<nb_obs, 256, 0, st>>>(N, obs_time, ts, Jbuf, rbuf, delta_r, delta_t, ss_c, bp_obs);
+    Tm.Begin("k_time_backsub_terms", st);
+    k_time_backsub_terms<<<nb_time, 256, 0, st>>>(T, time_ptr, time_full, ts, mo, obs8, intr, half_side, Jbuf, rbuf, tdata, delta_r, params[x],
+                                                  params[c], delta_t, bp_time);
     Tm.End(st);
     Tm.Begin("k_marker_schur_finish", st);
-    k_marker_schur_finish<<<1, 256, 0, st>>>(nb_time, bp_time, nb_obs, bp_obs, red + RL.scal(), solve_out, res);
+    k_marker_schur_finish<<<1, 256, 0, st>>>(nb_time, bp_time, red + RL.scal(), solve_out, res);
     Tm.End(st);
     if (!chk("k_marker_schur_finish")) return RSBA_ERR_HIP;
     if (hipMemcpyAsync(res_host, res, RES_SIZE * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return RSBA_ERR_HIP;
