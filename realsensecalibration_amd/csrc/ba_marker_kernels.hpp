@@ -88,9 +88,13 @@ __global__ void __launch_bounds__(64) k_marker_eval(int N, const MarkerObs* __re
                               const double* __restrict__ params, const double* __restrict__ intr, double half_side,
                               int with_jacobian, double* __restrict__ Jbuf, double* __restrict__ rbuf,
                               double* __restrict__ sumsq_per_obs) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const MarkerObs o = mo[i];
+  // Jacobian rows leave through LDS: a thread's 36 doubles per corner would otherwise be 64 scattered 288-byte pieces per
+  // store instruction (1152 B between neighbouring lanes); staged, consecutive lanes write consecutive words
+  __shared__ double stage[64 * 37];
+  const int i0 = blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
+  const bool live = i < N;
+  const int ii = live ? i : N - 1;   // lanes past the end keep going for the barriers, on the last block's data
+  const MarkerObs o = mo[ii];
   const double fx = intr[4 * o.camera], fy = intr[4 * o.camera + 1], ppx = intr[4 * o.camera + 2], ppy = intr[4 * o.camera + 3];
   const double cx[4] = {-half_side, half_side, half_side, -half_side};
   const double cy[4] = {half_side, half_side, -half_side, -half_side};
@@ -101,8 +105,8 @@ __global__ void __launch_bounds__(64) k_marker_eval(int N, const MarkerObs* __re
       if (o.full_marker >= 0) { const double* m = params + o.full_marker; RotateD(m, p); p[0] += m[3]; p[1] += m[4]; p[2] += m[5]; }
       { const double* t = params + o.full_time; RotateD(t, p); p[0] += t[3]; p[1] += t[4]; p[2] += t[5]; }
       if (o.full_cam >= 0) { const double* c = params + o.full_cam; RotateD(c, p); p[0] += c[3]; p[1] += c[4]; p[2] += c[5]; }
-      const double r0 = fx * p[0] / p[2] + ppx - obs8[8 * (size_t)i + 2 * k];
-      const double r1 = fy * p[1] / p[2] + ppy - obs8[8 * (size_t)i + 2 * k + 1];
+      const double r0 = fx * p[0] / p[2] + ppx - obs8[8 * (size_t)ii + 2 * k];
+      const double r1 = fy * p[1] / p[2] + ppy - obs8[8 * (size_t)ii + 2 * k + 1];
       ss += r0 * r0 + r1 * r1;
     }
   } else {
@@ -120,13 +124,19 @@ __global__ void __launch_bounds__(64) k_marker_eval(int N, const MarkerObs* __re
       if (o.full_cam >= 0) { RotateJet<18>(cam, p); p[0] = p[0] + cam[3]; p[1] = p[1] + cam[4]; p[2] = p[2] + cam[5]; }
       const J xp = JConst<18>(fx) * p[0] / p[2] + JConst<18>(ppx);
       const J yp = JConst<18>(fy) * p[1] / p[2] + JConst<18>(ppy);
-      const double r0 = xp.a - obs8[8 * (size_t)i + 2 * k], r1 = yp.a - obs8[8 * (size_t)i + 2 * k + 1];
-      rbuf[8 * (size_t)i + 2 * k] = r0; rbuf[8 * (size_t)i + 2 * k + 1] = r1;
-      for (int q = 0; q < 18; ++q) { Jbuf[(size_t)(8 * i + 2 * k) * 18 + q] = xp.v[q]; Jbuf[(size_t)(8 * i + 2 * k + 1) * 18 + q] = yp.v[q]; }
+      const double r0 = xp.a - obs8[8 * (size_t)ii + 2 * k], r1 = yp.a - obs8[8 * (size_t)ii + 2 * k + 1];
+      if (live) { rbuf[8 * (size_t)i + 2 * k] = r0; rbuf[8 * (size_t)i + 2 * k + 1] = r1; }
+      for (int q = 0; q < 18; ++q) { stage[threadIdx.x * 37 + q] = xp.v[q]; stage[threadIdx.x * 37 + 18 + q] = yp.v[q]; }
+      __syncthreads();
+      {
+        const int nlive = min(64, N - i0);
+        for (int e = threadIdx.x; e < nlive * 36; e += 64) { const int t = e / 36, q = e - 36 * t; Jbuf[(size_t)(i0 + t) * 144 + 36 * k + q] = stage[t * 37 + q]; }
+      }
+      __syncthreads();
       ss += r0 * r0 + r1 * r1;
     }
   }
-  sumsq_per_obs[i] = ss;
+  if (live) sumsq_per_obs[i] = ss;
 }
 
 // One workgroup: normal equations in a fixed order, Jacobi scale, LM damping, Cholesky, step, candidate.
