@@ -677,7 +677,12 @@ struct MarkerSchurDevice {
     if (lds_s) lds_elim += PL.packed() * sizeof(double);
     // Without the LDS accumulators every entry is a read-modify-write in the partial system: few enough workgroups that
     // their partial systems stay in the L2s (8 x 4 MB) then, as many as there are times otherwise (at most 1024).
-    const size_t cap = lds_s ? 1024 : std::min<size_t>(1024, std::max<size_t>(64, ((size_t)24 << 20) / (PL.size() * sizeof(double))));
+    // With the sums in LDS a workgroup fills a CU: one chunk per CU (more chunks only add partial systems to write, to
+    // zero and to reduce: 1024 chunks cost 11 % of the iteration on 5000 times)
+    size_t cap_lds = 256;
+    { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cap_lds = (size_t)prop.multiProcessorCount; }
+    if (getenv("RSBA_MT_CHUNKS")) cap_lds = (size_t)std::max(1, atoi(getenv("RSBA_MT_CHUNKS")));
+    const size_t cap = lds_s ? cap_lds : std::min<size_t>(1024, std::max<size_t>(64, ((size_t)24 << 20) / (PL.size() * sizeof(double))));
     G = (int)std::min<size_t>((size_t)T, cap);
     std::vector<int> cptr(G + 1, 0);
     {
