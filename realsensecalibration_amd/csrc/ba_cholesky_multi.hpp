@@ -1,4 +1,5 @@
-// The reduced camera system on SEVERAL workgroups (n <= 384, n a multiple of 32: 32, 48 or 64 cameras).
+// The reduced camera system on SEVERAL workgroups (32 to 64 cameras; the system is padded with identity rows and columns
+// to whole 32-wide panels).
 //
 // One workgroup factors the 384 x 384 system in ~310 us, and the phase profile says why: the sequential 32 x 32
 // diagonal factorisation (6-8 us per panel) runs next to a row update that one CU cannot feed — its loads are latency x
@@ -59,7 +60,7 @@ __device__ __forceinline__ void StoreShared(double* p, double v) { __hip_atomic_
 
 // BackSubstituteBlocks (ba_cholesky.hpp) with the strip of the NEXT block row in flight while this one is applied: the
 // twelve strips of L come back from memory one dependent round trip each (~2.5 us), which was all this phase cost.
-// 512 threads, n a multiple of 32 (the kernel below); same arithmetic, same order.
+// 512 threads, n a multiple of 32 (the padded dimension of the kernel below); same arithmetic, same order.
 __device__ __forceinline__ double* BackSubstituteBlocksPrefetch(int n, double* __restrict__ A, double* lds) {
   const int tid = threadIdx.x, nt = blockDim.x;
   double* y = lds;                                 // n
@@ -115,7 +116,10 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
                              double* __restrict__ res, IterParams ip, int* __restrict__ chol_ok, StageGate gate, MultiCholFlags f, int tag,
                              long long* __restrict__ mtrace /* diagnostic: [G][16][8] wall-clock stamps, or nullptr */) {
   extern __shared__ double lds[];
-  const int n = L.nc, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
+  // nreal unknowns, padded to n = whole panels: rows / columns nreal .. n-1 are identity (their solution is 0, their part of
+  // L the identity), the right-hand side row sits at row n of A (leading dimension n)
+  const int nreal = L.nc, n = (nreal + RSBA_PB - 1) / RSBA_PB * RSBA_PB;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
   const int G = gridDim.x, w = blockIdx.x;
   const int np = n / RSBA_PB;              // column panels; blocks 0 .. np (block np: the rhs row alone)
   const long long budget = gate.budget > 0 ? gate.budget : RSBA_STALL_TICKS;
@@ -141,29 +145,34 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
 
   // pipelined first iteration: the Jacobi scale needs the whole damping diagonal
   if (gate.ready != nullptr && ip.first) {
-    for (int g = 0; g * gate.cols < n; ++g)
+    for (int g = 0; g * gate.cols < nreal; ++g)
       if (!WaitReady(gate.ready + 1 + g, gate.tag, w == 0 ? gate.waited : nullptr, gate.budget)) { stalled = true; break; }
   } else if (gate.ready != nullptr && w == 0) {
     if (!WaitReady(gate.ready + 1, gate.tag, gate.waited, gate.budget)) stalled = true;   // workgroup 0 starts with S(0, 0)
   }
   if (!stalled) {
     for (int i = tid; i < n; i += nt) {
-      const double sc = ip.first ? (ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(red[L.diagU() + i])) : 1.0) : scale_c[i];
+      double sc = 1.0;
+      if (i < nreal) {
+        sc = ip.first ? (ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(red[L.diagU() + i])) : 1.0) : scale_c[i];
+        if (ip.first && w == 0) scale_c[i] = sc;
+      }
       scl[i] = sc;
-      if (ip.first && w == 0) scale_c[i] = sc;
     }
     if (w == 0 && tid == 0) __hip_atomic_store(chol_ok, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  // scaled, damped entry (gi, gj) of the system, gi < n; the rhs row (gi == n) from gc + corr
+  // scaled, damped entry (gi, gj) of the padded system; the rhs row (gi == n) from gc + corr.  raw = S[gi][gj] (see Sat)
   auto sys = [&](int gi, int gj, double raw) {
-    if (gi == n) return scl[gj] * (red[L.gc() + gj] + red[L.corr() + gj]);
+    if (gi == n) return gj < nreal ? scl[gj] * (red[L.gc() + gj] + red[L.corr() + gj]) : 0.0;
+    if (gi >= nreal || gj >= nreal) return gi == gj ? 1.0 : 0.0;   // padding
     double v = raw * (scl[gi] * scl[gj]);
     if (gi == gj) v += fmin(fmax(scl[gi] * scl[gi] * red[L.diagU() + gi], ip.min_lm_diagonal), ip.max_lm_diagonal) * inv_radius;
     return v;
   };
+  auto Sat = [&](int gi, int gj) { return (gi < nreal && gj < nreal) ? S[(size_t)gi * nreal + gj] : 0.0; };
   if (w == 0 && !stalled) {   // the first diagonal block
-    for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) { const int r = e >> 5, c = e & 31; Pre[r * RSBA_PLD + c] = sys(r, c, S[(size_t)r * n + c]); }
+    for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) { const int r = e >> 5, c = e & 31; Pre[r * RSBA_PLD + c] = sys(r, c, Sat(r, c)); }
     __syncthreads();
   }
 
@@ -189,14 +198,19 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
       if (ks == 0) {
         const int r = lane >> 2, c0 = (lane & 3) * 8;
         const int gi = b * RSBA_PB + (hb & 1) * 16 + r;
-        double v[8];
-        if (gi < n) {
-          const double2* sp = reinterpret_cast<const double2*>(S + (size_t)gi * n + kb + c0);
+        double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (gi < nreal) {
+          if (kb + c0 + 8 <= nreal) {
+            const double2* sp = reinterpret_cast<const double2*>(S + (size_t)gi * nreal + kb + c0);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const double2 t = sp[u]; v[2 * u] = t.x; v[2 * u + 1] = t.y; }
+            for (int u = 0; u < 4; ++u) { const double2 t = sp[u]; v[2 * u] = t.x; v[2 * u + 1] = t.y; }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Sat(gi, kb + c0 + u);   // the padded last panel
+          }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) Pan[(prow + r) * RSBA_PLD + c0 + u] = gi <= n ? sys(gi, kb + c0 + u, gi < n ? v[u] : 0.0) : 0.0;
+        for (int u = 0; u < 8; ++u) Pan[(prow + r) * RSBA_PLD + c0 + u] = gi <= n ? sys(gi, kb + c0 + u, v[u]) : 0.0;
       }
       __builtin_amdgcn_wave_barrier();
       if (p == 0) return;
@@ -291,7 +305,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
         double sv[2] = {0.0, 0.0};
         if (!s_late) {
 #pragma unroll
-          for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; sv[u] = S[(size_t)(nb0 + r) * n + nb0 + c]; }
+          for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; sv[u] = Sat(nb0 + r, nb0 + c); }
         }
         {
           // The product is symmetric: tiles (0,0) and (1,1) take two waves each (halves of the K range, one operand to
@@ -431,7 +445,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int e = tid + u * nt, r = e >> 5, c = e & 31;
-          Pre[r * RSBA_PLD + c] += sys(nb0 + r, nb0 + c, S[(size_t)(nb0 + r) * n + nb0 + c]);
+          Pre[r * RSBA_PLD + c] += sys(nb0 + r, nb0 + c, Sat(nb0 + r, nb0 + c));
         }
         __syncthreads();
       }
@@ -462,7 +476,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
   if (gate.trace && tid == 0) gate.trace[13] = wall_clock64();   // factorisation complete on every workgroup
   double* ysol = A + (size_t)n * n;
   double* y = BackSubstituteBlocksPrefetch(n, A, lds);
-  for (int i = tid; i < n; i += nt) ysol[i] = y[i];
+  for (int i = tid; i < n; i += nt) ysol[i] = y[i];   // (the epilogue reads the first nreal entries)
   __threadfence_block();
   __syncthreads();
   int ok = 1;
@@ -473,6 +487,8 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
   SolveDone(gate);
 }
 
-__host__ __device__ inline size_t MultiCholLdsDoubles(int n) { return (size_t)(n + RSBA_PB) * RSBA_PLD + 4 * RSBA_PB * RSBA_PLD + 64 + n; }
+// n = the padded dimension
+__host__ __device__ inline int MultiCholPadded(int nc) { return (nc + RSBA_PB - 1) / RSBA_PB * RSBA_PB; }
+__host__ __device__ inline size_t MultiCholLdsDoubles(int nc) { const int n = MultiCholPadded(nc); return (size_t)(n + RSBA_PB) * RSBA_PLD + 4 * RSBA_PB * RSBA_PLD + 64 + n; }
 
 }  // namespace rsba

@@ -496,7 +496,7 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->intr, 4 * C)) || (rc = DevAlloc(&s->cam[0], 6 * C)) || (rc = DevAlloc(&s->cam[1], 6 * C)) || (rc = DevAlloc(&s->cam0, 6 * C)) ||
       (rc = DevAlloc(&s->pts[0], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts[1], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts0, 3 * (size_t)P)) ||
       (rc = DevAlloc(&s->camc[0], CC_STRIDE * C)) || (rc = DevAlloc(&s->camc[1], CC_STRIDE * C)) || (rc = DevAlloc(&s->scale_c, 6 * C)) ||
-      (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(s->nc + 2) * s->nc)) || (rc = DevAlloc(&s->W, s->nc > RSBA_CHOL_MAXN ? (size_t)(s->nc + 1) * s->nc : 1)) ||
+      (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(MultiCholPadded(s->nc) + 2) * MultiCholPadded(s->nc))) || (rc = DevAlloc(&s->W, s->nc > RSBA_CHOL_MAXN ? (size_t)(s->nc + 1) * s->nc : 1)) ||
       (rc = DevAlloc(&s->chol_ok, 3)) ||
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
       (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)))
@@ -539,10 +539,10 @@ static int UploadPoints(rsba_solver* s) {
     s->pipelined = SetupPipeline(s);
   }
   {
-    // several workgroups for the reduced system: 32, 48 or 64 cameras (whole 32-wide panels), full symmetric S
+    // several workgroups for the reduced system: 32 to 64 cameras (padded to whole 32-wide panels), full symmetric S
     const char* e = getenv("RSBA_CHOL_WGS");
     const int want = e ? atoi(e) : 4;
-    if (want > 1 && s->opt.schur_impl != 0 && s->nc % RSBA_PB == 0 && s->nc >= 6 * RSBA_PB && s->nc <= RSBA_CHOL_MAXN && !s->pipelined_mg) {
+    if (want > 1 && s->opt.schur_impl != 0 && s->nc >= 6 * RSBA_PB && s->nc <= RSBA_CHOL_MAXN && !s->pipelined_mg) {
       s->chol_wgs = std::min(want, RSBA_MC_MAXG);
       if ((rc = DevAlloc(&s->mc_flags, 48))) return rc;
       HIPCHK(hipMemset(s->mc_flags, 0, 48 * sizeof(int)));

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from realsensecalibration_amd import capi, synthetic as syn
 
-# cameras from the command line: 40 runs the one-workgroup Cholesky, 32 / 48 / 64 the four-workgroup one
+# cameras from the command line: below 32 runs the one-workgroup Cholesky, 32 .. 64 the four-workgroup one
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 prob = syn.make_problem(C, 20000, 10, seed=7)
 problem = capi.Problem.points(prob)
