@@ -642,12 +642,24 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
     bool any = false;
     const double X[3] = {pts_x[3 * (size_t)j], pts_x[3 * (size_t)j + 1], pts_x[3 * (size_t)j + 2]};
     double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, bv[3] = {0, 0, 0}, a1 = 0, a2 = 0;
+    // observation records four slots ahead of the one in use (k_point_pass: a thread's records are otherwise a chain of
+    // dependent round trips to memory; the grid is 1.5 workgroups per CU)
+    int camq[4]; double2 uvq[4];
+    auto fill = [&](int u, int t) {
+      const size_t qq = (size_t)t * 64 + lane;
+      camq[u] = t < te ? obs.cam[qq] : -1;
+      uvq[u] = t < te ? obs.uv[qq] : make_double2(0.0, 0.0);
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fill(u, tb + u);
     for (int t = tb; t < te; ++t) {
-      const size_t q = (size_t)t * 64 + lane;
-      const int cam = obs.cam[q];
+      const int cam = camq[0];
+      const double2 uv = uvq[0];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { camq[u] = camq[u + 1]; uvq[u] = uvq[u + 1]; }
+      fill(3, t + 4);
       if (cam < 0) continue;
       any = true;
-      const double2 uv = obs.uv[q];
       double r[2], jc[12], jp[6];
       ResidualJacobian(camc_x + (size_t)cam * (kStage ? RSBA_CC_LDS : CC_STRIDE), X, uv.x, uv.y, r, jc, jp);
       double sq;
@@ -681,11 +693,15 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
            0.5 * (dp[0] * Vd[0] + dp[1] * Vd[1] + dp[2] * Vd[2]);
     dp2 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
     xc2 += Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fill(u, tb + u);
     for (int t = tb; t < te; ++t) {
-      const size_t q = (size_t)t * 64 + lane;
-      const int cam = obs.cam[q];
+      const int cam = camq[0];
+      const double2 uv = uvq[0];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { camq[u] = camq[u + 1]; uvq[u] = uvq[u + 1]; }
+      fill(3, t + 4);
       if (cam < 0) continue;
-      const double2 uv = obs.uv[q];
       double r[2];
       Residual(camc_c + (size_t)cam * (kStage ? RSBA_CC_LDS : CC_STRIDE), Xc, uv.x, uv.y, r);
       const double s = r[0] * r[0] + r[1] * r[1];

@@ -117,12 +117,29 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
     bool any = false;
     const double X[3] = {pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2]};
     double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
-    for (int t = obs.row_ptr[j >> 6]; t < obs.row_ptr[(j >> 6) + 1]; ++t) {
+    // The grid is small (1.5 workgroups per CU at 100k points): a thread's ~20 observation records are a chain of
+    // dependent round trips to memory unless several are in flight — four slots are loaded ahead of the one in use.
+    const int t0 = obs.row_ptr[j >> 6], t1 = obs.row_ptr[(j >> 6) + 1];
+    int camq[4]; double2 uvq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t qq = (size_t)(t0 + u) * 64 + lane;
+      camq[u] = t0 + u < t1 ? obs.cam[qq] : -1;
+      uvq[u] = t0 + u < t1 ? obs.uv[qq] : make_double2(0.0, 0.0);
+    }
+    for (int t = t0; t < t1; ++t) {
       const size_t q = (size_t)t * 64 + lane;
-      const int cam = obs.cam[q];
+      const int cam = camq[0];
+      const double2 uv = uvq[0];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { camq[u] = camq[u + 1]; uvq[u] = uvq[u + 1]; }
+      {
+        const size_t qq = (size_t)(t + 4) * 64 + lane;
+        camq[3] = t + 4 < t1 ? obs.cam[qq] : -1;
+        uvq[3] = t + 4 < t1 ? obs.uv[qq] : make_double2(0.0, 0.0);
+      }
       if (cam < 0) continue;
       any = true;
-      const double2 uv = obs.uv[q];
       double r[2], jc[12], jp[6], sq;
       ResidualJacobian(camc + (size_t)cam * ccs, X, uv.x, uv.y, r, jc, jp);
       cost += LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
