@@ -627,10 +627,28 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
     double* lx = lds;
     double* lc = lds + (size_t)C * RSBA_CC_LDS;
     double* ld = lc + (size_t)C * RSBA_CC_LDS;
-    for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; lx[c * RSBA_CC_LDS + e] = camc_xg[i]; }
+    // copies with eight loads in flight per thread (a plain copy loop waits for every load; what comes after the solve is
+    // the tail of the LM step and was eight dependent round trips to the solve's output)
+    auto stage_camc = [&](const double* __restrict__ src, double* dst) {
+      for (int i0 = 0; i0 < C * CC_STRIDE; i0 += 8 * blockDim.x) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * blockDim.x + tid; v[u] = i < C * CC_STRIDE ? src[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * blockDim.x + tid; if (i < C * CC_STRIDE) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; dst[c * RSBA_CC_LDS + e] = v[u]; } }
+      }
+    };
+    stage_camc(camc_xg, lx);
     wait_solve();
-    for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; lc[c * RSBA_CC_LDS + e] = camc_cg[i]; }
-    for (int i = tid; i < 6 * C; i += blockDim.x) ld[i] = dcam_g[i];
+    {
+      double dv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { const int i = u * blockDim.x + tid; dv[u] = i < 6 * C ? dcam_g[i] : 0.0; }
+      stage_camc(camc_cg, lc);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { const int i = u * blockDim.x + tid; if (i < 6 * C) ld[i] = dv[u]; }
+      for (int i = 2 * blockDim.x + tid; i < 6 * C; i += blockDim.x) ld[i] = dcam_g[i];
+    }
     __syncthreads();
     camc_x = lx; camc_c = lc; dcam = ld;
   } else {

@@ -107,7 +107,17 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
   extern __shared__ double lds[];
   double* camc_l = lds;      // C x 33 when staged
   const int tid = threadIdx.x;
-  if (kStageCamc) for (int i = tid; i < C * CC_STRIDE; i += blockDim.x) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; camc_l[c * RSBA_CC_LDS + e] = camc_g[i]; }
+  if (kStageCamc) {
+    // eight loads in flight per thread before the first LDS store (a plain copy loop waits for every load: 8 round trips
+    // at the head of every LM step)
+    for (int i0 = 0; i0 < C * CC_STRIDE; i0 += 8 * blockDim.x) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * blockDim.x + tid; v[u] = i < C * CC_STRIDE ? camc_g[i] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * blockDim.x + tid; if (i < C * CC_STRIDE) { const int c = i / CC_STRIDE, e = i - c * CC_STRIDE; camc_l[c * RSBA_CC_LDS + e] = v[u]; } }
+    }
+  }
   __syncthreads();
   const double* camc = kStageCamc ? camc_l : camc_g;
   const int ccs = kStageCamc ? RSBA_CC_LDS : CC_STRIDE;
