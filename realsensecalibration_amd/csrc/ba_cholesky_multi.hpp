@@ -403,9 +403,17 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
       }
       RSBA_MC_STAMP(4);
       if (!WaitFlagWG(f.tdone + p, tag, f.error, budget)) { stalled = true; break; }
-      for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) {
-        const int r = e >> 5, c = e & 31;   // T[r][c], r >= c: stored at A[kb + c][kb + r] for r > c, the diagonal in row n + 1
-        T[r * RSBA_PLD + c] = r > c ? A[(size_t)(kb + c) * n + kb + r] : (r == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
+      {
+        // T[r][c], r >= c: stored at A[kb + c][kb + r] for r > c, the diagonal in row n + 1.  Both of a thread's entries
+        // are loaded before either is stored: this is on the chain from one factorisation to the next
+        double tv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = tid + u * nt, r = e >> 5, c = e & 31;
+          tv[u] = r > c ? A[(size_t)(kb + c) * n + kb + r] : (r == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int e = tid + u * nt; T[(e >> 5) * RSBA_PLD + (e & 31)] = tv[u]; }
       }
       __syncthreads();
       RSBA_MC_STAMP(5);
