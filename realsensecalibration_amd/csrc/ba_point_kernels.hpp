@@ -474,7 +474,9 @@ __device__ void CholeskySolveBlocked(int n, double* __restrict__ A, double* __re
 // visible, then gate.done = tag releases the back-substitution that is waiting for it (pipelined schedule).
 __device__ __forceinline__ void SolveDone(const StageGate& gate) {
   if (gate.done == nullptr) return;
-  __threadfence();
+  // every wave's stores are performed at the barrier (they are in this XCD's L2); ONE release then writes the L2 back
+  // and sets the flag — a fence in each of the eight waves was eight write-backs in a row at the tail of the LM step
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(gate.done, gate.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
