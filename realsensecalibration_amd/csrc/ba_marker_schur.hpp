@@ -566,23 +566,23 @@ k_marker_schur_finish(int nb_time, const double* __restrict__ bp_time, const dou
 }
 
 struct MarkerSchurDevice {
-  int N = 0, T = 0, nr = 0, nfull = 0, G = 0, dmax = 0, nb_time = 0, nb_obs = 0;
+  int N = 0, T = 0, nr = 0, nfull = 0, G = 0, dmax = 0, nb_time = 0;
   double half_side = 0;
   MarkerObs* mo = nullptr;
   TimeSlots* ts = nullptr;
   int *chunk_ptr = nullptr, *time_ptr = nullptr, *slot_ptr = nullptr, *slot_col = nullptr, *time_full = nullptr, *col_full = nullptr,
-      *obs_time = nullptr, *ok_flag = nullptr;
+      *ok_flag = nullptr;
   double *obs8 = nullptr, *intr = nullptr, *params[2] = {nullptr, nullptr}, *params0 = nullptr;
-  double *Jbuf = nullptr, *rbuf = nullptr, *ss_x = nullptr, *ss_c = nullptr, *scale_t = nullptr, *scale_r = nullptr, *tdata = nullptr,
+  double *Jbuf = nullptr, *rbuf = nullptr, *ss_x = nullptr, *scale_t = nullptr, *scale_r = nullptr, *tdata = nullptr,
          *part = nullptr, *red = nullptr, *A = nullptr, *Wm = nullptr, *delta_r = nullptr, *delta_t = nullptr, *bp_time = nullptr,
-         *bp_obs = nullptr, *solve_out = nullptr, *res = nullptr;
+         *solve_out = nullptr, *res = nullptr;
   int cur = 0;
   size_t lds_elim = 0;
   bool lds_s = false;   // the chunk sums of S live in LDS
 
   void Free() {
-    void* ptrs[] = {mo, ts, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, obs_time, ok_flag, obs8, intr, params[0], params[1],
-                    params0, Jbuf, rbuf, ss_x, ss_c, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, bp_obs, solve_out, res};
+    void* ptrs[] = {mo, ts, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ok_flag, obs8, intr, params[0], params[1],
+                    params0, Jbuf, rbuf, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     mo = nullptr; ts = nullptr;
   }
@@ -623,7 +623,7 @@ struct MarkerSchurDevice {
     std::vector<int> order(N);
     for (int i = 0; i < N; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return p.time_index[x] < p.time_index[y]; });
-    std::vector<int> tptr(T + 1, 0), sptr(T + 1, 0), scol, otime(N);
+    std::vector<int> tptr(T + 1, 0), sptr(T + 1, 0), scol;
     std::vector<MarkerObs> hmo(N);
     std::vector<TimeSlots> hts(N);
     std::vector<double> hobs(8 * (size_t)N);
@@ -659,7 +659,6 @@ struct MarkerSchurDevice {
         s.col_marker = p.uses_marker(i) ? red_col[C + p.marker_index[i]] : -1;
         s.slot_cam = s.col_cam >= 0 ? (int)(std::lower_bound(cols.begin(), cols.end(), s.col_cam) - cols.begin()) : -1;
         s.slot_marker = s.col_marker >= 0 ? (int)(std::lower_bound(cols.begin(), cols.end(), s.col_marker) - cols.begin()) : -1;
-        otime[k] = t;
         memcpy(&hobs[8 * (size_t)k], &p.observations[8 * (size_t)i], 8 * sizeof(double));
       }
       sptr[t + 1] = sptr[t] + (int)cols.size();
@@ -699,24 +698,24 @@ struct MarkerSchurDevice {
       for (int k = 1; k <= G; ++k) if (cptr[k] > c2.back()) c2.push_back(cptr[k]);
       G = (int)c2.size() - 1; cptr = c2;
     }
-    nb_time = (T + 3) / 4; nb_obs = (N + 255) / 256;
+    nb_time = (T + 3) / 4;
     auto al = [](void** q, size_t bytes) { return hipMalloc(q, std::max<size_t>(bytes, 8)) == hipSuccess; };
     const size_t nA = (size_t)(nr + 2) * nr;
     if (!al((void**)&mo, N * sizeof(MarkerObs)) || !al((void**)&ts, N * sizeof(TimeSlots)) || !al((void**)&chunk_ptr, (G + 1) * 4) ||
         !al((void**)&time_ptr, (T + 1) * 4) || !al((void**)&slot_ptr, (T + 1) * 4) || !al((void**)&slot_col, scol.size() * 4) ||
-        !al((void**)&time_full, T * 4) || !al((void**)&col_full, nr * 4) || !al((void**)&obs_time, N * 4) || !al((void**)&ok_flag, 4) ||
+        !al((void**)&time_full, T * 4) || !al((void**)&col_full, nr * 4) || !al((void**)&ok_flag, 4) ||
         !al((void**)&obs8, 8 * (size_t)N * 8) || !al((void**)&intr, p.intrinsics.size() * 8) || !al((void**)&params[0], nfull * 8) ||
         !al((void**)&params[1], nfull * 8) || !al((void**)&params0, nfull * 8) || !al((void**)&Jbuf, (size_t)N * 144 * 8) ||
-        !al((void**)&rbuf, (size_t)N * 8 * 8) || !al((void**)&ss_x, N * 8) || !al((void**)&ss_c, N * 8) || !al((void**)&scale_t, 6 * (size_t)T * 8) ||
+        !al((void**)&rbuf, (size_t)N * 8 * 8) || !al((void**)&ss_x, N * 8) || !al((void**)&scale_t, 6 * (size_t)T * 8) ||
         !al((void**)&scale_r, nr * 8) || !al((void**)&tdata, 48 * (size_t)T * 8) || !al((void**)&part, (size_t)G * PL.size() * 8) ||
         !al((void**)&red, RL.size() * 8) || !al((void**)&A, nA * 8) || (nr > RSBA_CHOL_MAXN && !al((void**)&Wm, nA * 8)) ||
         !al((void**)&delta_r, nr * 8) || !al((void**)&delta_t, 6 * (size_t)T * 8) || !al((void**)&bp_time, 4 * (size_t)nb_time * 8) ||
-        !al((void**)&bp_obs, 2 * (size_t)nb_obs * 8) || !al((void**)&solve_out, 8 * 8) || !al((void**)&res, RES_SIZE * 8))
+        !al((void**)&solve_out, 8 * 8) || !al((void**)&res, RES_SIZE * 8))
       return RSBA_ERR_HIP;
     auto up = [](void* d, const void* h, size_t bytes) { return bytes == 0 || hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) == hipSuccess; };
     if (!up(mo, hmo.data(), N * sizeof(MarkerObs)) || !up(ts, hts.data(), N * sizeof(TimeSlots)) || !up(chunk_ptr, cptr.data(), (G + 1) * 4) ||
         !up(time_ptr, tptr.data(), (T + 1) * 4) || !up(slot_ptr, sptr.data(), (T + 1) * 4) || !up(slot_col, scol.data(), scol.size() * 4) ||
-        !up(time_full, tfull.data(), T * 4) || !up(col_full, cf.data(), nr * 4) || !up(obs_time, otime.data(), N * 4) ||
+        !up(time_full, tfull.data(), T * 4) || !up(col_full, cf.data(), nr * 4) ||
         !up(obs8, hobs.data(), 8 * (size_t)N * 8) || !up(intr, p.intrinsics.data(), p.intrinsics.size() * 8) ||
         !up(params0, p.parameters.data(), nfull * 8))
       return RSBA_ERR_HIP;
