@@ -1,0 +1,217 @@
+// Dense SPD factorisation of the reduced camera system for n > 384 (more than 64 cameras) in ONE launch.
+//
+// ba_cholesky_large.hpp spreads the right-looking factorisation over the chip with one launch per 32-wide panel and lets
+// every workgroup refactor the 32 x 32 diagonal block itself (48 launches of ~26 us at 256 cameras).  Here every 64 x 64
+// tile (I >= J) of the lower triangle is one RESIDENT workgroup that keeps its tile in LDS from the first panel to the
+// last that touches it, and the panels are chained with flags in global memory (the protocol of ba_cholesky_multi.hpp:
+// agent-scope stores behind s_waitcnt, relaxed polls, one acquire fence; ~1.2 us per hop):
+//
+//   panel p (tile column Jp = p / 2, half hf = p & 1):
+//     diagonal tile (Jp, Jp)   factors the 32 x 32 block (one wavefront, DiagFactorInverse), stores L11 / T = L11^-1,
+//                              raises tdone[p]; for hf = 0 it also solves X for its rows 32..63
+//     column tiles (I, Jp)     wait for tdone[p], X = Rows T' on the matrix cores, store X as L, raise xdone[p][I];
+//                              for hf = 0 their columns 32..63 then take -X_I X_Jp[32..63]'
+//     trailing tiles (I, J>Jp) wait for xdone[p][I] and xdone[p][J], load the two 64 x 32 strips of X, tile -= X_I X_J'
+//
+// A tile retires after panel 2J + 1.  The matrix is padded with identity to whole panels (as in ba_cholesky_multi.hpp);
+// the right-hand side rides along as row m.  F gets the layout BackSubstituteBlocks reads (L in the lower triangle, T in
+// the strict upper triangle of the diagonal blocks, y in row n, inverse pivots in row n + 1); k_chol_finish does the rest.
+// All tiles must be resident at once (two workgroups per CU): the host checks the tile count and falls back to the
+// multi-launch path otherwise; every wait has the budget of WaitReady and gives up instead of hanging.
+#pragma once
+#include "ba_cholesky_large.hpp"
+#include "ba_cholesky_multi.hpp"
+
+namespace rsba {
+
+#define RSBA_TL 65   // leading dimension of the resident tile (64 x 64, odd stride)
+
+struct TileCholFlags {
+  int* tdone;    // [np]            == tag: L11 / T of panel p are in F
+  int* xdone;    // [np][nrt]       == tag: X of panel p for tile row I is in F
+  int* error;    // != 0: somebody gave up
+  int nrt;
+};
+
+__host__ __device__ inline size_t TileCholLdsDoubles() { return (size_t)64 * RSBA_TL + 64 * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD + 64; }
+
+__global__ void __launch_bounds__(256, 2)
+k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scaled, damped system + rhs row (k_sys_build) */,
+                        double* __restrict__ F /* (n + 2) x n */, int* __restrict__ ok_flag, TileCholFlags f, int tag,
+                        double* __restrict__ res) {
+  extern __shared__ double lds[];
+  double* Tl = lds;                              // the tile, 64 x 65
+  double* XI = Tl + 64 * RSBA_TL;                // 64 x 33: X of this tile's rows for the current panel
+  double* T = XI + 64 * RSBA_PLD;                // 32 x 33
+  double* Pan = T + RSBA_PB * RSBA_PLD;          // 32 x 33 (diagonal tiles)   |  together: XJ, 64 x 33 (the others)
+  double* Lt = Pan + RSBA_PB * RSBA_PLD;         // 32 x 33 (diagonal tiles)   |
+  double* XJ = Pan;
+  double* invd = Lt + RSBA_PB * RSBA_PLD;        // 64
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mi = lane & 15, kk = lane >> 4;
+  const int m = (n + RSBA_PB - 1) / RSBA_PB * RSBA_PB, np = m / RSBA_PB;
+  const long long budget = RSBA_STALL_TICKS;
+  __shared__ int s_good;
+  // tile (I, J), I >= J, from the linear index
+  const int t = blockIdx.x;
+  int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while (I * (I + 1) / 2 > t) --I;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  const int J = t - I * (I + 1) / 2;
+  const int r0 = 64 * I, c0 = 64 * J;
+  if (c0 >= m) return;   // (the tile row of the rhs row reaches one column past the matrix when m is a multiple of 64)
+  // entry (gi, gj) of the padded system; row m is the right-hand side
+  auto sysv = [&](int gi, int gj) {
+    if (gi > m || gj >= m) return 0.0;
+    if (gi == m) return gj < n ? W[(size_t)n * n + gj] : 0.0;
+    if (gi >= n || gj >= n) return gi == gj ? 1.0 : 0.0;
+    return W[(size_t)gi * n + gj];
+  };
+  for (int e = tid; e < 64 * 64; e += 256) { const int r = e >> 6, c = e & 63; Tl[r * RSBA_TL + c] = sysv(r0 + r, c0 + c); }
+  if (t == 0 && tid == 0) __hip_atomic_store(ok_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  // store a value of L / y into F (real entries only; the rhs row m lands in row n)
+  auto storeF = [&](int gi, int gj, double v) {
+    if (gj >= n) return;
+    if (gi < n) StoreShared(&F[(size_t)gi * n + gj], v);
+    else if (gi == m) StoreShared(&F[(size_t)n * n + gj], v);
+  };
+  auto loadF = [&](int gi, int gj) -> double {   // L entry (gi, gj) of the padded factor, gi > gj's panel
+    if (gj >= n) return 0.0;                     // padded columns: identity, nothing below the diagonal
+    if (gi < n) return F[(size_t)gi * n + gj];
+    if (gi == m) return F[(size_t)n * n + gj];
+    return 0.0;
+  };
+  bool stalled = false;
+  const int plast = min(2 * J + 1, np - 1);
+  for (int p = 0; p <= plast && !stalled; ++p) {
+    const int Jp = p >> 1, hf = p & 1, kb = p * RSBA_PB, lc = 32 * hf;   // lc: the panel's first column inside a tile of column Jp
+    if (J == Jp) {
+      if (I == J) {
+        // ---- diagonal tile: factor the block at [lc, lc + 32)^2
+        for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) { const int r = e >> 5, c = e & 31; Pan[r * RSBA_PLD + c] = Tl[(lc + r) * RSBA_TL + lc + c]; }
+        __syncthreads();
+        if (wave == 0) {
+          const bool good = DiagFactorInverseCall((lds_double*)Pan, RSBA_PB, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane);
+          if (lane == 0) s_good = good ? 1 : 0;
+        }
+        __syncthreads();
+        for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) {
+          const int r = e >> 5, c = e & 31;
+          if (kb + r < n && kb + c < n) StoreShared(&F[(size_t)(kb + r) * n + kb + c], c > r ? T[c * RSBA_PLD + r] : Pan[r * RSBA_PLD + c]);
+        }
+        if (tid < RSBA_PB && kb + tid < n) StoreShared(&F[(size_t)(n + 1) * n + kb + tid], invd[tid]);
+        if (tid == 0 && !s_good) __hip_atomic_store(ok_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PublishFlagWG(f.tdone + p, tag);
+      } else {
+        if (!WaitFlagWG(f.tdone + p, tag, f.error, budget)) { stalled = true; break; }
+        {
+          double tv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = tid + u * 256, r = e >> 5, c = e & 31;   // T[r][c], r >= c
+            tv[u] = (kb + r < n && kb + c < n) ? (r > c ? F[(size_t)(kb + c) * n + kb + r] : (r == c ? F[(size_t)(n + 1) * n + kb + c] : 0.0))
+                                                : (r == c ? 1.0 : 0.0);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; T[(e >> 5) * RSBA_PLD + (e & 31)] = tv[u]; }
+        }
+        __syncthreads();
+      }
+      // ---- X = Rows T' for this tile's rows below the diagonal block: wave w takes rows 16 w .. 16 w + 15
+      {
+        const int rlo = (I == J) ? lc + RSBA_PB : 0;     // first tile row that is below the diagonal block
+        d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        const int row = 16 * wave + mi;
+#pragma unroll
+        for (int qs = 0; qs < RSBA_PB; qs += 4) {
+          const double a = Tl[row * RSBA_TL + lc + qs + kk];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[mi * RSBA_PLD + qs + kk], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[(16 + mi) * RSBA_PLD + qs + kk], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int r = 16 * wave + kk + 4 * tt;
+          const bool below = r >= rlo;
+          const double x0 = below ? acc0[tt] : 0.0, x1 = below ? acc1[tt] : 0.0;
+          XI[r * RSBA_PLD + mi] = x0; XI[r * RSBA_PLD + 16 + mi] = x1;
+          if (below) {
+            Tl[r * RSBA_TL + lc + mi] = x0; Tl[r * RSBA_TL + lc + 16 + mi] = x1;
+            storeF(r0 + r, kb + mi, x0); storeF(r0 + r, kb + 16 + mi, x1);
+          }
+        }
+      }
+      PublishFlagWG(f.xdone + (size_t)p * f.nrt + I, tag);
+      // ---- first half done: this tile's columns 32..63 take -X_I X_Jp[rows 32..63]'
+      if (hf == 0 && 2 * J + 1 < np) {
+        if (I != J) {
+          if (!WaitFlagWG(f.xdone + (size_t)p * f.nrt + J, tag, f.error, budget)) { stalled = true; break; }
+          double xv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int e = tid + u * 256, r = 32 + (e >> 5), c = e & 31; xv[u] = loadF(c0 + r, kb + c); }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; XJ[(32 + (e >> 5)) * RSBA_PLD + (e & 31)] = xv[u]; }
+          __syncthreads();
+        }
+        const double* XB = (I == J) ? XI : XJ;
+        d4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+        const int row = 16 * wave + mi;
+#pragma unroll
+        for (int qs = 0; qs < RSBA_PB; qs += 4) {
+          const double a = XI[row * RSBA_PLD + qs + kk];
+          a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, XB[(32 + mi) * RSBA_PLD + qs + kk], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, XB[(48 + mi) * RSBA_PLD + qs + kk], a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int r = 16 * wave + kk + 4 * tt;
+          Tl[r * RSBA_TL + 32 + mi] -= a0[tt];
+          Tl[r * RSBA_TL + 48 + mi] -= a1[tt];
+        }
+        __syncthreads();
+      }
+    } else {
+      // ---- trailing tile: tile -= X_I X_J'
+      if (!WaitFlagWG(f.xdone + (size_t)p * f.nrt + I, tag, f.error, budget)) { stalled = true; break; }
+      if (I != J && !WaitFlagWG(f.xdone + (size_t)p * f.nrt + J, tag, f.error, budget)) { stalled = true; break; }
+      {
+        double xi[8], xj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = tid + u * 256, r = e >> 5, c = e & 31;
+          xi[u] = loadF(r0 + r, kb + c);
+          xj[u] = I != J ? loadF(c0 + r, kb + c) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = tid + u * 256, r = e >> 5, c = e & 31;
+          XI[r * RSBA_PLD + c] = xi[u];
+          if (I != J) XJ[r * RSBA_PLD + c] = xj[u];
+        }
+      }
+      __syncthreads();
+      const double* XB = (I == J) ? XI : XJ;
+      d4_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+      const int row = 16 * wave + mi;
+#pragma unroll
+      for (int qs = 0; qs < RSBA_PB; qs += 4) {
+        const double a = XI[row * RSBA_PLD + qs + kk];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, XB[(16 * jb + mi) * RSBA_PLD + qs + kk], acc[jb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) Tl[(16 * wave + kk + 4 * tt) * RSBA_TL + 16 * jb + mi] -= acc[jb][tt];
+      __syncthreads();
+    }
+  }
+  if (stalled && tid == 0) {
+    __hip_atomic_store(f.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ok_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    res[RES_STALL] = 1.0;   // the host repeats the step with the multi-launch factorisation
+  }
+}
+
+}  // namespace rsba

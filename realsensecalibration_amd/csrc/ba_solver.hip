@@ -30,6 +30,7 @@
 #include "ba_point_kernels.hpp"
 #include "ba_cholesky_large.hpp"
 #include "ba_cholesky_multi.hpp"
+#include "ba_cholesky_tiles.hpp"
 #include "ba_problem.hpp"
 #include "ba_schur_tiled.hpp"
 #include "ba_solver.hpp"
@@ -129,6 +130,8 @@ struct rsba_solver {
   int step_tag = 0;
   int chol_wgs = 1;          // > 1: the reduced system is factored by this many workgroups (ba_cholesky_multi.hpp)
   int* mc_flags = nullptr;   // tdone[16] | strip_ready[16] | wg_done[8] | error
+  int* tc_flags = nullptr;   // persistent tiled factorisation (more than 64 cameras): tdone[np] | xdone[np][nrt] | error
+  int tc_np = 0, tc_nrt = 0, tc_tiles = 0;   // 0 tiles: the multi-launch path
   long long* mc_trace = nullptr;   // RSBA_MC_TRACE=1: stamps of the latest multi-workgroup factorisation
   hipStream_t sB = nullptr;
   // Multi-GPU pipeline: the stage flags the Cholesky waits on are published on the communication stream sR, each after
@@ -375,7 +378,7 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res, s->cam_free, s->mc_flags};
+                  s->block_part, s->small_red, s->gmax, s->res, s->cam_free, s->mc_flags, s->tc_flags};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
@@ -549,6 +552,22 @@ static int UploadPoints(rsba_solver* s) {
       if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, RSBA_MC_MAXG * 16 * 8))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, RSBA_MC_MAXG * 16 * 8 * sizeof(long long))); }
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(MultiCholLdsDoubles(s->nc) * sizeof(double))));
+    }
+    // more than 64 cameras: one resident workgroup per 64 x 64 tile, if they all fit on the chip at once
+    const char* e2 = getenv("RSBA_CHOL_TILES");
+    if (s->nc > RSBA_CHOL_MAXN && !(e2 && atoi(e2) == 0)) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) {
+        const int m = MultiCholPadded(s->nc), nrt = (m + 1 + 63) / 64, ntiles = nrt * (nrt + 1) / 2;
+        if (ntiles <= 2 * prop.multiProcessorCount) {
+          s->tc_np = m / RSBA_PB; s->tc_nrt = nrt; s->tc_tiles = ntiles;
+          const size_t nflags = (size_t)s->tc_np * (nrt + 1) + 1;
+          if ((rc = DevAlloc(&s->tc_flags, nflags))) return rc;
+          HIPCHK(hipMemset(s->tc_flags, 0, nflags * sizeof(int)));
+          HIPCHK(hipFuncSetAttribute((const void*)k_chol_tiles_persistent, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(TileCholLdsDoubles() * sizeof(double))));
+        }
+      }
     }
   }
   {
@@ -751,6 +770,13 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     k_sys_build<<<n + 1, 256, 0, st>>>(s->red, s->L, s->W, keep_system_copy ? s->S_copy : nullptr, keep_system_copy ? s->rhs_copy : nullptr,
                                        s->scale_c, ip, s->opt.schur_impl != 0 ? 1 : 0, s->chol_ok);
     T.End(st);
+    if (s->tc_tiles > 0) {
+      T.Begin("k_chol_tiles_persistent", st);
+      k_chol_tiles_persistent<<<s->tc_tiles, 256, TileCholLdsDoubles() * sizeof(double), st>>>(
+          n, s->W, s->A, s->chol_ok, TileCholFlags{s->tc_flags, s->tc_flags + s->tc_np, s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1), s->tc_nrt},
+          s->step_tag, s->res);
+      T.End(st);
+    } else {
     const size_t lds_s = CholStepLdsDoubles() * sizeof(double);
     T.Begin("k_chol_step(all panels)", st);
     for (int kb = 0; kb < n; kb += RSBA_PB) {
@@ -759,6 +785,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       k_chol_step<<<nrt * (nrt + 1) / 2, 256, lds_s, st>>>(n, kb, s->W, s->A, s->chol_ok);
     }
     T.End(st);
+    }
     const size_t lds_f = std::max((size_t)4 * 1024, (size_t)((n + 63) & ~63) + 3 * RSBA_PB * RSBA_PLD + 64) * sizeof(double);
     T.Begin("k_chol_finish", st);
     k_chol_finish<<<1, 1024, lds_f, st>>>(C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res,
@@ -857,6 +884,13 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
         fclose(f);
       }
     }
+  }
+  if (!pipe && s->tc_tiles > 0 && s->res_host[RES_STALL] != 0.0) {
+    fprintf(stderr, "rsba: persistent tiled Cholesky stalled; using the multi-launch factorisation\n");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(s->res, 0, RES_SIZE * sizeof(double)));
+    s->tc_tiles = 0;
+    return PointsStep(s, radius, first, keep_system_copy);
   }
   if (!pipe && s->chol_wgs > 1 && s->res_host[RES_STALL] != 0.0) {
     // the workgroups of the factorisation did not run side by side (cannot happen on an idle stream): one workgroup then
