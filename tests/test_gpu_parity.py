@@ -661,3 +661,23 @@ def test_multi_workgroup_cholesky_stall_falls_back(oracle, capfd):
         del os.environ["RSBA_TEST_STALL"]
     assert "falling back" in capfd.readouterr().err
     assert np.array_equal(got, ref) and np.array_equal(log, log_ref)
+
+
+# ------------------------------------------------------------------ persistent tiled Cholesky (more than 64 cameras)
+@pytest.mark.parametrize("C,P,k", [(65, 1400, 9), (100, 2200, 10), (128, 2600, 10)])
+def test_persistent_tiled_cholesky_matches_oracle_and_multi_launch(oracle, C, P, k):
+    """More than 64 cameras: one resident workgroup per 64 x 64 tile of the reduced system, chained by flags
+    (ba_cholesky_tiles.hpp).  C = 65: a padded last panel; C = 100: an odd number of panels (the last tile column holds one);
+    C = 128: whole tiles, the right-hand side row alone in its tile row.  Oracle parity, the multi-launch factorisation
+    (RSBA_CHOL_TILES=0) to rounding, bitwise reproducibility."""
+    prob = syn.make_problem(C, P, k, seed=900 + C)
+    got, s, log = _compare_solve(oracle, prob, 1)
+    again, s2, log2 = capi.solve_points(prob)
+    assert np.array_equal(got, again) and np.array_equal(log, log2)
+    os.environ["RSBA_CHOL_TILES"] = "0"
+    try:
+        other, so, _ = capi.solve_points(prob)
+    finally:
+        del os.environ["RSBA_CHOL_TILES"]
+    assert so.num_iterations == s.num_iterations
+    assert np.abs(other - got).max() < 1e-9 * max(1.0, np.abs(got).max())
