@@ -29,6 +29,7 @@
 // are applied by the Cholesky's panel loads (PanelSource).
 #pragma once
 #include "ba_cholesky_large.hpp"
+#include "ba_cholesky_tiles.hpp"
 #include "ba_marker_kernels.hpp"
 
 namespace rsba {
@@ -577,12 +578,14 @@ struct MarkerSchurDevice {
          *part = nullptr, *red = nullptr, *A = nullptr, *Wm = nullptr, *delta_r = nullptr, *delta_t = nullptr, *bp_time = nullptr,
          *solve_out = nullptr, *res = nullptr;
   int cur = 0;
+  int* tc_flags = nullptr;   // persistent tiled factorisation of a large reduced system (ba_cholesky_tiles.hpp)
+  int tc_np = 0, tc_nrt = 0, tc_tiles = 0, tc_tag = 0;
   size_t lds_elim = 0;
   bool lds_s = false;   // the chunk sums of S live in LDS
 
   void Free() {
     void* ptrs[] = {mo, ts, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ok_flag, obs8, intr, params[0], params[1],
-                    params0, Jbuf, rbuf, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res};
+                    params0, Jbuf, rbuf, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res, tc_flags};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     mo = nullptr; ts = nullptr;
   }
@@ -730,6 +733,18 @@ struct MarkerSchurDevice {
     } else {
       if (hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CholStepLdsDoubles() * sizeof(double))) != hipSuccess)
         return RSBA_ERR_HIP;
+      int dev = 0; hipDeviceProp_t prop;
+      const char* e2 = getenv("RSBA_CHOL_TILES");
+      if (!(e2 && atoi(e2) == 0) && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+        const int m = MultiCholPadded(nr), nrt = (m + 1 + 63) / 64, ntiles = nrt * (nrt + 1) / 2;
+        if (ntiles <= 2 * prop.multiProcessorCount) {
+          tc_np = m / RSBA_PB; tc_nrt = nrt; tc_tiles = ntiles;
+          const size_t nflags = (size_t)tc_np * (nrt + 1) + 1;
+          if (!al((void**)&tc_flags, nflags * sizeof(int)) || hipMemset(tc_flags, 0, nflags * sizeof(int)) != hipSuccess) return RSBA_ERR_HIP;
+          if (hipFuncSetAttribute((const void*)k_chol_tiles_persistent, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(TileCholLdsDoubles() * sizeof(double))) != hipSuccess) return RSBA_ERR_HIP;
+        }
+      }
     }
     return RSBA_OK;
   }
@@ -776,14 +791,21 @@ struct MarkerSchurDevice {
       Tm.Begin("k_sys_build", st);
       k_sys_build<<<nr + 1, 256, 0, st>>>(red, RL, Wm, nullptr, nullptr, scale_r, ip, 1, ok_flag);
       Tm.End(st);
-      const size_t lds_s = CholStepLdsDoubles() * sizeof(double);
-      Tm.Begin("k_chol_step(all panels)", st);
-      for (int kb = 0; kb < nr; kb += RSBA_PB) {
-        const int r0 = kb + std::min(RSBA_PB, nr - kb);
-        const int nrt = (nr + 1 - r0 + RSBA_CT - 1) / RSBA_CT;
-        k_chol_step<<<nrt * (nrt + 1) / 2, 256, lds_s, st>>>(nr, kb, Wm, A, ok_flag);
+      if (tc_tiles > 0) {
+        Tm.Begin("k_chol_tiles_persistent", st);
+        k_chol_tiles_persistent<<<tc_tiles, 256, TileCholLdsDoubles() * sizeof(double), st>>>(
+            nr, Wm, A, ok_flag, TileCholFlags{tc_flags, tc_flags + tc_np, tc_flags + (size_t)tc_np * (tc_nrt + 1), tc_nrt}, ++tc_tag, res);
+        Tm.End(st);
+      } else {
+        const size_t lds_s = CholStepLdsDoubles() * sizeof(double);
+        Tm.Begin("k_chol_step(all panels)", st);
+        for (int kb = 0; kb < nr; kb += RSBA_PB) {
+          const int r0 = kb + std::min(RSBA_PB, nr - kb);
+          const int nrt = (nr + 1 - r0 + RSBA_CT - 1) / RSBA_CT;
+          k_chol_step<<<nrt * (nrt + 1) / 2, 256, lds_s, st>>>(nr, kb, Wm, A, ok_flag);
+        }
+        Tm.End(st);
       }
-      Tm.End(st);
       const size_t lds_f = std::max((size_t)4 * 1024, (size_t)((nr + 63) & ~63) + 3 * RSBA_PB * RSBA_PLD + 64) * sizeof(double);
       Tm.Begin("k_marker_chol_finish", st);
       k_marker_chol_finish<<<1, 1024, lds_f, st>>>(nr, red, A, scale_r, col_full, params[x], params[c], delta_r, solve_out, ok_flag);
@@ -800,6 +822,13 @@ struct MarkerSchurDevice {
     if (!chk("k_marker_schur_finish")) return RSBA_ERR_HIP;
     if (hipMemcpyAsync(res_host, res, RES_SIZE * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return RSBA_ERR_HIP;
     { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) { fprintf(stderr, "rsba: marker-chain step failed: %s\n", hipGetErrorString(e)); return RSBA_ERR_HIP; } }
+    if (tc_tiles > 0 && res_host[RES_STALL] != 0.0) {
+      // the tiles of the persistent factorisation were not all running side by side: the multi-launch path then
+      fprintf(stderr, "rsba: persistent tiled Cholesky stalled; using the multi-launch factorisation\n");
+      tc_tiles = 0;
+      if (hipMemset(res, 0, RES_SIZE * sizeof(double)) != hipSuccess) return RSBA_ERR_HIP;
+      return Step(st, o, radius, first, res_host, Tm);
+    }
     return RSBA_OK;
   }
   int SumSquares(hipStream_t st, double* out) {
