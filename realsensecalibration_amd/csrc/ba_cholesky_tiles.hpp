@@ -214,4 +214,111 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
   }
 }
 
+// Block back-substitution L' x = y for the large system on SEVERAL workgroups (k_chol_finish does it on one: 48 dependent
+// strips of L from memory, 0.3 ms at 256 cameras).  Workgroup g owns three consecutive 32-column blocks of y.  From the
+// last block up: the owner of block b has applied every later block to its columns, so x_b = T_b' y_b; it publishes x_b
+// (32 doubles + a flag); every workgroup with columns below b subtracts L[b, own columns]' x_b from its part of y — the strip
+// it needs is loaded one block ahead (its addresses do not depend on x).  The chain is T'y + a hop only where the owner
+// changes; workgroup 0 ends with block 0, has seen every flag, and runs the camera-step epilogue.
+#define RSBA_BSM_BPG 3   // blocks per workgroup (96 columns)
+__global__ void __launch_bounds__(256)
+k_backsub_multi(int C, const double* __restrict__ red, RedLayout L, const double* __restrict__ F, double* __restrict__ xsol,
+                const double* __restrict__ scale_c, const double* __restrict__ cam_x, double* __restrict__ cam_c,
+                const double* __restrict__ intr, double* __restrict__ camc_c, double* __restrict__ dcam,
+                const double* __restrict__ gmax_p, double* __restrict__ res, const int* __restrict__ ok_flag,
+                const double* __restrict__ cam_free, int* __restrict__ xdone, int* __restrict__ error, int tag) {
+  __shared__ double yown[32 * RSBA_BSM_BPG];       // this workgroup's columns of y
+  __shared__ double Tb[RSBA_BSM_BPG][RSBA_PB * RSBA_PLD];   // T of this workgroup's own blocks, loaded before the chain arrives
+  __shared__ double xb[RSBA_PB];
+  __shared__ double part[2][128];
+  __shared__ double epi[4 * 256];
+  const int n = L.nc, tid = threadIdx.x, w = blockIdx.x;
+  const int m = (n + RSBA_PB - 1) / RSBA_PB * RSBA_PB, nblk = m / RSBA_PB;
+  const int cw = 32 * RSBA_BSM_BPG, col0 = w * cw;          // own columns [col0, col0 + cw)
+  const int q = tid & 127, hp = tid >> 7;                   // column (q < cw) and half of the block's 32 rows
+  const long long budget = RSBA_STALL_TICKS;
+  for (int i = tid; i < cw; i += 256) yown[i] = col0 + i < n ? F[(size_t)n * n + col0 + i] : 0.0;
+  // T_b (r >= c): stored at F[kb + c][kb + r] for r > c, the diagonal in row n + 1; identity on the padding
+  for (int e = tid; e < RSBA_BSM_BPG * RSBA_PB * RSBA_PB; e += 256) {
+    const int j = e >> 10, r = (e >> 5) & 31, c = e & 31, kb = col0 + 32 * j;
+    Tb[j][r * RSBA_PLD + c] = (kb + r < n && kb + c < n) ? (r > c ? F[(size_t)(kb + c) * n + kb + r] : (r == c ? F[(size_t)(n + 1) * n + kb + c] : 0.0))
+                                                         : (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  // strip part of block b for this thread: L[32 b + 16 hp + c][col0 + q], c < 16 (zero outside the real lower triangle)
+  auto load_strip = [&](int b, double (&d)[16]) {
+    const int gq = col0 + q;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int gi = 32 * b + 16 * hp + c;
+      d[c] = (b >= 0 && q < cw && gq < 32 * b && gq < n && gi < n) ? F[(size_t)gi * n + gq] : 0.0;
+    }
+  };
+  const int btop = nblk - 1;
+  // the strips of the next three blocks are in flight: an iteration is ~1 us, a load from memory 2-3 us
+  double lv[16], l1[16], l2[16], l3[16];
+  load_strip(btop, lv); load_strip(btop - 1, l1); load_strip(btop - 2, l2);
+  bool stalled = false;
+  int pending = -1;   // a block of this workgroup whose x is stored but not flagged yet
+  // wave 0 stored x with agent-scope stores; the flag follows once they are performed — not right after the stores (that
+  // wait is a memory round trip on the owner's own chain) but one block later, behind the update
+  auto publish_pending = [&]() {
+    if (pending >= 0 && tid < 64) {
+      __builtin_amdgcn_s_waitcnt(0);
+      if (tid == 0) __hip_atomic_store(xdone + pending, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    pending = -1;
+  };
+  __shared__ double xg[32 * RSBA_BSM_BPG];   // the x of another workgroup's three blocks, fetched at once
+  for (int b = btop; b >= w * RSBA_BSM_BPG && !stalled; --b) {   // blocks below this workgroup's columns do not touch them
+    const int owner = b / RSBA_BSM_BPG, kb = 32 * b;
+    load_strip(b - 3, l3);
+    publish_pending();
+    if (w == owner) {
+      if (tid < RSBA_PB) {
+        const double* Tj = Tb[b - owner * RSBA_BSM_BPG];
+        double sacc = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < RSBA_PB; ++i) sacc += Tj[i * RSBA_PLD + tid] * yown[kb - col0 + i];
+        xb[tid] = sacc;
+        if (kb + tid < n) StoreShared(&xsol[kb + tid], sacc);
+      }
+      pending = b;
+      __syncthreads();
+    } else {
+      // another workgroup's blocks: one wait and one fetch for its whole range (its flags come in descending block order:
+      // the lowest one says all three are there) — a wait and a round trip per block made the low workgroups, which see
+      // every block, the slowest part of the chain
+      const int bl = owner * RSBA_BSM_BPG;                         // the owner's lowest block
+      if (b == min(btop, bl + RSBA_BSM_BPG - 1)) {
+        if (!WaitFlagWG(xdone + bl, tag, error, budget)) { stalled = true; break; }
+        if (tid < 32 * RSBA_BSM_BPG) xg[tid] = 32 * bl + tid < n ? xsol[32 * bl + tid] : 0.0;
+        __syncthreads();
+      }
+      if (tid < RSBA_PB) xb[tid] = xg[kb - 32 * bl + tid];
+      __syncthreads();
+    }
+    // y[own columns < kb] -= L[block b rows, column]' x_b, the two halves of the rows added in a fixed order
+    {
+      double sacc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) sacc += lv[c] * xb[16 * hp + c];
+      if (q < 128) part[hp][q] = sacc;
+    }
+    __syncthreads();
+    if (tid < cw && col0 + tid < kb) yown[tid] -= part[0][tid] + part[1][tid];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { lv[c] = l1[c]; l1[c] = l2[c]; l2[c] = l3[c]; }
+    __syncthreads();
+  }
+  publish_pending();
+  if (stalled) { if (tid == 0) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 1.0; } return; }
+  if (w != 0) return;
+  // workgroup 0: every block's x is in xsol and visible (it waited for, or produced, each of them)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  int ok = 1;
+  if (tid == 0) ok = __hip_atomic_load(ok_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  CameraStepEpilogue(C, red, L, scale_c, xsol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, ok, epi, cam_free);
+}
+
 }  // namespace rsba

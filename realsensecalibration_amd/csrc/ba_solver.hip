@@ -561,7 +561,7 @@ static int UploadPoints(rsba_solver* s) {
         const int m = MultiCholPadded(s->nc), nrt = (m + 1 + 63) / 64, ntiles = nrt * (nrt + 1) / 2;
         if (ntiles <= 2 * prop.multiProcessorCount) {
           s->tc_np = m / RSBA_PB; s->tc_nrt = nrt; s->tc_tiles = ntiles;
-          const size_t nflags = (size_t)s->tc_np * (nrt + 1) + 1;
+          const size_t nflags = (size_t)s->tc_np * (nrt + 2) + 1;   // tdone | xdone | error | xdone of the back-substitution
           if ((rc = DevAlloc(&s->tc_flags, nflags))) return rc;
           HIPCHK(hipMemset(s->tc_flags, 0, nflags * sizeof(int)));
           HIPCHK(hipFuncSetAttribute((const void*)k_chol_tiles_persistent, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -786,11 +786,21 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     }
     T.End(st);
     }
+    if (s->tc_tiles > 0 && !(getenv("RSBA_BACKSUB_MULTI") && atoi(getenv("RSBA_BACKSUB_MULTI")) == 0)) {
+      // block back-substitution on several workgroups (three 32-column blocks each); x goes to row n of W (free by now)
+      const int nblk = s->tc_np, G = (nblk + RSBA_BSM_BPG - 1) / RSBA_BSM_BPG;
+      int* fl = s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1);   // [error | xdone ...]
+      T.Begin("k_backsub_multi", st);
+      k_backsub_multi<<<G, 256, 0, st>>>(C, s->red, s->L, s->A, s->W + (size_t)n * n, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam,
+                                         s->gmax, s->res, s->chol_ok, s->cam_free, fl + 1, fl, s->step_tag);
+      T.End(st);
+    } else {
     const size_t lds_f = std::max((size_t)4 * 1024, (size_t)((n + 63) & ~63) + 3 * RSBA_PB * RSBA_PLD + 64) * sizeof(double);
     T.Begin("k_chol_finish", st);
     k_chol_finish<<<1, 1024, lds_f, st>>>(C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res,
                                           s->chol_ok, s->cam_free);
     T.End(st);
+    }
   }
   DebugSync(st, "k_reduced_system_solve");
   T.Begin("k_backsub_candidate", st);
