@@ -68,7 +68,7 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
     return W[(size_t)gi * n + gj];
   };
   for (int e = tid; e < 64 * 64; e += 256) { const int r = e >> 6, c = e & 63; Tl[r * RSBA_TL + c] = sysv(r0 + r, c0 + c); }
-  if (t == 0 && tid == 0) __hip_atomic_store(ok_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t == 0 && tid == 0) { __hip_atomic_store(ok_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 0.0; }   // (a stall, half a second later, sets it)
   __syncthreads();
   // store a value of L / y into F (real entries only; the rhs row m lands in row n)
   auto storeF = [&](int gi, int gj, double v) {

@@ -504,6 +504,8 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
       (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)))
     return rc;
+  HIPCHK(hipMemset(s->res, 0, RES_SIZE * sizeof(double)));   // (not every path writes every field: RES_STALL above 64 cameras)
+  HIPCHK(hipMemset(s->small_red, 0, 8 * sizeof(double)));
   HIPCHK(hipMemset(s->chol_ok, 0, 3 * sizeof(int)));   // [0] Cholesky status, [1] arrival counter of the back-substitution's blocks, [2] its wait timed out
   HIPCHK(hipMemcpy(s->obs_u, u.data(), N * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->obs_v, v.data(), N * sizeof(double), hipMemcpyHostToDevice));
