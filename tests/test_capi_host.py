@@ -84,6 +84,23 @@ def test_synthetic_marker_chain_is_consistent(oracle):
     assert np.all(p["params"][:6] == 0) and np.all(p["params"][6 * 34:6 * 35] == 0)
 
 
+def test_set_camera_constant_argument_checks():
+    """Problem::SetParameterBlockConstant mirror: point model only, camera index checked (no GPU needed)."""
+    from realsensecalibration_amd import synthetic as syn
+    p = capi.Problem.points(syn.make_problem(3, 20, 3, seed=1))
+    p.set_camera_constant(0)
+    p.set_camera_constant(2, False)
+    for bad in (-1, 3):
+        with pytest.raises(capi.RsbaError):
+            p.set_camera_constant(bad)
+    p.close()
+    intr = ol.read_intrinsics(ol.SERIALS_MAIN)
+    m = capi.Problem.correspondence(os.path.join(G, "hongo", "correspondence.txt"), capi.MODEL_MARKER_CHAIN, ol.MARKER_SIDE_MAIN, intr)
+    with pytest.raises(capi.RsbaError):
+        m.set_camera_constant(1)      # the marker-chain wiring fixes camera 0 / marker 0 itself
+    m.close()
+
+
 def test_intrinsics_xml_reader():
     for sn, ref in zip(ol.SERIALS_MAIN, ol.read_intrinsics(ol.SERIALS_MAIN)):
         assert np.array_equal(capi.read_intrinsics_xml(os.path.join(G, "intrinsics", sn + ".xml")), ref)
