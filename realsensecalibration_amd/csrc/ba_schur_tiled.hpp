@@ -200,6 +200,10 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
 // K_A2: pair kernel.  One workgroup per (tile, segment of chunks); thread (ia, ib) owns camera pair
 // (16 ga + ia, 16 gb + ib).  LDS: point data of the current chunk + the 32 visibility bit-rows.
 // ------------------------------------------------------------------------------------------------
+// acc + a b + c d as two dependent FMAs.  (`acc += a * b + c * d` is three instructions — the sum of products is rounded
+// on its own before it is added — and the elimination kernel is bound by the number of fp64 instructions it issues.)
+__device__ __forceinline__ double Fma2(double a, double b, double c, double d, double acc) { return fma(c, d, fma(a, b, acc)); }
+
 struct SideConst {
   double R[9], t[3], fx, fy;
   bool small;
@@ -592,7 +596,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
         for (int q = 0; q < 6; ++q) {
           if (q == 3) acc[6 * p + q] += z0 * eb0[3];
           else if (q == 4) acc[6 * p + q] += z1 * eb1[4];
-          else acc[6 * p + q] += z0 * eb0[q] + z1 * eb1[q];
+          else acc[6 * p + q] = Fma2(z0, eb0[q], z1, eb1[q], acc[6 * p + q]);
         }
       }
     }
@@ -692,18 +696,32 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
       int t = 0;
 #pragma unroll
       for (int p = 0; p < 6; ++p) {
-        const double z0 = e0[p] * m00 + e1[p] * m01, z1 = e0[p] * m01 + e1[p] * m11;
+        // e0[4] and e1[3] are structural zeros (see SideRows): one product instead of two wherever they enter
+        double z0, z1;
+        if (p == 3) { z0 = e0[3] * m00; z1 = e0[3] * m01; }
+        else if (p == 4) { z0 = e1[4] * m01; z1 = e1[4] * m11; }
+        else { z0 = e0[p] * m00 + e1[p] * m01; z1 = e0[p] * m01 + e1[p] * m11; }
 #pragma unroll
-        for (int q = p; q < 6; ++q) { acc[t] += z0 * e0[q] + z1 * e1[q]; ++t; }
+        for (int q = p; q < 6; ++q) {
+          if (q == 3) acc[t] = fma(z0, e0[3], acc[t]);
+          else if (q == 4) acc[t] = fma(z1, e1[4], acc[t]);
+          else acc[t] = Fma2(z0, e0[q], z1, e1[q], acc[t]);
+          ++t;
+        }
       }
       // E'E: top-left 3x3 (upper) and diagonal 3..5
-      acc[21] += e0[0] * e0[0] + e1[0] * e1[0]; acc[22] += e0[0] * e0[1] + e1[0] * e1[1]; acc[23] += e0[0] * e0[2] + e1[0] * e1[2];
-      acc[24] += e0[1] * e0[1] + e1[1] * e1[1]; acc[25] += e0[1] * e0[2] + e1[1] * e1[2]; acc[26] += e0[2] * e0[2] + e1[2] * e1[2];
-      acc[27] += e0[3] * e0[3] + e1[3] * e1[3]; acc[28] += e0[4] * e0[4] + e1[4] * e1[4]; acc[29] += e0[5] * e0[5] + e1[5] * e1[5];
+      acc[21] = Fma2(e0[0], e0[0], e1[0], e1[0], acc[21]); acc[22] = Fma2(e0[0], e0[1], e1[0], e1[1], acc[22]); acc[23] = Fma2(e0[0], e0[2], e1[0], e1[2], acc[23]);
+      acc[24] = Fma2(e0[1], e0[1], e1[1], e1[1], acc[24]); acc[25] = Fma2(e0[1], e0[2], e1[1], e1[2], acc[25]); acc[26] = Fma2(e0[2], e0[2], e1[2], e1[2], acc[26]);
+      // e1[3] and e0[4] are structural zeros
+      acc[27] = fma(e0[3], e0[3], acc[27]); acc[28] = fma(e1[4], e1[4], acc[28]); acc[29] = Fma2(e0[5], e0[5], e1[5], e1[5], acc[29]);
       const double f0 = n0[0] * pd[9] + n0[1] * pd[10] + n0[2] * pd[11];
       const double f1 = n1[0] * pd[9] + n1[1] * pd[10] + n1[2] * pd[11];
 #pragma unroll
-      for (int p = 0; p < 6; ++p) { acc[30 + p] += e0[p] * r0 + e1[p] * r1; acc[36 + p] += e0[p] * f0 + e1[p] * f1; }
+      for (int p = 0; p < 6; ++p) {
+        if (p == 3) { acc[33] = fma(e0[3], r0, acc[33]); acc[39] = fma(e0[3], f0, acc[39]); }
+        else if (p == 4) { acc[34] = fma(e1[4], r1, acc[34]); acc[40] = fma(e1[4], f1, acc[40]); }
+        else { acc[30 + p] = Fma2(e0[p], r0, e1[p], r1, acc[30 + p]); acc[36 + p] = Fma2(e0[p], f0, e1[p], f1, acc[36 + p]); }
+      }
     }
   }
   double* out = partial + (size_t)seg_index * RSBA_PART * 256;
