@@ -32,6 +32,7 @@
 // observation (point side only), forms the damped inverse point blocks and writes the 12 doubles per point the
 // Schur kernel stages.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <vector>
@@ -204,6 +205,14 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
 // on its own before it is added — and the elimination kernel is bound by the number of fp64 instructions it issues.)
 __device__ __forceinline__ double Fma2(double a, double b, double c, double d, double acc) { return fma(c, d, fma(a, b, acc)); }
 
+// 1 / x for the depth of a point in a camera: v_rcp_f64 and two Newton steps, five instructions where the IEEE division
+// sequence (scale, rcp, two Newton steps, quotient, residual, fmas, fixup) is eleven; within an ulp or two of it.
+__device__ __forceinline__ double RcpNewton(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+
 struct SideConst {
   double R[9], t[3], fx, fy;
   bool small;
@@ -224,7 +233,7 @@ __device__ __forceinline__ void SideRows(const SideConst& s, const double X[3], 
   const double q1 = s.R[3] * X[0] + s.R[4] * X[1] + s.R[5] * X[2];
   const double q2 = s.R[6] * X[0] + s.R[7] * X[1] + s.R[8] * X[2];
   const double p0 = q0 + s.t[0], p1 = q1 + s.t[1], p2 = q2 + s.t[2];
-  const double iz = 1.0 / p2;
+  const double iz = RcpNewton(p2);
   const double al = s.fx * iz * sq, be = s.fy * iz * sq;   // sqrt(rho') scales every Jacobian entry of the observation
   const double ga = -al * p0 * iz, de = -be * p1 * iz;
   const double w0 = s.small ? X[0] : q0, w1 = s.small ? X[1] : q1, w2 = s.small ? X[2] : q2;
@@ -243,6 +252,7 @@ struct SideLds {
 };
 
 // Reduced Jacobian rows from LDS-resident camera constants (same arithmetic as SideRows).
+template <bool kSmall>
 __device__ __forceinline__ void SideRowsLds(const double* __restrict__ c, const double X[3], double sq, double e0[6], double e1[6],
                                             double n0[3], double n1[3]) {
   const double r0 = c[0], r1 = c[1], r2 = c[2], r3 = c[3], r4 = c[4], r5 = c[5], r6 = c[6], r7 = c[7], r8 = c[8];
@@ -250,10 +260,10 @@ __device__ __forceinline__ void SideRowsLds(const double* __restrict__ c, const 
   const double q1 = r3 * X[0] + r4 * X[1] + r5 * X[2];
   const double q2 = r6 * X[0] + r7 * X[1] + r8 * X[2];
   const double p0 = q0 + c[9], p1 = q1 + c[10], p2 = q2 + c[11];
-  const double iz = 1.0 / p2;
+  const double iz = RcpNewton(p2);
   const double al = c[12] * iz * sq, be = c[13] * iz * sq;
   const double ga = -al * p0 * iz, de = -be * p1 * iz;
-  const bool small = c[14] != 0.0;
+  const bool small = kSmall && c[14] != 0.0;   // kSmall false: no camera of the tile takes the small-angle branch
   const double w0 = small ? X[0] : q0, w1 = small ? X[1] : q1, w2 = small ? X[2] : q2;
   e0[0] = w1 * ga; e0[1] = w2 * al - w0 * ga; e0[2] = -w1 * al; e0[3] = al; e0[4] = 0.0; e0[5] = ga;
   e1[0] = w1 * de - w2 * be; e1[1] = -w0 * de; e1[2] = w0 * be; e1[3] = 0.0; e1[4] = be; e1[5] = de;
@@ -508,7 +518,7 @@ struct SchurArgs {
   long long* wg_trace;  // diagnostic (RSBA_TRACE=2): start / end / compute-end stamp of every block
 };
 
-template <bool kLoss>
+template <bool kLoss, bool kSmall>
 __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& sg, int seg_index, int ticket, double* pt, unsigned long long (*mk)[RSBA_CW], double* sc) {
   const int C = a.C, P = a.P, nwords = a.nwords;
   const double* __restrict__ camc = a.camc;
@@ -576,12 +586,12 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
         sqb = sq_cm[cam_ptr[cam_b] + cam_prefix[(size_t)cam_b * nwords + gw] + __popcll(mk[RSBA_TG + ib][wcur] & below)];
       }
       double ea0[6], ea1[6], na0[3], na1[3];
-      SideRowsLds(ca, X, sqa, ea0, ea1, na0, na1);
+      SideRowsLds<kSmall>(ca, X, sqa, ea0, ea1, na0, na1);
       // t = Na Vinv (2x3), then the b side, M = t Nb' (2x2), Z = Ea' M (6x2)
       const double t00 = na0[0] * v0 + na0[1] * v1 + na0[2] * v2, t01 = na0[0] * v1 + na0[1] * v3 + na0[2] * v4, t02 = na0[0] * v2 + na0[1] * v4 + na0[2] * v5;
       const double t10 = na1[0] * v0 + na1[1] * v1 + na1[2] * v2, t11 = na1[0] * v1 + na1[1] * v3 + na1[2] * v4, t12 = na1[0] * v2 + na1[1] * v4 + na1[2] * v5;
       double eb0[6], eb1[6], nb0[3], nb1[3];
-      SideRowsLds(cb, X, sqb, eb0, eb1, nb0, nb1);
+      SideRowsLds<kSmall>(cb, X, sqb, eb0, eb1, nb0, nb1);
       const double m00 = t00 * nb0[0] + t01 * nb0[1] + t02 * nb0[2], m01 = t00 * nb1[0] + t01 * nb1[1] + t02 * nb1[2];
       const double m10 = t10 * nb0[0] + t11 * nb0[1] + t12 * nb0[2], m11 = t10 * nb1[0] + t11 * nb1[1] + t12 * nb1[2];
       // Z = Ea' M, acc += Z Eb.  Entries e0[4] and e1[3] are structural zeros ([A | Pj], Pj = [[al,0,ga],[0,be,de]]):
@@ -685,7 +695,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
       const double q0 = A.R[0] * X[0] + A.R[1] * X[1] + A.R[2] * X[2] + A.t[0];
       const double q1 = A.R[3] * X[0] + A.R[4] * X[1] + A.R[5] * X[2] + A.t[1];
       const double q2 = A.R[6] * X[0] + A.R[7] * X[1] + A.R[8] * X[2] + A.t[2];
-      const double iz = 1.0 / q2;
+      const double iz = RcpNewton(q2);
       const double r0 = (A.fx * q0 * iz + ppx - uu) * sqa, r1 = (A.fy * q1 * iz + ppy - vv) * sqa;
       // M' = I - N Vinv N'  (2x2 symmetric)
       const double t00 = n0[0] * v0 + n0[1] * v1 + n0[2] * v2, t01 = n0[0] * v1 + n0[1] * v3 + n0[2] * v4, t02 = n0[0] * v2 + n0[1] * v4 + n0[2] * v5;
@@ -839,7 +849,15 @@ k_schur_tiles(SchurArgs a) {
   if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b] = wall_clock64();
   if (sg.self >= 2) ReducerSegment(a, sg, b);
   else if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, b, pt, mk);
-  else PairSegment<kLoss>(a, sg, seg_index, b, pt, mk, sc);
+  else {
+    // two instances of the pair tile: the small-angle selects of the Jacobian rows (12 instructions per hit) are compiled in
+    // only when one of the tile's 32 cameras takes that branch this iteration
+    const int t = threadIdx.x;
+    const int cam = t < RSBA_TG ? RSBA_TG * sg.ga + t : RSBA_TG * sg.gb + (t - RSBA_TG);
+    const int any_small = __syncthreads_or(t < 2 * RSBA_TG && cam < a.C && a.camc[(size_t)cam * CC_STRIDE + CC_SMALL] != 0.0);
+    if (any_small) PairSegment<kLoss, true>(a, sg, seg_index, b, pt, mk, sc);
+    else PairSegment<kLoss, false>(a, sg, seg_index, b, pt, mk, sc);
+  }
   if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b + 1] = wall_clock64();
 }
 

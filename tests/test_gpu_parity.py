@@ -293,6 +293,33 @@ def test_pipelined_solve_matches_oracle_and_sequential_schedule(oracle, C, P, k,
     assert np.array_equal(got, again) and np.array_equal(log, log2)
 
 
+def _in_the_frame_of_camera(prob, c0):
+    """The same problem expressed in camera c0's (initial) orientation: points X' = R0 X, rotations R' = R R0', so
+    camera c0's angle-axis vector is exactly zero — AngleAxisRotatePoint's first-order branch and its derivative
+    (in the reference that is camera 0 and every marker of the test2 fixture)."""
+    C = prob["C"]
+    out = dict(prob)
+    par = prob["params"].copy()
+    cams = par[:6 * C].reshape(C, 6)
+    R = syn._matrix_from_rotvec(cams[:, :3])
+    R0 = R[c0]
+    cams[:, :3] = syn._rotvec_from_matrix(R @ R0.T)
+    cams[c0, :3] = 0.0
+    par[6 * C:] = (par[6 * C:].reshape(-1, 3) @ R0.T).reshape(-1)
+    out["params"] = par
+    return out
+
+
+@pytest.mark.parametrize("C,P,k,c0,impl", [(8, 1500, 6, 0, 0), (8, 1500, 6, 5, 1), (24, 2600, 8, 0, 1), (40, 3000, 9, 21, 1), (64, 3600, 12, 63, 1)])
+def test_camera_with_zero_rotation_takes_the_small_angle_branch(oracle, C, P, k, c0, impl):
+    """A camera whose angle-axis vector is exactly zero is linearised with the first-order rotation; the tiled Schur
+    kernel compiles that select into a second instance of its pair tiles, taken only by the tiles that hold such a
+    camera (with 24+ cameras both instances run in the same launch)."""
+    prob = _in_the_frame_of_camera(syn.make_problem(C, P, k, seed=900 + C), c0)
+    assert np.all(prob["params"][6 * c0:6 * c0 + 3] == 0.0)
+    _compare_solve(oracle, prob, impl)
+
+
 @pytest.mark.parametrize("who", ["1", "2"])
 def test_pipeline_stall_falls_back_to_sequential_schedule(oracle, capfd, who):
     """RSBA_TEST_STALL=1 makes the waiting Cholesky look for a tag nobody publishes: it must give up after its 0.5 s
