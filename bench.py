@@ -36,7 +36,7 @@ FP64_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz; vector and
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50, help="timed LM iterations (50 = Ceres' max_num_iterations default, SURVEY 8d)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg3", help="cfg2 | cfg3 (default; the metric's config) | cfg5-like via --points")
     ap.add_argument("--points", type=int, default=None, help="points per rank (default: the config's)")
@@ -108,12 +108,14 @@ def main():
     # negative tolerances: no convergence test can fire (0 would still stop on a bitwise-equal candidate cost)
     fixed = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
                  max_num_consecutive_invalid_steps=1 << 30, min_trust_region_radius=0.0)
-    sv_w = capi.Solver(problem, options(max_num_iterations=max(args.warmup, 1), **fixed))
-    sv_w.run()
-    sv_w.close()
-    # timed pass: HIP events only around the two kernels the roofline is quoted on (4 records per iteration); the full
+    # W warm-up iterations on the solver that is timed (same device buffers, same streams), then its options are set for
+    # the timed run: HIP events only around the kernel the roofline is quoted on (on every fourth step); the full
     # per-kernel table comes from an identical K-step pass right after it, outside the timed region
-    sv_k = capi.Solver(problem, options(max_num_iterations=args.steps, profile_kernels=0 if args.no_events else 2, **fixed))
+    sv_k = capi.Solver(problem, options(max_num_iterations=max(args.warmup, 1), **fixed))
+    if args.warmup > 0:
+        s_w = sv_k.run()
+        assert s_w.num_iterations == args.warmup, (s_w.num_iterations, args.warmup)
+    sv_k.configure_run(args.steps, 0 if args.no_events else 2)
 
     def sync():
         torch.cuda.synchronize()

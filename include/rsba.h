@@ -216,6 +216,10 @@ int rsba_solve(rsba_problem* p, const rsba_options* o, rsba_summary* summary);
 int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out);
 int rsba_solver_run(rsba_solver* s, rsba_summary* summary); /* LM loop; restarts from the uploaded state */
 int rsba_solver_download(rsba_solver* s);                    /* device state -> problem parameters */
+/* ceres::Solve takes its Solver::Options per call (bundle_adjustment_manager.cpp:90-94): the next rsba_solver_run of this
+ * solver stops after max_num_iterations and records kernel times as profile_kernels says (rsba_options); the kernel
+ * statistics collected so far are dropped.  bench.py warms a solver up with W iterations, then times K on the same one. */
+int rsba_solver_configure_run(rsba_solver* s, int32_t max_num_iterations, int32_t profile_kernels);
 int rsba_solver_iterations(const rsba_solver* s, rsba_iteration* out, int32_t capacity); /* rows written */
 int rsba_solver_kernel_stats(const rsba_solver* s, rsba_kernel_stat* out, int32_t capacity);
 /* final 1/2 sum rho and sum of squared raw residuals of the last run (all ranks' total) */

@@ -25,7 +25,7 @@ EXPORTS = [
     "rsba_solver_destroy", "rsba_points_linearize_and_step", "rsba_points_linearize_payload", "rsba_comm_unique_id", "rsba_read_intrinsics_xml",
     "rsba_write_outputs", "rsba_reprojection_error", "rsba_reprojection_check_files",
     "rsba_base_pose_from_marker_detection", "rsba_marker_pose_in_camera", "rsba_marker_corners_in_camera", "rsba_solve_pnp_epnp",
-    "rsba_problem_initial_camera_poses", "rsba_problem_set_camera_constant", "rsba_solver_full_report",
+    "rsba_problem_initial_camera_poses", "rsba_problem_set_camera_constant", "rsba_solver_full_report", "rsba_solver_configure_run",
 ]
 
 
@@ -108,6 +108,7 @@ def load():
     lib.rsba_solver_iterations.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.rsba_solver_kernel_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.rsba_solver_full_report.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    lib.rsba_solver_configure_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.rsba_solver_final_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rsba_solver_destroy.argtypes = [C.c_void_p]
     lib.rsba_points_linearize_and_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 4
@@ -259,6 +260,10 @@ class Solver:
         s = Summary()
         _chk(load().rsba_solver_run(self.h, C.byref(s)), "rsba_solver_run")
         return s
+
+    def configure_run(self, max_num_iterations, profile_kernels=0):
+        """Options of the next run() of this solver (ceres::Solve takes them per call); drops the kernel statistics."""
+        _chk(load().rsba_solver_configure_run(self.h, int(max_num_iterations), int(profile_kernels)), "rsba_solver_configure_run")
 
     def download(self):
         _chk(load().rsba_solver_download(self.h), "rsba_solver_download")

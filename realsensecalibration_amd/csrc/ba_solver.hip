@@ -65,7 +65,9 @@ class KernelTimer {
  public:
   // mode 0: off, 1: every kernel, 2: only the two kernels the roofline is quoted on, and only every fourth LM step (the
   // host-side cost of the event records sits on the critical path between two launches: ~40 us per step when every
-  // step was recorded, 5% of the step).  Events come from a pool: creating one per record costs more than recording it.
+  // step was recorded, 5% of the step).  Events come from a pool: creating one per record costs more than recording it;
+  // they are timing-only (hipEventDisableSystemFence): a default event writes back and invalidates the caches when it
+  // completes, between two kernels of the iteration that was measured at ~40 us per recorded kernel.
   void Enable(int mode) { mode_ = mode; on_ = false; }
   bool enabled() const { return mode_ != 0 && sampled_; }
   bool all_kernels() const { return mode_ == 1; }   // the kernels that wait inside (solve, back-substitution) are only timed then
@@ -91,7 +93,7 @@ class KernelTimer {
   }
   void Add(const char* name, double ms) { auto& st = stats_[name]; st.first += 1; st.second += ms; }
   void Reset() { Collect(); stats_.clear(); for (hipEvent_t e : pool_) (void)hipEventDestroy(e); pool_.clear(); }
-  void Reserve(int n) { while ((int)pool_.size() < n) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; pool_.push_back(e); } }
+  void Reserve(int n) { while ((int)pool_.size() < n) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) break; pool_.push_back(e); } }
   const std::map<std::string, std::pair<int64_t, double>>& stats() const { return stats_; }
  private:
   hipEvent_t Get() {
@@ -1117,6 +1119,17 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
   s->last_summary = sum; s->has_run = true;
   if (sum_out) *sum_out = sum;
   return rc;
+}
+
+int rsba_solver_configure_run(rsba_solver* s, int32_t max_num_iterations, int32_t profile_kernels) {
+  if (!s || max_num_iterations < 0 || profile_kernels < 0 || profile_kernels > 2) return RSBA_ERR_ARG;
+  if (hipSetDevice(s->device) != hipSuccess) return RSBA_ERR_HIP;
+  s->opt.max_num_iterations = max_num_iterations;
+  s->opt.profile_kernels = profile_kernels;
+  s->timer.Reset();
+  s->timer.Enable(profile_kernels);
+  if (profile_kernels) s->timer.Reserve(256);
+  return RSBA_OK;
 }
 
 int rsba_solver_download(rsba_solver* s) {

@@ -101,6 +101,12 @@ def test_set_camera_constant_argument_checks():
     m.close()
 
 
+def test_configure_run_rejects_a_null_solver():
+    """rsba_solver_configure_run (per-run Solver::Options): argument check only, no GPU needed."""
+    lib = capi.load()
+    assert lib.rsba_solver_configure_run(None, 10, 0) == capi.ERR_ARG
+
+
 def test_intrinsics_xml_reader():
     for sn, ref in zip(ol.SERIALS_MAIN, ol.read_intrinsics(ol.SERIALS_MAIN)):
         assert np.array_equal(capi.read_intrinsics_xml(os.path.join(G, "intrinsics", sn + ".xml")), ref)

@@ -249,6 +249,30 @@ def test_rccl_collective_path_single_rank(oracle):
     assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
 
 
+def test_configure_run_changes_the_next_run_only():
+    """rsba_solver_configure_run: the same solver stopped after 2 iterations, then run for 5, gives what a fresh solver
+    with max_num_iterations = 5 gives, bit for bit (a run restarts from the uploaded state); bad arguments are refused."""
+    prob = syn.make_problem(24, 2500, 8, seed=77)
+    problem = capi.Problem.points(prob)
+    fixed = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0)
+    sv = capi.Solver(problem, capi.default_options(max_num_iterations=2, **fixed))
+    assert sv.run().num_iterations == 2
+    sv.configure_run(5, 2)
+    s5 = sv.run()
+    log5 = sv.iterations()
+    assert "k_schur_tiles" in sv.kernel_stats()
+    for bad in ((-1, 0), (3, 7)):
+        with pytest.raises(capi.RsbaError):
+            sv.configure_run(*bad)
+    sv.close()
+    fresh = capi.Solver(problem, capi.default_options(max_num_iterations=5, **fixed))
+    f5 = fresh.run()
+    assert s5.num_iterations == f5.num_iterations == 5 and s5.final_cost == f5.final_cost
+    assert np.array_equal(log5, fresh.iterations())
+    fresh.close()
+    problem.close()
+
+
 def test_solve_is_bitwise_reproducible():
     """The default path has no atomics: every reduction runs in a fixed order, so two solves of the same problem
     give bit-identical parameters and iteration logs (and every rank of a multi-GPU run factors identical bits)."""

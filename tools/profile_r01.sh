@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 rm -rf gpurun_out/prof_kt gpurun_out/prof_pmc_*
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/prof_kt.json 2> gpurun_out/prof_kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_kt.json 2> gpurun_out/prof_kt.err
 export RSBA_PIPELINE=0
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_pmc_fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/prof_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_pmc_write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/prof_pmc_write.err
