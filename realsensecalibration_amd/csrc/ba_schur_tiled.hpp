@@ -665,7 +665,8 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
 //   [30,36) E' r                                           (-> g_c)
 //   [36,42) E' N V^-1 g_p                                  (-> -corr)
 template <bool kLoss>
-__device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& sg, int seg_index, int ticket, double* pt, unsigned long long (*mk)[RSBA_CW]) {
+__device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& sg, int seg_index, int ticket, double* pt, unsigned long long (*mk)[RSBA_CW],
+                                            unsigned short (*lst)[RSBA_CHUNK], int* cnt) {
   const int C = a.C, P = a.P, nwords = a.nwords;
   const double* __restrict__ camc = a.camc;
   const unsigned long long* __restrict__ cam_mask = a.cam_mask;
@@ -679,7 +680,6 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   const int tid = threadIdx.x, ia = tid >> 4, ib = tid & 15;
   const int cam_a = RSBA_TG * sg.ga + ia;
   const bool live = cam_a < C;
-  const unsigned long long lane_bits = 0x0001000100010001ull << ib;
   const double* cca = camc + (size_t)(live ? cam_a : 0) * CC_STRIDE;
   SideConst A;
   LoadSide(cca, A);
@@ -700,20 +700,36 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
       mk[row][w] = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
     }
     __syncthreads();
-    int w = 0;
-    unsigned long long h = live ? (mk[ia][0] & lane_bits) : 0ull;
-    if (live) { while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & lane_bits; } }
+    // The camera's points of this chunk as a list, dealt to its 16 lanes BY RANK (lane s takes entries s, s + 16, ...): every
+    // lane of a camera gets the same number of hits to within one (dealing by bit position left the lanes of a wave at 62 %
+    // utilisation: max over 64 lanes of a Binomial(128, 0.3) against its mean), the rank of a point in the camera's own
+    // observation list is the list index, and u / v / sqrt(rho') are read from consecutive addresses by consecutive lanes.
+    // Thread (row, j) expands half a mask word: 16 threads per camera.
+    {
+      const int row = tid >> 4, j = tid & 15, w = j >> 1, half = j & 1;
+      int base = 0;
+#pragma unroll
+      for (int x = 0; x < RSBA_CW; ++x) base += x < w ? __popcll(mk[row][x]) : 0;
+      const unsigned long long m = mk[row][w];
+      unsigned int my = half ? (unsigned int)(m >> 32) : (unsigned int)m;
+      if (half) base += __popc((unsigned int)m);
+      if (j == 15) cnt[row] = base + __popc(my);
+      const int p0 = w * 64 + half * 32;
+      while (my != 0u) {
+        const int b = __ffs((int)my) - 1;
+        my &= my - 1u;
+        lst[row][base++] = (unsigned short)(p0 + b);
+      }
+    }
+    __syncthreads();
+    const int n_a = live ? cnt[ia] : 0;
+    const int obs_chunk = live ? obs0 + cam_prefix[(size_t)cam_a * nwords + wb] : 0;
 #pragma unroll 1
-    while (h != 0ull) {
-      const int bit = __ffsll((long long)h) - 1;
-      const int wcur = w;
-      h &= h - 1;
-      while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & lane_bits; }
-      const double* pd = pt + (size_t)(wcur * 64 + bit) * RSBA_PT_STRIDE;
+    for (int i = ib; i < n_a; i += 16) {
+      const double* pd = pt + (size_t)lst[ia][i] * RSBA_PT_STRIDE;
       const double X[3] = {pd[0], pd[1], pd[2]};
       const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
-      // rank of this point in the camera's own observation list
-      const int oi = obs0 + cam_prefix[(size_t)cam_a * nwords + wb + wcur] + __popcll(mk[ia][wcur] & ((1ull << bit) - 1ull));
+      const int oi = obs_chunk + i;   // rank of this point in the camera's own observation list
       const double sqa = kLoss ? sq_cm[oi] : 1.0;
       const double uu = u_cm[oi], vv = v_cm[oi];
       double e0[6], e1[6], n0[3], n1[3];
@@ -859,6 +875,8 @@ k_schur_tiles(SchurArgs a) {
   __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];            // 48 KB
   __shared__ unsigned long long mk[2 * RSBA_TG][RSBA_CW];       // 2 KB
   __shared__ double sc[2 * RSBA_TG * RSBA_SC_STRIDE];           // 4 KB
+  __shared__ unsigned short lst[RSBA_TG][RSBA_CHUNK];           // 16 KB: self tiles, a camera's points of the chunk
+  __shared__ int cnt[RSBA_TG];
   // Work is handed out by ticket, not by block index: blocks are assigned to the 8 XCDs round-robin and each XCD
   // dispatches its own in order, so an XCD that is a little slower (the one that lends a CU to the Cholesky has 62 slots
   // instead of 64) starts the last blocks of a stage tens of microseconds late, and the stage ends with them.  With
@@ -876,7 +894,7 @@ k_schur_tiles(SchurArgs a) {
   if (a.trace && b == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
   if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b] = wall_clock64();
   if (sg.self >= 2) ReducerSegment(a, sg, b);
-  else if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, b, pt, mk);
+  else if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, b, pt, mk, lst, cnt);
   else {
     // two instances of the pair tile: the small-angle selects of the Jacobian rows (12 instructions per hit) are compiled in
     // only when one of the tile's 32 cameras takes that branch this iteration
