@@ -297,8 +297,9 @@ __device__ __forceinline__ void SideRowsUnscaledLds(const double* __restrict__ c
   d2[0] = al * al; d2[1] = be * be;
 }
 
-// The 120 pairs ia < ib of a diagonal tile, packed: lane t of waves 0/1 owns pair (kDiagIa[t], kDiagIb[t]); waves 2/3 of a
-// diagonal-tile workgroup retire right after the chunk is staged, so a diagonal tile costs two waves, not four.
+// The 120 pairs ia < ib of a diagonal tile, packed: lane t of waves 0/1 owns pair (kDiagPair[t] >> 4, kDiagPair[t] & 15); the
+// lanes of waves 2/3 of a diagonal-tile workgroup have empty hit lists (they only help staging), so a diagonal tile costs two
+// waves of arithmetic, not four.
 __device__ __constant__ unsigned char kDiagPair[128] = {
 #define RSBA_P(a, b) (unsigned char)((a) * 16 + (b))
     RSBA_P(0,1),RSBA_P(0,2),RSBA_P(0,3),RSBA_P(0,4),RSBA_P(0,5),RSBA_P(0,6),RSBA_P(0,7),RSBA_P(0,8),RSBA_P(0,9),RSBA_P(0,10),RSBA_P(0,11),RSBA_P(0,12),RSBA_P(0,13),RSBA_P(0,14),RSBA_P(0,15),
@@ -656,8 +657,8 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
 
 // Self tiles: everything that is a sum over ONE camera's observations — the diagonal block U_a - W V^-1 W' (a, a),
 // diag(U_a) for the LM damping, the camera gradient g_c and the Schur correction of the right-hand side.
-// Camera a sees ~3x the points a pair shares, so its points are dealt to 16 lanes: lane (ia, s) takes the bits
-// {s, s+16, s+32, s+48} of every mask word.  The residual needs this observation's pixel: u/v are kept in a second,
+// Camera a sees ~3x the points a pair shares, so its points are dealt to 16 lanes: lane (ia, s) takes the points of
+// rank s, s + 16, ... in the camera's list of the chunk (built in LDS, see below).  The residual needs this observation's pixel: u/v are kept in a second,
 // camera-major copy (u_cm, v_cm) addressed by the rank of the point in the camera's own list.
 // Per-lane sums (42, the K = J_l factor is applied by the tile's finisher, FinishSelfSlot):
 //   [0,21)  upper triangle of  E'(I - N V^-1 N')E   = core of  U_a - W V^-1 W'
