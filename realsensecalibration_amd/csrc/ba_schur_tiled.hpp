@@ -557,11 +557,16 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
   double* __restrict__ partial = a.partial;
   const int tid = threadIdx.x;
   const bool diag_tile = sg.ga == sg.gb;
-  // off-diagonal tile: lane = (ia, ib) directly; diagonal tile: the 120 pairs ia < ib sit in lanes 0..119
-  const int pr = diag_tile ? (tid < 120 ? kDiagPair[tid] : 0) : tid;
+  // off-diagonal tile: lane = (ia, ib) directly.  Diagonal tile: the 120 pairs ia < ib sit in lanes 0..119 of BOTH halves of
+  // the workgroup; waves 0/1 walk the even mask words of a chunk, waves 2/3 the odd ones, and the two partial blocks are
+  // added through LDS at the end of the entry (with the pairs in two waves only, a diagonal-tile entry held its slot as
+  // long as a full tile's for half the arithmetic).
+  const int dt = diag_tile ? (tid & 127) : tid;
+  const int pr = diag_tile ? (dt < 120 ? kDiagPair[dt] : 0) : tid;
   const int ia = pr >> 4, ib = pr & 15;
   const int cam_a = RSBA_TG * sg.ga + ia, cam_b = RSBA_TG * sg.gb + ib;
-  const bool live = cam_a < C && cam_b < C && (!diag_tile || tid < 120);
+  const bool live = cam_a < C && cam_b < C && (!diag_tile || dt < 120);
+  const int w0 = diag_tile ? (tid >> 7) : 0, wstep = diag_tile ? 2 : 1;
   for (int i = tid; i < 2 * RSBA_TG * RSBA_SC_STRIDE; i += 256) {
     const int row = i / RSBA_SC_STRIDE, e = i - row * RSBA_SC_STRIDE;
     const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
@@ -592,15 +597,15 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
     // runs max-over-lanes(hits in 512 points) trips, not the sum over words of the per-word maxima
     // one flat loop per lane: (w, h) is the lane's cursor into its hit list; the cursor advance is a tiny inner loop
     // that does not touch the accumulators
-    int w = 0;
-    unsigned long long h = live ? (mk[ia][0] & mk[RSBA_TG + ib][0]) : 0ull;
-    if (live) { while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & mk[RSBA_TG + ib][w]; } }
+    int w = w0;
+    unsigned long long h = live ? (mk[ia][w0] & mk[RSBA_TG + ib][w0]) : 0ull;
+    if (live) { while (h == 0ull && w + wstep < RSBA_CW) { w += wstep; h = mk[ia][w] & mk[RSBA_TG + ib][w]; } }
 #pragma unroll 1
     while (h != 0ull) {
       const int bit = __ffsll((long long)h) - 1;
       const int wcur = w;
       h &= h - 1;
-      while (h == 0ull && w < RSBA_CW - 1) { ++w; h = mk[ia][w] & mk[RSBA_TG + ib][w]; }
+      while (h == 0ull && w + wstep < RSBA_CW) { w += wstep; h = mk[ia][w] & mk[RSBA_TG + ib][w]; }
       const double* pd = pt + (size_t)(wcur * 64 + bit) * RSBA_PT_STRIDE;
       const double X[3] = {pd[0], pd[1], pd[2]};
       const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
@@ -638,6 +643,19 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
           else acc[6 * p + q] = Fma2(z0, eb0[qq], z1, eb1[qq], acc[6 * p + q]);
         }
       }
+    }
+  }
+  if (diag_tile) {
+    // odd-word half (waves 2/3) -> LDS -> even-word half; the point buffer is free once every lane has left the chunk loop
+    __syncthreads();
+    if (tid >= 128 && dt < 120) {
+#pragma unroll
+      for (int i = 0; i < 36; ++i) pt[i * 128 + dt] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 120) {
+#pragma unroll
+      for (int i = 0; i < 36; ++i) acc[i] += pt[i * 128 + tid];
     }
   }
   // slot of pair (ia, ib) in the workgroup's partial block is ia*16+ib whatever lane computed it
