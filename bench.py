@@ -219,12 +219,17 @@ def main():
         # dominant kernel = most CU-time: duration x share of the chip it occupies (the one-workgroup kernels hold 1 of
         # 256 CUs; the pipelined Cholesky runs beside k_schur_tiles on its reserved CU)
         one_wg = ("k_reduced_system_solve", "k_finish_candidate", "k_chol_finish", "k_publish_result", "k_finish_linearize")
-        order = sorted(stats.items(), key=lambda kv: -kv[1][1] * (1.0 / 256.0 if kv[0] in one_wg else 1.0))
+        # per ITERATION (average launch x launches per iteration): the timed region samples the roofline kernel on every
+        # fourth step only, so totals over the recorded launches are not comparable between kernels
+        def cu_time(kv):
+            n, (c, _) = kv
+            return per[n][1] * max(1.0, round(c / float(args.steps))) * (1.0 / 256.0 if n in one_wg else 1.0)
+        order = sorted(stats.items(), key=lambda kv: -cu_time(kv))
         out["roofline"] = roof(order[0][0])
         it_s = elapsed / args.steps
         out["roofline"]["iteration_hbm_view"] = {"algorithmic_bytes_per_iteration": b_iter, "achieved_GBps": b_iter / it_s / 1e9,
                                                  "frac_of_8TBps": b_iter / it_s / 1e9 / HBM_PEAK_GBS}
-        rest = sorted(order[1:], key=lambda kv: -kv[1][1])  # the others by plain duration
+        rest = sorted(order[1:], key=lambda kv: -per[kv[0]][1] * max(1.0, round(kv[1][0] / float(args.steps))))  # the others by plain duration per iteration
         out["roofline_other_kernels"] = [roof(n) for n, _ in rest[:3]]
         out["kernels"] = {n: {"launches": int(c), "avg_us": 1e3 * a, "measured": "timed region" if n in stats_timed else "repeat pass"}
                           for n, (c, a) in sorted(per.items())}
