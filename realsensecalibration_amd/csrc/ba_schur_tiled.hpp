@@ -73,6 +73,8 @@ struct TiledSchur {
   double* grp_sum = nullptr;                // [ngrp][42][256] sums of RSBA_GRP consecutive segments
   double* tile_sum = nullptr;               // [ntiles][42][256]
   int* tree_error = nullptr;
+  int* grp_flag = nullptr;                  // [ngrp] launch number of the latest complete group sum (reducers)
+  int epoch = 0;                            // launches so far
   int* sync_cnt = nullptr;                  // arrival counters, self-resetting: [ngrp] group members, [ntiles] groups done, [16] stage tiles, [ntiles] reducers done
   int nsync = 0, nblocks = 0;               // counters; blocks of the launch (segments + reducers)
   int* ready = nullptr;                     // ready[1 + g] = step tag once stage g (self tile g + pair tiles (g, g' >= g)) is in S
@@ -365,7 +367,7 @@ __device__ __forceinline__ void TreeSum(const double* __restrict__ in, int n, do
 // finishers, whose results are written with ordinary stores, write theirs back.
 template <int NV>
 __device__ __forceinline__ bool GroupReduce(const SchurSeg& sg, const double* __restrict__ partial, double* __restrict__ grp_sum,
-                                            int* __restrict__ sync_cnt, int ngrp, double* v) {
+                                            int* __restrict__ sync_cnt, int ngrp, double* v, int* __restrict__ grp_flag, int epoch) {
   __shared__ int s_last;
   const int tid = threadIdx.x;
   __builtin_amdgcn_s_waitcnt(0);
@@ -381,7 +383,10 @@ __device__ __forceinline__ bool GroupReduce(const SchurSeg& sg, const double* __
   if (tid == 0) __hip_atomic_store(&sync_cnt[sg.grp], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  if (tid == 0) s_last = __hip_atomic_fetch_add(&sync_cnt[ngrp + sg.tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.tile_ngrp - 1;
+  if (tid == 0) {
+    __hip_atomic_store(&grp_flag[sg.grp], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the group's sum is acknowledged (s_waitcnt above)
+    s_last = __hip_atomic_fetch_add(&sync_cnt[ngrp + sg.tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.tile_ngrp - 1;
+  }
   __syncthreads();
   // tiles of a few groups only (many cameras: 136 pair tiles at 256 cameras) have no reducers: the workgroup that
   // completes the last group adds the group sums itself
@@ -541,6 +546,8 @@ struct SchurArgs {
   double* __restrict__ tile_sum;   // [ntiles][42][256]
   int* tree_error;                 // set when a reducer gave up waiting (cannot happen; never hang)
   int* ticket;                     // next entry of the work list (block_seg)
+  int* grp_flag;                   // [ngrp] = epoch once the group's sum is in grp_sum (the reducers add groups as they arrive)
+  int epoch;                       // launch number, never 0
   long long* trace;   // diagnostic (RSBA_TRACE=1)
   long long* wg_trace;  // diagnostic (RSBA_TRACE=2): start / end / compute-end stamp of every block
 };
@@ -666,7 +673,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
   }
   if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();
   double v[36];
-  if (!GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
+  if (!GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v, a.grp_flag, a.epoch)) return;
   FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L, a.cam_free);
   if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -802,7 +809,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   for (int i = 0; i < RSBA_PART; ++i) __hip_atomic_store(&out[i * 256 + tid], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();
   double v[RSBA_PART];
-  if (!GroupReduce<RSBA_PART>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v)) return;
+  if (!GroupReduce<RSBA_PART>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v, a.grp_flag, a.epoch)) return;
   FinishSelfSlot(C, sg.ga, v, camc, a.red, a.L, a.cam_free);
   if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
   if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
@@ -818,21 +825,30 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
   const int tid = threadIdx.x;
   int* cnt_groups = a.sync_cnt + a.ngrp + sg.tile;
   int* cnt_red = a.sync_cnt + a.ngrp + a.ntiles + 16 + sg.tile;
-  if (tid == 0) {
-    const long long t0 = wall_clock64();
-    int ok = 1;
-    while (__hip_atomic_load(cnt_groups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sg.tile_ngrp) {
-      __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > RSBA_STALL_TICKS) { ok = 0; break; }   // cannot happen (see GroupReduce); never hang
-    }
-    s_flag = ok;
-  }
-  __syncthreads();
-  if (!s_flag) { if (tid == 0) __hip_atomic_store(a.tree_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();   // the tile's groups are complete
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // The groups are added in group order AS THEY ARRIVE (per-group flags), four at a time: when the tile's last group is
+  // summed, a reducer has one batch left to read instead of all ~30 group sums (that read sat at the tail of every stage,
+  // and the stages are what the Cholesky waits for).  The sums are read with agent-scope loads (like the flags: coherent
+  // without invalidating this XCD's L2 under the pair tiles running beside); the order of the additions is the old one.
   const int c0 = sg.word_begin, c1 = sg.word_end;
   double* ts = a.tile_sum + (size_t)sg.tile * RSBA_PART * 256 + tid;
+  const int* gf = a.grp_flag + sg.tile_grp0;
+  const long long t_begin = wall_clock64();
+  auto wait_groups = [&](int q0, int q1) {   // whole workgroup; false: gave up (cannot happen, see GroupReduce; never hang)
+    if (tid == 0) {
+      int ok = 1;
+      for (int q = q0; q < q1 && ok; ++q)
+        while (__hip_atomic_load(&gf[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+          __builtin_amdgcn_s_sleep(4);
+          if (wall_clock64() - t_begin > RSBA_STALL_TICKS) { ok = 0; break; }
+        }
+      s_flag = ok;
+    }
+    __syncthreads();
+    const int ok = s_flag;
+    __syncthreads();
+    return ok != 0;
+  };
+  bool all_ok = true;
   {
     // up to RSBA_RED_COMPS components of this slot over all groups, in group order, four groups in flight
     double v[RSBA_RED_COMPS];
@@ -841,20 +857,26 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
     const double* in = a.grp_sum + (size_t)sg.tile_grp0 * RSBA_PART * 256 + (size_t)c0 * 256 + tid;
     int q = 0;
     for (; q + 3 < sg.tile_ngrp; q += 4) {
+      all_ok = wait_groups(q, q + 4) && all_ok;
       double x[4][RSBA_RED_COMPS];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int i = 0; i < RSBA_RED_COMPS; ++i) x[u][i] = (c0 + i < c1) ? in[(size_t)(q + u) * RSBA_PART * 256 + i * 256] : 0.0;
+        for (int i = 0; i < RSBA_RED_COMPS; ++i)
+          x[u][i] = (c0 + i < c1) ? __hip_atomic_load(&in[(size_t)(q + u) * RSBA_PART * 256 + i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
       for (int i = 0; i < RSBA_RED_COMPS; ++i) v[i] = (((v[i] + x[0][i]) + x[1][i]) + x[2][i]) + x[3][i];
     }
+    if (q < sg.tile_ngrp) all_ok = wait_groups(q, sg.tile_ngrp) && all_ok;
     for (; q < sg.tile_ngrp; ++q)
 #pragma unroll
-      for (int i = 0; i < RSBA_RED_COMPS; ++i) if (c0 + i < c1) v[i] += in[(size_t)q * RSBA_PART * 256 + i * 256];
+      for (int i = 0; i < RSBA_RED_COMPS; ++i)
+        if (c0 + i < c1) v[i] += __hip_atomic_load(&in[(size_t)q * RSBA_PART * 256 + i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();   // the tile's groups are complete and added
 #pragma unroll
     for (int i = 0; i < RSBA_RED_COMPS; ++i) if (c0 + i < c1) __hip_atomic_store(&ts[(c0 + i) * 256], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (!all_ok && tid == 0) __hip_atomic_store(a.tree_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0) s_flag = __hip_atomic_fetch_add(cnt_red, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.nred - 1;

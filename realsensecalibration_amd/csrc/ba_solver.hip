@@ -341,7 +341,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nblocks)) ||
       (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
-      (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) ||
+      (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) ||
       (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm, cmpos.size())) || (rc = DevAlloc(&u_cm, cmpos.size())) || (rc = DevAlloc(&v_cm, cmpos.size())))
@@ -353,6 +353,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     HIPCHK(hipMemcpy(v_cm, vcm.data(), vcm.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   HIPCHK(hipMemset(sync_cnt, 0, (size_t)nsync * sizeof(int)));
+  HIPCHK(hipMemset(grp_flag, 0, (size_t)std::max(ngrp, 1) * sizeof(int)));
   HIPCHK(hipMemset(tree_error, 0, 2 * sizeof(int)));   // [0] error flag, [1] ticket counter of the Schur kernel
   HIPCHK(hipMemset(ready, 0, 16 * sizeof(int)));
   HIPCHK(hipMemcpy(block_seg, border.data(), border.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -369,7 +370,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, ready, block_seg, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
+  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   cam_mask = nullptr;
 }
@@ -634,6 +635,7 @@ void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& 
   a.grp_sum = grp_sum; a.sync_cnt = sync_cnt; a.ngrp = ngrp; a.ntiles = ntiles; a.block_seg = block_seg; a.last_group = ngroups - 1; a.tile_sum = tile_sum; a.tree_error = tree_error; a.ticket = tree_error + 1;
   a.ready = ready; a.tag = tag; a.red = s->red; a.L = s->L; a.nblocks_pp = grid_pp; a.block_scal = block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
+  a.grp_flag = grp_flag; a.epoch = ++epoch;
   T.Begin("k_schur_tiles", st);
   if (ip.huber_delta != 0.0) k_schur_tiles<true><<<nblocks, 256, 0, st>>>(a);
   else k_schur_tiles<false><<<nblocks, 256, 0, st>>>(a);
