@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz; vector and matrix fp64 share this peak
                            # (the guide's Matrix-cores table has no fp64 row: AMD datasheet figure)
+PEAK_SOURCE = "AMD MI355X datasheet: 78.6 TFLOP/s fp64 vector = fp64 matrix (256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz); MI355X_MICROARCH.md has no fp64 row"
 
 
 def parse():
@@ -47,13 +48,37 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, torch.distributed.run
+    with a rendezvous on 127.0.0.1) BEFORE this process touches HIP, relay their output and leave with their exit code.
+    Children, never a re-exec: this process only counts devices (which does not initialise the GPU on this image)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
@@ -116,6 +141,10 @@ def main():
         s_w = sv_k.run()
         assert s_w.num_iterations == args.warmup, (s_w.num_iterations, args.warmup)
     sv_k.configure_run(args.steps, 0 if args.no_events else 2)
+    # the communicator the timed solver all-reduces over must span exactly --gpus ranks (1 = no communicator)
+    rccl_nranks = sv_k.comm_nranks()
+    if rccl_nranks != args.gpus:
+        raise SystemExit("RCCL communicator spans %d rank(s), --gpus %d" % (rccl_nranks, args.gpus))
 
     def sync():
         torch.cuda.synchronize()
@@ -152,7 +181,7 @@ def main():
     value = iters_per_s * (N_total / 2_000_000.0) if args.config == "cfg3" else iters_per_s
     out = {
         "metric": "LM iterations/sec (64 cams x 100k pts point model; + final reprojection RMS px)",
-        "value": value, "unit": "LM iterations/s (of the 2M-observation workload)", "n_gpus": world,
+        "value": value, "unit": "LM iterations/s (of the 2M-observation workload)", "n_gpus": world, "rccl_nranks": rccl_nranks,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d cams x %d points, %d observations (%d views/point), point model <2,6,3>, "
@@ -184,8 +213,8 @@ def main():
         chol_flops = nc ** 3 / 3.0 + 2.0 * nc ** 2
         b_iter = syn.algorithmic_bytes_per_iteration(C, P_rank, N_rank)
         pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc_path):
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc.json", "r01_pmc.json")) if os.path.exists(q)), "")
+        if pmc_path:
             try:
                 pmc = json.load(open(pmc_path))
             except Exception:
@@ -199,20 +228,23 @@ def main():
             traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
             if "schur_tiles" in name or "schur_pairs" in name or "linearize_schur" in name:
                 ach = schur_flops / lpi / (ms * 1e-3) / 1e12
-                return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                return {"kernel": name, "bound": "mfma", "pipe": "v_fma_f64 (fp64 VALU issue; the kernel executes no MFMA)",
+                        "achieved": ach, "peak": FP64_PEAK_TFLOPS, "peak_source": PEAK_SOURCE, "unit": "TFLOP/s",
                         "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "avg_launch_us": 1e3 * ms,
                         "algorithmic_flops_per_launch": schur_flops / lpi, "launches_per_iteration": lpi,
-                        "note": "fp64-FMA-bound point elimination: sum_j k_j(k_j+1)/2 blocks x 216 flop (+rhs); the fp64 vector "
-                                "and MFMA pipes share the 78.6 TF peak (AMD datasheet; the guide has no fp64 row)"}
+                        "note": "compute-bound point elimination on the fp64 vector pipe: sum_j k_j(k_j+1)/2 blocks x 216 flop (+rhs); "
+                                "\"bound\" keeps the schema's compute label, \"pipe\" names the real one (PMC: zero MFMA ops in this kernel)"}
             if "reduced_system" in name:
                 ach = chol_flops / lpi / (ms * 1e-3) / 1e12
-                return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                return {"kernel": name, "bound": "mfma", "pipe": "v_mfma_f64_16x16x4_f64", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
+                        "peak_source": PEAK_SOURCE, "unit": "TFLOP/s",
                         "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "avg_launch_us": 1e3 * ms,
                         "algorithmic_flops_per_launch": chol_flops / lpi, "launches_per_iteration": lpi,
                         "note": "dense (6C)^3/3 + 2(6C)^2 Cholesky solve on four workgroups (a chain of 32 x 32 factorisations: latency-bound by construction)"}
             share = {"k_point_pass": 24 * N_rank + 48 * P_rank, "k_backsub_candidate": 24 * N_rank + 48 * P_rank}.get(name, b_iter)
             ach = share / lpi / (ms * 1e-3) / 1e9
-            return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s",
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic, "avg_launch_us": 1e3 * ms, "algorithmic_bytes_per_launch": share / lpi,
                     "launches_per_iteration": lpi}
 
@@ -251,7 +283,10 @@ def main():
         o = oracle_lib.load()
         ncpu = len(os.sched_getaffinity(0))
         res = {}
-        for nt in sorted({1, min(ncpu, 64)}):
+        # 1 thread is what the reference runs (Solver::Options::num_threads default, bundle_adjustment_manager.cpp:90-92);
+        # all host cores is SURVEY 8(d)'s second figure
+        # (64 as well on bigger hosts: the per-thread copies of S make the all-core run reduction-bound)
+        for nt in sorted({1, min(ncpu, 64), ncpu}):
             oo = o.options(max_num_iterations=args.cpu_iters, num_threads=nt, function_tolerance=-1.0, parameter_tolerance=-1.0,
                            gradient_tolerance=-1.0, huber_delta=huber)
             x_cpu, s_cpu, log_cpu = o.solve_points(prob, oo)
@@ -276,7 +311,8 @@ def main():
                                "sample": "%d LM iterations of the same %s problem (oracle/: Jet AutoDiff + Schur + dense LLT, "
                                          "-O3 -march=native, OpenMP over points); single thread = %.4f it/s"
                                          % (args.cpu_iters, args.config, res[1]),
-                               "single_thread_value": res[1], "multi_thread_value": res.get(min(ncpu, 64)), "multi_threads": min(ncpu, 64), "host_cores": ncpu}
+                               "single_thread_value": res[1], "all_cores_value": res.get(ncpu), "all_cores_threads": ncpu,
+                               "by_threads": {str(k_): v_ for k_, v_ in sorted(res.items())}, "host_cores": ncpu}
         out["speedup_vs_cpu_baseline"] = iters_per_s / res[best]
     # RCCL prints a version banner through C stdio, which sits in libc's buffer until exit when stdout is a pipe and
     # would land AFTER the JSON line: push it out first so that the JSON is the last line of stdout

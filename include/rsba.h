@@ -114,8 +114,10 @@ typedef struct rsba_iteration {
   int32_t iteration;
   int32_t step_is_valid;
   int32_t step_is_successful;
-  int32_t reserved;
+  int32_t linear_solver_iterations; /* ls_iter: 1 for the direct DENSE_SCHUR solve, 0 for row 0 */
   double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
+  double iteration_time_in_seconds;  /* iter_time */
+  double cumulative_time_in_seconds; /* total_time, since the start of the minimiser loop */
 } rsba_iteration;
 
 typedef struct rsba_kernel_stat {
@@ -251,6 +253,9 @@ int rsba_points_linearize_payload(rsba_problem* p, const rsba_options* o, double
 /* ncclGetUniqueId: rank 0 calls this and ships the 128 bytes to the other ranks (bench.py does it
  * through torch.distributed); every rank then passes it in rsba_options.comm_unique_id. */
 int rsba_comm_unique_id(void* out128);
+/* ncclCommCount of the solver's communicator: the number of ranks its all-reduces really span (1 without a
+ * communicator).  bench.py prints it as `rccl_nranks` and refuses to report a line when it differs from --gpus. */
+int rsba_solver_comm_nranks(const rsba_solver* s);
 
 /* ------------------------------------------------------------------ files either side of the path */
 /* IO::GetIntrinsics (my_io.cpp:5-31) without OpenCV: reads <intrinsics> 3x3 from an OpenCV

@@ -26,6 +26,7 @@ EXPORTS = [
     "rsba_write_outputs", "rsba_reprojection_error", "rsba_reprojection_check_files",
     "rsba_base_pose_from_marker_detection", "rsba_marker_pose_in_camera", "rsba_marker_corners_in_camera", "rsba_solve_pnp_epnp",
     "rsba_problem_initial_camera_poses", "rsba_problem_set_camera_constant", "rsba_solver_full_report", "rsba_solver_configure_run",
+    "rsba_solver_comm_nranks",
 ]
 
 
@@ -49,9 +50,10 @@ class Summary(C.Structure):
 
 class Iteration(C.Structure):
     _fields_ = [("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32),
-                ("reserved", C.c_int32), ("cost", C.c_double), ("cost_change", C.c_double),
+                ("linear_solver_iterations", C.c_int32), ("cost", C.c_double), ("cost_change", C.c_double),
                 ("gradient_max_norm", C.c_double), ("step_norm", C.c_double), ("relative_decrease", C.c_double),
-                ("trust_region_radius", C.c_double)]
+                ("trust_region_radius", C.c_double), ("iteration_time_in_seconds", C.c_double),
+                ("cumulative_time_in_seconds", C.c_double)]
 
 
 class KernelStat(C.Structure):
@@ -111,6 +113,7 @@ def load():
     lib.rsba_solver_configure_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.rsba_solver_final_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rsba_solver_destroy.argtypes = [C.c_void_p]
+    lib.rsba_solver_comm_nranks.argtypes = [C.c_void_p]
     lib.rsba_points_linearize_and_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 4
     lib.rsba_points_linearize_payload.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]
     lib.rsba_comm_unique_id.argtypes = [C.c_void_p]
@@ -278,6 +281,10 @@ class Solver:
         arr = (KernelStat * cap)()
         n = load().rsba_solver_kernel_stats(self.h, arr, cap)
         return {a.name.decode(): (a.launches, a.total_ms) for a in arr[:n]}
+
+    def comm_nranks(self):
+        """ncclCommCount of the solver's communicator (1 without one)."""
+        return int(load().rsba_solver_comm_nranks(self.h))
 
     def full_report(self):
         n = load().rsba_solver_full_report(self.h, None, 0)

@@ -846,6 +846,23 @@ __global__ void k_publish_result(const double* __restrict__ small_red, double* _
   PostToHost(res, host, seq);
 }
 
+// Gradient evaluation at x without a solve (TrustRegionMinimizer::HandleSuccessfulStep's EvaluateGradientAndJacobian when
+// the run ends right after an accepted step): cost and max |gradient| from the linearisation payload, posted to the host.
+__global__ void __launch_bounds__(256)
+k_gradient_result(const double* __restrict__ red, RedLayout L, const double* __restrict__ gmax_p, double* __restrict__ res,
+                  double* host, double seq) {
+  __shared__ double sm[256];
+  const int tid = threadIdx.x;
+  double gm = 0.0;
+  for (int i = tid; i < L.nc; i += 256) gm = fmax(gm, fabs(red[L.gc() + i]));
+  sm[tid] = gm;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (tid < off) sm[tid] = fmax(sm[tid], sm[tid + off]); __syncthreads(); }
+  if (tid == 0) { res[RES_COST_X] = 0.5 * red[L.scal() + 0]; res[RES_GMAX] = fmax(*gmax_p, sm[0]); }
+  __syncthreads();
+  PostToHost(res, host, seq);
+}
+
 // Cost only at the current point-model parameters (used by rsba_reprojection_error).
 __global__ void __launch_bounds__(256)
 k_cost_only(int P, ObsSliced obs, const double* __restrict__ camc, const double* __restrict__ pts,

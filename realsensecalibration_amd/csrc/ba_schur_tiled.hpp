@@ -79,6 +79,8 @@ struct TiledSchur {
   int nsync = 0, nblocks = 0;               // counters; blocks of the launch (segments + reducers)
   int* ready = nullptr;                     // ready[1 + g] = step tag once stage g (self tile g + pair tiles (g, g' >= g)) is in S
   int* block_seg = nullptr;                 // [nseg] launch order: block -> segment
+  int* block_seg_self = nullptr;            // [nblocks_self] the self segments and their reducers only (gradient evaluation)
+  int nblocks_self = 0;
   int ngrp = 0;
   double* block_scal = nullptr;
   // robust-loss support: sqrt(rho') per observation in camera-major order
@@ -96,6 +98,8 @@ struct TiledSchur {
   int Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T);
   void LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
   void LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag);
+  // the self tiles only: cost, g_c, max |g_p| at x (what HandleSuccessfulStep evaluates at the new point); S is not formed
+  void LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
   void Free();
 };
 
@@ -538,6 +542,7 @@ struct SchurArgs {
   const int* __restrict__ block_seg;
   int* __restrict__ ready;
   int tag;            // 0: nobody is waiting (sequential schedule)
+  int self_only;      // 1: the work list holds the self tiles only (gradient evaluation): no stage bookkeeping
   double* __restrict__ red;
   RedLayout L;
   int nblocks_pp;
@@ -677,7 +682,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
   FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L, a.cam_free);
   if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.trace && tid == 0) a.trace[17 + sg.stage] = wall_clock64();
+  if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
 
 // Self tiles: everything that is a sum over ONE camera's observations — the diagonal block U_a - W V^-1 W' (a, a),
@@ -812,9 +817,10 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   if (!GroupReduce<RSBA_PART>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v, a.grp_flag, a.epoch)) return;
   FinishSelfSlot(C, sg.ga, v, camc, a.red, a.L, a.cam_free);
   if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
+  if (a.self_only) return;
   if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.trace && tid == 0) a.trace[17 + sg.stage] = wall_clock64();
+  if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
 
 // Reducer workgroup `part` of tile sg.tile (see GroupReduce): components [word_begin, word_end) of the tile sums; the
@@ -894,6 +900,7 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
     for (int i = 0; i < RSBA_PART; ++i) v[i] = ts[i * 256];
     FinishSelfSlot(a.C, sg.ga, v, a.camc, a.red, a.L, a.cam_free);
     if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
+    if (a.self_only) return;
   } else {
     double v[36];
 #pragma unroll
@@ -902,7 +909,7 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
   }
   if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.trace && tid == 0) a.trace[17 + sg.stage] = wall_clock64();
+  if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
 
 // K_A2: the Schur elimination kernel.  One workgroup per segment (a range of 64-point words of one tile), in block order

@@ -77,6 +77,12 @@ class KernelTimer {
     on_ = sampled_ && (mode_ == 1 || (mode_ == 2 && Major(name)));
     if (!on_) return;
     Pending p; p.name = name; p.a = Get(); p.b = Get();
+    if (p.a == nullptr || p.b == nullptr) {   // no event could be created: this launch is simply not timed
+      if (p.a) pool_.push_back(p.a);
+      if (p.b) pool_.push_back(p.b);
+      on_ = false;
+      return;
+    }
     (void)hipEventRecord(p.a, s);
     pending_.push_back(p);
   }
@@ -98,6 +104,7 @@ class KernelTimer {
  private:
   hipEvent_t Get() {
     if (pool_.empty()) Reserve(64);
+    if (pool_.empty()) return nullptr;
     hipEvent_t e = pool_.back(); pool_.pop_back();
     return e;
   }
@@ -334,6 +341,10 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     for (int q = 0; q < nseg; ++q) border.push_back(q);   // segments are stored pair tiles first, self tiles after them
     for (int t = 0; t < ntiles; ++t) for (int q : red_of_tile[t]) border.push_back(q);
   }
+  std::vector<int> border_self;
+  for (int q = 0; q < nseg; ++q) if (sg[q].self == 1) border_self.push_back(q);
+  for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2]) for (int q : red_of_tile[t]) border_self.push_back(q);
+  nblocks_self = (int)border_self.size();
   nseg_pair = 0;
   for (int q = 0; q < nseg; ++q) if (!sg[q].self) ++nseg_pair;  // pair tiles come first, self tiles after them, reducers last
   grid_pp = std::max(1, std::min((P + 255) / 256, 2048));
@@ -341,7 +352,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nblocks)) ||
       (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
-      (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) ||
+      (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) || (rc = DevAlloc(&block_seg_self, (size_t)nblocks_self)) ||
       (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm, cmpos.size())) || (rc = DevAlloc(&u_cm, cmpos.size())) || (rc = DevAlloc(&v_cm, cmpos.size())))
@@ -357,6 +368,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   HIPCHK(hipMemset(tree_error, 0, 2 * sizeof(int)));   // [0] error flag, [1] ticket counter of the Schur kernel
   HIPCHK(hipMemset(ready, 0, 16 * sizeof(int)));
   HIPCHK(hipMemcpy(block_seg, border.data(), border.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(block_seg_self, border_self.data(), border_self.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_mask, mask.data(), mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(segs, sg.data(), sg.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_prefix, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -370,7 +382,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
+  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, block_seg_self, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   cam_mask = nullptr;
 }
@@ -539,7 +551,7 @@ static int UploadPoints(rsba_solver* s) {
     HIPCHK(hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CholStepLdsDoubles() * sizeof(double))));
   }
   if (s->opt.schur_impl != 0) {
-    if (getenv("RSBA_TRACE")) {
+    if (getenv("RSBA_TRACE") && s->nc <= RSBA_CHOL_MAXN) {   // the 32 slots are laid out for at most four stages (64 cameras)
       // diagnostics: wall-clock stamps of the step (1) and of every block of the Schur kernel (2)
       if (hipMalloc((void**)&s->trace, 32 * sizeof(long long)) != hipSuccess || hipMemset(s->trace, 0, 32 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
       if (atoi(getenv("RSBA_TRACE")) == 2 && hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
@@ -627,18 +639,33 @@ void TiledSchur::LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTim
 
 // The Schur elimination launch: self segments first, then the pair tiles stage by stage; results land in s->red.
 // tag != 0: the ready flags are published for a Cholesky that is already waiting (pipelined schedule).
-void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag) {
+static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   const int x = s->cur;
   SchurArgs a;
-  a.C = C; a.P = P; a.nwords = nwords; a.camc = s->camc[x]; a.cam_free = s->cam_free; a.segs = segs; a.cam_mask = cam_mask; a.ptdata = ptdata;
-  a.cam_prefix = cam_prefix; a.cam_ptr = cam_ptr; a.sq_cm = sq_cm; a.u_cm = u_cm; a.v_cm = v_cm; a.partial = partial;
-  a.grp_sum = grp_sum; a.sync_cnt = sync_cnt; a.ngrp = ngrp; a.ntiles = ntiles; a.block_seg = block_seg; a.last_group = ngroups - 1; a.tile_sum = tile_sum; a.tree_error = tree_error; a.ticket = tree_error + 1;
-  a.ready = ready; a.tag = tag; a.red = s->red; a.L = s->L; a.nblocks_pp = grid_pp; a.block_scal = block_scal; a.gmax_p = s->gmax;
+  a.C = ts.C; a.P = ts.P; a.nwords = ts.nwords; a.camc = s->camc[x]; a.cam_free = s->cam_free; a.segs = ts.segs; a.cam_mask = ts.cam_mask; a.ptdata = ts.ptdata;
+  a.cam_prefix = ts.cam_prefix; a.cam_ptr = ts.cam_ptr; a.sq_cm = ts.sq_cm; a.u_cm = ts.u_cm; a.v_cm = ts.v_cm; a.partial = ts.partial;
+  a.grp_sum = ts.grp_sum; a.sync_cnt = ts.sync_cnt; a.ngrp = ts.ngrp; a.ntiles = ts.ntiles; a.block_seg = ts.block_seg; a.last_group = ts.ngroups - 1; a.tile_sum = ts.tile_sum;
+  a.tree_error = ts.tree_error; a.ticket = ts.tree_error + 1;
+  a.ready = ts.ready; a.tag = tag; a.self_only = 0; a.red = s->red; a.L = s->L; a.nblocks_pp = ts.grid_pp; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
-  a.grp_flag = grp_flag; a.epoch = ++epoch;
+  a.grp_flag = ts.grp_flag; a.epoch = ++ts.epoch;
+  return a;
+}
+
+void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag) {
+  const SchurArgs a = MakeSchurArgs(*this, s, tag);
   T.Begin("k_schur_tiles", st);
   if (ip.huber_delta != 0.0) k_schur_tiles<true><<<nblocks, 256, 0, st>>>(a);
   else k_schur_tiles<false><<<nblocks, 256, 0, st>>>(a);
+  T.End(st);
+}
+
+void TiledSchur::LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st) {
+  SchurArgs a = MakeSchurArgs(*this, s, 0);
+  a.block_seg = block_seg_self; a.self_only = 1; a.trace = nullptr; a.wg_trace = nullptr;
+  T.Begin("k_schur_tiles(self only)", st);
+  if (ip.huber_delta != 0.0) k_schur_tiles<true><<<nblocks_self, 256, 0, st>>>(a);
+  else k_schur_tiles<false><<<nblocks_self, 256, 0, st>>>(a);
   T.End(st);
 }
 
@@ -646,6 +673,26 @@ int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
   hipStream_t st = s->stream;
   LaunchPointPass(s, ip, T, st);
   LaunchTiles(s, ip, T, st, 0);
+  return RSBA_OK;
+}
+
+// Wait for the result block of the step (or gradient evaluation) just enqueued: poll the sequence word the last kernel
+// posts (PostToHost).  After 2 s of polling the stream that POSTS the result is synchronised (the in-kernel waits give up
+// after RSBA_STALL_TICKS, ten times that in the multi-GPU pipeline, so the synchronisation returns); a dead queue cannot
+// spin us forever.
+static int WaitResult(rsba_solver* s, hipStream_t posting) {
+  s->res_seq += 1.0;
+  volatile double* seq = s->res_host + (RES_SIZE - 1);
+  auto t_poll = std::chrono::steady_clock::now();
+  while (*seq != s->res_seq) {
+    __builtin_ia32_pause();
+    if (std::chrono::steady_clock::now() - t_poll > std::chrono::seconds(2)) {
+      HIPCHK(hipStreamSynchronize(posting));
+      if (*seq != s->res_seq) { fprintf(stderr, "rsba: step finished without posting its result\n"); return RSBA_ERR_HIP; }
+      t_poll = std::chrono::steady_clock::now();
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
   return RSBA_OK;
 }
 
@@ -828,10 +875,12 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   if (s->comm) {
     const bool mg = pipe && s->pipelined_mg;
     T.Begin("k_finish_candidate", st);
-    k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, nullptr, nullptr, 0.0, mg ? s->res : nullptr, s->trace, s->chol_ok + 2);
+    // res_stall: with a communicator the stall flag of the factorisation (multi-workgroup / persistent tiles: in-kernel
+    // waits) and of the pipeline rides in small_red[5] and is SUMMED over the ranks in every schedule, so that all ranks
+    // take the same fallback below and keep issuing the same collectives
+    k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, nullptr, nullptr, 0.0, s->res, s->trace, mg ? s->chol_ok + 2 : nullptr);
     T.End(st);
-    // the candidate's sums (and, pipelined, the stall flags: a stall on one rank must send every rank back to the
-    // sequential schedule together); pipelined, all RCCL traffic stays on the communication stream
+    // the candidate's sums and the stall flags; pipelined, all RCCL traffic stays on the communication stream
     hipStream_t sc = st;
     if (mg) {
       HIPCHK(hipEventRecord(s->ev_bs, st));
@@ -839,25 +888,11 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       sc = s->sR;
     }
     NCCLCHK(ncclAllReduce(s->small_red, s->small_red, 8, ncclDouble, ncclSum, s->comm, sc));
-    k_publish_result<<<1, 64, 0, sc>>>(s->small_red, s->res, s->res_host, s->res_seq + 1.0, mg ? 1 : 0, s->trace);
+    k_publish_result<<<1, 64, 0, sc>>>(s->small_red, s->res, s->res_host, s->res_seq + 1.0, 1, s->trace);
   }
   HIPCHK(hipGetLastError());
   if (s->trace) s->host_t[2] = std::chrono::steady_clock::now();
-  {
-    // wait for the step's result block: poll the sequence word the last kernel posts (see PostToHost); a stream
-    // synchronisation every 2 s of polling keeps a dead queue from spinning us forever
-    s->res_seq += 1.0;
-    volatile double* seq = s->res_host + (RES_SIZE - 1);
-    auto t_poll = std::chrono::steady_clock::now();
-    while (*seq != s->res_seq) {
-      __builtin_ia32_pause();
-      if (std::chrono::steady_clock::now() - t_poll > std::chrono::seconds(2)) {
-        HIPCHK(hipStreamSynchronize(st));
-        if (*seq != s->res_seq) { fprintf(stderr, "rsba: step finished without posting its result\n"); return RSBA_ERR_HIP; }
-      }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-  }
+  { const int rcw = WaitResult(s, s->comm && pipe && s->pipelined_mg ? s->sR : st); if (rcw != RSBA_OK) return rcw; }
   if (s->trace) {
     const auto now = std::chrono::steady_clock::now();
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -930,29 +965,110 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   return RSBA_OK;
 }
 
+// Cost and gradient at the current x without a solve: what Ceres' HandleSuccessfulStep evaluates at the accepted point.
+// Only needed when the run ends right after an accepted step (otherwise the next step's linearisation delivers them).
+// Leaves res_host[RES_COST_X] and res_host[RES_GMAX] filled.
+static int PointsGradient(rsba_solver* s, double radius) {
+  const int C = s->C, P = s->P, x = s->cur;
+  hipStream_t st = s->stream;
+  IterParams ip = MakeIterParams(s->opt, radius, false);
+  ip.cam_free = s->cam_free;
+  KernelTimer& T = s->timer;
+  T.NextStep();
+  if (s->opt.schur_impl == 0) {
+    HIPCHK(hipMemsetAsync(s->red, 0, s->L.size() * sizeof(double), st));
+    const bool stage = (size_t)C * (RSBA_ACC_PER_CAM + RSBA_CC_LDS) * sizeof(double) <= 96 * 1024;
+    const size_t lds = (size_t)C * (RSBA_ACC_PER_CAM + (stage ? RSBA_CC_LDS : 0)) * sizeof(double);
+    if (stage)
+      k_linearize_schur_ref<true><<<s->grid_lin, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p,
+                                                                 s->red, s->L, s->gmax, s->block_scal, ip);
+    else
+      k_linearize_schur_ref<false><<<s->grid_lin, 256, lds, st>>>(C, P, s->obs_u, s->obs_v, s->obs_cam, s->pt_ptr, s->camc[x], s->pts[x], s->scale_p,
+                                                                  s->red, s->L, s->gmax, s->block_scal, ip);
+    k_finish_linearize<<<1, 256, 0, st>>>(s->grid_lin, s->block_scal, s->red, s->L, s->gmax);
+  } else {
+    s->tiled.LaunchPointPass(s, ip, T, st);
+    s->tiled.LaunchSelfOnly(s, ip, T, st);
+  }
+  if (s->comm) {
+    // g_c and the scalars are sums over the ranks' shards, max |g_p| a maximum
+    NCCLCHK(ncclGroupStart());
+    NCCLCHK(ncclAllReduce(s->red + s->L.gc(), s->red + s->L.gc(), (size_t)s->nc, ncclDouble, ncclSum, s->comm, st));
+    NCCLCHK(ncclAllReduce(s->red + s->L.scal(), s->red + s->L.scal(), 8, ncclDouble, ncclSum, s->comm, st));
+    NCCLCHK(ncclAllReduce(s->gmax, s->gmax, 1, ncclDouble, ncclMax, s->comm, st));
+    NCCLCHK(ncclGroupEnd());
+  }
+  k_gradient_result<<<1, 256, 0, st>>>(s->red, s->L, s->gmax, s->res, s->res_host, s->res_seq + 1.0);
+  HIPCHK(hipGetLastError());
+  return WaitResult(s, st);
+}
+
 // ------------------------------------------------------------------------------------------------
 // TrustRegionMinimizer, host side.  `step(radius, first)` must leave res[] filled.
 // ------------------------------------------------------------------------------------------------
-template <typename StepFn, typename AcceptFn>
-static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn accept) {
+// `eval()` must leave res[RES_COST_X] and res[RES_GMAX] of the CURRENT point filled, without a solve.
+//
+// Order of the tests is Ceres 1.14's (trust_region_minimizer.cc): after an
+// accepted step the new point is re-linearised and ITS gradient decides the gradient-tolerance stop before any further
+// solve is interpreted.  Here a step() call linearises, solves and evaluates the candidate in one go, so the new point's
+// cost and gradient arrive with the NEXT step(): they are written back into the accepted iteration's row, and when the
+// gradient test fires that step's solve and candidate are discarded.  When the run ends right after an accepted step
+// (iteration limit), eval() supplies them.
+template <typename StepFn, typename AcceptFn, typename EvalFn>
+static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn accept, EvalFn eval) {
   const rsba_options& o = s->opt;
   s->iters.clear();
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
   int invalid_run = 0;
   bool first = true;
+  bool x_moved = false;   // the latest row is an accepted step whose cost / gradient at the new point are not in yet
+  size_t printed = 0;     // rows of the progress table already on stdout
   double x_cost = 0, gmax = 0, x_norm = 0;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto t_iter = t_start;
   sum->num_successful_steps = sum->num_unsuccessful_steps = 0;
   sum->termination_type = RSBA_NO_CONVERGENCE; sum->stop_reason = RSBA_STOP_NONE;
+  // Ceres' progress table (bundle_adjustment_manager.cpp:92 minimizer_progress_to_stdout): a row goes out once it is final
+  auto flush_rows = [&]() {
+    if (!o.minimizer_progress_to_stdout) { printed = s->iters.size(); return; }
+    for (; printed < s->iters.size(); ++printed) {
+      const rsba_iteration& r = s->iters[printed];
+      if (printed == 0) printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter  iter_time  total_time\n");
+      printf("%4d % 8e   % 3.2e   % 3.2e  % 3.2e  % 3.2e % 3.2e     % 4d   % 3.2e   % 3.2e\n", r.iteration, r.cost, r.cost_change, r.gradient_max_norm,
+             r.step_norm, r.relative_decrease, r.trust_region_radius, r.linear_solver_iterations, r.iteration_time_in_seconds, r.cumulative_time_in_seconds);
+    }
+  };
+  auto push_row = [&](rsba_iteration& it) {
+    const auto now = std::chrono::steady_clock::now();
+    it.iteration_time_in_seconds = std::chrono::duration<double>(now - t_iter).count();
+    it.cumulative_time_in_seconds = std::chrono::duration<double>(now - t_start).count();
+    t_iter = now;
+    s->iters.push_back(it);
+  };
   auto finish = [&](int term, int reason) {
     sum->termination_type = term; sum->stop_reason = reason; sum->final_cost = x_cost;
     sum->num_iterations = (int)s->iters.size() - 1;
+    flush_rows();
     return RSBA_OK;
+  };
+  // the accepted point's own cost and gradient (evaluated by the linearisation that follows the acceptance)
+  auto settle_moved = [&]() {
+    rsba_iteration& last = s->iters.back();
+    last.cost = x_cost; last.gradient_max_norm = gmax;
+    x_moved = false;
   };
   for (;;) {
     // checks of FinalizeIterationAndCheckIfMinimizerCanContinue for the previous iteration
     if (!first) {
-      if (s->iters.back().iteration >= o.max_num_iterations) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_ITERATIONS);
-      if (gmax <= o.gradient_tolerance) return finish(RSBA_CONVERGENCE, RSBA_STOP_GRADIENT);
+      const bool at_limit = s->iters.back().iteration >= o.max_num_iterations;
+      if (x_moved && (at_limit || radius < o.min_trust_region_radius)) {
+        int rc = eval();
+        if (rc != RSBA_OK) return rc;
+        x_cost = s->res_host[RES_COST_X]; gmax = s->res_host[RES_GMAX];
+        settle_moved();
+      }
+      if (at_limit) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_ITERATIONS);
+      if (!x_moved && gmax <= o.gradient_tolerance) return finish(RSBA_CONVERGENCE, RSBA_STOP_GRADIENT);
       if (radius < o.min_trust_region_radius) return finish(RSBA_CONVERGENCE, RSBA_STOP_MIN_RADIUS);
     }
     int rc = step(radius, first);
@@ -962,16 +1078,21 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
     if (first) {
       // iteration 0: the evaluation at the starting point
       rsba_iteration it0{}; it0.iteration = 0; it0.cost = x_cost; it0.gradient_max_norm = gmax; it0.trust_region_radius = radius;
-      s->iters.push_back(it0);
+      push_row(it0);
       sum->initial_cost = x_cost;
-      if (!std::isfinite(x_cost)) { sum->final_cost = x_cost; sum->termination_type = RSBA_FAILURE; sum->stop_reason = RSBA_STOP_INITIAL_FAILURE; sum->num_iterations = 0; return RSBA_OK; }
-      if (o.minimizer_progress_to_stdout) printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d % .6e\n", 0, x_cost);
+      if (!std::isfinite(x_cost)) { sum->final_cost = x_cost; sum->termination_type = RSBA_FAILURE; sum->stop_reason = RSBA_STOP_INITIAL_FAILURE; sum->num_iterations = 0; flush_rows(); return RSBA_OK; }
       first = false;
       if (gmax <= o.gradient_tolerance) return finish(RSBA_CONVERGENCE, RSBA_STOP_GRADIENT);
       if (o.max_num_iterations <= 0) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_ITERATIONS);
+      if (radius < o.min_trust_region_radius) return finish(RSBA_CONVERGENCE, RSBA_STOP_MIN_RADIUS);
+    } else if (x_moved) {
+      settle_moved();
+      if (gmax <= o.gradient_tolerance) return finish(RSBA_CONVERGENCE, RSBA_STOP_GRADIENT);   // this step's solve and candidate are discarded
     }
+    flush_rows();
     rsba_iteration it{};
     it.iteration = s->iters.back().iteration + 1;
+    it.linear_solver_iterations = 1;   // a direct solve (Ceres reports 1 for DENSE_SCHUR)
     it.cost = x_cost; it.gradient_max_norm = gmax;
     const bool solved = r[RES_CHOL_OK] != 0.0 && std::isfinite(r[RES_MCC]) && std::isfinite(r[RES_STEP2]);
     const double mcc = r[RES_MCC];
@@ -979,37 +1100,36 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
     if (!it.step_is_valid) {
       ++invalid_run;
       ++sum->num_unsuccessful_steps;
-      if (invalid_run >= o.max_num_consecutive_invalid_steps) { it.trust_region_radius = radius; s->iters.push_back(it); return finish(RSBA_FAILURE, RSBA_STOP_INVALID_STEPS); }
+      if (invalid_run >= o.max_num_consecutive_invalid_steps) { it.trust_region_radius = radius; push_row(it); return finish(RSBA_FAILURE, RSBA_STOP_INVALID_STEPS); }
       radius /= decrease_factor; decrease_factor *= 2.0;
       it.trust_region_radius = radius;
-      s->iters.push_back(it);
+      push_row(it);
       continue;
     }
     invalid_run = 0;
     const double cand_cost = r[RES_COST_C];
     it.step_norm = std::sqrt(r[RES_STEP2]);
     it.trust_region_radius = radius;
-    if (it.step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { s->iters.push_back(it); return finish(RSBA_CONVERGENCE, RSBA_STOP_PARAMETER); }
+    if (it.step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { push_row(it); return finish(RSBA_CONVERGENCE, RSBA_STOP_PARAMETER); }
     it.cost_change = x_cost - cand_cost;
-    if (std::fabs(it.cost_change) <= o.function_tolerance * x_cost) { s->iters.push_back(it); return finish(RSBA_CONVERGENCE, RSBA_STOP_FUNCTION); }
+    if (std::fabs(it.cost_change) <= o.function_tolerance * x_cost) { push_row(it); return finish(RSBA_CONVERGENCE, RSBA_STOP_FUNCTION); }
     it.relative_decrease = it.cost_change / mcc;
     if (it.relative_decrease > o.min_relative_decrease) {
       accept();
-      x_cost = cand_cost;  // re-evaluated by the next linearisation; kept for the summary if we stop here
+      x_cost = cand_cost;  // re-evaluated by the next linearisation (settle_moved); kept for the summary if we stop here
       s->final_sumsq = r[RES_SUMSQ_C];
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
       radius = std::min(o.max_trust_region_radius, radius);
       decrease_factor = 2.0;
       it.step_is_successful = 1; it.cost = cand_cost; it.trust_region_radius = radius;
       ++sum->num_successful_steps;
+      x_moved = true;
     } else {
       radius /= decrease_factor; decrease_factor *= 2.0;
       it.trust_region_radius = radius;
       ++sum->num_unsuccessful_steps;
     }
-    if (o.minimizer_progress_to_stdout)
-      printf("%4d % .6e % .3e % .3e % .3e % .3e % .3e\n", it.iteration, it.cost, it.cost_change, it.gradient_max_norm, it.step_norm, it.relative_decrease, it.trust_region_radius);
-    s->iters.push_back(it);
+    push_row(it);
   }
 }
 
@@ -1027,6 +1147,14 @@ int rsba_comm_unique_id(void* out128) {
   if (ncclGetUniqueId(&id) != ncclSuccess) return RSBA_ERR_COMM;
   memcpy(out128, &id, sizeof(id));
   return RSBA_OK;
+}
+
+int rsba_solver_comm_nranks(const rsba_solver* s) {
+  if (!s) return 0;
+  if (!s->comm) return 1;
+  int n = 0;
+  if (ncclCommCount(s->comm, &n) != ncclSuccess) return 0;
+  return n;
 }
 
 int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out) {
@@ -1092,8 +1220,9 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
     if ((rc = rsba::ResetPoints(s)) != RSBA_OK) return rc;
     if (hipStreamSynchronize(s->stream) != hipSuccess) return RSBA_ERR_HIP;
     const auto t0 = std::chrono::steady_clock::now();
-    rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { return rsba::PointsStep(s, radius, first, false); },
-                            [&]() { s->cur = 1 - s->cur; });
+    double cur_radius = s->opt.initial_trust_region_radius;
+    rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { cur_radius = radius; return rsba::PointsStep(s, radius, first, false); },
+                            [&]() { s->cur = 1 - s->cur; }, [&]() { return rsba::PointsGradient(s, cur_radius); });
     sum.minimizer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc == RSBA_OK && s->tiled.tree_error) {
       // a reducer workgroup of the Schur kernel gave up waiting for its tile (cannot happen by construction): the sums
@@ -1108,12 +1237,16 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
     if ((rc = s->eliminate_times ? s->marker_schur.Reset(s->stream) : s->marker.Reset(s->stream)) != RSBA_OK) return rc;
     if (hipStreamSynchronize(s->stream) != hipSuccess) return RSBA_ERR_HIP;
     const auto t0 = std::chrono::steady_clock::now();
+    double mk_radius = s->opt.initial_trust_region_radius;
     if (s->eliminate_times)
-      rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { return s->marker_schur.Step(s->stream, s->opt, radius, first, s->res_host, s->timer); },
-                              [&]() { s->marker_schur.Accept(); });
+      rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { mk_radius = radius; return s->marker_schur.Step(s->stream, s->opt, radius, first, s->res_host, s->timer); },
+                              [&]() { s->marker_schur.Accept(); },
+                              // (the marker-chain step is small: a full step at the accepted point, of which only cost and gradient are used)
+                              [&]() { return s->marker_schur.Step(s->stream, s->opt, mk_radius, false, s->res_host, s->timer); });
     else
-      rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { return s->marker.Step(s->stream, s->opt, radius, first, s->res_host, s->timer); },
-                              [&]() { s->marker.Accept(); });
+      rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { mk_radius = radius; return s->marker.Step(s->stream, s->opt, radius, first, s->res_host, s->timer); },
+                              [&]() { s->marker.Accept(); },
+                              [&]() { return s->marker.Step(s->stream, s->opt, mk_radius, false, s->res_host, s->timer); });
     sum.minimizer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
   s->timer.Collect();
