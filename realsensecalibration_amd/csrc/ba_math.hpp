@@ -84,6 +84,23 @@ RSBA_HD void Residual(const double* cc, const double X[3], double u, double v, d
   r[1] = cc[CC_FY] * p1 * iz + cc[CC_PPY] - v;
 }
 
+// Residual + the point-side Jacobian block only (2x3 row-major): what the linearisation of a point needs of an
+// observation (V = sum Jp'Jp, g_p = sum Jp'r); same arithmetic as ResidualJacobian.
+RSBA_HD void ResidualPointJacobian(const double* cc, const double X[3], double u, double v, double r[2], double jp[6]) {
+  const double* R = cc + CC_R;
+  const double q0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
+  const double q1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
+  const double q2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
+  const double p0 = q0 + cc[CC_T + 0], p1 = q1 + cc[CC_T + 1], p2 = q2 + cc[CC_T + 2];
+  const double iz = 1.0 / p2;
+  r[0] = cc[CC_FX] * p0 * iz + cc[CC_PPX] - u;
+  r[1] = cc[CC_FY] * p1 * iz + cc[CC_PPY] - v;
+  const double al = cc[CC_FX] * iz, be = cc[CC_FY] * iz;
+  const double ga = -al * p0 * iz, de = -be * p1 * iz;
+  jp[0] = al * R[0] + ga * R[6]; jp[1] = al * R[1] + ga * R[7]; jp[2] = al * R[2] + ga * R[8];
+  jp[3] = be * R[3] + de * R[6]; jp[4] = be * R[4] + de * R[7]; jp[5] = be * R[5] + de * R[8];
+}
+
 // Residual + Jacobian blocks.  jc: 2x6 row-major (d/d rvec, d/d tvec), jp: 2x3 row-major.
 RSBA_HD void ResidualJacobian(const double* cc, const double X[3], double u, double v, double r[2],
                               double jc[12], double jp[6]) {

@@ -575,6 +575,10 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
   SolveDone(gate);
 }
 
+// Per-point linearisation record kept between LM steps (see k_point_damp in ba_schur_tiled.hpp):
+// V_j = sum Jp'Jp (6, symmetric), g_pj = sum Jp'r (3), the point's share of sum rho (1).
+#define RSBA_LIN_STRIDE 10
+
 // Observations as the point-centric kernels walk them: sliced ELL.  A slice is 64 consecutive points (one wavefront);
 // slot t of lane l sits at (row_ptr[slice] + t) * 64 + l, slots in camera order, cam < 0 pads a point with fewer views
 // than the widest of its slice.  A wavefront's loads are then contiguous (1 KB of pixels, 256 B of camera indices per
@@ -593,14 +597,26 @@ struct ObsSliced {
 __device__ __forceinline__ void FinishCandidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
                                                 double* __restrict__ res, double* host, double seq, const double* res_stall = nullptr);
 
-template <bool kStage>
+// kFused (tiled path): the linearisation of the points at x is READ (lin_x: V, g_p as the Schur kernel used them) instead
+// of accumulated again, and the second pass, which evaluates the candidate's residuals anyway, takes the candidate's 2x3
+// blocks along and WRITES its linearisation (lin_c; sqrt(rho') into sq_cm_c): if the step is accepted the next LM
+// iteration starts from it without another pass over the observation records (k_point_damp).
+struct FusedLin {
+  const double* __restrict__ lin_x;   // [P][RSBA_LIN_STRIDE]
+  double* __restrict__ lin_c;
+  const int* __restrict__ cm_pos;     // sliced slot -> camera-major position (robust loss only)
+  double* __restrict__ sq_cm_c;
+};
+
+template <bool kStage, bool kFused>
 __global__ void __launch_bounds__(256)
 k_backsub_candidate(int C, int P, ObsSliced obs,
                     const double* __restrict__ camc_xg, const double* __restrict__ camc_cg,
                     const double* __restrict__ dcam_g, const double* __restrict__ pts_x, double* __restrict__ pts_c,
                     const double* __restrict__ scale_p, double* __restrict__ block_part /* gridDim.x x 8 */, IterParams ip,
                     int* __restrict__ done_cnt, double* __restrict__ small_red, double* __restrict__ res, double* host, double seq,
-                    const int* __restrict__ solve_done, int solve_tag, long long* __restrict__ waited, int* __restrict__ wait_timeout) {
+                    const int* __restrict__ solve_done, int solve_tag, long long* __restrict__ waited, int* __restrict__ wait_timeout,
+                    FusedLin fl) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   // camera constants at x and at the candidate, and the camera step: 70 doubles per camera, LDS-resident when they fit
@@ -662,6 +678,12 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
     bool any = false;
     const double X[3] = {pts_x[3 * (size_t)j], pts_x[3 * (size_t)j + 1], pts_x[3 * (size_t)j + 2]};
     double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, bv[3] = {0, 0, 0}, a1 = 0, a2 = 0;
+    if (kFused) {
+      const double* ln = fl.lin_x + (size_t)j * RSBA_LIN_STRIDE;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) V[i] = ln[i];
+      gp[0] = ln[6]; gp[1] = ln[7]; gp[2] = ln[8];
+    }
     // observation records four slots ahead of the one in use (k_point_pass: a thread's records are otherwise a chain of
     // dependent round trips to memory; the grid is 1.5 workgroups per CU)
     int camq[4]; double2 uvq[4];
@@ -693,10 +715,12 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
 #pragma unroll
         for (int i = 0; i < 6; ++i) jp[i] *= sq;
       }
-      V[0] += jp[0] * jp[0] + jp[3] * jp[3]; V[1] += jp[0] * jp[1] + jp[3] * jp[4]; V[2] += jp[0] * jp[2] + jp[3] * jp[5];
-      V[3] += jp[1] * jp[1] + jp[4] * jp[4]; V[4] += jp[1] * jp[2] + jp[4] * jp[5]; V[5] += jp[2] * jp[2] + jp[5] * jp[5];
+      if (!kFused) {
+        V[0] += jp[0] * jp[0] + jp[3] * jp[3]; V[1] += jp[0] * jp[1] + jp[3] * jp[4]; V[2] += jp[0] * jp[2] + jp[3] * jp[5];
+        V[3] += jp[1] * jp[1] + jp[4] * jp[4]; V[4] += jp[1] * jp[2] + jp[4] * jp[5]; V[5] += jp[2] * jp[2] + jp[5] * jp[5];
+      }
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { gp[a] += jp[a] * r[0] + jp[3 + a] * r[1]; bv[a] += jp[a] * e0 + jp[3 + a] * e1; }
+      for (int a = 0; a < 3; ++a) { if (!kFused) gp[a] += jp[a] * r[0] + jp[3 + a] * r[1]; bv[a] += jp[a] * e0 + jp[3 + a] * e1; }
       a1 += e0 * r[0] + e1 * r[1];
       a2 += e0 * e0 + e1 * e1;
     }
@@ -713,6 +737,7 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
            0.5 * (dp[0] * Vd[0] + dp[1] * Vd[1] + dp[2] * Vd[2]);
     dp2 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
     xc2 += Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2];
+    double Vc[6] = {0, 0, 0, 0, 0, 0}, gc[3] = {0, 0, 0}, costj_c = 0.0;   // the candidate's linearisation (kFused)
 #pragma unroll
     for (int u = 0; u < 4; ++u) fill(u, tb + u);
     for (int t = tb; t < te; ++t) {
@@ -722,12 +747,36 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
       for (int u = 0; u < 3; ++u) { camq[u] = camq[u + 1]; uvq[u] = uvq[u + 1]; }
       fill(3, t + 4);
       if (cam < 0) continue;
-      double r[2];
-      Residual(camc_c + (size_t)cam * (kStage ? RSBA_CC_LDS : CC_STRIDE), Xc, uv.x, uv.y, r);
-      const double s = r[0] * r[0] + r[1] * r[1];
-      double sq;
-      cost_c += LossAndScale(ip.huber_delta, s, &sq);
-      ss_c += s;
+      if (kFused) {
+        double r[2], jp[6], sq;
+        ResidualPointJacobian(camc_c + (size_t)cam * (kStage ? RSBA_CC_LDS : CC_STRIDE), Xc, uv.x, uv.y, r, jp);
+        const double s = r[0] * r[0] + r[1] * r[1];
+        costj_c += LossAndScale(ip.huber_delta, s, &sq);
+        ss_c += s;
+        if (ip.huber_delta != 0.0) fl.sq_cm_c[fl.cm_pos[(size_t)t * 64 + lane]] = sq;
+        if (sq != 1.0) {
+          r[0] *= sq; r[1] *= sq;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) jp[i] *= sq;
+        }
+        Vc[0] += jp[0] * jp[0] + jp[3] * jp[3]; Vc[1] += jp[0] * jp[1] + jp[3] * jp[4]; Vc[2] += jp[0] * jp[2] + jp[3] * jp[5];
+        Vc[3] += jp[1] * jp[1] + jp[4] * jp[4]; Vc[4] += jp[1] * jp[2] + jp[4] * jp[5]; Vc[5] += jp[2] * jp[2] + jp[5] * jp[5];
+        gc[0] += jp[0] * r[0] + jp[3] * r[1]; gc[1] += jp[1] * r[0] + jp[4] * r[1]; gc[2] += jp[2] * r[0] + jp[5] * r[1];
+      } else {
+        double r[2];
+        Residual(camc_c + (size_t)cam * (kStage ? RSBA_CC_LDS : CC_STRIDE), Xc, uv.x, uv.y, r);
+        const double s = r[0] * r[0] + r[1] * r[1];
+        double sq;
+        costj_c += LossAndScale(ip.huber_delta, s, &sq);
+        ss_c += s;
+      }
+    }
+    cost_c += costj_c;
+    if (kFused) {
+      double* ln = fl.lin_c + (size_t)j * RSBA_LIN_STRIDE;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ln[i] = Vc[i];
+      ln[6] = gc[0]; ln[7] = gc[1]; ln[8] = gc[2]; ln[9] = costj_c;
     }
   }
   // block reduction in a fixed order

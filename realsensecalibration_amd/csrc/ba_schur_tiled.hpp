@@ -87,7 +87,9 @@ struct TiledSchur {
   int* cam_prefix = nullptr;                // [ngroups*16][nwords] set bits of cam_mask before each word
   int* cam_ptr = nullptr;                   // [ngroups*16+1] start of each camera's observation list
   int* cm_pos = nullptr;                    // [rows*64] observation (sliced layout, see ObsSliced) -> camera-major position
-  double* sq_cm = nullptr;                  // [N]
+  double* sq_cm2[2] = {nullptr, nullptr};   // [N] each: sqrt(rho') at x / at the candidate (same double buffering as the points)
+  double* lin2[2] = {nullptr, nullptr};     // [P][RSBA_LIN_STRIDE] each: V_j (6), g_pj (3), the point's share of sum rho, at x / at the candidate
+  bool lin_valid = false;                   // lin2[cur] holds the linearisation of the current x (set by a completed step of this run)
   double *u_cm = nullptr, *v_cm = nullptr;  // [N] observations in camera-major order (self tiles need the pixel)
   int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
             const std::vector<int>& sliced_q /* sliced slot -> CSR position, -1 pads */, bool staged);
@@ -97,6 +99,8 @@ struct TiledSchur {
   std::vector<int> stage_tile, stage_seg;
   int Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T);
   void LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
+  // the point pass of a step whose x already has its linearisation in lin2[cur] (every step but a run's first)
+  void LaunchPointDamp(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
   void LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag);
   // the self tiles only: cost, g_c, max |g_p| at x (what HandleSuccessfulStep evaluates at the new point); S is not formed
   void LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
@@ -110,7 +114,8 @@ template <bool kStageCamc>
 __global__ void __launch_bounds__(256)
 k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, const double* __restrict__ pts,
              double* __restrict__ scale_p, double* __restrict__ ptdata, double* __restrict__ block_scal,
-             const int* __restrict__ cm_pos /* sliced like obs */, double* __restrict__ sq_cm, IterParams ip) {
+             const int* __restrict__ cm_pos /* sliced like obs */, double* __restrict__ sq_cm, double* __restrict__ lin /* [P][RSBA_LIN_STRIDE] */,
+             IterParams ip) {
   extern __shared__ double lds[];
   double* camc_l = lds;      // C x 33 when staged
   const int tid = threadIdx.x;
@@ -133,7 +138,7 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
     const int lane = j & 63;
     bool any = false;
     const double X[3] = {pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2]};
-    double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
+    double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, cost_j = 0.0;
     // The grid is small (1.5 workgroups per CU at 100k points): a thread's ~20 observation records are a chain of
     // dependent round trips to memory unless several are in flight — four slots are loaded ahead of the one in use.
     const int t0 = obs.row_ptr[j >> 6], t1 = obs.row_ptr[(j >> 6) + 1];
@@ -159,7 +164,7 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
       any = true;
       double r[2], jc[12], jp[6], sq;
       ResidualJacobian(camc + (size_t)cam * ccs, X, uv.x, uv.y, r, jc, jp);
-      cost += LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
+      cost_j += LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
       if (ip.huber_delta != 0.0) sq_cm[cm_pos[q]] = sq;
       if (sq != 1.0) {
         r[0] *= sq; r[1] *= sq;
@@ -170,12 +175,71 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
       V[3] += jp[1] * jp[1] + jp[4] * jp[4]; V[4] += jp[1] * jp[2] + jp[4] * jp[5]; V[5] += jp[2] * jp[2] + jp[5] * jp[5];
       gp[0] += jp[0] * r[0] + jp[3] * r[1]; gp[1] += jp[1] * r[0] + jp[4] * r[1]; gp[2] += jp[2] * r[0] + jp[5] * r[1];
     }
+    cost += cost_j;
+    {
+      // the linearisation of the point, kept: a rejected step damps it again with the smaller radius (k_point_damp)
+      double* ln = lin + (size_t)j * RSBA_LIN_STRIDE;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ln[i] = V[i];
+      ln[6] = gp[0]; ln[7] = gp[1]; ln[8] = gp[2]; ln[9] = cost_j;
+    }
     double sp[3] = {1.0, 1.0, 1.0};
     if (ip.jacobi_scaling) {
       if (ip.first) { sp[0] = 1.0 / (1.0 + sqrt(V[0])); sp[1] = 1.0 / (1.0 + sqrt(V[3])); sp[2] = 1.0 / (1.0 + sqrt(V[5])); }
       else { sp[0] = scale_p[3 * (size_t)j]; sp[1] = scale_p[3 * (size_t)j + 1]; sp[2] = scale_p[3 * (size_t)j + 2]; }
     }
     if (ip.first) { scale_p[3 * (size_t)j] = sp[0]; scale_p[3 * (size_t)j + 1] = sp[1]; scale_p[3 * (size_t)j + 2] = sp[2]; }
+    double Vi[6];
+    const bool ok = PointBlockInverse(V, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, ip.radius, Vi);
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Vi[i] = 0.0;
+      if (any) fail += 1.0;
+    }
+    double y[3];
+    Sym3MulVec(Vi, gp, y);
+    double* pd = ptdata + (size_t)j * RSBA_PT_STRIDE;
+    pd[0] = X[0]; pd[1] = X[1]; pd[2] = X[2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pd[3 + i] = Vi[i];
+    pd[9] = y[0]; pd[10] = y[1]; pd[11] = y[2];
+    xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+    gmax = fmax(gmax, fmax(fabs(gp[0]), fmax(fabs(gp[1]), fabs(gp[2]))));
+  }
+  __shared__ double s[4][256];
+  s[0][tid] = cost; s[1][tid] = xn; s[2][tid] = fail; s[3][tid] = gmax;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { s[0][tid] += s[0][tid + off]; s[1][tid] += s[1][tid + off]; s[2][tid] += s[2][tid + off]; s[3][tid] = fmax(s[3][tid], s[3][tid + off]); }
+    __syncthreads();
+  }
+  if (tid < 4) block_scal[4 * blockIdx.x + tid] = s[tid][0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_A1': the point pass of every LM step but the first.  The linearisation of the points at x is already there:
+// V_j, g_pj and the point's share of the cost were written either by k_point_pass (first step) or, for an accepted
+// candidate, by the back-substitution kernel, which evaluates the candidate's residuals anyway and now takes the 2x3
+// blocks along (k_backsub_candidate: the candidate's residuals ARE the next iteration's).  What is left per step is the
+// radius-dependent part: damped inverse point block, V^-1 g_p, and the per-block scalars the Schur kernel folds.
+// No observation record is read: 29 doubles in, 12 out per point.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_point_damp(int P, const double* __restrict__ pts, const double* __restrict__ scale_p, const double* __restrict__ lin,
+             double* __restrict__ ptdata, double* __restrict__ block_scal, IterParams ip) {
+  const int tid = threadIdx.x;
+  double cost = 0, xn = 0, fail = 0, gmax = 0;
+  for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
+    const double* ln = lin + (size_t)j * RSBA_LIN_STRIDE;
+    double V[6], gp[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) V[i] = ln[i];
+    gp[0] = ln[6]; gp[1] = ln[7]; gp[2] = ln[8];
+    cost += ln[9];
+    const double X[3] = {pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2]};
+    double sp[3] = {1.0, 1.0, 1.0};
+    if (ip.jacobi_scaling) { sp[0] = scale_p[3 * (size_t)j]; sp[1] = scale_p[3 * (size_t)j + 1]; sp[2] = scale_p[3 * (size_t)j + 2]; }
+    const bool any = V[0] != 0.0 || V[3] != 0.0 || V[5] != 0.0;   // a point with observations has a non-zero block
     double Vi[6];
     const bool ok = PointBlockInverse(V, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, ip.radius, Vi);
     if (!ok) {

@@ -186,6 +186,7 @@ struct rsba_solver {
   int grid_lin = 0, grid_pts = 0;
   int cur = 0;
   TiledSchur tiled;
+  bool fused_lin = true;     // RSBA_FUSED_LIN=0: every step runs the full point pass (the round-1 schedule)
 
   // ---- marker-chain model
   MarkerDevice marker;
@@ -355,7 +356,9 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) || (rc = DevAlloc(&block_seg_self, (size_t)nblocks_self)) ||
       (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
-      (rc = DevAlloc(&sq_cm, cmpos.size())) || (rc = DevAlloc(&u_cm, cmpos.size())) || (rc = DevAlloc(&v_cm, cmpos.size())))
+      (rc = DevAlloc(&sq_cm2[0], cmpos.size())) || (rc = DevAlloc(&sq_cm2[1], cmpos.size())) ||
+      (rc = DevAlloc(&lin2[0], (size_t)P * RSBA_LIN_STRIDE)) || (rc = DevAlloc(&lin2[1], (size_t)P * RSBA_LIN_STRIDE)) ||
+      (rc = DevAlloc(&u_cm, cmpos.size())) || (rc = DevAlloc(&v_cm, cmpos.size())))
     return rc;
   {
     std::vector<double> ucm(cmpos.size(), 0.0), vcm(cmpos.size(), 0.0);
@@ -382,7 +385,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, block_seg_self, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm, u_cm, v_cm};
+  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, block_seg_self, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   cam_mask = nullptr;
 }
@@ -557,6 +560,7 @@ static int UploadPoints(rsba_solver* s) {
       if (atoi(getenv("RSBA_TRACE")) == 2 && hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
     }
     s->pipelined = SetupPipeline(s);
+    s->fused_lin = !(getenv("RSBA_FUSED_LIN") && atoi(getenv("RSBA_FUSED_LIN")) == 0);
   }
   {
     // several workgroups for the reduced system: 32 to 64 cameras (padded to whole 32-wide panels), full symmetric S
@@ -619,6 +623,7 @@ static int ResetPoints(rsba_solver* s) {
   HIPCHK(hipMemcpyAsync(s->cam[0], s->cam0, 6 * s->C * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   HIPCHK(hipMemcpyAsync(s->pts[0], s->pts0, 3 * (size_t)s->P * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   s->cur = 0;
+  s->tiled.lin_valid = false;   // a run starts with a full point pass at the uploaded point
   return RSBA_OK;
 }
 
@@ -630,11 +635,25 @@ void TiledSchur::LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTim
   T.Begin("k_point_pass", st);
   if (stage)
     k_point_pass<true><<<grid_pp, 256, lds, st>>>(C, P, s->sliced(), s->camc[x], s->pts[x], s->scale_p, ptdata,
-                                                  block_scal, cm_pos, sq_cm, ip);
+                                                  block_scal, cm_pos, sq_cm2[x], lin2[x], ip);
   else
     k_point_pass<false><<<grid_pp, 256, lds, st>>>(C, P, s->sliced(), s->camc[x], s->pts[x], s->scale_p, ptdata,
-                                                   block_scal, cm_pos, sq_cm, ip);
+                                                   block_scal, cm_pos, sq_cm2[x], lin2[x], ip);
   T.End(st);
+}
+
+void TiledSchur::LaunchPointDamp(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st) {
+  const int x = s->cur;
+  T.Begin("k_point_damp", st);
+  k_point_damp<<<grid_pp, 256, 0, st>>>(P, s->pts[x], s->scale_p, lin2[x], ptdata, block_scal, ip);
+  T.End(st);
+}
+
+// The point side of a step: a full pass over the observation records only when x has no linearisation yet (the first
+// step of a run, or RSBA_FUSED_LIN=0); otherwise the kept one is damped with this step's radius.
+static void LaunchPointSide(TiledSchur& ts, rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st) {
+  if (ts.lin_valid && !ip.first) ts.LaunchPointDamp(s, ip, T, st);
+  else ts.LaunchPointPass(s, ip, T, st);
 }
 
 // The Schur elimination launch: self segments first, then the pair tiles stage by stage; results land in s->red.
@@ -643,7 +662,7 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   const int x = s->cur;
   SchurArgs a;
   a.C = ts.C; a.P = ts.P; a.nwords = ts.nwords; a.camc = s->camc[x]; a.cam_free = s->cam_free; a.segs = ts.segs; a.cam_mask = ts.cam_mask; a.ptdata = ts.ptdata;
-  a.cam_prefix = ts.cam_prefix; a.cam_ptr = ts.cam_ptr; a.sq_cm = ts.sq_cm; a.u_cm = ts.u_cm; a.v_cm = ts.v_cm; a.partial = ts.partial;
+  a.cam_prefix = ts.cam_prefix; a.cam_ptr = ts.cam_ptr; a.sq_cm = ts.sq_cm2[x]; a.u_cm = ts.u_cm; a.v_cm = ts.v_cm; a.partial = ts.partial;
   a.grp_sum = ts.grp_sum; a.sync_cnt = ts.sync_cnt; a.ngrp = ts.ngrp; a.ntiles = ts.ntiles; a.block_seg = ts.block_seg; a.last_group = ts.ngroups - 1; a.tile_sum = ts.tile_sum;
   a.tree_error = ts.tree_error; a.ticket = ts.tree_error + 1;
   a.ready = ts.ready; a.tag = tag; a.self_only = 0; a.red = s->red; a.L = s->L; a.nblocks_pp = ts.grid_pp; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
@@ -671,7 +690,7 @@ void TiledSchur::LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTime
 
 int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
   hipStream_t st = s->stream;
-  LaunchPointPass(s, ip, T, st);
+  LaunchPointSide(*this, s, ip, T, st);
   LaunchTiles(s, ip, T, st, 0);
   return RSBA_OK;
 }
@@ -749,7 +768,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(n)) * sizeof(double);
     // the point pass first: it is the head of the critical path; the Cholesky (which must be resident before the
     // Schur kernel fills the chip) goes out while it runs
-    ts.LaunchPointPass(s, ip, T, st);
+    LaunchPointSide(ts, s, ip, T, st);
     if (s->trace) s->host_t[1] = std::chrono::steady_clock::now();
     const bool mg = s->pipelined_mg;
     // multi-GPU: the gates open on the flags the communication stream publishes after each stage's all-reduce, the
@@ -861,14 +880,23 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   int* fin_cnt = s->comm ? nullptr : s->chol_ok + 1;
   {
     const size_t lds_b = (size_t)C * (2 * RSBA_CC_LDS + 6) * sizeof(double);
-    if (lds_b <= 60 * 1024)
-      k_backsub_candidate<true><<<s->grid_pts, 256, lds_b, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
-                                                                 s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0,
-        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag, pipe && T.all_kernels() ? s->chol_waited + 1 : nullptr, s->chol_ok + 2);
-    else
-      k_backsub_candidate<false><<<s->grid_pts, 256, 0, st>>>(C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x],
-                                                              s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, s->res, s->res_host, s->res_seq + 1.0,
-        pipe ? s->tiled.ready + 15 : nullptr, s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag, pipe && T.all_kernels() ? s->chol_waited + 1 : nullptr, s->chol_ok + 2);
+    const bool fused = s->opt.schur_impl != 0 && s->fused_lin;
+    const FusedLin fl = fused ? FusedLin{s->tiled.lin2[x], s->tiled.lin2[c], s->tiled.cm_pos, s->tiled.sq_cm2[c]} : FusedLin{nullptr, nullptr, nullptr, nullptr};
+    const int* solve_done = pipe ? s->tiled.ready + 15 : nullptr;
+    const int solve_tag = s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag;
+    long long* waited = pipe && T.all_kernels() ? s->chol_waited + 1 : nullptr;
+#define RSBA_BACKSUB_ARGS C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x], s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, \
+                          s->res, s->res_host, s->res_seq + 1.0, solve_done, solve_tag, waited, s->chol_ok + 2, fl
+    if (lds_b <= 60 * 1024) {
+      if (fused) k_backsub_candidate<true, true><<<s->grid_pts, 256, lds_b, st>>>(RSBA_BACKSUB_ARGS);
+      else k_backsub_candidate<true, false><<<s->grid_pts, 256, lds_b, st>>>(RSBA_BACKSUB_ARGS);
+    } else {
+      if (fused) k_backsub_candidate<false, true><<<s->grid_pts, 256, 0, st>>>(RSBA_BACKSUB_ARGS);
+      else k_backsub_candidate<false, false><<<s->grid_pts, 256, 0, st>>>(RSBA_BACKSUB_ARGS);
+    }
+#undef RSBA_BACKSUB_ARGS
+    // a completed step leaves lin2[x] (point pass or an earlier candidate) and lin2[c] (this candidate) in place
+    if (fused) s->tiled.lin_valid = true;
   }
   T.End(st);
   DebugSync(st, "k_backsub_candidate");
@@ -987,7 +1015,7 @@ static int PointsGradient(rsba_solver* s, double radius) {
                                                                   s->red, s->L, s->gmax, s->block_scal, ip);
     k_finish_linearize<<<1, 256, 0, st>>>(s->grid_lin, s->block_scal, s->red, s->L, s->gmax);
   } else {
-    s->tiled.LaunchPointPass(s, ip, T, st);
+    LaunchPointSide(s->tiled, s, ip, T, st);
     s->tiled.LaunchSelfOnly(s, ip, T, st);
   }
   if (s->comm) {
