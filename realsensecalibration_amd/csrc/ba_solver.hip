@@ -167,6 +167,7 @@ struct rsba_solver {
   int max_views = 0;
   RedLayout L{0};
   std::vector<int64_t> order;       // sorted position -> original observation index
+  std::vector<int> pt_perm;         // device position of a point -> its index in the problem (empty: identity); BalancedPointOrder
   double *obs_u = nullptr, *obs_v = nullptr, *intr = nullptr;
   // sliced-ELL copy of the observations for the point-centric kernels (ObsSliced)
   int *sl_row_ptr = nullptr, *sl_cam = nullptr;
@@ -199,6 +200,116 @@ namespace rsba {
 // ------------------------------------------------------------------------------------------------
 // Static structure of the tiled Schur kernel: visibility bitsets, tiles, segments.
 // ------------------------------------------------------------------------------------------------
+// Word bounds of the segments one PAIR tile's points are cut into (ns + 1 values, in 64-point mask words): the same for
+// every pair tile.  Shared by TiledSchur::Build and by the point ordering below (whose units are these segments' chunks).
+static int DeviceCUs() {
+  int cus = 256;
+  hipDeviceProp_t prop; int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  return cus;
+}
+static std::vector<int> SegmentBounds(int nW, int ns) {
+  // Optional tapered segments (RSBA_TAPER > 1: the first of a tile is that many times as long as the last).  A stage is
+  // over when its last block is, so long-blocks-first should end it earlier; measured, it does not (a stage is only
+  // ~1-2 "rounds" of slots deep and two blocks share a CU's VALU, so a block's duration follows its CU-mate more than
+  // its own length).  Default off.
+  const double taper = getenv("RSBA_TAPER") ? atof(getenv("RSBA_TAPER")) : 1.0;
+  std::vector<int> bound(ns + 1, 0);
+  const double hi = 2.0 * taper / (taper + 1.0), lo = 2.0 - hi;
+  double cum = 0.0;
+  for (int i = 0; i < ns; ++i) { cum += ns > 1 ? hi - (hi - lo) * i / (ns - 1) : 1.0; bound[i + 1] = (int)std::llround(nW * cum / ns); }
+  bound[ns] = nW;
+  bool ok = true;
+  for (int i = 0; i < ns; ++i) ok = ok && bound[i + 1] > bound[i];
+  if (!ok) for (int i = 0; i <= ns; ++i) bound[i] = (int)((int64_t)nW * i / ns);
+  return bound;
+}
+static int PairSegmentsPerTile(int C, int P, bool staged) {
+  const int ngroups = (C + RSBA_TG - 1) / RSBA_TG;
+  int npair_tiles = 0;
+  for (int ga = 0; ga < ngroups; ++ga) for (int gb = ga; gb < ngroups; ++gb) if (!(ga == gb && std::min(RSBA_TG, C - RSBA_TG * ga) < 2)) ++npair_tiles;
+  // measured at 64 cameras: the pipelined schedule likes shorter workgroups (a stage ends with its last one), the
+  // sequential one fewer partial sums
+  const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : (staged ? 8 : 4);
+  const int target = seg_per_cu * DeviceCUs();
+  const int nW = (P + 63) / 64;
+  const int ns = (int)std::lround((double)target / std::max(1, npair_tiles));
+  return std::max(1, std::min(ns, nW));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Point order for the tiled Schur kernel.
+//
+// A lane of a pair tile walks the points its two cameras share, chunk by chunk (RSBA_CHUNK points of one segment), and
+// a wavefront runs as many trips per chunk as its busiest lane: with the points in file order the hit counts of the
+// 64 pairs of a wave are Binomial(~490, (k/C)^2) — at 64 cameras x 20 views the busiest lane has 38 % more hits than the
+// mean, i.e. 26 % of the lane-trips of the dominant kernel are masked off.  Which point sits in which chunk is free (points are
+// independent given the cameras), so the points are dealt to the chunks such that every camera PAIR gets about the same
+// number of shared points in every chunk: greedily, each point (in a fixed pseudo-random order) goes to the best of a
+// few candidate chunks, "best" = fewest points so far that share a pair with it, relative to the chunk's fill.
+// Measured on the 64 x 100k x 20 problem: lane utilisation of the pair tiles 74 % -> 86 % for ~0.5 s of set-up.
+// The permutation is internal: parameters are uploaded / downloaded through it, nothing the caller sees changes order.
+// Deterministic (fixed seed): two solvers of the same problem add in the same order.
+// Returns perm (position -> original point); empty = keep the file order.
+// ------------------------------------------------------------------------------------------------
+static std::vector<int> BalancedPointOrder(int C, int P, bool staged, const std::vector<int>& ptr, const std::vector<int>& cam) {
+  const char* env = getenv("RSBA_BALANCE");
+  const int mode = env ? atoi(env) : 1;
+  if (mode == 0 || C < 2 || P < 4 * RSBA_CHUNK) return {};
+  const int nW = (P + 63) / 64;
+  const std::vector<int> bound = SegmentBounds(nW, PairSegmentsPerTile(C, P, staged));
+  // units: the chunks the pair tiles synchronise on
+  std::vector<int> ubeg, ucap;
+  for (size_t i = 0; i + 1 < bound.size(); ++i)
+    for (int w = bound[i]; w < bound[i + 1]; w += RSBA_CW) {
+      const int we = std::min(w + RSBA_CW, bound[i + 1]);
+      ubeg.push_back(64 * w);
+      ucap.push_back(std::min(64 * we, P) - 64 * w);
+    }
+  const int nu = (int)ubeg.size();
+  if (nu < 2 || (double)nu * C * C > 3e8) return {};   // (the pair counters: 2 bytes per unit and camera pair)
+  const int64_t N = ptr[P];
+  const double pairs_per_point = N > 0 ? 0.5 * ((double)N / P) * ((double)N / P) : 1.0;
+  // candidates per point: bounded work (~6e8 counter reads), at least 2, at most 32 (or RSBA_BALANCE = number)
+  int D = mode > 1 ? mode : (int)std::max(2.0, std::min(32.0, 6e8 / (std::max(1.0, pairs_per_point) * P)));
+  D = std::min(D, nu);
+  std::vector<uint16_t> cnt((size_t)nu * C * C, 0);   // [unit][a][b], a < b
+  std::vector<int> fill(nu, 0), unit_of(P, 0);
+  // fixed pseudo-random visiting order and candidate choice (splitmix64)
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { uint64_t z = (st += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+  std::vector<int> visit(P);
+  for (int j = 0; j < P; ++j) visit[j] = j;
+  for (int j = P - 1; j > 0; --j) std::swap(visit[j], visit[(size_t)(rnd() % (uint64_t)(j + 1))]);
+  int open_from = 0;   // all units below are full
+  for (int j : visit) {
+    const int b = ptr[j], k = ptr[j + 1] - b;
+    const int* cj = cam.data() + b;
+    int best = -1; double best_s = 0.0;
+    for (int d = 0, tries = 0; d < D || best < 0; ++tries) {
+      int g;
+      if (tries < 4 * D) { g = (int)(rnd() % (uint64_t)nu); if (fill[g] >= ucap[g]) continue; }
+      else { while (open_from < nu && fill[open_from] >= ucap[open_from]) ++open_from; g = open_from; for (; g < nu && fill[g] >= ucap[g]; ++g) {} if (g >= nu) break; }
+      ++d;
+      const uint16_t* c = &cnt[(size_t)g * C * C];
+      long sum = 0;
+      for (int x = 0; x < k; ++x) { const uint16_t* row = c + (size_t)cj[x] * C; for (int y = x + 1; y < k; ++y) sum += row[cj[y]]; }
+      const double sc = (double)sum / (double)(fill[g] + 1);
+      if (best < 0 || sc < best_s) { best = g; best_s = sc; }
+      if (tries >= 4 * D) break;
+    }
+    if (best < 0) return {};   // cannot happen: the capacities add up to P
+    uint16_t* c = &cnt[(size_t)best * C * C];
+    for (int x = 0; x < k; ++x) { uint16_t* row = c + (size_t)cj[x] * C; for (int y = x + 1; y < k; ++y) if (row[cj[y]] != 0xFFFF) ++row[cj[y]]; }
+    unit_of[j] = best; ++fill[best];
+  }
+  // positions: the points of a unit in ascending original order
+  std::vector<int> next(ubeg), perm(P, -1);
+  for (int j = 0; j < P; ++j) perm[next[unit_of[j]]++] = j;
+  for (int q = 0; q < P; ++q) if (perm[q] < 0) return {};
+  return perm;
+}
+
 int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
                       const std::vector<int>& sliced_q, bool staged) {
   C = C_; P = P_;
@@ -229,12 +340,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   }
   for (int ga = 0; ga < ngroups; ++ga) { tab.push_back(ga); tab.push_back(ga); tab.push_back(1); wt.push_back(0.25); }
   ntiles = (int)wt.size();
-  int cus = 256;
-  { hipDeviceProp_t prop; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
-  // measured at 64 cameras: the pipelined schedule likes shorter workgroups (a stage ends with its last one), the
-  // sequential one fewer partial sums
-  const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : (staged ? 8 : 4);
-  const int target = seg_per_cu * cus;
+  const int cus = DeviceCUs();
   // the pair tiles share `target` workgroups, same number for every tile; the self tiles (much lighter) get 2 per CU in
   // total.  (Sizing each stage's workgroups to whole rounds of slots was tried for the pipelined schedule: no gain, and
   // the two schedules would no longer add in the same order.)
@@ -246,24 +352,9 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   stage_tile.assign(nstages + 1, 0); stage_seg.assign(nstages + 1, 0);
   for (int t = 0; t < ntiles; ++t) {
     const bool self = tab[3 * t + 2] != 0;
-    int ns = self ? (2 * cus + ngroups - 1) / ngroups : (int)std::lround((double)target / std::max(1, npair_tiles));
     const int nW = (P + 63) / 64;  // mask words that hold points
-    ns = std::max(1, std::min(ns, nW));
-    // Optional tapered segments (RSBA_TAPER > 1: the first of a tile is that many times as long as the last).  A stage is
-    // over when its last block is, so long-blocks-first should end it earlier; measured, it does not (a stage is only
-    // ~1-2 "rounds" of slots deep and two blocks share a CU's VALU, so a block's duration follows its CU-mate more than
-    // its own length).  Default off.
-    const double taper = getenv("RSBA_TAPER") ? atof(getenv("RSBA_TAPER")) : 1.0;
-    std::vector<int> bound(ns + 1, 0);
-    {
-      const double hi = 2.0 * taper / (taper + 1.0), lo = 2.0 - hi;
-      double cum = 0.0;
-      for (int i = 0; i < ns; ++i) { cum += ns > 1 ? hi - (hi - lo) * i / (ns - 1) : 1.0; bound[i + 1] = (int)std::llround(nW * cum / ns); }
-      bound[ns] = nW;
-      bool ok = true;
-      for (int i = 0; i < ns; ++i) ok = ok && bound[i + 1] > bound[i];
-      if (!ok) for (int i = 0; i <= ns; ++i) bound[i] = (int)((int64_t)nW * i / ns);
-    }
+    const int ns = self ? std::max(1, std::min((2 * cus + ngroups - 1) / ngroups, nW)) : PairSegmentsPerTile(C, P, staged);
+    const std::vector<int> bound = SegmentBounds(nW, ns);
     for (int i = 0; i < ns; ++i) {
       SchurSeg e; memset(&e, 0, sizeof(e));
       e.ga = tab[3 * t]; e.gb = tab[3 * t + 1]; e.self = tab[3 * t + 2];
@@ -493,6 +584,60 @@ static int UploadPoints(rsba_solver* s) {
   std::vector<double> u(N), v(N);
   std::vector<int> cam(N);
   for (int64_t q = 0; q < N; ++q) { const int64_t i = s->order[q]; u[q] = p.observations[2 * i]; v[q] = p.observations[2 * i + 1]; cam[q] = p.camera_index[i]; }
+  int rc;
+  if (s->opt.schur_impl != 0) {
+    // the tiled kernel keeps one visibility bit per (camera, point): a camera observing the same point
+    // twice needs the reference kernel (still on the GPU)
+    bool dup = false;
+    for (int j = 0; j < P && !dup; ++j) for (int q = ptr[j] + 1; q < ptr[j + 1]; ++q) if (cam[q] == cam[q - 1]) { dup = true; break; }
+    if (dup) s->opt.schur_impl = 0;
+  }
+  if (s->opt.schur_impl != 0) {
+    if (getenv("RSBA_TRACE") && s->nc <= RSBA_CHOL_MAXN) {   // the 32 slots are laid out for at most four stages (64 cameras)
+      // diagnostics: wall-clock stamps of the step (1) and of every block of the Schur kernel (2)
+      if (hipMalloc((void**)&s->trace, 32 * sizeof(long long)) != hipSuccess || hipMemset(s->trace, 0, 32 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
+      if (atoi(getenv("RSBA_TRACE")) == 2 && hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
+    }
+    s->pipelined = SetupPipeline(s);
+    s->fused_lin = !(getenv("RSBA_FUSED_LIN") && atoi(getenv("RSBA_FUSED_LIN")) == 0);
+  }
+  {
+    // Multi-GPU: the pipelined schedule issues other collectives than the sequential one, so the ranks have to agree.
+    // Every rank with a communicator takes part in this one all-reduce (min), whatever its own answer was (a shard
+    // with duplicate observations runs schur_impl 0 and cannot pipeline); it is also the communicator's first
+    // collective, so connection set-up happens here and not inside a step.
+    const char* e1 = getenv("RSBA_PIPELINE"); const char* e2 = getenv("RSBA_PIPELINE_MG");
+    const bool mg_possible = s->comm && !(e1 && atoi(e1) == 0) && (e2 && atoi(e2) == 1);
+    if (mg_possible) {
+      int h = s->pipelined ? 1 : 0, *d = nullptr;
+      if ((rc = DevAlloc(&d, 1))) return rc;
+      HIPCHK(hipMemcpy(d, &h, sizeof(int), hipMemcpyHostToDevice));
+      NCCLCHK(ncclAllReduce(d, d, 1, ncclInt32, ncclMin, s->comm, s->stream));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      HIPCHK(hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost));
+      (void)hipFree(d);
+      if (!h) { s->pipelined = false; s->pipelined_mg = false; }
+    }
+  }
+  if (s->opt.schur_impl != 0) {
+    // chunk-balanced point order for the tiled kernel (BalancedPointOrder): everything below is laid out in it
+    const auto tb0 = std::chrono::steady_clock::now();
+    std::vector<int> perm = BalancedPointOrder(C, P, s->pipelined, ptr, cam);
+    if (!perm.empty()) {
+      std::vector<int> ptr2(P + 1, 0), cam2(N);
+      std::vector<double> u2(N), v2(N);
+      std::vector<int64_t> order2(N);
+      for (int jn = 0; jn < P; ++jn) ptr2[jn + 1] = ptr2[jn] + (ptr[perm[jn] + 1] - ptr[perm[jn]]);
+      for (int jn = 0; jn < P; ++jn) {
+        const int b0 = ptr[perm[jn]], n = ptr[perm[jn] + 1] - b0, d0 = ptr2[jn];
+        for (int t = 0; t < n; ++t) { u2[d0 + t] = u[b0 + t]; v2[d0 + t] = v[b0 + t]; cam2[d0 + t] = cam[b0 + t]; order2[d0 + t] = s->order[b0 + t]; }
+      }
+      ptr.swap(ptr2); cam.swap(cam2); u.swap(u2); v.swap(v2); s->order.swap(order2);
+      s->pt_perm.swap(perm);
+    }
+    if (getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: point order %s in %.3f s\n", s->pt_perm.empty() ? "kept" : "balanced over the Schur kernel's chunks",
+                                      std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count());
+  }
 
   // sliced-ELL layout: slice = 64 consecutive points, as wide as its widest point
   const int nslices = (P + 63) / 64;
@@ -511,7 +656,6 @@ static int UploadPoints(rsba_solver* s) {
       sl_q[e] = q; sl_cam[e] = cam[q]; sl_uv[2 * e] = u[q]; sl_uv[2 * e + 1] = v[q];
     }
 
-  int rc;
   if ((rc = DevAlloc(&s->obs_u, N)) || (rc = DevAlloc(&s->obs_v, N)) || (rc = DevAlloc(&s->obs_cam, N)) || (rc = DevAlloc(&s->pt_ptr, P + 1)) ||
       (rc = DevAlloc(&s->sl_row_ptr, nslices + 1)) || (rc = DevAlloc(&s->sl_cam, sl_elems)) || (rc = DevAlloc(&s->sl_uv, sl_elems)) ||
       (rc = DevAlloc(&s->intr, 4 * C)) || (rc = DevAlloc(&s->cam[0], 6 * C)) || (rc = DevAlloc(&s->cam[1], 6 * C)) || (rc = DevAlloc(&s->cam0, 6 * C)) ||
@@ -534,33 +678,24 @@ static int UploadPoints(rsba_solver* s) {
   HIPCHK(hipMemcpy(s->sl_uv, sl_uv.data(), sl_elems * sizeof(double2), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->intr, p.intrinsics.data(), 4 * C * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->cam0, p.parameters.data(), 6 * C * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(s->pts0, p.parameters.data() + 6 * C, 3 * (size_t)P * sizeof(double), hipMemcpyHostToDevice));
+  if (s->pt_perm.empty()) {
+    HIPCHK(hipMemcpy(s->pts0, p.parameters.data() + 6 * C, 3 * (size_t)P * sizeof(double), hipMemcpyHostToDevice));
+  } else {
+    std::vector<double> xp(3 * (size_t)P);
+    const double* src = p.parameters.data() + 6 * C;
+    for (int jn = 0; jn < P; ++jn) { const size_t o = 3 * (size_t)s->pt_perm[jn]; xp[3 * (size_t)jn] = src[o]; xp[3 * (size_t)jn + 1] = src[o + 1]; xp[3 * (size_t)jn + 2] = src[o + 2]; }
+    HIPCHK(hipMemcpy(s->pts0, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   // launch geometry: fixed grids (deterministic second-stage reductions depend only on these)
   s->grid_lin = std::max(1, std::min((P + 3) / 4, 2048));
   s->grid_pts = std::max(1, std::min((P + 255) / 256, 2048));
   if ((rc = DevAlloc(&s->block_scal, 4 * (size_t)std::max(s->grid_lin, 4096))) || (rc = DevAlloc(&s->block_part, 8 * (size_t)s->grid_pts))) return rc;
-  if (s->opt.schur_impl != 0) {
-    // the tiled kernel keeps one visibility bit per (camera, point): a camera observing the same point
-    // twice needs the reference kernel (still on the GPU)
-    bool dup = false;
-    for (int j = 0; j < P && !dup; ++j) for (int q = ptr[j] + 1; q < ptr[j + 1]; ++q) if (cam[q] == cam[q - 1]) { dup = true; break; }
-    if (dup) s->opt.schur_impl = 0;
-  }
   // dynamic LDS above 48 KB has to be asked for, once
   if (s->nc <= RSBA_CHOL_MAXN) {
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(s->nc)) * sizeof(double);
     if (lds_c > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
   } else {
     HIPCHK(hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CholStepLdsDoubles() * sizeof(double))));
-  }
-  if (s->opt.schur_impl != 0) {
-    if (getenv("RSBA_TRACE") && s->nc <= RSBA_CHOL_MAXN) {   // the 32 slots are laid out for at most four stages (64 cameras)
-      // diagnostics: wall-clock stamps of the step (1) and of every block of the Schur kernel (2)
-      if (hipMalloc((void**)&s->trace, 32 * sizeof(long long)) != hipSuccess || hipMemset(s->trace, 0, 32 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
-      if (atoi(getenv("RSBA_TRACE")) == 2 && hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
-    }
-    s->pipelined = SetupPipeline(s);
-    s->fused_lin = !(getenv("RSBA_FUSED_LIN") && atoi(getenv("RSBA_FUSED_LIN")) == 0);
   }
   {
     // several workgroups for the reduced system: 32 to 64 cameras (padded to whole 32-wide panels), full symmetric S
@@ -591,24 +726,6 @@ static int UploadPoints(rsba_solver* s) {
       }
     }
   }
-  {
-    // Multi-GPU: the pipelined schedule issues other collectives than the sequential one, so the ranks have to agree.
-    // Every rank with a communicator takes part in this one all-reduce (min), whatever its own answer was (a shard
-    // with duplicate observations runs schur_impl 0 and cannot pipeline); it is also the communicator's first
-    // collective, so connection set-up happens here and not inside a step.
-    const char* e1 = getenv("RSBA_PIPELINE"); const char* e2 = getenv("RSBA_PIPELINE_MG");
-    const bool mg_possible = s->comm && !(e1 && atoi(e1) == 0) && (e2 && atoi(e2) == 1);
-    if (mg_possible) {
-      int h = s->pipelined ? 1 : 0, *d = nullptr;
-      if ((rc = DevAlloc(&d, 1))) return rc;
-      HIPCHK(hipMemcpy(d, &h, sizeof(int), hipMemcpyHostToDevice));
-      NCCLCHK(ncclAllReduce(d, d, 1, ncclInt32, ncclMin, s->comm, s->stream));
-      HIPCHK(hipStreamSynchronize(s->stream));
-      HIPCHK(hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost));
-      (void)hipFree(d);
-      if (!h) { s->pipelined = false; s->pipelined_mg = false; }
-    }
-  }
   if (s->opt.schur_impl != 0) {
     rc = s->tiled.Build(C, P, ptr, cam, u, v, sl_q, s->pipelined);
     if (rc != RSBA_OK) return rc;
@@ -616,6 +733,16 @@ static int UploadPoints(rsba_solver* s) {
     fprintf(stderr, "rsba: schur_impl=0 handles at most 64 views per point (problem has %d)\n", maxk);
     return RSBA_ERR_UNSUPPORTED;
   }
+  return RSBA_OK;
+}
+
+// Device point array (3P, in the solver's internal point order) -> dst in the problem's own order.
+static int DownloadPoints(const rsba_solver* s, const double* dev, double* dst) {
+  const size_t P = (size_t)s->P;
+  if (s->pt_perm.empty()) return hipMemcpy(dst, dev, 3 * P * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? RSBA_OK : RSBA_ERR_HIP;
+  std::vector<double> xp(3 * P);
+  if (hipMemcpy(xp.data(), dev, 3 * P * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return RSBA_ERR_HIP;
+  for (size_t jn = 0; jn < P; ++jn) { const size_t o = 3 * (size_t)s->pt_perm[jn]; dst[o] = xp[3 * jn]; dst[o + 1] = xp[3 * jn + 1]; dst[o + 2] = xp[3 * jn + 2]; }
   return RSBA_OK;
 }
 
@@ -1301,8 +1428,7 @@ int rsba_solver_download(rsba_solver* s) {
   rsba_problem& p = *s->prob;
   if (p.model == RSBA_MODEL_POINTS) {
     if (hipMemcpy(p.parameters.data(), s->cam[s->cur], 6 * s->C * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return RSBA_ERR_HIP;
-    if (hipMemcpy(p.parameters.data() + 6 * s->C, s->pts[s->cur], 3 * (size_t)s->P * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return RSBA_ERR_HIP;
-    return RSBA_OK;
+    return rsba::DownloadPoints(s, s->pts[s->cur], p.parameters.data() + 6 * s->C);
   }
   return s->eliminate_times ? s->marker_schur.Download(&p) : s->marker.Download(&p);
 }
@@ -1445,7 +1571,7 @@ int rsba_points_linearize_and_step(rsba_problem* p, const rsba_options* o, doubl
     if (delta) {
       std::vector<double> xc(6 * s->C + 3 * (size_t)s->P);
       if (hipMemcpy(xc.data(), s->cam[1 - s->cur], 6 * s->C * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RSBA_ERR_HIP;
-      if (hipMemcpy(xc.data() + 6 * s->C, s->pts[1 - s->cur], 3 * (size_t)s->P * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RSBA_ERR_HIP;
+      if (rsba::DownloadPoints(s, s->pts[1 - s->cur], xc.data() + 6 * s->C) != RSBA_OK) rc = RSBA_ERR_HIP;
       for (size_t i = 0; i < xc.size(); ++i) delta[i] = xc[i] - p->parameters[i];
     }
     if (scalars) {

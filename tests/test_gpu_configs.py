@@ -194,3 +194,26 @@ def test_two_rank_solve_matches_unsharded_oracle(oracle, tmp_path):
     for case in res["cases"]:
         assert case["same_iterations"] and case["same_stop_reason"] and case["same_accept_reject"], case
         assert case["max_block_rel"] < 1e-6 and case["cost_rel"] < 1e-9, case
+
+
+# ------------------------------------------------------------------ internal point order
+@pytest.mark.parametrize("C,P,k,huber", [(24, 6000, 8, 0.0), (40, 9000, 10, 1.0), (70, 5000, 9, 0.0)])
+def test_balanced_point_order_is_internal(oracle, C, P, k, huber, monkeypatch):
+    """The tiled Schur kernel deals the points to its chunks so that every camera pair has about the same number of shared
+    points per chunk (BalancedPointOrder).  The permutation must not be visible: same trajectory and same parameter
+    blocks, in the caller's order, as with the file order (RSBA_BALANCE=0) and as the oracle; the stage-level step too."""
+    prob = syn.make_problem(C, P, k, seed=90 + C, outlier_frac=0.05 if huber else 0.0)
+    ref, s_ref, log_ref = oracle.solve_points(prob, oracle.options(huber_delta=huber, num_threads=_threads()))
+    got, s_got, log_got = capi.solve_points(prob, capi.default_options(huber_delta=huber))
+    a = capi.points_linearize_and_step(prob, 1e4, capi.default_options(huber_delta=huber))
+    monkeypatch.setenv("RSBA_BALANCE", "0")
+    plain, s_plain, log_plain = capi.solve_points(prob, capi.default_options(huber_delta=huber))
+    b = capi.points_linearize_and_step(prob, 1e4, capi.default_options(huber_delta=huber))
+    for x, sx, lx in ((got, s_got, log_got), (plain, s_plain, log_plain)):
+        assert (sx.num_iterations, sx.stop_reason) == (s_ref.num_iterations, s_ref.stop_reason)
+        assert np.array_equal(lx[:, 7], log_ref[:, 7])
+        assert _block_rel(x, ref, C) < 1e-6
+        assert abs(sx.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
+    assert _block_rel(got, plain, C) < 1e-8
+    assert np.abs(a["delta"] - b["delta"]).max() < 1e-9 * np.abs(b["delta"]).max()
+    assert np.abs(a["S"] - b["S"]).max() < 1e-11 * np.abs(b["S"]).max()
