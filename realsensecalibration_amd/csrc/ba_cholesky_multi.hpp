@@ -24,6 +24,12 @@
 namespace rsba {
 
 #define RSBA_MC_MAXG 6
+#ifndef RSBA_MC_NPF
+#define RSBA_MC_NPF 3         // 32-column slabs of a 16-row half in flight in the row update (4 spills registers)
+#endif
+#ifndef RSBA_MC_NPF_FUSED
+#define RSBA_MC_NPF_FUSED 1   // ... fetched ahead of the strip by the fused update + look-ahead of the next diagonal block (two operand streams; 2 spills, and a spill costs more than the round trip it hides)
+#endif
 
 struct MultiCholFlags {
   int* tdone;         // [16]  == tag when panel p's L11 / T are in global memory
@@ -143,6 +149,15 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
   const double inv_radius = 1.0 / ip.radius;
   const int mi = lane & 15, kk = lane >> 4;
 
+  // Pipelined: the kernel is resident long before its first columns exist.  The diagonal factorisation is ~15 KB of
+  // straight-line code whose first execution on a CU ran 2 - 5 us longer than the later ones (instruction cache): wave 0
+  // of every workgroup runs it once on an identity block while there is nothing to do anyway.
+  if (gate.ready != nullptr && !ip.first) {
+    for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) { const int r = e >> 5, c = e & 31; Pre[r * RSBA_PLD + c] = r == c ? 1.0 : 0.0; }
+    __syncthreads();
+    if (wave == 0) (void)DiagFactorInverseCall((lds_double*)Pre, RSBA_PB, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane);
+    __syncthreads();
+  }
   // pipelined first iteration: the Jacobi scale needs the whole damping diagonal
   if (gate.ready != nullptr && ip.first) {
     for (int g = 0; g * gate.cols < nreal; ++g)
@@ -180,6 +195,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
   for (int p = 0; p < np && !stalled; ++p) {
     const int kb = p * RSBA_PB;
     RSBA_MC_STAMP(0);
+    bool s_pending = false;   // the next diagonal block still lacks its entries of S (added after this panel's X)
     // this workgroup's blocks b >= p: b = first, first + G, ...
     const int first = p + ((w - p % G) + G) % G;
     const int nown = first > np ? 0 : (np - first) / G + 1;
@@ -192,53 +208,63 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
     // A wave loads what it updates itself: no workgroup barrier in between.
     // (ks, nsplit): this wave's slice of the K range; slice 0 owns the rows in Pan, the others leave their products in
     // `part` (slot pslot) for slice 0 to add in a fixed order after the barrier.
-    auto load_update_half = [&](int hb, int ks, int nsplit, int pslot) {
+    auto load_update_half = [&](int hb, int ks, int nsplit, double* pdst /* 16 x 32 partial tile of a slice ks > 0 */) {
       const int j = hb >> 1, b = first + j * G;
       const int prow = j * RSBA_PB + (hb & 1) * 16;
-      if (ks == 0) {
-        const int r = lane >> 2, c0 = (lane & 3) * 8;
-        const int gi = b * RSBA_PB + (hb & 1) * 16 + r;
-        double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (gi < nreal) {
-          if (kb + c0 + 8 <= nreal) {
-            const double2* sp = reinterpret_cast<const double2*>(S + (size_t)gi * nreal + kb + c0);
+      // all global loads of the item are issued before anything waits for one of them (every dependent round trip costs
+      // ~2 us beside the Schur kernel): the panel's columns of S first, then the first slabs of the rows of L
+      const int sr = lane >> 2, sc0 = (lane & 3) * 8;
+      const int sgi = b * RSBA_PB + (hb & 1) * 16 + sr;
+      double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ks == 0 && sgi < nreal) {
+        if (kb + sc0 + 8 <= nreal) {
+          const double2* sp = reinterpret_cast<const double2*>(S + (size_t)sgi * nreal + kb + sc0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const double2 t = sp[u]; v[2 * u] = t.x; v[2 * u + 1] = t.y; }
-          } else {
+          for (int u = 0; u < 4; ++u) { const double2 t = sp[u]; v[2 * u] = t.x; v[2 * u + 1] = t.y; }
+        } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = Sat(gi, kb + c0 + u);   // the padded last panel
-          }
+          for (int u = 0; u < 8; ++u) v[u] = Sat(sgi, kb + sc0 + u);   // the padded last panel
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) Pan[(prow + r) * RSBA_PLD + c0 + u] = gi <= n ? sys(gi, kb + c0 + u, v[u]) : 0.0;
       }
-      __builtin_amdgcn_wave_barrier();
-      if (p == 0) return;
       const int nq = kb / RSBA_PB, qper = (nq + nsplit - 1) / nsplit;
       const int qa = ks * qper * RSBA_PB, qb = min(kb, (ks + 1) * qper * RSBA_PB);   // this slice's columns
       const int grow = b * RSBA_PB + (hb & 1) * 16 + mi;
       const bool gl = grow <= n;
       const double* arow = A + (size_t)(gl ? grow : 0) * n + 8 * kk;
       d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-      double an[8], an2[8];
+      // RSBA_MC_NPF slabs of the rows in flight: the rows were written by other CUs a moment ago and come back at memory
+      // latency, so the length of this loop is (slabs / slabs in flight) round trips
+      double buf[RSBA_MC_NPF][8];
       auto fetch = [&](double (&d)[8], int q) {
         const double2* pa = reinterpret_cast<const double2*>(arow + q);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { const double2 t = pa[v]; d[2 * v] = gl ? t.x : 0.0; d[2 * v + 1] = gl ? t.y : 0.0; }
+        for (int v2 = 0; v2 < 4; ++v2) { const double2 t = pa[v2]; d[2 * v2] = gl ? t.x : 0.0; d[2 * v2 + 1] = gl ? t.y : 0.0; }
       };
-      if (qa < qb) fetch(an, qa);
-      if (qa + RSBA_PB < qb) fetch(an2, qa + RSBA_PB);
-      for (int q0 = qa; q0 < qb; q0 += RSBA_PB) {
-        double ac[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { ac[u] = an[u]; an[u] = an2[u]; }
-        if (q0 + 2 * RSBA_PB < qb) fetch(an2, q0 + 2 * RSBA_PB);
+      for (int i = 0; i < RSBA_MC_NPF; ++i) if (qa + i * RSBA_PB < qb) fetch(buf[i], qa + i * RSBA_PB);
+      if (ks == 0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const double b0 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + mi];
-          const double b1 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + 16 + mi];
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b1, acc1, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) Pan[(prow + sr) * RSBA_PLD + sc0 + u] = sgi <= n ? sys(sgi, kb + sc0 + u, v[u]) : 0.0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (p == 0) return;
+      for (int qg = qa; qg < qb; qg += RSBA_MC_NPF * RSBA_PB) {
+#pragma unroll
+        for (int i = 0; i < RSBA_MC_NPF; ++i) {
+          const int q0 = qg + i * RSBA_PB;
+          if (q0 < qb) {
+            double ac[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ac[u] = buf[i][u];
+            if (q0 + RSBA_MC_NPF * RSBA_PB < qb) fetch(buf[i], q0 + RSBA_MC_NPF * RSBA_PB);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const double b0 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + mi];
+              const double b1 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + 16 + mi];
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b1, acc1, 0, 0, 0);
+            }
+          }
         }
       }
 #pragma unroll
@@ -248,11 +274,120 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
           Pan[r * RSBA_PLD + mi] -= acc0[t];
           Pan[r * RSBA_PLD + 16 + mi] -= acc1[t];
         } else {
-          part[pslot * 512 + (kk + 4 * t) * 32 + mi] = acc0[t];
-          part[pslot * 512 + (kk + 4 * t) * 32 + 16 + mi] = acc1[t];
+          pdst[(kk + 4 * t) * 32 + mi] = acc0[t];
+          pdst[(kk + 4 * t) * 32 + 16 + mi] = acc1[t];
         }
       }
     };
+
+    // The NEXT owner's diagonal block (block p + 1, slot 0), half h, K slice ks of nf: ONE pass over its rows of L gives
+    // both the update of this panel's columns (rows x strip of block p, as load_update_half) and the look-ahead product
+    // L[block p+1, 0:kb] L[block p+1, 0:kb]' that the next factorisation needs (tile (h, h); the waves of half 1 also load
+    // half 0's rows for the cross tile (1, 0)).  The two used to be separate passes over the same rows — the look-ahead
+    // before the strip arrived, the update after it — and one CU streams such rows at memory latency: together they were
+    // the longest item of a panel (14.5 us against 9 us of factorisation on the owner), i.e. what the chain of panels
+    // waited for.  Two phases: fused_prefetch issues the first slabs' loads at the top of the panel (the rows are this
+    // workgroup's own and final; nothing of block p is needed for them), fused_consume runs once the strip is in LDS.
+    // Slices ks > 0 leave their products in the partial area `fp` (slice 0 keeps the rows in Pan); fixed order of addition
+    // below.  fp: diag tile (h, ks) at (h nf + ks) 256 | cross tile (ks) at (2 nf + ks) 256 | update (h, ks >= 1) at
+    // 3 nf 256 + (h (nf - 1) + ks - 1) 512.
+    double pf[2 * RSBA_MC_NPF_FUSED][8];   // [0, NPF): this half's rows, [NPF, 2 NPF): half 0's rows (cross tile)
+    auto fused_rows = [&](int h, double const*& ra, double const*& rz) {
+      const int nb0 = kb + RSBA_PB;
+      ra = A + (size_t)(nb0 + 16 * h + mi) * n + 8 * kk;     // this half's rows (row nb0 + 16 h + mi <= n - 1)
+      rz = A + (size_t)(nb0 + mi) * n + 8 * kk;              // half 0's rows
+    };
+    auto fused_fetch = [&](int h, int i, int q) {
+      const double *ra, *rz;
+      fused_rows(h, ra, rz);
+      const double2* pa = reinterpret_cast<const double2*>(ra + q);
+#pragma unroll
+      for (int v2 = 0; v2 < 4; ++v2) { const double2 t = pa[v2]; pf[i][2 * v2] = t.x; pf[i][2 * v2 + 1] = t.y; }
+      if (h == 1) {
+        const double2* pz = reinterpret_cast<const double2*>(rz + q);
+#pragma unroll
+        for (int v2 = 0; v2 < 4; ++v2) { const double2 t2 = pz[v2]; pf[RSBA_MC_NPF_FUSED + i][2 * v2] = t2.x; pf[RSBA_MC_NPF_FUSED + i][2 * v2 + 1] = t2.y; }
+      }
+    };
+    auto fused_range = [&](int ks, int nf, int& qa, int& qb) {
+      const int nq = kb / RSBA_PB, qper = (nq + nf - 1) / nf;
+      qa = ks * qper * RSBA_PB; qb = min(kb, (ks + 1) * qper * RSBA_PB);
+    };
+    auto fused_prefetch = [&](int h, int ks, int nf) {
+      int qa, qb;
+      fused_range(ks, nf, qa, qb);
+#pragma unroll
+      for (int i = 0; i < RSBA_MC_NPF_FUSED; ++i) if (qa + i * RSBA_PB < qb) fused_fetch(h, i, qa + i * RSBA_PB);
+    };
+    auto fused_consume = [&](int h, int ks, int nf, double* fp) {
+      const int nb0 = kb + RSBA_PB;
+      const int prow = h * 16;                       // slot 0
+      // the panel's columns of S for these rows (slice 0): issued now, used after the products
+      const int sr = lane >> 2, sc0 = (lane & 3) * 8;
+      const int sgi = nb0 + h * 16 + sr;             // < n: block p + 1 is a block of the matrix
+      double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ks == 0 && sgi < nreal) {
+        if (kb + sc0 + 8 <= nreal) {
+          const double2* sp = reinterpret_cast<const double2*>(S + (size_t)sgi * nreal + kb + sc0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const double2 t = sp[u]; v[2 * u] = t.x; v[2 * u + 1] = t.y; }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = Sat(sgi, kb + sc0 + u);
+        }
+      }
+      int qa, qb;
+      fused_range(ks, nf, qa, qb);
+      d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, dg = {0, 0, 0, 0}, cr = {0, 0, 0, 0};
+      for (int qg = qa; qg < qb; qg += RSBA_MC_NPF_FUSED * RSBA_PB) {
+#pragma unroll
+        for (int i = 0; i < RSBA_MC_NPF_FUSED; ++i) {
+          const int q0 = qg + i * RSBA_PB;
+          if (q0 < qb) {
+            double ca[8], cz[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { ca[u] = pf[i][u]; cz[u] = h == 1 ? pf[RSBA_MC_NPF_FUSED + i][u] : 0.0; }
+            if (q0 + RSBA_MC_NPF_FUSED * RSBA_PB < qb) fused_fetch(h, i, q0 + RSBA_MC_NPF_FUSED * RSBA_PB);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const double b0 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + mi];
+              const double b1 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + 16 + mi];
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[u], b0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[u], b1, acc1, 0, 0, 0);
+              dg = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[u], ca[u], dg, 0, 0, 0);
+              if (h == 1) cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[u], cz[u], cr, 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (ks == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) Pan[(prow + sr) * RSBA_PLD + sc0 + u] = sys(sgi, kb + sc0 + u, v[u]);
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (ks == 0) {
+          const int r = prow + kk + 4 * t;
+          Pan[r * RSBA_PLD + mi] -= acc0[t];
+          Pan[r * RSBA_PLD + 16 + mi] -= acc1[t];
+        } else {
+          double* up = fp + 3 * nf * 256 + (h * (nf - 1) + ks - 1) * 512;
+          up[(kk + 4 * t) * 32 + mi] = acc0[t];
+          up[(kk + 4 * t) * 32 + 16 + mi] = acc1[t];
+        }
+        fp[(h * nf + ks) * 256 + (kk + 4 * t) * 16 + mi] = dg[t];
+        if (h == 1) fp[(2 * nf + ks) * 256 + (kk + 4 * t) * 16 + mi] = cr[t];
+      }
+    };
+    // How the eight waves share the next owner's work in panel p > 0: with other owned blocks to update, waves 0..3 take
+    // the fused item in two K slices and waves 4..7 the other blocks; alone (late panels) all waves take fused slices.
+    const int nhp_no = 2 * nown - 2;
+    double* const fp_area = lds + (size_t)(kb + nown * RSBA_PB) * RSBA_PLD;                        // free rows behind the panel blocks ...
+    const int fp_avail = (max_rows - kb - nown * RSBA_PB) * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD;      // ... contiguous with T | Lt | Xl
+    const int nf_no = nhp_no > 0 ? 2 : ((768 * 4 + 1024 * 3 <= fp_avail) ? 4 : 3);
+    const bool fused_wave = next_owner && p > 0 && wave < 2 * nf_no;
+    if (fused_wave) fused_prefetch(wave / nf_no, wave % nf_no, nf_no);
 
     if (owner) {
       // Pre = this panel's diagonal block, fully updated during the previous panel.
@@ -279,7 +414,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        for (int hb = 2 + (wave - 1); hb < 2 * nown; hb += nwave - 1) load_update_half(hb, 0, 1, 0);
+        for (int hb = 2 + (wave - 1); hb < 2 * nown; hb += nwave - 1) load_update_half(hb, 0, 1, nullptr);
       }
       __syncthreads();
       RSBA_MC_STAMP(4);
@@ -294,72 +429,34 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
       PublishFlagWG(f.tdone + p, tag);
       RSBA_MC_STAMP(5);
     } else {
-      if (next_owner) {
-        // Look-ahead, before anything of this panel is needed: the NEXT diagonal block's entries of the system minus
-        // L[block p+1, 0:kb] L[block p+1, 0:kb]' — this workgroup's own rows, final since the last panel — so that only the
-        // X X' of this panel stands between T(p) and the next factorisation.  Wave = (tile row, tile column, half of K).
-        const int nb0 = kb + RSBA_PB;   // first row / column of block p + 1
-        // block p + 1 opens a new camera group whose columns may not be published yet: its entries of S are added after
-        // this panel's X instead (the product below only needs L) — waiting here would hold up this panel for everybody
-        const bool s_late = gate.ready != nullptr && !ip.first && (nb0 % gate.cols == 0 || kb % gate.cols == 0);   // (this panel's own gate is passed further down)
-        double sv[2] = {0.0, 0.0};
-        if (!s_late) {
+      // The next owner's look-ahead: Pre = the NEXT diagonal block's entries of the system minus
+      // L[block p+1, 0:kb] L[block p+1, 0:kb]'.  The product is formed in the same pass over block p + 1's rows as this
+      // panel's update (fused_half below); here only the entries of S are fetched, early, so that their latency is hidden.
+      const int nb0_la = kb + RSBA_PB;   // first row / column of block p + 1
+      // block p + 1 opens a new camera group whose columns may not be published yet: its entries of S are added after
+      // this panel's X instead (the product only needs L) — waiting here would hold up this panel for everybody
+      const bool s_late = next_owner && gate.ready != nullptr && !ip.first && (nb0_la % gate.cols == 0 || kb % gate.cols == 0);   // (this panel's own gate is passed further down)
+      double sv[2] = {0.0, 0.0};
+      if (next_owner && !s_late) {
 #pragma unroll
-          for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; sv[u] = Sat(nb0 + r, nb0 + c); }
-        }
-        {
-          // The product is symmetric: tiles (0,0) and (1,1) take two waves each (halves of the K range, one operand to
-          // load), tile (1,0) four (quarters, two operands), tile (0,1) is its mirror.  One CU pulls ~30 GB/s of such rows:
-          // the bytes are what this phase costs.
-          const bool cross = wave >= 4;
-          const int ti = wave >= 2 ? 1 : 0, tj = (wave >= 2 && wave < 4) ? 1 : 0;
-          const int nsl = cross ? 4 : 2, sl = cross ? wave - 4 : (wave & 1);
-          const int nq = kb / RSBA_PB, qper = (nq + nsl - 1) / nsl;
-          const int qa = sl * qper * RSBA_PB, qb = min(kb, (sl + 1) * qper * RSBA_PB);
-          const double* ra = A + (size_t)(nb0 + 16 * ti + mi) * n + 8 * kk;
-          const double* rb = A + (size_t)(nb0 + 16 * tj + mi) * n + 8 * kk;
-          d4_t acc = {0, 0, 0, 0};
-          double xa[8], xb[8], ya[8], yb[8];
-          auto fetch2 = [&](double (&da)[8], double (&db)[8], int q) {
-            const double2* pa = reinterpret_cast<const double2*>(ra + q);
+        for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; sv[u] = Sat(nb0_la + r, nb0_la + c); }
+      }
+      // (the diagonal entries' damping term, diag U, is fetched here too: inside sys() it would be one more dependent round
+      // trip in the assembly of Pre; it belongs to the payload of the block's camera group like the entries of S)
+      auto sys_pre = [&](int gi, int gj, double raw, double du) {
+        if (gi >= nreal || gj >= nreal) return gi == gj ? 1.0 : 0.0;
+        double v = raw * (scl[gi] * scl[gj]);
+        if (gi == gj) v += fmin(fmax(scl[gi] * scl[gi] * du, ip.min_lm_diagonal), ip.max_lm_diagonal) * inv_radius;
+        return v;
+      };
+      auto load_du = [&](int u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; return (r == c && nb0_la + r < nreal) ? red[L.diagU() + nb0_la + r] : 0.0; };
+      double du[2] = {0.0, 0.0};
+      if (next_owner && !s_late) { du[0] = load_du(0); du[1] = load_du(1); }
+      if (next_owner && p == 0) {
+        s_pending = s_late;
+        // nothing to subtract yet
 #pragma unroll
-            for (int v = 0; v < 4; ++v) { const double2 t = pa[v]; da[2 * v] = t.x; da[2 * v + 1] = t.y; }
-            if (cross) {
-              const double2* pb = reinterpret_cast<const double2*>(rb + q);
-#pragma unroll
-              for (int v = 0; v < 4; ++v) { const double2 t2 = pb[v]; db[2 * v] = t2.x; db[2 * v + 1] = t2.y; }
-            } else {
-#pragma unroll
-              for (int v = 0; v < 8; ++v) db[v] = da[v];
-            }
-          };
-          if (qa < qb) fetch2(xa, xb, qa);
-          if (qa + RSBA_PB < qb) fetch2(ya, yb, qa + RSBA_PB);
-          for (int q0 = qa; q0 < qb; q0 += RSBA_PB) {
-            double ca[8], cb[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { ca[u] = xa[u]; cb[u] = xb[u]; xa[u] = ya[u]; xb[u] = yb[u]; }
-            if (q0 + 2 * RSBA_PB < qb) fetch2(ya, yb, q0 + 2 * RSBA_PB);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[u], cb[u], acc, 0, 0, 0);
-          }
-#pragma unroll
-          for (int t = 0; t < 4; ++t) part[wave * 256 + (kk + 4 * t) * 16 + mi] = acc[t];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int e = tid + u * nt, r = e >> 5, c = e & 31;
-          double d;
-          if ((r >> 4) == (c >> 4)) {
-            const int pw = (r >> 4) * 2, o = (r & 15) * 16 + (c & 15);
-            d = part[pw * 256 + o] + part[(pw + 1) * 256 + o];
-          } else {
-            const int o = r >= 16 ? (r & 15) * 16 + (c & 15) : (c & 15) * 16 + (r & 15);   // tile (1,0), or its mirror
-            d = ((part[4 * 256 + o] + part[5 * 256 + o]) + part[6 * 256 + o]) + part[7 * 256 + o];
-          }
-          Pre[r * RSBA_PLD + c] = (s_late ? 0.0 : sys(nb0 + r, nb0 + c, sv[u])) - d;
-        }
+        for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; Pre[r * RSBA_PLD + c] = s_late ? 0.0 : sys(nb0_la + r, nb0_la + c, sv[u]); }
         __syncthreads();
       }
       RSBA_MC_STAMP(1);
@@ -377,18 +474,85 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
         __syncthreads();
       }
       RSBA_MC_STAMP(3);
-      // the panel's own columns of S are first needed here: everything above (look-ahead product, strip) ran while the
+      // the panel's own columns of S are first needed here: everything above (strip) ran while the
       // Schur kernel was still producing this camera group
       if (gate.ready != nullptr && kb % gate.cols == 0 && !ip.first) {
         if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
       }
-      {
+      // The next diagonal block's entries of S, if they were held back above (s_late): block p + 1 belongs to this panel's
+      // camera group (gate just passed), or opens the next one — whose stage the Schur kernel has usually published by now
+      // (the factorisation runs behind it): one look at the flag, no waiting.  Only if it is not there yet do the entries
+      // come after this panel's X (the tail below), where they cost a wait and a round trip on the chain of panels.
+      bool have_s = !s_late;
+      if (s_late && p > 0) {
+        if (nb0_la % gate.cols != 0) have_s = true;   // same group as this panel
+        else {
+          __shared__ int s_gate_open;
+          if (tid == 0) s_gate_open = __hip_atomic_load(gate.ready + 1 + nb0_la / gate.cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gate.tag;
+          __syncthreads();
+          have_s = s_gate_open != 0;
+          if (have_s) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (have_s) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; sv[u] = Sat(nb0_la + r, nb0_la + c); }
+          du[0] = load_du(0); du[1] = load_du(1);
+        }
+        s_pending = !have_s;
+      } else if (s_late && p == 0 && nb0_la % gate.cols != 0) {
+        // panel 0: block 1 belongs to group 0, whose gate has just been passed
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; Pre[r * RSBA_PLD + c] = sys(nb0_la + r, nb0_la + c, Sat(nb0_la + r, nb0_la + c)); }
+        s_pending = false;
+        __syncthreads();
+      }
+      if (next_owner && p > 0) {
+        const int nf = nf_no, nhp = nhp_no, nsp = (nhp > 0 && nhp <= 2) ? 2 : 1;
+        double* fp = fp_area;
+        double* part2 = fp_area + 768 * nf + 1024 * (nf - 1);   // partials of the other blocks' second K slice (nsp == 2)
+        if (fused_wave) fused_consume(wave / nf, wave % nf, nf, fp);
+        else for (int it = wave - 2 * nf; it < nhp * nsp; it += nwave - 2 * nf) {
+          const int hb = 2 + it / nsp, ks = it - (it / nsp) * nsp;
+          load_update_half(hb, ks, nsp, part2 + (size_t)(hb - 2) * 512);
+        }
+        __syncthreads();
+        // slices >= 1 of the update in slice order (slice 0 is already in Pan), then the next diagonal block ahead of its panel
+        for (int e = tid; e < 2 * 512; e += nt) {
+          const int h = e >> 9, r = (e >> 5) & 15, c = e & 31;
+          double sum = 0.0;
+          for (int k2 = 0; k2 < nf - 1; ++k2) sum += fp[3 * nf * 256 + (h * (nf - 1) + k2) * 512 + r * 32 + c];
+          Pan[(h * 16 + r) * RSBA_PLD + c] -= sum;
+        }
+        if (nsp > 1) {
+          for (int e = tid; e < nhp * 512; e += nt) {
+            const int hq = e >> 9, r = (e >> 5) & 15, c = e & 31, hb = 2 + hq;
+            Pan[((hb >> 1) * RSBA_PB + (hb & 1) * 16 + r) * RSBA_PLD + c] -= part2[(size_t)hq * 512 + r * 32 + c];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = tid + u * nt, r = e >> 5, c = e & 31;
+          double d = 0.0;
+          if ((r >> 4) == (c >> 4)) {
+            const int hh = r >> 4, o = (r & 15) * 16 + (c & 15);
+            for (int k2 = 0; k2 < nf; ++k2) d += fp[(hh * nf + k2) * 256 + o];
+          } else {
+            const int o = r >= 16 ? (r & 15) * 16 + (c & 15) : (c & 15) * 16 + (r & 15);   // tile (1,0), or its mirror
+            for (int k2 = 0; k2 < nf; ++k2) d += fp[(2 * nf + k2) * 256 + o];
+          }
+          sv[u] = (have_s ? sys_pre(nb0_la + r, nb0_la + c, sv[u], du[u]) : 0.0) - d;
+        }
+        __syncthreads();   // T | Lt | Xl may hold partials: everybody has read them before Pre and, later, T are written
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int e = tid + u * nt; Pre[(e >> 5) * RSBA_PLD + (e & 31)] = sv[u]; }
+        __syncthreads();
+      } else {
         // few 16-row halves (late panels): several waves share one, each a slice of the K range — the update is a chain
         // of dependent load latencies per wave, so its length is what counts
         const int nh = 2 * nown, nsplit = (p > 0 && nh <= 2) ? 4 : ((p > 0 && nh <= 4) ? 2 : 1);
         for (int it = wave; it < nh * nsplit; it += nwave) {
           const int hb = it / nsplit, ks = it - hb * nsplit;
-          load_update_half(hb, ks, nsplit, hb * (nsplit - 1) + ks - 1);
+          load_update_half(hb, ks, nsplit, part + (hb * (nsplit - 1) + ks - 1) * 512);
         }
         __syncthreads();
         if (nsplit > 1) {
@@ -448,7 +612,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
       // (before anything that may wait for the Schur kernel)
       PublishFlagWG(f.strip_ready + p + 1, tag);
       const int nb0 = kb + RSBA_PB;
-      if (gate.ready != nullptr && !ip.first && (nb0 % gate.cols == 0 || kb % gate.cols == 0)) {   // the deferred entries of S (see the look-ahead)
+      if (s_pending) {   // the deferred entries of S (see the look-ahead)
         if (!WaitReady(gate.ready + 1 + nb0 / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
