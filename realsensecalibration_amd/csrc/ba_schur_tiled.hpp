@@ -56,7 +56,8 @@ class KernelTimer;
 struct SchurSeg {
   int ga, gb, word_begin, word_end, self;
   // in-kernel reduction tree of the pair tiles: segment -> group of RSBA_GRP consecutive segments -> tile -> stage
-  int tile, grp, grp_seg0, grp_nseg, tile_grp0, tile_ngrp, stage, stage_ntiles, nred, pad1, pad2;
+  int tile, grp, grp_seg0, grp_nseg, tile_grp0, tile_ngrp, stage, stage_ntiles, nred, index, pad2;
+  // index: the entry's own number (segs_ordered, the copy in launch order, is what the kernel reads: one load per ticket)
   // self: 0 pair segment, 1 self segment, 2 / 3 reducer of a pair / self tile (word_begin..word_end = its components)
 };
 #define RSBA_GRP 8          // segments per reduction group
@@ -78,8 +79,10 @@ struct TiledSchur {
   int* sync_cnt = nullptr;                  // arrival counters, self-resetting: [ngrp] group members, [ntiles] groups done, [16] stage tiles, [ntiles] reducers done
   int nsync = 0, nblocks = 0;               // counters; blocks of the launch (segments + reducers)
   int* ready = nullptr;                     // ready[1 + g] = step tag once stage g (self tile g + pair tiles (g, g' >= g)) is in S
-  int* block_seg = nullptr;                 // [nseg] launch order: block -> segment
-  int* block_seg_self = nullptr;            // [nblocks_self] the self segments and their reducers only (gradient evaluation)
+  int* block_seg = nullptr;                 // [nseg] launch order: block -> segment (host-side diagnostics)
+  SchurSeg* segs_ordered = nullptr;         // [nblocks] the entries in launch order (what a ticket indexes)
+  SchurSeg* segs_ordered_self = nullptr;    // [nblocks_self] the self segments and their reducers only (gradient evaluation)
+  int* small_flag = nullptr;                // != 0: some camera takes the small-angle branch this linearisation (point side kernels)
   int nblocks_self = 0;
   int ngrp = 0;
   double* block_scal = nullptr;
@@ -107,6 +110,16 @@ struct TiledSchur {
   void Free();
 };
 
+// One word for the Schur kernel: does ANY camera take AngleAxisRotatePoint's small-angle branch at this linearisation?
+// (Workgroup 0 of the point-side kernel, which runs right before the Schur kernel in every step.)
+__device__ __forceinline__ void PublishSmallAngleFlag(int C, const double* __restrict__ camc_g, int* __restrict__ small_flag) {
+  if (blockIdx.x != 0) return;
+  int f = 0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) f |= camc_g[(size_t)c * CC_STRIDE + CC_SMALL] != 0.0 ? 1 : 0;
+  f = __syncthreads_or(f);
+  if (threadIdx.x == 0) *small_flag = f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K_A1: point pass, one thread per point.
 // ------------------------------------------------------------------------------------------------
@@ -115,10 +128,11 @@ __global__ void __launch_bounds__(256)
 k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, const double* __restrict__ pts,
              double* __restrict__ scale_p, double* __restrict__ ptdata, double* __restrict__ block_scal,
              const int* __restrict__ cm_pos /* sliced like obs */, double* __restrict__ sq_cm, double* __restrict__ lin /* [P][RSBA_LIN_STRIDE] */,
-             IterParams ip) {
+             int* __restrict__ small_flag, IterParams ip) {
   extern __shared__ double lds[];
   double* camc_l = lds;      // C x 33 when staged
   const int tid = threadIdx.x;
+  PublishSmallAngleFlag(C, camc_g, small_flag);
   if (kStageCamc) {
     // eight loads in flight per thread before the first LDS store (a plain copy loop waits for every load: 8 round trips
     // at the head of every LM step)
@@ -226,8 +240,10 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_point_damp(int P, const double* __restrict__ pts, const double* __restrict__ scale_p, const double* __restrict__ lin,
-             double* __restrict__ ptdata, double* __restrict__ block_scal, IterParams ip) {
+             double* __restrict__ ptdata, double* __restrict__ block_scal, int C, const double* __restrict__ camc_g,
+             int* __restrict__ small_flag, IterParams ip) {
   const int tid = threadIdx.x;
+  PublishSmallAngleFlag(C, camc_g, small_flag);
   double cost = 0, xn = 0, fail = 0, gmax = 0;
   for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
     const double* ln = lin + (size_t)j * RSBA_LIN_STRIDE;
@@ -603,7 +619,8 @@ struct SchurArgs {
   double* __restrict__ grp_sum;
   int* __restrict__ sync_cnt;
   int ngrp, ntiles, last_group;
-  const int* __restrict__ block_seg;
+  const SchurSeg* __restrict__ segs_ordered;   // the work list in launch order
+  const int* __restrict__ small_flag;          // see TiledSchur::small_flag
   int* __restrict__ ready;
   int tag;            // 0: nobody is waiting (sequential schedule)
   int self_only;      // 1: the work list holds the self tiles only (gradient evaluation): no stage bookkeeping
@@ -643,32 +660,61 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
   const int cam_a = RSBA_TG * sg.ga + ia, cam_b = RSBA_TG * sg.gb + ib;
   const bool live = cam_a < C && cam_b < C && (!diag_tile || dt < 120);
   const int w0 = diag_tile ? (tid >> 7) : 0, wstep = diag_tile ? 2 : 1;
-  for (int i = tid; i < 2 * RSBA_TG * RSBA_SC_STRIDE; i += 256) {
+  // camera constants of the tile's 32 cameras: two values per thread, loaded here, stored with the first chunk's data
+  double scv[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = tid + 256 * u;
     const int row = i / RSBA_SC_STRIDE, e = i - row * RSBA_SC_STRIDE;
     const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
     const double* cc = camc + (size_t)(cam < C ? cam : 0) * CC_STRIDE;
-    double v = 0.0;
-    if (e < 9) v = cc[CC_R + e]; else if (e < 12) v = cc[CC_T + e - 9]; else if (e == 12) v = cc[CC_FX]; else if (e == 13) v = cc[CC_FY]; else if (e == 14) v = cc[CC_SMALL];
-    sc[i] = v;
+    const int src = e < 9 ? CC_R + e : (e < 12 ? CC_T + e - 9 : (e == 12 ? CC_FX : (e == 13 ? CC_FY : CC_SMALL)));
+    scv[u] = e < 15 ? cc[src] : 0.0;
   }
   const double* ca = sc + ia * RSBA_SC_STRIDE;
   const double* cb = sc + (RSBA_TG + ib) * RSBA_SC_STRIDE;
+  {
+    // first chunk: point data and visibility rows through registers, every load (camera constants included) issued before
+    // the first LDS store — one round trip.  (The accumulators are not live yet: 48 more registers here are free.)
+    const int wb = sg.word_begin;
+    const int nwc = min(RSBA_CW, sg.word_end - wb);
+    const int j0 = wb * 64;
+    const int np = max(0, min(nwc * 64, P - j0));
+    constexpr int kPtPerThread = RSBA_CHUNK * RSBA_PT_STRIDE / 256;
+    double pv[kPtPerThread];
+#pragma unroll
+    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; pv[u] = i < np * RSBA_PT_STRIDE ? ptdata[(size_t)j0 * RSBA_PT_STRIDE + i] : 0.0; }
+    unsigned long long mv;
+    {
+      const int row = tid >> 3, w = tid & 7;  // 32 rows x 8 words = 256 threads
+      const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
+      mv = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
+    }
+    sc[tid] = scv[0]; sc[tid + 256] = scv[1];
+#pragma unroll
+    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; if (i < np * RSBA_PT_STRIDE) pt[i] = pv[u]; }
+    mk[tid >> 3][tid & 7] = mv;
+    __syncthreads();
+  }
   double acc[36];
 #pragma unroll
   for (int i = 0; i < 36; ++i) acc[i] = 0.0;
 
   for (int wb = sg.word_begin; wb < sg.word_end; wb += RSBA_CW) {
     const int nwc = min(RSBA_CW, sg.word_end - wb);  // words of this LDS chunk
-    const int j0 = wb * 64;
-    const int np = max(0, min(nwc * 64, P - j0));
-    __syncthreads();
-    for (int i = tid; i < np * RSBA_PT_STRIDE; i += 256) pt[i] = ptdata[(size_t)j0 * RSBA_PT_STRIDE + i];
-    {
-      const int row = tid >> 3, w = tid & 7;  // 32 rows x 8 words = 256 threads
-      const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
-      mk[row][w] = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
+    if (wb != sg.word_begin) {
+      // later chunks of a long segment (more than 64 cameras: many tiles, few segments each)
+      const int j0 = wb * 64;
+      const int np = max(0, min(nwc * 64, P - j0));
+      __syncthreads();
+      for (int i = tid; i < np * RSBA_PT_STRIDE; i += 256) pt[i] = ptdata[(size_t)j0 * RSBA_PT_STRIDE + i];
+      {
+        const int row = tid >> 3, w = tid & 7;
+        const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
+        mk[row][w] = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     // every lane walks ITS OWN hit list through the whole chunk: the word index is per lane, so a wave
     // runs max-over-lanes(hits in 512 points) trips, not the sum over words of the per-word maxima
     // one flat loop per lane: (w, h) is the lane's cursor into its hit list; the cursor advance is a tiny inner loop
@@ -787,13 +833,22 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
     const int nwc = min(RSBA_CW, sg.word_end - wb);
     const int j0 = wb * 64;
     const int np = max(0, min(nwc * 64, P - j0));
-    __syncthreads();
-    for (int i = tid; i < np * RSBA_PT_STRIDE; i += 256) pt[i] = ptdata[(size_t)j0 * RSBA_PT_STRIDE + i];
+    // every load of the chunk (and, on the first chunk, the camera's constants above) in flight before the first LDS store
+    constexpr int kPtPerThread = RSBA_CHUNK * RSBA_PT_STRIDE / 256;
+    double pv[kPtPerThread];
+#pragma unroll
+    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; pv[u] = i < np * RSBA_PT_STRIDE ? ptdata[(size_t)j0 * RSBA_PT_STRIDE + i] : 0.0; }
+    unsigned long long mv = 0ull;
     if (tid < RSBA_TG * RSBA_CW) {
       const int row = tid >> 3, w = tid & 7;
       const int cam = RSBA_TG * sg.ga + row;
-      mk[row][w] = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
+      mv = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
     }
+    const int obs_chunk_pre = live ? cam_prefix[(size_t)cam_a * nwords + wb] : 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; if (i < np * RSBA_PT_STRIDE) pt[i] = pv[u]; }
+    if (tid < RSBA_TG * RSBA_CW) mk[tid >> 3][tid & 7] = mv;
     __syncthreads();
     // The camera's points of this chunk as a list, dealt to its 16 lanes BY RANK (lane s takes entries s, s + 16, ...): every
     // lane of a camera gets the same number of hits to within one (dealing by bit position left the lanes of a wave at 62 %
@@ -818,7 +873,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
     }
     __syncthreads();
     const int n_a = live ? cnt[ia] : 0;
-    const int obs_chunk = live ? obs0 + cam_prefix[(size_t)cam_a * nwords + wb] : 0;
+    const int obs_chunk = live ? obs0 + obs_chunk_pre : 0;
 #pragma unroll 1
     for (int i = ib; i < n_a; i += 16) {
       const double* pd = pt + (size_t)lst[ia][i] * RSBA_PT_STRIDE;
@@ -994,26 +1049,31 @@ k_schur_tiles(SchurArgs a) {
   // instead of 64) starts the last blocks of a stage tens of microseconds late, and the stage ends with them.  With
   // tickets the order of the work list is the order in which slots take it up, whoever they are.  (The sums do not
   // depend on who does which segment.)  The last ticket resets the counter for the next launch.
-  __shared__ int s_ticket;
+  // What stands between the dispatch of a workgroup and its first hit is a chain of dependent round trips to memory, ~1-2 us
+  // each beside 500 other workgroups, per entry of ~45 us: ticket -> entry -> camera constants / point data / visibility
+  // rows.  It used to be six long (ticket, block -> segment index, segment, small-angle flags of the tile's cameras,
+  // camera constants, point data); now the entry is ONE load off the ticket (segs_ordered), the small-angle flag is one
+  // word for the whole problem, fetched with the ticket, and everything an entry stages is in flight before the first
+  // LDS store (PairSegment / SelfSegment).
+  __shared__ int s_ticket, s_small;
   if (threadIdx.x == 0) {
+    const int sm = __hip_atomic_load(a.small_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_ticket = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_small = sm;
     if (s_ticket == (int)gridDim.x - 1) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   const int b = s_ticket;
-  const int seg_index = a.block_seg[b];
-  const SchurSeg sg = a.segs[seg_index];
+  const SchurSeg sg = a.segs_ordered[b];
+  const int seg_index = sg.index;
   if (a.trace && b == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
   if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b] = wall_clock64();
   if (sg.self >= 2) ReducerSegment(a, sg, b);
   else if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, b, pt, mk, lst, cnt);
   else {
     // two instances of the pair tile: the small-angle selects of the Jacobian rows (12 instructions per hit) are compiled in
-    // only when one of the tile's 32 cameras takes that branch this iteration
-    const int t = threadIdx.x;
-    const int cam = t < RSBA_TG ? RSBA_TG * sg.ga + t : RSBA_TG * sg.gb + (t - RSBA_TG);
-    const int any_small = __syncthreads_or(t < 2 * RSBA_TG && cam < a.C && a.camc[(size_t)cam * CC_STRIDE + CC_SMALL] != 0.0);
-    if (any_small) PairSegment<kLoss, true>(a, sg, seg_index, b, pt, mk, sc);
+    // only when some camera takes that branch this iteration (a rotation of exactly zero: the reference's test2 fixture)
+    if (s_small) PairSegment<kLoss, true>(a, sg, seg_index, b, pt, mk, sc);
     else PairSegment<kLoss, false>(a, sg, seg_index, b, pt, mk, sc);
   }
   if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b + 1] = wall_clock64();

@@ -444,7 +444,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nblocks)) ||
       (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
-      (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) || (rc = DevAlloc(&block_seg_self, (size_t)nblocks_self)) ||
+      (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered_self, (size_t)nblocks_self)) || (rc = DevAlloc(&small_flag, 1)) ||
       (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm2[0], cmpos.size())) || (rc = DevAlloc(&sq_cm2[1], cmpos.size())) ||
@@ -462,7 +462,15 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   HIPCHK(hipMemset(tree_error, 0, 2 * sizeof(int)));   // [0] error flag, [1] ticket counter of the Schur kernel
   HIPCHK(hipMemset(ready, 0, 16 * sizeof(int)));
   HIPCHK(hipMemcpy(block_seg, border.data(), border.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(block_seg_self, border_self.data(), border_self.size() * sizeof(int), hipMemcpyHostToDevice));
+  {
+    for (size_t q = 0; q < sg.size(); ++q) sg[q].index = (int)q;
+    std::vector<SchurSeg> ord(border.size()), ord_self(std::max<size_t>(border_self.size(), 1));
+    for (size_t b = 0; b < border.size(); ++b) ord[b] = sg[border[b]];
+    for (size_t b = 0; b < border_self.size(); ++b) ord_self[b] = sg[border_self[b]];
+    HIPCHK(hipMemcpy(segs_ordered, ord.data(), ord.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(segs_ordered_self, ord_self.data(), ord_self.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(small_flag, 0, sizeof(int)));
+  }
   HIPCHK(hipMemcpy(cam_mask, mask.data(), mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(segs, sg.data(), sg.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_prefix, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -476,7 +484,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, block_seg_self, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm};
+  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, segs_ordered, segs_ordered_self, small_flag, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   cam_mask = nullptr;
 }
@@ -762,17 +770,17 @@ void TiledSchur::LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTim
   T.Begin("k_point_pass", st);
   if (stage)
     k_point_pass<true><<<grid_pp, 256, lds, st>>>(C, P, s->sliced(), s->camc[x], s->pts[x], s->scale_p, ptdata,
-                                                  block_scal, cm_pos, sq_cm2[x], lin2[x], ip);
+                                                  block_scal, cm_pos, sq_cm2[x], lin2[x], small_flag, ip);
   else
     k_point_pass<false><<<grid_pp, 256, lds, st>>>(C, P, s->sliced(), s->camc[x], s->pts[x], s->scale_p, ptdata,
-                                                   block_scal, cm_pos, sq_cm2[x], lin2[x], ip);
+                                                   block_scal, cm_pos, sq_cm2[x], lin2[x], small_flag, ip);
   T.End(st);
 }
 
 void TiledSchur::LaunchPointDamp(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st) {
   const int x = s->cur;
   T.Begin("k_point_damp", st);
-  k_point_damp<<<grid_pp, 256, 0, st>>>(P, s->pts[x], s->scale_p, lin2[x], ptdata, block_scal, ip);
+  k_point_damp<<<grid_pp, 256, 0, st>>>(P, s->pts[x], s->scale_p, lin2[x], ptdata, block_scal, C, s->camc[x], small_flag, ip);
   T.End(st);
 }
 
@@ -790,7 +798,7 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   SchurArgs a;
   a.C = ts.C; a.P = ts.P; a.nwords = ts.nwords; a.camc = s->camc[x]; a.cam_free = s->cam_free; a.segs = ts.segs; a.cam_mask = ts.cam_mask; a.ptdata = ts.ptdata;
   a.cam_prefix = ts.cam_prefix; a.cam_ptr = ts.cam_ptr; a.sq_cm = ts.sq_cm2[x]; a.u_cm = ts.u_cm; a.v_cm = ts.v_cm; a.partial = ts.partial;
-  a.grp_sum = ts.grp_sum; a.sync_cnt = ts.sync_cnt; a.ngrp = ts.ngrp; a.ntiles = ts.ntiles; a.block_seg = ts.block_seg; a.last_group = ts.ngroups - 1; a.tile_sum = ts.tile_sum;
+  a.grp_sum = ts.grp_sum; a.sync_cnt = ts.sync_cnt; a.ngrp = ts.ngrp; a.ntiles = ts.ntiles; a.segs_ordered = ts.segs_ordered; a.small_flag = ts.small_flag; a.last_group = ts.ngroups - 1; a.tile_sum = ts.tile_sum;
   a.tree_error = ts.tree_error; a.ticket = ts.tree_error + 1;
   a.ready = ts.ready; a.tag = tag; a.self_only = 0; a.red = s->red; a.L = s->L; a.nblocks_pp = ts.grid_pp; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
@@ -808,7 +816,7 @@ void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& 
 
 void TiledSchur::LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st) {
   SchurArgs a = MakeSchurArgs(*this, s, 0);
-  a.block_seg = block_seg_self; a.self_only = 1; a.trace = nullptr; a.wg_trace = nullptr;
+  a.segs_ordered = segs_ordered_self; a.self_only = 1; a.trace = nullptr; a.wg_trace = nullptr;
   T.Begin("k_schur_tiles(self only)", st);
   if (ip.huber_delta != 0.0) k_schur_tiles<true><<<nblocks_self, 256, 0, st>>>(a);
   else k_schur_tiles<false><<<nblocks_self, 256, 0, st>>>(a);
