@@ -28,7 +28,7 @@ namespace rsba {
 #define RSBA_MC_NPF 3         // 32-column slabs of a 16-row half in flight in the row update (4 spills registers)
 #endif
 #ifndef RSBA_MC_NPF_FUSED
-#define RSBA_MC_NPF_FUSED 1   // ... fetched ahead of the strip by the fused update + look-ahead of the next diagonal block (two operand streams; 2 spills, and a spill costs more than the round trip it hides)
+#define RSBA_MC_NPF_FUSED 1   // slabs per operand stream fetched at the top of the panel by the cross-tile waves; the single-stream row waves keep twice as many (2 -> 25 spilled registers, and a spill costs more than the round trip it hides)
 #endif
 
 struct MultiCholFlags {
@@ -291,35 +291,37 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
     // Slices ks > 0 leave their products in the partial area `fp` (slice 0 keeps the rows in Pan); fixed order of addition
     // below.  fp: diag tile (h, ks) at (h nf + ks) 256 | cross tile (ks) at (2 nf + ks) 256 | update (h, ks >= 1) at
     // 3 nf 256 + (h (nf - 1) + ks - 1) 512.
-    double pf[2 * RSBA_MC_NPF_FUSED][8];   // [0, NPF): this half's rows, [NPF, 2 NPF): half 0's rows (cross tile)
-    auto fused_rows = [&](int h, double const*& ra, double const*& rz) {
-      const int nb0 = kb + RSBA_PB;
-      ra = A + (size_t)(nb0 + 16 * h + mi) * n + 8 * kk;     // this half's rows (row nb0 + 16 h + mi <= n - 1)
-      rz = A + (size_t)(nb0 + mi) * n + 8 * kk;              // half 0's rows
-    };
-    auto fused_fetch = [&](int h, int i, int q) {
-      const double *ra, *rz;
-      fused_rows(h, ra, rz);
-      const double2* pa = reinterpret_cast<const double2*>(ra + q);
+    // Roles of the eight waves (next owner, p > 0): "row" waves (half h, K slice ks of nf) stream ONE operand — their
+    // half's rows — for the update and the diagonal tile (h, h); two "cross" waves stream both halves' rows, each over half
+    // of K, for tile (1, 0); with other owned blocks to update the last two waves take those (load_update_half).
+    // RSBA_MC_NPF_FUSED slabs per stream are fetched at the top of the panel and kept in flight.
+    double pf[2 * RSBA_MC_NPF_FUSED][8];   // row waves: [0, NPF) their rows; cross waves: [0, NPF) half 1's rows, [NPF, 2 NPF) half 0's
+    auto rows_ptr = [&](int h) { return A + (size_t)(kb + RSBA_PB + 16 * h + mi) * n + 8 * kk; };   // row nb0 + 16 h + mi <= n - 1
+    auto fetch8 = [&](double (&d)[8], const double* src) {
+      const double2* pa = reinterpret_cast<const double2*>(src);
 #pragma unroll
-      for (int v2 = 0; v2 < 4; ++v2) { const double2 t = pa[v2]; pf[i][2 * v2] = t.x; pf[i][2 * v2 + 1] = t.y; }
-      if (h == 1) {
-        const double2* pz = reinterpret_cast<const double2*>(rz + q);
-#pragma unroll
-        for (int v2 = 0; v2 < 4; ++v2) { const double2 t2 = pz[v2]; pf[RSBA_MC_NPF_FUSED + i][2 * v2] = t2.x; pf[RSBA_MC_NPF_FUSED + i][2 * v2 + 1] = t2.y; }
-      }
+      for (int v2 = 0; v2 < 4; ++v2) { const double2 t = pa[v2]; d[2 * v2] = t.x; d[2 * v2 + 1] = t.y; }
     };
     auto fused_range = [&](int ks, int nf, int& qa, int& qb) {
       const int nq = kb / RSBA_PB, qper = (nq + nf - 1) / nf;
       qa = ks * qper * RSBA_PB; qb = min(kb, (ks + 1) * qper * RSBA_PB);
     };
-    auto fused_prefetch = [&](int h, int ks, int nf) {
+    auto row_prefetch = [&](int h, int ks, int nf) {
       int qa, qb;
       fused_range(ks, nf, qa, qb);
 #pragma unroll
-      for (int i = 0; i < RSBA_MC_NPF_FUSED; ++i) if (qa + i * RSBA_PB < qb) fused_fetch(h, i, qa + i * RSBA_PB);
+      for (int i = 0; i < 2 * RSBA_MC_NPF_FUSED; ++i) if (qa + i * RSBA_PB < qb) fetch8(pf[i], rows_ptr(h) + qa + i * RSBA_PB);
     };
-    auto fused_consume = [&](int h, int ks, int nf, double* fp) {
+    auto cross_prefetch = [&](int cs) {
+      int qa, qb;
+      fused_range(cs, 2, qa, qb);
+#pragma unroll
+      for (int i = 0; i < RSBA_MC_NPF_FUSED; ++i)
+        if (qa + i * RSBA_PB < qb) { fetch8(pf[i], rows_ptr(1) + qa + i * RSBA_PB); fetch8(pf[RSBA_MC_NPF_FUSED + i], rows_ptr(0) + qa + i * RSBA_PB); }
+    };
+    // fp: diag tile (h, ks) at (h nf + ks) 256 | cross tile (cs) at (2 nf + cs) 256 | update (h, ks >= 1) at
+    // (2 nf + 2) 256 + (h (nf - 1) + ks - 1) 512
+    auto row_consume = [&](int h, int ks, int nf, double* fp) {
       const int nb0 = kb + RSBA_PB;
       const int prow = h * 16;                       // slot 0
       // the panel's columns of S for these rows (slice 0): issued now, used after the products
@@ -338,25 +340,22 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
       }
       int qa, qb;
       fused_range(ks, nf, qa, qb);
-      d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, dg = {0, 0, 0, 0}, cr = {0, 0, 0, 0};
-      for (int qg = qa; qg < qb; qg += RSBA_MC_NPF_FUSED * RSBA_PB) {
+      constexpr int D = 2 * RSBA_MC_NPF_FUSED;
+      d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, dg = {0, 0, 0, 0};
+      for (int qg = qa; qg < qb; qg += D * RSBA_PB) {
 #pragma unroll
-        for (int i = 0; i < RSBA_MC_NPF_FUSED; ++i) {
+        for (int i = 0; i < D; ++i) {
           const int q0 = qg + i * RSBA_PB;
           if (q0 < qb) {
-            double ca[8], cz[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { ca[u] = pf[i][u]; cz[u] = h == 1 ? pf[RSBA_MC_NPF_FUSED + i][u] : 0.0; }
-            if (q0 + RSBA_MC_NPF_FUSED * RSBA_PB < qb) fused_fetch(h, i, q0 + RSBA_MC_NPF_FUSED * RSBA_PB);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               const double b0 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + mi];
               const double b1 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + 16 + mi];
-              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[u], b0, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[u], b1, acc1, 0, 0, 0);
-              dg = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[u], ca[u], dg, 0, 0, 0);
-              if (h == 1) cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[u], cz[u], cr, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pf[i][u], b0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pf[i][u], b1, acc1, 0, 0, 0);
+              dg = __builtin_amdgcn_mfma_f64_16x16x4f64(pf[i][u], pf[i][u], dg, 0, 0, 0);
             }
+            if (q0 + D * RSBA_PB < qb) fetch8(pf[i], rows_ptr(h) + q0 + D * RSBA_PB);   // refilled behind its own products: D - 1 slabs of products ahead of its use
           }
         }
       }
@@ -372,22 +371,41 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
           Pan[r * RSBA_PLD + mi] -= acc0[t];
           Pan[r * RSBA_PLD + 16 + mi] -= acc1[t];
         } else {
-          double* up = fp + 3 * nf * 256 + (h * (nf - 1) + ks - 1) * 512;
+          double* up = fp + (2 * nf + 2) * 256 + (h * (nf - 1) + ks - 1) * 512;
           up[(kk + 4 * t) * 32 + mi] = acc0[t];
           up[(kk + 4 * t) * 32 + 16 + mi] = acc1[t];
         }
         fp[(h * nf + ks) * 256 + (kk + 4 * t) * 16 + mi] = dg[t];
-        if (h == 1) fp[(2 * nf + ks) * 256 + (kk + 4 * t) * 16 + mi] = cr[t];
       }
     };
-    // How the eight waves share the next owner's work in panel p > 0: with other owned blocks to update, waves 0..3 take
-    // the fused item in two K slices and waves 4..7 the other blocks; alone (late panels) all waves take fused slices.
-    const int nhp_no = 2 * nown - 2;
-    double* const fp_area = lds + (size_t)(kb + nown * RSBA_PB) * RSBA_PLD;                        // free rows behind the panel blocks ...
-    const int fp_avail = (max_rows - kb - nown * RSBA_PB) * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD;      // ... contiguous with T | Lt | Xl
-    const int nf_no = nhp_no > 0 ? 2 : ((768 * 4 + 1024 * 3 <= fp_avail) ? 4 : 3);
-    const bool fused_wave = next_owner && p > 0 && wave < 2 * nf_no;
-    if (fused_wave) fused_prefetch(wave / nf_no, wave % nf_no, nf_no);
+    auto cross_consume = [&](int cs, int nf, double* fp) {
+      int qa, qb;
+      fused_range(cs, 2, qa, qb);
+      constexpr int D = RSBA_MC_NPF_FUSED;
+      d4_t cr = {0, 0, 0, 0};
+      for (int qg = qa; qg < qb; qg += D * RSBA_PB) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          const int q0 = qg + i * RSBA_PB;
+          if (q0 < qb) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cr = __builtin_amdgcn_mfma_f64_16x16x4f64(pf[i][u], pf[D + i][u], cr, 0, 0, 0);
+            if (q0 + D * RSBA_PB < qb) { fetch8(pf[i], rows_ptr(1) + q0 + D * RSBA_PB); fetch8(pf[D + i], rows_ptr(0) + q0 + D * RSBA_PB); }
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fp[(2 * nf + cs) * 256 + (kk + 4 * t) * 16 + mi] = cr[t];
+    };
+    const int nhp_no = 2 * nown - 2;                // 16-row halves of the other owned blocks
+    double* const fp_area = lds + (size_t)(kb + nown * RSBA_PB) * RSBA_PLD;   // free rows behind the panel blocks, contiguous with T | Lt | Xl:
+                                                                               // (max_rows - kb - 32 nown) 33 + 3168 >= 5280 doubles
+    const int nf_no = nhp_no > 0 ? 2 : 3;           // 1536 nf + 512 (nf - 1) ... = 2560 / 4096 doubles of partials
+    const bool no_panel = next_owner && p > 0;
+    const bool row_wave = no_panel && wave < 2 * nf_no;
+    const bool cross_wave = no_panel && !row_wave && wave < 2 * nf_no + 2;
+    if (row_wave) row_prefetch(wave / nf_no, wave % nf_no, nf_no);
+    if (cross_wave) cross_prefetch(wave - 2 * nf_no);
 
     if (owner) {
       // Pre = this panel's diagonal block, fully updated during the previous panel.
@@ -507,27 +525,18 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
         __syncthreads();
       }
       if (next_owner && p > 0) {
-        const int nf = nf_no, nhp = nhp_no, nsp = (nhp > 0 && nhp <= 2) ? 2 : 1;
+        const int nf = nf_no, nhp = nhp_no;
         double* fp = fp_area;
-        double* part2 = fp_area + 768 * nf + 1024 * (nf - 1);   // partials of the other blocks' second K slice (nsp == 2)
-        if (fused_wave) fused_consume(wave / nf, wave % nf, nf, fp);
-        else for (int it = wave - 2 * nf; it < nhp * nsp; it += nwave - 2 * nf) {
-          const int hb = 2 + it / nsp, ks = it - (it / nsp) * nsp;
-          load_update_half(hb, ks, nsp, part2 + (size_t)(hb - 2) * 512);
-        }
+        if (row_wave) row_consume(wave / nf, wave % nf, nf, fp);
+        else if (cross_wave) cross_consume(wave - 2 * nf, nf, fp);
+        else for (int hb = 2 + (wave - 2 * nf - 2); hb < 2 + nhp; hb += nwave - 2 * nf - 2) load_update_half(hb, 0, 1, nullptr);
         __syncthreads();
         // slices >= 1 of the update in slice order (slice 0 is already in Pan), then the next diagonal block ahead of its panel
         for (int e = tid; e < 2 * 512; e += nt) {
           const int h = e >> 9, r = (e >> 5) & 15, c = e & 31;
           double sum = 0.0;
-          for (int k2 = 0; k2 < nf - 1; ++k2) sum += fp[3 * nf * 256 + (h * (nf - 1) + k2) * 512 + r * 32 + c];
+          for (int k2 = 0; k2 < nf - 1; ++k2) sum += fp[(2 * nf + 2) * 256 + (h * (nf - 1) + k2) * 512 + r * 32 + c];
           Pan[(h * 16 + r) * RSBA_PLD + c] -= sum;
-        }
-        if (nsp > 1) {
-          for (int e = tid; e < nhp * 512; e += nt) {
-            const int hq = e >> 9, r = (e >> 5) & 15, c = e & 31, hb = 2 + hq;
-            Pan[((hb >> 1) * RSBA_PB + (hb & 1) * 16 + r) * RSBA_PLD + c] -= part2[(size_t)hq * 512 + r * 32 + c];
-          }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -538,7 +547,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
             for (int k2 = 0; k2 < nf; ++k2) d += fp[(hh * nf + k2) * 256 + o];
           } else {
             const int o = r >= 16 ? (r & 15) * 16 + (c & 15) : (c & 15) * 16 + (r & 15);   // tile (1,0), or its mirror
-            for (int k2 = 0; k2 < nf; ++k2) d += fp[(2 * nf + k2) * 256 + o];
+            d = fp[(2 * nf) * 256 + o] + fp[(2 * nf + 1) * 256 + o];
           }
           sv[u] = (have_s ? sys_pre(nb0_la + r, nb0_la + c, sv[u], du[u]) : 0.0) - d;
         }
