@@ -9,7 +9,9 @@ Follows /root/reference/Main_Calibration/correspondencer.cpp:
                                           file runs it.  Pinned on the reference's own output: the camera rows of the
                                           committed Common/Correspondence/hongo/correspondence.txt are EPnP results
                                           (tests/test_initial_guess.py::test_epnp_reproduces_the_committed_initial_guesses).
-Linear algebra is numpy's LAPACK (svd / lstsq / eigh), deliberately not the Jacobi routines of the product.
+Linear algebra is numpy's LAPACK (svd / lstsq / eigh), deliberately not the Jacobi routines of the product — except the
+3 x 3 SVD that fixes the SIGNS of the control-point axes, which restates OpenCV 4.0.1's own Jacobi routine (see
+opencv_jacobi_svd_ut): with it the committed camera rows are reproduced to their six printed digits.
 """
 import numpy as np
 
@@ -49,16 +51,55 @@ def marker_corners_in_camera(pose, side):
     return np.stack([t - E + F, t + E + F, t + E - F, t - E - F])
 
 
+def opencv_jacobi_svd_ut(A):
+    """U' (rows) and the singular values of a small square matrix as OpenCV 4.0.1's cvSVD(..., CV_SVD_U_T) returns them:
+    JacobiSVDImpl_<double> of modules/core/src/lapack.cpp (one-sided Hestenes Jacobi on the rows of A', cyclic pairs, the
+    a < b branch of the rotation, selection sort of the singular values).  Only the SIGNS of the vectors are the point of
+    restating it: EPnP's control points inherit them, and on noisy data the pose depends on them."""
+    A = np.asarray(A, float)
+    n = A.shape[0]
+    At = A.T.copy()
+    w2 = (At * At).sum(1)
+    eps = np.finfo(float).eps * 10
+    for _ in range(max(n, 30)):
+        changed = False
+        for i in range(n - 1):
+            for j in range(i + 1, n):
+                a, b, p = w2[i], w2[j], float(At[i] @ At[j])
+                if abs(p) <= eps * np.sqrt(a * b):
+                    continue
+                p *= 2
+                beta = a - b
+                gamma = np.hypot(p, beta)
+                if beta < 0:
+                    s = np.sqrt((gamma - beta) * 0.5 / gamma)
+                    c = p / (gamma * s * 2)
+                else:
+                    c = np.sqrt((gamma + beta) / (gamma * 2))
+                    s = p / (gamma * c * 2)
+                t0, t1 = c * At[i] + s * At[j], -s * At[i] + c * At[j]
+                At[i], At[j] = t0, t1
+                w2[i], w2[j] = t0 @ t0, t1 @ t1
+                changed = True
+        if not changed:
+            break
+    W = np.sqrt((At * At).sum(1))
+    for i in range(n - 1):
+        j = i + int(np.argmax(W[i:]))   # first maximum, as the strict comparison of the selection sort picks it
+        if i != j:
+            W[[i, j]] = W[[j, i]]
+            At[[i, j]] = At[[j, i]]
+    return At / np.where(W > 0, W, 1.0)[:, None], W
+
+
 def epnp(obj, img, k4):
     obj, img = np.asarray(obj, float).reshape(-1, 3), np.asarray(img, float).reshape(-1, 2)
     n = len(obj)
     fu, fv, uc, vc = k4
     c0 = obj.mean(0)
-    w, V = np.linalg.eigh((obj - c0).T @ (obj - c0))
-    order = np.argsort(-w)
-    # sign of a principal axis: its largest component positive (OpenCV leaves it to cvSVD; matters only with noisy data)
-    axes = [V[:, i] * (1.0 if V[np.argmax(np.abs(V[:, i])), i] >= 0 else -1.0) for i in order]
-    cws = np.vstack([c0] + [c0 + np.sqrt(max(w[i], 0) / n) * ax for i, ax in zip(order, axes)])
+    # principal axes and their signs as OpenCV's epnp.cpp gets them (cvSVD of PW0'PW0 with CV_SVD_U_T)
+    axes, w = opencv_jacobi_svd_ut((obj - c0).T @ (obj - c0))
+    cws = np.vstack([c0] + [c0 + np.sqrt(max(w[i], 0) / n) * axes[i] for i in range(3)])
     CC = (cws[1:] - cws[0]).T
     al = np.linalg.solve(CC, (obj - c0).T).T
     alphas = np.hstack([1 - al.sum(1, keepdims=True), al])

@@ -17,6 +17,7 @@
 //
 // Host code, double precision, no device work: the problem sizes are a few hundred points per camera.
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -80,6 +81,54 @@ void JacobiEigenSym(int n, double* A, double* evals, double* V) {
   memcpy(V, Vs.data(), Vs.size() * sizeof(double));
 }
 
+// U' and the singular values of a 3 x 3 matrix exactly as cvSVD(A, W, U', 0, CV_SVD_MODIFY_A | CV_SVD_U_T) delivers them in
+// OpenCV 4.0.1 (modules/core/src/lapack.cpp, JacobiSVDImpl_<double>: one-sided Hestenes Jacobi on the rows of A', pairs
+// (i, j) in cyclic order, rotation angle from (a - b, 2p) with the branch on a < b, singular values sorted by selection).
+// OpenCV is a third-party dependency of the reference and is not vendored; this restates the published routine for
+// ONE reason: epnp.cpp takes the principal axes of the model points from this call (choose_control_points), their SIGNS
+// are whatever the rotation sequence leaves, and with noisy detections the EPnP pose depends on them.  With these signs
+// the camera rows the reference committed in Common/Correspondence/hongo/correspondence.txt (written by
+// Correspondencer::CalculateTransforms, correspondencer.cpp:192-195) are reproduced to their six printed digits.
+void JacobiSvdUt3(const double* A, double* Ut /* rows: left singular vectors */, double* W) {
+  double At[9], w2[3];
+  for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) At[3 * i + k] = A[3 * k + i];
+  for (int i = 0; i < 3; ++i) w2[i] = At[3 * i] * At[3 * i] + At[3 * i + 1] * At[3 * i + 1] + At[3 * i + 2] * At[3 * i + 2];
+  const double eps = DBL_EPSILON * 10;
+  for (int iter = 0; iter < 30; ++iter) {
+    bool changed = false;
+    for (int i = 0; i < 2; ++i)
+      for (int j = i + 1; j < 3; ++j) {
+        double* Ai = At + 3 * i; double* Aj = At + 3 * j;
+        double a = w2[i], b = w2[j], p = Ai[0] * Aj[0] + Ai[1] * Aj[1] + Ai[2] * Aj[2];
+        if (std::fabs(p) <= eps * std::sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = std::hypot(p, beta);
+        double c, sn;
+        if (beta < 0) { const double delta = (gamma - beta) * 0.5; sn = std::sqrt(delta / gamma); c = p / (gamma * sn * 2); }
+        else { c = std::sqrt((gamma + beta) / (gamma * 2)); sn = p / (gamma * c * 2); }
+        a = b = 0;
+        for (int k = 0; k < 3; ++k) {
+          const double t0 = c * Ai[k] + sn * Aj[k], t1 = -sn * Ai[k] + c * Aj[k];
+          Ai[k] = t0; Aj[k] = t1;
+          a += t0 * t0; b += t1 * t1;
+        }
+        w2[i] = a; w2[j] = b;
+        changed = true;
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < 3; ++i) W[i] = std::sqrt(At[3 * i] * At[3 * i] + At[3 * i + 1] * At[3 * i + 1] + At[3 * i + 2] * At[3 * i + 2]);
+  for (int i = 0; i < 2; ++i) {
+    int j = i;
+    for (int k = i + 1; k < 3; ++k) if (W[j] < W[k]) j = k;
+    if (i != j) { std::swap(W[i], W[j]); for (int k = 0; k < 3; ++k) std::swap(At[3 * i + k], At[3 * j + k]); }
+  }
+  for (int i = 0; i < 3; ++i) {
+    const double sc = W[i] > DBL_MIN ? 1.0 / W[i] : 0.0;   // (a vanishing direction: coplanar points, refused further down)
+    for (int k = 0; k < 3; ++k) Ut[3 * i + k] = At[3 * i + k] * sc;
+  }
+}
+
 // Minimum-norm least squares x = argmin |A x - b|, A m x k (k <= 5), through the eigen-decomposition of A'A
 // (what cvSolve(..., CV_SVD) returns for these well-posed 6 x k systems).
 void LeastSquares(int m, int k, const double* A, const double* b, double* x) {
@@ -127,18 +176,14 @@ struct EPnP {
 
   void ChooseControlPoints() {
     for (int k = 0; k < 3; ++k) { double s = 0; for (int i = 0; i < n; ++i) s += pws[3 * i + k]; cws[0][k] = s / n; }
-    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ev[3], V[9];
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dc[3], uct[9];
     for (int i = 0; i < n; ++i)
       for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] += (pws[3 * i + a] - cws[0][a]) * (pws[3 * i + b] - cws[0][b]);
-    JacobiEigenSym(3, C, ev, V);
+    // principal axes with the signs OpenCV's SVD gives them (epnp.cpp choose_control_points: cvSVD of PW0'PW0, U transposed)
+    JacobiSvdUt3(C, uct, dc);
     for (int i = 1; i < 4; ++i) {
-      // The sign of a principal axis is the SVD routine's business in OpenCV (cvSVD) and changes the result when the
-      // data are noisy (not when they are exact); here: the axis' largest component is positive.
-      double* ax = V + 3 * (i - 1);
-      int big = 0;
-      for (int j = 1; j < 3; ++j) if (std::fabs(ax[j]) > std::fabs(ax[big])) big = j;
-      const double k = (ax[big] < 0 ? -1.0 : 1.0) * std::sqrt(std::max(ev[i - 1], 0.0) / n);
-      for (int j = 0; j < 3; ++j) cws[i][j] = cws[0][j] + k * ax[j];
+      const double k = std::sqrt(std::max(dc[i - 1], 0.0) / n);
+      for (int j = 0; j < 3; ++j) cws[i][j] = cws[0][j] + k * uct[3 * (i - 1) + j];
     }
   }
   bool ComputeBarycentric() {
