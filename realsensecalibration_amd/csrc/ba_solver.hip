@@ -13,6 +13,7 @@
 // factors the identical system, so no broadcast is needed and all ranks take identical decisions.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -115,6 +116,40 @@ class KernelTimer {
   std::vector<Pending> pending_;
   std::vector<hipEvent_t> pool_;
   std::map<std::string, std::pair<int64_t, double>> stats_;
+};
+
+// roctx ranges around the stages of an LM step (K1 residual + cost, K2 linearise, K3 Schur accumulate, K4
+// reduced solve, K5 back-substitution, K6 LM bookkeeping, K7 RCCL), for `rocprofv3 --marker-trace`.  Opt-in (RSBA_ROCTX=1):
+// the library is looked up at run time (librocprofiler-sdk-roctx.so, then libroctx64.so), nothing is linked, and without
+// the variable a range is one branch.  The ranges bracket the host-side LAUNCHES; the kernels carry their own names.
+class RoctxRange {
+ public:
+  explicit RoctxRange(const char* name) { if (Api().push) { Api().push(name); on_ = true; } }
+  ~RoctxRange() { End(); }
+  void End() { if (on_) { Api().pop(); on_ = false; } }
+  RoctxRange(const RoctxRange&) = delete;
+  RoctxRange& operator=(const RoctxRange&) = delete;
+ private:
+  struct Fns { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+  static const Fns& Api() {
+    static const Fns fns = [] {
+      Fns f;
+      const char* e = getenv("RSBA_ROCTX");
+      if (!e || atoi(e) == 0) return f;
+      for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+        if (void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+          f.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+          f.pop = (int (*)())dlsym(h, "roctxRangePop");
+          if (f.push && f.pop) return f;
+          f = Fns();
+        }
+      }
+      fprintf(stderr, "rsba: RSBA_ROCTX set but no roctx library could be loaded\n");
+      return f;
+    }();
+    return fns;
+  }
+  bool on_ = false;
 };
 
 template <typename T>
@@ -787,6 +822,7 @@ void TiledSchur::LaunchPointDamp(rsba_solver* s, const IterParams& ip, KernelTim
 // The point side of a step: a full pass over the observation records only when x has no linearisation yet (the first
 // step of a run, or RSBA_FUSED_LIN=0); otherwise the kept one is damped with this step's radius.
 static void LaunchPointSide(TiledSchur& ts, rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st) {
+  RoctxRange rr("K1+K2 point side: residuals, cost, point blocks (or their damping)");
   if (ts.lin_valid && !ip.first) ts.LaunchPointDamp(s, ip, T, st);
   else ts.LaunchPointPass(s, ip, T, st);
 }
@@ -807,6 +843,7 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
 }
 
 void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag) {
+  RoctxRange rr("K2+K3 camera-side rows + Schur elimination into the reduced system");
   const SchurArgs a = MakeSchurArgs(*this, s, tag);
   T.Begin("k_schur_tiles", st);
   if (ip.huber_delta != 0.0) k_schur_tiles<true><<<nblocks, 256, 0, st>>>(a);
@@ -815,6 +852,7 @@ void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& 
 }
 
 void TiledSchur::LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st) {
+  RoctxRange rr("K2 camera gradient only (self tiles)");
   SchurArgs a = MakeSchurArgs(*this, s, 0);
   a.segs_ordered = segs_ordered_self; a.self_only = 1; a.trace = nullptr; a.wg_trace = nullptr;
   T.Begin("k_schur_tiles(self only)", st);
@@ -908,6 +946,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const bool mg = s->pipelined_mg;
     // multi-GPU: the gates open on the flags the communication stream publishes after each stage's all-reduce, the
     // panels are read from the (all-reduced) row slab of their own group, and the waits may last as long as the slowest rank
+    RoctxRange rr_k4("K4 reduced camera system: Cholesky + solve (launched ahead, gated on the Schur stages)");
     T.Begin("k_reduced_system_solve", s->sB);
     if (s->chol_wgs > 1 && !mg)
       k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
@@ -920,6 +959,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
                                                      s->chol_ok, StageGate{mg ? s->ready_global : ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15,
                                                                            T.all_kernels() ? s->chol_waited : nullptr, s->trace, mg ? 10 * RSBA_STALL_TICKS : 0});
     T.End(s->sB);
+    rr_k4.End();
     ts.LaunchTiles(s, ip, T, st, tag);
     if (mg) {
       // communication stream: stage by stage, as the Schur kernel publishes them locally — the row slab of S of the
@@ -947,6 +987,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   DebugSync(st, "linearize+schur");
 
   if (s->comm && !(pipe && s->pipelined_mg)) {
+    RoctxRange rr_k7("K7 RCCL all-reduce of the reduced system");
     // one group: the sum of the packed reduced system and the max of the point-gradient bound go out as one launch
     NCCLCHK(ncclGroupStart());
     NCCLCHK(ncclAllReduce(s->red, s->red, s->L.size(), ncclDouble, ncclSum, s->comm, st));
@@ -954,6 +995,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     NCCLCHK(ncclGroupEnd());
   }
 
+  RoctxRange rr_k4s(pipe ? "K4 (already launched)" : "K4 reduced camera system: Cholesky + solve");
   if (pipe) {
     // issued at the top of the step (see below): nothing left to launch here
   } else if (s->nc <= RSBA_CHOL_MAXN) {
@@ -1009,6 +1051,8 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     T.End(st);
     }
   }
+  rr_k4s.End();
+  RoctxRange rr_k5("K5 back-substitution + candidate (K1 at the candidate, fused re-linearisation)");
   DebugSync(st, "k_reduced_system_solve");
   T.Begin("k_backsub_candidate", st);
   // single GPU: the kernel's last workgroup finishes the step (sums, result block, post to the host)
@@ -1034,6 +1078,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (fused) s->tiled.lin_valid = true;
   }
   T.End(st);
+  rr_k5.End();
   DebugSync(st, "k_backsub_candidate");
   if (s->comm) {
     const bool mg = pipe && s->pipelined_mg;
@@ -1055,6 +1100,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   }
   HIPCHK(hipGetLastError());
   if (s->trace) s->host_t[2] = std::chrono::steady_clock::now();
+  RoctxRange rr_k6("K6 LM bookkeeping: wait for the step's result block");
   { const int rcw = WaitResult(s, s->comm && pipe && s->pipelined_mg ? s->sR : st); if (rcw != RSBA_OK) return rcw; }
   if (s->trace) {
     const auto now = std::chrono::steady_clock::now();
