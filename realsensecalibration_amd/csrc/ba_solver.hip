@@ -836,7 +836,7 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   a.cam_prefix = ts.cam_prefix; a.cam_ptr = ts.cam_ptr; a.sq_cm = ts.sq_cm2[x]; a.u_cm = ts.u_cm; a.v_cm = ts.v_cm; a.partial = ts.partial;
   a.grp_sum = ts.grp_sum; a.sync_cnt = ts.sync_cnt; a.ngrp = ts.ngrp; a.ntiles = ts.ntiles; a.segs_ordered = ts.segs_ordered; a.small_flag = ts.small_flag; a.last_group = ts.ngroups - 1; a.tile_sum = ts.tile_sum;
   a.tree_error = ts.tree_error; a.ticket = ts.tree_error + 1;
-  a.ready = ts.ready; a.tag = tag; a.self_only = 0; a.red = s->red; a.L = s->L; a.nblocks_pp = ts.grid_pp; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
+  a.ready = ts.ready; a.tag = tag; a.self_only = 0; { static const int nt = getenv("RSBA_NO_TICKET") ? atoi(getenv("RSBA_NO_TICKET")) : 0; a.no_ticket = nt; } a.red = s->red; a.L = s->L; a.nblocks_pp = ts.grid_pp; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
   a.grp_flag = ts.grp_flag; a.epoch = ++ts.epoch;
   return a;
