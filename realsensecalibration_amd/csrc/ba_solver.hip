@@ -31,6 +31,7 @@
 #include "ba_point_kernels.hpp"
 #include "ba_cholesky_large.hpp"
 #include "ba_cholesky_multi.hpp"
+#include "ba_cholesky_diag.hpp"
 #include "ba_cholesky_tiles.hpp"
 #include "ba_problem.hpp"
 #include "ba_schur_tiled.hpp"
@@ -173,6 +174,7 @@ struct rsba_solver {
                              // (both exercise the fallback to the sequential schedule)
   int step_tag = 0;
   int chol_wgs = 1;          // > 1: the reduced system is factored by this many workgroups (ba_cholesky_multi.hpp)
+  bool chol_diag = false;    // RSBA_CHOL_DIAG=1: ... with the diagonal chain in workgroup 0 (ba_cholesky_diag.hpp, opt-in: measured slower)
   int* mc_flags = nullptr;   // tdone[16] | strip_ready[16] | wg_done[8] | error
   int* tc_flags = nullptr;   // persistent tiled factorisation (more than 64 cameras): tdone[np] | xdone[np][nrt] | error
   int tc_np = 0, tc_nrt = 0, tc_tiles = 0;   // 0 tiles: the multi-launch path
@@ -746,8 +748,11 @@ static int UploadPoints(rsba_solver* s) {
     const int want = e ? atoi(e) : 4;
     if (want > 1 && s->opt.schur_impl != 0 && s->nc >= 6 * RSBA_PB && s->nc <= RSBA_CHOL_MAXN && !s->pipelined_mg) {
       s->chol_wgs = std::min(want, RSBA_MC_MAXG);
-      if ((rc = DevAlloc(&s->mc_flags, 48))) return rc;
-      HIPCHK(hipMemset(s->mc_flags, 0, 48 * sizeof(int)));
+      if ((rc = DevAlloc(&s->mc_flags, 64))) return rc;
+      HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
+      s->chol_diag = getenv("RSBA_CHOL_DIAG") && atoi(getenv("RSBA_CHOL_DIAG")) == 1 && s->chol_wgs >= 2;   // opt-in (see ba_cholesky_diag.hpp)
+      HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(DiagCholLdsDoubles(s->nc) * sizeof(double))));
       if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, RSBA_MC_MAXG * 16 * 8))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, RSBA_MC_MAXG * 16 * 8 * sizeof(long long))); }
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(MultiCholLdsDoubles(s->nc) * sizeof(double))));
@@ -948,11 +953,16 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // panels are read from the (all-reduced) row slab of their own group, and the waits may last as long as the slowest rank
     RoctxRange rr_k4("K4 reduced camera system: Cholesky + solve (launched ahead, gated on the Schur stages)");
     T.Begin("k_reduced_system_solve", s->sB);
-    if (s->chol_wgs > 1 && !mg)
+    if (s->chol_wgs > 1 && !mg && s->chol_diag)
+      k_reduced_system_solve_diag<<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
+          C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
+          StageGate{ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0},
+          DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48}, tag, s->mc_trace);
+    else if (s->chol_wgs > 1 && !mg)
       k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
           StageGate{ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0},
-          MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 40}, tag, s->mc_trace);
+          MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48}, tag, s->mc_trace);
     else
     k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                      s->camc[c], s->dcam, s->gmax, s->res, ip, (mg || getenv("RSBA_TRANSPOSED_SOURCE")) ? 2 : 1,
@@ -1001,10 +1011,15 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   } else if (s->nc <= RSBA_CHOL_MAXN) {
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(s->nc)) * sizeof(double);
     T.Begin("k_reduced_system_solve", st);
-    if (s->chol_wgs > 1 && !keep_system_copy)
+    if (s->chol_wgs > 1 && !keep_system_copy && s->chol_diag)
+      k_reduced_system_solve_diag<<<s->chol_wgs, 512, DiagCholLdsDoubles(s->nc) * sizeof(double), st>>>(
+          C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
+          StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0}, DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48},
+          s->step_tag, s->mc_trace);
+    else if (s->chol_wgs > 1 && !keep_system_copy)
       k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(s->nc) * sizeof(double), st>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
-          StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0}, MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 40},
+          StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0}, MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48},
           s->step_tag, s->mc_trace);
     else
     k_reduced_system_solve<<<1, 512, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
@@ -1156,7 +1171,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // the workgroups of the factorisation did not run side by side (cannot happen on an idle stream): one workgroup then
     fprintf(stderr, "rsba: multi-workgroup Cholesky stalled; using one workgroup\n");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemset(s->mc_flags, 0, 48 * sizeof(int)));
+    HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
     s->chol_wgs = 1;
     return PointsStep(s, radius, first, keep_system_copy);
   }
@@ -1167,7 +1182,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(s->tiled.sync_cnt, 0, (size_t)s->tiled.nsync * sizeof(int)));
     HIPCHK(hipMemset(s->tiled.tree_error + 1, 0, sizeof(int)));
-    if (s->mc_flags) HIPCHK(hipMemset(s->mc_flags, 0, 48 * sizeof(int)));
+    if (s->mc_flags) HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
     s->pipelined = false; s->pipelined_mg = false;
     return PointsStep(s, radius, first, keep_system_copy);
   }

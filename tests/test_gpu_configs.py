@@ -217,3 +217,25 @@ def test_balanced_point_order_is_internal(oracle, C, P, k, huber, monkeypatch):
     assert _block_rel(got, plain, C) < 1e-8
     assert np.abs(a["delta"] - b["delta"]).max() < 1e-9 * np.abs(b["delta"]).max()
     assert np.abs(a["S"] - b["S"]).max() < 1e-11 * np.abs(b["S"]).max()
+
+
+# ------------------------------------------------------------------ opt-in factorisation with the diagonal chain in one workgroup
+@pytest.mark.parametrize("C,P,k,huber", [(33, 2500, 8, 0.0), (48, 3000, 9, 1.0), (64, 4000, 12, 0.0)])
+def test_diagonal_workgroup_cholesky_opt_in(oracle, C, P, k, huber, monkeypatch):
+    """RSBA_CHOL_DIAG=1 (ba_cholesky_diag.hpp: workgroup 0 keeps the chain of diagonal factorisations, the others own the
+    rows below): same trajectory and blocks as the oracle, pipelined and sequential schedule bit for bit, two runs bit for
+    bit."""
+    monkeypatch.setenv("RSBA_CHOL_DIAG", "1")
+    prob = syn.make_problem(C, P, k, seed=60 + C, outlier_frac=0.05 if huber else 0.0)
+    ref, s_ref, log_ref = oracle.solve_points(prob, oracle.options(huber_delta=huber, num_threads=_threads()))
+    got, s_got, log_got = capi.solve_points(prob, capi.default_options(huber_delta=huber))
+    again, s_again, log_again = capi.solve_points(prob, capi.default_options(huber_delta=huber))
+    assert (s_got.num_iterations, s_got.stop_reason) == (s_ref.num_iterations, s_ref.stop_reason)
+    assert np.array_equal(log_got[:, 7], log_ref[:, 7])
+    assert _block_rel(got, ref, C) < 1e-6
+    assert abs(s_got.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
+    assert np.array_equal(got, again) and np.array_equal(log_got, log_again)
+    monkeypatch.setenv("RSBA_PIPELINE", "0")
+    monkeypatch.setenv("RSBA_SEG_PER_CU", "8")
+    seq, s_seq, log_seq = capi.solve_points(prob, capi.default_options(huber_delta=huber))
+    assert np.array_equal(got, seq) and np.array_equal(log_got, log_seq)
