@@ -55,6 +55,7 @@ struct PartLayout {
 struct TimeSlots {  // per residual block, in time order: where its camera / marker block sits
   int slot_cam, slot_marker;   // index in its time's slot list (-1: block not part of the residual)
   int col_cam, col_marker;     // first column in the reduced system (-1)
+  int camera, pad;             // camera index of the detection (its intrinsics), whether or not the camera pose is a parameter
 };
 
 // 6 x 6 SPD inverse through Cholesky; false when a pivot is not positive and finite.
@@ -100,6 +101,18 @@ __device__ inline bool InvertSpd6(const double* A, double* E) {
   return ok;
 }
 
+// Constants of every pose of the parameter array at the current linearisation (rotation matrix, left Jacobian of SO(3),
+// translation, AngleAxisRotatePoint's branch): once per pose instead of once per corner of every residual block.
+__global__ void __launch_bounds__(256) k_pose_constants(int nposes, const double* __restrict__ params, double* __restrict__ posec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nposes) return;
+  const double zero4[4] = {0.0, 0.0, 0.0, 0.0};
+  double cc[CC_STRIDE];
+  CameraConstants(params + 6 * (size_t)i, zero4, cc);
+#pragma unroll
+  for (int q = 0; q < CC_STRIDE; ++q) posec[(size_t)i * CC_STRIDE + q] = cc[q];
+}
+
 struct ElimArgs {
   int nr, dmax;
   const int* __restrict__ chunk_ptr;   // [G + 1] times of each workgroup
@@ -107,10 +120,15 @@ struct ElimArgs {
   const int* __restrict__ slot_ptr;    // [T + 1] slots (distinct camera / marker blocks) of each time
   const int* __restrict__ slot_col;    // first reduced column of each slot, ascending inside a time
   const int* __restrict__ time_full;   // offset of the time block in the full parameter array
+  const int* __restrict__ col_full;    // reduced column -> index in the full parameter array
   const TimeSlots* __restrict__ ts;
-  const double* __restrict__ J;        // [N][8][18]
-  const double* __restrict__ r;        // [N][8]
-  const double* __restrict__ sumsq;    // [N]
+  // the residual blocks' Jacobians are NOT stored: every tile of 32 blocks is evaluated where it is used, analytically
+  // (MarkerCornerResidualJacobian, ba_math.hpp) from the poses' constants of this linearisation
+  const MarkerObs* __restrict__ mo;    // [N]
+  const double* __restrict__ obs8;     // [N][8]
+  const double* __restrict__ intr;     // [C][4]
+  const double* __restrict__ posec;    // [poses][CC_STRIDE]: R, left Jacobian, t, branch flag of every pose at x (k_pose_constants)
+  double half_side;
   const double* __restrict__ params_x;
   double* __restrict__ scale_t;        // [6 T]
   double* __restrict__ tdata;          // [T][48]: E (36), g_t (6)
@@ -144,7 +162,9 @@ k_time_eliminate(ElimArgs a) {
   int* mk = scol + dmax / 6 + 1;          //   bit i: staged residual block i has the slot
   int* kb = mk + dmax / 6 + 1;            //   where the slot's block sits in a residual's Jacobian: column 0 (camera) or 12 (marker)
   // the chunk's sum of S (packed lower triangle): in LDS when it fits, else straight in the workgroup's partial system
-  double* Sl = (double*)(sl + ((2 * RSBA_MT_TILE + 3 * (dmax / 6 + 1) + 1) & ~1));
+  // pose constants of the current time: the time pose, then one per slot (camera / marker block of the time)
+  double* pcl = (double*)(sl + ((2 * RSBA_MT_TILE + 3 * (dmax / 6 + 1) + 1) & ~1));   // [dmax / 6 + 2][CC_STRIDE]
+  double* Sl = pcl + (size_t)(dmax / 6 + 2) * CC_STRIDE;
   double* P = a.part + (size_t)blockIdx.x * RL.size();
   double* Sacc = kLdsS ? Sl : P + RL.S();
   for (size_t e = tid; e < RL.packed(); e += RSBA_MT_THREADS) Sacc[e] = 0.0;
@@ -164,24 +184,38 @@ k_time_eliminate(ElimArgs a) {
     for (int e = tid; e < d; e += RSBA_MT_THREADS) Gr[e] = 0.0;
     if (tid < 43) Vs[tid] = 0.0;
     for (int e = tid; e < nslot; e += RSBA_MT_THREADS) scol[e] = a.slot_col[s0 + e];
+    for (int e = tid; e < (nslot + 1) * CC_STRIDE; e += RSBA_MT_THREADS) {
+      const int ps = e / CC_STRIDE, q = e - ps * CC_STRIDE;
+      const int pose = (ps == 0 ? a.time_full[t] : a.col_full[a.slot_col[s0 + ps - 1]]) / 6;
+      pcl[e] = a.posec[(size_t)pose * CC_STRIDE + q];
+    }
     const int ntile = (nobs + RSBA_MT_TILE - 1) / RSBA_MT_TILE;
     auto stage = [&](int tile) {
       const int b0 = o0 + tile * RSBA_MT_TILE, nb = min(RSBA_MT_TILE, nobs - tile * RSBA_MT_TILE);
       __syncthreads();   // the previous tile has been consumed
-      {
-        // all loads of the tile in flight before the first LDS store (a loop with an unknown bound waits for each)
-        constexpr int kIter = (RSBA_MT_TILE * 144 + RSBA_MT_THREADS - 1) / RSBA_MT_THREADS;
-        double v[kIter];
-#pragma unroll
-        for (int k = 0; k < kIter; ++k) { const int e = tid + k * RSBA_MT_THREADS; v[k] = e < nb * 144 ? a.J[(size_t)b0 * 144 + e] : 0.0; }
-        const double rv = tid < nb * 8 ? a.r[(size_t)b0 * 8 + tid] : 0.0;
-#pragma unroll
-        for (int k = 0; k < kIter; ++k) { const int e = tid + k * RSBA_MT_THREADS; if (e < nb * 144) Jt[(e / 144) * RSBA_MT_JLD + e % 144] = v[k]; }
-        if (tid < nb * 8) rt[tid] = rv;
+      if (tid < nb * 4) {
+        // one corner of one residual block per thread: residuals (2) and Jacobian rows (2 x 18)
+        const int b = tid >> 2, k = tid & 3;
+        const TimeSlots sb = a.ts[b0 + b];
+        const double u = a.obs8[8 * (size_t)(b0 + b) + 2 * k], v = a.obs8[8 * (size_t)(b0 + b) + 2 * k + 1];
+        const double hs = a.half_side;
+        const double cx = (k == 0 || k == 3) ? -hs : hs, cy = k < 2 ? hs : -hs;
+        // (the rows go straight into the staged tile: a local 2 x 18 array would not fit the 128 registers of a
+        //  1024-thread workgroup; the poses' constants come from LDS, staged once per time)
+        MarkerCornerResidualJacobian(sb.slot_cam >= 0 ? pcl + (size_t)(1 + sb.slot_cam) * CC_STRIDE : nullptr, pcl,
+                                     sb.slot_marker >= 0 ? pcl + (size_t)(1 + sb.slot_marker) * CC_STRIDE : nullptr,
+                                     a.intr + 4 * sb.camera, cx, cy, u, v,
+                                     rt + b * 8 + 2 * k, Jt + b * RSBA_MT_JLD + 36 * k);
       }
-      for (int e = tid; e < nb; e += RSBA_MT_THREADS) { sl[2 * e] = a.ts[b0 + e].slot_cam; sl[2 * e + 1] = a.ts[b0 + e].slot_marker; sqv[e] = a.sumsq[b0 + e]; }
+      for (int e = tid; e < nb; e += RSBA_MT_THREADS) { sl[2 * e] = a.ts[b0 + e].slot_cam; sl[2 * e + 1] = a.ts[b0 + e].slot_marker; }
       for (int e = tid; e < nslot; e += RSBA_MT_THREADS) mk[e] = 0;
       __syncthreads();
+      if (tid < nb) {   // squared residual norm of a block, corner by corner
+        double ss = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ss += rt[tid * 8 + 2 * k] * rt[tid * 8 + 2 * k] + rt[tid * 8 + 2 * k + 1] * rt[tid * 8 + 2 * k + 1];
+        sqv[tid] = ss;
+      }
       // which staged residual blocks belong to a slot (bit order = block order: the sums below run in a fixed order)
       if (tid < nb) {
         const int sc = sl[2 * tid], sm = sl[2 * tid + 1];
@@ -450,7 +484,7 @@ k_marker_chol_finish(int nr, const double* __restrict__ red, double* __restrict_
 __global__ void __launch_bounds__(256)
 k_time_backsub_terms(int T, const int* __restrict__ time_ptr, const int* __restrict__ time_full, const TimeSlots* __restrict__ ts,
                      const MarkerObs* __restrict__ mo, const double* __restrict__ obs8, const double* __restrict__ intr, double half_side,
-                     const double* __restrict__ J, const double* __restrict__ rres, const double* __restrict__ tdata,
+                     const double* __restrict__ posec /* pose constants at x */, const double* __restrict__ tdata,
                      const double* __restrict__ delta_r, const double* __restrict__ params_x, double* __restrict__ params_c,
                      double* __restrict__ delta_t, double* __restrict__ bpart /* gridDim.x x 4 */) {
   __shared__ double s_part[4][4];
@@ -465,13 +499,24 @@ k_time_backsub_terms(int T, const int* __restrict__ time_ptr, const int* __restr
       double dc[6], dm[6];
 #pragma unroll
       for (int x = 0; x < 6; ++x) { dc[x] = s.col_cam >= 0 ? delta_r[s.col_cam + x] : 0.0; dm[x] = s.col_marker >= 0 ? delta_r[s.col_marker + x] : 0.0; }
-      const double* Ji = J + (size_t)i * 144;
-      for (int q = 0; q < 8; ++q) {
-        double m = 0.0;
+      // the block's Jacobian rows, corner by corner, recomputed (never stored: see ElimArgs)
+      const MarkerObs o = mo[i];
+      const double* pcc = o.full_cam >= 0 ? posec + (size_t)(o.full_cam / 6) * CC_STRIDE : nullptr;
+      const double* pct = posec + (size_t)(o.full_time / 6) * CC_STRIDE;
+      const double* pcm = o.full_marker >= 0 ? posec + (size_t)(o.full_marker / 6) * CC_STRIDE : nullptr;
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        double rr[2], Jc[36];
+        MarkerCornerResidualJacobian(pcc, pct, pcm, intr + 4 * o.camera, (k == 0 || k == 3) ? -half_side : half_side, k < 2 ? half_side : -half_side,
+                                     obs8[8 * (size_t)i + 2 * k], obs8[8 * (size_t)i + 2 * k + 1], rr, Jc);
 #pragma unroll
-        for (int x = 0; x < 6; ++x) m += Ji[q * 18 + x] * dc[x] + Ji[q * 18 + 12 + x] * dm[x];
+        for (int q = 0; q < 2; ++q) {
+          double m = 0.0;
 #pragma unroll
-        for (int x = 0; x < 6; ++x) h[x] += Ji[q * 18 + 6 + x] * m;
+          for (int x = 0; x < 6; ++x) m += Jc[q * 18 + x] * dc[x] + Jc[q * 18 + 12 + x] * dm[x];
+#pragma unroll
+          for (int x = 0; x < 6; ++x) h[x] += Jc[q * 18 + 6 + x] * m;
+        }
       }
     }
 #pragma unroll
@@ -509,12 +554,23 @@ k_time_backsub_terms(int T, const int* __restrict__ time_ptr, const int* __restr
         dl[6 + x] = dt[x];
         dl[12 + x] = s.col_marker >= 0 ? delta_r[s.col_marker + x] : 0.0;
       }
-      const double* Ji = J + (size_t)i * 144;
-      for (int q = 0; q < 8; ++q) {
-        double m = 0.0;
+      {
+        const double* pcc = o.full_cam >= 0 ? posec + (size_t)(o.full_cam / 6) * CC_STRIDE : nullptr;
+        const double* pct = posec + (size_t)(o.full_time / 6) * CC_STRIDE;
+        const double* pcm = o.full_marker >= 0 ? posec + (size_t)(o.full_marker / 6) * CC_STRIDE : nullptr;
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+          double rr[2], Jc[36];
+          MarkerCornerResidualJacobian(pcc, pct, pcm, intr + 4 * o.camera, (k == 0 || k == 3) ? -half_side : half_side, k < 2 ? half_side : -half_side,
+                                       obs8[8 * (size_t)i + 2 * k], obs8[8 * (size_t)i + 2 * k + 1], rr, Jc);
 #pragma unroll
-        for (int x = 0; x < 18; ++x) m += Ji[q * 18 + x] * dl[x];
-        mcc -= m * (rres[(size_t)i * 8 + q] + 0.5 * m);
+          for (int q = 0; q < 2; ++q) {
+            double m = 0.0;
+#pragma unroll
+            for (int x = 0; x < 18; ++x) m += Jc[q * 18 + x] * dl[x];
+            mcc -= m * (rr[q] + 0.5 * m);
+          }
+        }
       }
       // candidate residuals: cameras and markers of the candidate are in params_c already (reduced solve), the time here
       const double fx = intr[4 * o.camera], fy = intr[4 * o.camera + 1], ppx = intr[4 * o.camera + 2], ppy = intr[4 * o.camera + 3];
@@ -574,7 +630,7 @@ struct MarkerSchurDevice {
   int *chunk_ptr = nullptr, *time_ptr = nullptr, *slot_ptr = nullptr, *slot_col = nullptr, *time_full = nullptr, *col_full = nullptr,
       *ok_flag = nullptr;
   double *obs8 = nullptr, *intr = nullptr, *params[2] = {nullptr, nullptr}, *params0 = nullptr;
-  double *Jbuf = nullptr, *rbuf = nullptr, *ss_x = nullptr, *scale_t = nullptr, *scale_r = nullptr, *tdata = nullptr,
+  double *posec = nullptr, *ss_x = nullptr, *scale_t = nullptr, *scale_r = nullptr, *tdata = nullptr,
          *part = nullptr, *red = nullptr, *A = nullptr, *Wm = nullptr, *delta_r = nullptr, *delta_t = nullptr, *bp_time = nullptr,
          *solve_out = nullptr, *res = nullptr;
   int cur = 0;
@@ -585,7 +641,7 @@ struct MarkerSchurDevice {
 
   void Free() {
     void* ptrs[] = {mo, ts, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ok_flag, obs8, intr, params[0], params[1],
-                    params0, Jbuf, rbuf, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res, tc_flags};
+                    params0, posec, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res, tc_flags};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     mo = nullptr; ts = nullptr;
   }
@@ -660,6 +716,7 @@ struct MarkerSchurDevice {
         TimeSlots& s = hts[k];
         s.col_cam = p.uses_camera(i) ? red_col[p.camera_index[i]] : -1;
         s.col_marker = p.uses_marker(i) ? red_col[C + p.marker_index[i]] : -1;
+        s.camera = p.camera_index[i]; s.pad = 0;
         s.slot_cam = s.col_cam >= 0 ? (int)(std::lower_bound(cols.begin(), cols.end(), s.col_cam) - cols.begin()) : -1;
         s.slot_marker = s.col_marker >= 0 ? (int)(std::lower_bound(cols.begin(), cols.end(), s.col_marker) - cols.begin()) : -1;
         memcpy(&hobs[8 * (size_t)k], &p.observations[8 * (size_t)i], 8 * sizeof(double));
@@ -674,7 +731,7 @@ struct MarkerSchurDevice {
     // chunks of consecutive times, balanced by work; the partial systems together stay below 2 GB
     const RedLayout RL{nr};
     const PartLayout PL{nr};
-    lds_elim = (size_t)(13 * dmax + 96 + RSBA_MT_TILE * (RSBA_MT_JLD + 9)) * sizeof(double) + (size_t)(2 * RSBA_MT_TILE + 3 * (dmax / 6 + 1) + 2) * sizeof(int);
+    lds_elim = (size_t)(13 * dmax + 96 + RSBA_MT_TILE * (RSBA_MT_JLD + 9) + (dmax / 6 + 2) * CC_STRIDE) * sizeof(double) + (size_t)(2 * RSBA_MT_TILE + 3 * (dmax / 6 + 1) + 2) * sizeof(int);
     lds_s = lds_elim + PL.packed() * sizeof(double) <= 156 * 1024;
     if (lds_s) lds_elim += PL.packed() * sizeof(double);
     // Without the LDS accumulators every entry is a read-modify-write in the partial system: few enough workgroups that
@@ -708,8 +765,8 @@ struct MarkerSchurDevice {
         !al((void**)&time_ptr, (T + 1) * 4) || !al((void**)&slot_ptr, (T + 1) * 4) || !al((void**)&slot_col, scol.size() * 4) ||
         !al((void**)&time_full, T * 4) || !al((void**)&col_full, nr * 4) || !al((void**)&ok_flag, 4) ||
         !al((void**)&obs8, 8 * (size_t)N * 8) || !al((void**)&intr, p.intrinsics.size() * 8) || !al((void**)&params[0], nfull * 8) ||
-        !al((void**)&params[1], nfull * 8) || !al((void**)&params0, nfull * 8) || !al((void**)&Jbuf, (size_t)N * 144 * 8) ||
-        !al((void**)&rbuf, (size_t)N * 8 * 8) || !al((void**)&ss_x, N * 8) || !al((void**)&scale_t, 6 * (size_t)T * 8) ||
+        !al((void**)&params[1], nfull * 8) || !al((void**)&params0, nfull * 8) || !al((void**)&posec, (size_t)(nfull / 6) * CC_STRIDE * 8) ||
+        !al((void**)&ss_x, N * 8) || !al((void**)&scale_t, 6 * (size_t)T * 8) ||
         !al((void**)&scale_r, nr * 8) || !al((void**)&tdata, 48 * (size_t)T * 8) || !al((void**)&part, (size_t)G * PL.size() * 8) ||
         !al((void**)&red, RL.size() * 8) || !al((void**)&A, nA * 8) || (nr > RSBA_CHOL_MAXN && !al((void**)&Wm, nA * 8)) ||
         !al((void**)&delta_r, nr * 8) || !al((void**)&delta_t, 6 * (size_t)T * 8) || !al((void**)&bp_time, 4 * (size_t)nb_time * 8) ||
@@ -770,10 +827,10 @@ struct MarkerSchurDevice {
     };
     if (!chk("(before marker step)")) return RSBA_ERR_HIP;
     const RedLayout RL{nr};
-    Tm.Begin("k_marker_eval", st);
-    k_marker_eval<<<(N + 63) / 64, 64, 0, st>>>(N, mo, obs8, params[x], intr, half_side, 1, Jbuf, rbuf, ss_x);
+    Tm.Begin("k_pose_constants", st);
+    k_pose_constants<<<(nfull / 6 + 255) / 256, 256, 0, st>>>(nfull / 6, params[x], posec);
     Tm.End(st);
-    ElimArgs ea{nr, dmax, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, ts, Jbuf, rbuf, ss_x, params[x], scale_t, tdata, part, ip};
+    ElimArgs ea{nr, dmax, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ts, mo, obs8, intr, posec, half_side, params[x], scale_t, tdata, part, ip};
     Tm.Begin("k_time_eliminate", st);
     if (lds_s) k_time_eliminate<true><<<G, RSBA_MT_THREADS, lds_elim, st>>>(ea);
     else k_time_eliminate<false><<<G, RSBA_MT_THREADS, lds_elim, st>>>(ea);
@@ -813,7 +870,7 @@ struct MarkerSchurDevice {
     }
     if (!chk("reduced solve")) return RSBA_ERR_HIP;
     Tm.Begin("k_time_backsub_terms", st);
-    k_time_backsub_terms<<<nb_time, 256, 0, st>>>(T, time_ptr, time_full, ts, mo, obs8, intr, half_side, Jbuf, rbuf, tdata, delta_r, params[x],
+    k_time_backsub_terms<<<nb_time, 256, 0, st>>>(T, time_ptr, time_full, ts, mo, obs8, intr, half_side, posec, tdata, delta_r, params[x],
                                                   params[c], delta_t, bp_time);
     Tm.End(st);
     Tm.Begin("k_marker_schur_finish", st);

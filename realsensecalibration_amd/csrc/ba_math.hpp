@@ -133,6 +133,81 @@ RSBA_HD void ResidualJacobian(const double* cc, const double X[3], double u, dou
   jc[9] = 0.0; jc[10] = be; jc[11] = de;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Marker-chain functors (Main_Calibration/bundle_adjustment.h:56-343), ONE CORNER, analytically.
+//
+//   X = (cx, cy, 0)  --marker-->  p_m = R_m X + t_m  --time-->  p_t = R_t p_m + t_t  --camera-->  p_c = R_c p_t + t_c
+//   r = (fx p_c0 / p_c2 + ppx - u,  fy p_c1 / p_c2 + ppy - v)
+// with the marker and / or the camera transform absent in three of the four functors (pc_marker / pc_cam == nullptr).
+// J is 2 x 18, columns camera | time | marker (rvec3, tvec3 each), zero for an absent block.  With Pj = d r / d p_c and
+// Q the 2 x 3 sensitivity of r to the point ENTERING a transform (Q_c = Pj, Q_t = Pj R_c, Q_m = Pj R_c R_t):
+//   d r / d t = Q,      d r / d w = [w* x Q_0 ; w* x Q_1] Jl(w)      (rows of -Q [w*]x are w* x Q_i)
+// where w* is the rotated point R p (Rodrigues branch) or the unrotated p (AngleAxisRotatePoint's first-order branch,
+// theta^2 <= DBL_EPSILON: AutoDiff differentiates p + w x p there), and Jl the left Jacobian of SO(3) (identity in that
+// branch) — exactly the point model's rule (above), applied once per transform of the chain.  Pose constants come in
+// CameraConstants' layout (CC_R, CC_K = Jl, CC_T, CC_SMALL; the intrinsics slots are not used).
+// Replaces the DJet<18> evaluation of k_marker_eval where the marker-chain model runs at scale: ~1.2k FMAs per residual
+// block instead of ~20k, cheap enough to be recomputed wherever a Jacobian row is needed instead of being stored.
+// ------------------------------------------------------------------------------------------------
+RSBA_HD void MarkerCornerResidualJacobian(const double* pc_cam, const double* pc_time, const double* pc_marker, const double* intr4,
+                                          double cx, double cy, double u, double v, double r[2], double J[36]) {
+  auto rot = [](const double* pc, const double in[3], double q[3], double out[3]) {
+    const double* R = pc + CC_R;
+    q[0] = R[0] * in[0] + R[1] * in[1] + R[2] * in[2];
+    q[1] = R[3] * in[0] + R[4] * in[1] + R[5] * in[2];
+    q[2] = R[6] * in[0] + R[7] * in[1] + R[8] * in[2];
+    out[0] = q[0] + pc[CC_T]; out[1] = q[1] + pc[CC_T + 1]; out[2] = q[2] + pc[CC_T + 2];
+  };
+  // the 2 x 6 block of one transform from Q (2 x 3), the point that entered it (pin) and its rotated image (q)
+  auto block = [](const double* pc, const double Q[6], const double pin[3], const double q[3], double* Jb /* row stride 18 */) {
+    const bool small = pc[CC_SMALL] != 0.0;
+    const double w0 = small ? pin[0] : q[0], w1 = small ? pin[1] : q[1], w2 = small ? pin[2] : q[2];
+    const double* K = pc + CC_K;
+    for (int i = 0; i < 2; ++i) {
+      const double q0 = Q[3 * i], q1 = Q[3 * i + 1], q2 = Q[3 * i + 2];
+      const double a0 = w1 * q2 - w2 * q1, a1 = w2 * q0 - w0 * q2, a2 = w0 * q1 - w1 * q0;   // w* x Q_i
+      Jb[18 * i + 0] = a0 * K[0] + a1 * K[3] + a2 * K[6];
+      Jb[18 * i + 1] = a0 * K[1] + a1 * K[4] + a2 * K[7];
+      Jb[18 * i + 2] = a0 * K[2] + a1 * K[5] + a2 * K[8];
+      Jb[18 * i + 3] = q0; Jb[18 * i + 4] = q1; Jb[18 * i + 5] = q2;
+    }
+  };
+  const double X[3] = {cx, cy, 0.0};
+  double qm[3] = {0, 0, 0}, pm[3] = {X[0], X[1], X[2]};
+  if (pc_marker) rot(pc_marker, X, qm, pm);
+  double qt[3], pt[3];
+  rot(pc_time, pm, qt, pt);
+  double qc[3] = {0, 0, 0}, pcm[3] = {pt[0], pt[1], pt[2]};
+  if (pc_cam) rot(pc_cam, pt, qc, pcm);
+  const double fx = intr4[0], fy = intr4[1], ppx = intr4[2], ppy = intr4[3];
+  const double iz = 1.0 / pcm[2];
+  r[0] = fx * pcm[0] * iz + ppx - u;
+  r[1] = fy * pcm[1] * iz + ppy - v;
+  const double al = fx * iz, be = fy * iz;
+  const double ga = -al * pcm[0] * iz, de = -be * pcm[1] * iz;
+  for (int i = 0; i < 36; ++i) J[i] = 0.0;
+  // camera transform
+  double Qt[6];   // sensitivity to p_t
+  if (pc_cam) {
+    const double Qc[6] = {al, 0.0, ga, 0.0, be, de};
+    block(pc_cam, Qc, pt, qc, J + 0);
+    const double* R = pc_cam + CC_R;
+    for (int j = 0; j < 3; ++j) { Qt[j] = al * R[j] + ga * R[6 + j]; Qt[3 + j] = be * R[3 + j] + de * R[6 + j]; }
+  } else {
+    Qt[0] = al; Qt[1] = 0.0; Qt[2] = ga; Qt[3] = 0.0; Qt[4] = be; Qt[5] = de;
+  }
+  // time transform
+  block(pc_time, Qt, pm, qt, J + 6);
+  // marker transform
+  if (pc_marker) {
+    const double* R = pc_time + CC_R;
+    double Qm[6];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 3; ++j) Qm[3 * i + j] = Qt[3 * i] * R[j] + Qt[3 * i + 1] * R[3 + j] + Qt[3 * i + 2] * R[6 + j];
+    block(pc_marker, Qm, X, qm, J + 12);
+  }
+}
+
 // ceres::HuberLoss / CauchyLoss + Corrector for rho'' <= 0 (both): returns rho(s) and the factor sqrt(rho'(s)) that
 // scales the residual and both Jacobian blocks.  delta > 0: Huber with a = delta; delta < 0: Cauchy with a = -delta
 // (the sign is this implementation's internal encoding of rsba_options::loss_type); 0: no loss.

@@ -18,4 +18,16 @@ int h_point_block_inverse(const double* V6, const double* s3, double lo, double 
   return rsba::PointBlockInverse(V6, s3, lo, hi, radius, out6) ? 1 : 0;
 }
 double h_loss(double delta, double s, double* sq) { return rsba::LossAndScale(delta, s, sq); }
+// marker-chain residual block: r (8), J (8 x 18), from the analytic per-corner routine; camera / marker may be NULL
+void h_marker_residual_jacobian(const double* cam6, const double* tim6, const double* mar6, double half_side, const double* intr4,
+                                const double* obs8, double* r8, double* j8x18) {
+  const double zero4[4] = {0, 0, 0, 0};
+  double cc[rsba::CC_STRIDE], ct[rsba::CC_STRIDE], cm[rsba::CC_STRIDE];
+  if (cam6) rsba::CameraConstants(cam6, zero4, cc);
+  rsba::CameraConstants(tim6, zero4, ct);
+  if (mar6) rsba::CameraConstants(mar6, zero4, cm);
+  const double cx[4] = {-half_side, half_side, half_side, -half_side}, cy[4] = {half_side, half_side, -half_side, -half_side};
+  for (int k = 0; k < 4; ++k)
+    rsba::MarkerCornerResidualJacobian(cam6 ? cc : nullptr, ct, mar6 ? cm : nullptr, intr4, cx[k], cy[k], obs8[2 * k], obs8[2 * k + 1], r8 + 2 * k, j8x18 + 36 * k);
+}
 }

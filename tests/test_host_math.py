@@ -87,3 +87,54 @@ def test_huber_matches_ceres_definition(hm):
     rho = hm.h_loss(1.0, 9.0, C.byref(sq))
     assert abs(rho - (2 * 3.0 - 1.0)) < 1e-15 and abs(sq.value - np.sqrt(1.0 / 3.0)) < 1e-15
     assert hm.h_loss(0.0, 9.0, C.byref(sq)) == 9.0 and sq.value == 1.0
+
+
+# ------------------------------------------------------------------ marker-chain functors, analytic (ba_math.hpp MarkerCornerResidualJacobian)
+def _marker_rj(hm, cam, tim, mar, side, intr, obs8):
+    r, j = np.zeros(8), np.zeros(8 * 18)
+    hm.h_marker_residual_jacobian.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+    cam = None if cam is None else np.ascontiguousarray(cam, float)
+    mar = None if mar is None else np.ascontiguousarray(mar, float)
+    tim, intr, obs8 = (np.ascontiguousarray(x, float) for x in (tim, intr, obs8))
+    hm.h_marker_residual_jacobian(vp(cam), vp(tim), vp(mar), C.c_double(side / 2), vp(intr), vp(obs8), vp(r), vp(j))
+    return r, j.reshape(8, 18)
+
+
+@pytest.mark.parametrize("with_cam,with_marker", [(True, True), (True, False), (False, True), (False, False)])
+def test_marker_chain_analytic_matches_autodiff(hm, oracle, with_cam, with_marker):
+    """The four functors of Main_Calibration/bundle_adjustment.h:56-343 (camera and / or marker transform absent): residuals
+    and the 8 x 18 Jacobian of the analytic routine against the oracle's dual numbers, random poses."""
+    rng = np.random.default_rng(5 + 2 * with_cam + with_marker)
+    worst = 0.0
+    for _ in range(300):
+        def pose(z):
+            ang = rng.uniform(1e-3, 3.0)
+            ax = rng.normal(size=3)
+            return np.concatenate([ax / np.linalg.norm(ax) * ang, rng.normal(0, 0.2, 2), [z]])
+        cam = pose(0.3) if with_cam else None
+        tim, mar = pose(1.5), (pose(0.1) if with_marker else None)
+        intr = np.array([rng.uniform(380, 640), rng.uniform(380, 640), rng.uniform(300, 330), rng.uniform(230, 245)])
+        obs8 = rng.uniform(0, 640, 8)
+        r0, j0 = oracle.marker_residual_jacobian(cam, tim, mar, 0.0148, intr, obs8)
+        if not np.all(np.isfinite(j0)) or np.abs(j0).max() > 1e7:
+            continue   # a corner (almost) in the camera plane
+        r1, j1 = _marker_rj(hm, cam, tim, mar, 0.0148, intr, obs8)
+        worst = max(worst, np.abs(r0 - r1).max() / max(1.0, np.abs(r0).max()), np.abs(j0 - j1).max() / max(1.0, np.abs(j0).max()))
+    assert worst < 1e-11, worst
+
+
+@pytest.mark.parametrize("theta", [0.0, 1e-12, 1e-9, 1.2e-8, 2e-8, 1e-7, 1e-4])
+def test_marker_chain_analytic_small_rotations(hm, oracle, theta):
+    """Each of the three rotations across AngleAxisRotatePoint's theta^2 = DBL_EPSILON switch (the test2 fixture has all
+    marker rvecs exactly zero): the analytic blocks follow the branch AutoDiff differentiates."""
+    ax = np.array([0.3, -0.5, 0.8]) / np.linalg.norm([0.3, -0.5, 0.8])
+    base = [np.array([0.4, -0.2, 0.3, 0.05, -0.02, 0.4]), np.array([-0.3, 0.5, 0.2, 0.1, 0.05, 1.2]), np.array([0.2, 0.1, -0.4, 0.02, 0.03, 0.1])]
+    intr, obs8 = np.array([630.0, 625.0, 316.0, 240.0]), np.linspace(200, 400, 8)
+    for which in range(3):
+        poses = [b.copy() for b in base]
+        poses[which][:3] = ax * theta
+        r0, j0 = oracle.marker_residual_jacobian(poses[0], poses[1], poses[2], 0.048, intr, obs8)
+        r1, j1 = _marker_rj(hm, poses[0], poses[1], poses[2], 0.048, intr, obs8)
+        assert np.abs(r0 - r1).max() < 1e-9
+        assert np.abs(j0 - j1).max() < 1e-8 * np.abs(j0).max(), which
