@@ -24,6 +24,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ba_marker_kernels.hpp"
@@ -284,7 +285,8 @@ static int PairSegmentsPerTile(int C, int P, bool staged) {
 // independent given the cameras), so the points are dealt to the chunks such that every camera PAIR gets about the same
 // number of shared points in every chunk: greedily, each point (in a fixed pseudo-random order) goes to the best of a
 // few candidate chunks, "best" = fewest points so far that share a pair with it, relative to the chunk's fill.
-// Measured on the 64 x 100k x 20 problem: lane utilisation of the pair tiles 74 % -> 86 % for ~0.5 s of set-up.
+// Measured on the 64 x 100k x 20 problem: lane utilisation of the pair tiles 74 % -> 86 % for ~0.5 s of single-threaded
+// set-up; the dealing runs as 8 independent streams on up to 8 host threads.
 // The permutation is internal: parameters are uploaded / downloaded through it, nothing the caller sees changes order.
 // Deterministic (fixed seed): two solvers of the same problem add in the same order.
 // Returns perm (position -> original point); empty = keep the file order.
@@ -312,34 +314,74 @@ static std::vector<int> BalancedPointOrder(int C, int P, bool staged, const std:
   D = std::min(D, nu);
   std::vector<uint16_t> cnt((size_t)nu * C * C, 0);   // [unit][a][b], a < b
   std::vector<int> fill(nu, 0), unit_of(P, 0);
-  // fixed pseudo-random visiting order and candidate choice (splitmix64)
-  uint64_t st = 0x9E3779B97F4A7C15ull;
-  auto rnd = [&]() { uint64_t z = (st += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+  // fixed pseudo-random visiting order (splitmix64)
+  auto mix = [](uint64_t& st) { uint64_t z = (st += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
   std::vector<int> visit(P);
-  for (int j = 0; j < P; ++j) visit[j] = j;
-  for (int j = P - 1; j > 0; --j) std::swap(visit[j], visit[(size_t)(rnd() % (uint64_t)(j + 1))]);
-  int open_from = 0;   // all units below are full
-  for (int j : visit) {
-    const int b = ptr[j], k = ptr[j + 1] - b;
-    const int* cj = cam.data() + b;
-    int best = -1; double best_s = 0.0;
-    for (int d = 0, tries = 0; d < D || best < 0; ++tries) {
-      int g;
-      if (tries < 4 * D) { g = (int)(rnd() % (uint64_t)nu); if (fill[g] >= ucap[g]) continue; }
-      else { while (open_from < nu && fill[open_from] >= ucap[open_from]) ++open_from; g = open_from; for (; g < nu && fill[g] >= ucap[g]; ++g) {} if (g >= nu) break; }
-      ++d;
-      const uint16_t* c = &cnt[(size_t)g * C * C];
-      long sum = 0;
-      for (int x = 0; x < k; ++x) { const uint16_t* row = c + (size_t)cj[x] * C; for (int y = x + 1; y < k; ++y) sum += row[cj[y]]; }
-      const double sc = (double)sum / (double)(fill[g] + 1);
-      if (best < 0 || sc < best_s) { best = g; best_s = sc; }
-      if (tries >= 4 * D) break;
-    }
-    if (best < 0) return {};   // cannot happen: the capacities add up to P
-    uint16_t* c = &cnt[(size_t)best * C * C];
-    for (int x = 0; x < k; ++x) { uint16_t* row = c + (size_t)cj[x] * C; for (int y = x + 1; y < k; ++y) if (row[cj[y]] != 0xFFFF) ++row[cj[y]]; }
-    unit_of[j] = best; ++fill[best];
+  {
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    for (int j = 0; j < P; ++j) visit[j] = j;
+    for (int j = P - 1; j > 0; --j) std::swap(visit[j], visit[(size_t)(mix(st) % (uint64_t)(j + 1))]);
   }
+  // Independent streams: the units are cut into kStreams contiguous ranges, the visiting order into runs of matching
+  // capacity, and every stream deals its run to its own units.  The number of streams is a constant (not the number of
+  // threads that happen to run them): the order, and with it every sum of the solve, is the same on every machine.
+  constexpr int kStreams = 8;
+  const int nstream = nu >= 4 * kStreams ? kStreams : 1;
+  std::vector<int> su(nstream + 1, 0), sp(nstream + 1, 0);
+  for (int t = 0; t < nstream; ++t) {
+    su[t + 1] = (int)((int64_t)nu * (t + 1) / nstream);
+    int capsum = 0;
+    for (int g = su[t]; g < su[t + 1]; ++g) capsum += ucap[g];
+    sp[t + 1] = sp[t] + capsum;
+  }
+  if (sp[nstream] != P) return {};   // cannot happen: the capacities add up to P
+  std::atomic<int> failed{0};
+  auto run_stream = [&](int t) {
+    const int g0 = su[t], ng = su[t + 1] - su[t];
+    const int Dt = std::min(D, ng);
+    uint64_t st = 0xD1B54A32D192ED03ull * (uint64_t)(t + 1);
+    int open_from = g0;   // all units of the stream below are full
+    for (int q = sp[t]; q < sp[t + 1]; ++q) {
+      const int j = visit[q];
+      const int b = ptr[j], k = ptr[j + 1] - b;
+      const int* cj = cam.data() + b;
+      int best = -1; double best_s = 0.0;
+      auto score = [&](int g) {
+        const uint16_t* c = &cnt[(size_t)g * C * C];
+        long sum = 0;
+        for (int x = 0; x < k; ++x) { const uint16_t* row = c + (size_t)cj[x] * C; for (int y = x + 1; y < k; ++y) sum += row[cj[y]]; }
+        const double sc = (double)sum / (double)(fill[g] + 1);
+        if (best < 0 || sc < best_s) { best = g; best_s = sc; }
+      };
+      if (ng <= D) {
+        // few enough units in the stream: all of them that still have room (first minimum wins)
+        for (int g = g0; g < g0 + ng; ++g) if (fill[g] < ucap[g]) score(g);
+      } else {
+        for (int d = 0, tries = 0; d < Dt || best < 0; ++tries) {
+          int g;
+          if (tries < 4 * Dt) { g = g0 + (int)(mix(st) % (uint64_t)ng); if (fill[g] >= ucap[g]) continue; }
+          else { while (open_from < g0 + ng && fill[open_from] >= ucap[open_from]) ++open_from; g = open_from; if (g >= g0 + ng) break; }
+          ++d;
+          score(g);
+          if (tries >= 4 * Dt) break;
+        }
+      }
+      if (best < 0) { failed = 1; return; }
+      uint16_t* c = &cnt[(size_t)best * C * C];
+      for (int x = 0; x < k; ++x) { uint16_t* row = c + (size_t)cj[x] * C; for (int y = x + 1; y < k; ++y) if (row[cj[y]] != 0xFFFF) ++row[cj[y]]; }
+      unit_of[j] = best; ++fill[best];
+    }
+  };
+  {
+    const int nthreads = std::max(1, std::min<int>(nstream, (int)std::thread::hardware_concurrency()));
+    std::atomic<int> next_stream{0};
+    auto worker = [&]() { for (int t = next_stream++; t < nstream; t = next_stream++) run_stream(t); };
+    std::vector<std::thread> pool;
+    for (int i = 1; i < nthreads; ++i) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+  }
+  if (failed) return {};
   // positions: the points of a unit in ascending original order
   std::vector<int> next(ubeg), perm(P, -1);
   for (int j = 0; j < P; ++j) perm[next[unit_of[j]]++] = j;
