@@ -13,13 +13,14 @@
 //     the diagonal, store their X, and hand block b over (flag rows_ready[b]) after panel b - 2; nothing waits for them but
 //     the last slabs of workgroup 0's update one panel later.
 //
-// STATUS (round 2): opt-in, RSBA_CHOL_DIAG=1.  Measured at 64 cameras beside the Schur kernel: the hop is gone from the
-// chain (factor -> X -> X X' -> next factor: 2.8 us between two factorisations), but workgroup 0's seven remaining waves
-// need 10 - 19 us per panel for the strip, the wait for rows_ready and the fused update (every dependent global load costs
-// ~2 us there and the kernel has no registers left for deeper prefetch), which is longer than the 8.5 - 10 us factorisation
-// they are meant to hide behind: 0.493 ms per LM iteration against 0.475 ms with the round-robin kernel.  What would make it
-// pay: T published right after the factorisation by a dedicated wave (the row workgroups get it 3 us earlier), the wait for
-// rows_ready only in front of the last slab, and the update in an out-of-line routine with its own register allocation.
+// STATUS (round 2): the default for 32 to 64 cameras (RSBA_CHOL_DIAG=0 selects the round-robin kernel).  Measured at 64
+// cameras beside the Schur kernel: 0.466 ms per LM iteration against 0.477 ms round-robin, 206 against 221 us alone
+// (sequential schedule).  What it took after the first version (0.493 ms): T and L11 stored by ONE wave right after the
+// factorisation and published before the X barrier (the row workgroups start 3 us earlier; publishing at the end of the
+// panel instead gives the gain back: 0.475 ms), the right-hand-side row brought up to date with plain dot products from a
+// prefetched row instead of a ninth MFMA tile, and the fused update's operand loads issued before its LDS stores.  A panel
+// of the chain is now factor (8.5 - 10 us) + 3.2 us for X, X X' and four barriers; the seven other waves' strip, wait for
+// rows_ready and fused update fit behind the factorisation for all but the first two panels.
 //
 // Same arithmetic per entry as the multi kernel's (products over fixed K slices, added in a fixed order): bitwise
 // reproducible, identical on every rank.  All waits carry a budget: a stall gives up (RES_STALL), never hangs.
@@ -211,6 +212,37 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         }
       }
     };
+    // The right-hand-side row's columns of the panel (one wave): rhs[kb + c] - sum_q L[n][q] L[kb + c][q], c < 32 — one row,
+    // so no matrix cores: the row's kb entries come into LDS in one round trip (the unused rows of its panel block), lane
+    // (c, half) adds every second term, the two halves meet in a shuffle.  Fixed order.  As an MFMA half streamed over the
+    // whole K range by one wave it was the longest item of the diagonal workgroup's panel (13 us at kb = 288).
+    double rhs_av[6] = {0, 0, 0, 0, 0, 0}, rhs_c = 0.0;   // one wave's share of the row and of the right-hand side, fetched early
+    auto rhs_row_prefetch = [&]() {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) { const int q = lane + 64 * u; rhs_av[u] = q < kb ? A[(size_t)n * n + q] : 0.0; }
+      rhs_c = sys(n, kb + (lane & 31), 0.0);
+    };
+    auto rhs_row_update = [&](int j) {
+      double* arow_l = Pan + (size_t)(j * RSBA_PB + 1) * RSBA_PLD;   // rows 1.. of the block: 31 x 33 >= kb doubles
+      const int c = lane & 31, half = lane >> 5;
+#pragma unroll
+      for (int u = 0; u < 6; ++u) { const int q = lane + 64 * u; if (q < kb) arow_l[q] = rhs_av[u]; }
+      __builtin_amdgcn_wave_barrier();
+      // lane (c, half) adds the terms q = half, half + 2, ...: eight running sums (q mod 16), so that the LDS reads of
+      // one round do not wait for the additions of the last (kb is a multiple of 32)
+      double sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int q0 = half; q0 < kb; q0 += 16) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sacc[u] += arow_l[q0 + 2 * u] * Bst[(q0 + 2 * u) * RSBA_PLD + c];
+      }
+      double sum = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
+      sum += __shfl_xor(sum, 32, 64);
+      __builtin_amdgcn_wave_barrier();
+      if (half == 0) Pan[(size_t)(j * RSBA_PB) * RSBA_PLD + c] = rhs_c - sum;
+      // rows 1 .. 15 of the half feed the X product row by row and are never stored: whatever they hold is harmless, but
+      // keep them finite
+      for (int e = lane; e < 15 * RSBA_PB; e += 64) Pan[(size_t)(j * RSBA_PB + 1 + e / RSBA_PB) * RSBA_PLD + (e % RSBA_PB)] = 0.0;
+    };
     // X = Rows T' for one 16-row half in slot j, stored as L (and kept in Xl for the next diagonal block)
     auto solve_half = [&](int b, int j, int half, bool keep) {
       const int prow = j * RSBA_PB + half * 16;
@@ -269,6 +301,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         if (!DiagFactorInverseCall((lds_double*)Pre, RSBA_PB, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane) && lane == 0) s_ok = 0;
       } else {
         // ---- waves 1 .. 7: strip of block p, then block p + 1 (fused update + look-ahead product) and the rhs row
+        if (p > 0 && wave == (has_next ? 7 : 1)) rhs_row_prefetch();
         if (p > 0) {
           for (int e = tid - 64; e < (kb >> 2) * RSBA_PB; e += nt - 64) {
             const int c = e / (kb >> 2), q0 = (e - c * (kb >> 2)) * 4;
@@ -290,6 +323,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
           }
           bar7();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          if (mtrace && tid == 64) mtrace[((size_t)w * 16 + p) * 8 + 1] = wall_clock64();   // strip in LDS, rows_ready seen
         }
         if (has_next && p > 0) {
           // waves 1..4: row waves (half h, K slice ks of 2): update + diagonal tile (h, h); waves 5, 6: cross tile (1, 0), K
@@ -357,6 +391,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
               }
               fp_diag[(h * 2 + ks) * 256 + (kk + 4 * t) * 16 + mi] = dg[t];
             }
+            if (mtrace && tid == 128) mtrace[((size_t)w * 16 + p) * 8 + 2] = wall_clock64();   // row wave (h 0, slice 1) done
           } else if (rw < 6) {
             const int cs = rw - 4;
             const int nq = kb / RSBA_PB, qper = (nq + 1) / 2;
@@ -387,12 +422,13 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
 #pragma unroll
             for (int t = 0; t < 4; ++t) fp_cross[cs * 256 + (kk + 4 * t) * 16 + mi] = cr[t];
           } else {
-            load_update_half(np, jr, 0, 0, 1, nullptr);
+            rhs_row_update(jr);
+            if (mtrace && lane == 0) mtrace[((size_t)w * 16 + p) * 8 + 3] = wall_clock64();   // rhs row done
           }
         } else {
           // panel 0 (nothing to subtract yet) or the last panel (no next block): plain loads of the panel's columns
           if (has_next) { for (int hb = wave - 1; hb < 2; hb += nwave - 1) load_update_half(p + 1, 0, hb, 0, 1, nullptr); }
-          if (wave == (has_next ? 7 : 1)) load_update_half(np, jr, 0, 0, 1, nullptr);
+          if (wave == (has_next ? 7 : 1)) { if (p > 0) rhs_row_update(jr); else load_update_half(np, jr, 0, 0, 1, nullptr); }
         }
       }
       __syncthreads();   // [A] the factor (T, Lt, invd, Pre = L11) and the updates are done
@@ -406,12 +442,14 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
           Pan[(h * 16 + r) * RSBA_PLD + c] -= fp_upd[h * 512 + r * 32 + c];
         }
       }
-      if (wave != 0) {
-        for (int e = tid - 64; e < RSBA_PB * RSBA_PB; e += nt - 64) {
+      if (wave == 7) {
+        // L11 / T leave through ONE wave: it alone waits for their acknowledgements (below, after the next barrier) and
+        // publishes them — the row workgroups get T(p) while this workgroup is still busy with X
+        for (int e = lane; e < RSBA_PB * RSBA_PB; e += 64) {
           const int r = e >> 5, c = e & 31;
           StoreShared(&A[(size_t)(kb + r) * n + kb + c], c > r ? T[c * RSBA_PLD + r] : Pre[r * RSBA_PLD + c]);
         }
-        if (tid >= 64 && tid < 64 + RSBA_PB) StoreShared(&A[(size_t)(n + 1) * n + kb + tid - 64], invd[tid - 64]);
+        if (lane < RSBA_PB) StoreShared(&A[(size_t)(n + 1) * n + kb + lane], invd[lane]);
       }
       // look-ahead part of the next diagonal block (everything but this panel's X X'), kept in registers until Xl is free
       if (has_next) {
@@ -435,6 +473,12 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       // X = Rows T': block p + 1 (two halves, kept in Xl) and the rhs row
       if (has_next) { if (wave == 1 || wave == 2) solve_half(p + 1, 0, wave - 1, true); }
       if (wave == 3) solve_half(np, jr, 0, false);
+      if (wave == 7) {
+        // (publishing T only at the end of the panel takes this wait off the chain but delays the row workgroups, whose
+        //  last slab the next panel's update waits for: measured 0.475 against 0.466 ms per LM iteration)
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) __hip_atomic_store(f.tdone + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __syncthreads();   // [C] Xl
       RSBA_DC_STAMP(5);
       if (has_next) {
@@ -464,14 +508,11 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         __syncthreads();   // [E] the next diagonal block is ready: wave 0 goes on
       }
       RSBA_DC_STAMP(6);
-      // L11 / T / X are on their way: waves 1..7 wait for the acknowledgements and publish; wave 0 does not wait
+      // X is on its way: waves 1..7 wait for the acknowledgements and publish the strip; wave 0 does not wait
       if (wave != 0) {
         __builtin_amdgcn_s_waitcnt(0);
         bar7();
-        if (wave == 1 && lane == 0) {
-          __hip_atomic_store(f.tdone + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (has_next) __hip_atomic_store(f.strip_ready + p + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (wave == 1 && lane == 0 && has_next) __hip_atomic_store(f.strip_ready + p + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       { double* t = Pre; Pre = PreN; PreN = t; }
       RSBA_DC_STAMP(7);

@@ -175,7 +175,7 @@ struct rsba_solver {
                              // (both exercise the fallback to the sequential schedule)
   int step_tag = 0;
   int chol_wgs = 1;          // > 1: the reduced system is factored by this many workgroups (ba_cholesky_multi.hpp)
-  bool chol_diag = false;    // RSBA_CHOL_DIAG=1: ... with the diagonal chain in workgroup 0 (ba_cholesky_diag.hpp, opt-in: measured slower)
+  bool chol_diag = false;    // ... with the diagonal chain in workgroup 0 (ba_cholesky_diag.hpp; RSBA_CHOL_DIAG=0: blocks dealt round-robin, ba_cholesky_multi.hpp)
   int* mc_flags = nullptr;   // tdone[16] | strip_ready[16] | wg_done[8] | error
   int* tc_flags = nullptr;   // persistent tiled factorisation (more than 64 cameras): tdone[np] | xdone[np][nrt] | error
   int tc_np = 0, tc_nrt = 0, tc_tiles = 0;   // 0 tiles: the multi-launch path
@@ -792,7 +792,7 @@ static int UploadPoints(rsba_solver* s) {
       s->chol_wgs = std::min(want, RSBA_MC_MAXG);
       if ((rc = DevAlloc(&s->mc_flags, 64))) return rc;
       HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
-      s->chol_diag = getenv("RSBA_CHOL_DIAG") && atoi(getenv("RSBA_CHOL_DIAG")) == 1 && s->chol_wgs >= 2;   // opt-in (see ba_cholesky_diag.hpp)
+      s->chol_diag = !(getenv("RSBA_CHOL_DIAG") && atoi(getenv("RSBA_CHOL_DIAG")) == 0) && s->chol_wgs >= 2;   // RSBA_CHOL_DIAG=0: round-robin kernel
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(DiagCholLdsDoubles(s->nc) * sizeof(double))));
       if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, RSBA_MC_MAXG * 16 * 8))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, RSBA_MC_MAXG * 16 * 8 * sizeof(long long))); }

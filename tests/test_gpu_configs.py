@@ -219,13 +219,14 @@ def test_balanced_point_order_is_internal(oracle, C, P, k, huber, monkeypatch):
     assert np.abs(a["S"] - b["S"]).max() < 1e-11 * np.abs(b["S"]).max()
 
 
-# ------------------------------------------------------------------ opt-in factorisation with the diagonal chain in one workgroup
+# ------------------------------------------------------------------ both several-workgroup factorisations of the reduced system
+@pytest.mark.parametrize("diag", [1, 0])
 @pytest.mark.parametrize("C,P,k,huber", [(33, 2500, 8, 0.0), (48, 3000, 9, 1.0), (64, 4000, 12, 0.0)])
-def test_diagonal_workgroup_cholesky_opt_in(oracle, C, P, k, huber, monkeypatch):
-    """RSBA_CHOL_DIAG=1 (ba_cholesky_diag.hpp: workgroup 0 keeps the chain of diagonal factorisations, the others own the
-    rows below): same trajectory and blocks as the oracle, pipelined and sequential schedule bit for bit, two runs bit for
-    bit."""
-    monkeypatch.setenv("RSBA_CHOL_DIAG", "1")
+def test_diagonal_and_round_robin_cholesky(oracle, C, P, k, huber, diag, monkeypatch):
+    """ba_cholesky_diag.hpp (the default for 32 to 64 cameras: workgroup 0 keeps the chain of diagonal factorisations, the
+    others own the rows below) and ba_cholesky_multi.hpp (RSBA_CHOL_DIAG=0: blocks dealt round-robin): same trajectory and
+    blocks as the oracle, pipelined and sequential schedule bit for bit, two runs bit for bit."""
+    monkeypatch.setenv("RSBA_CHOL_DIAG", str(diag))
     prob = syn.make_problem(C, P, k, seed=60 + C, outlier_frac=0.05 if huber else 0.0)
     ref, s_ref, log_ref = oracle.solve_points(prob, oracle.options(huber_delta=huber, num_threads=_threads()))
     got, s_got, log_got = capi.solve_points(prob, capi.default_options(huber_delta=huber))
