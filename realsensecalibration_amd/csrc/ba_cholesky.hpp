@@ -106,11 +106,30 @@ __device__ __forceinline__ bool WaitReady(const int* flag, int tag, long long* w
   return s_wait_ok != 0;
 }
 
-// Factor the padded 32 x 32 diagonal block held in LDS (rows of `Pd`, stride RSBA_PLD) and invert it.  One wavefront.
-// Out: Pd rows < nb = L11 (upper part zeroed), Lt = padded L11, T = L11^-1, invd = 1/diag.  Returns false on a
-// non-positive pivot.  (Rows/columns >= nb are padded with identity so all 32 steps run unconditionally; lanes 32..63
-// shadow lanes 0..31, so the whole sequence is one branch-free basic block.  The empty asm statements pin every updated
-// value at its step: without them LLVM sinks the updates towards their uses and spills ~1300 registers.)
+// Factor the padded 32 x 32 diagonal block held in LDS (rows of `Pan`, stride RSBA_PLD) and invert it.  One wavefront.
+// Out: Pan rows < nb = L11 (upper part zeroed; kWritePan), Lt = padded L11, T = L11^-1 (kInverse), invd = 1/diag.  Returns
+// false on a non-positive pivot (no select sits on the pivot chain: the pivot's 1/sqrt and everything after it are NaN then,
+// one ballot at the end finds out; the caller marks the step invalid).  Rows/columns >= nb are padded with identity so all
+// 32 steps run unconditionally: one branch-free basic block.
+//
+// Lane = row (lanes 32..63 shadow lanes 0..31).  A wavefront issues IN ORDER, so what a step costs is decided by the
+// program order (tools/factor_bench.hip, tools/lat_bench.hip: a dependent v_fma_f64 has 8 cycles of latency, v_rsq_f64 20,
+// a v_readlane pair into an SGPR operand 20, LDS write -> read 76):
+//   * the pivot chain of step j + 1 — v_readlane of the pivot, v_rsq_f64, two Newton steps of three dependent operations,
+//     the scaling of the column, ~125 cycles — alternates, stage by stage, with the updates step j still owes (the empty asm
+//     statements pin that order; without them LLVM also sinks the updates towards their uses and spills);
+//   * column j + 1 (the next pivot) and j + 2 take their multiplier l_cj straight out of lane c's register (v_readlane ->
+//     SGPR operand); for the columns >= j + 3 the scaled column goes through a 32-double LDS buffer (two, by step parity)
+//     and comes back as broadcast reads, two columns per ds_read2_b64 instead of four v_readlane and their hazard nops:
+//     read at the START of the next step, a whole step after the write, applied a few stages later.  No pivot ever
+//     waits for LDS, and one step's multipliers are all the registers this takes (the callers sit at the 256-VGPR cap
+//     and keep their state in the registers this routine leaves alone);
+//   * two 16-column halves: the steps j < 16 only update the columns up to 15 (for all 32 rows: L11 of the top-left block
+//     and L21 below it), the bottom-right block then takes its rank-16 update L21 L21' from the matrix cores in one go,
+//     and the steps j >= 16 work on it alone.
+// 3.6 us alone on a SIMD against 6.0 us for the version that scaled, broadcast and updated step by step (+ 2.1 us for the
+// inverse either way).  Every sum has a fixed order: bitwise reproducible.
+template <bool kInverse = true, bool kWritePan = true>
 __device__ __forceinline__ bool DiagFactorInverse(double* __restrict__ Pan, int nb, double* __restrict__ T, double* __restrict__ Lt,
                                                   double* __restrict__ invd, int lane) {
 #ifdef RSBA_PROFILE_PHASES
@@ -118,46 +137,85 @@ __device__ __forceinline__ bool DiagFactorInverse(double* __restrict__ Pan, int 
 #endif
       double row[RSBA_PB];
       const int lr = lane & 31;
+      if (lr < nb) {
 #pragma unroll
-      for (int c = 0; c < RSBA_PB; ++c) row[c] = (lr < nb) ? Pan[lr * RSBA_PLD + c] : (c == lr ? 1.0 : 0.0);
-      bool good = true;
-      double ilv = 1.0;  // 1 / L[lr][lr]
-      // Two 16-column halves: the steps j < 16 only update the columns up to 15 (for all 32 rows: that gives L11 of the
-      // top-left block and L21 below it), the bottom-right block then takes its rank-16 update L21 L21' from the matrix
-      // cores in one go, and the steps j >= 16 work on it alone.  The v_readlane broadcasts are what a step costs (~430 of
-      // ~610 cycles): 240 pairs instead of 496.  (Two loops, not one with a conditional bound: with the bound and the
-      // rank-16 block inside one loop body LLVM stopped unrolling fully and put row[] into scratch memory.)
-#define RSBA_FACTOR_STEP(CEND)                                                                                          \
-      {                                                                                                                 \
-        const double d = ReadLaneD(row[j], j);                                                                          \
-        if (!(d > 0.0) || !(d <= DBL_MAX)) good = false;                                                                \
-        const double dd = good ? d : 1.0;                                                                               \
-        /* il = 1/sqrt(d): hardware estimate + two Newton steps (full fp64); l = d * il */                              \
-        double il = __builtin_amdgcn_rsq(dd);                                                                           \
-        il = il * (1.5 - 0.5 * dd * il * il);                                                                           \
-        il = il * (1.5 - 0.5 * dd * il * il);                                                                           \
-        const double lij = (lr == j) ? dd * il : row[j] * il;                                                           \
-        row[j] = lij;                                                                                                   \
-        if (lr == j) ilv = il;                                                                                          \
-        invd[j] = il; /* wave-uniform value */                                                                          \
-        /* a_ic -= l_ij l_cj with l_cj read straight out of lane c's register (v_readlane -> SGPR operand): no LDS  */  \
-        /* round trip on the critical path.  Entries above the diagonal (c > row) pick up garbage; never read.       */  \
-        /* groups of four: the eight v_readlane of a group issue back to back, so the SGPR-write -> VALU-read       */  \
-        /* hazard of one value is covered by the next ones instead of s_nops                                         */  \
-        _Pragma("unroll") for (int c0 = j + 1; c0 < (CEND); c0 += 4) {                                                  \
-          double lc[4];                                                                                                 \
-          _Pragma("unroll") for (int u = 0; u < 4; ++u) lc[u] = (c0 + u < (CEND)) ? ReadLaneD(lij, c0 + u) : 0.0;       \
-          _Pragma("unroll") for (int u = 0; u < 4; ++u) if (c0 + u < (CEND)) row[c0 + u] -= lij * lc[u];                \
-          _Pragma("unroll") for (int u = 0; u < 4; ++u) if (c0 + u < (CEND)) asm volatile("" : "+v"(row[c0 + u]));      \
-        }                                                                                                               \
+        for (int c = 0; c < RSBA_PB; ++c) row[c] = Pan[lr * RSBA_PLD + c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < RSBA_PB; ++c) row[c] = (c == lr) ? 1.0 : 0.0;
       }
 #pragma unroll
-      for (int j = 0; j < 16; ++j) RSBA_FACTOR_STEP(16)
-      {
-        // A22 -= L21 L21': L21 (rows 16..31, columns 0..15) through the Lt tile into MFMA operand layout, the product
-        // back through the (still unused) T tile into the rows' registers
+      for (int c = 0; c < RSBA_PB; ++c) asm volatile("" : "+v"(row[c]));   // all 32 in registers now (else the padding constants of the late columns stay live beside the loaded values)
+      double* colbuf = T + 20 * RSBA_PLD;   // rows 20, 21 of the T tile (two buffers, by step parity): free until the inverse, clear of the rank-16 product (rows < 16)
+      double nv[16];                        // multipliers of step j - 1, read at the start of step j
+      double ilv = 0.0, lij, il;            // lane j keeps 1 / L[j][j]
+#define RSBA_PIN(x) asm volatile("" : "+v"(x))
+      // pivot J from scratch (first step of a half): il = 1/sqrt(d) from the hardware estimate + two Newton steps (full fp64)
+#define RSBA_FACTOR_CHAIN0(J)                                                                                           \
+      {                                                                                                                 \
+        const double d = ReadLaneD(row[J], J);                                                                          \
+        double y = __builtin_amdgcn_rsq(d);                                                                             \
+        double e = __builtin_fma(-(d * y), 0.5 * y, 0.5);                                                               \
+        y = __builtin_fma(y, e, y);                                                                                     \
+        e = __builtin_fma(-(d * y), 0.5 * y, 0.5);                                                                      \
+        il = __builtin_fma(y, e, y);                                                                                    \
+        lij = row[J] * il;                                                                                              \
+      }
+      // what step j does between two stages of the next pivot's chain: item 0 = column j + 2 by v_readlane, items 1.. =
+      // the delayed updates of step j - 1 (columns j + 2 .. CEND - 1), nearest column first
+#define RSBA_FACTOR_ITEMS(S)                                                                                            \
+      _Pragma("unroll") for (int i = (S); i < nitems; i += 6) {                                                         \
+        if (i == 0) {                                                                                                   \
+          if (j + 2 < (CEND_)) { const double lc = ReadLaneD(lij, j + 2); row[j + 2] -= lij * lc; RSBA_PIN(row[j + 2]); } \
+        } else if (j > (BASE_)) {                                                                                       \
+          const int c = j + 1 + i;                                                                                      \
+          if (c < (CEND_)) { row[c] -= row[j - 1] * nv[c - (BASE_)]; RSBA_PIN(row[c]); }                                \
+        }                                                                                                               \
+      }
+#define RSBA_FACTOR_STEP                                                                                                \
+      {                                                                                                                 \
+        row[j] = lij;   /* l_ij; lane j: sqrt(d) */                                                                     \
+        if (lr == j) ilv = il;                                                                                          \
+        RSBA_PIN(ilv);   /* select now: else every step's il stays live to the end */                                   \
+        const int nitems = (CEND_) - j - 1;                                                                             \
+        double lij_n = 0.0, il_n = 0.0;                                                                                 \
+        /* the multipliers step j - 1 left in its buffer a whole step ago, for the columns >= j + 2 */                  \
+        if (j > (BASE_)) { _Pragma("unroll") for (int c = j + 2; c < (CEND_); ++c) nv[c - (BASE_)] = colbuf[((j - 1) & 1) * RSBA_PLD + c]; } \
+        if (j + 3 < (CEND_)) { if (lane < 32) colbuf[(j & 1) * RSBA_PLD + lane] = lij; }                                \
+        if (j + 1 < (CEND_)) {                                                                                          \
+          { const double lc = ReadLaneD(lij, j + 1); row[j + 1] -= lij * lc; RSBA_PIN(row[j + 1]); }                    \
+          const double d = ReadLaneD(row[j + 1], j + 1);                                                                \
+          double y0 = __builtin_amdgcn_rsq(d); RSBA_PIN(y0);                                                            \
+          double t = d * y0, h = 0.5 * y0; RSBA_PIN(t); RSBA_PIN(h);                                                    \
+          RSBA_FACTOR_ITEMS(0)                                                                                          \
+          double e = __builtin_fma(-t, h, 0.5); RSBA_PIN(e);                                                            \
+          RSBA_FACTOR_ITEMS(1)                                                                                          \
+          double y1 = __builtin_fma(y0, e, y0); RSBA_PIN(y1);                                                           \
+          RSBA_FACTOR_ITEMS(2)                                                                                          \
+          t = d * y1; h = 0.5 * y1; RSBA_PIN(t); RSBA_PIN(h);                                                           \
+          RSBA_FACTOR_ITEMS(3)                                                                                          \
+          e = __builtin_fma(-t, h, 0.5); RSBA_PIN(e);                                                                   \
+          RSBA_FACTOR_ITEMS(4)                                                                                          \
+          il_n = __builtin_fma(y1, e, y1); RSBA_PIN(il_n);                                                              \
+          RSBA_FACTOR_ITEMS(5)                                                                                          \
+          lij_n = row[j + 1] * il_n; RSBA_PIN(lij_n);                                                                   \
+        }                                                                                                               \
+        lij = lij_n; il = il_n;                                                                                         \
+      }
+      RSBA_FACTOR_CHAIN0(0)
+#define CEND_ 16
+#define BASE_ 0
 #pragma unroll
-        for (int c = 0; c < 16; ++c) Lt[lr * RSBA_PLD + c] = row[c];
+      for (int j = 0; j < 16; ++j) RSBA_FACTOR_STEP
+#undef CEND_
+#undef BASE_
+      {
+        // columns 0..15 are final: into the Lt tile (upper part zero); A22 -= L21 L21' with L21 (rows 16..31) taken from
+        // there in MFMA operand layout, the product back through the (still unused) T tile into the rows' registers
+        if (lane < 32) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) Lt[lr * RSBA_PLD + c] = (c <= lr) ? row[c] : 0.0;
+        }
         __builtin_amdgcn_wave_barrier();
         const int mi = lane & 15, mk = lane >> 4;
         d4_t acc = {0, 0, 0, 0};
@@ -172,26 +230,39 @@ __device__ __forceinline__ bool DiagFactorInverse(double* __restrict__ Pan, int 
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
           const double upd = T[(lr & 15) * RSBA_PLD + c];
-          if (lr >= 16) row[16 + c] -= upd;
+          row[16 + c] -= (lr >= 16) ? upd : 0.0;
         }
 #pragma unroll
-        for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(row[16 + c]));
+        for (int c = 0; c < 16; ++c) RSBA_PIN(row[16 + c]);
       }
+      RSBA_FACTOR_CHAIN0(16)
+#define CEND_ 32
+#define BASE_ 16
 #pragma unroll
-      for (int j = 16; j < RSBA_PB; ++j) RSBA_FACTOR_STEP(RSBA_PB)
+      for (int j = 16; j < RSBA_PB; ++j) RSBA_FACTOR_STEP
+#undef CEND_
+#undef BASE_
 #undef RSBA_FACTOR_STEP
-      // padded factor -> Lt (32 x 33); the real rows also back into the panel
+#undef RSBA_FACTOR_ITEMS
+#undef RSBA_FACTOR_CHAIN0
+#undef RSBA_PIN
+      // columns 16..31 of the padded factor -> Lt (32 x 33); the real rows also back into the panel
+      if (lane < 32) {
+        invd[lane] = ilv;
 #pragma unroll
-      for (int c = 0; c < RSBA_PB; ++c) {
-        const double v = (c <= lr) ? row[c] : 0.0;
-        Lt[lr * RSBA_PLD + c] = v;
-        if (lr < nb) Pan[lr * RSBA_PLD + c] = v;
+        for (int c = 16; c < RSBA_PB; ++c) Lt[lr * RSBA_PLD + c] = (c <= lr) ? row[c] : 0.0;
+        if (kWritePan && lr < nb) {
+#pragma unroll
+          for (int c = 0; c < RSBA_PB; ++c) Pan[lr * RSBA_PLD + c] = (c <= lr) ? row[c] : 0.0;
+        }
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      const bool good = __builtin_amdgcn_ballot_w64(!(ilv > 0.0) || !(ilv <= DBL_MAX)) == 0;
 #ifdef RSBA_PROFILE_PHASES
       if (lane == 0) { long long _w1 = clock64(); g_phase_cycles[10] += _w1 - _w0; _w0 = _w1; }
 #endif
+      if (!kInverse) return good;
       // T = L11^-1 in 16 x 16 blocks: T = [[T11, 0], [-T22 L21 T11, T22]].  Lanes 0..15 invert the top-left block and
       // lanes 16..31 the bottom-right one at the same time (column lr & 15 each, a 16-step chain instead of 32); the
       // off-diagonal block is two 16x16x16 products on the matrix cores.
@@ -247,8 +318,8 @@ __device__ __forceinline__ bool DiagFactorInverse(double* __restrict__ Pan, int 
 // other waves grows.  As a separate function it gets its own allocation and the caller saves what it needs around one
 // call per panel.  The LDS pointers keep their address space across the call (ds_read, not flat loads).
 typedef __attribute__((address_space(3))) double lds_double;
-__device__ __noinline__ bool DiagFactorInverseCall(lds_double* Pan, int nb, lds_double* T, lds_double* Lt, lds_double* invd, int lane) {
-  return DiagFactorInverse((double*)Pan, nb, (double*)T, (double*)Lt, (double*)invd, lane);
+static __device__ __noinline__ bool DiagFactorInverseCall(lds_double* Pan, int nb, lds_double* T, lds_double* Lt, lds_double* invd, int lane) {
+  return DiagFactorInverse<true, true>((double*)Pan, nb, (double*)T, (double*)Lt, (double*)invd, lane);
 }
 
 // Blocked back-substitution L' x = y with the stored block inverses; y (row n of A) is copied to LDS and holds x on

@@ -4,23 +4,22 @@
 // factor(p+1) crosses from one workgroup to the next at EVERY panel: store, acknowledgement, flag, poll, load — ~2.6 us of
 // the ~16 us a panel took, and the next owner's row update had to be finished by then as well.  Here
 //
-//   * workgroup 0 owns the diagonal: at panel p its wave 0 factors block p (DiagFactorInverse) while its other seven waves
-//     bring block p + 1 up to date (the update of panel p's columns fused with the look-ahead product, as in the multi
-//     kernel) and the right-hand-side row; then X(p+1, p) = Rows T', X X', and wave 0 goes on with block p + 1.  T never
-//     leaves the workgroup on the critical path: a panel costs factor + X + X X' + four barriers.
+//   * workgroup 0 owns the diagonal: at panel p its wave 0 factors block p (DiagFactorInverse) while six other waves bring
+//     the columns of panel p up to date in the rows of block p + 1 (three K slices per 16-row half, matrix cores); then
+//     X(p+1, p) = Rows T', X X', and wave 0 goes on with block p + 1.  T never leaves the workgroup on the critical path.
+//     Wave 4 shares wave 0's SIMD and stays out of everything between two factorisations: fp64 MFMAs run on the SIMD's fp64
+//     vector lanes on this chip, and a wave issuing them back to back slows its SIMD partner down 14-fold
+//     (tools/factor_bench.hip) — for the same reason nothing but MFMA work runs beside the update waves.
 //   * workgroups 1 .. G-1 own the rows BELOW: block b belongs to workgroup 1 + b mod (G - 1) for the panels p <= b - 2;
-//     they receive the strip of block p and T(p) through global memory (flags strip_ready / tdone, as before) one hop behind
-//     the diagonal, store their X, and hand block b over (flag rows_ready[b]) after panel b - 2; nothing waits for them but
-//     the last slabs of workgroup 0's update one panel later.
+//     they receive the strip of block p and T(p) through global memory (flags strip_ready / tdone) one hop behind the
+//     diagonal, store their X, and hand block b over (flag rows_ready[b]) after panel b - 2.  With X(b, p) at hand they
+//     also add X X' to the block's LOOK-AHEAD SUM  sum_{q <= b-2} X(b, q) X(b, q)'  (three 16 x 16 tiles per block, kept in
+//     LDS) and hand it over with the block: workgroup 0 subtracts it from S(b, b) and only adds the last panel's X X'
+//     itself — it used to stream the block's rows a second time for it, 43 % of its matrix-core work.
+//   * the right-hand-side row is block np (one row): a row workgroup's like any other until panel np - 2, workgroup 0's at
+//     the last panel.
 //
-// STATUS (round 2): the default for 32 to 64 cameras (RSBA_CHOL_DIAG=0 selects the round-robin kernel).  Measured at 64
-// cameras beside the Schur kernel: 0.466 ms per LM iteration against 0.477 ms round-robin, 206 against 221 us alone
-// (sequential schedule).  What it took after the first version (0.493 ms): T and L11 stored by ONE wave right after the
-// factorisation and published before the X barrier (the row workgroups start 3 us earlier; publishing at the end of the
-// panel instead gives the gain back: 0.475 ms), the right-hand-side row brought up to date with plain dot products from a
-// prefetched row instead of a ninth MFMA tile, and the fused update's operand loads issued before its LDS stores.  A panel
-// of the chain is now factor (8.5 - 10 us) + 3.2 us for X, X X' and four barriers; the seven other waves' strip, wait for
-// rows_ready and fused update fit behind the factorisation for all but the first two panels.
+// STATUS (round 2): the default for 32 to 64 cameras (RSBA_CHOL_DIAG=0 selects the round-robin kernel).
 //
 // Same arithmetic per entry as the multi kernel's (products over fixed K slices, added in a fixed order): bitwise
 // reproducible, identical on every rank.  All waits carry a budget: a stall gives up (RES_STALL), never hangs.
@@ -33,7 +32,9 @@ struct DiagCholFlags {
   int* tdone;         // [16]  == tag when panel p's L11 / T are in global memory
   int* strip_ready;   // [16]  == tag when the rows of block p hold L for all columns < 32 p          (workgroup 0)
   int* rows_ready;    // [16]  == tag when the rows of block b hold L for all columns < 32 (b - 1)    (its row workgroup)
-  int* error;         // != 0: somebody gave up waiting
+  int* error;         // [0] != 0: somebody gave up waiting; [4 + w]: (tag << 4) | panels workgroup w is through
+  double* dg;         // [np + 1][32 * 32] look-ahead sums handed over with the blocks (tiles (0,0), (1,0), (1,1) of 256)
+  double* ah;         // [np + 1][32 * 32] the blocks as handed over: updated through their second-last panel, unsolved
 };
 
 #ifndef RSBA_DC_NPF
@@ -48,13 +49,218 @@ __host__ __device__ inline size_t DiagCholLdsDoubles(int nc) {
   return (size_t)(n + RSBA_PB) * RSBA_PLD + 5 * RSBA_PB * RSBA_PLD + 32 + n + 1024;   // 163.6 KB at 64 cameras: the static __shared__ words still fit below 160 KiB
 }
 
+// What one of the diagonal workgroup's six update waves (wk = 0 .. 5) does in panel p >= 1 while wave 0 factors block p.
+//
+// The rows of block p + 1 come from their row workgroup WITHOUT their newest 32 columns: that workgroup hands the block over
+// after the update of its panel p - 1, before T(p - 1) has reached it — the updated, unsolved block Ahat(p+1, p-1) (ah) and
+// the look-ahead sum through panel p - 2 — and X(p+1, p-1) = Ahat T(p-1)' is formed HERE, with the T(p-1) this workgroup kept
+// in LDS (tprev).  (It used to wait for the row workgroup's X: T(p-1) out, X back, two store acknowledgements, two flag polls
+// and two loads, 8 us after T(p-1) was published.)
+//
+// A compute unit moves only ~20 GB/s of freshly handed-over data (its own memory queue, ~2 us per round trip beside the Schur
+// kernel), so NOTHING is loaded twice: the strip of block p — the B operand, in LDS as the image of the block's 32 rows, SLD
+// doubles apart, read back with ds_read_b128 — is what this routine held in registers as the A operand one panel ago (the
+// rows of block p + 1 become the strip of panel p + 1): after barrier [A], when the old strip is dead, every wave writes its
+// slabs into the image.  The newest slab comes from xprev, the one after that (X(p+1, p)) from the panel's tail.
+//
+//   1. wave 0 polls the block's flag and the camera group of its own columns of S; the six meet at the LDS counter;
+//   2. ONE round trip: for waves 0, 1 their 16 rows of Ahat and of S (slice 0's panel rows start as S'), everybody's share of the
+//      next diagonal block (pre_n = S'(p+1, p+1) - look-ahead sum as handed over), then this wave's slabs of the rows of block
+//      p + 1 (half h, K slice [sa, sb) of whole 32-column slabs, <= 4; lane (mi, kk): row mi, columns 8 kk ..);
+//   3. waves 0, 1: X(p+1, p-1) -> xprev (LDS; the workgroup's wave 4 sends it to memory);
+//   4. the unit: acc = A[rows, slabs] B', the older slabs as they arrive; the six meet again, then the newest slab (p - 1) from
+//      xprev; acc is left at out (slice 0: subtracted from the panel rows, stride 33; slices 1, 2: a partial tile, stride 32);
+//      waves 2, 3, 4 also one tile each of X X' of the newest panel (what the look-ahead sum still lacks) into tprev's place;
+//   5. barrier [A] of the whole workgroup (s_barrier: the other two waves are at theirs), then the slabs into the strip image.
+//
+// Out of line and static: its own register allocation instead of pushing the kernel's state into scratch (the reloads would land
+// in the tail of every panel), and with internal linkage nothing is saved for the caller as long as it stays within the
+// caller-saved registers.  *ok_lds = 0 if a flag did not come.
+typedef __attribute__((address_space(3))) int lds_int;
+// The routine's constants, in LDS (set once per launch): as arguments they would not fit the argument registers, and the
+// ones passed on the stack cost a scratch round trip at every entry.
+struct DiagConst {
+  const double* A; const double* S; const double* ah; const double* dg; const double* diag_u;
+  const int* rows_ready; const int* error; const int* gate_ready;
+  long long budget, gate_budget;
+  double min_diag, max_diag, inv_radius;
+  int n, nreal, SLD, tag, gate_tag, gate_cols, gated;
+  lds_double* Bst; lds_double* tprev; lds_double* xprev; lds_double* scl;
+  lds_int* s_wb; lds_int* ok_lds;
+  long long* tr;
+};
+typedef __attribute__((address_space(3))) const DiagConst lds_DiagConst;
+static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, int wk, int sa, int sb, int p, int do_unit, lds_double* out, lds_double* pre_n) {
+  const double* __restrict__ A = dc->A;
+  const double* __restrict__ S = dc->S;
+  const int n = dc->n, nreal = dc->nreal, SLD = dc->SLD, tag = dc->tag;
+  lds_double* Bst = dc->Bst; lds_double* tprev = dc->tprev; lds_double* xprev = dc->xprev; const lds_double* scl = dc->scl;
+  lds_int* s_wb = dc->s_wb; lds_int* ok_lds = dc->ok_lds;
+  const int wb_target = 12 * (p - 1) + 6;
+  long long* tr = dc->tr ? dc->tr + (size_t)p * 8 : nullptr;
+  const int lane = threadIdx.x & 63, mi = lane & 15, kk = lane >> 4, h = wk & 1;
+  const int nb0 = kb + RSBA_PB;   // block p + 1's first row
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) d2_t lds_d2;
+  auto meet = [&](int target) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) {
+      __hip_atomic_fetch_add(s_wb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(s_wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  // 1. the block's flag (at the last panel: the right-hand-side row's, which still comes solved)
+  if (wk == 0 && lane == 0) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(dc->rows_ready + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__hip_atomic_load(dc->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > dc->budget) { __hip_atomic_store(ok_lds, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+    }
+    // ... and the camera group of block p + 1's own columns of S (a stage of the Schur kernel; the row workgroups wait for it too)
+    if (do_unit && dc->gated && nb0 % dc->gate_cols == 0) {
+      const long long t1 = wall_clock64();
+      while (__hip_atomic_load(dc->gate_ready + 1 + nb0 / dc->gate_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != dc->gate_tag) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t1 > (dc->gate_budget > 0 ? dc->gate_budget : RSBA_STALL_TICKS)) { __hip_atomic_store(ok_lds, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+      }
+    }
+  }
+  meet(wb_target);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (tr && wk == 0 && lane == 0) tr[2] = wall_clock64();
+  if (!do_unit) { meet(wb_target + 6); return; }   // (the last panel: the caller goes on to the right-hand-side row, barrier [A] is his)
+  // 2. everything in one round trip
+  double pf[4][8], ax[8], sv8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ns[3] = {0.0, 0.0, 0.0}, ndd[3] = {0.0, 0.0, 0.0}, ndu = 0.0;
+  const int sr = lane >> 2, sc0 = (lane & 3) * 8, sgi = nb0 + h * 16 + sr;
+  if (wk < 2) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ax[u] = dc->ah[(size_t)(p + 1) * 1024 + (16 * wk + mi) * RSBA_PB + 4 * u + kk];   // MFMA A operand: row mi, k = 4 u + kk
+  }
+  // the next diagonal block: entries e = thread + 384 u of S(p+1, p+1), its damping diagonal, the look-ahead sum
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int e = wk * 64 + lane + u * 384, r = e >> 5, c = e & 31;
+    if (e < RSBA_PB * RSBA_PB) {
+      if (nb0 + r < nreal && nb0 + c < nreal) ns[u] = S[(size_t)(nb0 + r) * nreal + nb0 + c];
+      if (r == c && nb0 + r < nreal) ndu = dc->diag_u[nb0 + r];
+      ndd[u] = dc->dg[(size_t)(p + 1) * 1024 + r * 32 + c];
+    }
+  }
+  // slice 0 also brings the rows' own entries of S (off the diagonal: scaled, no damping term)
+  if (wk < 2 && sgi < nreal) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) sv8[u] = S[(size_t)sgi * nreal + kb + sc0 + u];
+  }
+  // (the slabs last: the loads return in order, and X(p+1, p-1) is formed while they are still arriving)
+  {
+    const double* arow = A + (size_t)(nb0 + h * 16 + mi) * n + 8 * kk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (sa + i < sb && sa + i < p - 1) {
+        const double2* pa = reinterpret_cast<const double2*>(arow + (sa + i) * RSBA_PB);
+#pragma unroll
+        for (int v2 = 0; v2 < 4; ++v2) { const double2 t = pa[v2]; pf[i][2 * v2] = t.x; pf[i][2 * v2 + 1] = t.y; }
+      }
+    }
+  }
+  if (wk < 2) {
+    // slice 0's rows of the panel start as S'
+    const double si = sgi < nreal ? scl[sgi] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) out[sr * RSBA_PLD + sc0 + u] = kb + sc0 + u < nreal ? sv8[u] * (si * scl[kb + sc0 + u]) : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int e = wk * 64 + lane + u * 384, r = e >> 5, c = e & 31, gi = nb0 + r, gj = nb0 + c;
+    if (e < RSBA_PB * RSBA_PB) {
+      double v = gi == gj ? 1.0 : 0.0;   // padding
+      if (gi < nreal && gj < nreal) {
+        v = ns[u] * (scl[gi] * scl[gj]);
+        if (gi == gj) v += fmin(fmax(scl[gi] * scl[gi] * ndu, dc->min_diag), dc->max_diag) * dc->inv_radius;
+      }
+      pre_n[r * RSBA_PLD + c] = v - ndd[u];
+    }
+  }
+  if (tr && wk == 0 && lane == 0) tr[5] = wall_clock64();
+  // 3. X(p+1, p-1) = Ahat T(p-1)', 16 rows per wave
+  if (wk < 2) {
+    d4_t x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[u], tprev[mi * RSBA_PLD + 4 * u + kk], x0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[u], tprev[(16 + mi) * RSBA_PLD + 4 * u + kk], x1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int lr = 16 * wk + kk + 4 * t;
+      xprev[lr * SLD + mi] = x0[t]; xprev[lr * SLD + 16 + mi] = x1[t];   // (wave 4 sends it to memory)
+    }
+  }
+  // 4. the unit: the older slabs as they arrive (the strip is in LDS, nothing else is needed), ...
+  d4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+  auto slab_mfma = [&](const double (&av)[8], int q0) {
+    // B[k][j] = L[kb + j][k]: lane (mi, kk) takes the eight k = q0 + 8 kk + u of strip rows mi and 16 + mi in four 16-byte reads each
+    double bb[8];   // (one tile's operands at a time: the routine has to stay within the registers no caller has to save)
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) { const d2_t t0 = *reinterpret_cast<const lds_d2*>(Bst + (size_t)mi * SLD + 8 * kk + q0 + u); bb[u] = t0[0]; bb[u + 1] = t0[1]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bb[u], a0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) { const d2_t t1 = *reinterpret_cast<const lds_d2*>(Bst + (size_t)(16 + mi) * SLD + 8 * kk + q0 + u); bb[u] = t1[0]; bb[u + 1] = t1[1]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bb[u], a1, 0, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (sa + i < sb && sa + i < p - 1) slab_mfma(pf[i], (sa + i) * RSBA_PB);
+  // ... then, when X(p+1, p-1) is there (the second meeting), the newest one
+  meet(wb_target + 6);
+  if (tr && wk == 0 && lane == 0) tr[6] = wall_clock64();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (sa + i < sb && sa + i == p - 1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pf[i][u] = xprev[(h * 16 + mi) * SLD + 8 * kk + u];
+      slab_mfma(pf[i], (sa + i) * RSBA_PB);
+    }
+  }
+  // X X' of the newest panel: tiles (0,0), (1,0), (1,1) by waves 2, 3, 4 into tprev's tile, 3 x 256 doubles
+  if (wk >= 2 && wk <= 4) {
+    const int t3 = wk - 2, ti = t3 == 0 ? 0 : 1, tj = t3 == 2 ? 1 : 0;
+    d4_t xx = {0, 0, 0, 0};
+#pragma unroll
+    for (int qs = 0; qs < RSBA_PB; qs += 4)
+      xx = __builtin_amdgcn_mfma_f64_16x16x4f64(xprev[(16 * ti + mi) * SLD + qs + kk], xprev[(16 * tj + mi) * SLD + qs + kk], xx, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tprev[t3 * 256 + (kk + 4 * t) * 16 + mi] = xx[t];   // (tprev was last read in step 3: the second meeting since)
+  }
+  const int ks = wk >> 1;
+  if (ks == 0) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (ks == 0) { out[(kk + 4 * t) * RSBA_PLD + mi] -= a0[t]; out[(kk + 4 * t) * RSBA_PLD + 16 + mi] -= a1[t]; }
+    else { out[(kk + 4 * t) * 32 + mi] = a0[t]; out[(kk + 4 * t) * 32 + 16 + mi] = a1[t]; }
+  }
+  if (tr && wk == 0 && lane == 0) tr[3] = wall_clock64();
+  // 5. [A]; then this wave's slabs of the rows of block p + 1 into the strip image of the next panel
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (sa + i < sb) {
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) { d2_t t; t[0] = pf[i][u]; t[1] = pf[i][u + 1]; *reinterpret_cast<lds_d2*>(Bst + (size_t)(h * 16 + mi) * SLD + (sa + i) * RSBA_PB + 8 * kk + u) = t; }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(512)
 k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double* __restrict__ A, double* __restrict__ scale_c,
                             const double* __restrict__ cam_x, double* __restrict__ cam_c, const double* __restrict__ intr,
                             double* __restrict__ camc_c, double* __restrict__ dcam, const double* __restrict__ gmax_p,
                             double* __restrict__ res, IterParams ip, int* __restrict__ chol_ok, StageGate gate, DiagCholFlags f, int tag,
                             long long* __restrict__ mtrace /* diagnostic: [G][16][8] wall-clock stamps, or nullptr */) {
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // (16: the strip image is read and written 16 bytes at a time)
   const int nreal = L.nc, n = (nreal + RSBA_PB - 1) / RSBA_PB * RSBA_PB;
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
   const int G = gridDim.x, w = blockIdx.x;
@@ -126,24 +332,47 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) { const int r = e >> 5, c = e & 31; Pre[r * RSBA_PLD + c] = sys(r, c, Sat(r, c)); }
     __syncthreads();
   }
-  // barrier of waves 1 .. 7 (wave 0 is in the factorisation)
-  auto bar7 = [&]() {
+  // barrier of the diagonal workgroup's working waves 1, 2, 3, 5, 6, 7 while wave 0 is in the factorisation (wave 4 shares its
+  // SIMD and idles; DiagUpdateWave counts on the same LDS word)
+  const bool idle4 = w == 0 && wave == 4;
+  auto bar6 = [&]() {
     ++wb_gen;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) {
       __hip_atomic_fetch_add(&s_wb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      while (__hip_atomic_load(&s_wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (nwave - 1) * wb_gen) __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(&s_wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (nwave - 2) * wb_gen) __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   };
+  __shared__ DiagConst s_dc;
+  if (w == 0 && tid == 0) {
+    s_dc.A = A; s_dc.S = S; s_dc.ah = f.ah; s_dc.dg = f.dg; s_dc.diag_u = red + L.diagU();
+    s_dc.rows_ready = f.rows_ready; s_dc.error = f.error; s_dc.gate_ready = gate.ready;
+    s_dc.budget = budget; s_dc.gate_budget = gate.budget;
+    s_dc.min_diag = ip.min_lm_diagonal; s_dc.max_diag = ip.max_lm_diagonal; s_dc.inv_radius = inv_radius;
+    s_dc.n = n; s_dc.nreal = nreal; s_dc.SLD = n - 30; s_dc.tag = tag; s_dc.gate_tag = gate.tag; s_dc.gate_cols = gate.cols;
+    s_dc.gated = (gate.ready != nullptr && !ip.first) ? 1 : 0;
+    s_dc.Bst = (lds_double*)lds; s_dc.tprev = (lds_double*)Xl; s_dc.xprev = (lds_double*)(lds + (n - 30 - RSBA_PB)); s_dc.scl = (lds_double*)scl;
+    s_dc.s_wb = (lds_int*)&s_wb; s_dc.ok_lds = (lds_int*)&s_w7ok;
+    s_dc.tr = mtrace;   // (workgroup 0's stamps start at mtrace)
+  }
+  __syncthreads();
+  // a row workgroup's look-ahead tiles: 4 block slots x 3 tiles x 256 doubles where workgroup 0 keeps Pre / PreN / scratch
+  double* dtile = PreA;
+  const int gmr = G - 1;
 
 #define RSBA_DC_STAMP(k) do { if (mtrace && tid == 0) mtrace[((size_t)w * 16 + p) * 8 + (k)] = wall_clock64(); } while (0)
   for (int p = 0; p < np && !stalled; ++p) {
     const int kb = p * RSBA_PB;
     RSBA_DC_STAMP(0);
+    // LDS below T.  A row workgroup: strip of block p, k-major with stride 33 (Bst), then its blocks of the panel.  The diagonal
+    // workgroup: strip of block p as the image of its rows, 32 x SLD doubles (see DiagUpdateWave; the two doubles of padding shift
+    // consecutive rows by 16 bytes, so the ds_read_b128 of the sixteen rows of a B tile do not meet in a bank), then the panel
+    // block of the next rows and the partial tiles of K slice 2:  32 (n - 30) + 1056 + 1024 <= 33 (n + 32).
+    const int SLD = n - 30;
     double* Bst = lds;
-    double* Pan = lds + (size_t)kb * RSBA_PLD;
+    double* Pan = w == 0 ? lds + (size_t)32 * SLD : lds + (size_t)kb * RSBA_PLD;
     // One 16-row half of a block b in slot j: its columns of the panel (scaled, damped) into Pan, minus A[rows, 0:kb] Bst'
     // over K slice ks of nsplit (slice 0 owns the rows in Pan, the others leave 16 x 32 partial tiles at pdst).
     auto load_update_half = [&](int b, int j, int half, int ks, int nsplit, double* pdst) {
@@ -212,39 +441,10 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         }
       }
     };
-    // The right-hand-side row's columns of the panel (one wave): rhs[kb + c] - sum_q L[n][q] L[kb + c][q], c < 32 — one row,
-    // so no matrix cores: the row's kb entries come into LDS in one round trip (the unused rows of its panel block), lane
-    // (c, half) adds every second term, the two halves meet in a shuffle.  Fixed order.  As an MFMA half streamed over the
-    // whole K range by one wave it was the longest item of the diagonal workgroup's panel (13 us at kb = 288).
-    double rhs_av[6] = {0, 0, 0, 0, 0, 0}, rhs_c = 0.0;   // one wave's share of the row and of the right-hand side, fetched early
-    auto rhs_row_prefetch = [&]() {
-#pragma unroll
-      for (int u = 0; u < 6; ++u) { const int q = lane + 64 * u; rhs_av[u] = q < kb ? A[(size_t)n * n + q] : 0.0; }
-      rhs_c = sys(n, kb + (lane & 31), 0.0);
-    };
-    auto rhs_row_update = [&](int j) {
-      double* arow_l = Pan + (size_t)(j * RSBA_PB + 1) * RSBA_PLD;   // rows 1.. of the block: 31 x 33 >= kb doubles
-      const int c = lane & 31, half = lane >> 5;
-#pragma unroll
-      for (int u = 0; u < 6; ++u) { const int q = lane + 64 * u; if (q < kb) arow_l[q] = rhs_av[u]; }
-      __builtin_amdgcn_wave_barrier();
-      // lane (c, half) adds the terms q = half, half + 2, ...: eight running sums (q mod 16), so that the LDS reads of
-      // one round do not wait for the additions of the last (kb is a multiple of 32)
-      double sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int q0 = half; q0 < kb; q0 += 16) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sacc[u] += arow_l[q0 + 2 * u] * Bst[(q0 + 2 * u) * RSBA_PLD + c];
-      }
-      double sum = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
-      sum += __shfl_xor(sum, 32, 64);
-      __builtin_amdgcn_wave_barrier();
-      if (half == 0) Pan[(size_t)(j * RSBA_PB) * RSBA_PLD + c] = rhs_c - sum;
-      // rows 1 .. 15 of the half feed the X product row by row and are never stored: whatever they hold is harmless, but
-      // keep them finite
-      for (int e = lane; e < 15 * RSBA_PB; e += 64) Pan[(size_t)(j * RSBA_PB + 1 + e / RSBA_PB) * RSBA_PLD + (e % RSBA_PB)] = 0.0;
-    };
     // X = Rows T' for one 16-row half in slot j, stored as L (and kept in Xl for the next diagonal block)
-    auto solve_half = [&](int b, int j, int half, bool keep) {
+    // (keep 1: also into Xl for the next diagonal block; keep 2: also back into the block's panel rows, for X X'; keep 3: into
+    //  Xl ONLY — somebody else sends it to memory)
+    auto solve_half = [&](int b, int j, int half, int keep) {
       const int prow = j * RSBA_PB + half * 16;
       d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
@@ -256,11 +456,12 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int lr = half * 16 + kk + 4 * tt, grow = b * RSBA_PB + lr;
-        if (grow <= n) {
+        if (grow <= n && keep != 3) {
           StoreShared(&A[(size_t)grow * n + kb + mi], acc0[tt]);
           StoreShared(&A[(size_t)grow * n + kb + 16 + mi], acc1[tt]);
         }
-        if (keep) { Xl[lr * RSBA_PLD + mi] = acc0[tt]; Xl[lr * RSBA_PLD + 16 + mi] = acc1[tt]; }
+        if (keep == 1 || keep == 3) { Xl[lr * RSBA_PLD + mi] = acc0[tt]; Xl[lr * RSBA_PLD + 16 + mi] = acc1[tt]; }
+        if (keep == 2) { Pan[(prow + kk + 4 * tt) * RSBA_PLD + mi] = acc0[tt]; Pan[(prow + kk + 4 * tt) * RSBA_PLD + 16 + mi] = acc1[tt]; }
       }
     };
 
@@ -268,211 +469,98 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       // ============================================================ the diagonal workgroup
       const bool has_next = p + 1 < np;
       const int nb0 = kb + RSBA_PB;                 // first row / column of block p + 1
-      const int jr = has_next ? 1 : 0;              // slot of the right-hand-side row (block np); slot 0: block p + 1
-      // block p + 1's diagonal entries of S and their damping terms: fetched now when their camera group is known to be
-      // published (same group as this panel, or the next one whose flag is already up), else after this panel's X
-      bool have_s = false, s_pending = false;
-      double sv[2] = {0.0, 0.0}, du[2] = {0.0, 0.0};
-      if (has_next) {
-        if (gate.ready == nullptr || ip.first || nb0 % gate.cols != 0) have_s = true;
-        else {
-          __shared__ int s_gate_open;
-          if (tid == 0) s_gate_open = __hip_atomic_load(gate.ready + 1 + nb0 / gate.cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gate.tag;
-          __syncthreads();
-          have_s = s_gate_open != 0;
-          if (have_s) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        s_pending = !have_s;
-        if (have_s) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int e = tid + u * nt, r = e >> 5, c = e & 31;
-            sv[u] = Sat(nb0 + r, nb0 + c);
-            du[u] = (r == c && nb0 + r < nreal) ? red[L.diagU() + nb0 + r] : 0.0;
-          }
-        }
-      }
-      // partial tiles of the fused update (K slices 1): diagonal tiles (h, ks) behind the panel blocks (>= 1056 doubles free),
-      // cross tiles (cs) in Xl, update partials (h) in the scratch area
-      double* fp_diag = lds + (size_t)(kb + (jr + 1) * RSBA_PB) * RSBA_PLD;
-      double* fp_cross = Xl;
-      double* fp_upd = scratch;
+      // X(p+1, p-1), formed during the update, lives in the last 32 columns of the strip image's rows (free while there is a next
+      // block: the strip is at most n - 64 columns wide then)
+      double* xprev = Bst + (SLD - RSBA_PB);
+      const bool unit_wave = wave != 0 && !idle4;
+      // partial tiles of the update (K slices 1 and 2 of three; slice 0 lands in the panel rows): slice 1 in the scratch
+      // area, slice 2 behind the panel block
+      double* part1 = scratch;
+      double* part2 = Pan + RSBA_PB * RSBA_PLD;
       if (wave == 0) {
         if (!DiagFactorInverseCall((lds_double*)Pre, RSBA_PB, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane) && lane == 0) s_ok = 0;
-      } else {
-        // ---- waves 1 .. 7: strip of block p, then block p + 1 (fused update + look-ahead product) and the rhs row
-        if (p > 0 && wave == (has_next ? 7 : 1)) rhs_row_prefetch();
+        RSBA_DC_STAMP(1);
+      } else if (!idle4) {
+        // ---- waves 1, 2, 3, 5, 6, 7: strip of block p, then the columns of panel p in the rows of block p + 1: half h of the
+        // rows, K slice ks of three (whole 32-column slabs), see DiagUpdateWave
+        const int wk = wave < 4 ? wave - 1 : wave - 2;   // 0 .. 5
+        const int h = wk & 1, ks = wk >> 1;
+        const int qper = (p + 2) / 3, sa = ks * qper, sb = min(p, (ks + 1) * qper);   // slabs [sa, sb), sb - sa <= 4
+        const bool unit = has_next && p > 0;
         if (p > 0) {
-          for (int e = tid - 64; e < (kb >> 2) * RSBA_PB; e += nt - 64) {
-            const int c = e / (kb >> 2), q0 = (e - c * (kb >> 2)) * 4;
-            const double* lrow = A + (size_t)(kb + c) * n + q0;
-            const double2 a01 = *reinterpret_cast<const double2*>(lrow), a23 = *reinterpret_cast<const double2*>(lrow + 2);
-            Bst[(q0 + 0) * RSBA_PLD + c] = a01.x; Bst[(q0 + 1) * RSBA_PLD + c] = a01.y;
-            Bst[(q0 + 2) * RSBA_PLD + c] = a23.x; Bst[(q0 + 3) * RSBA_PLD + c] = a23.y;
+          DiagUpdateWave((lds_DiagConst*)&s_dc, kb, wk, sa, sb, p, unit ? 1 : 0,
+                         (lds_double*)(ks == 0 ? Pan + h * 16 * RSBA_PLD : (ks == 1 ? part1 : part2) + h * 512), (lds_double*)PreN);
+          if (mtrace && tid == 64) mtrace[((size_t)w * 16 + p) * 8 + 3] = wall_clock64();   // wave 1's unit done
+          if (!unit && wave == 1) {
+            // the last panel: the right-hand-side row alone, rhs[kb + c] - sum_q L[n][q] L[kb + c][q]: one row, so no matrix
+            // cores; lane (c, half) adds every second group of eight terms into eight running sums, the halves meet in a shuffle
+            const int c = lane & 31, half = lane >> 5;
+            const double* arow_n = A + (size_t)n * n;
+            double sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int q0 = half * 8; q0 < kb; q0 += 16) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) sacc[u] += arow_n[q0 + u] * Bst[(size_t)c * SLD + q0 + u];
+            }
+            double sum = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
+            sum += __shfl_xor(sum, 32, 64);
+            const double rc = sys(n, kb + c, 0.0);
+            for (int e = lane; e < 16 * RSBA_PB; e += 64) Pan[(size_t)(e / RSBA_PB) * RSBA_PLD + (e % RSBA_PB)] = 0.0;   // rows 1 .. 15 feed the X product and are never stored: keep them finite
+            __builtin_amdgcn_wave_barrier();
+            if (half == 0) Pan[c] = rc - sum;
           }
-          // block p + 1's rows must hold L through column kb - 1: the last 32 columns come from its row workgroup's panel
-          // p - 1 (one hop behind the diagonal)
-          if (has_next && p >= 1 && wave == 1 && lane == 0) {
-            const long long t0 = wall_clock64();
-            int ok = 1;
-            while (__hip_atomic_load(f.rows_ready + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
-              __builtin_amdgcn_s_sleep(2);
-              if (__hip_atomic_load(f.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > budget) { ok = 0; break; }
-            }
-            if (!ok) __hip_atomic_store(&s_w7ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-          bar7();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          if (mtrace && tid == 64) mtrace[((size_t)w * 16 + p) * 8 + 1] = wall_clock64();   // strip in LDS, rows_ready seen
-        }
-        if (has_next && p > 0) {
-          // waves 1..4: row waves (half h, K slice ks of 2): update + diagonal tile (h, h); waves 5, 6: cross tile (1, 0), K
-          // slice cs of 2; wave 7: the right-hand-side row
-          const int rw = wave - 1;
-          if (rw < 4) {
-            const int h = rw >> 1, ks = rw & 1;
-            const int sr = lane >> 2, sc0 = (lane & 3) * 8;
-            const int sgi = nb0 + h * 16 + sr;
-            double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ks == 0 && sgi < nreal) {
-              if (kb + sc0 + 8 <= nreal) {
-                const double2* sp = reinterpret_cast<const double2*>(S + (size_t)sgi * nreal + kb + sc0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const double2 t = sp[u]; v[2 * u] = t.x; v[2 * u + 1] = t.y; }
-              } else {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = Sat(sgi, kb + sc0 + u);
-              }
-            }
-            const int nq = kb / RSBA_PB, qper = (nq + 1) / 2;
-            const int qa = ks * qper * RSBA_PB, qb = min(kb, (ks + 1) * qper * RSBA_PB);
-            const double* ra = A + (size_t)(nb0 + 16 * h + mi) * n + 8 * kk;
-            constexpr int D = 2 * RSBA_DC_NPF;
-            double pf[D][8];
-            auto fetch8 = [&](double (&d)[8], const double* src) {
-              const double2* pa = reinterpret_cast<const double2*>(src);
-#pragma unroll
-              for (int v2 = 0; v2 < 4; ++v2) { const double2 t = pa[v2]; d[2 * v2] = t.x; d[2 * v2 + 1] = t.y; }
-            };
-#pragma unroll
-            for (int i = 0; i < D; ++i) if (qa + i * RSBA_PB < qb) fetch8(pf[i], ra + qa + i * RSBA_PB);
-            d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, dg = {0, 0, 0, 0};
-            for (int qg = qa; qg < qb; qg += D * RSBA_PB) {
-#pragma unroll
-              for (int i = 0; i < D; ++i) {
-                const int q0 = qg + i * RSBA_PB;
-                if (q0 < qb) {
-#pragma unroll
-                  for (int u = 0; u < 8; ++u) {
-                    const double b0 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + mi];
-                    const double b1 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + 16 + mi];
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pf[i][u], b0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pf[i][u], b1, acc1, 0, 0, 0);
-                    dg = __builtin_amdgcn_mfma_f64_16x16x4f64(pf[i][u], pf[i][u], dg, 0, 0, 0);
-                  }
-                  if (q0 + D * RSBA_PB < qb) fetch8(pf[i], ra + q0 + D * RSBA_PB);
-                }
-              }
-            }
-            if (ks == 0) {
-#pragma unroll
-              for (int u = 0; u < 8; ++u) Pan[(h * 16 + sr) * RSBA_PLD + sc0 + u] = sys(sgi, kb + sc0 + u, v[u]);
-              __builtin_amdgcn_wave_barrier();
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              if (ks == 0) {
-                const int r = h * 16 + kk + 4 * t;
-                Pan[r * RSBA_PLD + mi] -= acc0[t];
-                Pan[r * RSBA_PLD + 16 + mi] -= acc1[t];
-              } else {
-                fp_upd[h * 512 + (kk + 4 * t) * 32 + mi] = acc0[t];
-                fp_upd[h * 512 + (kk + 4 * t) * 32 + 16 + mi] = acc1[t];
-              }
-              fp_diag[(h * 2 + ks) * 256 + (kk + 4 * t) * 16 + mi] = dg[t];
-            }
-            if (mtrace && tid == 128) mtrace[((size_t)w * 16 + p) * 8 + 2] = wall_clock64();   // row wave (h 0, slice 1) done
-          } else if (rw < 6) {
-            const int cs = rw - 4;
-            const int nq = kb / RSBA_PB, qper = (nq + 1) / 2;
-            const int qa = cs * qper * RSBA_PB, qb = min(kb, (cs + 1) * qper * RSBA_PB);
-            const double* r1 = A + (size_t)(nb0 + 16 + mi) * n + 8 * kk;
-            const double* r0 = A + (size_t)(nb0 + mi) * n + 8 * kk;
-            constexpr int D = RSBA_DC_NPF;
-            double p1[D][8], p0[D][8];
-            auto fetch8 = [&](double (&d)[8], const double* src) {
-              const double2* pa = reinterpret_cast<const double2*>(src);
-#pragma unroll
-              for (int v2 = 0; v2 < 4; ++v2) { const double2 t = pa[v2]; d[2 * v2] = t.x; d[2 * v2 + 1] = t.y; }
-            };
-#pragma unroll
-            for (int i = 0; i < D; ++i) if (qa + i * RSBA_PB < qb) { fetch8(p1[i], r1 + qa + i * RSBA_PB); fetch8(p0[i], r0 + qa + i * RSBA_PB); }
-            d4_t cr = {0, 0, 0, 0};
-            for (int qg = qa; qg < qb; qg += D * RSBA_PB) {
-#pragma unroll
-              for (int i = 0; i < D; ++i) {
-                const int q0 = qg + i * RSBA_PB;
-                if (q0 < qb) {
-#pragma unroll
-                  for (int u = 0; u < 8; ++u) cr = __builtin_amdgcn_mfma_f64_16x16x4f64(p1[i][u], p0[i][u], cr, 0, 0, 0);
-                  if (q0 + D * RSBA_PB < qb) { fetch8(p1[i], r1 + q0 + D * RSBA_PB); fetch8(p0[i], r0 + q0 + D * RSBA_PB); }
-                }
-              }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fp_cross[cs * 256 + (kk + 4 * t) * 16 + mi] = cr[t];
-          } else {
-            rhs_row_update(jr);
-            if (mtrace && lane == 0) mtrace[((size_t)w * 16 + p) * 8 + 3] = wall_clock64();   // rhs row done
-          }
-        } else {
-          // panel 0 (nothing to subtract yet) or the last panel (no next block): plain loads of the panel's columns
-          if (has_next) { for (int hb = wave - 1; hb < 2; hb += nwave - 1) load_update_half(p + 1, 0, hb, 0, 1, nullptr); }
-          if (wave == (has_next ? 7 : 1)) { if (p > 0) rhs_row_update(jr); else load_update_half(np, jr, 0, 0, 1, nullptr); }
+        } else if (has_next) {
+          if (wk < 2) load_update_half(p + 1, 0, wk, 0, 1, nullptr);   // panel 0: nothing to subtract yet
+        } else if (wave == 1) {
+          load_update_half(np, 0, 0, 0, 1, nullptr);
         }
       }
-      __syncthreads();   // [A] the factor (T, Lt, invd, Pre = L11) and the updates are done
+      if (idle4 && has_next && p > 0) {
+        // wave 4, the STORE wave: X(p+1, p-1) to memory as soon as the update waves have formed it (their third meeting)
+        if (lane == 0) { while (__hip_atomic_load(&s_wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 12 * p) __builtin_amdgcn_s_sleep(2); }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 2
+        for (int u = 0; u < 16; ++u) { const int e = lane + 64 * u, r = e >> 5, c = e & 31; StoreShared(&A[(size_t)(nb0 + r) * n + kb - RSBA_PB + c], xprev[(size_t)r * SLD + c]); }
+      }
+      if (!(unit_wave && has_next && p > 0)) __syncthreads();   // [A] the factor (T, Lt, invd, Pre = L11) and the updates are done (the update waves: inside DiagUpdateWave)
       RSBA_DC_STAMP(4);
       if (!s_ok && tid == 0) __hip_atomic_store(chol_ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (s_w7ok == 0) { stalled = true; break; }
-      // slice 1 of the update in fixed order (slice 0 is in Pan); waves 1..7 also send L11 / T on their way
+      // slices 1 and 2 of the update in fixed order (slice 0 is in Pan)
       if (has_next && p > 0) {
         for (int e = tid; e < 2 * 512; e += nt) {
           const int h = e >> 9, r = (e >> 5) & 15, c = e & 31;
-          Pan[(h * 16 + r) * RSBA_PLD + c] -= fp_upd[h * 512 + r * 32 + c];
+          Pan[(h * 16 + r) * RSBA_PLD + c] = (Pan[(h * 16 + r) * RSBA_PLD + c] - part1[h * 512 + r * 32 + c]) - part2[h * 512 + r * 32 + c];
+        }
+      }
+      // The next diagonal block: PreN holds S' minus the look-ahead sum as handed over (DiagUpdateWave); now minus X X' of the
+      // panel the block came without (its tiles are in Xl's place), at [D] minus this panel's.  Panel 0: S' alone, from here.
+      if (has_next) {
+        for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) {
+          const int r = e >> 5, c = e & 31;
+          if (p > 0) {
+            const int rr = max(r, c), cc = min(r, c), t3 = (rr >> 4) + (cc >> 4);
+            PreN[r * RSBA_PLD + c] -= (r >> 4) == (c >> 4) ? Xl[t3 * 256 + (r & 15) * 16 + (c & 15)] : Xl[256 + (rr & 15) * 16 + (cc & 15)];
+          } else {
+            PreN[r * RSBA_PLD + c] = sys(nb0 + r, nb0 + c, Sat(nb0 + r, nb0 + c));
+          }
         }
       }
       if (wave == 7) {
         // L11 / T leave through ONE wave: it alone waits for their acknowledgements (below, after the next barrier) and
-        // publishes them — the row workgroups get T(p) while this workgroup is still busy with X
+        // publishes them — the row workgroups get T(p) while this workgroup is still busy with X.  AFTER the look-ahead
+        // values above: those come from global loads, and the s_waitcnt vmcnt(0) in front of their use would also wait
+        // for these stores' acknowledgements (gfx9 counts loads and stores in one counter)
         for (int e = lane; e < RSBA_PB * RSBA_PB; e += 64) {
           const int r = e >> 5, c = e & 31;
           StoreShared(&A[(size_t)(kb + r) * n + kb + c], c > r ? T[c * RSBA_PLD + r] : Pre[r * RSBA_PLD + c]);
         }
         if (lane < RSBA_PB) StoreShared(&A[(size_t)(n + 1) * n + kb + lane], invd[lane]);
       }
-      // look-ahead part of the next diagonal block (everything but this panel's X X'), kept in registers until Xl is free
-      if (has_next) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int e = tid + u * nt, r = e >> 5, c = e & 31;
-          double d = 0.0;
-          if (p > 0) {
-            if ((r >> 4) == (c >> 4)) {
-              const int hh = r >> 4, o = (r & 15) * 16 + (c & 15);
-              d = fp_diag[(hh * 2) * 256 + o] + fp_diag[(hh * 2 + 1) * 256 + o];
-            } else {
-              const int o = r >= 16 ? (r & 15) * 16 + (c & 15) : (c & 15) * 16 + (r & 15);   // tile (1,0), or its mirror
-              d = fp_cross[o] + fp_cross[256 + o];
-            }
-          }
-          sv[u] = (have_s ? sys_pre(nb0 + r, nb0 + c, sv[u], du[u]) : 0.0) - d;
-        }
-      }
-      __syncthreads();   // [B] Pan complete, partial tiles consumed (Xl is free again)
-      // X = Rows T': block p + 1 (two halves, kept in Xl) and the rhs row
-      if (has_next) { if (wave == 1 || wave == 2) solve_half(p + 1, 0, wave - 1, true); }
-      if (wave == 3) solve_half(np, jr, 0, false);
+      __syncthreads();   // [B] Pan complete, partial tiles consumed
+      // X = Rows T': block p + 1 (two halves, kept in Xl), or the rhs row at the last panel
+      if (has_next) { if (wave == 1 || wave == 2) solve_half(p + 1, 0, wave - 1, 3); }
+      else if (wave == 3) solve_half(np, 0, 0, 0);
       if (wave == 7) {
         // (publishing T only at the end of the panel takes this wait off the chain but delays the row workgroups, whose
         //  last slab the next panel's update waits for: measured 0.475 against 0.466 ms per LM iteration)
@@ -480,11 +568,19 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         if (lane == 0) __hip_atomic_store(f.tdone + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();   // [C] Xl
-      RSBA_DC_STAMP(5);
       if (has_next) {
-        // X X' (tiles by waves 1..4) -> scratch, then the next diagonal block
-        if (wave >= 1 && wave <= 4) {
-          const int ti = (wave - 1) >> 1, tj = (wave - 1) & 1;
+        // X X' (tiles by waves 1, 2, 3, 5) -> scratch; X(p+1, p) into the next strip's image, behind the columns the update waves
+        // left there (waves 0, 6, 7), and to memory (wave 4);
+        // then the next diagonal block
+        if (wave == 0 || wave >= 6) {
+          for (int e = (wave == 0 ? 0 : wave - 5) * 64 + lane; e < RSBA_PB * RSBA_PB; e += 192) { const int r = e >> 5, c = e & 31; Bst[(size_t)r * SLD + kb + c] = Xl[r * RSBA_PLD + c]; }
+        } else if (idle4) {
+#pragma unroll 2
+          for (int u = 0; u < 16; ++u) { const int e = lane + 64 * u, r = e >> 5, c = e & 31; StoreShared(&A[(size_t)(nb0 + r) * n + kb + c], Xl[r * RSBA_PLD + c]); }
+        }
+        if (wave != 0 && wave != 4 && wave <= 5) {
+          const int xt = wave < 4 ? wave - 1 : 3;
+          const int ti = xt >> 1, tj = xt & 1;
           d4_t acc = {0, 0, 0, 0};
 #pragma unroll
           for (int qs = 0; qs < RSBA_PB; qs += 4)
@@ -493,37 +589,32 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
           for (int t = 0; t < 4; ++t) scratch[(16 * ti + kk + 4 * t) * 32 + 16 * tj + mi] = acc[t];
         }
         __syncthreads();   // [D]
-        if (s_pending) {   // the next camera group had not been published when this panel began: its entries of S now
-          if (!WaitReady(gate.ready + 1 + nb0 / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
-          // (-d) + S, then - X X': the same three roundings in the same order as (S - d) - X X' of the early path, so the
-          // bits do not depend on whether the flag was up when the panel began
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int e = tid + u * nt, r = e >> 5, c = e & 31;
-            sv[u] += sys(nb0 + r, nb0 + c, Sat(nb0 + r, nb0 + c));
-          }
+        for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) {
+          const int r = e >> 5, c = e & 31;
+          PreN[r * RSBA_PLD + c] -= scratch[r * 32 + c];
+          Xl[r * RSBA_PLD + c] = T[r * RSBA_PLD + c];   // T(p) for the next panel's X(p+2, p): the factorisation is about to overwrite its tile
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const int e = tid + u * nt, r = e >> 5, c = e & 31; PreN[r * RSBA_PLD + c] = sv[u] - scratch[r * 32 + c]; }
         __syncthreads();   // [E] the next diagonal block is ready: wave 0 goes on
       }
-      RSBA_DC_STAMP(6);
-      // X is on its way: waves 1..7 wait for the acknowledgements and publish the strip; wave 0 does not wait
-      if (wave != 0) {
+      // X(p+1, p-1) and X(p+1, p) are on their way to memory: wave 4 waits for the acknowledgements and tells the row workgroups;
+      // nobody else does (this workgroup's next strip does not come from those stores)
+      if (idle4 && has_next) {
         __builtin_amdgcn_s_waitcnt(0);
-        bar7();
-        if (wave == 1 && lane == 0 && has_next) __hip_atomic_store(f.strip_ready + p + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(f.strip_ready + p + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       { double* t = Pre; Pre = PreN; PreN = t; }
       RSBA_DC_STAMP(7);
     } else {
-      // ============================================================ a row workgroup: blocks b >= p + 2, b mod (G - 1) == w - 1
-      const int gm = G - 1;
+      // ============================================================ a row workgroup: blocks b >= p + 2, b mod (G - 1) == w - 1,
+      // the right-hand-side row counting as block np (its first half only)
+      const int gm = gmr;
       int first = p + 2;
       first += ((w - 1) - first % gm + gm) % gm;
-      const int nown = first >= np ? 0 : (np - 1 - first) / gm + 1;
-      if (nown == 0) continue;
-      auto blk = [&](int j) { return first + j * gm; };
+      const int nfull = first >= np ? 0 : (np - 1 - first) / gm + 1;     // whole blocks
+      const bool rhs_mine = np % gm == w - 1 && p + 2 <= np;             // block np: panels p <= np - 2
+      const int nh = 2 * nfull + (rhs_mine ? 1 : 0);                     // 16-row halves to bring up to date and solve
+      if (nh == 0) continue;
+      auto blk = [&](int j) { return j < nfull ? first + j * gm : np; };
       if (p > 0) {
         if (!WaitFlagWG(f.strip_ready + p, tag, f.error, budget)) { stalled = true; break; }
         RSBA_DC_STAMP(2);
@@ -535,13 +626,16 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
           Bst[(q0 + 2) * RSBA_PLD + c] = a23.x; Bst[(q0 + 3) * RSBA_PLD + c] = a23.y;
         }
         __syncthreads();
+      } else {
+        // the look-ahead sums start at zero
+        for (int e = tid; e < 12 * 256; e += nt) dtile[e] = 0.0;
       }
       RSBA_DC_STAMP(3);
       if (gate.ready != nullptr && kb % gate.cols == 0 && !ip.first) {
         if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
       }
       {
-        const int nh = 2 * nown, nsplit = (p > 0 && nh <= 2) ? 4 : ((p > 0 && nh <= 4) ? 2 : 1);
+        const int nsplit = (p > 0 && nh <= 2) ? 4 : ((p > 0 && nh <= 4) ? 2 : 1);
         double* part = T;   // T | Lt | Xl are idle before T(p) arrives: up to six 16 x 32 partial tiles
         for (int it = wave; it < nh * nsplit; it += nwave) {
           const int hb = it / nsplit, ks = it - hb * nsplit;
@@ -559,24 +653,62 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         }
       }
       RSBA_DC_STAMP(4);
+      // Block p + 2 leaves this workgroup NOW, before T(p) is here: updated through this panel, unsolved (slot 0 of the panel
+      // rows), with its look-ahead sum through panel p - 1.  The diagonal workgroup solves it with its own T(p) (see
+      // DiagUpdateWave); the rows' columns < 32 p have been in memory since the last panel.
+      const bool lv = nfull > 0 && first == p + 2;
+      if (lv) {
+        for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) StoreShared(&f.ah[(size_t)(p + 2) * 1024 + e], Pan[(e >> 5) * RSBA_PLD + (e & 31)]);
+        const double* dt = dtile + (((p + 2) / gm) & 3) * 3 * 256;
+        for (int e = tid; e < 3 * 256; e += nt) {
+          const int t3 = e >> 8, r = (e >> 4) & 15, c = e & 15, ti = t3 == 0 ? 0 : 1, tj = t3 == 2 ? 1 : 0;
+          StoreShared(&f.dg[(size_t)(p + 2) * 1024 + (16 * ti + r) * 32 + 16 * tj + c], dt[e]);
+          if (t3 == 1) StoreShared(&f.dg[(size_t)(p + 2) * 1024 + c * 32 + 16 + r], dt[e]);   // the mirror of tile (1, 0): the reader takes whole rows
+        }
+        PublishFlagWG(f.rows_ready + p + 2, tag);
+      }
+      if (nh == (lv ? 2 : 0)) {   // nothing left to solve in this panel
+        if (tid == 0) __hip_atomic_store(f.error + 4 + w, (tag << 4) | (p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
       if (!WaitFlagWG(f.tdone + p, tag, f.error, budget)) { stalled = true; break; }
       {
+        // (read along the rows of the stored T': whole cache lines; transposed on the way into LDS)
         double tv[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int e = tid + u * nt, r = e >> 5, c = e & 31;
-          tv[u] = r > c ? A[(size_t)(kb + c) * n + kb + r] : (r == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
+          const int e = tid + u * nt, i = e >> 5, j = e & 31;
+          tv[u] = j > i ? A[(size_t)(kb + i) * n + kb + j] : (j == i ? A[(size_t)(n + 1) * n + kb + i] : 0.0);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const int e = tid + u * nt; T[(e >> 5) * RSBA_PLD + (e & 31)] = tv[u]; }
+        for (int u = 0; u < 2; ++u) {
+          const int e = tid + u * nt, i = e >> 5, j = e & 31;
+          if (j >= i) { T[j * RSBA_PLD + i] = tv[u]; if (j > i) T[i * RSBA_PLD + j] = 0.0; }
+        }
       }
       __syncthreads();
       RSBA_DC_STAMP(5);
-      for (int hb = wave; hb < 2 * nown; hb += nwave) solve_half(blk(hb >> 1), hb >> 1, hb & 1, false);
+      for (int hb = wave + (lv ? 2 : 0); hb < nh; hb += nwave) solve_half(blk(hb >> 1), hb >> 1, hb & 1, (hb >> 1) < nfull ? 2 : 0);
       RSBA_DC_STAMP(6);
-      // block p + 2 leaves this workgroup after this panel: its rows are final through column 32 (p + 1) - 1
-      if (first == p + 2) PublishFlagWG(f.rows_ready + p + 2, tag);
+      // X(b, p) is on its way to memory and sits in the blocks' panel rows: the look-ahead sums take their X X'
+      __syncthreads();
+      for (int it = wave + (lv ? 3 : 0); it < 3 * nfull; it += nwave) {
+        const int j = it / 3, t3 = it - 3 * j, ti = t3 == 0 ? 0 : 1, tj = t3 == 2 ? 1 : 0;
+        double* dt = dtile + (((blk(j) / gm) & 3) * 3 + t3) * 256;
+        d4_t acc;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = dt[(kk + 4 * t) * 16 + mi];
+#pragma unroll
+        for (int qs = 0; qs < RSBA_PB; qs += 4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pan[(j * RSBA_PB + 16 * ti + mi) * RSBA_PLD + qs + kk], Pan[(j * RSBA_PB + 16 * tj + mi) * RSBA_PLD + qs + kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dt[(kk + 4 * t) * 16 + mi] = acc[t];
+      }
+      // the right-hand-side row (block np) leaves after panel np - 2, solved: rows_ready[np]
+      if (rhs_mine && p + 2 == np) PublishFlagWG(f.rows_ready + np, tag);
       else { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }
+      // progress: every X(., p) of this workgroup's blocks is in memory
+      if (tid == 0) __hip_atomic_store(f.error + 4 + w, (tag << 4) | (p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       RSBA_DC_STAMP(7);
     }
   }

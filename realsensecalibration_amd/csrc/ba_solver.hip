@@ -179,6 +179,7 @@ struct rsba_solver {
   int* mc_flags = nullptr;   // tdone[16] | strip_ready[16] | wg_done[8] | error
   int* tc_flags = nullptr;   // persistent tiled factorisation (more than 64 cameras): tdone[np] | xdone[np][nrt] | error
   int tc_np = 0, tc_nrt = 0, tc_tiles = 0;   // 0 tiles: the multi-launch path
+  double* mc_dg = nullptr;         // look-ahead sums and unsolved blocks handed over between the workgroups of k_reduced_system_solve_diag
   long long* mc_trace = nullptr;   // RSBA_MC_TRACE=1: stamps of the latest multi-workgroup factorisation
   hipStream_t sB = nullptr;
   // Multi-GPU pipeline: the stage flags the Cholesky waits on are published on the communication stream sR, each after
@@ -574,7 +575,7 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res, s->cam_free, s->mc_flags, s->tc_flags};
+                  s->block_part, s->small_red, s->gmax, s->res, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
@@ -792,7 +793,12 @@ static int UploadPoints(rsba_solver* s) {
       s->chol_wgs = std::min(want, RSBA_MC_MAXG);
       if ((rc = DevAlloc(&s->mc_flags, 64))) return rc;
       HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
-      s->chol_diag = !(getenv("RSBA_CHOL_DIAG") && atoi(getenv("RSBA_CHOL_DIAG")) == 0) && s->chol_wgs >= 2;   // RSBA_CHOL_DIAG=0: round-robin kernel
+      // RSBA_CHOL_DIAG=0: round-robin kernel.  A row workgroup of the diagonal-chain kernel keeps the look-ahead sums of at
+      // most four blocks
+      const int np_d = MultiCholPadded(s->nc) / RSBA_PB;
+      s->chol_diag = !(getenv("RSBA_CHOL_DIAG") && atoi(getenv("RSBA_CHOL_DIAG")) == 0) && s->chol_wgs >= 2 &&
+                     (np_d - 2 + s->chol_wgs - 2) / (s->chol_wgs - 1) <= 4;
+      if (s->chol_diag && (rc = DevAlloc(&s->mc_dg, (size_t)2 * (np_d + 1) * 1024))) return rc;   // look-ahead sums | blocks as handed over
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(DiagCholLdsDoubles(s->nc) * sizeof(double))));
       if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, RSBA_MC_MAXG * 16 * 8))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, RSBA_MC_MAXG * 16 * 8 * sizeof(long long))); }
@@ -999,7 +1005,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       k_reduced_system_solve_diag<<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
           StageGate{ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0},
-          DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48}, tag, s->mc_trace);
+          DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024}, tag, s->mc_trace);
     else if (s->chol_wgs > 1 && !mg)
       k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
@@ -1056,7 +1062,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (s->chol_wgs > 1 && !keep_system_copy && s->chol_diag)
       k_reduced_system_solve_diag<<<s->chol_wgs, 512, DiagCholLdsDoubles(s->nc) * sizeof(double), st>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
-          StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0}, DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48},
+          StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0}, DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024},
           s->step_tag, s->mc_trace);
     else if (s->chol_wgs > 1 && !keep_system_copy)
       k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(s->nc) * sizeof(double), st>>>(
