@@ -69,8 +69,8 @@ __host__ __device__ inline size_t DiagCholLdsDoubles(int nc) {
 //      p + 1 (half h, K slice [sa, sb) of whole 32-column slabs, <= 4; lane (mi, kk): row mi, columns 8 kk ..);
 //   3. waves 0, 1: X(p+1, p-1) -> xprev (LDS; the workgroup's wave 4 sends it to memory);
 //   4. the unit: acc = A[rows, slabs] B', the older slabs as they arrive; the six meet again, then the newest slab (p - 1) from
-//      xprev; acc is left at out (slice 0: subtracted from the panel rows, stride 33; slices 1, 2: a partial tile, stride 32);
-//      waves 2, 3, 4 also one tile each of X X' of the newest panel (what the look-ahead sum still lacks) into tprev's place;
+//      xprev; waves 2, 3, 4 also take one tile each of X X' of the newest panel (what the look-ahead sum still lacks)
+//      off pre_n; the three slices then subtract their products from the panel rows (out, stride 33) one after the other;
 //   5. barrier [A] of the whole workgroup (s_barrier: the other two waves are at theirs), then the slabs into the strip image.
 //
 // Out of line and static: its own register allocation instead of pushing the kernel's state into scratch (the reloads would land
@@ -80,12 +80,12 @@ typedef __attribute__((address_space(3))) int lds_int;
 // The routine's constants, in LDS (set once per launch): as arguments they would not fit the argument registers, and the
 // ones passed on the stack cost a scratch round trip at every entry.
 struct DiagConst {
-  const double* A; const double* S; const double* ah; const double* dg; const double* diag_u;
+  const double* A; const double* S; const double* ah; const double* dg; const double* diag_u; const double* gc; const double* corr;
   const int* rows_ready; const int* error; const int* gate_ready;
   long long budget, gate_budget;
   double min_diag, max_diag, inv_radius;
   int n, nreal, SLD, tag, gate_tag, gate_cols, gated;
-  lds_double* Bst; lds_double* tprev; lds_double* xprev; lds_double* scl;
+  lds_double* Bst; lds_double* t_tile[2]; lds_double* xprev; lds_double* scl;
   lds_int* s_wb; lds_int* ok_lds;
   long long* tr;
 };
@@ -94,10 +94,10 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
   const double* __restrict__ A = dc->A;
   const double* __restrict__ S = dc->S;
   const int n = dc->n, nreal = dc->nreal, SLD = dc->SLD, tag = dc->tag;
-  lds_double* Bst = dc->Bst; lds_double* tprev = dc->tprev; lds_double* xprev = dc->xprev; const lds_double* scl = dc->scl;
+  lds_double* Bst = dc->Bst; const lds_double* tprev = dc->t_tile[(p - 1) & 1]; lds_double* xprev = dc->xprev; const lds_double* scl = dc->scl;   // (T(p-1): the factorisation alternates between two tiles)
   lds_int* s_wb = dc->s_wb; lds_int* ok_lds = dc->ok_lds;
-  const int wb_target = 12 * (p - 1) + 6;
-  long long* tr = dc->tr ? dc->tr + (size_t)p * 8 : nullptr;
+  const int wb_target = 18 * (p - 1) + 6;
+  long long* tr = dc->tr ? dc->tr + (size_t)p * 8 : nullptr;   // (workgroup 0's stamps start at mtrace)
   const int lane = threadIdx.x & 63, mi = lane & 15, kk = lane >> 4, h = wk & 1;
   const int nb0 = kb + RSBA_PB;   // block p + 1's first row
   typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -111,14 +111,15 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   };
-  // 1. the block's flag (at the last panel: the right-hand-side row's, which still comes solved)
-  if (wk == 0 && lane == 0) {
+  // 1. the block's flag (at the last panel: the right-hand-side row's, which still comes solved), and the camera group of block
+  // p + 1's own columns of S (a stage of the Schur kernel; the row workgroups wait for it too).  Every wave looks for itself:
+  // normally both are up and nobody waits for anybody.
+  if (lane == 0) {
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(dc->rows_ready + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
       __builtin_amdgcn_s_sleep(2);
       if (__hip_atomic_load(dc->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > dc->budget) { __hip_atomic_store(ok_lds, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
     }
-    // ... and the camera group of block p + 1's own columns of S (a stage of the Schur kernel; the row workgroups wait for it too)
     if (do_unit && dc->gated && nb0 % dc->gate_cols == 0) {
       const long long t1 = wall_clock64();
       while (__hip_atomic_load(dc->gate_ready + 1 + nb0 / dc->gate_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != dc->gate_tag) {
@@ -127,10 +128,10 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
       }
     }
   }
-  meet(wb_target);
+  __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (tr && wk == 0 && lane == 0) tr[2] = wall_clock64();
-  if (!do_unit) { meet(wb_target + 6); return; }   // (the last panel: the caller goes on to the right-hand-side row, barrier [A] is his)
+  if (!do_unit) { meet(wb_target); meet(wb_target + 6); meet(wb_target + 12); return; }   // (the last panel: the caller goes on to the right-hand-side row, barrier [A] is his)
   // 2. everything in one round trip
   double pf[4][8], ax[8], sv8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ns[3] = {0.0, 0.0, 0.0}, ndd[3] = {0.0, 0.0, 0.0}, ndu = 0.0;
   const int sr = lane >> 2, sc0 = (lane & 3) * 8, sgi = nb0 + h * 16 + sr;
@@ -214,8 +215,8 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
   };
 #pragma unroll
   for (int i = 0; i < 4; ++i) if (sa + i < sb && sa + i < p - 1) slab_mfma(pf[i], (sa + i) * RSBA_PB);
-  // ... then, when X(p+1, p-1) is there (the second meeting), the newest one
-  meet(wb_target + 6);
+  // ... then, when X(p+1, p-1) is there (the first meeting), the newest one
+  meet(wb_target);
   if (tr && wk == 0 && lane == 0) tr[6] = wall_clock64();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -225,7 +226,8 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
       slab_mfma(pf[i], (sa + i) * RSBA_PB);
     }
   }
-  // X X' of the newest panel: tiles (0,0), (1,0), (1,1) by waves 2, 3, 4 into tprev's tile, 3 x 256 doubles
+  // X X' of the newest panel — what the look-ahead sum as handed over lacks: tiles (0,0), (1,0), (1,1) by waves 2, 3, 4, taken off
+  // pre_n (whose entries everybody wrote before the meeting); tile (1,0) also off its mirror
   if (wk >= 2 && wk <= 4) {
     const int t3 = wk - 2, ti = t3 == 0 ? 0 : 1, tj = t3 == 2 ? 1 : 0;
     d4_t xx = {0, 0, 0, 0};
@@ -233,14 +235,22 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
     for (int qs = 0; qs < RSBA_PB; qs += 4)
       xx = __builtin_amdgcn_mfma_f64_16x16x4f64(xprev[(16 * ti + mi) * SLD + qs + kk], xprev[(16 * tj + mi) * SLD + qs + kk], xx, 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) tprev[t3 * 256 + (kk + 4 * t) * 16 + mi] = xx[t];   // (tprev was last read in step 3: the second meeting since)
+    for (int t = 0; t < 4; ++t) {
+      const int r = 16 * ti + kk + 4 * t, c = 16 * tj + mi;
+      pre_n[r * RSBA_PLD + c] -= xx[t];
+      if (t3 == 1) pre_n[c * RSBA_PLD + r] -= xx[t];
+    }
   }
+  // the three slices' products leave one after the other, straight into the panel rows (slice 0 wrote S' there): S' - P0 - P1 - P2
+  // in this order, no partial tiles, nothing left to merge in the panel's tail
   const int ks = wk >> 1;
-  if (ks == 0) __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    if (ks == 0) { out[(kk + 4 * t) * RSBA_PLD + mi] -= a0[t]; out[(kk + 4 * t) * RSBA_PLD + 16 + mi] -= a1[t]; }
-    else { out[(kk + 4 * t) * 32 + mi] = a0[t]; out[(kk + 4 * t) * 32 + 16 + mi] = a1[t]; }
+  for (int s3 = 0; s3 < 3; ++s3) {
+    if (ks == s3) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { out[(kk + 4 * t) * RSBA_PLD + mi] -= a0[t]; out[(kk + 4 * t) * RSBA_PLD + 16 + mi] -= a1[t]; }
+    }
+    if (s3 < 2) meet(wb_target + 6 * (s3 + 1));
   }
   if (tr && wk == 0 && lane == 0) tr[3] = wall_clock64();
   // 5. [A]; then this wave's slabs of the rows of block p + 1 into the strip image of the next panel
@@ -250,6 +260,87 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
     if (sa + i < sb) {
 #pragma unroll
       for (int u = 0; u < 8; u += 2) { d2_t t; t[0] = pf[i][u]; t[1] = pf[i][u + 1]; *reinterpret_cast<lds_d2*>(Bst + (size_t)(h * 16 + mi) * SLD + (sa + i) * RSBA_PB + 8 * kk + u) = t; }
+    }
+  }
+}
+
+// A row workgroup's update unit: one 16-row half of block b (at the rows `rows` of the workgroup's panel block, stride 33): its
+// columns of panel p (scaled; the right-hand-side row, b = np: s (gc + corr)), minus A[rows, K slice ks of nsplit] Bst' (Bst: the
+// strip of block p, k-major, stride 33).  Slice 0 owns the rows, the others leave a 16 x 32 partial tile at pdst.  The whole
+// slice (up to four 32-column slabs of 8 doubles per lane) is fetched in ONE round trip, together with the entries of S — two
+// slabs at a time and refilled as they were consumed, the update took two to three round trips of 3.5 us beside the Schur
+// kernel.  Out of line and static for its registers (see DiagUpdateWave).
+static __device__ __noinline__ void RowUpdateHalf(lds_DiagConst* dc, int kb, int b, int half, int ks, int nsplit, const lds_double* Bst, lds_double* rows, lds_double* pdst) {
+  const double* __restrict__ A = dc->A;
+  const double* __restrict__ S = dc->S;
+  const int n = dc->n, nreal = dc->nreal;
+  const lds_double* scl = dc->scl;
+  const int lane = threadIdx.x & 63, mi = lane & 15, kk = lane >> 4;
+  const int sr = lane >> 2, sc0 = (lane & 3) * 8;
+  const int sgi = b * RSBA_PB + half * 16 + sr;
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (ks == 0) {
+    if (sgi < nreal) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) v[u] = S[(size_t)sgi * nreal + kb + sc0 + u];
+    } else if (sgi == n) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) { v[u] = dc->gc[kb + sc0 + u]; v2[u] = dc->corr[kb + sc0 + u]; }
+    }
+  }
+  const int nq = kb / RSBA_PB, qper = (nq + nsplit - 1) / nsplit;
+  const int qa = ks * qper * RSBA_PB, qb = min(kb, (ks + 1) * qper * RSBA_PB);
+  const int grow = b * RSBA_PB + half * 16 + mi;
+  const bool gl = grow <= n;
+  const double* arow = A + (size_t)(gl ? grow : 0) * n + 8 * kk;
+  d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  double buf[4][8];
+  auto fetch = [&](double (&d)[8], int q) {
+    const double2* pa = reinterpret_cast<const double2*>(arow + q);
+#pragma unroll
+    for (int v4 = 0; v4 < 4; ++v4) { const double2 t = pa[v4]; d[2 * v4] = gl ? t.x : 0.0; d[2 * v4 + 1] = gl ? t.y : 0.0; }
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (qa + i * RSBA_PB < qb) fetch(buf[i], qa + i * RSBA_PB);
+  if (ks == 0) {
+    const double si = sgi < nreal ? scl[sgi] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int gj = kb + sc0 + u;
+      double val = 0.0;
+      if (gj < nreal) val = sgi == n ? scl[gj] * (v[u] + v2[u]) : v[u] * (si * scl[gj]);
+      rows[sr * RSBA_PLD + sc0 + u] = val;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (kb == 0) return;
+  for (int qg = qa; qg < qb; qg += 4 * RSBA_PB) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q0 = qg + i * RSBA_PB;
+      if (q0 < qb) {
+        double ac[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ac[u] = buf[i][u];
+        if (q0 + 4 * RSBA_PB < qb) fetch(buf[i], q0 + 4 * RSBA_PB);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double b0 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + mi];
+          const double b1 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + 16 + mi];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b1, acc1, 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (ks == 0) {
+      rows[(kk + 4 * t) * RSBA_PLD + mi] -= acc0[t];
+      rows[(kk + 4 * t) * RSBA_PLD + 16 + mi] -= acc1[t];
+    } else {
+      pdst[(kk + 4 * t) * 32 + mi] = acc0[t];
+      pdst[(kk + 4 * t) * 32 + 16 + mi] = acc1[t];
     }
   }
 }
@@ -346,16 +437,16 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   };
   __shared__ DiagConst s_dc;
-  if (w == 0 && tid == 0) {
-    s_dc.A = A; s_dc.S = S; s_dc.ah = f.ah; s_dc.dg = f.dg; s_dc.diag_u = red + L.diagU();
+  if (tid == 0) {
+    s_dc.A = A; s_dc.S = S; s_dc.ah = f.ah; s_dc.dg = f.dg; s_dc.diag_u = red + L.diagU(); s_dc.gc = red + L.gc(); s_dc.corr = red + L.corr();
     s_dc.rows_ready = f.rows_ready; s_dc.error = f.error; s_dc.gate_ready = gate.ready;
     s_dc.budget = budget; s_dc.gate_budget = gate.budget;
     s_dc.min_diag = ip.min_lm_diagonal; s_dc.max_diag = ip.max_lm_diagonal; s_dc.inv_radius = inv_radius;
     s_dc.n = n; s_dc.nreal = nreal; s_dc.SLD = n - 30; s_dc.tag = tag; s_dc.gate_tag = gate.tag; s_dc.gate_cols = gate.cols;
     s_dc.gated = (gate.ready != nullptr && !ip.first) ? 1 : 0;
-    s_dc.Bst = (lds_double*)lds; s_dc.tprev = (lds_double*)Xl; s_dc.xprev = (lds_double*)(lds + (n - 30 - RSBA_PB)); s_dc.scl = (lds_double*)scl;
+    s_dc.Bst = (lds_double*)lds; s_dc.t_tile[0] = (lds_double*)T; s_dc.t_tile[1] = (lds_double*)(lds + (size_t)32 * (n - 30) + RSBA_PB * RSBA_PLD); s_dc.xprev = (lds_double*)(lds + (n - 30 - RSBA_PB)); s_dc.scl = (lds_double*)scl;
     s_dc.s_wb = (lds_int*)&s_wb; s_dc.ok_lds = (lds_int*)&s_w7ok;
-    s_dc.tr = mtrace;   // (workgroup 0's stamps start at mtrace)
+    s_dc.tr = mtrace;
   }
   __syncthreads();
   // a row workgroup's look-ahead tiles: 4 block slots x 3 tiles x 256 doubles where workgroup 0 keeps Pre / PreN / scratch
@@ -473,12 +564,11 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       // block: the strip is at most n - 64 columns wide then)
       double* xprev = Bst + (SLD - RSBA_PB);
       const bool unit_wave = wave != 0 && !idle4;
-      // partial tiles of the update (K slices 1 and 2 of three; slice 0 lands in the panel rows): slice 1 in the scratch
-      // area, slice 2 behind the panel block
-      double* part1 = scratch;
-      double* part2 = Pan + RSBA_PB * RSBA_PLD;
+      // T(p) goes into one of two tiles in turn (the second one behind the panel block): T(p-1) is still being used — X(p+1, p-1)
+      // is formed with it — while block p is factored
+      double* Tc = (p & 1) ? Pan + RSBA_PB * RSBA_PLD : T;
       if (wave == 0) {
-        if (!DiagFactorInverseCall((lds_double*)Pre, RSBA_PB, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane) && lane == 0) s_ok = 0;
+        if (!DiagFactorInverseCall((lds_double*)Pre, RSBA_PB, (lds_double*)Tc, (lds_double*)Lt, (lds_double*)invd, lane) && lane == 0) s_ok = 0;
         RSBA_DC_STAMP(1);
       } else if (!idle4) {
         // ---- waves 1, 2, 3, 5, 6, 7: strip of block p, then the columns of panel p in the rows of block p + 1: half h of the
@@ -489,7 +579,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         const bool unit = has_next && p > 0;
         if (p > 0) {
           DiagUpdateWave((lds_DiagConst*)&s_dc, kb, wk, sa, sb, p, unit ? 1 : 0,
-                         (lds_double*)(ks == 0 ? Pan + h * 16 * RSBA_PLD : (ks == 1 ? part1 : part2) + h * 512), (lds_double*)PreN);
+                         (lds_double*)(Pan + h * 16 * RSBA_PLD), (lds_double*)PreN);
           if (mtrace && tid == 64) mtrace[((size_t)w * 16 + p) * 8 + 3] = wall_clock64();   // wave 1's unit done
           if (!unit && wave == 1) {
             // the last panel: the right-hand-side row alone, rhs[kb + c] - sum_q L[n][q] L[kb + c][q]: one row, so no matrix
@@ -516,7 +606,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       }
       if (idle4 && has_next && p > 0) {
         // wave 4, the STORE wave: X(p+1, p-1) to memory as soon as the update waves have formed it (their third meeting)
-        if (lane == 0) { while (__hip_atomic_load(&s_wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 12 * p) __builtin_amdgcn_s_sleep(2); }
+        if (lane == 0) { while (__hip_atomic_load(&s_wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 18 * (p - 1) + 6) __builtin_amdgcn_s_sleep(2); }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll 2
@@ -526,59 +616,40 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       RSBA_DC_STAMP(4);
       if (!s_ok && tid == 0) __hip_atomic_store(chol_ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (s_w7ok == 0) { stalled = true; break; }
-      // slices 1 and 2 of the update in fixed order (slice 0 is in Pan)
-      if (has_next && p > 0) {
-        for (int e = tid; e < 2 * 512; e += nt) {
-          const int h = e >> 9, r = (e >> 5) & 15, c = e & 31;
-          Pan[(h * 16 + r) * RSBA_PLD + c] = (Pan[(h * 16 + r) * RSBA_PLD + c] - part1[h * 512 + r * 32 + c]) - part2[h * 512 + r * 32 + c];
-        }
+      // ---- the tail: two barriers.  The panel rows of block p + 1 are complete (DiagUpdateWave), PreN holds everything of the
+      // next diagonal block but this panel's X X' (panel 0: built here).
+      if (has_next && p == 0) {
+        for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) { const int r = e >> 5, c = e & 31; PreN[r * RSBA_PLD + c] = sys(nb0 + r, nb0 + c, Sat(nb0 + r, nb0 + c)); }
+        __syncthreads();
       }
-      // The next diagonal block: PreN holds S' minus the look-ahead sum as handed over (DiagUpdateWave); now minus X X' of the
-      // panel the block came without (its tiles are in Xl's place), at [D] minus this panel's.  Panel 0: S' alone, from here.
-      if (has_next) {
-        for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) {
-          const int r = e >> 5, c = e & 31;
-          if (p > 0) {
-            const int rr = max(r, c), cc = min(r, c), t3 = (rr >> 4) + (cc >> 4);
-            PreN[r * RSBA_PLD + c] -= (r >> 4) == (c >> 4) ? Xl[t3 * 256 + (r & 15) * 16 + (c & 15)] : Xl[256 + (rr & 15) * 16 + (cc & 15)];
-          } else {
-            PreN[r * RSBA_PLD + c] = sys(nb0 + r, nb0 + c, Sat(nb0 + r, nb0 + c));
-          }
-        }
+      // X = Rows T': block p + 1 (two halves, kept in Xl), or the rhs row at the last panel; meanwhile L11 / T leave through the
+      // store wave (it shares the factoring wave's SIMD and does nothing else): issued now, their acknowledgements awaited at
+      // the end of the panel — nobody on the chain waits for a store (a round trip costs 3.5 us beside the Schur kernel; the
+      // row workgroups need T(p) only after they have handed the next block over)
+      {
+        double* Tsave = T; T = Tc;   // (solve_half reads T)
+        if (has_next) { if (wave == 1 || wave == 2) solve_half(p + 1, 0, wave - 1, 3); }
+        else if (wave == 3) solve_half(np, 0, 0, 0);
+        T = Tsave;
       }
-      if (wave == 7) {
-        // L11 / T leave through ONE wave: it alone waits for their acknowledgements (below, after the next barrier) and
-        // publishes them — the row workgroups get T(p) while this workgroup is still busy with X.  AFTER the look-ahead
-        // values above: those come from global loads, and the s_waitcnt vmcnt(0) in front of their use would also wait
-        // for these stores' acknowledgements (gfx9 counts loads and stores in one counter)
-        for (int e = lane; e < RSBA_PB * RSBA_PB; e += 64) {
-          const int r = e >> 5, c = e & 31;
-          StoreShared(&A[(size_t)(kb + r) * n + kb + c], c > r ? T[c * RSBA_PLD + r] : Pre[r * RSBA_PLD + c]);
+      if (idle4) {
+#pragma unroll 2
+        for (int u = 0; u < 16; ++u) {
+          const int e = lane + 64 * u, r = e >> 5, c = e & 31;
+          StoreShared(&A[(size_t)(kb + r) * n + kb + c], c > r ? Tc[c * RSBA_PLD + r] : Pre[r * RSBA_PLD + c]);
         }
         if (lane < RSBA_PB) StoreShared(&A[(size_t)(n + 1) * n + kb + lane], invd[lane]);
       }
-      __syncthreads();   // [B] Pan complete, partial tiles consumed
-      // X = Rows T': block p + 1 (two halves, kept in Xl), or the rhs row at the last panel
-      if (has_next) { if (wave == 1 || wave == 2) solve_half(p + 1, 0, wave - 1, 3); }
-      else if (wave == 3) solve_half(np, 0, 0, 0);
-      if (wave == 7) {
-        // (publishing T only at the end of the panel takes this wait off the chain but delays the row workgroups, whose
-        //  last slab the next panel's update waits for: measured 0.475 against 0.466 ms per LM iteration)
-        __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0) __hip_atomic_store(f.tdone + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
       __syncthreads();   // [C] Xl
       if (has_next) {
-        // X X' (tiles by waves 1, 2, 3, 5) -> scratch; X(p+1, p) into the next strip's image, behind the columns the update waves
-        // left there (waves 0, 6, 7), and to memory (wave 4);
-        // then the next diagonal block
+        // X X' straight off PreN (tiles by waves 1, 2, 3, 5); X(p+1, p) into the next strip's image, behind the columns the update
+        // waves left there (waves 0, 6, 7), and to memory (wave 4)
         if (wave == 0 || wave >= 6) {
           for (int e = (wave == 0 ? 0 : wave - 5) * 64 + lane; e < RSBA_PB * RSBA_PB; e += 192) { const int r = e >> 5, c = e & 31; Bst[(size_t)r * SLD + kb + c] = Xl[r * RSBA_PLD + c]; }
         } else if (idle4) {
 #pragma unroll 2
           for (int u = 0; u < 16; ++u) { const int e = lane + 64 * u, r = e >> 5, c = e & 31; StoreShared(&A[(size_t)(nb0 + r) * n + kb + c], Xl[r * RSBA_PLD + c]); }
-        }
-        if (wave != 0 && wave != 4 && wave <= 5) {
+        } else {
           const int xt = wave < 4 ? wave - 1 : 3;
           const int ti = xt >> 1, tj = xt & 1;
           d4_t acc = {0, 0, 0, 0};
@@ -586,21 +657,18 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
           for (int qs = 0; qs < RSBA_PB; qs += 4)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xl[(16 * ti + mi) * RSBA_PLD + qs + kk], Xl[(16 * tj + mi) * RSBA_PLD + qs + kk], acc, 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) scratch[(16 * ti + kk + 4 * t) * 32 + 16 * tj + mi] = acc[t];
-        }
-        __syncthreads();   // [D]
-        for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) {
-          const int r = e >> 5, c = e & 31;
-          PreN[r * RSBA_PLD + c] -= scratch[r * 32 + c];
-          Xl[r * RSBA_PLD + c] = T[r * RSBA_PLD + c];   // T(p) for the next panel's X(p+2, p): the factorisation is about to overwrite its tile
+          for (int t = 0; t < 4; ++t) PreN[(16 * ti + kk + 4 * t) * RSBA_PLD + 16 * tj + mi] -= acc[t];
         }
         __syncthreads();   // [E] the next diagonal block is ready: wave 0 goes on
       }
-      // X(p+1, p-1) and X(p+1, p) are on their way to memory: wave 4 waits for the acknowledgements and tells the row workgroups;
+      // T(p), X(p+1, p-1) and X(p+1, p) are on their way to memory: wave 4 waits for the acknowledgements and tells the row workgroups;
       // nobody else does (this workgroup's next strip does not come from those stores)
-      if (idle4 && has_next) {
+      if (idle4) {
         __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0) __hip_atomic_store(f.strip_ready + p + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+          __hip_atomic_store(f.tdone + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (has_next) __hip_atomic_store(f.strip_ready + p + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       { double* t = Pre; Pre = PreN; PreN = t; }
       RSBA_DC_STAMP(7);
@@ -639,7 +707,8 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         double* part = T;   // T | Lt | Xl are idle before T(p) arrives: up to six 16 x 32 partial tiles
         for (int it = wave; it < nh * nsplit; it += nwave) {
           const int hb = it / nsplit, ks = it - hb * nsplit;
-          load_update_half(blk(hb >> 1), hb >> 1, hb & 1, ks, nsplit, part + (hb * (nsplit - 1) + ks - 1) * 512);
+          RowUpdateHalf((lds_DiagConst*)&s_dc, kb, blk(hb >> 1), hb & 1, ks, nsplit, (const lds_double*)Bst, (lds_double*)(Pan + ((hb >> 1) * RSBA_PB + (hb & 1) * 16) * RSBA_PLD),
+                        (lds_double*)(part + (hb * (nsplit - 1) + ks - 1) * 512));
         }
         __syncthreads();
         if (nsplit > 1) {

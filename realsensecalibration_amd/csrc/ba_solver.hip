@@ -609,6 +609,38 @@ static IterParams MakeIterParams(const rsba_options& o, double radius, bool firs
   return ip;
 }
 
+// The pipelined schedule needs the solver's two streams to run CONCURRENTLY: the factorisation, launched first on sB,
+// spins on flags of the Schur kernel behind it on the main stream.  HIP promises no such thing: streams are dealt onto a
+// few hardware queues, and two streams of one queue run one after the other (seen after stream churn: 1 solver lifetime in
+// ~100 at 64 cameras, more at 33) — the factorisation then waits out its stall budget (0.5 s) before the solver falls back
+// to the sequential schedule.  So ask once, at set-up: a waiter on sB and the setter of its flag behind it on the main stream.
+__global__ void k_probe_wait(int* flag, long long budget_ticks, int* seen) {
+  const long long t0 = wall_clock64();
+  int ok = 0;
+  while (wall_clock64() - t0 < budget_ticks) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) { ok = 1; break; }
+    __builtin_amdgcn_s_sleep(16);
+  }
+  *seen = ok;
+}
+__global__ void k_probe_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// true: a kernel on `main` starts while one on `side` is running
+static bool StreamsRunConcurrently(hipStream_t side, hipStream_t main) {
+  int* d = nullptr;
+  if (hipMalloc((void**)&d, 2 * sizeof(int)) != hipSuccess) return false;
+  int seen = 0;
+  bool ok = hipMemset(d, 0, 2 * sizeof(int)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  if (ok) {
+    k_probe_wait<<<1, 1, 0, side>>>(d, 200000 /* 2 ms */, d + 1);
+    k_probe_set<<<1, 1, 0, main>>>(d);
+    ok = hipStreamSynchronize(side) == hipSuccess && hipStreamSynchronize(main) == hipSuccess &&
+         hipMemcpy(&seen, d + 1, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  (void)hipFree(d);
+  return ok && seen == 1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Upload of the point model: observations are re-ordered by (point, camera) so that one point's
 // records are contiguous; the permutation is kept so nothing the caller sees changes order.
@@ -634,8 +666,17 @@ static bool SetupPipeline(rsba_solver* s) {
   const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
   std::vector<uint32_t> mask(words, mode == 2 ? 0xffffffffu : 0u);
   if (mode != 2) mask[0] = 1u;
-  bool ok = hipExtStreamCreateWithCUMask(&s->sB, words, mask.data()) == hipSuccess &&
-            hipMalloc((void**)&s->chol_waited, 2 * sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, 2 * sizeof(long long)) == hipSuccess;
+  // (a few attempts: every new stream is dealt onto the next hardware queue)
+  bool ok = false;
+  std::vector<hipStream_t> rejected;
+  for (int attempt = 0; attempt < 4 && !ok; ++attempt) {
+    if (hipExtStreamCreateWithCUMask(&s->sB, words, mask.data()) != hipSuccess) { s->sB = nullptr; break; }
+    ok = StreamsRunConcurrently(s->sB, s->stream);
+    if (!ok) { rejected.push_back(s->sB); s->sB = nullptr; }
+  }
+  for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+  if (!ok && getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: the side stream does not run beside the main stream, solve not pipelined\n");
+  ok = ok && hipMalloc((void**)&s->chol_waited, 2 * sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, 2 * sizeof(long long)) == hipSuccess;
   if (ok && mg) {
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
