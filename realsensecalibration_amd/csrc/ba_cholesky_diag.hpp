@@ -269,8 +269,10 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
 // strip of block p, k-major, stride 33).  Slice 0 owns the rows, the others leave a 16 x 32 partial tile at pdst.  The whole
 // slice (up to four 32-column slabs of 8 doubles per lane) is fetched in ONE round trip, together with the entries of S — two
 // slabs at a time and refilled as they were consumed, the update took two to three round trips of 3.5 us beside the Schur
-// kernel.  Out of line and static for its registers (see DiagUpdateWave).
-static __device__ __noinline__ void RowUpdateHalf(lds_DiagConst* dc, int kb, int b, int half, int ks, int nsplit, const lds_double* Bst, lds_double* rows, lds_double* pdst) {
+// kernel — and with this thread's share of the STRIP (every wave of the workgroup calls, with or without a unit; the barrier
+// behind the strip is inside): as a phase of its own in front of the units the strip cost another round trip.  Out of line and
+// static for its registers (see DiagUpdateWave).
+static __device__ __noinline__ void RowUpdateHalf(lds_DiagConst* dc, int kb, int do_strip, int has_unit, int b, int half, int ks, int nsplit, lds_double* Bst, lds_double* rows, lds_double* pdst) {
   const double* __restrict__ A = dc->A;
   const double* __restrict__ S = dc->S;
   const int n = dc->n, nreal = dc->nreal;
@@ -278,8 +280,25 @@ static __device__ __noinline__ void RowUpdateHalf(lds_DiagConst* dc, int kb, int
   const int lane = threadIdx.x & 63, mi = lane & 15, kk = lane >> 4;
   const int sr = lane >> 2, sc0 = (lane & 3) * 8;
   const int sgi = b * RSBA_PB + half * 16 + sr;
+  // the strip of block p straight into LDS (global_load_lds, no registers; as inline assembly, see DiagUpdateWave... the compiler
+  // must not know): the image of its 32 rows, kb + 2 doubles apart — one wave instruction = 64 lanes x 16 bytes = 128 doubles of
+  // ONE row; the two doubles of padding shift consecutive rows by 16 bytes, so the ds_read_b128 of the sixteen rows of a B tile
+  // do not meet in a bank.  Rows wave, wave + 8, ...  First in the queue: the loads return in order.
+  const int sld = kb + 2;
+  if (do_strip) {
+    for (int r = threadIdx.x >> 6; r < RSBA_PB; r += 8) {
+      for (int c0 = 0; c0 < kb; c0 += 128) {
+        if (c0 + 2 * lane < kb) {
+          const double* gsrc = A + (size_t)(kb + r) * n + c0 + 2 * lane;
+          const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(Bst + (size_t)r * sld + c0));
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+        }
+      }
+    }
+  }
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (ks == 0) {
+  if (has_unit && ks == 0) {
     if (sgi < nreal) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) v[u] = S[(size_t)sgi * nreal + kb + sc0 + u];
@@ -300,8 +319,13 @@ static __device__ __noinline__ void RowUpdateHalf(lds_DiagConst* dc, int kb, int
 #pragma unroll
     for (int v4 = 0; v4 < 4; ++v4) { const double2 t = pa[v4]; d[2 * v4] = gl ? t.x : 0.0; d[2 * v4 + 1] = gl ? t.y : 0.0; }
   };
+  if (has_unit) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) if (qa + i * RSBA_PB < qb) fetch(buf[i], qa + i * RSBA_PB);
+    for (int i = 0; i < 4; ++i) if (qa + i * RSBA_PB < qb) fetch(buf[i], qa + i * RSBA_PB);
+  }
+  if (do_strip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the strip has landed (the compiler does not count its loads)
+  if (do_strip) __syncthreads();
+  if (!has_unit) return;
   if (ks == 0) {
     const double si = sgi < nreal ? scl[sgi] : 0.0;
 #pragma unroll
@@ -323,12 +347,19 @@ static __device__ __noinline__ void RowUpdateHalf(lds_DiagConst* dc, int kb, int
 #pragma unroll
         for (int u = 0; u < 8; ++u) ac[u] = buf[i][u];
         if (q0 + 4 * RSBA_PB < qb) fetch(buf[i], q0 + 4 * RSBA_PB);
+        {
+          // B[k][j] = L[kb + j][k]: lane (mi, kk) takes the eight k = q0 + 8 kk + u of strip rows mi and 16 + mi in four 16-byte reads each
+          typedef double d2_t __attribute__((ext_vector_type(2)));
+          typedef __attribute__((address_space(3))) const d2_t lds_cd2;
+          double bb[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const double b0 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + mi];
-          const double b1 = Bst[(q0 + 8 * kk + u) * RSBA_PLD + 16 + mi];
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], b1, acc1, 0, 0, 0);
+          for (int u = 0; u < 8; u += 2) { const d2_t t0 = *reinterpret_cast<lds_cd2*>(Bst + (size_t)mi * sld + 8 * kk + q0 + u); bb[u] = t0[0]; bb[u + 1] = t0[1]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], bb[u], acc0, 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 8; u += 2) { const d2_t t1 = *reinterpret_cast<lds_cd2*>(Bst + (size_t)(16 + mi) * sld + 8 * kk + q0 + u); bb[u] = t1[0]; bb[u + 1] = t1[1]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[u], bb[u], acc1, 0, 0, 0);
         }
       }
     }
@@ -457,13 +488,13 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   for (int p = 0; p < np && !stalled; ++p) {
     const int kb = p * RSBA_PB;
     RSBA_DC_STAMP(0);
-    // LDS below T.  A row workgroup: strip of block p, k-major with stride 33 (Bst), then its blocks of the panel.  The diagonal
-    // workgroup: strip of block p as the image of its rows, 32 x SLD doubles (see DiagUpdateWave; the two doubles of padding shift
+    // LDS below T.  A row workgroup: strip of block p as the image of its rows, 32 x (kb + 2) doubles (RowUpdateHalf), then its
+    // blocks of the panel.  The diagonal workgroup: the same image, 32 x SLD doubles (see DiagUpdateWave; the two doubles of padding shift
     // consecutive rows by 16 bytes, so the ds_read_b128 of the sixteen rows of a B tile do not meet in a bank), then the panel
     // block of the next rows and the partial tiles of K slice 2:  32 (n - 30) + 1056 + 1024 <= 33 (n + 32).
     const int SLD = n - 30;
     double* Bst = lds;
-    double* Pan = w == 0 ? lds + (size_t)32 * SLD : lds + (size_t)kb * RSBA_PLD;
+    double* Pan = w == 0 ? lds + (size_t)32 * SLD : lds + (size_t)32 * (kb + 2);
     // One 16-row half of a block b in slot j: its columns of the panel (scaled, damped) into Pan, minus A[rows, 0:kb] Bst'
     // over K slice ks of nsplit (slice 0 owns the rows in Pan, the others leave 16 x 32 partial tiles at pdst).
     auto load_update_half = [&](int b, int j, int half, int ks, int nsplit, double* pdst) {
@@ -686,14 +717,6 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       if (p > 0) {
         if (!WaitFlagWG(f.strip_ready + p, tag, f.error, budget)) { stalled = true; break; }
         RSBA_DC_STAMP(2);
-        for (int e = tid; e < (kb >> 2) * RSBA_PB; e += nt) {
-          const int c = e / (kb >> 2), q0 = (e - c * (kb >> 2)) * 4;
-          const double* lrow = A + (size_t)(kb + c) * n + q0;
-          const double2 a01 = *reinterpret_cast<const double2*>(lrow), a23 = *reinterpret_cast<const double2*>(lrow + 2);
-          Bst[(q0 + 0) * RSBA_PLD + c] = a01.x; Bst[(q0 + 1) * RSBA_PLD + c] = a01.y;
-          Bst[(q0 + 2) * RSBA_PLD + c] = a23.x; Bst[(q0 + 3) * RSBA_PLD + c] = a23.y;
-        }
-        __syncthreads();
       } else {
         // the look-ahead sums start at zero
         for (int e = tid; e < 12 * 256; e += nt) dtile[e] = 0.0;
@@ -705,9 +728,11 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       {
         const int nsplit = (p > 0 && nh <= 2) ? 4 : ((p > 0 && nh <= 4) ? 2 : 1);
         double* part = T;   // T | Lt | Xl are idle before T(p) arrives: up to six 16 x 32 partial tiles
-        for (int it = wave; it < nh * nsplit; it += nwave) {
-          const int hb = it / nsplit, ks = it - hb * nsplit;
-          RowUpdateHalf((lds_DiagConst*)&s_dc, kb, blk(hb >> 1), hb & 1, ks, nsplit, (const lds_double*)Bst, (lds_double*)(Pan + ((hb >> 1) * RSBA_PB + (hb & 1) * 16) * RSBA_PLD),
+        // (normally at most eight units, one per wave; every wave calls once with the strip's load and its barrier in there)
+        for (int it = wave, first_call = 1; first_call || it < nh * nsplit; it += nwave, first_call = 0) {
+          const int has_unit = it < nh * nsplit ? 1 : 0;
+          const int hb = has_unit ? it / nsplit : 0, ks = has_unit ? it - hb * nsplit : 0;
+          RowUpdateHalf((lds_DiagConst*)&s_dc, kb, first_call, has_unit, blk(hb >> 1), hb & 1, ks, nsplit, (lds_double*)Bst, (lds_double*)(Pan + ((hb >> 1) * RSBA_PB + (hb & 1) * 16) * RSBA_PLD),
                         (lds_double*)(part + (hb * (nsplit - 1) + ks - 1) * 512));
         }
         __syncthreads();
