@@ -388,7 +388,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   const int G = gridDim.x, w = blockIdx.x;
   const int np = n / RSBA_PB;              // column panels; blocks 0 .. np (block np: the rhs row alone, workgroup 0's)
   const long long budget = gate.budget > 0 ? gate.budget : RSBA_STALL_TICKS;
-  __shared__ int s_ok, s_wb, s_w7ok;
+  __shared__ int s_ok, s_wb, s_w7ok, s_fdone;
   int wb_gen = 0;
   // LDS: strip (32 p rows of 33) | this workgroup's blocks of the panel (32 x 33 each) | T | Lt | Xl | invd | scale | Pre | Pre2 | scratch
   const int max_rows = n + RSBA_PB;
@@ -402,7 +402,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   double* scratch = PreB + RSBA_PB * RSBA_PLD;     // 1024 doubles
   double* Pre = PreA;        // the diagonal block being factored
   double* PreN = PreB;       // the next one, built during this panel
-  if (tid == 0) { s_ok = 1; s_wb = 0; s_w7ok = 1; }
+  if (tid == 0) { s_ok = 1; s_wb = 0; s_w7ok = 1; s_fdone = 0; }
   if (gate.trace && tid == 0 && w == 0) gate.trace[0] = wall_clock64();
   bool stalled = false;
   const double* S = red + L.S();
@@ -600,6 +600,8 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       double* Tc = (p & 1) ? Pan + RSBA_PB * RSBA_PLD : T;
       if (wave == 0) {
         if (!DiagFactorInverseCall((lds_double*)Pre, RSBA_PB, (lds_double*)Tc, (lds_double*)Lt, (lds_double*)invd, lane) && lane == 0) s_ok = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&s_fdone, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // wave 4 sends T on its way at once
         RSBA_DC_STAMP(1);
       } else if (!idle4) {
         // ---- waves 1, 2, 3, 5, 6, 7: strip of block p, then the columns of panel p in the rows of block p + 1: half h of the
@@ -635,8 +637,23 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
           load_update_half(np, 0, 0, 0, 1, nullptr);
         }
       }
+      if (idle4) {
+        // wave 4, the STORE wave (it shares the factoring wave's SIMD and does nothing else): L11 / T as soon as the factorisation
+        // is through — the row workgroups' next panel hangs on T(p), and it used to leave only in the panel's tail — their
+        // acknowledgements awaited right behind [A]; nobody on the chain waits for a store (a round trip costs 3.5 us beside the
+        // Schur kernel)
+        if (lane == 0) { while (__hip_atomic_load(&s_fdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < p + 1) __builtin_amdgcn_s_sleep(4); }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 2
+        for (int u = 0; u < 16; ++u) {
+          const int e = lane + 64 * u, r = e >> 5, c = e & 31;
+          StoreShared(&A[(size_t)(kb + r) * n + kb + c], c > r ? Tc[c * RSBA_PLD + r] : Pre[r * RSBA_PLD + c]);
+        }
+        if (lane < RSBA_PB) StoreShared(&A[(size_t)(n + 1) * n + kb + lane], invd[lane]);
+      }
       if (idle4 && has_next && p > 0) {
-        // wave 4, the STORE wave: X(p+1, p-1) to memory as soon as the update waves have formed it (their third meeting)
+        // ... and X(p+1, p-1) as soon as the update waves have formed it (their first meeting)
         if (lane == 0) { while (__hip_atomic_load(&s_wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 18 * (p - 1) + 6) __builtin_amdgcn_s_sleep(2); }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -653,10 +670,8 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) { const int r = e >> 5, c = e & 31; PreN[r * RSBA_PLD + c] = sys(nb0 + r, nb0 + c, Sat(nb0 + r, nb0 + c)); }
         __syncthreads();
       }
-      // X = Rows T': block p + 1 (two halves, kept in Xl), or the rhs row at the last panel; meanwhile L11 / T leave through the
-      // store wave (it shares the factoring wave's SIMD and does nothing else): issued now, their acknowledgements awaited at
-      // the end of the panel — nobody on the chain waits for a store (a round trip costs 3.5 us beside the Schur kernel; the
-      // row workgroups need T(p) only after they have handed the next block over)
+      // X = Rows T': block p + 1 (two halves, kept in Xl), or the rhs row at the last panel; meanwhile wave 4 waits for the
+      // acknowledgements of L11 / T (on their way since the factorisation ended) and publishes them
       {
         double* Tsave = T; T = Tc;   // (solve_half reads T)
         if (has_next) { if (wave == 1 || wave == 2) solve_half(p + 1, 0, wave - 1, 3); }
@@ -664,12 +679,8 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         T = Tsave;
       }
       if (idle4) {
-#pragma unroll 2
-        for (int u = 0; u < 16; ++u) {
-          const int e = lane + 64 * u, r = e >> 5, c = e & 31;
-          StoreShared(&A[(size_t)(kb + r) * n + kb + c], c > r ? Tc[c * RSBA_PLD + r] : Pre[r * RSBA_PLD + c]);
-        }
-        if (lane < RSBA_PB) StoreShared(&A[(size_t)(n + 1) * n + kb + lane], invd[lane]);
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) __hip_atomic_store(f.tdone + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();   // [C] Xl
       if (has_next) {
@@ -692,14 +703,11 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         }
         __syncthreads();   // [E] the next diagonal block is ready: wave 0 goes on
       }
-      // T(p), X(p+1, p-1) and X(p+1, p) are on their way to memory: wave 4 waits for the acknowledgements and tells the row workgroups;
+      // X(p+1, p) is on its way to memory: wave 4 waits for the acknowledgements and tells the row workgroups;
       // nobody else does (this workgroup's next strip does not come from those stores)
       if (idle4) {
         __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0) {
-          __hip_atomic_store(f.tdone + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (has_next) __hip_atomic_store(f.strip_ready + p + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (lane == 0 && has_next) __hip_atomic_store(f.strip_ready + p + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       { double* t = Pre; Pre = PreN; PreN = t; }
       RSBA_DC_STAMP(7);
@@ -751,15 +759,20 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       // rows), with its look-ahead sum through panel p - 1.  The diagonal workgroup solves it with its own T(p) (see
       // DiagUpdateWave); the rows' columns < 32 p have been in memory since the last panel.
       const bool lv = nfull > 0 && first == p + 2;
-      if (lv) {
-        for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) StoreShared(&f.ah[(size_t)(p + 2) * 1024 + e], Pan[(e >> 5) * RSBA_PLD + (e & 31)]);
+      if (lv && wave == nwave - 1) {
+        // (one wave stores, waits for the acknowledgements and publishes; the others go on to T(p) — the wait for the stores would
+        //  cost everybody a round trip, and the last wave never has a half to solve in a panel that hands a block over)
+#pragma unroll 2
+        for (int u = 0; u < 16; ++u) { const int e = lane + 64 * u; StoreShared(&f.ah[(size_t)(p + 2) * 1024 + e], Pan[(e >> 5) * RSBA_PLD + (e & 31)]); }
         const double* dt = dtile + (((p + 2) / gm) & 3) * 3 * 256;
-        for (int e = tid; e < 3 * 256; e += nt) {
-          const int t3 = e >> 8, r = (e >> 4) & 15, c = e & 15, ti = t3 == 0 ? 0 : 1, tj = t3 == 2 ? 1 : 0;
+#pragma unroll 2
+        for (int u = 0; u < 12; ++u) {
+          const int e = lane + 64 * u, t3 = e >> 8, r = (e >> 4) & 15, c = e & 15, ti = t3 == 0 ? 0 : 1, tj = t3 == 2 ? 1 : 0;
           StoreShared(&f.dg[(size_t)(p + 2) * 1024 + (16 * ti + r) * 32 + 16 * tj + c], dt[e]);
           if (t3 == 1) StoreShared(&f.dg[(size_t)(p + 2) * 1024 + c * 32 + 16 + r], dt[e]);   // the mirror of tile (1, 0): the reader takes whole rows
         }
-        PublishFlagWG(f.rows_ready + p + 2, tag);
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) __hip_atomic_store(f.rows_ready + p + 2, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (nh == (lv ? 2 : 0)) {   // nothing left to solve in this panel
         if (tid == 0) __hip_atomic_store(f.error + 4 + w, (tag << 4) | (p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -645,10 +645,14 @@ static bool StreamsRunConcurrently(hipStream_t side, hipStream_t main) {
 // Upload of the point model: observations are re-ordered by (point, camera) so that one point's
 // records are contiguous; the permutation is kept so nothing the caller sees changes order.
 // ------------------------------------------------------------------------------------------------
-// Streams and events of the pipelined solve.  The Cholesky stream is created with a CU mask: that gives it a hardware
-// queue of its own (a waiting kernel must never sit in front of its producers in a shared queue) and one CU that the
-// chip-filling kernels launched after it cannot take (without the reservation a one-workgroup kernel that needs a whole
-// CU was measured to start 4.5 ms late).  RSBA_PIPELINE=0 switches the pipeline off, =2 gives sB all CUs.
+// Streams and events of the pipelined solve.  The Cholesky stream is created with a CU mask — of ALL CUs: what it buys is a
+// hardware queue of its own (a waiting kernel must never sit in front of its producers in a shared queue; probed below).
+// Round 1 masked it down to bit 0 (one CU per XCD) "to reserve a CU"; a mask reserves nothing — the main stream's kernels
+// run on those CUs too — and it has a failure mode: when one of the eight CUs is still busy at dispatch, that workgroup of
+// the factorisation waits, the Schur kernel keeps the CU full, and the back-substitution launched behind it fills it with
+// workgroups that spin on the factorisation's flag — which now can never start.  Seen as 8-14 stalls (0.5 s each, then the
+// sequential schedule for good) per 60 solver lifetimes at 33 cameras, none with the full mask, same speed at 64 cameras.
+// RSBA_PIPELINE=0 switches the pipeline off, =3 restores the one-bit mask.
 static bool SetupPipeline(rsba_solver* s) {
   const char* env = getenv("RSBA_PIPELINE");
   const int mode = env ? atoi(env) : 1;
@@ -664,8 +668,8 @@ static bool SetupPipeline(rsba_solver* s) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) return false;
   const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
-  std::vector<uint32_t> mask(words, mode == 2 ? 0xffffffffu : 0u);
-  if (mode != 2) mask[0] = 1u;
+  std::vector<uint32_t> mask(words, mode == 3 ? 0u : 0xffffffffu);
+  if (mode == 3) mask[0] = 1u;
   // (a few attempts: every new stream is dealt onto the next hardware queue)
   bool ok = false;
   std::vector<hipStream_t> rejected;
