@@ -10,16 +10,24 @@
 //     Wave 4 shares wave 0's SIMD and stays out of everything between two factorisations: fp64 MFMAs run on the SIMD's fp64
 //     vector lanes on this chip, and a wave issuing them back to back slows its SIMD partner down 14-fold
 //     (tools/factor_bench.hip) — for the same reason nothing but MFMA work runs beside the update waves.
-//   * workgroups 1 .. G-1 own the rows BELOW: block b belongs to workgroup 1 + b mod (G - 1) for the panels p <= b - 2;
-//     they receive the strip of block p and T(p) through global memory (flags strip_ready / tdone) one hop behind the
-//     diagonal, store their X, and hand block b over (flag rows_ready[b]) after panel b - 2.  With X(b, p) at hand they
-//     also add X X' to the block's LOOK-AHEAD SUM  sum_{q <= b-2} X(b, q) X(b, q)'  (three 16 x 16 tiles per block, kept in
-//     LDS) and hand it over with the block: workgroup 0 subtracts it from S(b, b) and only adds the last panel's X X'
-//     itself — it used to stream the block's rows a second time for it, 43 % of its matrix-core work.
-//   * the right-hand-side row is block np (one row): a row workgroup's like any other until panel np - 2, workgroup 0's at
-//     the last panel.
+//   * workgroups 1 .. G-1 own the rows BELOW: block b belongs to workgroup 1 + b mod (G - 1) for the panels p <= b - 2.  Per
+//     panel: the strip of block p (flag strip_ready, LDS-DMA) and the update of their blocks' columns of the panel in one
+//     round trip (RowUpdateHalf); the block that leaves (b = p + 2) is handed over RIGHT THEN — unsolved, with its look-ahead
+//     sum  sum_{q <= b-3} X(b, q) X(b, q)'  (three 16 x 16 tiles per block, kept in LDS), flag rows_ready[b], through one store
+//     wave — and workgroup 0 forms X(b, b-2) with the T(b-2) it still has in LDS; for the others they wait for T(p) (flag
+//     tdone), solve X = Rows T', store it and add X X' to the blocks' sums.  Workgroup 0 therefore never waits for an X that
+//     needs its own T to come back first, and only adds the last two panels' X X' to a diagonal block itself — it used to
+//     stream the block's rows a second time for the whole sum, 43 % of its matrix-core work.
+//   * the right-hand-side row is block np (one row): a row workgroup's like any other until panel np - 2 (handed over solved:
+//     rows_ready[np]), workgroup 0's at the last panel.
+//   * stores are wave 4's business in workgroup 0 (L11 / T the moment the block is factored, the two newest X blocks, their
+//     acknowledgements, the flags tdone and strip_ready); nobody on the chain waits for a store.
 //
-// STATUS (round 2): the default for 32 to 64 cameras (RSBA_CHOL_DIAG=0 selects the round-robin kernel).
+// STATUS (round 2): the default for 32 to 64 cameras (RSBA_CHOL_DIAG=0 selects the round-robin kernel): 0.470 against 0.479 ms
+// per LM iteration at 64 cameras, 199 against 221 us alone.  A panel of workgroup 0 takes 11 - 13 us when the next block is
+// there (factorisation 6.3, update waves' data 4 - 5 us after they ask + 2 - 4 us of matrix cores, tail 2.2), but the row
+// workgroups need 13 - 15 us per panel (every global round trip costs 2.3 - 8 us beside the Schur kernel), so it waits for
+// rows_ready in about half of the panels.  DESIGN.md section 4, "round 2", item 5 has the measurements and what was dropped.
 //
 // Same arithmetic per entry as the multi kernel's (products over fixed K slices, added in a fixed order): bitwise
 // reproducible, identical on every rank.  All waits carry a budget: a stall gives up (RES_STALL), never hangs.
@@ -37,11 +45,8 @@ struct DiagCholFlags {
   double* ah;         // [np + 1][32 * 32] the blocks as handed over: updated through their second-last panel, unsolved
 };
 
-#ifndef RSBA_DC_NPF
-#define RSBA_DC_NPF 1   // 32-column slabs per operand stream in flight in the cross-tile waves (twice as many in the row waves)
-#endif
 #ifndef RSBA_DC_UPD_NPF
-#define RSBA_DC_UPD_NPF 2   // ... in the plain row update (row workgroups, right-hand-side row)
+#define RSBA_DC_UPD_NPF 2   // 32-column slabs in flight in load_update_half (panel 0 only: nothing to subtract there yet)
 #endif
 
 __host__ __device__ inline size_t DiagCholLdsDoubles(int nc) {
