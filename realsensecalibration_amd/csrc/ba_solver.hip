@@ -832,21 +832,25 @@ static int UploadPoints(rsba_solver* s) {
   }
   {
     // several workgroups for the reduced system: 32 to 64 cameras (padded to whole 32-wide panels), full symmetric S
+    // (the diagonal-chain kernel, one workgroup for the diagonal + five for the rows below by default: 0.469 against 0.474 ms per
+    //  LM iteration with three row workgroups — fewer blocks per workgroup, more K slices per block; up to 8; the round-robin kernel
+    //  RSBA_CHOL_DIAG=0: four, up to RSBA_MC_MAXG)
     const char* e = getenv("RSBA_CHOL_WGS");
-    const int want = e ? atoi(e) : 4;
+    const bool want_diag = !(getenv("RSBA_CHOL_DIAG") && atoi(getenv("RSBA_CHOL_DIAG")) == 0);
+    const int want = e ? atoi(e) : (want_diag ? 6 : 4);
     if (want > 1 && s->opt.schur_impl != 0 && s->nc >= 6 * RSBA_PB && s->nc <= RSBA_CHOL_MAXN && !s->pipelined_mg) {
-      s->chol_wgs = std::min(want, RSBA_MC_MAXG);
+      s->chol_wgs = std::min(want, want_diag ? 8 : RSBA_MC_MAXG);
       if ((rc = DevAlloc(&s->mc_flags, 64))) return rc;
       HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
       // RSBA_CHOL_DIAG=0: round-robin kernel.  A row workgroup of the diagonal-chain kernel keeps the look-ahead sums of at
       // most four blocks
       const int np_d = MultiCholPadded(s->nc) / RSBA_PB;
-      s->chol_diag = !(getenv("RSBA_CHOL_DIAG") && atoi(getenv("RSBA_CHOL_DIAG")) == 0) && s->chol_wgs >= 2 &&
-                     (np_d - 2 + s->chol_wgs - 2) / (s->chol_wgs - 1) <= 4;
+      s->chol_diag = want_diag && s->chol_wgs >= 2 && (np_d - 2 + s->chol_wgs - 2) / (s->chol_wgs - 1) <= 4;
+      if (!s->chol_diag) s->chol_wgs = std::min(s->chol_wgs, RSBA_MC_MAXG);
       if (s->chol_diag && (rc = DevAlloc(&s->mc_dg, (size_t)2 * (np_d + 1) * 1024))) return rc;   // look-ahead sums | blocks as handed over
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(DiagCholLdsDoubles(s->nc) * sizeof(double))));
-      if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, RSBA_MC_MAXG * 16 * 8))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, RSBA_MC_MAXG * 16 * 8 * sizeof(long long))); }
+      if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, 8 * 16 * 8))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, 8 * 16 * 8 * sizeof(long long))); }
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(MultiCholLdsDoubles(s->nc) * sizeof(double))));
     }
@@ -1692,7 +1696,7 @@ int rsba_solver_final_costs(const rsba_solver* s, double* cost, double* sum_sq) 
 void rsba_solver_destroy(rsba_solver* s) {
   if (s && s->mc_trace) {
     // diagnostic: per workgroup and panel, microseconds since the kernel's first stamp
-    std::vector<long long> h(RSBA_MC_MAXG * 16 * 8);
+    std::vector<long long> h(8 * 16 * 8);
     if (hipMemcpy(h.data(), s->mc_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
       long long t0 = 0; for (long long v : h) if (v && (!t0 || v < t0)) t0 = v;
       for (int w = 0; w < s->chol_wgs; ++w) for (int p = 0; p < s->nc / 32; ++p) {
