@@ -23,8 +23,8 @@
 //   * stores are wave 4's business in workgroup 0 (L11 / T the moment the block is factored, the two newest X blocks, their
 //     acknowledgements, the flags tdone and strip_ready); nobody on the chain waits for a store.
 //
-// STATUS (round 2): the default for 32 to 64 cameras (RSBA_CHOL_DIAG=0 selects the round-robin kernel): 0.470 against 0.479 ms
-// per LM iteration at 64 cameras, 199 against 221 us alone.  A panel of workgroup 0 takes 11 - 13 us when the next block is
+// STATUS (round 2): the default for 32 to 64 cameras, on six workgroups (RSBA_CHOL_DIAG=0 selects the round-robin kernel):
+// 0.465 - 0.470 against 0.479 ms per LM iteration at 64 cameras, 184 against 221 us alone.  A panel of workgroup 0 takes 11 - 13 us when the next block is
 // there (factorisation 6.3, update waves' data 4 - 5 us after they ask + 2 - 4 us of matrix cores, tail 2.2), but the row
 // workgroups need 13 - 15 us per panel (every global round trip costs 2.3 - 8 us beside the Schur kernel), so it waits for
 // rows_ready in about half of the panels.  DESIGN.md section 4, "round 2", item 5 has the measurements and what was dropped.

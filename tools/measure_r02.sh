@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 python bench.py > gpurun_out/r02_bench_default.json 2> gpurun_out/r02_bench_default.err
 RSBA_TRACE=2 RSBA_TRACE_FILE=gpurun_out/wgtrace.txt python bench.py --no-cpu-baseline --steps 8 --warmup 2 > /dev/null 2> gpurun_out/r02_trace2.err
 python tools/schur_timeline_summary.py gpurun_out/wgtrace.txt > gpurun_out/r02_schur_block_timeline.txt
-RSBA_MC_TRACE=1 RSBA_TRACE=1 python bench.py --no-cpu-baseline --steps 6 --warmup 2 2>&1 | grep -E "rsba\[(mc|trace)\]" | tail -49 > gpurun_out/r02_cholesky_diag_timeline_pipelined.txt
+RSBA_MC_TRACE=1 RSBA_TRACE=1 python bench.py --no-cpu-baseline --steps 6 --warmup 2 2>&1 | grep -E "rsba\[(mc|trace)\]" | tail -100 > gpurun_out/r02_cholesky_diag_timeline_pipelined.txt
 python tools/mc_chain.py gpurun_out/r02_cholesky_diag_timeline_pipelined.txt >> gpurun_out/r02_cholesky_diag_timeline_pipelined.txt
 python bench.py --config cfg5 --points 62500 --no-cpu-baseline --steps 20 > gpurun_out/r02_bench_cfg5_shard.json 2>/dev/null
 python bench.py --config cfg4 --points 125000 --no-cpu-baseline --steps 30 > gpurun_out/r02_bench_cfg4_shard.json 2>/dev/null
