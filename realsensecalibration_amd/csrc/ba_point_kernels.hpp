@@ -596,6 +596,8 @@ struct ObsSliced {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void FinishCandidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
                                                 double* __restrict__ res, double* host, double seq, const double* res_stall = nullptr);
+__device__ __forceinline__ void FinishCandidateIn(double (*s)[256], int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
+                                                  double* __restrict__ res, double* host, double seq, const double* res_stall = nullptr);
 
 // kFused (tiled path): the linearisation of the points at x is READ (lin_x: V, g_p as the Schur kernel used them) instead
 // of accumulated again, and the second pass, which evaluates the candidate's residuals anyway, takes the candidate's 2x3
@@ -606,6 +608,7 @@ struct FusedLin {
   double* __restrict__ lin_c;
   const int* __restrict__ cm_pos;     // sliced slot -> camera-major position (robust loss only)
   double* __restrict__ sq_cm_c;
+  long long* trace;                   // diagnostic (RSBA_TRACE=1): [28] workgroup 0 past the solve's flag, [29] result posted
 };
 
 template <bool kStage, bool kFused>
@@ -637,6 +640,7 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
         if (wall_clock64() - t0 > RSBA_STALL_TICKS) { __hip_atomic_store(wait_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
       if (waited != nullptr && blockIdx.x == 0) *waited += wall_clock64() - t0;   // the kernel's span minus this is its own work
+      if (fl.trace != nullptr && blockIdx.x == 0) fl.trace[28] = wall_clock64();
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -812,6 +816,400 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
       }
       __syncthreads();
       FinishCandidate((int)gridDim.x, block_part, small_red, res, host, seq);
+      if (fl.trace != nullptr && tid == 0) fl.trace[29] = wall_clock64();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_B, projective form (the default when the point linearisation is kept between steps and the cameras' rows fit LDS).
+//
+// k_backsub_candidate above took 53 us of the 0.465 ms step at 64 cameras x 100k points, all of them behind the solve: per
+// observation and pass it read ~25 camera constants from LDS (R, Jl, t, intrinsics, the camera step; every lane its own
+// camera, so nothing is broadcast: 16 KB per observation slot and wavefront, 13 us of LDS time per CU with two workgroups
+// and no bank conflict, three times that measured) and spent ~135 instructions on residual, both Jacobian blocks and
+// Jc dc.  Nothing of that needs the camera block itself:
+//   h = A [X; 1],  A = [fx R0 | fx t0 ;  fy R1 | fy t1 ;  R2 | t2]   (3 x 4 per camera)
+//   r = (h0 / h2 + ppx - u, h1 / h2 + ppy - v),      d r_i / d X = (A_i - (h_i / h2) A_2)[0:3] / h2
+// and the change of r along the camera step dc = (dw, dt) is the same expression with the DERIVATIVE of h along the step,
+//   dh = B [X; 1],  B = the rows of A with R replaced by [theta]x W and t by dt,   theta = Jl(w) dw,
+//   W = R (Rodrigues branch: d(R X) = theta x (R X)) or I (AngleAxisRotatePoint's first-order branch: d = theta x X),
+//   Jc dc = ((dh0 - (h0 / h2) dh2) / h2, (dh1 - (h1 / h2) dh2) / h2)
+// — 26 doubles per camera for the pass at x, 14 for the pass at the candidate (the principal point kept apart: folded
+// into A it would cancel again in every Jacobian entry), built once per workgroup from the camera
+// constants (A before the solve's flag is up, B and the candidate's A behind it).  Per observation:
+// ~56 + ~51 instructions instead of ~2 x 135; the division is v_rcp_f64 + two Newton steps (RcpNewton).  The first eight
+// observation records, the point and its linearisation are in flight before the kernel waits for the solve.
+// Same sums, same order over a point's observations; the results differ from the other form in the last bits only.
+// ------------------------------------------------------------------------------------------------
+#define RSBA_PJ_NX 26      // rows of the table at x: A (12), B (12), ppx, ppy
+#define RSBA_PJ_NC 14      // rows of the table at the candidate: A (12), ppx, ppy
+#define RSBA_BS_REG 10     // observation records a lane keeps in registers (both passes read them from there) ...
+
+// 1 / x: v_rcp_f64 and two Newton steps, five instructions where the IEEE division sequence (scale, rcp, two Newton steps,
+// quotient, residual, fmas, fixup) is eleven; within an ulp or two of it.
+__device__ __forceinline__ double RcpNewton(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+
+// Loads of what the solve has just published (camera step, candidate's camera constants): agent scope, so that they
+// are served by the memory side without an acquire fence — a fence per workgroup invalidates the XCD's L2 each time, and
+// 391 of them at the same moment made this stage 10 us long.
+__device__ __forceinline__ double LoadFresh(const double* p) {
+  return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One entry per ds_read_b64.  The compiler pairs neighbouring entries into ds_read2st64_b64, which the LDS serves in four
+// groups of 16 lanes, banked modulo 32 dwords, at half the bytes per clock (MI355X_MICROARCH.md, LDS): 16 lanes with 16
+// different cameras conflict two- to three-fold, and the 13 paired reads of a slot cost ~260 LDS cycles per wavefront —
+// with six wavefronts per CU the passes ran at ~1400 cycles per slot, all of it LDS time.  ds_read_b64 is served in two
+// groups of 32 lanes, banked modulo 64: conflict-free while the cameras of a half-wave differ by less than 32.
+#define RSBA_LDS_RD(dst, k) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "i"((k) * kCpad * 8))
+template <int kCpad>
+__device__ __forceinline__ void ReadRows26(unsigned ad, double* a) {
+  RSBA_LDS_RD(a[0], 0); RSBA_LDS_RD(a[1], 1); RSBA_LDS_RD(a[2], 2); RSBA_LDS_RD(a[3], 3); RSBA_LDS_RD(a[4], 4); RSBA_LDS_RD(a[5], 5);
+  RSBA_LDS_RD(a[6], 6); RSBA_LDS_RD(a[7], 7); RSBA_LDS_RD(a[8], 8); RSBA_LDS_RD(a[9], 9); RSBA_LDS_RD(a[10], 10); RSBA_LDS_RD(a[11], 11);
+  RSBA_LDS_RD(a[12], 12); RSBA_LDS_RD(a[13], 13); RSBA_LDS_RD(a[14], 14); RSBA_LDS_RD(a[15], 15); RSBA_LDS_RD(a[16], 16); RSBA_LDS_RD(a[17], 17);
+  RSBA_LDS_RD(a[18], 18); RSBA_LDS_RD(a[19], 19); RSBA_LDS_RD(a[20], 20); RSBA_LDS_RD(a[21], 21); RSBA_LDS_RD(a[22], 22); RSBA_LDS_RD(a[23], 23);
+  RSBA_LDS_RD(a[24], 24); RSBA_LDS_RD(a[25], 25);
+  // (the values are operands of the wait: nothing that uses them moves above it)
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+               "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]));
+  asm volatile("" : "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]),
+               "+v"(a[22]), "+v"(a[23]), "+v"(a[24]), "+v"(a[25]));
+}
+template <int kCpad>
+__device__ __forceinline__ void ReadRows14(unsigned ad, double* a) {
+  RSBA_LDS_RD(a[0], 0); RSBA_LDS_RD(a[1], 1); RSBA_LDS_RD(a[2], 2); RSBA_LDS_RD(a[3], 3); RSBA_LDS_RD(a[4], 4); RSBA_LDS_RD(a[5], 5);
+  RSBA_LDS_RD(a[6], 6); RSBA_LDS_RD(a[7], 7); RSBA_LDS_RD(a[8], 8); RSBA_LDS_RD(a[9], 9); RSBA_LDS_RD(a[10], 10); RSBA_LDS_RD(a[11], 11);
+  RSBA_LDS_RD(a[12], 12); RSBA_LDS_RD(a[13], 13);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+               "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]));
+}
+#undef RSBA_LDS_RD
+
+// LDS of a workgroup, in doubles: the two tables, then the records of kLds slots (a double2 and an int per lane and slot).
+template <int kCpad, int kLds>
+struct BacksubProjLds {
+  static constexpr int kTables = (RSBA_PJ_NX + RSBA_PJ_NC) * kCpad;
+  static constexpr int kUv = 4 * kLds * 64 * 2;     // [wave][slot][lane] double2
+  static constexpr int kCam = 4 * kLds * 64 / 2;    // [wave][slot][lane] int
+  static constexpr size_t kBytes = (size_t)(kTables + kUv + kCam) * sizeof(double);
+};
+
+// The tables are element-major — entry k of camera c at [k * kCpad + c] — so that the lanes of a wavefront, each
+// reading entry k of ITS camera, hit 64 different banks as long as their cameras differ by less than 32 (the records of a
+// point are in camera order, so the cameras of one slot cluster), the same camera is a broadcast, and k is an immediate
+// offset.
+//
+// Observation records: a lane's first RSBA_BS_REG slots stay in registers, the next kLds in LDS (lane-private: [wave]
+// [slot][lane]); all of them are fetched BEFORE the kernel waits for the solve and serve both passes.  (All twenty in
+// registers do not fit beside the passes' ~190 registers with two workgroups per CU: the compiler put the pixel pairs into
+// scratch and fetched one per slot, each a trip to memory — 16 + 20 us for the two passes.)  Slots beyond that are
+// streamed from memory (correct, slow: points seen by more than RSBA_BS_REG + kLds cameras of a slice).
+//
+// Work is dealt by SLICE (64 points, one wavefront), wave w of workgroup b taking slices b + G (w + 4 i): with G = two
+// workgroups per CU every CU gets six or seven wavefronts of work; one workgroup per 256 points is 1.5 per CU, i.e. half
+// the CUs with twice the LDS traffic of the others.
+template <int kCpad, int kLds, bool kLoss>
+__global__ void __launch_bounds__(256, 2)
+k_backsub_candidate_proj(int C, int P, ObsSliced obs,
+                         const double* __restrict__ camc_xg, const double* __restrict__ camc_cg,
+                         const double* __restrict__ dcam_g, const double* __restrict__ pts_x, double* __restrict__ pts_c,
+                         const double* __restrict__ scale_p, double* __restrict__ block_part /* gridDim.x x 8 */, IterParams ip,
+                         int* __restrict__ done_cnt, double* __restrict__ small_red, double* __restrict__ res, double* host, double seq,
+                         const int* __restrict__ solve_done, int solve_tag, long long* __restrict__ waited, int* __restrict__ wait_timeout,
+                         FusedLin fl) {
+  using L = BacksubProjLds<kCpad, kLds>;
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  double* lx = lds;                                  // [RSBA_PJ_NX][kCpad]
+  double* lc = lds + RSBA_PJ_NX * kCpad;             // [RSBA_PJ_NC][kCpad]
+  double2* uvl = reinterpret_cast<double2*>(lds + L::kTables) + (size_t)wv * kLds * 64 + lane;   // + slot * 64
+  int* caml = reinterpret_cast<int*>(lds + L::kTables + L::kUv) + (size_t)wv * kLds * 64 + lane;
+  // Until B is built, what it takes of the constants at x — Jl (9), W (9), fx, fy: 20 rows — sits in the rows of the
+  // candidate's table (0..13) and of B (14..19 -> rows 12..17 of the table at x).  Thread c reads column c of all of it
+  // before it writes column c of B and of the candidate's table, so nothing is overwritten unread.
+  auto lk = [&](int k, int c) -> double& { return k < RSBA_PJ_NC ? lc[k * kCpad + c] : lx[(12 + k - RSBA_PJ_NC) * kCpad + c]; };
+  const int nslices = (P + 63) >> 6;
+  int slice = blockIdx.x + (int)gridDim.x * wv;
+  int j = slice * 64 + lane;
+  // --- everything that does not depend on the solve: the cameras' rows at x, what B takes of the constants at x, then this
+  // wavefront's first slice — points, their linearisation, and the observation records of every lane (the workgroups sit
+  // here for ~100 us of the pipelined step: whatever they hold by then is not fetched behind the solve, where the step
+  // waits for this kernel alone)
+  for (int c = tid; c < C; c += blockDim.x) {
+    const double* cc = camc_xg + (size_t)c * CC_STRIDE;
+    const double fx = cc[CC_FX], fy = cc[CC_FY];
+    const bool small = cc[CC_SMALL] != 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      lx[i * kCpad + c] = fx * cc[CC_R + i];
+      lx[(4 + i) * kCpad + c] = fy * cc[CC_R + 3 + i];
+      lx[(8 + i) * kCpad + c] = cc[CC_R + 6 + i];
+    }
+    lx[3 * kCpad + c] = fx * cc[CC_T];
+    lx[7 * kCpad + c] = fy * cc[CC_T + 1];
+    lx[11 * kCpad + c] = cc[CC_T + 2];
+    lx[24 * kCpad + c] = cc[CC_PPX];
+    lx[25 * kCpad + c] = cc[CC_PPY];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      lk(i, c) = cc[CC_K + i];
+      lk(9 + i, c) = small ? ((i == 0 || i == 4 || i == 8) ? 1.0 : 0.0) : cc[CC_R + i];   // W: R, or I in the first-order branch
+    }
+    lk(18, c) = fx; lk(19, c) = fy;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  int tb = 0, te = 0;
+  double X[3] = {0, 0, 0}, V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, sp[3] = {1, 1, 1};
+  int camq[RSBA_BS_REG]; double2 uvq[RSBA_BS_REG];
+  auto load_point = [&]() {
+    tb = obs.row_ptr[slice]; te = obs.row_ptr[slice + 1];
+    if (j < P) {
+      const double* ln = fl.lin_x + (size_t)j * RSBA_LIN_STRIDE;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) V[i] = ln[i];
+      gp[0] = ln[6]; gp[1] = ln[7]; gp[2] = ln[8];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { X[i] = pts_x[3 * (size_t)j + i]; sp[i] = scale_p[3 * (size_t)j + i]; }
+    }
+    // (the slots of a slice's missing points are padding: cam < 0)
+#pragma unroll
+    for (int u = 0; u < RSBA_BS_REG; ++u) {
+      const size_t qq = (size_t)(tb + u) * 64 + lane;
+      camq[u] = tb + u < te ? obs.cam[qq] : -1;
+      uvq[u] = tb + u < te ? obs.uv[qq] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < kLds; u0 += 5) {
+      int cv[5]; double2 uv[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int t = tb + RSBA_BS_REG + u0 + u;
+        const size_t qq = (size_t)t * 64 + lane;
+        cv[u] = (u0 + u < kLds && t < te) ? obs.cam[qq] : -1;
+        uv[u] = (u0 + u < kLds && t < te) ? obs.uv[qq] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 5; ++u) if (u0 + u < kLds) { caml[(u0 + u) * 64] = cv[u]; uvl[(u0 + u) * 64] = uv[u]; }
+    }
+  };
+  if (slice < nslices) load_point();
+  // --- the solve (pipelined schedule: this kernel is launched behind the Schur kernel and sits here until the
+  // factorisation's workgroup 0 has published the camera step; see k_backsub_candidate)
+  if (solve_done != nullptr) {
+    if (tid == 0) {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(solve_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != solve_tag) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > RSBA_STALL_TICKS) { __hip_atomic_store(wait_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+      if (waited != nullptr && blockIdx.x == 0) *waited += wall_clock64() - t0;
+      if (fl.trace != nullptr && blockIdx.x == 0) fl.trace[28] = wall_clock64();
+    }
+  }
+  __syncthreads();
+  // (sequential schedule: the kernel boundary has made the solve's output visible; the agent-scope loads cost nothing extra)
+  for (int c = tid; c < C; c += blockDim.x) {
+    // this camera's column of the constants at x, the camera step, the candidate's constants — all loads first
+    double kk[20], dc[6], v[16];
+    const double* cc = camc_cg + (size_t)c * CC_STRIDE;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dc[i] = LoadFresh(dcam_g + 6 * (size_t)c + i);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = LoadFresh(cc + CC_R + i);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[9 + i] = LoadFresh(cc + CC_T + i);
+    v[12] = LoadFresh(cc + CC_FX); v[13] = LoadFresh(cc + CC_FY); v[14] = LoadFresh(cc + CC_PPX); v[15] = LoadFresh(cc + CC_PPY);
+#pragma unroll
+    for (int i = 0; i < 20; ++i) kk[i] = lk(i, c);
+    // B: the rows of A with R -> [theta]x W, t -> dt;  theta = Jl dw
+    const double th0 = kk[0] * dc[0] + kk[1] * dc[1] + kk[2] * dc[2];
+    const double th1 = kk[3] * dc[0] + kk[4] * dc[1] + kk[5] * dc[2];
+    const double th2 = kk[6] * dc[0] + kk[7] * dc[1] + kk[8] * dc[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double w0 = kk[9 + i], w1 = kk[12 + i], w2 = kk[15 + i];   // column i of W
+      lx[(12 + i) * kCpad + c] = kk[18] * (th1 * w2 - th2 * w1);
+      lx[(16 + i) * kCpad + c] = kk[19] * (th2 * w0 - th0 * w2);
+      lx[(20 + i) * kCpad + c] = th0 * w1 - th1 * w0;
+    }
+    lx[15 * kCpad + c] = kk[18] * dc[3];
+    lx[19 * kCpad + c] = kk[19] * dc[4];
+    lx[23 * kCpad + c] = dc[5];
+    // the candidate's A
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      lc[i * kCpad + c] = v[12] * v[i];
+      lc[(4 + i) * kCpad + c] = v[13] * v[3 + i];
+      lc[(8 + i) * kCpad + c] = v[6 + i];
+    }
+    lc[3 * kCpad + c] = v[12] * v[9];
+    lc[7 * kCpad + c] = v[13] * v[10];
+    lc[11 * kCpad + c] = v[11];
+    lc[12 * kCpad + c] = v[14];
+    lc[13 * kCpad + c] = v[15];
+  }
+  __syncthreads();
+  if (fl.trace != nullptr && blockIdx.x == 0 && tid == 0) fl.trace[32] = wall_clock64();
+  const unsigned lx_ad = (unsigned)(size_t)(lds_double*)lx, lc_ad = (unsigned)(size_t)(lds_double*)lc;   // LDS byte addresses
+  double mcc = 0, cost_c = 0, dp2 = 0, xc2 = 0, ss_c = 0;
+  for (bool first = true; slice < nslices; slice += 4 * (int)gridDim.x, j = slice * 64 + lane, first = false) {
+    if (!first) load_point();
+    const int nslot = te - tb;   // the same for the 64 lanes
+    bool any = false;
+    double bv[3] = {0, 0, 0}, a1 = 0, a2 = 0;
+    // pass at x: b = sum Jp' (Jc dc), a1 = sum (Jc dc)' r, a2 = sum |Jc dc|^2
+    auto at_x = [&](int cam, double2 uv) {
+      if (cam < 0) return;
+      any = true;
+      double av[RSBA_PJ_NX];
+      ReadRows26<kCpad>(lx_ad + 8u * (unsigned)cam, av);
+#define RSBA_A(k) av[k]
+      const double h0 = fma(RSBA_A(0), X[0], fma(RSBA_A(1), X[1], fma(RSBA_A(2), X[2], RSBA_A(3))));
+      const double h1 = fma(RSBA_A(4), X[0], fma(RSBA_A(5), X[1], fma(RSBA_A(6), X[2], RSBA_A(7))));
+      const double h2 = fma(RSBA_A(8), X[0], fma(RSBA_A(9), X[1], fma(RSBA_A(10), X[2], RSBA_A(11))));
+      const double d0 = fma(RSBA_A(12), X[0], fma(RSBA_A(13), X[1], fma(RSBA_A(14), X[2], RSBA_A(15))));
+      const double d1 = fma(RSBA_A(16), X[0], fma(RSBA_A(17), X[1], fma(RSBA_A(18), X[2], RSBA_A(19))));
+      const double d2 = fma(RSBA_A(20), X[0], fma(RSBA_A(21), X[1], fma(RSBA_A(22), X[2], RSBA_A(23))));
+      const double iz = RcpNewton(h2);
+      const double pr0 = h0 * iz, pr1 = h1 * iz;
+      double r[2] = {pr0 + RSBA_A(24) - uv.x, pr1 + RSBA_A(25) - uv.y};
+      double jp[6] = {fma(-pr0, RSBA_A(8), RSBA_A(0)) * iz, fma(-pr0, RSBA_A(9), RSBA_A(1)) * iz, fma(-pr0, RSBA_A(10), RSBA_A(2)) * iz,
+                      fma(-pr1, RSBA_A(8), RSBA_A(4)) * iz, fma(-pr1, RSBA_A(9), RSBA_A(5)) * iz, fma(-pr1, RSBA_A(10), RSBA_A(6)) * iz};
+      double e0 = fma(-pr0, d2, d0) * iz, e1 = fma(-pr1, d2, d1) * iz;
+      if (kLoss) {
+        double sq;
+        LossAndScale(ip.huber_delta, r[0] * r[0] + r[1] * r[1], &sq);
+        if (sq != 1.0) {
+          r[0] *= sq; r[1] *= sq; e0 *= sq; e1 *= sq;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) jp[i] *= sq;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) bv[a] += jp[a] * e0 + jp[3 + a] * e1;
+      a1 += e0 * r[0] + e1 * r[1];
+      a2 += e0 * e0 + e1 * e1;
+    };
+#pragma unroll
+    for (int u = 0; u < RSBA_BS_REG; ++u) { if (u < nslot) at_x(camq[u], uvq[u]); __builtin_amdgcn_sched_barrier(0); }
+    {
+      const int nl = min(kLds, nslot - RSBA_BS_REG);
+#pragma unroll 1
+      for (int u = 0; u < nl; ++u) at_x(caml[u * 64], uvl[u * 64]);
+    }
+    for (int t = tb + RSBA_BS_REG + kLds; t < te; ++t) {   // (points with more views than a lane keeps)
+      const size_t qq = (size_t)t * 64 + lane;
+      at_x(obs.cam[qq], obs.uv[qq]);
+    }
+    if (fl.trace != nullptr && blockIdx.x == 0 && tid == 0) fl.trace[33] = wall_clock64();
+    double Vi[6];
+    const bool ok = PointBlockInverse(V, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, ip.radius, Vi);
+    double tv[3] = {gp[0] + bv[0], gp[1] + bv[1], gp[2] + bv[2]}, dp[3] = {0, 0, 0};
+    if (ok && any) { Sym3MulVec(Vi, tv, dp); dp[0] = -dp[0]; dp[1] = -dp[1]; dp[2] = -dp[2]; }
+    const double Xc[3] = {X[0] + dp[0], X[1] + dp[1], X[2] + dp[2]};
+    double Vc[6] = {0, 0, 0, 0, 0, 0}, gc[3] = {0, 0, 0}, costj_c = 0.0;
+    if (j < P) {
+      pts_c[3 * (size_t)j] = Xc[0]; pts_c[3 * (size_t)j + 1] = Xc[1]; pts_c[3 * (size_t)j + 2] = Xc[2];
+      double Vd[3];
+      Sym3MulVec(V, dp, Vd);
+      mcc -= a1 + (dp[0] * gp[0] + dp[1] * gp[1] + dp[2] * gp[2]) + 0.5 * a2 + (dp[0] * bv[0] + dp[1] * bv[1] + dp[2] * bv[2]) +
+             0.5 * (dp[0] * Vd[0] + dp[1] * Vd[1] + dp[2] * Vd[2]);
+      dp2 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
+      xc2 += Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2];
+    }
+    // pass at the candidate: its cost and its linearisation
+    auto at_c = [&](int cam, double2 uv, int t) {
+      if (cam < 0) return;
+      double av[RSBA_PJ_NC];
+      ReadRows14<kCpad>(lc_ad + 8u * (unsigned)cam, av);
+      const double h0 = fma(RSBA_A(0), Xc[0], fma(RSBA_A(1), Xc[1], fma(RSBA_A(2), Xc[2], RSBA_A(3))));
+      const double h1 = fma(RSBA_A(4), Xc[0], fma(RSBA_A(5), Xc[1], fma(RSBA_A(6), Xc[2], RSBA_A(7))));
+      const double h2 = fma(RSBA_A(8), Xc[0], fma(RSBA_A(9), Xc[1], fma(RSBA_A(10), Xc[2], RSBA_A(11))));
+      const double iz = RcpNewton(h2);
+      const double pr0 = h0 * iz, pr1 = h1 * iz;
+      double r[2] = {pr0 + RSBA_A(12) - uv.x, pr1 + RSBA_A(13) - uv.y};
+      double jp[6] = {fma(-pr0, RSBA_A(8), RSBA_A(0)) * iz, fma(-pr0, RSBA_A(9), RSBA_A(1)) * iz, fma(-pr0, RSBA_A(10), RSBA_A(2)) * iz,
+                      fma(-pr1, RSBA_A(8), RSBA_A(4)) * iz, fma(-pr1, RSBA_A(9), RSBA_A(5)) * iz, fma(-pr1, RSBA_A(10), RSBA_A(6)) * iz};
+#undef RSBA_A
+      const double s = r[0] * r[0] + r[1] * r[1];
+      ss_c += s;
+      if (kLoss) {
+        double sq;
+        costj_c += LossAndScale(ip.huber_delta, s, &sq);
+        fl.sq_cm_c[fl.cm_pos[(size_t)t * 64 + lane]] = sq;
+        if (sq != 1.0) {
+          r[0] *= sq; r[1] *= sq;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) jp[i] *= sq;
+        }
+      } else {
+        costj_c += s;
+      }
+      Vc[0] += jp[0] * jp[0] + jp[3] * jp[3]; Vc[1] += jp[0] * jp[1] + jp[3] * jp[4]; Vc[2] += jp[0] * jp[2] + jp[3] * jp[5];
+      Vc[3] += jp[1] * jp[1] + jp[4] * jp[4]; Vc[4] += jp[1] * jp[2] + jp[4] * jp[5]; Vc[5] += jp[2] * jp[2] + jp[5] * jp[5];
+      gc[0] += jp[0] * r[0] + jp[3] * r[1]; gc[1] += jp[1] * r[0] + jp[4] * r[1]; gc[2] += jp[2] * r[0] + jp[5] * r[1];
+    };
+#pragma unroll
+    for (int u = 0; u < RSBA_BS_REG; ++u) { if (u < nslot) at_c(camq[u], uvq[u], tb + u); __builtin_amdgcn_sched_barrier(0); }
+    {
+      const int nl = min(kLds, nslot - RSBA_BS_REG);
+#pragma unroll 1
+      for (int u = 0; u < nl; ++u) at_c(caml[u * 64], uvl[u * 64], tb + RSBA_BS_REG + u);
+    }
+    for (int t = tb + RSBA_BS_REG + kLds; t < te; ++t) {
+      const size_t qq = (size_t)t * 64 + lane;
+      at_c(obs.cam[qq], obs.uv[qq], t);
+    }
+    if (j < P) {
+      cost_c += costj_c;
+      double* ln = fl.lin_c + (size_t)j * RSBA_LIN_STRIDE;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ln[i] = Vc[i];
+      ln[6] = gc[0]; ln[7] = gc[1]; ln[8] = gc[2]; ln[9] = costj_c;
+    }
+  }
+  // block reduction in a fixed order (in the records' LDS, once every wavefront is through with its own), then (single
+  // GPU) the last workgroup adds the blocks and posts the result
+  if (fl.trace != nullptr && blockIdx.x == 0 && tid == 0) fl.trace[34] = wall_clock64();
+  static_assert(L::kUv >= 5 * 256, "the block sums reuse the records' LDS");
+  __syncthreads();
+  double (*s)[256] = reinterpret_cast<double (*)[256]>(lds + L::kTables);
+  s[0][tid] = mcc; s[1][tid] = cost_c; s[2][tid] = dp2; s[3][tid] = xc2; s[4][tid] = ss_c;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) s[q][tid] += s[q][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid < 5) __hip_atomic_store(&block_part[8 * blockIdx.x + tid], s[tid][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (done_cnt != nullptr) {
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+      s_last = __hip_atomic_fetch_add(done_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+      if (s_last) __hip_atomic_store(done_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (fl.trace != nullptr && blockIdx.x == 0 && tid == 0) fl.trace[35] = wall_clock64();
+    if (s_last) {
+      if (fl.trace != nullptr && tid == 0) fl.trace[36] = wall_clock64();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (tid == 0 && wait_timeout != nullptr) {
+        res[RES_WAIT_TIMEOUT] = (double)__hip_atomic_load(wait_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(wait_timeout, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      FinishCandidateIn(s, (int)gridDim.x, block_part, small_red, res, host, seq);
+      if (fl.trace != nullptr && tid == 0) fl.trace[29] = wall_clock64();
     }
   }
 }
@@ -822,9 +1220,9 @@ __device__ __forceinline__ void PublishResult(const double* __restrict__ small_r
 __device__ __forceinline__ void PostToHost(const double* __restrict__ res, double* host, double seq);
 // One workgroup: small_red[0..4] = fixed-order sums of the per-block partials; with res != nullptr (single GPU) the
 // result block is completed and posted to the host straight away.
-__device__ __forceinline__ void FinishCandidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
-                                                double* __restrict__ res, double* host, double seq, const double* res_stall) {
-  __shared__ double s[5][256];
+// (s: 5 x 256 doubles of LDS the caller can spare)
+__device__ __forceinline__ void FinishCandidateIn(double (*s)[256], int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
+                                                  double* __restrict__ res, double* host, double seq, const double* res_stall) {
   const int tid = threadIdx.x;
   double v[5] = {0, 0, 0, 0, 0};
   if (tid < 256) {
@@ -851,6 +1249,11 @@ __device__ __forceinline__ void FinishCandidate(int nblocks, const double* __res
     __syncthreads();
     PostToHost(res, host, seq);
   }
+}
+__device__ __forceinline__ void FinishCandidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
+                                                double* __restrict__ res, double* host, double seq, const double* res_stall) {
+  __shared__ double s[5][256];
+  FinishCandidateIn(s, nblocks, block_part, small_red, res, host, seq, res_stall);
 }
 __global__ void __launch_bounds__(256)
 k_finish_candidate(int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red, double* __restrict__ res,

@@ -241,8 +241,9 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
 __global__ void __launch_bounds__(256)
 k_point_damp(int P, const double* __restrict__ pts, const double* __restrict__ scale_p, const double* __restrict__ lin,
              double* __restrict__ ptdata, double* __restrict__ block_scal, int C, const double* __restrict__ camc_g,
-             int* __restrict__ small_flag, IterParams ip) {
+             int* __restrict__ small_flag, IterParams ip, long long* trace = nullptr) {
   const int tid = threadIdx.x;
+  if (trace != nullptr && blockIdx.x == 0 && tid == 0) trace[30] = wall_clock64();
   PublishSmallAngleFlag(C, camc_g, small_flag);
   double cost = 0, xn = 0, fail = 0, gmax = 0;
   for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {
@@ -281,6 +282,7 @@ k_point_damp(int P, const double* __restrict__ pts, const double* __restrict__ s
     __syncthreads();
   }
   if (tid < 4) block_scal[4 * blockIdx.x + tid] = s[tid][0];
+  if (trace != nullptr && blockIdx.x == gridDim.x - 1 && tid == 0) trace[31] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -291,13 +293,7 @@ k_point_damp(int P, const double* __restrict__ pts, const double* __restrict__ s
 // on its own before it is added — and the elimination kernel is bound by the number of fp64 instructions it issues.)
 __device__ __forceinline__ double Fma2(double a, double b, double c, double d, double acc) { return fma(c, d, fma(a, b, acc)); }
 
-// 1 / x for the depth of a point in a camera: v_rcp_f64 and two Newton steps, five instructions where the IEEE division
-// sequence (scale, rcp, two Newton steps, quotient, residual, fmas, fixup) is eleven; within an ulp or two of it.
-__device__ __forceinline__ double RcpNewton(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return fma(fma(-x, r, 1.0), r, r);
-}
+// (1 / x for the depth of a point in a camera: RcpNewton, ba_point_kernels.hpp)
 
 struct SideConst {
   double R[9], t[3], fx, fy;

@@ -190,6 +190,7 @@ struct rsba_solver {
   int* ready_global = nullptr;
   long long* chol_waited = nullptr;   // device: ticks the pipelined Cholesky spent waiting for its columns (cumulative)
   long long chol_waited_seen = 0, backsub_waited_seen = 0;   // [1]: the back-substitution's wait for the solve
+  long long trace_prev_post = 0;   // RSBA_TRACE=1: device time at which the previous step posted its result
   long long* trace = nullptr;   // RSBA_TRACE=1: 32 wall-clock stamps of the pipelined step
   std::chrono::steady_clock::time_point host_t[4];
   long long* wg_trace = nullptr;  // RSBA_TRACE=2: per-block stamps of the Schur kernel, dumped to RSBA_TRACE_FILE
@@ -242,10 +243,14 @@ namespace rsba {
 // Word bounds of the segments one PAIR tile's points are cut into (ns + 1 values, in 64-point mask words): the same for
 // every pair tile.  Shared by TiledSchur::Build and by the point ordering below (whose units are these segments' chunks).
 static int DeviceCUs() {
-  int cus = 256;
-  hipDeviceProp_t prop; int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-  return cus;
+  // (one device per process; asked once — the step asks for it as well)
+  static const int cached = []() {
+    int cus = 256;
+    hipDeviceProp_t prop; int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    return cus;
+  }();
+  return cached;
 }
 static std::vector<int> SegmentBounds(int nW, int ns) {
   // Optional tapered segments (RSBA_TAPER > 1: the first of a tile is that many times as long as the last).  A stage is
@@ -728,7 +733,7 @@ static int UploadPoints(rsba_solver* s) {
   if (s->opt.schur_impl != 0) {
     if (getenv("RSBA_TRACE") && s->nc <= RSBA_CHOL_MAXN) {   // the 32 slots are laid out for at most four stages (64 cameras)
       // diagnostics: wall-clock stamps of the step (1) and of every block of the Schur kernel (2)
-      if (hipMalloc((void**)&s->trace, 32 * sizeof(long long)) != hipSuccess || hipMemset(s->trace, 0, 32 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
+      if (hipMalloc((void**)&s->trace, 64 * sizeof(long long)) != hipSuccess || hipMemset(s->trace, 0, 64 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
       if (atoi(getenv("RSBA_TRACE")) == 2 && hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
     }
     s->pipelined = SetupPipeline(s);
@@ -822,7 +827,7 @@ static int UploadPoints(rsba_solver* s) {
   // launch geometry: fixed grids (deterministic second-stage reductions depend only on these)
   s->grid_lin = std::max(1, std::min((P + 3) / 4, 2048));
   s->grid_pts = std::max(1, std::min((P + 255) / 256, 2048));
-  if ((rc = DevAlloc(&s->block_scal, 4 * (size_t)std::max(s->grid_lin, 4096))) || (rc = DevAlloc(&s->block_part, 8 * (size_t)s->grid_pts))) return rc;
+  if ((rc = DevAlloc(&s->block_scal, 4 * (size_t)std::max(s->grid_lin, 4096))) || (rc = DevAlloc(&s->block_part, 8 * (size_t)std::max(s->grid_pts, 2 * DeviceCUs())))) return rc;
   // dynamic LDS above 48 KB has to be asked for, once
   if (s->nc <= RSBA_CHOL_MAXN) {
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(s->nc)) * sizeof(double);
@@ -917,7 +922,7 @@ void TiledSchur::LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTim
 void TiledSchur::LaunchPointDamp(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st) {
   const int x = s->cur;
   T.Begin("k_point_damp", st);
-  k_point_damp<<<grid_pp, 256, 0, st>>>(P, s->pts[x], s->scale_p, lin2[x], ptdata, block_scal, C, s->camc[x], small_flag, ip);
+  k_point_damp<<<grid_pp, 256, 0, st>>>(P, s->pts[x], s->scale_p, lin2[x], ptdata, block_scal, C, s->camc[x], small_flag, ip, s->trace);
   T.End(st);
 }
 
@@ -1169,16 +1174,31 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   T.Begin("k_backsub_candidate", st);
   // single GPU: the kernel's last workgroup finishes the step (sums, result block, post to the host)
   int* fin_cnt = s->comm ? nullptr : s->chol_ok + 1;
+  int grid_bs = s->grid_pts;   // workgroups of the back-substitution = blocks of partial sums the finisher adds
   {
     const size_t lds_b = (size_t)C * (2 * RSBA_CC_LDS + 6) * sizeof(double);
     const bool fused = s->opt.schur_impl != 0 && s->fused_lin;
-    const FusedLin fl = fused ? FusedLin{s->tiled.lin2[x], s->tiled.lin2[c], s->tiled.cm_pos, s->tiled.sq_cm2[c]} : FusedLin{nullptr, nullptr, nullptr, nullptr};
+    const FusedLin fl = fused ? FusedLin{s->tiled.lin2[x], s->tiled.lin2[c], s->tiled.cm_pos, s->tiled.sq_cm2[c], s->trace} : FusedLin{nullptr, nullptr, nullptr, nullptr, s->trace};
     const int* solve_done = pipe ? s->tiled.ready + 15 : nullptr;
     const int solve_tag = s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag;
     long long* waited = pipe && T.all_kernels() ? s->chol_waited + 1 : nullptr;
 #define RSBA_BACKSUB_ARGS C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x], s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, \
                           s->res, s->res_host, s->res_seq + 1.0, solve_done, solve_tag, waited, s->chol_ok + 2, fl
-    if (lds_b <= 60 * 1024) {
+    // (RSBA_BACKSUB_PROJ=0: the form that reads the camera constants themselves, for comparison)
+    static const bool proj_form = !(getenv("RSBA_BACKSUB_PROJ") && atoi(getenv("RSBA_BACKSUB_PROJ")) == 0);
+    if (fused && proj_form && C <= 128) {
+      // slices of 64 points dealt to two workgroups per CU (k_backsub_candidate_proj); ten slots of a lane's observation
+      // records in registers, ten (<= 64 cameras) or six more in LDS, both tables + records <= 72 KB per workgroup
+      grid_bs = std::max(1, std::min(2 * DeviceCUs(), (P + 63) / 64));
+      const bool loss = ip.huber_delta != 0.0;
+      if (C <= 64) {
+        if (loss) k_backsub_candidate_proj<64, 10, true><<<grid_bs, 256, BacksubProjLds<64, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
+        else k_backsub_candidate_proj<64, 10, false><<<grid_bs, 256, BacksubProjLds<64, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
+      } else {
+        if (loss) k_backsub_candidate_proj<128, 6, true><<<grid_bs, 256, BacksubProjLds<128, 6>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
+        else k_backsub_candidate_proj<128, 6, false><<<grid_bs, 256, BacksubProjLds<128, 6>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
+      }
+    } else if (lds_b <= 60 * 1024) {
       if (fused) k_backsub_candidate<true, true><<<s->grid_pts, 256, lds_b, st>>>(RSBA_BACKSUB_ARGS);
       else k_backsub_candidate<true, false><<<s->grid_pts, 256, lds_b, st>>>(RSBA_BACKSUB_ARGS);
     } else {
@@ -1198,7 +1218,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // res_stall: with a communicator the stall flag of the factorisation (multi-workgroup / persistent tiles: in-kernel
     // waits) and of the pipeline rides in small_red[5] and is SUMMED over the ranks in every schedule, so that all ranks
     // take the same fallback below and keep issuing the same collectives
-    k_finish_candidate<<<1, 256, 0, st>>>(s->grid_pts, s->block_part, s->small_red, nullptr, nullptr, 0.0, s->res, s->trace, mg ? s->chol_ok + 2 : nullptr);
+    k_finish_candidate<<<1, 256, 0, st>>>(grid_bs, s->block_part, s->small_red, nullptr, nullptr, 0.0, s->res, s->trace, mg ? s->chol_ok + 2 : nullptr);
     T.End(st);
     // the candidate's sums and the stall flags; pipelined, all RCCL traffic stays on the communication stream
     hipStream_t sc = st;
@@ -1230,7 +1250,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     s->chol_waited_seen = w[0]; s->backsub_waited_seen = w[1];
   }
   if (s->trace && s->opt.schur_impl != 0) {
-    long long h[32];
+    long long h[64];
     HIPCHK(hipMemcpy(h, s->trace, sizeof(h), hipMemcpyDeviceToHost));
     const long long t0 = h[24];
     fprintf(stderr, "rsba[trace] us since first tile block: chol start %.1f ready0 seen %.1f | gates (wait..pass)", (h[0] - t0) * 0.01, (h[1] - t0) * 0.01);
@@ -1238,6 +1258,13 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     fprintf(stderr, " factored %.1f back-substituted %.1f end %.1f | published: self %.1f stages", (h[13] - t0) * 0.01, (h[14] - t0) * 0.01, (h[15] - t0) * 0.01, (h[16] - t0) * 0.01);
     for (int g = 0; g < s->tiled.nstages; ++g) fprintf(stderr, " %.1f", (h[17 + g] - t0) * 0.01);
     if (s->comm) fprintf(stderr, " | after the solve: candidate sums start +%.1f, publish +%.1f", (h[26] - h[15]) * 0.01, (h[27] - h[15]) * 0.01);
+    // the tail of the step: back-substitution past the solve's flag, result posted; and this step's head: the previous result
+    // posted -> damping kernel's first workgroup -> its last -> first Schur block
+    fprintf(stderr, " | backsub past the flag %.1f posted %.1f | head: previous post -> damp start %.1f -> damp end %.1f -> first tile block %.1f",
+            (h[28] - t0) * 0.01, (h[29] - t0) * 0.01, (h[30] - s->trace_prev_post) * 0.01, (h[31] - h[30]) * 0.01, (t0 - h[31]) * 0.01);
+    fprintf(stderr, " | backsub wg 0 after the flag: staged +%.1f pass at x +%.1f pass at the candidate +%.1f block sums +%.1f; last workgroup arrives +%.1f",
+            (h[32] - h[28]) * 0.01, (h[33] - h[28]) * 0.01, (h[34] - h[28]) * 0.01, (h[35] - h[28]) * 0.01, (h[36] - h[28]) * 0.01);
+    s->trace_prev_post = h[29];
     fprintf(stderr, "\n");
     if (s->wg_trace && s->step_tag == 5) {
       // one step's block timeline: block, segment, tile, self, stage, words, start, compute end, end (us)

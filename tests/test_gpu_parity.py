@@ -9,6 +9,7 @@ import os
 import numpy as np
 import pytest
 
+import gauge
 import oracle_lib as ol
 from realsensecalibration_amd import capi
 from realsensecalibration_amd import synthetic as syn
@@ -60,7 +61,7 @@ def test_reduced_system_and_step_match_oracle(oracle, impl, C, P, k, radius):
 
 
 # ------------------------------------------------------------------ whole solves
-def _compare_solve(oracle, prob, impl, huber=0.0, strict_params=True, iter_cost_tol=1e-7, **optkw):
+def _compare_solve(oracle, prob, impl, huber=0.0, strict_params=True, iter_cost_tol=1e-7, modulo_gauge=False, **optkw):
     o_ref = oracle.options(huber_delta=huber, **optkw)
     ref, s_ref, log_ref = oracle.solve_points(prob, o_ref)
     got, s_got, log_got = capi.solve_points(prob, capi.default_options(schur_impl=impl, huber_delta=huber, **optkw))
@@ -73,7 +74,13 @@ def _compare_solve(oracle, prob, impl, huber=0.0, strict_params=True, iter_cost_
     # every iterate has the same cost (relative to the largest cost on the trajectory)
     assert np.abs(log_got[:, 1] - log_ref[:, 1]).max() / log_ref[:, 1].max() < iter_cost_tol
     if strict_params:
-        assert _block_rel(got, ref, prob["C"]) < 1e-6
+        rel = _block_rel(got, ref, prob["C"])
+        if modulo_gauge and rel >= 1e-6:
+            # all blocks free: the solutions may sit at different places of the similarity orbit the cost does not see
+            # (tests/gauge.py); moved onto each other along it they have to agree like everywhere else
+            assert rel < 1e-3
+            rel = _block_rel(gauge.align(got, ref, prob["C"])[0], ref, prob["C"])
+        assert rel < 1e-6
     c_ref, ss_ref = oracle.points_cost(prob, ref)
     c_got, ss_got = oracle.points_cost(prob, got)
     rms_ref, rms_got = np.sqrt(ss_ref / (2 * prob["N"])), np.sqrt(ss_got / (2 * prob["N"]))
@@ -97,8 +104,13 @@ def test_config2_full_size(oracle, impl):
 
 @pytest.mark.parametrize("impl", IMPLS)
 def test_huber_and_rejected_steps(oracle, impl):
+    """17 iterations, the radius grows to 4e11 with every block free: rounding differences between two correct solvers are
+    amplified along the 7-dof gauge orbit (measured between two forms of the back-substitution kernel on this problem:
+    2.7e-5 in the raw parameters, 3.4e-9 after moving one solution onto the other along the orbit, every iterate's cost
+    equal to 1e-9 relative).  Costs, decisions and RMS are compared as everywhere; the parameters raw when they agree to
+    1e-6, otherwise modulo the gauge."""
     prob = syn.make_problem(8, 1500, 6, seed=9, outlier_frac=0.05)
-    _compare_solve(oracle, prob, impl, huber=1.0)
+    _compare_solve(oracle, prob, impl, huber=1.0, modulo_gauge=True)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
