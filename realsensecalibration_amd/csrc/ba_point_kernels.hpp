@@ -578,6 +578,8 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
 // Per-point linearisation record kept between LM steps (see k_point_damp in ba_schur_tiled.hpp):
 // V_j = sum Jp'Jp (6, symmetric), g_pj = sum Jp'r (3), the point's share of sum rho (1).
 #define RSBA_LIN_STRIDE 10
+// Per-point record the Schur kernel stages (ptdata): X (3), the damped inverse point block (6), V^-1 g_p (3).
+#define RSBA_PT_STRIDE 12
 
 // Observations as the point-centric kernels walk them: sliced ELL.  A slice is 64 consecutive points (one wavefront);
 // slot t of lane l sits at (row_ptr[slice] + t) * 64 + l, slots in camera order, cam < 0 pads a point with fewer views
@@ -609,6 +611,14 @@ struct FusedLin {
   const int* __restrict__ cm_pos;     // sliced slot -> camera-major position (robust loss only)
   double* __restrict__ sq_cm_c;
   long long* trace;                   // diagnostic (RSBA_TRACE=1): [28] workgroup 0 past the solve's flag, [29] result posted
+  // k_backsub_candidate_proj only.  The candidate damped ahead of the decision: an accepted step whose radius update is
+  // clamped (rho >= 0.94, the usual case) continues with radius / (1/3); its damped inverse point blocks, V^-1 g_p and
+  // the per-block scalars — what k_point_damp would compute from lin_c at the head of the next step — are written here,
+  // and the next step starts with the Schur kernel.  nullptr: not this time.
+  double* ptdata_next = nullptr;      // [P][RSBA_PT_STRIDE]
+  double* block_scal_next = nullptr;  // [gridDim.x][4]: cost, |X|^2, singular point blocks, max |g_p|
+  int* small_flag_next = nullptr;     // does any camera of the candidate take the small-angle branch
+  double radius_next = 0.0;
 };
 
 template <bool kStage, bool kFused>
@@ -1013,6 +1023,15 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
     }
   }
   __syncthreads();
+  // the solve's half of the result block, in registers of every workgroup: whoever turns out to be the last one completes
+  // and posts it without another trip to memory for it
+  const double res_pre = (done_cnt != nullptr && tid < RES_SIZE) ? LoadFresh(res + tid) : 0.0;
+  if (fl.small_flag_next != nullptr && blockIdx.x == 0) {
+    int f = 0;
+    for (int c = tid; c < C; c += blockDim.x) f |= LoadFresh(camc_cg + (size_t)c * CC_STRIDE + CC_SMALL) != 0.0 ? 1 : 0;
+    f = __syncthreads_or(f);
+    if (tid == 0) *fl.small_flag_next = f;
+  }
   // (sequential schedule: the kernel boundary has made the solve's output visible; the agent-scope loads cost nothing extra)
   for (int c = tid; c < C; c += blockDim.x) {
     // this camera's column of the constants at x, the camera step, the candidate's constants — all loads first
@@ -1057,18 +1076,21 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
   __syncthreads();
   if (fl.trace != nullptr && blockIdx.x == 0 && tid == 0) fl.trace[32] = wall_clock64();
   const unsigned lx_ad = (unsigned)(size_t)(lds_double*)lx, lc_ad = (unsigned)(size_t)(lds_double*)lc;   // LDS byte addresses
-  double mcc = 0, cost_c = 0, dp2 = 0, xc2 = 0, ss_c = 0;
+  double mcc = 0, cost_c = 0, dp2 = 0, xc2 = 0, ss_c = 0, fail_n = 0, gmax_n = 0;
   for (bool first = true; slice < nslices; slice += 4 * (int)gridDim.x, j = slice * 64 + lane, first = false) {
     if (!first) load_point();
     const int nslot = te - tb;   // the same for the 64 lanes
     bool any = false;
     double bv[3] = {0, 0, 0}, a1 = 0, a2 = 0;
     // pass at x: b = sum Jp' (Jc dc), a1 = sum (Jc dc)' r, a2 = sum |Jc dc|^2
+    // (no branch around a slot: a padding record — cam < 0 — reads camera 0 and its contribution is selected away; with a
+    //  branch per slot the compiler merges the accumulators behind it with ~40 register copies per slot)
     auto at_x = [&](int cam, double2 uv) {
-      if (cam < 0) return;
-      any = true;
+      const bool valid = cam >= 0;
+      if (kLoss && !valid) return;   // (the robust variant has no registers to spare for the select form: it branches)
+      any = any || valid;
       double av[RSBA_PJ_NX];
-      ReadRows26<kCpad>(lx_ad + 8u * (unsigned)cam, av);
+      ReadRows26<kCpad>(lx_ad + 8u * (unsigned)(valid ? cam : 0), av);
 #define RSBA_A(k) av[k]
       const double h0 = fma(RSBA_A(0), X[0], fma(RSBA_A(1), X[1], fma(RSBA_A(2), X[2], RSBA_A(3))));
       const double h1 = fma(RSBA_A(4), X[0], fma(RSBA_A(5), X[1], fma(RSBA_A(6), X[2], RSBA_A(7))));
@@ -1091,13 +1113,15 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
           for (int i = 0; i < 6; ++i) jp[i] *= sq;
         }
       }
+      // every term of the three sums carries e0 or e1
+      e0 = valid ? e0 : 0.0; e1 = valid ? e1 : 0.0;
 #pragma unroll
       for (int a = 0; a < 3; ++a) bv[a] += jp[a] * e0 + jp[3 + a] * e1;
       a1 += e0 * r[0] + e1 * r[1];
       a2 += e0 * e0 + e1 * e1;
     };
 #pragma unroll
-    for (int u = 0; u < RSBA_BS_REG; ++u) { if (u < nslot) at_x(camq[u], uvq[u]); __builtin_amdgcn_sched_barrier(0); }
+    for (int u = 0; u < RSBA_BS_REG; ++u) { at_x(camq[u], uvq[u]); __builtin_amdgcn_sched_barrier(0); }
     {
       const int nl = min(kLds, nslot - RSBA_BS_REG);
 #pragma unroll 1
@@ -1125,15 +1149,16 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
     }
     // pass at the candidate: its cost and its linearisation
     auto at_c = [&](int cam, double2 uv, int t) {
-      if (cam < 0) return;
+      const bool valid = cam >= 0;
+      if (kLoss && !valid) return;
       double av[RSBA_PJ_NC];
-      ReadRows14<kCpad>(lc_ad + 8u * (unsigned)cam, av);
+      ReadRows14<kCpad>(lc_ad + 8u * (unsigned)(valid ? cam : 0), av);
       const double h0 = fma(RSBA_A(0), Xc[0], fma(RSBA_A(1), Xc[1], fma(RSBA_A(2), Xc[2], RSBA_A(3))));
       const double h1 = fma(RSBA_A(4), Xc[0], fma(RSBA_A(5), Xc[1], fma(RSBA_A(6), Xc[2], RSBA_A(7))));
       const double h2 = fma(RSBA_A(8), Xc[0], fma(RSBA_A(9), Xc[1], fma(RSBA_A(10), Xc[2], RSBA_A(11))));
-      const double iz = RcpNewton(h2);
+      const double iz = valid ? RcpNewton(h2) : 0.0;      // a padding record: zero rows, and a zero residual below
       const double pr0 = h0 * iz, pr1 = h1 * iz;
-      double r[2] = {pr0 + RSBA_A(12) - uv.x, pr1 + RSBA_A(13) - uv.y};
+      double r[2] = {valid ? pr0 + RSBA_A(12) - uv.x : 0.0, valid ? pr1 + RSBA_A(13) - uv.y : 0.0};
       double jp[6] = {fma(-pr0, RSBA_A(8), RSBA_A(0)) * iz, fma(-pr0, RSBA_A(9), RSBA_A(1)) * iz, fma(-pr0, RSBA_A(10), RSBA_A(2)) * iz,
                       fma(-pr1, RSBA_A(8), RSBA_A(4)) * iz, fma(-pr1, RSBA_A(9), RSBA_A(5)) * iz, fma(-pr1, RSBA_A(10), RSBA_A(6)) * iz};
 #undef RSBA_A
@@ -1141,8 +1166,9 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
       ss_c += s;
       if (kLoss) {
         double sq;
-        costj_c += LossAndScale(ip.huber_delta, s, &sq);
-        fl.sq_cm_c[fl.cm_pos[(size_t)t * 64 + lane]] = sq;
+        const double rho = LossAndScale(ip.huber_delta, s, &sq);
+        costj_c += valid ? rho : 0.0;
+        if (valid) fl.sq_cm_c[fl.cm_pos[(size_t)t * 64 + lane]] = sq;
         if (sq != 1.0) {
           r[0] *= sq; r[1] *= sq;
 #pragma unroll
@@ -1156,7 +1182,7 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
       gc[0] += jp[0] * r[0] + jp[3] * r[1]; gc[1] += jp[1] * r[0] + jp[4] * r[1]; gc[2] += jp[2] * r[0] + jp[5] * r[1];
     };
 #pragma unroll
-    for (int u = 0; u < RSBA_BS_REG; ++u) { if (u < nslot) at_c(camq[u], uvq[u], tb + u); __builtin_amdgcn_sched_barrier(0); }
+    for (int u = 0; u < RSBA_BS_REG; ++u) { at_c(camq[u], uvq[u], tb + u); __builtin_amdgcn_sched_barrier(0); }
     {
       const int nl = min(kLds, nslot - RSBA_BS_REG);
 #pragma unroll 1
@@ -1172,24 +1198,46 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
 #pragma unroll
       for (int i = 0; i < 6; ++i) ln[i] = Vc[i];
       ln[6] = gc[0]; ln[7] = gc[1]; ln[8] = gc[2]; ln[9] = costj_c;
+      if (fl.ptdata_next != nullptr) {
+        // k_point_damp's arithmetic on the candidate's linearisation, for the radius a clamped update gives
+        const bool anyc = Vc[0] != 0.0 || Vc[3] != 0.0 || Vc[5] != 0.0;
+        double Vn[6];
+        if (!PointBlockInverse(Vc, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, fl.radius_next, Vn)) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) Vn[i] = 0.0;
+          if (anyc) fail_n += 1.0;
+        }
+        double y[3];
+        Sym3MulVec(Vn, gc, y);
+        double* pd = fl.ptdata_next + (size_t)j * RSBA_PT_STRIDE;
+        pd[0] = Xc[0]; pd[1] = Xc[1]; pd[2] = Xc[2];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pd[3 + i] = Vn[i];
+        pd[9] = y[0]; pd[10] = y[1]; pd[11] = y[2];
+        gmax_n = fmax(gmax_n, fmax(fabs(gc[0]), fmax(fabs(gc[1]), fabs(gc[2]))));
+      }
     }
   }
   // block reduction in a fixed order (in the records' LDS, once every wavefront is through with its own), then (single
   // GPU) the last workgroup adds the blocks and posts the result
   if (fl.trace != nullptr && blockIdx.x == 0 && tid == 0) fl.trace[34] = wall_clock64();
-  static_assert(L::kUv >= 5 * 256, "the block sums reuse the records' LDS");
+  static_assert(L::kUv >= 7 * 256, "the block sums reuse the records' LDS");
   __syncthreads();
   double (*s)[256] = reinterpret_cast<double (*)[256]>(lds + L::kTables);
-  s[0][tid] = mcc; s[1][tid] = cost_c; s[2][tid] = dp2; s[3][tid] = xc2; s[4][tid] = ss_c;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) {
+  {
+    // every wavefront its 64 sums by butterfly, thread q the four wavefronts' sums of quantity q
+    const double w7[7] = {WaveSum(mcc), WaveSum(cost_c), WaveSum(dp2), WaveSum(xc2), WaveSum(ss_c), WaveSum(fail_n), WaveMax(gmax_n)};
+    if (lane == 0) {
 #pragma unroll
-      for (int q = 0; q < 5; ++q) s[q][tid] += s[q][tid + off];
+      for (int q = 0; q < 7; ++q) s[q][wv] = w7[q];
     }
-    __syncthreads();
   }
+  __syncthreads();
+  if (tid < 6) s[tid][0] = ((s[tid][0] + s[tid][1]) + s[tid][2]) + s[tid][3];
+  if (tid == 6) s[6][0] = fmax(fmax(s[6][0], s[6][1]), fmax(s[6][2], s[6][3]));
+  __syncthreads();
   if (tid < 5) __hip_atomic_store(&block_part[8 * blockIdx.x + tid], s[tid][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fl.block_scal_next != nullptr && tid < 4) fl.block_scal_next[4 * blockIdx.x + tid] = tid == 0 ? s[1][0] : (tid == 1 ? s[3][0] : (tid == 2 ? s[5][0] : s[6][0]));
   if (done_cnt != nullptr) {
     __shared__ int s_last;
     __builtin_amdgcn_s_waitcnt(0);
@@ -1202,13 +1250,39 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
     if (fl.trace != nullptr && blockIdx.x == 0 && tid == 0) fl.trace[35] = wall_clock64();
     if (s_last) {
       if (fl.trace != nullptr && tid == 0) fl.trace[36] = wall_clock64();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (tid == 0 && wait_timeout != nullptr) {
-        res[RES_WAIT_TIMEOUT] = (double)__hip_atomic_load(wait_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(wait_timeout, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the blocks' sums (agent-scope loads: no fence), thread t blocks t, t + 256, ...; butterflies; four wavefronts
+      double v[5] = {0, 0, 0, 0, 0};
+      for (int b = tid; b < (int)gridDim.x; b += 256) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) v[q] += LoadFresh(block_part + 8 * b + q);
       }
+      const double timed_out = (tid == 0 && wait_timeout != nullptr) ? (double)__hip_atomic_load(wait_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      __syncthreads();   // (s is read above by nobody any more: the block sums went out before the counter)
+#pragma unroll
+      for (int q = 0; q < 5; ++q) { const double w = WaveSum(v[q]); if (lane == 0) s[q][wv] = w; }
+      if (tid == 0) { s[5][0] = timed_out; if (wait_timeout != nullptr) __hip_atomic_store(wait_timeout, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       __syncthreads();
-      FinishCandidateIn(s, (int)gridDim.x, block_part, small_red, res, host, seq);
+      if (tid < RES_SIZE - 1) {
+        // PublishResult's arithmetic, one value per thread, on the copy of the solve's half taken behind the flag
+        const double sm[5] = {((s[0][0] + s[0][1]) + s[0][2]) + s[0][3], ((s[1][0] + s[1][1]) + s[1][2]) + s[1][3], ((s[2][0] + s[2][1]) + s[2][2]) + s[2][3],
+                              ((s[3][0] + s[3][1]) + s[3][2]) + s[3][3], ((s[4][0] + s[4][1]) + s[4][2]) + s[4][3]};
+        if (tid < 5) small_red[tid] = sm[tid];
+        double c = 0.5 * sm[1];
+        if (!(c == c) || !(fabs(c) <= DBL_MAX)) c = DBL_MAX;  // Ceres: failed evaluation -> max double
+        double out = res_pre;
+        if (tid == RES_MCC) out = sm[0];
+        else if (tid == RES_COST_C) out = c;
+        else if (tid == RES_STEP2) out = res_pre + sm[2];
+        else if (tid == RES_XCNORM2) out = res_pre + sm[3];
+        else if (tid == RES_SUMSQ_C) out = sm[4];
+        else if (tid == RES_WAIT_TIMEOUT && wait_timeout != nullptr) out = s[5][0];
+        res[tid] = out;
+        if (host != nullptr) __hip_atomic_store(&host[tid], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (host != nullptr && tid < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: the values before the sequence number
+        if (tid == 0) __hip_atomic_store(&host[RES_SIZE - 1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       if (fl.trace != nullptr && tid == 0) fl.trace[29] = wall_clock64();
     }
   }
@@ -1221,26 +1295,25 @@ __device__ __forceinline__ void PostToHost(const double* __restrict__ res, doubl
 // One workgroup: small_red[0..4] = fixed-order sums of the per-block partials; with res != nullptr (single GPU) the
 // result block is completed and posted to the host straight away.
 // (s: 5 x 256 doubles of LDS the caller can spare)
+// (WaveSum: a butterfly over the 64 lanes, the same value in every lane, a fixed order)
 __device__ __forceinline__ void FinishCandidateIn(double (*s)[256], int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
                                                   double* __restrict__ res, double* host, double seq, const double* res_stall) {
   const int tid = threadIdx.x;
-  double v[5] = {0, 0, 0, 0, 0};
+  // the first four wavefronts add the blocks (thread t: blocks t, t + 256, ...), each wavefront its 64 sums by butterfly,
+  // thread q the four wavefronts' sums of quantity q: two barriers instead of the nine of a 256-wide tree (this runs
+  // behind the last workgroup of the step's last kernel)
   if (tid < 256) {
+    double v[5] = {0, 0, 0, 0, 0};
     for (int i = tid; i < nblocks; i += 256) {
 #pragma unroll
       for (int q = 0; q < 5; ++q) v[q] += block_part[8 * i + q];
     }
 #pragma unroll
-    for (int q = 0; q < 5; ++q) s[q][tid] = v[q];
+    for (int q = 0; q < 5; ++q) { const double w = WaveSum(v[q]); if ((tid & 63) == 0) s[q][tid >> 6] = w; }
   }
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) {
-#pragma unroll
-      for (int q = 0; q < 5; ++q) s[q][tid] += s[q][tid + off];
-    }
-    __syncthreads();
-  }
+  if (tid < 5) s[tid][0] = ((s[tid][0] + s[tid][1]) + s[tid][2]) + s[tid][3];
+  __syncthreads();
   if (tid < 5) small_red[tid] = s[tid][0];
   if (tid == 5 && res_stall != nullptr) small_red[5] = res_stall[RES_STALL];   // summed over the ranks: a stall anywhere is everybody's
   if (res != nullptr) {

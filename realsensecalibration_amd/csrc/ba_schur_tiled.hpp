@@ -48,7 +48,7 @@ class KernelTimer;
 #define RSBA_TG 16          // cameras per group
 #define RSBA_CHUNK 512      // points per LDS chunk
 #define RSBA_CW (RSBA_CHUNK / 64)
-#define RSBA_PT_STRIDE 12   // X(3) Vinv(6) y(3)
+// (RSBA_PT_STRIDE, the record of a point — X(3) Vinv(6) y(3) — is defined in ba_point_kernels.hpp, whose back-substitution writes it too)
 #define RSBA_PART 42        // 36 block + 6 corr
 
 // A segment is a range of 64-point mask words of one tile (not necessarily chunk-aligned: small problems get as many
@@ -93,6 +93,13 @@ struct TiledSchur {
   double* sq_cm2[2] = {nullptr, nullptr};   // [N] each: sqrt(rho') at x / at the candidate (same double buffering as the points)
   double* lin2[2] = {nullptr, nullptr};     // [P][RSBA_LIN_STRIDE] each: V_j (6), g_pj (3), the point's share of sum rho, at x / at the candidate
   bool lin_valid = false;                   // lin2[cur] holds the linearisation of the current x (set by a completed step of this run)
+  // What ptdata / block_scal hold right now: the damped point blocks of state `pt_state` (index into the solver's double
+  // buffers) for trust-region radius `pt_radius`, the per-block scalars in `scal_blocks` blocks.  Written by the point
+  // pass, by the damping kernel — or by the back-substitution, which damps its candidate for the radius an accepted step
+  // with a clamped radius update leads to (three times this step's); the next step then launches no point-side kernel.
+  bool pt_valid = false;
+  int pt_state = -1, scal_blocks = 0;
+  double pt_radius = 0.0;
   double *u_cm = nullptr, *v_cm = nullptr;  // [N] observations in camera-major order (self tiles need the pixel)
   int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
             const std::vector<int>& sliced_q /* sliced slot -> CSR position, -1 pads */, bool staged);

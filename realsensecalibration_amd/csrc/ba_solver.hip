@@ -530,7 +530,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
       (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered_self, (size_t)nblocks_self)) || (rc = DevAlloc(&small_flag, 1)) ||
-      (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * grid_pp)) ||
+      (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * std::max(grid_pp, 2 * cus))) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm2[0], cmpos.size())) || (rc = DevAlloc(&sq_cm2[1], cmpos.size())) ||
       (rc = DevAlloc(&lin2[0], (size_t)P * RSBA_LIN_STRIDE)) || (rc = DevAlloc(&lin2[1], (size_t)P * RSBA_LIN_STRIDE)) ||
@@ -901,6 +901,7 @@ static int ResetPoints(rsba_solver* s) {
   HIPCHK(hipMemcpyAsync(s->pts[0], s->pts0, 3 * (size_t)s->P * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   s->cur = 0;
   s->tiled.lin_valid = false;   // a run starts with a full point pass at the uploaded point
+  s->tiled.pt_valid = false;
   return RSBA_OK;
 }
 
@@ -917,6 +918,7 @@ void TiledSchur::LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTim
     k_point_pass<false><<<grid_pp, 256, lds, st>>>(C, P, s->sliced(), s->camc[x], s->pts[x], s->scale_p, ptdata,
                                                    block_scal, cm_pos, sq_cm2[x], lin2[x], small_flag, ip);
   T.End(st);
+  pt_valid = true; pt_state = x; pt_radius = ip.radius; scal_blocks = grid_pp;
 }
 
 void TiledSchur::LaunchPointDamp(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st) {
@@ -924,14 +926,19 @@ void TiledSchur::LaunchPointDamp(rsba_solver* s, const IterParams& ip, KernelTim
   T.Begin("k_point_damp", st);
   k_point_damp<<<grid_pp, 256, 0, st>>>(P, s->pts[x], s->scale_p, lin2[x], ptdata, block_scal, C, s->camc[x], small_flag, ip, s->trace);
   T.End(st);
+  pt_valid = true; pt_state = x; pt_radius = ip.radius; scal_blocks = grid_pp;
 }
 
 // The point side of a step: a full pass over the observation records only when x has no linearisation yet (the first
 // step of a run, or RSBA_FUSED_LIN=0); otherwise the kept one is damped with this step's radius.
 static void LaunchPointSide(TiledSchur& ts, rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st) {
   RoctxRange rr("K1+K2 point side: residuals, cost, point blocks (or their damping)");
-  if (ts.lin_valid && !ip.first) ts.LaunchPointDamp(s, ip, T, st);
-  else ts.LaunchPointPass(s, ip, T, st);
+  if (ts.lin_valid && !ip.first) {
+    // (nothing to launch when the previous step's back-substitution has left exactly these blocks: k_backsub_candidate_proj)
+    if (!(ts.pt_valid && ts.pt_state == s->cur && ts.pt_radius == ip.radius)) ts.LaunchPointDamp(s, ip, T, st);
+  } else {
+    ts.LaunchPointPass(s, ip, T, st);
+  }
 }
 
 // The Schur elimination launch: self segments first, then the pair tiles stage by stage; results land in s->red.
@@ -943,7 +950,7 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   a.cam_prefix = ts.cam_prefix; a.cam_ptr = ts.cam_ptr; a.sq_cm = ts.sq_cm2[x]; a.u_cm = ts.u_cm; a.v_cm = ts.v_cm; a.partial = ts.partial;
   a.grp_sum = ts.grp_sum; a.sync_cnt = ts.sync_cnt; a.ngrp = ts.ngrp; a.ntiles = ts.ntiles; a.segs_ordered = ts.segs_ordered; a.small_flag = ts.small_flag; a.last_group = ts.ngroups - 1; a.tile_sum = ts.tile_sum;
   a.tree_error = ts.tree_error; a.ticket = ts.tree_error + 1;
-  a.ready = ts.ready; a.tag = tag; a.self_only = 0; { static const int nt = getenv("RSBA_NO_TICKET") ? atoi(getenv("RSBA_NO_TICKET")) : 0; a.no_ticket = nt; } a.red = s->red; a.L = s->L; a.nblocks_pp = ts.grid_pp; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
+  a.ready = ts.ready; a.tag = tag; a.self_only = 0; { static const int nt = getenv("RSBA_NO_TICKET") ? atoi(getenv("RSBA_NO_TICKET")) : 0; a.no_ticket = nt; } a.red = s->red; a.L = s->L; a.nblocks_pp = ts.scal_blocks; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
   a.grp_flag = ts.grp_flag; a.epoch = ++ts.epoch;
   return a;
@@ -1178,7 +1185,8 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   {
     const size_t lds_b = (size_t)C * (2 * RSBA_CC_LDS + 6) * sizeof(double);
     const bool fused = s->opt.schur_impl != 0 && s->fused_lin;
-    const FusedLin fl = fused ? FusedLin{s->tiled.lin2[x], s->tiled.lin2[c], s->tiled.cm_pos, s->tiled.sq_cm2[c], s->trace} : FusedLin{nullptr, nullptr, nullptr, nullptr, s->trace};
+    const FusedLin fl0 = fused ? FusedLin{s->tiled.lin2[x], s->tiled.lin2[c], s->tiled.cm_pos, s->tiled.sq_cm2[c], s->trace} : FusedLin{nullptr, nullptr, nullptr, nullptr, s->trace};
+    const FusedLin& fl = fl0;
     const int* solve_done = pipe ? s->tiled.ready + 15 : nullptr;
     const int solve_tag = s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag;
     long long* waited = pipe && T.all_kernels() ? s->chol_waited + 1 : nullptr;
@@ -1189,7 +1197,22 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (fused && proj_form && C <= 128) {
       // slices of 64 points dealt to two workgroups per CU (k_backsub_candidate_proj); ten slots of a lane's observation
       // records in registers, ten (<= 64 cameras) or six more in LDS, both tables + records <= 72 KB per workgroup
-      grid_bs = std::max(1, std::min(2 * DeviceCUs(), (P + 63) / 64));
+      // (16 fewer than the chip holds: the factorisation's workgroups are resident beside this kernel, and a workgroup that
+      //  has to wait for a slot starts behind the solve, without its records)
+      grid_bs = std::max(1, std::min(2 * DeviceCUs() - 16, (P + 63) / 64));
+      // RSBA_SPEC_DAMP=1: the candidate damped for the radius an accepted step with a clamped update continues with
+      // (MinimizeLoop: radius / max(1/3, ...)), so that the next step launches no point-side kernel.  Off by default: the
+      // damping kernel runs while the host is still launching the factorisation and the Schur kernel, i.e. it is not on
+      // the step's critical path, and the extra work in this kernel is (measured on one box: 0.438 vs 0.431 ms at the
+      // noise floor of a converged run, where half of the steps are rejected; no difference on converging steps)
+      static const bool spec = getenv("RSBA_SPEC_DAMP") && atoi(getenv("RSBA_SPEC_DAMP")) != 0;
+      FusedLin fl = fl0;
+      if (spec) {
+        TiledSchur& ts = s->tiled;
+        fl.ptdata_next = ts.ptdata; fl.block_scal_next = ts.block_scal; fl.small_flag_next = ts.small_flag;
+        fl.radius_next = std::min(s->opt.max_trust_region_radius, ip.radius / (1.0 / 3.0));
+        ts.pt_valid = true; ts.pt_state = c; ts.pt_radius = fl.radius_next; ts.scal_blocks = grid_bs;
+      }
       const bool loss = ip.huber_delta != 0.0;
       if (C <= 64) {
         if (loss) k_backsub_candidate_proj<64, 10, true><<<grid_bs, 256, BacksubProjLds<64, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
