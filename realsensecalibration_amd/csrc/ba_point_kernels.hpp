@@ -59,6 +59,8 @@ enum {
   RES_SUMSQ_C = 9,       // sum of squared raw residuals at the candidate (for the RMS metric)
   RES_STALL = 10,        // pipelined solve only: 1.0 when the Cholesky gave up waiting for its columns
   RES_WAIT_TIMEOUT = 11, // pipelined solve only: 1.0 when the back-substitution gave up waiting for the solve
+  // the trust-region decision as the device took it for the damping kernel queued behind the step (LmNext below)
+  RES_DEC_GO = 12, RES_DEC_ACCEPT = 13, RES_DEC_RADIUS = 14,
   RES_SIZE = 16
 };
 
@@ -601,6 +603,31 @@ __device__ __forceinline__ void FinishCandidate(int nblocks, const double* __res
 __device__ __forceinline__ void FinishCandidateIn(double (*s)[256], int nblocks, const double* __restrict__ block_part, double* __restrict__ small_red,
                                                   double* __restrict__ res, double* host, double seq, const double* res_stall = nullptr);
 
+// The step's accept / reject decision and next radius, taken on the device by the workgroup that completes the result
+// block — the arithmetic of MinimizeLoop, operation for operation and without fused multiply-adds, so that the host, which
+// takes the same decision from the same numbers a few microseconds later, arrives at the same bits.  It exists for ONE
+// consumer: k_point_damp for the NEXT step is queued right behind this step's last kernel and damps the point blocks of
+// whichever state the decision names, while the host is still reading the result and launching the factorisation and
+// the Schur kernel — the damping kernel leaves the step's critical path (~6 us of 0.43 ms).  dec[0] = 1 (go), dec[1] =
+// accepted, dec[2] = next radius; a host that stops, or decides differently, simply does not use what was damped.
+struct LmNext {
+  double* dec = nullptr;     // device, 4 doubles; nullptr: no decision wanted
+  double radius = 0, decrease_factor = 0, min_relative_decrease = 0, max_radius = 0;
+};
+__device__ __forceinline__ void DecideStep(const LmNext& lm, double x_cost, double cand_cost, double mcc, double step2, double chol_ok,
+                                           double* accept, double* next_radius) {
+  const bool solved = chol_ok != 0.0 && isfinite(mcc) && isfinite(step2);
+  *accept = 0.0;
+  *next_radius = __ddiv_rn(lm.radius, lm.decrease_factor);
+  if (!(solved && mcc > 0.0)) return;
+  const double rd = __ddiv_rn(__dsub_rn(x_cost, cand_cost), mcc);
+  if (!(rd > lm.min_relative_decrease)) return;
+  const double t = __dsub_rn(__dmul_rn(2.0, rd), 1.0);
+  const double t3 = __dmul_rn(__dmul_rn(t, t), t);
+  *accept = 1.0;
+  *next_radius = fmin(lm.max_radius, __ddiv_rn(lm.radius, fmax(1.0 / 3.0, __dsub_rn(1.0, t3))));
+}
+
 // kFused (tiled path): the linearisation of the points at x is READ (lin_x: V, g_p as the Schur kernel used them) instead
 // of accumulated again, and the second pass, which evaluates the candidate's residuals anyway, takes the candidate's 2x3
 // blocks along and WRITES its linearisation (lin_c; sqrt(rho') into sq_cm_c): if the step is accepted the next LM
@@ -619,6 +646,7 @@ struct FusedLin {
   double* block_scal_next = nullptr;  // [gridDim.x][4]: cost, |X|^2, singular point blocks, max |g_p|
   int* small_flag_next = nullptr;     // does any camera of the candidate take the small-angle branch
   double radius_next = 0.0;
+  LmNext lm;                          // k_backsub_candidate_proj, single GPU: see LmNext
 };
 
 template <bool kStage, bool kFused>
@@ -1276,8 +1304,25 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
         else if (tid == RES_XCNORM2) out = res_pre + sm[3];
         else if (tid == RES_SUMSQ_C) out = sm[4];
         else if (tid == RES_WAIT_TIMEOUT && wait_timeout != nullptr) out = s[5][0];
-        res[tid] = out;
-        if (host != nullptr) __hip_atomic_store(&host[tid], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (fl.lm.dec != nullptr) s[6][tid] = out;
+        if (fl.lm.dec == nullptr || tid < RES_DEC_GO) {
+          res[tid] = out;
+          if (host != nullptr) __hip_atomic_store(&host[tid], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      if (fl.lm.dec != nullptr) {
+        __syncthreads();
+        if (tid == 0) {
+          double acc, nr;
+          DecideStep(fl.lm, s[6][RES_COST_X], s[6][RES_COST_C], s[6][RES_MCC], s[6][RES_STEP2], s[6][RES_CHOL_OK], &acc, &nr);
+          const double d3[3] = {1.0, acc, nr};
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            fl.lm.dec[q] = d3[q];
+            res[RES_DEC_GO + q] = d3[q];
+            if (host != nullptr) __hip_atomic_store(&host[RES_DEC_GO + q], d3[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
       }
       if (host != nullptr && tid < 64) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: the values before the sequence number

@@ -245,12 +245,22 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
 // radius-dependent part: damped inverse point block, V^-1 g_p, and the per-block scalars the Schur kernel folds.
 // No observation record is read: 29 doubles in, 12 out per point.
 // ------------------------------------------------------------------------------------------------
+// `dec` != nullptr: the kernel was queued behind the PREVIOUS step's last kernel, before the host knew that step's outcome;
+// state and radius are the device's decision (LmNext, ba_point_kernels.hpp): accepted -> the candidate's buffers (the
+// `_c` pointers), rejected -> x's, radius = dec[2]; dec[0] == 0: nothing to do.
 __global__ void __launch_bounds__(256)
-k_point_damp(int P, const double* __restrict__ pts, const double* __restrict__ scale_p, const double* __restrict__ lin,
-             double* __restrict__ ptdata, double* __restrict__ block_scal, int C, const double* __restrict__ camc_g,
-             int* __restrict__ small_flag, IterParams ip, long long* trace = nullptr) {
+k_point_damp(int P, const double* pts_x, const double* __restrict__ scale_p, const double* lin_x,
+             double* __restrict__ ptdata, double* __restrict__ block_scal, int C, const double* camc_x,
+             int* __restrict__ small_flag, IterParams ip, long long* trace = nullptr, const double* __restrict__ dec = nullptr,
+             const double* pts_c = nullptr, const double* lin_c = nullptr, const double* camc_c = nullptr) {
   const int tid = threadIdx.x;
   if (trace != nullptr && blockIdx.x == 0 && tid == 0) trace[30] = wall_clock64();
+  const double *pts = pts_x, *lin = lin_x, *camc_g = camc_x;
+  if (dec != nullptr) {
+    if (dec[0] == 0.0) return;
+    if (dec[1] != 0.0) { pts = pts_c; lin = lin_c; camc_g = camc_c; }
+    ip.radius = dec[2];
+  }
   PublishSmallAngleFlag(C, camc_g, small_flag);
   double cost = 0, xn = 0, fail = 0, gmax = 0;
   for (int j = blockIdx.x * blockDim.x + tid; j < P; j += gridDim.x * blockDim.x) {

@@ -191,7 +191,16 @@ struct rsba_solver {
   long long* chol_waited = nullptr;   // device: ticks the pipelined Cholesky spent waiting for its columns (cumulative)
   long long chol_waited_seen = 0, backsub_waited_seen = 0;   // [1]: the back-substitution's wait for the solve
   long long trace_prev_post = 0;   // RSBA_TRACE=1: device time at which the previous step posted its result
-  long long* trace = nullptr;   // RSBA_TRACE=1: 32 wall-clock stamps of the pipelined step
+  // the trust-region state the device needs to take the step's decision itself (LmNext, ba_point_kernels.hpp): set by
+  // MinimizeLoop before every step; dec: the device's decision block; dec_step: this step queued a damping kernel on it
+  double lm_decrease_factor = 2.0;
+  double* dec = nullptr;
+  bool dec_step = false;
+  long long* trace = nullptr;   // RSBA_TRACE=1: 64 wall-clock stamps of the pipelined step
+  // RSBA_TRACE=3: the stamps of the last 256 steps in a ring (trace points at the current step's 64 slots), nothing is
+  // copied or printed per step — the step's own timing is not disturbed; TraceRingDump prints the gaps at the end of a run
+  long long* trace_base = nullptr;
+  int trace_ring = 0, trace_ring_first_tag = 0;
   std::chrono::steady_clock::time_point host_t[4];
   long long* wg_trace = nullptr;  // RSBA_TRACE=2: per-block stamps of the Schur kernel, dumped to RSBA_TRACE_FILE
   ncclComm_t comm = nullptr;
@@ -580,13 +589,13 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags};
+                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
   s->marker_schur.Free();
   if (s->res_host) (void)hipHostFree(s->res_host);
-  if (s->trace) (void)hipFree(s->trace);
+  if (s->trace_base) (void)hipFree(s->trace_base);
   if (s->wg_trace) (void)hipFree(s->wg_trace);
   if (s->chol_waited) (void)hipFree(s->chol_waited);
   if (s->sB) (void)hipStreamDestroy(s->sB);
@@ -733,7 +742,10 @@ static int UploadPoints(rsba_solver* s) {
   if (s->opt.schur_impl != 0) {
     if (getenv("RSBA_TRACE") && s->nc <= RSBA_CHOL_MAXN) {   // the 32 slots are laid out for at most four stages (64 cameras)
       // diagnostics: wall-clock stamps of the step (1) and of every block of the Schur kernel (2)
-      if (hipMalloc((void**)&s->trace, 64 * sizeof(long long)) != hipSuccess || hipMemset(s->trace, 0, 64 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
+      s->trace_ring = atoi(getenv("RSBA_TRACE")) == 3 ? 256 : 0;
+      const size_t nslot = 64 * (size_t)std::max(1, s->trace_ring);
+      if (hipMalloc((void**)&s->trace, nslot * sizeof(long long)) != hipSuccess || hipMemset(s->trace, 0, nslot * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
+      s->trace_base = s->trace;
       if (atoi(getenv("RSBA_TRACE")) == 2 && hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
     }
     s->pipelined = SetupPipeline(s);
@@ -802,7 +814,7 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(MultiCholPadded(s->nc) + 2) * MultiCholPadded(s->nc))) || (rc = DevAlloc(&s->W, s->nc > RSBA_CHOL_MAXN ? (size_t)(s->nc + 1) * s->nc : 1)) ||
       (rc = DevAlloc(&s->chol_ok, 3)) ||
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
-      (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)))
+      (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)) || (rc = DevAlloc(&s->dec, 4)))
     return rc;
   HIPCHK(hipMemset(s->res, 0, RES_SIZE * sizeof(double)));   // (not every path writes every field: RES_STALL above 64 cameras)
   HIPCHK(hipMemset(s->small_red, 0, 8 * sizeof(double)));
@@ -986,6 +998,29 @@ int TiledSchur::Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T) {
 // posts (PostToHost).  After 2 s of polling the stream that POSTS the result is synchronised (the in-kernel waits give up
 // after RSBA_STALL_TICKS, ten times that in the multi-GPU pipeline, so the synchronisation returns); a dead queue cannot
 // spin us forever.
+// RSBA_TRACE=3: the step-to-step gaps of the run's last steps, from the ring of device stamps (no per-step copies).
+static void TraceRingDump(rsba_solver* s) {
+  if (!s->trace_ring || !s->trace_base || s->trace_ring_first_tag == 0) return;
+  if (hipStreamSynchronize(s->stream) != hipSuccess) return;
+  std::vector<long long> h((size_t)64 * s->trace_ring);
+  if (hipMemcpy(h.data(), s->trace_base, h.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+  const int last = s->step_tag, first = std::max(s->trace_ring_first_tag + 1, last - s->trace_ring + 2);
+  std::vector<double> period, head, tail, damp_gap;
+  for (int t = first; t <= last; ++t) {
+    const long long* a = &h[(size_t)64 * ((t - 1) % s->trace_ring)];
+    const long long* b = &h[(size_t)64 * (t % s->trace_ring)];
+    if (a[24] == 0 || b[24] == 0 || a[29] == 0) continue;
+    period.push_back((b[24] - a[24]) * 0.01);          // first Schur block of one step -> of the next
+    head.push_back((b[24] - a[29]) * 0.01);            // result posted -> first Schur block of the next step
+    tail.push_back((a[29] - a[15]) * 0.01);            // the solve's end -> result posted (back-substitution)
+    if (b[31] > a[29]) damp_gap.push_back((b[31] - a[29]) * 0.01);   // result posted -> the damping kernel's end
+  }
+  auto med = [](std::vector<double> v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+  fprintf(stderr, "rsba[ring] %zu steps: period %.1f us = first tile block -> solve end ... -> result posted (%.1f after the solve) -> next first tile block %.1f"
+                  " (damping kernel done %.1f after the post)\n", period.size(), med(period), med(tail), med(head), med(damp_gap));
+  s->trace_ring_first_tag = 0;
+}
+
 static int WaitResult(rsba_solver* s, hipStream_t posting) {
   s->res_seq += 1.0;
   volatile double* seq = s->res_host + (RES_SIZE - 1);
@@ -1024,6 +1059,10 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   DebugSync(st, "k_camera_constants");
   const bool pipe = s->pipelined && s->opt.schur_impl != 0 && !keep_system_copy;
   ++s->step_tag;
+  if (s->trace_ring) {
+    if (s->trace_ring_first_tag == 0) s->trace_ring_first_tag = s->step_tag;
+    s->trace = s->trace_base + 64 * (size_t)(s->step_tag % s->trace_ring);
+  }
   // impl 0 accumulates into `red` with atomics; the tiled path writes every entry of it exactly once
   if (s->opt.schur_impl == 0) HIPCHK(hipMemsetAsync(s->red, 0, s->L.size() * sizeof(double), st));
   DebugSync(st, "memset red");
@@ -1213,6 +1252,15 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
         fl.radius_next = std::min(s->opt.max_trust_region_radius, ip.radius / (1.0 / 3.0));
         ts.pt_valid = true; ts.pt_state = c; ts.pt_radius = fl.radius_next; ts.scal_blocks = grid_bs;
       }
+      // single GPU: the workgroup that completes the result block takes the step's decision as well, and the damping
+      // kernel of the NEXT step is queued right here, behind this kernel, on that decision (LmNext; RSBA_DECIDED_DAMP=0:
+      // the host launches it once it has decided itself)
+      static const bool decided = !(getenv("RSBA_DECIDED_DAMP") && atoi(getenv("RSBA_DECIDED_DAMP")) == 0);
+      s->dec_step = decided && !spec && fin_cnt != nullptr;
+      if (s->dec_step) {
+        fl.lm.dec = s->dec; fl.lm.radius = ip.radius; fl.lm.decrease_factor = s->lm_decrease_factor;
+        fl.lm.min_relative_decrease = s->opt.min_relative_decrease; fl.lm.max_radius = s->opt.max_trust_region_radius;
+      }
       const bool loss = ip.huber_delta != 0.0;
       if (C <= 64) {
         if (loss) k_backsub_candidate_proj<64, 10, true><<<grid_bs, 256, BacksubProjLds<64, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
@@ -1233,6 +1281,15 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (fused) s->tiled.lin_valid = true;
   }
   T.End(st);
+  if (s->dec_step) {
+    TiledSchur& ts = s->tiled;
+    IterParams ipn = ip; ipn.first = 0;
+    T.Begin("k_point_damp", st);
+    k_point_damp<<<ts.grid_pp, 256, 0, st>>>(P, s->pts[x], s->scale_p, ts.lin2[x], ts.ptdata, ts.block_scal, C, s->camc[x], ts.small_flag, ipn, s->trace,
+                                             s->dec, s->pts[c], ts.lin2[c], s->camc[c]);
+    T.End(st);
+    ts.pt_valid = false;   // (until the decision is in: below)
+  }
   rr_k5.End();
   DebugSync(st, "k_backsub_candidate");
   if (s->comm) {
@@ -1257,12 +1314,19 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   if (s->trace) s->host_t[2] = std::chrono::steady_clock::now();
   RoctxRange rr_k6("K6 LM bookkeeping: wait for the step's result block");
   { const int rcw = WaitResult(s, s->comm && pipe && s->pipelined_mg ? s->sR : st); if (rcw != RSBA_OK) return rcw; }
-  if (s->trace) {
+  if (s->trace && !s->trace_ring) {
     const auto now = std::chrono::steady_clock::now();
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     fprintf(stderr, "rsba[host] since previous result %.1f us | enter -> point pass launched %.1f -> all launched %.1f -> result %.1f\n",
             us(s->host_t[3], s->host_t[0]), us(s->host_t[0], s->host_t[1]), us(s->host_t[1], s->host_t[2]), us(s->host_t[2], now));
     s->host_t[3] = now;
+  }
+  if (s->dec_step) {
+    // the damping kernel queued behind the step has damped (or is damping) the state and radius of the device's decision
+    TiledSchur& ts = s->tiled;
+    const double* r = s->res_host;
+    ts.pt_valid = r[RES_DEC_GO] != 0.0; ts.pt_state = r[RES_DEC_ACCEPT] != 0.0 ? c : x; ts.pt_radius = r[RES_DEC_RADIUS]; ts.scal_blocks = ts.grid_pp;
+    s->dec_step = false;
   }
   if (pipe && T.all_kernels()) {
     // the Cholesky's event span includes the time it slept on the ready flags: record that separately
@@ -1272,7 +1336,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     T.Add("k_backsub_candidate:waiting", (w[1] - s->backsub_waited_seen) * 1e-5);
     s->chol_waited_seen = w[0]; s->backsub_waited_seen = w[1];
   }
-  if (s->trace && s->opt.schur_impl != 0) {
+  if (s->trace && !s->trace_ring && s->opt.schur_impl != 0) {
     long long h[64];
     HIPCHK(hipMemcpy(h, s->trace, sizeof(h), hipMemcpyDeviceToHost));
     const long long t0 = h[24];
@@ -1320,6 +1384,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
     s->chol_wgs = 1;
+    s->tiled.pt_valid = false;
     return PointsStep(s, radius, first, keep_system_copy);
   }
   if (pipe && (s->res_host[RES_STALL] != 0.0 || s->res_host[RES_WAIT_TIMEOUT] != 0.0)) {
@@ -1331,6 +1396,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     HIPCHK(hipMemset(s->tiled.tree_error + 1, 0, sizeof(int)));
     if (s->mc_flags) HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
     s->pipelined = false; s->pipelined_mg = false;
+    s->tiled.pt_valid = false;
     return PointsStep(s, radius, first, keep_system_copy);
   }
   return RSBA_OK;
@@ -1442,6 +1508,7 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
       if (!x_moved && gmax <= o.gradient_tolerance) return finish(RSBA_CONVERGENCE, RSBA_STOP_GRADIENT);
       if (radius < o.min_trust_region_radius) return finish(RSBA_CONVERGENCE, RSBA_STOP_MIN_RADIUS);
     }
+    s->lm_decrease_factor = decrease_factor;
     int rc = step(radius, first);
     if (rc != RSBA_OK) return rc;
     const double* r = s->res_host;
@@ -1489,7 +1556,10 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
       accept();
       x_cost = cand_cost;  // re-evaluated by the next linearisation (settle_moved); kept for the summary if we stop here
       s->final_sumsq = r[RES_SUMSQ_C];
-      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+      // (2 rho - 1)^3 as two products: the device takes the same decision from the same numbers for the damping kernel it
+      // has queued (DecideStep, ba_point_kernels.hpp) and has to arrive at the same bits; std::pow may differ in the last one
+      const double t = 2.0 * it.relative_decrease - 1.0;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - (t * t) * t);
       radius = std::min(o.max_trust_region_radius, radius);
       decrease_factor = 2.0;
       it.step_is_successful = 1; it.cost = cand_cost; it.trust_region_radius = radius;
@@ -1595,6 +1665,7 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
     rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { cur_radius = radius; return rsba::PointsStep(s, radius, first, false); },
                             [&]() { s->cur = 1 - s->cur; }, [&]() { return rsba::PointsGradient(s, cur_radius); });
     sum.minimizer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    rsba::TraceRingDump(s);
     if (rc == RSBA_OK && s->tiled.tree_error) {
       // a reducer workgroup of the Schur kernel gave up waiting for its tile (cannot happen by construction): the sums
       // it produced are garbage, so is the result

@@ -15,6 +15,7 @@ unset RSBA_PIPELINE
 python3 tools/pmc_to_json.py gpurun_out/prof_pmc_fetch gpurun_out/prof_pmc_write gpurun_out/r02_pmc.json
 python3 tools/pmc_summary.py gpurun_out/prof_pmc_fetch gpurun_out/prof_pmc_write gpurun_out/prof_pmc_sq gpurun_out/prof_pmc_sq2 > gpurun_out/r02_pmc_summary.txt
 cp $(ls gpurun_out/prof_kt/*/*kernel_stats.csv | head -1) gpurun_out/r02_kernel_stats.csv
+python3 tools/kernel_gaps.py gpurun_out/prof_kt > gpurun_out/r02_step_gaps.txt
 tail -1 gpurun_out/prof_kt.json > gpurun_out/r02_bench_under_rocprof.json
 # marker-chain model at scale (time-block elimination): kernel trace of tools/marker_chain_scale.py
 rm -rf gpurun_out/prof_mc
