@@ -80,7 +80,22 @@ struct StageGate {
   long long* trace;   // diagnostic (RSBA_TRACE=1): wall-clock stamps of the waits, nullptr otherwise
   long long budget;   // ticks a wait may last before the kernel gives up (0: RSBA_STALL_TICKS); the multi-GPU pipeline waits
                       // for other ranks' collectives and gets ten times as long
+  // "every workgroup of this kernel is resident": the last one to start writes `tag` into the host's pinned word.  The host
+  // waits for it before it launches the Schur kernel on the first step of a run (see PointsStep): the first launch on the
+  // side stream was measured to start ~150 us late, and a factorisation that is not resident when the chip fills up does
+  // not get a CU with enough LDS until the back-substitution — which waits for it — has left.
+  int* started_cnt = nullptr;    // device
+  int* started_host = nullptr;   // pinned host memory
+  int started_need = 0;          // workgroups of the kernel
 };
+
+__device__ __forceinline__ void AnnounceResident(const StageGate& gate) {
+  if (gate.started_host == nullptr || threadIdx.x != 0) return;
+  if (__hip_atomic_fetch_add(gate.started_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gate.started_need - 1) {
+    __hip_atomic_store(gate.started_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(gate.started_host, gate.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 
 // Spin (one lane, sleeping between polls) until *flag == tag; false when the producer does not show up in
 // RSBA_STALL_TICKS of the 100 MHz wall clock — the caller gives up instead of hanging the queue.

@@ -409,6 +409,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   double* PreN = PreB;       // the next one, built during this panel
   if (tid == 0) { s_ok = 1; s_wb = 0; s_w7ok = 1; s_fdone = 0; }
   if (gate.trace && tid == 0 && w == 0) gate.trace[0] = wall_clock64();
+  AnnounceResident(gate);
   bool stalled = false;
   const double* S = red + L.S();
   const double inv_radius = 1.0 / ip.radius;

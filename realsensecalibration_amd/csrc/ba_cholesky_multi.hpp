@@ -144,6 +144,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
                                            // (up to six 16 x 32) and of the look-ahead product (eight 16 x 16)
   if (tid == 0) { s_ok = 1; s_wb = 0; }
   if (gate.trace && tid == 0 && w == 0) gate.trace[0] = wall_clock64();
+  AnnounceResident(gate);
   bool stalled = false;
   const double* S = red + L.S();
   const double inv_radius = 1.0 / ip.radius;

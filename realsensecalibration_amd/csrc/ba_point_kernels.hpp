@@ -504,6 +504,7 @@ k_reduced_system_solve(int C, double* __restrict__ red, RedLayout L, double* __r
   const bool gated = gate.ready != nullptr;
   if (gated) {
     if (gate.trace && tid == 0) gate.trace[0] = wall_clock64();
+    AnnounceResident(gate);
     if (ip.first) {
       for (int g = 0; g * gate.cols < n; ++g)
         if (!WaitReady(gate.ready + 1 + g, gate.tag, gate.waited, gate.budget)) { if (tid == 0) res[RES_STALL] = 1.0; SolveDone(gate); return; }

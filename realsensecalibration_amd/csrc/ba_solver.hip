@@ -196,6 +196,11 @@ struct rsba_solver {
   double lm_decrease_factor = 2.0;
   double* dec = nullptr;
   bool dec_step = false;
+  // pipelined schedule: steps that timed out (the step is repeated sequentially; the third time-out ends the pipelined
+  // schedule for this solver), and "the next pipelined step waits until the factorisation is resident" (first step of a
+  // run, first step after a time-out)
+  int pipe_stalls = 0;
+  bool pipe_check_resident = false;
   long long* trace = nullptr;   // RSBA_TRACE=1: 64 wall-clock stamps of the pipelined step
   // RSBA_TRACE=3: the stamps of the last 256 steps in a ring (trace points at the current step's 64 slots), nothing is
   // copied or printed per step — the step's own timing is not disturbed; TraceRingDump prints the gaps at the end of a run
@@ -539,7 +544,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
       (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered_self, (size_t)nblocks_self)) || (rc = DevAlloc(&small_flag, 1)) ||
-      (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 16)) || (rc = DevAlloc(&block_scal, (size_t)4 * std::max(grid_pp, 2 * cus))) ||
+      (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 24)) || (rc = DevAlloc(&block_scal, (size_t)4 * std::max(grid_pp, 2 * cus))) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm2[0], cmpos.size())) || (rc = DevAlloc(&sq_cm2[1], cmpos.size())) ||
       (rc = DevAlloc(&lin2[0], (size_t)P * RSBA_LIN_STRIDE)) || (rc = DevAlloc(&lin2[1], (size_t)P * RSBA_LIN_STRIDE)) ||
@@ -554,7 +559,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   HIPCHK(hipMemset(sync_cnt, 0, (size_t)nsync * sizeof(int)));
   HIPCHK(hipMemset(grp_flag, 0, (size_t)std::max(ngrp, 1) * sizeof(int)));
   HIPCHK(hipMemset(tree_error, 0, 2 * sizeof(int)));   // [0] error flag, [1] ticket counter of the Schur kernel
-  HIPCHK(hipMemset(ready, 0, 16 * sizeof(int)));
+  HIPCHK(hipMemset(ready, 0, 24 * sizeof(int)));   // [0] unused, [1 + g] stage g published, [15] the solve's done flag, [16] its started counter
   HIPCHK(hipMemcpy(block_seg, border.data(), border.size() * sizeof(int), hipMemcpyHostToDevice));
   {
     for (size_t q = 0; q < sg.size(); ++q) sg[q].index = (int)q;
@@ -1100,24 +1105,40 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // multi-GPU: the gates open on the flags the communication stream publishes after each stage's all-reduce, the
     // panels are read from the (all-reduced) row slab of their own group, and the waits may last as long as the slowest rank
     RoctxRange rr_k4("K4 reduced camera system: Cholesky + solve (launched ahead, gated on the Schur stages)");
+    // First step of a run: the Schur kernel is not launched before every workgroup of the factorisation is resident (its
+    // last workgroup to start writes the tag into a pinned word, StageGate).  The first launch on the side stream was
+    // measured to start ~150 us behind the main stream's kernels; a factorisation that arrives when the chip is full does
+    // not find a CU with enough LDS until the Schur kernel AND the back-substitution — whose workgroups hold their CUs
+    // while they wait for the solve — have left: with few points the step timed out (and fell back to the sequential
+    // schedule for good) in three of four solver lifetimes.  Later steps launch the factorisation ~5 us ahead on an idle
+    // stream.
+    const int gate_tag = s->test_stall == 1 ? tag + 1 : tag;
+    int* resident_word = (ip.first || s->pipe_check_resident) ? reinterpret_cast<int*>(s->res_host + RES_SIZE) : nullptr;
+    s->pipe_check_resident = false;
     T.Begin("k_reduced_system_solve", s->sB);
     if (s->chol_wgs > 1 && !mg && s->chol_diag)
       k_reduced_system_solve_diag<<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
-          StageGate{ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0},
+          StageGate{ts.ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0, ts.ready + 16, resident_word, s->chol_wgs},
           DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024}, tag, s->mc_trace);
     else if (s->chol_wgs > 1 && !mg)
       k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
-          StageGate{ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0},
+          StageGate{ts.ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0, ts.ready + 16, resident_word, s->chol_wgs},
           MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48}, tag, s->mc_trace);
     else
     k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                      s->camc[c], s->dcam, s->gmax, s->res, ip, (mg || getenv("RSBA_TRANSPOSED_SOURCE")) ? 2 : 1,
-                                                     s->chol_ok, StageGate{mg ? s->ready_global : ts.ready, s->test_stall == 1 ? tag + 1 : tag, 6 * RSBA_TG, ts.ready + 15,
-                                                                           T.all_kernels() ? s->chol_waited : nullptr, s->trace, mg ? 10 * RSBA_STALL_TICKS : 0});
+                                                     s->chol_ok, StageGate{mg ? s->ready_global : ts.ready, gate_tag, 6 * RSBA_TG, ts.ready + 15,
+                                                                           T.all_kernels() ? s->chol_waited : nullptr, s->trace, mg ? 10 * RSBA_STALL_TICKS : 0,
+                                                                           ts.ready + 16, resident_word, 1});
     T.End(s->sB);
     rr_k4.End();
+    if (resident_word != nullptr) {
+      volatile int* w = resident_word;
+      const auto t_res = std::chrono::steady_clock::now();
+      while (*w != gate_tag && std::chrono::steady_clock::now() - t_res < std::chrono::milliseconds(20)) __builtin_ia32_pause();
+    }
     ts.LaunchTiles(s, ip, T, st, tag);
     if (mg) {
       // communication stream: stage by stage, as the Schur kernel publishes them locally — the row slab of S of the
@@ -1390,14 +1411,21 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   if (pipe && (s->res_host[RES_STALL] != 0.0 || s->res_host[RES_WAIT_TIMEOUT] != 0.0)) {
     // the waiting Cholesky never saw its columns (its producers were not running beside it): nothing of x has been
     // touched, so repeat the step with the plain schedule and stay there
-    fprintf(stderr, "rsba: pipelined solve stalled; falling back to the sequential schedule\n");
+    fprintf(stderr, "rsba: pipelined solve stalled (step %d: %s); falling back to the sequential schedule%s\n", s->step_tag,
+            s->res_host[RES_STALL] != 0.0 ? "the factorisation gave up waiting for its columns" : "the back-substitution gave up waiting for the solve",
+            s->pipe_stalls + 1 < 3 && !s->test_stall ? " for this step" : "");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(s->tiled.sync_cnt, 0, (size_t)s->tiled.nsync * sizeof(int)));
     HIPCHK(hipMemset(s->tiled.tree_error + 1, 0, sizeof(int)));
     if (s->mc_flags) HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
+    // the repeat runs sequentially; a solver that has timed out three times stays there
+    ++s->pipe_stalls;
+    const bool was_mg = s->pipelined_mg;
     s->pipelined = false; s->pipelined_mg = false;
     s->tiled.pt_valid = false;
-    return PointsStep(s, radius, first, keep_system_copy);
+    const int rc_rep = PointsStep(s, radius, first, keep_system_copy);
+    if (s->pipe_stalls < 3 && !s->test_stall) { s->pipelined = true; s->pipelined_mg = was_mg; s->pipe_check_resident = true; }
+    return rc_rep;
   }
   return RSBA_OK;
 }
@@ -1632,7 +1660,8 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
     }
     s->comm = it->second;
   }
-  if (hipHostMalloc((void**)&s->res_host, RES_SIZE * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { rsba::FreeSolver(s); return RSBA_ERR_HIP; }
+  if (hipHostMalloc((void**)&s->res_host, (RES_SIZE + 8) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { rsba::FreeSolver(s); return RSBA_ERR_HIP; }
+  memset(s->res_host, 0, (RES_SIZE + 8) * sizeof(double));   // [RES_SIZE]: the factorisation's "resident" word (StageGate)
   if (p->model == RSBA_MODEL_POINTS) rc = rsba::UploadPoints(s);
   else {
     s->eliminate_times = rsba::MarkerSchurDevice::Wanted(*p, opt.schur_impl);
