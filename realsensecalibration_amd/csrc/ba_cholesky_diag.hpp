@@ -92,6 +92,7 @@ struct DiagConst {
   int n, nreal, SLD, tag, gate_tag, gate_cols, gated;
   lds_double* Bst; lds_double* t_tile[2]; lds_double* xprev; lds_double* scl;
   lds_int* s_wb; lds_int* ok_lds;
+  lds_int* acq;   // [0]: the newest block some update wave has claimed to acquire for the workgroup, [1]: the newest one acquired
   long long* tr;
 };
 typedef __attribute__((address_space(3))) const DiagConst lds_DiagConst;
@@ -119,22 +120,31 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
   // 1. the block's flag (at the last panel: the right-hand-side row's, which still comes solved), and the camera group of block
   // p + 1's own columns of S (a stage of the Schur kernel; the row workgroups wait for it too).  Every wave looks for itself:
   // normally both are up and nobody waits for anybody.
+  // One wave acquires for the workgroup (caches are per CU and per XCD: WaitFlagWG, ba_cholesky_multi.hpp): the first to get
+  // here claims block p + 1, looks for the flags and issues the one agent-scope acquire; the others wait for it in LDS.
   if (lane == 0) {
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(dc->rows_ready + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
-      __builtin_amdgcn_s_sleep(2);
-      if (__hip_atomic_load(dc->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > dc->budget) { __hip_atomic_store(ok_lds, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
-    }
-    if (do_unit && dc->gated && nb0 % dc->gate_cols == 0) {
-      const long long t1 = wall_clock64();
-      while (__hip_atomic_load(dc->gate_ready + 1 + nb0 / dc->gate_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != dc->gate_tag) {
-        __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t1 > (dc->gate_budget > 0 ? dc->gate_budget : RSBA_STALL_TICKS)) { __hip_atomic_store(ok_lds, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+    const int want = p + 1;
+    if (__hip_atomic_fetch_max(dc->acq, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(dc->rows_ready + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__hip_atomic_load(dc->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > dc->budget) { __hip_atomic_store(ok_lds, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
       }
+      if (do_unit && dc->gated && nb0 % dc->gate_cols == 0) {
+        const long long t1 = wall_clock64();
+        while (__hip_atomic_load(dc->gate_ready + 1 + nb0 / dc->gate_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != dc->gate_tag) {
+          __builtin_amdgcn_s_sleep(16);
+          if (wall_clock64() - t1 > (dc->gate_budget > 0 ? dc->gate_budget : RSBA_STALL_TICKS)) { __hip_atomic_store(ok_lds, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(dc->acq + 1, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      while (__hip_atomic_load(dc->acq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
     }
   }
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   if (tr && wk == 0 && lane == 0) tr[2] = wall_clock64();
   if (!do_unit) { meet(wb_target); meet(wb_target + 6); meet(wb_target + 12); return; }   // (the last panel: the caller goes on to the right-hand-side row, barrier [A] is his)
   // 2. everything in one round trip
@@ -393,7 +403,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   const int G = gridDim.x, w = blockIdx.x;
   const int np = n / RSBA_PB;              // column panels; blocks 0 .. np (block np: the rhs row alone, workgroup 0's)
   const long long budget = gate.budget > 0 ? gate.budget : RSBA_STALL_TICKS;
-  __shared__ int s_ok, s_wb, s_w7ok, s_fdone;
+  __shared__ int s_ok, s_wb, s_w7ok, s_fdone, s_acq[2];
   int wb_gen = 0;
   // LDS: strip (32 p rows of 33) | this workgroup's blocks of the panel (32 x 33 each) | T | Lt | Xl | invd | scale | Pre | Pre2 | scratch
   const int max_rows = n + RSBA_PB;
@@ -407,7 +417,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   double* scratch = PreB + RSBA_PB * RSBA_PLD;     // 1024 doubles
   double* Pre = PreA;        // the diagonal block being factored
   double* PreN = PreB;       // the next one, built during this panel
-  if (tid == 0) { s_ok = 1; s_wb = 0; s_w7ok = 1; s_fdone = 0; }
+  if (tid == 0) { s_ok = 1; s_wb = 0; s_w7ok = 1; s_fdone = 0; s_acq[0] = -1; s_acq[1] = -1; }
   if (gate.trace && tid == 0 && w == 0) gate.trace[0] = wall_clock64();
   AnnounceResident(gate);
   bool stalled = false;
@@ -482,7 +492,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     s_dc.n = n; s_dc.nreal = nreal; s_dc.SLD = n - 30; s_dc.tag = tag; s_dc.gate_tag = gate.tag; s_dc.gate_cols = gate.cols;
     s_dc.gated = (gate.ready != nullptr && !ip.first) ? 1 : 0;
     s_dc.Bst = (lds_double*)lds; s_dc.t_tile[0] = (lds_double*)T; s_dc.t_tile[1] = (lds_double*)(lds + (size_t)32 * (n - 30) + RSBA_PB * RSBA_PLD); s_dc.xprev = (lds_double*)(lds + (n - 30 - RSBA_PB)); s_dc.scl = (lds_double*)scl;
-    s_dc.s_wb = (lds_int*)&s_wb; s_dc.ok_lds = (lds_int*)&s_w7ok;
+    s_dc.s_wb = (lds_int*)&s_wb; s_dc.ok_lds = (lds_int*)&s_w7ok; s_dc.acq = (lds_int*)&s_acq[0];
     s_dc.tr = mtrace;
   }
   __syncthreads();

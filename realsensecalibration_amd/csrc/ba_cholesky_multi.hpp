@@ -49,9 +49,15 @@ __device__ __forceinline__ bool WaitFlagWG(const int* flag, int tag, const int* 
       if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > budget) { ok = 0; break; }
     }
     s_ok2 = ok;
+    // ONE acquire for the workgroup, by the wavefront that saw the flag: the invalidate it issues (buffer_inv sc1) empties
+    // this CU's L1 and the XCD's L2 of what other workgroups have rewritten — caches all wavefronts of the workgroup share —
+    // and the barrier orders everybody's loads behind it.  Every wavefront issuing its own (eight per wait, two waits per
+    // panel and workgroup) cost the factorisation ~0.25 us per wait: an acquire fence alone is 90 ns on an idle chip
+    // (tools/lat_bench.hip), and they queue.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   return s_ok2 != 0;
 }
 
