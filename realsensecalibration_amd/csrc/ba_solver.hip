@@ -1018,7 +1018,10 @@ static void TraceRingDump(rsba_solver* s) {
     period.push_back((b[24] - a[24]) * 0.01);          // first Schur block of one step -> of the next
     head.push_back((b[24] - a[29]) * 0.01);            // result posted -> first Schur block of the next step
     tail.push_back((a[29] - a[15]) * 0.01);            // the solve's end -> result posted (back-substitution)
-    if (b[31] > a[29]) damp_gap.push_back((b[31] - a[29]) * 0.01);   // result posted -> the damping kernel's end
+    // result posted -> the damping kernel's end: queued behind the step on the device's decision it stamps into the step's own
+    // window, launched by the host for the next step into that one's
+    if (a[31] > a[29]) damp_gap.push_back((a[31] - a[29]) * 0.01);
+    else if (b[31] > a[29]) damp_gap.push_back((b[31] - a[29]) * 0.01);
   }
   auto med = [](std::vector<double> v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
   fprintf(stderr, "rsba[ring] %zu steps: period %.1f us = first tile block -> solve end ... -> result posted (%.1f after the solve) -> next first tile block %.1f"
