@@ -133,11 +133,21 @@ def main():
     # negative tolerances: no convergence test can fire (0 would still stop on a bitwise-equal candidate cost)
     fixed = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
                  max_num_consecutive_invalid_steps=1 << 30, min_trust_region_radius=0.0)
-    # W warm-up iterations on the solver that is timed (same device buffers, same streams), then its options are set for
-    # the timed run: HIP events only around the kernel the roofline is quoted on (on every fourth step); the full
-    # per-kernel table comes from an identical K-step pass right after it, outside the timed region
-    sv_k = capi.Solver(problem, options(max_num_iterations=max(args.warmup, 1), **fixed))
+    # One solver for all of it (same device buffers, same streams, one communicator), three runs back to back:
+    #   1. the per-kernel pass: K iterations with HIP events around every launch (not timed; its table fills "kernels"),
+    #   2. W warm-up iterations,
+    #   3. the timed run: K iterations, events only around the kernel the roofline is quoted on, on every fourth step.
+    # The per-kernel pass comes FIRST so that the GPU has been under load for K + W steps when the timed region starts: after
+    # the host-side set-up the clocks take ~10-30 ms of work to come up (an iteration measured 0.455 ms in the first ten
+    # steps behind an idle gap and 0.415 ms forty steps later, tools/run_overhead.py), and with the pass behind the timed
+    # region a short timed region (--steps 20 --warmup 5) sat entirely inside that ramp.
+    sv_k = capi.Solver(problem, options(max_num_iterations=args.steps, profile_kernels=0 if args.no_events else 1, **fixed))
+    stats = {}
+    if not args.no_events:
+        sv_k.run()
+        stats = sv_k.kernel_stats()
     if args.warmup > 0:
+        sv_k.configure_run(args.warmup, 0)
         s_w = sv_k.run()
         assert s_w.num_iterations == args.warmup, (s_w.num_iterations, args.warmup)
     sv_k.configure_run(args.steps, 0 if args.no_events else 2)
@@ -164,12 +174,7 @@ def main():
     assert s_k.num_iterations == args.steps, (s_k.num_iterations, args.steps)
     stats_timed = sv_k.kernel_stats()
     sv_k.close()
-    stats = {}
     if not args.no_events:
-        sv_p = capi.Solver(problem, options(max_num_iterations=args.steps, profile_kernels=1, **fixed))
-        sv_p.run()
-        stats = sv_p.kernel_stats()
-        sv_p.close()
         stats.update(stats_timed)  # the roofline kernels: durations measured inside the timed region
 
     if rank != 0:
@@ -202,7 +207,7 @@ def main():
         waiting = {n.split(":")[0]: v for n, v in stats.items() if n.endswith(":waiting")}
         spans = {n: v for n, v in stats.items() if not n.endswith(":waiting")}
         # averages first (a kernel's span and its waiting may come from different passes: the timed pass records only the
-        # two roofline kernels, the repeat pass all of them), then own work = average span - average waiting
+        # two roofline kernels, the per-kernel pass all of them), then own work = average span - average waiting
         def avg(v):
             return v[1] / max(v[0], 1)
         stats = {n: (c, c * (avg((c, ms)) - avg(waiting[n]))) if n in waiting else (c, ms) for n, (c, ms) in spans.items()}
@@ -264,12 +269,12 @@ def main():
                                                  "frac_of_8TBps": b_iter / it_s / 1e9 / HBM_PEAK_GBS}
         rest = sorted(order[1:], key=lambda kv: -per[kv[0]][1] * max(1.0, round(kv[1][0] / float(args.steps))))  # the others by plain duration per iteration
         out["roofline_other_kernels"] = [roof(n) for n, _ in rest[:3]]
-        out["kernels"] = {n: {"launches": int(c), "avg_us": 1e3 * a, "measured": "timed region" if n in stats_timed else "repeat pass"}
+        out["kernels"] = {n: {"launches": int(c), "avg_us": 1e3 * a, "measured": "timed region" if n in stats_timed else "per-kernel pass"}
                           for n, (c, a) in sorted(per.items())}
         out["kernel_timing"] = ("HIP events on the launching stream; in the timed region only the dominant kernel (k_schur_tiles) is "
                                 "recorded, on every fourth LM step (an event record costs ~10 us of host time between two launches, "
-                                "which is on the critical path of a 0.43 ms step); the other kernels come from an identical repeat pass "
-                                "with every launch recorded")
+                                "which is on the critical path of a 0.43 ms step); the other kernels come from an identical K-step pass "
+                                "with every launch recorded, run on the same solver before the warm-up")
         for n, (c, ms) in waiting.items():
             if n not in out["kernels"]:
                 continue
