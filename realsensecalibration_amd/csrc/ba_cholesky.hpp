@@ -87,6 +87,10 @@ struct StageGate {
   int* started_cnt = nullptr;    // device
   int* started_host = nullptr;   // pinned host memory
   int started_need = 0;          // workgroups of the kernel
+  // first iteration of a run, pipelined: = tag once every camera's diag U is written (the Schur kernel ran every self tile
+  // first) — the Jacobi scale can be formed and the panels gated stage by stage like in every other iteration; nullptr: the
+  // first iteration waits for all stages
+  const int* all_diag = nullptr;
 };
 
 __device__ __forceinline__ void AnnounceResident(const StageGate& gate) {

@@ -425,19 +425,23 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   const double inv_radius = 1.0 / ip.radius;
   const int mi = lane & 15, kk = lane >> 4;
 
+  // gated stage by stage: every iteration but a run's first — and the first one too when the Schur kernel ran every self
+  // tile ahead of the pair tiles and says so (gate.all_diag)
+  const bool staged = gate.ready != nullptr && (!ip.first || gate.all_diag != nullptr);
   // warm the factorisation's code while there is nothing to do (see ba_cholesky_multi.hpp)
-  if (gate.ready != nullptr && !ip.first && w == 0) {
+  if (staged && w == 0) {
     for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) { const int r = e >> 5, c = e & 31; Pre[r * RSBA_PLD + c] = r == c ? 1.0 : 0.0; }
     __syncthreads();
     if (wave == 0) (void)DiagFactorInverseCall((lds_double*)Pre, RSBA_PB, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane);
     __syncthreads();
   }
   // pipelined first iteration: the Jacobi scale needs the whole damping diagonal
-  if (gate.ready != nullptr && ip.first) {
+  if (gate.ready != nullptr && ip.first && !staged) {
     for (int g = 0; g * gate.cols < nreal; ++g)
       if (!WaitReady(gate.ready + 1 + g, gate.tag, w == 0 ? gate.waited : nullptr, gate.budget)) { stalled = true; break; }
-  } else if (gate.ready != nullptr && w == 0) {
-    if (!WaitReady(gate.ready + 1, gate.tag, gate.waited, gate.budget)) stalled = true;   // workgroup 0 starts with S(0, 0)
+  } else if (staged) {
+    if (ip.first && !WaitReady(gate.all_diag, gate.tag, w == 0 ? gate.waited : nullptr, gate.budget)) stalled = true;   // every workgroup: the scales
+    if (!stalled && w == 0 && !WaitReady(gate.ready + 1, gate.tag, gate.waited, gate.budget)) stalled = true;   // workgroup 0 starts with S(0, 0)
   }
   if (!stalled) {
     for (int i = tid; i < n; i += nt) {
@@ -490,7 +494,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     s_dc.budget = budget; s_dc.gate_budget = gate.budget;
     s_dc.min_diag = ip.min_lm_diagonal; s_dc.max_diag = ip.max_lm_diagonal; s_dc.inv_radius = inv_radius;
     s_dc.n = n; s_dc.nreal = nreal; s_dc.SLD = n - 30; s_dc.tag = tag; s_dc.gate_tag = gate.tag; s_dc.gate_cols = gate.cols;
-    s_dc.gated = (gate.ready != nullptr && !ip.first) ? 1 : 0;
+    s_dc.gated = staged ? 1 : 0;
     s_dc.Bst = (lds_double*)lds; s_dc.t_tile[0] = (lds_double*)T; s_dc.t_tile[1] = (lds_double*)(lds + (size_t)32 * (n - 30) + RSBA_PB * RSBA_PLD); s_dc.xprev = (lds_double*)(lds + (n - 30 - RSBA_PB)); s_dc.scl = (lds_double*)scl;
     s_dc.s_wb = (lds_int*)&s_wb; s_dc.ok_lds = (lds_int*)&s_w7ok; s_dc.acq = (lds_int*)&s_acq[0];
     s_dc.tr = mtrace;
@@ -746,7 +750,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         for (int e = tid; e < 12 * 256; e += nt) dtile[e] = 0.0;
       }
       RSBA_DC_STAMP(3);
-      if (gate.ready != nullptr && kb % gate.cols == 0 && !ip.first) {
+      if (staged && kb % gate.cols == 0) {
         if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
       }
       {

@@ -92,6 +92,8 @@ struct TiledSchur {
   int* cm_pos = nullptr;                    // [rows*64] observation (sliced layout, see ObsSliced) -> camera-major position
   double* sq_cm2[2] = {nullptr, nullptr};   // [N] each: sqrt(rho') at x / at the candidate (same double buffering as the points)
   double* lin2[2] = {nullptr, nullptr};     // [P][RSBA_LIN_STRIDE] each: V_j (6), g_pj (3), the point's share of sum rho, at x / at the candidate
+  bool has_first_order = false;
+  SchurSeg* segs_ordered_first = nullptr;   // the work list of a run's FIRST step (pipelined): every self tile ahead of the pair tiles
   bool lin_valid = false;                   // lin2[cur] holds the linearisation of the current x (set by a completed step of this run)
   // What ptdata / block_scal hold right now: the damped point blocks of state `pt_state` (index into the solver's double
   // buffers) for trust-region radius `pt_radius`, the per-block scalars in `scal_blocks` blocks.  Written by the point
@@ -111,7 +113,7 @@ struct TiledSchur {
   void LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
   // the point pass of a step whose x already has its linearisation in lin2[cur] (every step but a run's first)
   void LaunchPointDamp(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
-  void LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag);
+  void LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag, bool first_staged = false);
   // the self tiles only: cost, g_c, max |g_p| at x (what HandleSuccessfulStep evaluates at the new point); S is not formed
   void LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
   void Free();
@@ -509,6 +511,16 @@ __device__ __forceinline__ bool StageArrive(const SchurSeg& sg, int* __restrict_
   return s_last != 0;
 }
 
+// A self tile is finished (its diag U, g_c, diagonal block are written and — StageArrive's fence, pipelined schedule —
+// visible): the last of the ngroups self tiles publishes ready[9].  Thread 0 only; call behind StageArrive.
+__device__ __forceinline__ void SelfTileArrive(int* __restrict__ sync_cnt, int ngrp, int ntiles, int ngroups, int* __restrict__ ready, int tag) {
+  int* cnt = sync_cnt + ngrp + ntiles + 15;
+  if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) {
+    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ready[9], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Self tile: lane (ia, s) holds slice s of camera 16 ga + ia's 42 sums in v[]; called by the whole workgroup (shuffles).
 // Adds the 16 slices in a fixed tree order, then K factors, diagonal S block, diag(U), g_c and the rhs correction.
 __device__ __forceinline__ void FinishSelfSlot(int C, int ga, double* v, const double* __restrict__ camc, double* __restrict__ red, RedLayout L,
@@ -632,6 +644,8 @@ struct SchurArgs {
   double* __restrict__ grp_sum;
   int* __restrict__ sync_cnt;
   int ngrp, ntiles, last_group;
+  int all_self;                    // 1: the self tiles' finishers count themselves and the last one publishes ready[9] (first step: every
+                                   // camera's diag U is known -> the factorisation's Jacobi scale, see TiledSchur::segs_ordered_first)
   const SchurSeg* __restrict__ segs_ordered;   // the work list in launch order
   const int* __restrict__ small_flag;          // see TiledSchur::small_flag
   int* __restrict__ ready;
@@ -951,7 +965,9 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   FinishSelfSlot(C, sg.ga, v, camc, a.red, a.L, a.cam_free);
   if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
   if (a.self_only) return;
-  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
+  const bool stage_done = StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0);
+  if (a.all_self && a.tag && tid == 0) SelfTileArrive(a.sync_cnt, a.ngrp, a.ntiles, a.last_group + 1, a.ready, a.tag);
+  if (!stage_done) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
@@ -1040,7 +1056,9 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
     for (int i = 0; i < 36; ++i) v[i] = ts[i * 256];
     FinishPairSlot(a.C, sg.ga, sg.gb, tid, v, a.camc, a.red, a.L, a.cam_free);
   }
-  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
+  const bool stage_done = StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0);
+  if (sg.self == 3 && a.all_self && a.tag && tid == 0) SelfTileArrive(a.sync_cnt, a.ngrp, a.ntiles, a.last_group + 1, a.ready, a.tag);
+  if (!stage_done) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }

@@ -532,6 +532,25 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     for (int q = 0; q < nseg; ++q) border.push_back(q);   // segments are stored pair tiles first, self tiles after them
     for (int t = 0; t < ntiles; ++t) for (int q : red_of_tile[t]) border.push_back(q);
   }
+  // First step of a run (pipelined): every self tile ahead of the pair tiles, their reducers right behind them — every
+  // camera's diag U is then known early (ready[9]), the factorisation forms its Jacobi scale and is gated stage by stage like
+  // in every other iteration instead of waiting for the last stage.
+  std::vector<int> border_first;
+  if (staged) {
+    std::vector<std::pair<double, int>> ord;
+    for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2]) for (int q = tsp[t]; q < tsp[t + 1]; ++q) ord.push_back({(q - tsp[t] + 0.5) / (tsp[t + 1] - tsp[t]), q});
+    std::stable_sort(ord.begin(), ord.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+    for (const auto& o : ord) border_first.push_back(o.second);
+    for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2]) for (int q : red_of_tile[t]) border_first.push_back(q);
+    for (int g = 0; g < nstages; ++g) {
+      std::vector<std::pair<double, int>> op;
+      for (int t = stage_tile[g]; t < stage_tile[g + 1]; ++t) for (int q = tsp[t]; q < tsp[t + 1]; ++q) op.push_back({(q - tsp[t] + 0.5) / (tsp[t + 1] - tsp[t]), q});
+      std::stable_sort(op.begin(), op.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+      for (const auto& o : op) border_first.push_back(o.second);
+      for (int t = stage_tile[g]; t < stage_tile[g + 1]; ++t) for (int q : red_of_tile[t]) border_first.push_back(q);
+    }
+    if ((int)border_first.size() != nblocks) border_first.clear();   // (cannot happen)
+  }
   std::vector<int> border_self;
   for (int q = 0; q < nseg; ++q) if (sg[q].self == 1) border_self.push_back(q);
   for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2]) for (int q : red_of_tile[t]) border_self.push_back(q);
@@ -543,7 +562,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   if ((rc = DevAlloc(&cam_mask, mask.size())) || (rc = DevAlloc(&segs, (size_t)nblocks)) ||
       (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
-      (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered_self, (size_t)nblocks_self)) || (rc = DevAlloc(&small_flag, 1)) ||
+      (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered_first, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered_self, (size_t)nblocks_self)) || (rc = DevAlloc(&small_flag, 1)) ||
       (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 24)) || (rc = DevAlloc(&block_scal, (size_t)4 * std::max(grid_pp, 2 * cus))) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm2[0], cmpos.size())) || (rc = DevAlloc(&sq_cm2[1], cmpos.size())) ||
@@ -567,6 +586,12 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     for (size_t b = 0; b < border.size(); ++b) ord[b] = sg[border[b]];
     for (size_t b = 0; b < border_self.size(); ++b) ord_self[b] = sg[border_self[b]];
     HIPCHK(hipMemcpy(segs_ordered, ord.data(), ord.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
+    has_first_order = !border_first.empty();
+    if (has_first_order) {
+      std::vector<SchurSeg> ordf(border_first.size());
+      for (size_t b = 0; b < border_first.size(); ++b) ordf[b] = sg[border_first[b]];
+      HIPCHK(hipMemcpy(segs_ordered_first, ordf.data(), ordf.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(segs_ordered_self, ord_self.data(), ord_self.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(small_flag, 0, sizeof(int)));
   }
@@ -583,7 +608,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, segs_ordered, segs_ordered_self, small_flag, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm};
+  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, segs_ordered, segs_ordered_first, segs_ordered_self, small_flag, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   cam_mask = nullptr;
 }
@@ -970,12 +995,14 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   a.ready = ts.ready; a.tag = tag; a.self_only = 0; { static const int nt = getenv("RSBA_NO_TICKET") ? atoi(getenv("RSBA_NO_TICKET")) : 0; a.no_ticket = nt; } a.red = s->red; a.L = s->L; a.nblocks_pp = ts.scal_blocks; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
   a.grp_flag = ts.grp_flag; a.epoch = ++ts.epoch;
+  a.all_self = 0;
   return a;
 }
 
-void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag) {
+void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag, bool first_staged) {
   RoctxRange rr("K2+K3 camera-side rows + Schur elimination into the reduced system");
-  const SchurArgs a = MakeSchurArgs(*this, s, tag);
+  SchurArgs a = MakeSchurArgs(*this, s, tag);
+  if (first_staged) { a.segs_ordered = segs_ordered_first; a.all_self = 1; }
   T.Begin("k_schur_tiles", st);
   if (ip.huber_delta != 0.0) k_schur_tiles<true><<<nblocks, 256, 0, st>>>(a);
   else k_schur_tiles<false><<<nblocks, 256, 0, st>>>(a);
@@ -1116,13 +1143,18 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // schedule for good) in three of four solver lifetimes.  Later steps launch the factorisation ~5 us ahead on an idle
     // stream.
     const int gate_tag = s->test_stall == 1 ? tag + 1 : tag;
+    // the first step of a run gated stage by stage too (diagonal-workgroup factorisation only): the Schur kernel runs every
+    // self tile first and publishes ready[9] when all cameras' diag U are written (RSBA_FIRST_STAGED=0: wait for all stages)
+    static const bool first_staged_on = !(getenv("RSBA_FIRST_STAGED") && atoi(getenv("RSBA_FIRST_STAGED")) == 0);
+    const bool first_staged = ip.first && first_staged_on && ts.has_first_order && s->chol_wgs > 1 && !mg && s->chol_diag;
+    const int* all_diag = first_staged ? ts.ready + 9 : nullptr;
     int* resident_word = (ip.first || s->pipe_check_resident) ? reinterpret_cast<int*>(s->res_host + RES_SIZE) : nullptr;
     s->pipe_check_resident = false;
     T.Begin("k_reduced_system_solve", s->sB);
     if (s->chol_wgs > 1 && !mg && s->chol_diag)
       k_reduced_system_solve_diag<<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
-          StageGate{ts.ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0, ts.ready + 16, resident_word, s->chol_wgs},
+          StageGate{ts.ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0, ts.ready + 16, resident_word, s->chol_wgs, all_diag},
           DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024}, tag, s->mc_trace);
     else if (s->chol_wgs > 1 && !mg)
       k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
@@ -1142,7 +1174,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       const auto t_res = std::chrono::steady_clock::now();
       while (*w != gate_tag && std::chrono::steady_clock::now() - t_res < std::chrono::milliseconds(20)) __builtin_ia32_pause();
     }
-    ts.LaunchTiles(s, ip, T, st, tag);
+    ts.LaunchTiles(s, ip, T, st, tag, first_staged);
     if (mg) {
       // communication stream: stage by stage, as the Schur kernel publishes them locally — the row slab of S of the
       // stage's camera group (complete once the stage is: the mirror blocks in it were written by earlier stages) and
