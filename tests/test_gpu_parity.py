@@ -94,6 +94,15 @@ def test_solve_matches_oracle(oracle, impl, C, P, k, seed):
     _compare_solve(oracle, syn.make_problem(C, P, k, seed=seed), impl)
 
 
+@pytest.mark.parametrize("C,P,k,huber", [(40, 2500, 30, 0.0), (40, 2500, 30, 1.5), (96, 2000, 24, 0.0), (96, 2000, 24, 1.5), (128, 1500, 14, 0.0)])
+def test_back_substitution_record_paths(oracle, C, P, k, huber):
+    """k_backsub_candidate_proj keeps ten observation records of a point in registers and ten (up to 64 cameras) or six (up to
+    128) in LDS; the records beyond that are streamed.  30 views at 40 cameras and 24 views at 96 cameras go through all three
+    paths, with and without the robust loss (a template parameter of the kernel); 128 cameras is the largest problem it takes."""
+    prob = syn.make_problem(C, P, k, seed=300 + C, outlier_frac=0.05 if huber else 0.0)
+    _compare_solve(oracle, prob, 1, huber=huber, modulo_gauge=True)
+
+
 @pytest.mark.parametrize("impl", IMPLS)
 def test_config2_full_size(oracle, impl):
     """BASELINE.json configs[1]: 8 cams x 10k points, 80k observations."""
