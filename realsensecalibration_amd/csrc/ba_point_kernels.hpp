@@ -953,7 +953,7 @@ struct BacksubProjLds {
 // workgroups per CU every CU gets six or seven wavefronts of work; one workgroup per 256 points is 1.5 per CU, i.e. half
 // the CUs with twice the LDS traffic of the others.
 template <int kCpad, int kLds, bool kLoss>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, kCpad <= 128 ? 2 : 1)
 k_backsub_candidate_proj(int C, int P, ObsSliced obs,
                          const double* __restrict__ camc_xg, const double* __restrict__ camc_cg,
                          const double* __restrict__ dcam_g, const double* __restrict__ pts_x, double* __restrict__ pts_c,

@@ -1289,12 +1289,14 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
                           s->res, s->res_host, s->res_seq + 1.0, solve_done, solve_tag, waited, s->chol_ok + 2, fl
     // (RSBA_BACKSUB_PROJ=0: the form that reads the camera constants themselves, for comparison)
     static const bool proj_form = !(getenv("RSBA_BACKSUB_PROJ") && atoi(getenv("RSBA_BACKSUB_PROJ")) == 0);
-    if (fused && proj_form && C <= 128) {
+    if (fused && proj_form && C <= 256) {
       // slices of 64 points dealt to two workgroups per CU (k_backsub_candidate_proj); ten slots of a lane's observation
-      // records in registers, ten (<= 64 cameras) or six more in LDS, both tables + records <= 72 KB per workgroup
+      // records in registers, ten (<= 64 cameras) or six (<= 128) more in LDS, both tables + records <= 72 KB per workgroup;
+      // up to 256 cameras one workgroup per CU (tables 80 KB + ten LDS slots)
       // (16 fewer than the chip holds: the factorisation's workgroups are resident beside this kernel, and a workgroup that
       //  has to wait for a slot starts behind the solve, without its records)
-      grid_bs = std::max(1, std::min(2 * DeviceCUs() - 16, (P + 63) / 64));
+      // (more than 128 cameras: the tables alone are 80 KB, one workgroup per CU)
+      grid_bs = std::max(1, std::min(C <= 128 ? 2 * DeviceCUs() - 16 : DeviceCUs() - 8, (P + 63) / 64));
       // RSBA_SPEC_DAMP=1: the candidate damped for the radius an accepted step with a clamped update continues with
       // (MinimizeLoop: radius / max(1/3, ...)), so that the next step launches no point-side kernel.  Off by default: the
       // damping kernel runs while the host is still launching the factorisation and the Schur kernel, i.e. it is not on
@@ -1317,13 +1319,28 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
         fl.lm.dec = s->dec; fl.lm.radius = ip.radius; fl.lm.decrease_factor = s->lm_decrease_factor;
         fl.lm.min_relative_decrease = s->opt.min_relative_decrease; fl.lm.max_radius = s->opt.max_trust_region_radius;
       }
+      // (more than 48 KB of dynamic LDS has to be asked for, once per kernel)
+      static const bool lds_attr_set = []() {
+        bool ok = true;
+        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<64, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<64, 10>::kBytes) == hipSuccess && ok;
+        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<64, 10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<64, 10>::kBytes) == hipSuccess && ok;
+        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<128, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<128, 6>::kBytes) == hipSuccess && ok;
+        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<128, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<128, 6>::kBytes) == hipSuccess && ok;
+        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<256, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<256, 10>::kBytes) == hipSuccess && ok;
+        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<256, 10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<256, 10>::kBytes) == hipSuccess && ok;
+        return ok;
+      }();
+      if (!lds_attr_set) return RSBA_ERR_HIP;
       const bool loss = ip.huber_delta != 0.0;
       if (C <= 64) {
         if (loss) k_backsub_candidate_proj<64, 10, true><<<grid_bs, 256, BacksubProjLds<64, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
         else k_backsub_candidate_proj<64, 10, false><<<grid_bs, 256, BacksubProjLds<64, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
-      } else {
+      } else if (C <= 128) {
         if (loss) k_backsub_candidate_proj<128, 6, true><<<grid_bs, 256, BacksubProjLds<128, 6>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
         else k_backsub_candidate_proj<128, 6, false><<<grid_bs, 256, BacksubProjLds<128, 6>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
+      } else {
+        if (loss) k_backsub_candidate_proj<256, 10, true><<<grid_bs, 256, BacksubProjLds<256, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
+        else k_backsub_candidate_proj<256, 10, false><<<grid_bs, 256, BacksubProjLds<256, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
       }
     } else if (lds_b <= 60 * 1024) {
       if (fused) k_backsub_candidate<true, true><<<s->grid_pts, 256, lds_b, st>>>(RSBA_BACKSUB_ARGS);
