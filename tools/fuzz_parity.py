@@ -34,8 +34,14 @@ for i in range(ncase):
     rel = block_rel(got, ref, C)
     rel_al = block_rel(gauge.align(got, ref, C)[0], ref, C) if rel >= 1e-6 else rel
     cost_rel = abs(s_got.final_cost - s_ref.final_cost) / s_ref.final_cost
+    # where the two trajectories part: relative difference of the iterates' costs at iterations 1..3 and the first iteration
+    # it exceeds 1e-9 (a defect shows at once; rounding amplified along flat directions shows late and grows gradually)
+    m = min(len(log_got), len(log_ref))
+    dc = np.abs(log_got[:m, 1] - log_ref[:m, 1]) / np.maximum(np.abs(log_ref[:m, 1]), 1e-300)
+    part = next((j for j in range(m) if dc[j] > 1e-9), -1)
+    early = dc[1:4].max() if m > 1 else 0.0
     good = ok and rel_al < 1e-6 and rel < 1e-3 and cost_rel < 1e-9
     bad += 0 if good else 1
-    print("%3d C=%3d P=%4d k=%2d huber=%.1f iters %2d raw %.1e aligned %.1e cost %.1e %s" % (i, C, P, k, huber, s_got.num_iterations, rel, rel_al, cost_rel, "ok" if good else "MISMATCH"), flush=True)
+    print("%3d C=%3d P=%4d k=%2d huber=%.1f iters %2d raw %.1e aligned %.1e cost %.1e | iterates' costs: first 3 %.0e, part at %d %s" % (i, C, P, k, huber, s_got.num_iterations, rel, rel_al, cost_rel, early, part, "ok" if good else "MISMATCH"), flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
