@@ -23,6 +23,13 @@ print("stage: first start .. last start | last end")
 for s in np.unique(d[:, 4]):
     m = d[:, 4] == s
     print("  %d: %.1f .. %.1f | %.1f" % (s, st[m].min(), st[m].max(), en[m].max()))
+# the tail of a stage: from the moment its last compute entry has stored its partial sums (group sums, reducers, tile
+# finishers and the stage's publication are what follows) to the end of its last entry (= the publication)
+print("stage tails (last compute entry's sums stored -> last entry of the stage ends):")
+for s in np.unique(d[:, 4]):
+    m = d[:, 4] == s
+    comp = m & (d[:, 3] < 2)
+    print("  %d: sums stored %.1f -> published %.1f  = %.1f us" % (s, ce[comp].max(), en[m].max(), en[m].max() - ce[comp].max()))
 print("entries running at t (us):", " ".join("%d:%d" % (t, ((st <= t) & (en > t)).sum()) for t in range(20, int(en.max()), 40)))
 order_s, order_e = np.sort(st), np.sort(en)
 nslots = int(((st <= 20) & (en > 20)).sum())
