@@ -73,30 +73,68 @@ RSBA_HD void CameraConstants(const double* cam6, const double* intr4, double* cc
   for (int i = CC_SMALL + 1; i < CC_STRIDE; ++i) cc[i] = 0.0;
 }
 
+// 1 / x for the depth of a point in a camera.  Device: v_rcp_f64 and two Newton steps, five instructions where the IEEE
+// division sequence (scale, rcp, two Newton steps, quotient, residual, fmas, fixup) is eleven; within an ulp of it.
+RSBA_HD double RcpNewton(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+#else
+  return 1.0 / x;
+#endif
+}
+
+// t^3 rounded once (to within 0.5 + 2^-50 ulp): the products' rounding errors are recovered with fused multiply-adds and added
+// back.  Ceres' radius update is radius / max(1/3, 1 - pow(2 rho - 1, 3)) (trust_region_minimizer.cc; the oracle calls
+// std::pow); glibc's pow is correctly rounded, a device pow is not the same function, and (t * t) * t carries two roundings.
+// This sequence is the same on the host (MinimizeLoop) and on the device (DecideStep) and gives pow's bits
+// (tests/test_host_math.py::test_cube_is_pow).
+RSBA_HD double Cube(double t) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const double t2 = t * t;
+  const double e = fma(t, t, -t2);     // t^2 = t2 + e exactly
+  const double p = t2 * t;
+  const double e2 = fma(t2, t, -p);    // t2 t = p + e2 exactly
+  return p + fma(e, t, e2);
+}
+
+// THE residual of one observation: p = R X + t, iz = 1 / p2, r = (fx p0 iz + ppx - u, fy p1 iz + ppy - v), as ONE fixed
+// sequence of roundings (every fused multiply-add is written out, so the compiler's contraction has nothing to decide).
+// Every kernel whose residual enters a gradient calls this function: g_c and the right-hand side in the Schur kernel's self
+// tiles, g_p and sqrt(rho') in the point pass and in the back-substitution's pass over the candidate (whose linearisation is
+// the next iteration's).  With every block free (Test1_BundleAdjustment/main.cpp:76-79) the cost has a 7-dof gauge orbit, the
+// gradient is orthogonal to it only if g_c and g_p are sums over the SAME residuals, and at a trust-region radius of 1e11 a
+// mismatch of a few ulps of the projection (~1e-13 px, coherent over a camera's observations) between the kernel that forms
+// g_c and the one that forms g_p is amplified into a drift of 1e-5 along the orbit (measured: the round-2 back-substitution
+// formed p from rows pre-multiplied by fx; tests/test_gpu_parity.py::test_huber_and_rejected_steps, raw parameters).
+RSBA_HD void ProjectResidual(const double* R, const double* t, double fx, double fy, double ppx, double ppy, const double X[3],
+                             double u, double v, double p[3], double* iz_out, double r[2]) {
+  p[0] = fma(R[0], X[0], fma(R[1], X[1], fma(R[2], X[2], t[0])));
+  p[1] = fma(R[3], X[0], fma(R[4], X[1], fma(R[5], X[2], t[1])));
+  p[2] = fma(R[6], X[0], fma(R[7], X[1], fma(R[8], X[2], t[2])));
+  const double iz = RcpNewton(p[2]);
+  *iz_out = iz;
+  r[0] = fma(fx * p[0], iz, ppx) - u;
+  r[1] = fma(fy * p[1], iz, ppy) - v;
+}
+
 // Residual only (operator()<double>), used for the candidate cost.
 RSBA_HD void Residual(const double* cc, const double X[3], double u, double v, double r[2]) {
-  const double q0 = cc[CC_R + 0] * X[0] + cc[CC_R + 1] * X[1] + cc[CC_R + 2] * X[2];
-  const double q1 = cc[CC_R + 3] * X[0] + cc[CC_R + 4] * X[1] + cc[CC_R + 5] * X[2];
-  const double q2 = cc[CC_R + 6] * X[0] + cc[CC_R + 7] * X[1] + cc[CC_R + 8] * X[2];
-  const double p0 = q0 + cc[CC_T + 0], p1 = q1 + cc[CC_T + 1], p2 = q2 + cc[CC_T + 2];
-  const double iz = 1.0 / p2;
-  r[0] = cc[CC_FX] * p0 * iz + cc[CC_PPX] - u;
-  r[1] = cc[CC_FY] * p1 * iz + cc[CC_PPY] - v;
+  double p[3], iz;
+  ProjectResidual(cc + CC_R, cc + CC_T, cc[CC_FX], cc[CC_FY], cc[CC_PPX], cc[CC_PPY], X, u, v, p, &iz, r);
 }
 
 // Residual + the point-side Jacobian block only (2x3 row-major): what the linearisation of a point needs of an
 // observation (V = sum Jp'Jp, g_p = sum Jp'r); same arithmetic as ResidualJacobian.
 RSBA_HD void ResidualPointJacobian(const double* cc, const double X[3], double u, double v, double r[2], double jp[6]) {
   const double* R = cc + CC_R;
-  const double q0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
-  const double q1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
-  const double q2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
-  const double p0 = q0 + cc[CC_T + 0], p1 = q1 + cc[CC_T + 1], p2 = q2 + cc[CC_T + 2];
-  const double iz = 1.0 / p2;
-  r[0] = cc[CC_FX] * p0 * iz + cc[CC_PPX] - u;
-  r[1] = cc[CC_FY] * p1 * iz + cc[CC_PPY] - v;
+  double p[3], iz;
+  ProjectResidual(R, cc + CC_T, cc[CC_FX], cc[CC_FY], cc[CC_PPX], cc[CC_PPY], X, u, v, p, &iz, r);
   const double al = cc[CC_FX] * iz, be = cc[CC_FY] * iz;
-  const double ga = -al * p0 * iz, de = -be * p1 * iz;
+  const double ga = -al * p[0] * iz, de = -be * p[1] * iz;
   jp[0] = al * R[0] + ga * R[6]; jp[1] = al * R[1] + ga * R[7]; jp[2] = al * R[2] + ga * R[8];
   jp[3] = be * R[3] + de * R[6]; jp[4] = be * R[4] + de * R[7]; jp[5] = be * R[5] + de * R[8];
 }
@@ -109,10 +147,9 @@ RSBA_HD void ResidualJacobian(const double* cc, const double X[3], double u, dou
   const double q0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
   const double q1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
   const double q2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
-  const double p0 = q0 + cc[CC_T + 0], p1 = q1 + cc[CC_T + 1], p2 = q2 + cc[CC_T + 2];
-  const double iz = 1.0 / p2;
-  r[0] = cc[CC_FX] * p0 * iz + cc[CC_PPX] - u;
-  r[1] = cc[CC_FY] * p1 * iz + cc[CC_PPY] - v;
+  double p[3], iz;
+  ProjectResidual(R, cc + CC_T, cc[CC_FX], cc[CC_FY], cc[CC_PPX], cc[CC_PPY], X, u, v, p, &iz, r);
+  const double p0 = p[0], p1 = p[1];
   const double al = cc[CC_FX] * iz, be = cc[CC_FY] * iz;
   const double ga = -al * p0 * iz, de = -be * p1 * iz;
   // d r / d X = Pj R

@@ -624,7 +624,7 @@ __device__ __forceinline__ void DecideStep(const LmNext& lm, double x_cost, doub
   const double rd = __ddiv_rn(__dsub_rn(x_cost, cand_cost), mcc);
   if (!(rd > lm.min_relative_decrease)) return;
   const double t = __dsub_rn(__dmul_rn(2.0, rd), 1.0);
-  const double t3 = __dmul_rn(__dmul_rn(t, t), t);
+  const double t3 = Cube(t);
   *accept = 1.0;
   *next_radius = fmin(lm.max_radius, __ddiv_rn(lm.radius, fmax(1.0 / 3.0, __dsub_rn(1.0, t3))));
 }
@@ -882,16 +882,10 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
 // Same sums, same order over a point's observations; the results differ from the other form in the last bits only.
 // ------------------------------------------------------------------------------------------------
 #define RSBA_PJ_NX 26      // rows of the table at x: A (12), B (12), ppx, ppy
-#define RSBA_PJ_NC 14      // rows of the table at the candidate: A (12), ppx, ppy
-#define RSBA_BS_REG 10     // observation records a lane keeps in registers (both passes read them from there) ...
+#define RSBA_PJ_NC 16      // rows of the table at the candidate: R (9), t (3), fx, fy, ppx, ppy — ProjectResidual's operands
+#define RSBA_BS_REG_LOSS 7  // observation records a lane of a robust instance keeps in registers (ten without a loss)
 
-// 1 / x: v_rcp_f64 and two Newton steps, five instructions where the IEEE division sequence (scale, rcp, two Newton steps,
-// quotient, residual, fmas, fixup) is eleven; within an ulp or two of it.
-__device__ __forceinline__ double RcpNewton(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return fma(fma(-x, r, 1.0), r, r);
-}
+// (1 / x: RcpNewton, ba_math.hpp)
 
 // Loads of what the solve has just published (camera step, candidate's camera constants): agent scope, so that they
 // are served by the memory side without an acquire fence — a fence per workgroup invalidates the XCD's L2 each time, and
@@ -920,12 +914,12 @@ __device__ __forceinline__ void ReadRows26(unsigned ad, double* a) {
                "+v"(a[22]), "+v"(a[23]), "+v"(a[24]), "+v"(a[25]));
 }
 template <int kCpad>
-__device__ __forceinline__ void ReadRows14(unsigned ad, double* a) {
+__device__ __forceinline__ void ReadRows16(unsigned ad, double* a) {
   RSBA_LDS_RD(a[0], 0); RSBA_LDS_RD(a[1], 1); RSBA_LDS_RD(a[2], 2); RSBA_LDS_RD(a[3], 3); RSBA_LDS_RD(a[4], 4); RSBA_LDS_RD(a[5], 5);
   RSBA_LDS_RD(a[6], 6); RSBA_LDS_RD(a[7], 7); RSBA_LDS_RD(a[8], 8); RSBA_LDS_RD(a[9], 9); RSBA_LDS_RD(a[10], 10); RSBA_LDS_RD(a[11], 11);
-  RSBA_LDS_RD(a[12], 12); RSBA_LDS_RD(a[13], 13);
+  RSBA_LDS_RD(a[12], 12); RSBA_LDS_RD(a[13], 13); RSBA_LDS_RD(a[14], 14); RSBA_LDS_RD(a[15], 15);
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
-               "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]));
+               "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
 }
 #undef RSBA_LDS_RD
 
@@ -943,16 +937,16 @@ struct BacksubProjLds {
 // point are in camera order, so the cameras of one slot cluster), the same camera is a broadcast, and k is an immediate
 // offset.
 //
-// Observation records: a lane's first RSBA_BS_REG slots stay in registers, the next kLds in LDS (lane-private: [wave]
+// Observation records: a lane's first kReg slots stay in registers, the next kLds in LDS (lane-private: [wave]
 // [slot][lane]); all of them are fetched BEFORE the kernel waits for the solve and serve both passes.  (All twenty in
 // registers do not fit beside the passes' ~190 registers with two workgroups per CU: the compiler put the pixel pairs into
 // scratch and fetched one per slot, each a trip to memory — 16 + 20 us for the two passes.)  Slots beyond that are
-// streamed from memory (correct, slow: points seen by more than RSBA_BS_REG + kLds cameras of a slice).
+// streamed from memory (correct, slow: points seen by more than kReg + kLds cameras of a slice).
 //
 // Work is dealt by SLICE (64 points, one wavefront), wave w of workgroup b taking slices b + G (w + 4 i): with G = two
 // workgroups per CU every CU gets six or seven wavefronts of work; one workgroup per 256 points is 1.5 per CU, i.e. half
 // the CUs with twice the LDS traffic of the others.
-template <int kCpad, int kLds, bool kLoss>
+template <int kCpad, int kReg, int kLds, bool kLoss>
 __global__ void __launch_bounds__(256, kCpad <= 128 ? 2 : 1)
 k_backsub_candidate_proj(int C, int P, ObsSliced obs,
                          const double* __restrict__ camc_xg, const double* __restrict__ camc_cg,
@@ -1005,7 +999,7 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
   __builtin_amdgcn_sched_barrier(0);
   int tb = 0, te = 0;
   double X[3] = {0, 0, 0}, V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, sp[3] = {1, 1, 1};
-  int camq[RSBA_BS_REG]; double2 uvq[RSBA_BS_REG];
+  int camq[kReg]; double2 uvq[kReg];
   auto load_point = [&]() {
     tb = obs.row_ptr[slice]; te = obs.row_ptr[slice + 1];
     if (j < P) {
@@ -1018,7 +1012,7 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
     }
     // (the slots of a slice's missing points are padding: cam < 0)
 #pragma unroll
-    for (int u = 0; u < RSBA_BS_REG; ++u) {
+    for (int u = 0; u < kReg; ++u) {
       const size_t qq = (size_t)(tb + u) * 64 + lane;
       camq[u] = tb + u < te ? obs.cam[qq] : -1;
       uvq[u] = tb + u < te ? obs.uv[qq] : make_double2(0.0, 0.0);
@@ -1028,7 +1022,7 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
       int cv[5]; double2 uv[5];
 #pragma unroll
       for (int u = 0; u < 5; ++u) {
-        const int t = tb + RSBA_BS_REG + u0 + u;
+        const int t = tb + kReg + u0 + u;
         const size_t qq = (size_t)t * 64 + lane;
         cv[u] = (u0 + u < kLds && t < te) ? obs.cam[qq] : -1;
         uv[u] = (u0 + u < kLds && t < te) ? obs.uv[qq] : make_double2(0.0, 0.0);
@@ -1089,18 +1083,13 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
     lx[15 * kCpad + c] = kk[18] * dc[3];
     lx[19 * kCpad + c] = kk[19] * dc[4];
     lx[23 * kCpad + c] = dc[5];
-    // the candidate's A
+    // the candidate's constants as ProjectResidual takes them
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      lc[i * kCpad + c] = v[12] * v[i];
-      lc[(4 + i) * kCpad + c] = v[13] * v[3 + i];
-      lc[(8 + i) * kCpad + c] = v[6 + i];
-    }
-    lc[3 * kCpad + c] = v[12] * v[9];
-    lc[7 * kCpad + c] = v[13] * v[10];
-    lc[11 * kCpad + c] = v[11];
-    lc[12 * kCpad + c] = v[14];
-    lc[13 * kCpad + c] = v[15];
+    for (int i = 0; i < 12; ++i) lc[i * kCpad + c] = v[i];
+    lc[12 * kCpad + c] = v[12];
+    lc[13 * kCpad + c] = v[13];
+    lc[14 * kCpad + c] = v[14];
+    lc[15 * kCpad + c] = v[15];
   }
   __syncthreads();
   if (fl.trace != nullptr && blockIdx.x == 0 && tid == 0) fl.trace[32] = wall_clock64();
@@ -1150,13 +1139,13 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
       a2 += e0 * e0 + e1 * e1;
     };
 #pragma unroll
-    for (int u = 0; u < RSBA_BS_REG; ++u) { at_x(camq[u], uvq[u]); __builtin_amdgcn_sched_barrier(0); }
+    for (int u = 0; u < kReg; ++u) { at_x(camq[u], uvq[u]); __builtin_amdgcn_sched_barrier(0); }
     {
-      const int nl = min(kLds, nslot - RSBA_BS_REG);
+      const int nl = min(kLds, nslot - kReg);
 #pragma unroll 1
       for (int u = 0; u < nl; ++u) at_x(caml[u * 64], uvl[u * 64]);
     }
-    for (int t = tb + RSBA_BS_REG + kLds; t < te; ++t) {   // (points with more views than a lane keeps)
+    for (int t = tb + kReg + kLds; t < te; ++t) {   // (points with more views than a lane keeps)
       const size_t qq = (size_t)t * 64 + lane;
       at_x(obs.cam[qq], obs.uv[qq]);
     }
@@ -1181,16 +1170,15 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
       const bool valid = cam >= 0;
       if (kLoss && !valid) return;
       double av[RSBA_PJ_NC];
-      ReadRows14<kCpad>(lc_ad + 8u * (unsigned)(valid ? cam : 0), av);
-      const double h0 = fma(RSBA_A(0), Xc[0], fma(RSBA_A(1), Xc[1], fma(RSBA_A(2), Xc[2], RSBA_A(3))));
-      const double h1 = fma(RSBA_A(4), Xc[0], fma(RSBA_A(5), Xc[1], fma(RSBA_A(6), Xc[2], RSBA_A(7))));
-      const double h2 = fma(RSBA_A(8), Xc[0], fma(RSBA_A(9), Xc[1], fma(RSBA_A(10), Xc[2], RSBA_A(11))));
-      const double iz = valid ? RcpNewton(h2) : 0.0;      // a padding record: zero rows, and a zero residual below
-      const double pr0 = h0 * iz, pr1 = h1 * iz;
-      double r[2] = {valid ? pr0 + RSBA_A(12) - uv.x : 0.0, valid ? pr1 + RSBA_A(13) - uv.y : 0.0};
-      double jp[6] = {fma(-pr0, RSBA_A(8), RSBA_A(0)) * iz, fma(-pr0, RSBA_A(9), RSBA_A(1)) * iz, fma(-pr0, RSBA_A(10), RSBA_A(2)) * iz,
-                      fma(-pr1, RSBA_A(8), RSBA_A(4)) * iz, fma(-pr1, RSBA_A(9), RSBA_A(5)) * iz, fma(-pr1, RSBA_A(10), RSBA_A(6)) * iz};
+      ReadRows16<kCpad>(lc_ad + 8u * (unsigned)(valid ? cam : 0), av);
 #undef RSBA_A
+      // the residual every gradient of the next iteration is made of: ProjectResidual's roundings, not the projective rows'
+      double p[3], iz, r[2];
+      ProjectResidual(av, av + 9, av[12], av[13], av[14], av[15], Xc, uv.x, uv.y, p, &iz, r);
+      if (!valid) { iz = 0.0; r[0] = 0.0; r[1] = 0.0; }   // a padding record: zero rows, and a zero residual
+      const double pr0 = p[0] * iz, pr1 = p[1] * iz, al = av[12] * iz, be = av[13] * iz;
+      double jp[6] = {fma(-pr0, av[6], av[0]) * al, fma(-pr0, av[7], av[1]) * al, fma(-pr0, av[8], av[2]) * al,
+                      fma(-pr1, av[6], av[3]) * be, fma(-pr1, av[7], av[4]) * be, fma(-pr1, av[8], av[5]) * be};
       const double s = r[0] * r[0] + r[1] * r[1];
       ss_c += s;
       if (kLoss) {
@@ -1211,13 +1199,13 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
       gc[0] += jp[0] * r[0] + jp[3] * r[1]; gc[1] += jp[1] * r[0] + jp[4] * r[1]; gc[2] += jp[2] * r[0] + jp[5] * r[1];
     };
 #pragma unroll
-    for (int u = 0; u < RSBA_BS_REG; ++u) { at_c(camq[u], uvq[u], tb + u); __builtin_amdgcn_sched_barrier(0); }
+    for (int u = 0; u < kReg; ++u) { at_c(camq[u], uvq[u], tb + u); __builtin_amdgcn_sched_barrier(0); }
     {
-      const int nl = min(kLds, nslot - RSBA_BS_REG);
+      const int nl = min(kLds, nslot - kReg);
 #pragma unroll 1
-      for (int u = 0; u < nl; ++u) at_c(caml[u * 64], uvl[u * 64], tb + RSBA_BS_REG + u);
+      for (int u = 0; u < nl; ++u) at_c(caml[u * 64], uvl[u * 64], tb + kReg + u);
     }
-    for (int t = tb + RSBA_BS_REG + kLds; t < te; ++t) {
+    for (int t = tb + kReg + kLds; t < te; ++t) {
       const size_t qq = (size_t)t * 64 + lane;
       at_c(obs.cam[qq], obs.uv[qq], t);
     }

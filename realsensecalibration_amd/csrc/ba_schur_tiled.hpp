@@ -312,7 +312,7 @@ k_point_damp(int P, const double* pts_x, const double* __restrict__ scale_p, con
 // on its own before it is added — and the elimination kernel is bound by the number of fp64 instructions it issues.)
 __device__ __forceinline__ double Fma2(double a, double b, double c, double d, double acc) { return fma(c, d, fma(a, b, acc)); }
 
-// (1 / x for the depth of a point in a camera: RcpNewton, ba_point_kernels.hpp)
+// (1 / x for the depth of a point in a camera: RcpNewton, ba_math.hpp)
 
 struct SideConst {
   double R[9], t[3], fx, fy;
@@ -912,13 +912,10 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
       const double uu = u_cm[oi], vv = v_cm[oi];
       double e0[6], e1[6], n0[3], n1[3];
       SideRows(A, X, sqa, e0, e1, n0, n1);
-      // residual from the rows just built: e0[3] = sq fx / z, e0[5] = -sq fx x / z^2  =>  fx x / z = -e0[5] / e0[3] * fx ... cheaper:
-      // recompute the projection directly (same arithmetic as ba_math.hpp::Residual)
-      const double q0 = A.R[0] * X[0] + A.R[1] * X[1] + A.R[2] * X[2] + A.t[0];
-      const double q1 = A.R[3] * X[0] + A.R[4] * X[1] + A.R[5] * X[2] + A.t[1];
-      const double q2 = A.R[6] * X[0] + A.R[7] * X[1] + A.R[8] * X[2] + A.t[2];
-      const double iz = RcpNewton(q2);
-      const double r0 = (A.fx * q0 * iz + ppx - uu) * sqa, r1 = (A.fy * q1 * iz + ppy - vv) * sqa;
+      // the residual: ProjectResidual (ba_math.hpp), the one sequence of roundings g_p was formed with as well
+      double pq[3], izq, rr[2];
+      ProjectResidual(A.R, A.t, A.fx, A.fy, ppx, ppy, X, uu, vv, pq, &izq, rr);
+      const double r0 = rr[0] * sqa, r1 = rr[1] * sqa;
       // M' = I - N Vinv N'  (2x2 symmetric)
       const double t00 = n0[0] * v0 + n0[1] * v1 + n0[2] * v2, t01 = n0[0] * v1 + n0[1] * v3 + n0[2] * v4, t02 = n0[0] * v2 + n0[1] * v4 + n0[2] * v5;
       const double t10 = n1[0] * v0 + n1[1] * v1 + n1[2] * v2, t11 = n1[0] * v1 + n1[1] * v3 + n1[2] * v4, t12 = n1[0] * v2 + n1[1] * v4 + n1[2] * v5;

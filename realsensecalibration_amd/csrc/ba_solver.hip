@@ -1320,28 +1320,24 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
         fl.lm.min_relative_decrease = s->opt.min_relative_decrease; fl.lm.max_radius = s->opt.max_trust_region_radius;
       }
       // (more than 48 KB of dynamic LDS has to be asked for, once per kernel)
+      // <cameras, slots in registers, slots in LDS, loss>: the robust instances keep fewer records in registers — the loss'
+      // square roots and the store of sqrt(rho') need the registers, and a spilled value is a trip to memory per slot
+#define RSBA_BS_INSTANCES(X) X(64, 10, 10, false) X(64, RSBA_BS_REG_LOSS, 11, true) X(128, 10, 6, false) X(128, RSBA_BS_REG_LOSS, 7, true) \
+                             X(256, 10, 10, false) X(256, 10, 10, true)
       static const bool lds_attr_set = []() {
         bool ok = true;
-        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<64, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<64, 10>::kBytes) == hipSuccess && ok;
-        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<64, 10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<64, 10>::kBytes) == hipSuccess && ok;
-        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<128, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<128, 6>::kBytes) == hipSuccess && ok;
-        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<128, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<128, 6>::kBytes) == hipSuccess && ok;
-        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<256, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<256, 10>::kBytes) == hipSuccess && ok;
-        ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<256, 10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<256, 10>::kBytes) == hipSuccess && ok;
+#define RSBA_X(cp, rg, ld, ls) ok = hipFuncSetAttribute((const void*)k_backsub_candidate_proj<cp, rg, ld, ls>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BacksubProjLds<cp, ld>::kBytes) == hipSuccess && ok;
+        RSBA_BS_INSTANCES(RSBA_X)
+#undef RSBA_X
         return ok;
       }();
       if (!lds_attr_set) return RSBA_ERR_HIP;
       const bool loss = ip.huber_delta != 0.0;
-      if (C <= 64) {
-        if (loss) k_backsub_candidate_proj<64, 10, true><<<grid_bs, 256, BacksubProjLds<64, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
-        else k_backsub_candidate_proj<64, 10, false><<<grid_bs, 256, BacksubProjLds<64, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
-      } else if (C <= 128) {
-        if (loss) k_backsub_candidate_proj<128, 6, true><<<grid_bs, 256, BacksubProjLds<128, 6>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
-        else k_backsub_candidate_proj<128, 6, false><<<grid_bs, 256, BacksubProjLds<128, 6>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
-      } else {
-        if (loss) k_backsub_candidate_proj<256, 10, true><<<grid_bs, 256, BacksubProjLds<256, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
-        else k_backsub_candidate_proj<256, 10, false><<<grid_bs, 256, BacksubProjLds<256, 10>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
-      }
+      const int cp = C <= 64 ? 64 : (C <= 128 ? 128 : 256);
+#define RSBA_X(cpad, rg, ld, ls) if (cp == cpad && loss == ls) k_backsub_candidate_proj<cpad, rg, ld, ls><<<grid_bs, 256, BacksubProjLds<cpad, ld>::kBytes, st>>>(RSBA_BACKSUB_ARGS);
+      RSBA_BS_INSTANCES(RSBA_X)
+#undef RSBA_X
+#undef RSBA_BS_INSTANCES
     } else if (lds_b <= 60 * 1024) {
       if (fused) k_backsub_candidate<true, true><<<s->grid_pts, 256, lds_b, st>>>(RSBA_BACKSUB_ARGS);
       else k_backsub_candidate<true, false><<<s->grid_pts, 256, lds_b, st>>>(RSBA_BACKSUB_ARGS);
@@ -1636,10 +1632,10 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
       accept();
       x_cost = cand_cost;  // re-evaluated by the next linearisation (settle_moved); kept for the summary if we stop here
       s->final_sumsq = r[RES_SUMSQ_C];
-      // (2 rho - 1)^3 as two products: the device takes the same decision from the same numbers for the damping kernel it
-      // has queued (DecideStep, ba_point_kernels.hpp) and has to arrive at the same bits; std::pow may differ in the last one
+      // (2 rho - 1)^3: Cube (ba_math.hpp) — pow's bits (trust_region_minimizer.cc calls pow), and the same sequence of exact
+      // operations the device runs when it takes this decision for the damping kernel it has queued (DecideStep)
       const double t = 2.0 * it.relative_decrease - 1.0;
-      radius = radius / std::max(1.0 / 3.0, 1.0 - (t * t) * t);
+      radius = radius / std::max(1.0 / 3.0, 1.0 - Cube(t));
       radius = std::min(o.max_trust_region_radius, radius);
       decrease_factor = 2.0;
       it.step_is_successful = 1; it.cost = cand_cost; it.trust_region_radius = radius;

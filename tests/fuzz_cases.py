@@ -1,0 +1,91 @@
+"""The randomised parity sweep's cases and its criterion (shared by tests/test_gpu_fuzz.py and tools/fuzz_parity.py).
+
+Test infrastructure: uses the oracle.  A case is a seeded random shape of the point model — 2..130 cameras, 2..34 views per
+point, 40..2500 points, no loss / Huber / Cauchy with 5 % outliers — with every block free, as the reference leaves them
+(Test1_BundleAdjustment/main.cpp:76-79, cost functor bundle_adjustmenter.cpp:106-148).
+
+Criterion (`verdict`; every number is relative; the bars come from tests/oracle_spread.py — BASELINE's own wherever the
+oracle agrees with ITSELF ten times better than that under a change of roundings, ten times the oracle's own spread where it
+does not):
+  * the costs of the first three iterates agree to 1e-12 — always (a defect shows at once, rounding shows late);
+  * same termination, iteration count and accept / reject sequence as the oracle — unless the oracle's own runs part;
+  * every iterate's cost agrees to 1e-9 — up to three iterations before the oracle's own runs part, if they do;
+  * final cost to max(1e-9, 10 x spread), reprojection RMS to max(1e-4 px, 10 x spread);
+  * parameters RAW, per block, to max(1e-6, 10 x spread) — no alignment along the gauge orbit.
+About one case in eight is of the second kind (robust loss, two to five views per point: the radius reaches 1e13 .. 1e16 and
+the run often ends at the iteration limit); tests/test_gpu_fuzz.py bounds their number.
+"""
+import numpy as np
+
+import oracle_spread
+from oracle_spread import block_rel, cost_tolerance
+from realsensecalibration_amd import synthetic as syn
+
+CAMERAS = [2, 3, 5, 8, 13, 17, 24, 31, 32, 33, 40, 48, 63, 64, 65, 70, 96, 128, 130]
+
+
+def cases(n, seed):
+    """n seeded cases: dicts with the problem's shape, its seed and the loss (kind, scale)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        C = int(rng.choice(CAMERAS))
+        k = int(rng.integers(2, min(C, 34) + 1))
+        P = int(rng.integers(40, 2500))
+        loss = str(rng.choice(["none", "none", "huber", "huber", "cauchy"]))
+        scale = float(rng.choice([1.0, 2.5])) if loss != "none" else 0.0
+        out.append(dict(index=i, C=C, P=P, k=k, seed=int(rng.integers(1, 1 << 30)), loss=loss, scale=scale))
+    return out
+
+
+def label(c):
+    return "%03d-C%d-P%d-k%d-%s%s" % (c["index"], c["C"], c["P"], c["k"], c["loss"], ("%.1f" % c["scale"]) if c["scale"] else "")
+
+
+def run(oracle, capi, c):
+    """Solves one case with the oracle (three times: oracle_spread) and with the HIP path; returns the numbers `verdict` looks at."""
+    prob = syn.make_problem(c["C"], c["P"], c["k"], seed=c["seed"], outlier_frac=0.0 if c["loss"] == "none" else 0.05)
+    # the oracle takes the Cauchy scale as a negative huber_delta (oracle/ba_oracle.hpp), the C ABI as loss_type = 1
+    hd = -c["scale"] if c["loss"] == "cauchy" else c["scale"]
+    ref, s_ref, log_ref = oracle.solve_points(prob, oracle.options(huber_delta=hd))
+    sp = oracle_spread.spread(oracle, prob, dict(huber_delta=hd), ref=(ref, s_ref, log_ref))
+    got, s_got, log_got = capi.solve_points(prob, capi.default_options(schur_impl=1, huber_delta=c["scale"], loss_type=1 if c["loss"] == "cauchy" else 0))
+    N = prob["N"]
+    _, ss_ref = oracle.points_cost(prob, ref, huber_delta=hd)
+    _, ss_got = oracle.points_cost(prob, got, huber_delta=hd)
+    m = min(len(log_got), len(log_ref))
+    first3 = max([abs(log_got[j, 1] - log_ref[j, 1]) / cost_tolerance(abs(log_ref[j, 1]), N, 1.0) for j in range(1, min(m, 4))] or [0.0])
+    return dict(
+        same_trajectory=bool(s_got.termination_type == s_ref.termination and s_got.stop_reason == s_ref.stop_reason and
+                             s_got.num_iterations == s_ref.num_iterations and np.array_equal(log_got[:, 7], log_ref[:, 7])),
+        iterations=int(s_ref.num_iterations), iterations_got=int(s_got.num_iterations),
+        first3=float(first3), part=oracle_spread.first_parting(log_got, log_ref, N, 1e-9),
+        radius_max=float(log_ref[:, 6].max()),
+        final_cost=abs(s_got.final_cost - s_ref.final_cost) / max(s_ref.final_cost, 1e-300),
+        final_cost_tol=cost_tolerance(s_ref.final_cost, N, 1e-9) / max(s_ref.final_cost, 1e-300),
+        rms=abs(np.sqrt(ss_ref / (2 * N)) - np.sqrt(ss_got / (2 * N))),
+        raw=block_rel(got, ref, c["C"]), spread=sp, bars=oracle_spread.bars(sp, N))
+
+
+def verdict(r):
+    """List of the criterion's clauses the case violates (empty: the case passes)."""
+    b, bad = r["bars"], []
+    if not r["first3"] <= 1e-12:
+        bad.append("first three iterates' costs %.1e" % r["first3"])
+    if b["same_trajectory"] and not r["same_trajectory"]:
+        bad.append("trajectory (iterations %d vs %d)" % (r["iterations_got"], r["iterations"]))
+    if r["part"] >= 0 and (b["agree_until"] is None or r["part"] <= b["agree_until"]):
+        bad.append("iterate %d's cost differs by more than 1e-9 (the oracle's own runs part at %d)" % (r["part"], r["spread"]["part"]))
+    if not r["final_cost"] <= max(b["final_cost"], r["final_cost_tol"]):
+        bad.append("final cost %.1e (bar %.1e)" % (r["final_cost"], b["final_cost"]))
+    if not r["rms"] <= b["rms"]:
+        bad.append("rms %.1e px (bar %.1e)" % (r["rms"], b["rms"]))
+    if not r["raw"] < b["raw"]:
+        bad.append("raw parameters %.1e (bar %.1e)" % (r["raw"], b["raw"]))
+    return bad
+
+
+def sensitive(r):
+    """Is this a case on which the oracle does not agree with itself to a tenth of BASELINE's bars?"""
+    b = r["bars"]
+    return b["raw"] > 1e-6 or b["final_cost"] > 1e-9 or b["rms"] > 1e-4 or not b["same_trajectory"] or b["agree_until"] is not None

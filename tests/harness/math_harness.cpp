@@ -17,6 +17,7 @@ void h_residual(const double* cam6, const double* intr4, const double* X, const 
 int h_point_block_inverse(const double* V6, const double* s3, double lo, double hi, double radius, double* out6) {
   return rsba::PointBlockInverse(V6, s3, lo, hi, radius, out6) ? 1 : 0;
 }
+double h_cube(double t) { return rsba::Cube(t); }
 double h_loss(double delta, double s, double* sq) { return rsba::LossAndScale(delta, s, sq); }
 // marker-chain residual block: r (8), J (8 x 18), from the analytic per-corner routine; camera / marker may be NULL
 void h_marker_residual_jacobian(const double* cam6, const double* tim6, const double* mar6, double half_side, const double* intr4,

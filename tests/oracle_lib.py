@@ -157,6 +157,18 @@ class Oracle:
 
 
 _ORACLE = None
+_VARIANT = None
+
+
+def load_nocontract(build=True):
+    """The oracle built with -ffp-contract=off (oracle/Makefile): same algorithm, different roundings."""
+    global _VARIANT
+    if _VARIANT is None:
+        so = os.path.join(ORACLE_DIR, "liboracle_nocontract.so")
+        if build:
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle_nocontract.so"])
+        _VARIANT = Oracle(so)
+    return _VARIANT
 
 
 def load(build=True):

@@ -9,8 +9,8 @@ import os
 import numpy as np
 import pytest
 
-import gauge
 import oracle_lib as ol
+import oracle_spread
 from realsensecalibration_amd import capi
 from realsensecalibration_amd import synthetic as syn
 
@@ -61,7 +61,10 @@ def test_reduced_system_and_step_match_oracle(oracle, impl, C, P, k, radius):
 
 
 # ------------------------------------------------------------------ whole solves
-def _compare_solve(oracle, prob, impl, huber=0.0, strict_params=True, iter_cost_tol=1e-7, modulo_gauge=False, **optkw):
+def _compare_solve(oracle, prob, impl, huber=0.0, params_bar=1e-6, iter_cost_tol=1e-7, **optkw):
+    """Whole solve against the oracle.  `params_bar`: the bar on the RAW parameters, per block — BASELINE.json's 1e-6 unless
+    the caller has measured that the oracle itself does not meet it on this problem (oracle_spread.bars); no alignment
+    along the gauge orbit anywhere.  Returns (parameters, summary, log, raw parameter difference)."""
     o_ref = oracle.options(huber_delta=huber, **optkw)
     ref, s_ref, log_ref = oracle.solve_points(prob, o_ref)
     got, s_got, log_got = capi.solve_points(prob, capi.default_options(schur_impl=impl, huber_delta=huber, **optkw))
@@ -73,19 +76,13 @@ def _compare_solve(oracle, prob, impl, huber=0.0, strict_params=True, iter_cost_
     assert abs(s_got.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
     # every iterate has the same cost (relative to the largest cost on the trajectory)
     assert np.abs(log_got[:, 1] - log_ref[:, 1]).max() / log_ref[:, 1].max() < iter_cost_tol
-    if strict_params:
-        rel = _block_rel(got, ref, prob["C"])
-        if modulo_gauge and rel >= 1e-6:
-            # all blocks free: the solutions may sit at different places of the similarity orbit the cost does not see
-            # (tests/gauge.py); moved onto each other along it they have to agree like everywhere else
-            assert rel < 1e-3
-            rel = _block_rel(gauge.align(got, ref, prob["C"])[0], ref, prob["C"])
-        assert rel < 1e-6
+    rel = _block_rel(got, ref, prob["C"])
+    assert rel < params_bar, "raw parameters differ by %.2e (bar %.1e)" % (rel, params_bar)
     c_ref, ss_ref = oracle.points_cost(prob, ref)
     c_got, ss_got = oracle.points_cost(prob, got)
     rms_ref, rms_got = np.sqrt(ss_ref / (2 * prob["N"])), np.sqrt(ss_got / (2 * prob["N"]))
     assert abs(rms_ref - rms_got) < 1e-4
-    return got, s_got, log_got
+    return got, s_got, log_got, rel
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -94,51 +91,61 @@ def test_solve_matches_oracle(oracle, impl, C, P, k, seed):
     _compare_solve(oracle, syn.make_problem(C, P, k, seed=seed), impl)
 
 
-@pytest.mark.parametrize("C,P,k,huber", [(40, 2500, 30, 0.0), (40, 2500, 30, 1.5), (96, 2000, 24, 0.0), (96, 2000, 24, 1.5), (128, 1500, 14, 0.0)])
+@pytest.mark.parametrize("C,P,k,huber", [(40, 2500, 30, 0.0), (40, 2500, 30, 1.5), (96, 2000, 24, 0.0), (96, 2000, 24, 1.5), (128, 1500, 14, 0.0),
+                                          (200, 1200, 26, 0.0), (200, 1200, 26, 1.5)])
 def test_back_substitution_record_paths(oracle, C, P, k, huber):
-    """k_backsub_candidate_proj keeps ten observation records of a point in registers and ten (up to 64 cameras) or six (up to
-    128) in LDS; the records beyond that are streamed.  30 views at 40 cameras and 24 views at 96 cameras go through all three
-    paths, with and without the robust loss (a template parameter of the kernel); 128 cameras is the largest problem it takes."""
+    """k_backsub_candidate_proj keeps a lane's first observation records in registers (ten; seven in the robust instances),
+    the next ones in LDS (ten / eleven up to 64 cameras, six / seven up to 128, ten up to 256) and streams the rest.  30 views at
+    40 cameras, 24 at 96 and 26 at 200 go through all three paths of all six instances — <64>, <128>, <256> with and without the
+    robust loss (a template parameter); 200 cameras without a loss is k_backsub_candidate_proj<256, 10, 10, false>, which no
+    BASELINE configuration reaches.  Raw parameters at 1e-6."""
     prob = syn.make_problem(C, P, k, seed=300 + C, outlier_frac=0.05 if huber else 0.0)
-    _compare_solve(oracle, prob, 1, huber=huber, modulo_gauge=True)
+    _compare_solve(oracle, prob, 1, huber=huber)
 
 
 @pytest.mark.parametrize("impl", IMPLS)
 def test_config2_full_size(oracle, impl):
     """BASELINE.json configs[1]: 8 cams x 10k points, 80k observations."""
     prob = syn.make_config("cfg2")
-    got, s, log = _compare_solve(oracle, prob, impl)
+    got, s, log, _ = _compare_solve(oracle, prob, impl)
     assert prob["N"] == 80_000
 
 
 @pytest.mark.parametrize("impl", IMPLS)
 def test_huber_and_rejected_steps(oracle, impl):
-    """17 iterations, the radius grows to 4e11 with every block free: rounding differences between two correct solvers are
-    amplified along the 7-dof gauge orbit (measured between two forms of the back-substitution kernel on this problem:
-    2.7e-5 in the raw parameters, 3.4e-9 after moving one solution onto the other along the orbit, every iterate's cost
-    equal to 1e-9 relative).  Costs, decisions and RMS are compared as everywhere; the parameters raw when they agree to
-    1e-6, otherwise modulo the gauge."""
+    """17 iterations, the radius grows to 4e11 with every block free (Test1_BundleAdjustment/main.cpp:76-79 fixes none): the
+    suite's longest robust run.  RAW parameters at 1e-6 — three executions of the oracle end within 1e-7 of each other here
+    (tests/test_oracle_self_sensitivity.py), so the bar is defined, and the HIP path measures 4e-8.  Round 2 compared this case
+    modulo the gauge orbit because its back-substitution ended 1.5e-5 away: that kernel formed the candidate's residuals —
+    the next iteration's g_p — from rows pre-multiplied by fx while the Schur kernel formed g_c from R and t, a mismatch of
+    ~1e-13 px that the radius amplified along the orbit.  Every residual that enters a gradient now comes from ONE function
+    (ProjectResidual, csrc/ba_math.hpp)."""
     prob = syn.make_problem(8, 1500, 6, seed=9, outlier_frac=0.05)
-    _compare_solve(oracle, prob, impl, huber=1.0, modulo_gauge=True)
+    _, s, _, rel = _compare_solve(oracle, prob, impl, huber=1.0)
+    assert s.num_iterations == 17 and rel < 5e-7
 
 
 @pytest.mark.parametrize("impl", IMPLS)
-@pytest.mark.parametrize("sigma,radius0,seed,min_rejected,strict", [(0.7, 1e4, 2, 2, False), (0.65, 1e6, 2, 5, False)])
-def test_rejected_steps_follow_the_same_trajectory(oracle, impl, sigma, radius0, seed, min_rejected, strict):
+@pytest.mark.parametrize("sigma,radius0,seed,min_rejected", [(0.7, 1e4, 2, 2), (0.65, 1e6, 2, 5)])
+def test_rejected_steps_follow_the_same_trajectory(oracle, impl, sigma, radius0, seed, min_rejected):
     """A far-off start: rejected steps, radius shrinkage by 2, 4, 8, ... and recovery.
 
-    All cameras and points are free (as in Test1_BundleAdjustment/main.cpp:76-79), so the cost has a
-    7-dof gauge orbit.  On the 20-iteration trajectory with 6 rejections, rounding differences between
-    two correct implementations drift along that orbit: costs, decisions and the RMS still agree, the
-    parameters themselves agree only to ~1e-2 there, so that case checks everything but the parameters."""
+    All cameras and points are free (as in Test1_BundleAdjustment/main.cpp:76-79), so the cost has a 7-dof gauge orbit, and far
+    from the minimum the damped systems are ill-conditioned (cond ~1e12): on these 20-iteration trajectories with up to six
+    rejections the ORACLE's own runs end ~1e-2 apart in the parameters when only its roundings change.  The bar on the raw
+    parameters is therefore ten times the oracle's own spread, measured here (oracle_spread); costs, decisions, RMS as
+    everywhere."""
     prob = syn.make_problem(8, 1500, 6, seed=9, outlier_frac=0.05)
     rng = np.random.default_rng(seed)
     bad = dict(prob)
     bad["params"] = prob["params"] + np.concatenate([rng.normal(0, sigma, 48), rng.normal(0, sigma, 3 * prob["P"])])
-    # far from the minimum the damped systems are ill-conditioned (cond ~1e12): intermediate costs of two
-    # correct solvers agree to ~1e-5, not 1e-7; the decisions and the end point still coincide
-    got, s, log = _compare_solve(oracle, bad, impl, strict_params=strict, iter_cost_tol=1e-3, initial_trust_region_radius=radius0)
+    sp = oracle_spread.spread(oracle, bad, dict(initial_trust_region_radius=radius0))
+    assert sp["same_trajectory"]
+    bar = oracle_spread.bars(sp, bad["N"])["raw"]
+    # intermediate costs of two correct solvers agree to ~1e-5 there, not 1e-7; the decisions and the end point coincide
+    got, s, log, rel = _compare_solve(oracle, bad, impl, params_bar=bar, iter_cost_tol=1e-3, initial_trust_region_radius=radius0)
     assert s.num_unsuccessful_steps >= min_rejected
+    print("raw parameters %.2e, the oracle against itself %.2e" % (rel, sp["raw"]))
 
 
 @pytest.mark.parametrize("impl", IMPLS)
@@ -325,7 +332,7 @@ def test_pipelined_solve_matches_oracle_and_sequential_schedule(oracle, C, P, k,
     and the sequential schedule's (RSBA_PIPELINE=0, same segment size) bit for bit.  C = 17 leaves a last group of one camera (a stage
     without any pair tile), C = 64 is the benchmark's shape, with Huber loss and outliers."""
     prob = syn.make_problem(C, P, k, seed=300 + C, outlier_frac=0.05 if huber else 0.0)
-    got, s, log = _compare_solve(oracle, prob, 1, huber=huber)
+    got, s, log, _ = _compare_solve(oracle, prob, 1, huber=huber)
     os.environ["RSBA_PIPELINE"] = "0"
     os.environ["RSBA_SEG_PER_CU"] = "8"   # the pipelined default: same segments, same summation order
     try:
@@ -427,7 +434,7 @@ def test_duplicate_observations_and_unobserved_points(oracle):
     q = dict(prob)
     q["cam_idx"] = np.ascontiguousarray(cam.astype(np.int32)); q["pt_idx"] = np.ascontiguousarray(pt.astype(np.int32))
     q["obs"] = np.ascontiguousarray(np.concatenate([obs2[keep], dup_obs]).reshape(-1)); q["N"] = len(cam)
-    got, s, log = _compare_solve(oracle, q, 1)
+    got, s, log, _ = _compare_solve(oracle, q, 1)
     C = q["C"]
     for j in drop_pts:
         assert np.array_equal(got[6 * C + 3 * j: 6 * C + 3 * j + 3], q["params"][6 * C + 3 * j: 6 * C + 3 * j + 3])
@@ -700,7 +707,7 @@ def test_multi_workgroup_cholesky_matches_oracle_and_single_workgroup(oracle, C,
     factors to each other (ba_cholesky_multi.hpp).  Oracle parity, bitwise reproducibility, the same answer (to rounding) from 1, 2, 3 and 6
     workgroups, and from the sequential schedule bit for bit."""
     prob = syn.make_problem(C, P, k, seed=500 + C)
-    got, s, log = _compare_solve(oracle, prob, 1)
+    got, s, log, _ = _compare_solve(oracle, prob, 1)
     again, s2, log2 = capi.solve_points(prob)
     assert np.array_equal(got, again) and np.array_equal(log, log2)
     for g in ("1", "2", "3", "6"):
@@ -743,7 +750,7 @@ def test_persistent_tiled_cholesky_matches_oracle_and_multi_launch(oracle, C, P,
     C = 128: whole tiles, the right-hand side row alone in its tile row.  Oracle parity, the multi-launch factorisation
     (RSBA_CHOL_TILES=0) to rounding, bitwise reproducibility."""
     prob = syn.make_problem(C, P, k, seed=900 + C)
-    got, s, log = _compare_solve(oracle, prob, 1)
+    got, s, log, _ = _compare_solve(oracle, prob, 1)
     again, s2, log2 = capi.solve_points(prob)
     assert np.array_equal(got, again) and np.array_equal(log, log2)
     os.environ["RSBA_CHOL_TILES"] = "0"

@@ -1,47 +1,25 @@
-"""Randomised parity sweep of the HIP path against the oracle (test infrastructure: uses tests/ helpers and oracle/).
-usage: python tools/fuzz_parity.py [cases] [seed]   — prints one line per case, exits non-zero on the first mismatch."""
+"""Randomised parity sweep of the HIP path against the oracle, beyond the seeds the suite pins (tests/test_gpu_fuzz.py runs
+the same cases function with fixed seeds; criterion and case generator: tests/fuzz_cases.py).  Test infrastructure.
+usage: python tools/fuzz_parity.py [cases] [seed]   — one line per case, exits non-zero when a case violates the criterion."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np
-import oracle_lib, gauge
-from realsensecalibration_amd import capi, synthetic as syn
-
-def block_rel(a, b, C):
-    worst = 0.0
-    for x, y in ((a[:6 * C].reshape(-1, 6), b[:6 * C].reshape(-1, 6)), (a[6 * C:].reshape(-1, 3), b[6 * C:].reshape(-1, 3))):
-        worst = max(worst, (np.abs(x - y).max(axis=1) / np.maximum(np.abs(y).max(axis=1), 1e-12)).max())
-    return worst
+import fuzz_cases, oracle_lib
+from realsensecalibration_amd import capi
 
 oracle = oracle_lib.load()
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-bad = 0
-for i in range(ncase):
-    C = int(rng.choice([2, 3, 5, 8, 13, 17, 24, 31, 32, 33, 40, 48, 63, 64, 65, 70, 96, 128, 130]))
-    k = int(rng.integers(2, min(C, 34) + 1))
-    P = int(rng.integers(40, 2500))
-    huber = float(rng.choice([0.0, 0.0, 1.0, 2.5]))
-    cauchy = huber == 0.0 and rng.random() < 0.15
-    prob = syn.make_problem(C, P, k, seed=int(rng.integers(1, 1 << 30)), outlier_frac=0.05 if (huber or cauchy) else 0.0)
-    kw = dict(huber_delta=huber)
-    if cauchy:
-        kw = dict(huber_delta=0.0, loss_type=2, loss_scale=2.0) if "loss_type" in capi.default_options.__code__.co_varnames else dict(huber_delta=0.0)
-    o_ref = oracle.options(huber_delta=huber)
-    ref, s_ref, log_ref = oracle.solve_points(prob, o_ref)
-    got, s_got, log_got = capi.solve_points(prob, capi.default_options(schur_impl=1, huber_delta=huber))
-    ok = (s_got.termination_type == s_ref.termination and s_got.num_iterations == s_ref.num_iterations and np.array_equal(log_got[:, 7], log_ref[:, 7]))
-    rel = block_rel(got, ref, C)
-    rel_al = block_rel(gauge.align(got, ref, C)[0], ref, C) if rel >= 1e-6 else rel
-    cost_rel = abs(s_got.final_cost - s_ref.final_cost) / s_ref.final_cost
-    # where the two trajectories part: relative difference of the iterates' costs at iterations 1..3 and the first iteration
-    # it exceeds 1e-9 (a defect shows at once; rounding amplified along flat directions shows late and grows gradually)
-    m = min(len(log_got), len(log_ref))
-    dc = np.abs(log_got[:m, 1] - log_ref[:m, 1]) / np.maximum(np.abs(log_ref[:m, 1]), 1e-300)
-    part = next((j for j in range(m) if dc[j] > 1e-9), -1)
-    early = dc[1:4].max() if m > 1 else 0.0
-    good = ok and rel_al < 1e-6 and rel < 1e-3 and cost_rel < 1e-9
-    bad += 0 if good else 1
-    print("%3d C=%3d P=%4d k=%2d huber=%.1f iters %2d raw %.1e aligned %.1e cost %.1e | iterates' costs: first 3 %.0e, part at %d %s" % (i, C, P, k, huber, s_got.num_iterations, rel, rel_al, cost_rel, early, part, "ok" if good else "MISMATCH"), flush=True)
-print("mismatches:", bad)
-sys.exit(1 if bad else 0)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+nbad = nsens = 0
+for c in fuzz_cases.cases(ncase, seed):
+    r = fuzz_cases.run(oracle, capi, c)
+    bad = fuzz_cases.verdict(r)
+    nbad += 1 if bad else 0
+    sens = fuzz_cases.sensitive(r)
+    nsens += 1 if sens else 0
+    sp = r["spread"]
+    print("%-34s iters %2d radius max %.0e | raw %.1e final cost %.1e rms %.0e first three %.0e part at %d | oracle vs itself: raw %.1e cost %.1e part at %d %s | %s" % (
+        fuzz_cases.label(c), r["iterations"], r["radius_max"], r["raw"], r["final_cost"], r["rms"], r["first3"], r["part"],
+        sp["raw"], sp["final_cost"], sp["part"], "SENSITIVE" if sens else "", "ok" if not bad else "MISMATCH: " + "; ".join(bad)), flush=True)
+print("mismatches:", nbad, "of", ncase, "; cases on which the oracle parts from itself:", nsens)
+sys.exit(1 if nbad else 0)
