@@ -253,6 +253,13 @@ int rsba_points_linearize_payload(rsba_problem* p, const rsba_options* o, double
 /* ncclGetUniqueId: rank 0 calls this and ships the 128 bytes to the other ranks (bench.py does it
  * through torch.distributed); every rank then passes it in rsba_options.comm_unique_id. */
 int rsba_comm_unique_id(void* out128);
+/* The same 128 bytes for a LOOPBACK group: world_size solver objects of ONE process on ONE GPU, each created and run by its own
+ * host thread with this id in rsba_options.comm_unique_id (and its rank).  The collectives of the multi-GPU schedule are then
+ * sums over the group's solvers on that GPU instead of ncclAllReduce over xGMI (csrc/ba_comm.hpp): the whole N > 1 schedule
+ * — sharded upload, three collectives per LM step, the summed stall flag — on a one-GPU box.  The ranks take turns on the
+ * device, so it measures nothing; it is how the multi-rank code path is tested where only one GPU is visible.  The reference
+ * has no counterpart (single-threaded: Main_Calibration/bundle_adjustment_manager.cpp:90-92). */
+int rsba_comm_loopback_id(void* out128);
 /* ncclCommCount of the solver's communicator: the number of ranks its all-reduces really span (1 without a
  * communicator).  bench.py prints it as `rccl_nranks` and refuses to report a line when it differs from --gpus. */
 int rsba_solver_comm_nranks(const rsba_solver* s);

@@ -22,7 +22,7 @@ EXPORTS = [
     "rsba_problem_marker_idx", "rsba_problem_camera_parameters", "rsba_problem_marker_transform",
     "rsba_problem_point3d_coordinates", "rsba_options_default", "rsba_solve", "rsba_solver_create", "rsba_solver_run",
     "rsba_solver_download", "rsba_solver_iterations", "rsba_solver_kernel_stats", "rsba_solver_final_costs",
-    "rsba_solver_destroy", "rsba_points_linearize_and_step", "rsba_points_linearize_payload", "rsba_comm_unique_id", "rsba_read_intrinsics_xml",
+    "rsba_solver_destroy", "rsba_points_linearize_and_step", "rsba_points_linearize_payload", "rsba_comm_unique_id", "rsba_comm_loopback_id", "rsba_read_intrinsics_xml",
     "rsba_write_outputs", "rsba_reprojection_error", "rsba_reprojection_check_files",
     "rsba_base_pose_from_marker_detection", "rsba_marker_pose_in_camera", "rsba_marker_corners_in_camera", "rsba_solve_pnp_epnp",
     "rsba_problem_initial_camera_poses", "rsba_problem_set_camera_constant", "rsba_solver_full_report", "rsba_solver_configure_run",
@@ -117,6 +117,7 @@ def load():
     lib.rsba_points_linearize_and_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 4
     lib.rsba_points_linearize_payload.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]
     lib.rsba_comm_unique_id.argtypes = [C.c_void_p]
+    lib.rsba_comm_loopback_id.argtypes = [C.c_void_p]
     lib.rsba_read_intrinsics_xml.argtypes = [C.c_char_p, C.c_void_p]
     lib.rsba_write_outputs.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.rsba_reprojection_error.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -356,6 +357,54 @@ def comm_unique_id():
     buf = (C.c_char * 128)()
     _chk(load().rsba_comm_unique_id(buf), "rsba_comm_unique_id")
     return bytes(buf)
+
+
+def comm_loopback_id():
+    """Id of a loopback group: the ranks are solvers of this process on one GPU (rsba.h)."""
+    buf = (C.c_char * 128)()
+    _chk(load().rsba_comm_loopback_id(buf), "rsba_comm_loopback_id")
+    return bytes(buf)
+
+
+def solve_points_sharded_loopback(shards, opts_kw=None, max_iterations=None):
+    """The multi-rank schedule on ONE GPU: shard r of `shards` (dicts from synthetic.make_problem(..., point_range=...), all
+    with the same cameras) is rank r of a loopback group, created and run by its own host thread, as one process per GPU
+    would.  Returns a list of (parameters, Summary, iteration log, comm_nranks) per rank; raises if a rank failed."""
+    import threading
+    world = len(shards)
+    uid = C.create_string_buffer(comm_loopback_id(), 128)
+    out, err = [None] * world, [None] * world
+
+    def rank_main(r):
+        p = sv = None
+        try:
+            o = default_options(rank=r, world_size=world, **(opts_kw or {}))
+            o.comm_unique_id = C.cast(uid, C.c_void_p)
+            p = Problem.points(shards[r])
+            sv = Solver(p, o)
+            if max_iterations is not None:
+                sv.configure_run(max_iterations)
+            nr = sv.comm_nranks()
+            s = sv.run()
+            sv.download()
+            out[r] = (p.params.copy(), s, sv.iterations(), nr)
+        except Exception as e:  # noqa: BLE001 (reported by the caller's thread)
+            err[r] = e
+        finally:
+            if sv is not None:
+                sv.close()
+            if p is not None:
+                p.close()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for r, e in enumerate(err):
+        if e is not None:
+            raise RuntimeError("loopback rank %d failed: %s" % (r, e))
+    return out
 
 
 def read_intrinsics_xml(path):

@@ -12,7 +12,6 @@
 // one (max) of the gradient bound, and one tiny (sum) of the candidate scalars.  Every rank then
 // factors the identical system, so no broadcast is needed and all ranks take identical decisions.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -27,6 +26,7 @@
 #include <thread>
 #include <vector>
 
+#include "ba_comm.hpp"
 #include "ba_marker_kernels.hpp"
 #include "ba_marker_schur.hpp"
 #include "ba_point_kernels.hpp"
@@ -48,11 +48,10 @@ namespace rsba {
       return RSBA_ERR_HIP;                                                                  \
     }                                                                                       \
   } while (0)
-#define NCCLCHK(expr)                                                                       \
+#define COMMCHK(expr)                                                                       \
   do {                                                                                      \
-    ncclResult_t _r = (expr);                                                               \
-    if (_r != ncclSuccess) {                                                                \
-      fprintf(stderr, "rsba: RCCL error %s at %s:%d\n", ncclGetErrorString(_r), __FILE__, __LINE__); \
+    if (!(expr)) {                                                                          \
+      fprintf(stderr, "rsba: collective failed at %s:%d\n", __FILE__, __LINE__);            \
       return RSBA_ERR_COMM;                                                                 \
     }                                                                                       \
   } while (0)
@@ -174,6 +173,8 @@ struct rsba_solver {
   int test_stall = 0;        // RSBA_TEST_STALL=1: the Cholesky waits for a tag nobody publishes, =2: the back-substitution does
                              // (both exercise the fallback to the sequential schedule)
   int step_tag = 0;
+  int inject_stall_step = 0; // RSBA_TEST_STALL_STEP=k (with a communicator; RSBA_TEST_STALL_RANK=r: on that rank only): step k reports a
+                             // stalled factorisation on this rank — the flag is summed over the ranks and ALL of them repeat the step
   int chol_wgs = 1;          // > 1: the reduced system is factored by this many workgroups (ba_cholesky_multi.hpp)
   bool chol_diag = false;    // ... with the diagonal chain in workgroup 0 (ba_cholesky_diag.hpp; RSBA_CHOL_DIAG=0: blocks dealt round-robin, ba_cholesky_multi.hpp)
   int* mc_flags = nullptr;   // tdone[16] | strip_ready[16] | wg_done[8] | error
@@ -208,7 +209,7 @@ struct rsba_solver {
   int trace_ring = 0, trace_ring_first_tag = 0;
   std::chrono::steady_clock::time_point host_t[4];
   long long* wg_trace = nullptr;  // RSBA_TRACE=2: per-block stamps of the Schur kernel, dumped to RSBA_TRACE_FILE
-  ncclComm_t comm = nullptr;
+  std::shared_ptr<Comm> comm;   // RCCL, or the one-GPU loopback group (ba_comm.hpp); null: single GPU
   KernelTimer timer;
   std::vector<rsba_iteration> iters;
   double final_cost = 0, final_sumsq = 0, setup_seconds = 0;
@@ -667,6 +668,7 @@ __global__ void k_probe_wait(int* flag, long long budget_ticks, int* seen) {
   }
   *seen = ok;
 }
+__global__ void k_set_double(double* p, double v) { *p = v; }
 __global__ void k_probe_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // true: a kernel on `main` starts while one on `side` is running
@@ -792,7 +794,7 @@ static int UploadPoints(rsba_solver* s) {
       int h = s->pipelined ? 1 : 0, *d = nullptr;
       if ((rc = DevAlloc(&d, 1))) return rc;
       HIPCHK(hipMemcpy(d, &h, sizeof(int), hipMemcpyHostToDevice));
-      NCCLCHK(ncclAllReduce(d, d, 1, ncclInt32, ncclMin, s->comm, s->stream));
+      COMMCHK(s->comm->MinInts(d, 1, s->stream));
       HIPCHK(hipStreamSynchronize(s->stream));
       HIPCHK(hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost));
       (void)hipFree(d);
@@ -1183,16 +1185,16 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       for (int g = 0; g < ts.nstages; ++g) {
         const int r0 = 6 * RSBA_TG * g, r1 = std::min(6 * RSBA_TG * (g + 1), n), rows = r1 - r0;
         k_wait_stage<<<1, 64, 0, s->sR>>>(ts.ready + 1 + g, tag, ts.tree_error);
-        NCCLCHK(ncclGroupStart());
-        NCCLCHK(ncclAllReduce(s->red + L.S() + (size_t)r0 * n, s->red + L.S() + (size_t)r0 * n, (size_t)rows * n, ncclDouble, ncclSum, s->comm, s->sR));
-        NCCLCHK(ncclAllReduce(s->red + L.gc() + r0, s->red + L.gc() + r0, rows, ncclDouble, ncclSum, s->comm, s->sR));
-        NCCLCHK(ncclAllReduce(s->red + L.corr() + r0, s->red + L.corr() + r0, rows, ncclDouble, ncclSum, s->comm, s->sR));
-        NCCLCHK(ncclAllReduce(s->red + L.diagU() + r0, s->red + L.diagU() + r0, rows, ncclDouble, ncclSum, s->comm, s->sR));
+        COMMCHK(s->comm->GroupStart());
+        COMMCHK(s->comm->SumDoubles(s->red + L.S() + (size_t)r0 * n, (size_t)rows * n, s->sR));
+        COMMCHK(s->comm->SumDoubles(s->red + L.gc() + r0, rows, s->sR));
+        COMMCHK(s->comm->SumDoubles(s->red + L.corr() + r0, rows, s->sR));
+        COMMCHK(s->comm->SumDoubles(s->red + L.diagU() + r0, rows, s->sR));
         if (g == ts.nstages - 1) {
-          NCCLCHK(ncclAllReduce(s->red + L.scal(), s->red + L.scal(), 8, ncclDouble, ncclSum, s->comm, s->sR));
-          NCCLCHK(ncclAllReduce(s->gmax, s->gmax, 1, ncclDouble, ncclMax, s->comm, s->sR));
+          COMMCHK(s->comm->SumDoubles(s->red + L.scal(), 8, s->sR));
+          COMMCHK(s->comm->MaxDoubles(s->gmax, 1, s->sR));
         }
-        NCCLCHK(ncclGroupEnd());
+        COMMCHK(s->comm->GroupEnd());
         k_set_flag<<<1, 64, 0, s->sR>>>(s->ready_global + 1 + g, tag);
       }
     }
@@ -1203,10 +1205,10 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   if (s->comm && !(pipe && s->pipelined_mg)) {
     RoctxRange rr_k7("K7 RCCL all-reduce of the reduced system");
     // one group: the sum of the packed reduced system and the max of the point-gradient bound go out as one launch
-    NCCLCHK(ncclGroupStart());
-    NCCLCHK(ncclAllReduce(s->red, s->red, s->L.size(), ncclDouble, ncclSum, s->comm, st));
-    NCCLCHK(ncclAllReduce(s->gmax, s->gmax, 1, ncclDouble, ncclMax, s->comm, st));
-    NCCLCHK(ncclGroupEnd());
+    COMMCHK(s->comm->GroupStart());
+    COMMCHK(s->comm->SumDoubles(s->red, s->L.size(), st));
+    COMMCHK(s->comm->MaxDoubles(s->gmax, 1, st));
+    COMMCHK(s->comm->GroupEnd());
   }
 
   RoctxRange rr_k4s(pipe ? "K4 (already launched)" : "K4 reduced camera system: Cholesky + solve");
@@ -1363,6 +1365,10 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   DebugSync(st, "k_backsub_candidate");
   if (s->comm) {
     const bool mg = pipe && s->pipelined_mg;
+    if (s->inject_stall_step != 0 && s->step_tag == s->inject_stall_step) {
+      k_set_double<<<1, 1, 0, st>>>(s->res + RES_STALL, 1.0);
+      s->inject_stall_step = 0;
+    }
     T.Begin("k_finish_candidate", st);
     // res_stall: with a communicator the stall flag of the factorisation (multi-workgroup / persistent tiles: in-kernel
     // waits) and of the pipeline rides in small_red[5] and is SUMMED over the ranks in every schedule, so that all ranks
@@ -1376,7 +1382,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       HIPCHK(hipStreamWaitEvent(s->sR, s->ev_bs, 0));
       sc = s->sR;
     }
-    NCCLCHK(ncclAllReduce(s->small_red, s->small_red, 8, ncclDouble, ncclSum, s->comm, sc));
+    COMMCHK(s->comm->SumDoubles(s->small_red, 8, sc));
     k_publish_result<<<1, 64, 0, sc>>>(s->small_red, s->res, s->res_host, s->res_seq + 1.0, 1, s->trace);
   }
   HIPCHK(hipGetLastError());
@@ -1505,11 +1511,11 @@ static int PointsGradient(rsba_solver* s, double radius) {
   }
   if (s->comm) {
     // g_c and the scalars are sums over the ranks' shards, max |g_p| a maximum
-    NCCLCHK(ncclGroupStart());
-    NCCLCHK(ncclAllReduce(s->red + s->L.gc(), s->red + s->L.gc(), (size_t)s->nc, ncclDouble, ncclSum, s->comm, st));
-    NCCLCHK(ncclAllReduce(s->red + s->L.scal(), s->red + s->L.scal(), 8, ncclDouble, ncclSum, s->comm, st));
-    NCCLCHK(ncclAllReduce(s->gmax, s->gmax, 1, ncclDouble, ncclMax, s->comm, st));
-    NCCLCHK(ncclGroupEnd());
+    COMMCHK(s->comm->GroupStart());
+    COMMCHK(s->comm->SumDoubles(s->red + s->L.gc(), (size_t)s->nc, st));
+    COMMCHK(s->comm->SumDoubles(s->red + s->L.scal(), 8, st));
+    COMMCHK(s->comm->MaxDoubles(s->gmax, 1, st));
+    COMMCHK(s->comm->GroupEnd());
   }
   k_gradient_result<<<1, 256, 0, st>>>(s->red, s->L, s->gmax, s->res, s->res_host, s->res_seq + 1.0);
   HIPCHK(hipGetLastError());
@@ -1666,12 +1672,16 @@ int rsba_comm_unique_id(void* out128) {
   return RSBA_OK;
 }
 
+int rsba_comm_loopback_id(void* out128) {
+  if (!out128) return RSBA_ERR_ARG;
+  rsba::LoopbackComm::NewId(out128);
+  return RSBA_OK;
+}
+
 int rsba_solver_comm_nranks(const rsba_solver* s) {
   if (!s) return 0;
   if (!s->comm) return 1;
-  int n = 0;
-  if (ncclCommCount(s->comm, &n) != ncclSuccess) return 0;
-  return n;
+  return s->comm->nranks();
 }
 
 int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out) {
@@ -1692,22 +1702,17 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
   if (opt.profile_kernels) s->timer.Reserve(256);
   int rc = RSBA_OK;
   if (opt.world_size > 1 || getenv("RSBA_FORCE_COMM")) {
-    // One communicator per unique id and process (an id can be used for one ncclCommInitRank only);
-    // solvers created later with the same id share it.  RSBA_FORCE_COMM=1 builds a 1-rank communicator
-    // so the collective path can be exercised on a single GPU.
-    static std::map<std::string, ncclComm_t> comms;
-    ncclUniqueId id;
-    if (opt.world_size > 1) memcpy(&id, opt.comm_unique_id, sizeof(id));
-    else if (ncclGetUniqueId(&id) != ncclSuccess) { rsba::FreeSolver(s); return RSBA_ERR_COMM; }
-    const std::string key = opt.world_size > 1 ? std::string((const char*)&id, sizeof(id)) : std::string("single");
-    auto it = comms.find(key);
-    if (it == comms.end()) {
-      ncclComm_t c = nullptr;
-      if (ncclCommInitRank(&c, std::max(opt.world_size, 1), id, opt.world_size > 1 ? opt.rank : 0) != ncclSuccess) { rsba::FreeSolver(s); return RSBA_ERR_COMM; }
-      it = comms.emplace(key, c).first;
-    }
-    s->comm = it->second;
+    // RCCL (one communicator per unique id and process; RSBA_FORCE_COMM=1: a 1-rank communicator, so that the collective
+    // path can be exercised on a single GPU), or — an id from rsba_comm_loopback_id — the ranks of one process on one GPU
+    s->comm = opt.world_size > 1 && rsba::LoopbackComm::IsLoopbackId(opt.comm_unique_id)
+                  ? rsba::LoopbackComm::Create(opt.world_size, opt.rank, opt.comm_unique_id)
+                  : rsba::RcclComm::Create(opt.world_size, opt.rank, opt.comm_unique_id);
+    if (!s->comm) { rsba::FreeSolver(s); return RSBA_ERR_COMM; }
   }
+  std::shared_ptr<rsba::Comm> comm_keep = s->comm;   // (outlives s on the error paths below)
+  rsba::CommScope device_turn(comm_keep.get());
+  if (s->comm && getenv("RSBA_TEST_STALL_STEP") && (!getenv("RSBA_TEST_STALL_RANK") || atoi(getenv("RSBA_TEST_STALL_RANK")) == opt.rank))
+    s->inject_stall_step = atoi(getenv("RSBA_TEST_STALL_STEP"));
   if (hipHostMalloc((void**)&s->res_host, (RES_SIZE + 8) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { rsba::FreeSolver(s); return RSBA_ERR_HIP; }
   memset(s->res_host, 0, (RES_SIZE + 8) * sizeof(double));   // [RES_SIZE]: the factorisation's "resident" word (StageGate)
   if (p->model == RSBA_MODEL_POINTS) rc = rsba::UploadPoints(s);
@@ -1722,7 +1727,7 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
     }
   }
   if (rc == RSBA_OK && hipDeviceSynchronize() != hipSuccess) rc = RSBA_ERR_HIP;
-  if (rc != RSBA_OK) { rsba::FreeSolver(s); return rc; }
+  if (rc != RSBA_OK) { if (comm_keep) comm_keep->Abort(); rsba::FreeSolver(s); return rc; }
   s->setup_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   *out = s;
   return RSBA_OK;
@@ -1734,6 +1739,8 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
   sum.setup_seconds = s->setup_seconds;
   if (hipSetDevice(s->device) != hipSuccess) return RSBA_ERR_HIP;
   int rc;
+  rsba::CommScope device_turn(s->comm.get());
+  struct AbortOnError { rsba_solver* s; int* rc; ~AbortOnError() { if (*rc != RSBA_OK && s->comm) s->comm->Abort(); } } abort_guard{s, &rc};
   if (s->prob->model == RSBA_MODEL_POINTS) {
     if ((rc = rsba::ResetPoints(s)) != RSBA_OK) return rc;
     if (hipStreamSynchronize(s->stream) != hipSuccess) return RSBA_ERR_HIP;

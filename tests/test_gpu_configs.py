@@ -87,6 +87,22 @@ def test_config5_shard_huber_forced_iterations(oracle):
     _forced_iterations_match(oracle, prob, 3, huber=huber)
 
 
+def test_config4_whole_problem_on_one_gpu(oracle):
+    """BASELINE.json configs[3] UNSHARDED: 64 cams x 1M points, 20M observations fit one MI355X (288 GB); the same three forced
+    iterations against the oracle, every block compared.  (In eight shards: tests/test_gpu_loopback.py.)"""
+    prob = syn.make_config("cfg4")
+    assert (prob["C"], prob["P"], prob["N"]) == (64, 1_000_000, 20_000_000)
+    _forced_iterations_match(oracle, prob, 3)
+
+
+def test_config5_whole_problem_on_one_gpu(oracle):
+    """BASELINE.json configs[4] UNSHARDED: 256 cams x 500k points, 10M observations, Huber."""
+    C, P, k, seed, outl, huber = syn.CONFIGS["cfg5"]
+    prob = syn.make_config("cfg5")
+    assert (prob["C"], prob["P"], prob["N"]) == (256, 500_000, 10_000_000)
+    _forced_iterations_match(oracle, prob, 3, huber=huber)
+
+
 def test_config5_shard_reduced_system_matches_oracle(oracle):
     """One linearisation of a (smaller) 256-camera Huber shard, stage by stage: S, rhs, step, model cost change."""
     C, P, k, seed, outl, huber = syn.CONFIGS["cfg5"]

@@ -1,0 +1,131 @@
+"""The multi-rank schedule on ONE GPU: N point shards = N solver objects of this process, each driven by its own host thread, their
+collectives summed over the group instead of sent through ncclAllReduce (csrc/ba_comm.hpp, rsba_comm_loopback_id).
+
+Everything of the N > 1 path except the RCCL call itself runs here: the sharded upload (all cameras, a contiguous range of the
+points: realsensecalibration_amd/distributed.py), the sequential multi-GPU schedule with its three collectives per LM step,
+the end-of-run gradient collectives, the stall flag summed over the ranks and the fallback every rank then takes.  The whole
+problem is what the ORACLE solves, unsharded; the reference itself is single-threaded and has no counterpart
+(Main_Calibration/bundle_adjustment_manager.cpp:90-92, Test1_BundleAdjustment/main.cpp:82-87).  What must hold:
+  * the stitched solution equals the oracle's of the whole problem like a single-GPU solve does (trajectory, costs, raw
+    parameters per block to 1e-6, RMS to 1e-4 px);
+  * every rank holds bit-identical camera blocks and took bit-identical decisions (identical iteration logs);
+  * the communicator really spans N ranks.
+BASELINE.json's configs[3] and configs[4] — 64 cameras x 1M points and 256 cameras x 500k points with Huber loss, both 8-GPU jobs —
+run here at their full size in 8 shards (three forced iterations bound the oracle's time).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from realsensecalibration_amd import capi
+from realsensecalibration_amd import distributed as rd
+from realsensecalibration_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+FORCED = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    lib = capi.load()
+    assert lib.rsba_device_count() > 0, "GPU tests need a HIP device; the product has no CPU path"
+    return lib
+
+
+def _threads():
+    return max(1, min(len(os.sched_getaffinity(0)), 64))
+
+
+def _block_rel(a, b, C):
+    worst = 0.0
+    for x, y in ((a[:6 * C].reshape(-1, 6), b[:6 * C].reshape(-1, 6)), (a[6 * C:].reshape(-1, 3), b[6 * C:].reshape(-1, 3))):
+        worst = max(worst, (np.abs(x - y).max(axis=1) / np.maximum(np.abs(y).max(axis=1), 1e-12)).max())
+    return worst
+
+
+def _shards(C, P, k, seed, world, outlier_frac=0.0):
+    return [syn.make_problem(C, P, k, seed, point_range=rd.shard_range(P, r, world), outlier_frac=outlier_frac) for r in range(world)]
+
+
+def _sharded_solve_matches_oracle(oracle, whole, shards, huber=0.0, iter_cost_tol=1e-9, **optkw):
+    """Runs the shards as a loopback group and the whole problem through the oracle; returns the ranks' results."""
+    C, world = whole["C"], len(shards)
+    ref, s_ref, log_ref = oracle.solve_points(whole, oracle.options(huber_delta=huber, num_threads=_threads(), **optkw))
+    ranks = capi.solve_points_sharded_loopback(shards, dict(huber_delta=huber, **optkw))
+    p0, s0, log0, _ = ranks[0]
+    for r, (p, s, log, nranks) in enumerate(ranks):
+        assert nranks == world
+        # the camera system is replicated: identical bits and identical decisions on every rank
+        assert np.array_equal(p[:6 * C], p0[:6 * C]), "rank %d's camera blocks differ from rank 0's" % r
+        assert np.array_equal(log[:, :8], log0[:, :8]), "rank %d's iteration log differs from rank 0's" % r
+        assert (s.termination_type, s.stop_reason, s.num_iterations, s.final_cost) == (s0.termination_type, s0.stop_reason, s0.num_iterations, s0.final_cost)
+    got = np.concatenate([p0[:6 * C]] + [p[6 * C:] for p, _, _, _ in ranks])
+    assert got.shape == ref.shape
+    assert (s0.termination_type, s0.stop_reason, s0.num_iterations) == (s_ref.termination, s_ref.stop_reason, s_ref.num_iterations)
+    assert np.array_equal(log0[:, 7], log_ref[:, 7])
+    assert np.abs(log0[:, 1] - log_ref[:, 1]).max() / log_ref[:, 1].max() < iter_cost_tol
+    assert abs(s0.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
+    assert np.allclose(log0[:, 6], log_ref[:, 6], rtol=1e-6)
+    rel = _block_rel(got, ref, C)
+    assert rel < 1e-6, "raw parameters differ by %.2e" % rel
+    ss_ref = oracle.points_cost(whole, ref, num_threads=_threads())[1]
+    ss_got = oracle.points_cost(whole, got, num_threads=_threads())[1]
+    assert abs(np.sqrt(ss_ref / (2 * whole["N"])) - np.sqrt(ss_got / (2 * whole["N"]))) < 1e-4
+    return ranks
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_config2_sharded(oracle, world):
+    """BASELINE.json configs[1] (8 cameras x 10k points, 80k observations) in 2 and in 8 shards, solved to convergence."""
+    C, P, k, seed, outl, huber = syn.CONFIGS["cfg2"]
+    whole = syn.make_config("cfg2")
+    ranks = _sharded_solve_matches_oracle(oracle, whole, _shards(C, P, k, seed, world))
+    assert ranks[0][1].num_iterations >= 3
+
+
+@pytest.mark.parametrize("C,P,k,huber,world", [(24, 4000, 8, 0.0, 2), (64, 6000, 12, 1.0, 3), (40, 5000, 9, 0.0, 5), (70, 3000, 10, 1.0, 4)])
+def test_sharded_solves_match_the_unsharded_oracle(oracle, C, P, k, huber, world):
+    """Other shapes: uneven shard sizes (3 and 5 ranks), the robust loss, the several-workgroup factorisation (40, 64 cameras)
+    and the tiled one above 64 cameras (70), all to convergence."""
+    outl = 0.05 if huber else 0.0
+    whole = syn.make_problem(C, P, k, 400 + C, outlier_frac=outl)
+    _sharded_solve_matches_oracle(oracle, whole, _shards(C, P, k, 400 + C, world, outl), huber=huber)
+
+
+def test_a_stall_on_one_rank_is_everybodys_stall(oracle, capfd):
+    """Step 2 of rank 1 reports a stalled factorisation (test hook RSBA_TEST_STALL_STEP / _RANK: what an in-kernel wait that ran
+    out of its budget leaves in the result block).  The flag travels in the candidate's sum all-reduce, so BOTH ranks repeat the
+    step with the one-workgroup factorisation and keep issuing the same collectives; the solve ends where the oracle's does."""
+    C, P, k, seed = 40, 5000, 9, 77
+    whole = syn.make_problem(C, P, k, seed)
+    os.environ["RSBA_TEST_STALL_STEP"], os.environ["RSBA_TEST_STALL_RANK"] = "2", "1"
+    try:
+        _sharded_solve_matches_oracle(oracle, whole, _shards(C, P, k, seed, 2))
+    finally:
+        del os.environ["RSBA_TEST_STALL_STEP"], os.environ["RSBA_TEST_STALL_RANK"]
+    err = capfd.readouterr().err
+    assert err.count("multi-workgroup Cholesky stalled; using one workgroup") == 2, err
+
+
+def test_config4_full_size_in_eight_shards(oracle):
+    """BASELINE.json configs[3] at its full size: 64 cameras x 1M points, 20M observations, 8 ranks of 125k points."""
+    C, P, k, seed, outl, huber = syn.CONFIGS["cfg4"]
+    whole = syn.make_config("cfg4")
+    assert (whole["C"], whole["P"], whole["N"]) == (64, 1_000_000, 20_000_000)
+    shards = _shards(C, P, k, seed, 8)
+    assert [s["P"] for s in shards] == [125_000] * 8
+    ranks = _sharded_solve_matches_oracle(oracle, whole, shards, max_num_iterations=3, **FORCED)
+    assert ranks[0][1].num_iterations == 3
+
+
+def test_config5_full_size_in_eight_shards(oracle):
+    """BASELINE.json configs[4] at its full size: 256 cameras x 500k points, 10M observations, Huber delta = 1 px with 5 %
+    outliers, 8 ranks of 62.5k points; every rank factors the 1536 x 1536 sum with the persistent tiled Cholesky."""
+    C, P, k, seed, outl, huber = syn.CONFIGS["cfg5"]
+    whole = syn.make_config("cfg5")
+    assert (whole["C"], whole["P"], whole["N"], huber, outl) == (256, 500_000, 10_000_000, 1.0, 0.05)
+    shards = _shards(C, P, k, seed, 8, outl)
+    ranks = _sharded_solve_matches_oracle(oracle, whole, shards, huber=huber, max_num_iterations=3, **FORCED)
+    assert ranks[0][1].num_iterations == 3
