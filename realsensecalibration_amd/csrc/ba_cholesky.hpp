@@ -91,6 +91,9 @@ struct StageGate {
   // first) — the Jacobi scale can be formed and the panels gated stage by stage like in every other iteration; nullptr: the
   // first iteration waits for all stages
   const int* all_diag = nullptr;
+  // multi-GPU pipeline, diagonal-workgroup factorisation: entry (i, j), i >= j, is read as S[j][i] — when camera group g's panels
+  // start only the group's ROW slab of S has been all-reduced (S is written symmetric to the bit, so the values are the same)
+  int transposed = 0;
 };
 
 __device__ __forceinline__ void AnnounceResident(const StageGate& gate) {

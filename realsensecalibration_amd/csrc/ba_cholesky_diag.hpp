@@ -90,6 +90,7 @@ struct DiagConst {
   long long budget, gate_budget;
   double min_diag, max_diag, inv_radius;
   int n, nreal, SLD, tag, gate_tag, gate_cols, gated;
+  int trs;  // 1: entry (i, j) of S is read as S[j][i] (multi-GPU pipeline: only camera group g's ROW slab is all-reduced when its panels start)
   lds_double* Bst; lds_double* t_tile[2]; lds_double* xprev; lds_double* scl;
   lds_int* s_wb; lds_int* ok_lds;
   lds_int* acq;   // [0]: the newest block some update wave has claimed to acquire for the workgroup, [1]: the newest one acquired
@@ -159,7 +160,7 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
   for (int u = 0; u < 3; ++u) {
     const int e = wk * 64 + lane + u * 384, r = e >> 5, c = e & 31;
     if (e < RSBA_PB * RSBA_PB) {
-      if (nb0 + r < nreal && nb0 + c < nreal) ns[u] = S[(size_t)(nb0 + r) * nreal + nb0 + c];
+      if (nb0 + r < nreal && nb0 + c < nreal) ns[u] = S[dc->trs ? (size_t)(nb0 + c) * nreal + nb0 + r : (size_t)(nb0 + r) * nreal + nb0 + c];
       if (r == c && nb0 + r < nreal) ndu = dc->diag_u[nb0 + r];
       ndd[u] = dc->dg[(size_t)(p + 1) * 1024 + r * 32 + c];
     }
@@ -167,7 +168,7 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
   // slice 0 also brings the rows' own entries of S (off the diagonal: scaled, no damping term)
   if (wk < 2 && sgi < nreal) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) sv8[u] = S[(size_t)sgi * nreal + kb + sc0 + u];
+    for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) sv8[u] = S[dc->trs ? (size_t)(kb + sc0 + u) * nreal + sgi : (size_t)sgi * nreal + kb + sc0 + u];
   }
   // (the slabs last: the loads return in order, and X(p+1, p-1) is formed while they are still arriving)
   {
@@ -316,7 +317,7 @@ static __device__ __noinline__ void RowUpdateHalf(lds_DiagConst* dc, int kb, int
   if (has_unit && ks == 0) {
     if (sgi < nreal) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) v[u] = S[(size_t)sgi * nreal + kb + sc0 + u];
+      for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) v[u] = S[dc->trs ? (size_t)(kb + sc0 + u) * nreal + sgi : (size_t)sgi * nreal + kb + sc0 + u];
     } else if (sgi == n) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) { v[u] = dc->gc[kb + sc0 + u]; v2[u] = dc->corr[kb + sc0 + u]; }
@@ -391,6 +392,8 @@ static __device__ __noinline__ void RowUpdateHalf(lds_DiagConst* dc, int kb, int
   }
 }
 
+// kTr: StageGate::transposed as a compile-time constant (the single-GPU instance must not carry the other one's registers)
+template <bool kTr>
 __global__ void __launch_bounds__(512)
 k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double* __restrict__ A, double* __restrict__ scale_c,
                             const double* __restrict__ cam_x, double* __restrict__ cam_c, const double* __restrict__ intr,
@@ -469,7 +472,8 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     if (gi == gj) v += fmin(fmax(scl[gi] * scl[gi] * du, ip.min_lm_diagonal), ip.max_lm_diagonal) * inv_radius;
     return v;
   };
-  auto Sat = [&](int gi, int gj) { return (gi < nreal && gj < nreal) ? S[(size_t)gi * nreal + gj] : 0.0; };
+  constexpr bool trs = kTr;
+  auto Sat = [&](int gi, int gj) { return (gi < nreal && gj < nreal) ? S[trs ? (size_t)gj * nreal + gi : (size_t)gi * nreal + gj] : 0.0; };
   if (w == 0 && !stalled) {   // the first diagonal block
     for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) { const int r = e >> 5, c = e & 31; Pre[r * RSBA_PLD + c] = sys(r, c, Sat(r, c)); }
     __syncthreads();
@@ -494,7 +498,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     s_dc.budget = budget; s_dc.gate_budget = gate.budget;
     s_dc.min_diag = ip.min_lm_diagonal; s_dc.max_diag = ip.max_lm_diagonal; s_dc.inv_radius = inv_radius;
     s_dc.n = n; s_dc.nreal = nreal; s_dc.SLD = n - 30; s_dc.tag = tag; s_dc.gate_tag = gate.tag; s_dc.gate_cols = gate.cols;
-    s_dc.gated = staged ? 1 : 0;
+    s_dc.gated = staged ? 1 : 0; s_dc.trs = kTr ? 1 : 0;
     s_dc.Bst = (lds_double*)lds; s_dc.t_tile[0] = (lds_double*)T; s_dc.t_tile[1] = (lds_double*)(lds + (size_t)32 * (n - 30) + RSBA_PB * RSBA_PLD); s_dc.xprev = (lds_double*)(lds + (n - 30 - RSBA_PB)); s_dc.scl = (lds_double*)scl;
     s_dc.s_wb = (lds_int*)&s_wb; s_dc.ok_lds = (lds_int*)&s_w7ok; s_dc.acq = (lds_int*)&s_acq[0];
     s_dc.tr = mtrace;
@@ -523,7 +527,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       const int sgi = b * RSBA_PB + half * 16 + sr;
       double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (ks == 0 && sgi < nreal) {
-        if (kb + sc0 + 8 <= nreal) {
+        if (kb + sc0 + 8 <= nreal && !trs) {
           const double2* sp = reinterpret_cast<const double2*>(S + (size_t)sgi * nreal + kb + sc0);
 #pragma unroll
           for (int u = 0; u < 4; ++u) { const double2 t = sp[u]; v[2 * u] = t.x; v[2 * u + 1] = t.y; }

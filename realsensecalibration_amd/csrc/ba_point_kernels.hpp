@@ -648,6 +648,9 @@ struct FusedLin {
   int* small_flag_next = nullptr;     // does any camera of the candidate take the small-angle branch
   double radius_next = 0.0;
   LmNext lm;                          // k_backsub_candidate_proj, single GPU: see LmNext
+  // k_backsub_candidate_proj with a communicator: the last workgroup leaves this rank's sums (and stall flags) in small_red for
+  // the all-reduce and touches neither the result block nor the host — k_publish_result completes the step behind the collective
+  int sums_only = 0;
 };
 
 template <bool kStage, bool kFused>
@@ -1284,6 +1287,10 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
         const double sm[5] = {((s[0][0] + s[0][1]) + s[0][2]) + s[0][3], ((s[1][0] + s[1][1]) + s[1][2]) + s[1][3], ((s[2][0] + s[2][1]) + s[2][2]) + s[2][3],
                               ((s[3][0] + s[3][1]) + s[3][2]) + s[3][3], ((s[4][0] + s[4][1]) + s[4][2]) + s[4][3]};
         if (tid < 5) small_red[tid] = sm[tid];
+        if (fl.sums_only) {
+          // summed over the ranks: a stall anywhere — the factorisation's in-kernel waits, this kernel's wait for the solve — is everybody's
+          if (tid == RES_STALL) small_red[5] = res_pre + s[5][0];
+        } else {
         double c = 0.5 * sm[1];
         if (!(c == c) || !(fabs(c) <= DBL_MAX)) c = DBL_MAX;  // Ceres: failed evaluation -> max double
         double out = res_pre;
@@ -1298,8 +1305,9 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
           res[tid] = out;
           if (host != nullptr) __hip_atomic_store(&host[tid], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        }
       }
-      if (fl.lm.dec != nullptr) {
+      if (fl.lm.dec != nullptr && !fl.sums_only) {
         __syncthreads();
         if (tid == 0) {
           double acc, nr;
@@ -1313,7 +1321,7 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
           }
         }
       }
-      if (host != nullptr && tid < 64) {
+      if (host != nullptr && tid < 64 && !fl.sums_only) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: the values before the sequence number
         if (tid == 0) __hip_atomic_store(&host[RES_SIZE - 1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -1396,11 +1404,22 @@ __device__ __forceinline__ void PostToHost(const double* __restrict__ res, doubl
     if (tid == 0) __hip_atomic_store(&host[RES_SIZE - 1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+// (lm.dec != nullptr: the step's decision for the damping kernel queued behind this one, as the single-GPU back-substitution
+//  takes it — here from the all-reduced sums, i.e. the same bits on every rank)
 __global__ void k_publish_result(const double* __restrict__ small_red, double* __restrict__ res, double* host, double seq, int stall_summed,
-                                 long long* trace = nullptr) {
+                                 long long* trace = nullptr, LmNext lm = LmNext()) {
   if (trace && threadIdx.x == 0 && blockIdx.x == 0) trace[27] = wall_clock64();
   if (blockIdx.x != 0) return;
-  if (threadIdx.x == 0) { PublishResult(small_red, res); if (stall_summed) res[RES_STALL] = small_red[5]; }
+  if (threadIdx.x == 0) {
+    PublishResult(small_red, res);
+    if (stall_summed) res[RES_STALL] = small_red[5];
+    if (lm.dec != nullptr) {
+      double acc, nr;
+      DecideStep(lm, res[RES_COST_X], res[RES_COST_C], res[RES_MCC], res[RES_STEP2], res[RES_CHOL_OK], &acc, &nr);
+      const double d3[3] = {1.0, acc, nr};
+      for (int q = 0; q < 3; ++q) { lm.dec[q] = d3[q]; res[RES_DEC_GO + q] = d3[q]; }
+    }
+  }
   __syncthreads();
   PostToHost(res, host, seq);
 }

@@ -1113,22 +1113,27 @@ k_schur_tiles(SchurArgs a) {
 
 
 // Multi-GPU pipeline, communication stream: k_wait_stage holds the stream until the Schur kernel has published stage g
-// locally (then RCCL all-reduces the stage's row slab of S and its vector ranges), k_set_flag publishes the reduced stage
-// to the Cholesky.  One wavefront, a handful of registers: it fits beside the chip-filling kernel.
+// locally; then ONE grouped all-reduce sums the stage's row slab of S (complete on every rank once the stage is: the finishers
+// write every block and its mirror) and the group's ranges of g_c, the right-hand-side correction and diag U; k_set_flag
+// publishes the summed stage to the factorisation, which reads the slab transposed (StageGate::transposed).  One wavefront and
+// a handful of registers each: they are dispatched at once beside the chip-filling Schur kernel and the resident
+// back-substitution.  (Tried instead, round 3: the lower trapezoid of the group's columns gathered into one buffer and
+// scattered back behind the all-reduce — half the bytes and one collective per stage, but the two copy kernels, fifteen
+// workgroups of 46 registers each, waited 5 to 26 us for slots on the full chip, every stage, on the path of the gate.)
+// (No fence in either kernel: what the Schur kernel published before the flag is acquired by the collective's own kernel
+//  start, what the collective wrote is released by its kernel end, and the flag store follows it in stream order.  With
+//  fences — an L2 write-back beside the Schur kernel or the prefetching back-substitution — k_set_flag took 5 to 29 us.)
 __global__ void __launch_bounds__(64) k_wait_stage(const int* __restrict__ flag, int tag, int* __restrict__ error) {
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
-      __builtin_amdgcn_s_sleep(32);
+      __builtin_amdgcn_s_sleep(8);
       if (wall_clock64() - t0 > 10 * RSBA_STALL_TICKS) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
   }
-  __syncthreads();
-  __threadfence();
 }
 __global__ void __launch_bounds__(64) k_set_flag(int* __restrict__ flag, int tag) {
-  __threadfence();
-  if (threadIdx.x == 0) __hip_atomic_store(flag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_store(flag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace rsba

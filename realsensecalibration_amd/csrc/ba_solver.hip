@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <thread>
@@ -187,7 +188,6 @@ struct rsba_solver {
   // the RCCL all-reduce of that stage's row slab of S (k_wait_stage / k_set_flag, ba_schur_tiled.hpp)
   bool pipelined_mg = false;
   hipStream_t sR = nullptr;
-  hipEvent_t ev_bs = nullptr;
   int* ready_global = nullptr;
   long long* chol_waited = nullptr;   // device: ticks the pipelined Cholesky spent waiting for its columns (cumulative)
   long long chol_waited_seen = 0, backsub_waited_seen = 0;   // [1]: the back-substitution's wait for the solve
@@ -208,6 +208,11 @@ struct rsba_solver {
   long long* trace_base = nullptr;
   int trace_ring = 0, trace_ring_first_tag = 0;
   std::chrono::steady_clock::time_point host_t[4];
+  // RSBA_HOSTPROF=1: host-side time of a step's phases, summed over the run and printed at its end (no device work, no print per step)
+  bool hostprof = false;
+  double hp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long hp_n = 0;
+  std::chrono::steady_clock::time_point hp_t, hp_result;
   long long* wg_trace = nullptr;  // RSBA_TRACE=2: per-block stamps of the Schur kernel, dumped to RSBA_TRACE_FILE
   std::shared_ptr<Comm> comm;   // RCCL, or the one-GPU loopback group (ba_comm.hpp); null: single GPU
   KernelTimer timer;
@@ -631,7 +636,6 @@ static void FreeSolver(rsba_solver* s) {
   if (s->chol_waited) (void)hipFree(s->chol_waited);
   if (s->sB) (void)hipStreamDestroy(s->sB);
   if (s->sR) (void)hipStreamDestroy(s->sR);
-  if (s->ev_bs) (void)hipEventDestroy(s->ev_bs);
   if (s->ready_global) (void)hipFree(s->ready_global);
   if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -705,10 +709,15 @@ static bool SetupPipeline(rsba_solver* s) {
   if (mode == 0) return false;
   s->test_stall = getenv("RSBA_TEST_STALL") ? std::max(1, atoi(getenv("RSBA_TEST_STALL"))) : 0;
   const bool mg = s->comm != nullptr;
-  // Multi-GPU pipeline: opt-in (RSBA_PIPELINE_MG=1).  With a 1-rank communicator on one GPU it is correct (the whole GPU
-  // suite passes) but not faster than the sequential multi-GPU schedule (0.89 vs 0.81 ms: the tail of the step —
-  // back-substitution, sums, hop to the communication stream, all-reduce, publish — costs what the overlap gains), and it
-  // could not be run on several GPUs in this environment.
+  // Multi-GPU pipeline: opt-in (RSBA_PIPELINE_MG=1).  Round 3: the same kernels as the single-GPU pipeline (diagonal-workgroup
+  // factorisation reading each stage's all-reduced row slab transposed, the back-substitution's last workgroup leaving the
+  // rank's sums for the all-reduce, the decision taken by k_publish_result) — with a 1-rank communicator 0.477 ms per LM
+  // iteration at 64 cameras x 100k points against 0.707 (round 2), 0.478 for the sequential multi-GPU schedule and 0.430
+  // without a communicator.  What is left of the gap is not in the kernels: the next step's factorisation and Schur kernel
+  // START ~35 us later after the posted result than on a process with two hardware queues, whatever the host does (it has
+  // launched both 7 us after the result in either case, RSBA_HOSTPROF=1) — the same 0.430 -> 0.470 ms is measured WITHOUT a
+  // communicator when two more hardware queues merely exist in the process.  It could not be run on
+  // several GPUs in this environment, so it stays opt-in.
   if (mg && !(getenv("RSBA_PIPELINE_MG") && atoi(getenv("RSBA_PIPELINE_MG")) == 1)) return false;
   if (s->nc > RSBA_CHOL_MAXN || s->C <= RSBA_TG) return false;        // one camera group: nothing to overlap
   hipDeviceProp_t prop;
@@ -716,23 +725,33 @@ static bool SetupPipeline(rsba_solver* s) {
   const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
   std::vector<uint32_t> mask(words, mode == 3 ? 0u : 0xffffffffu);
   if (mode == 3) mask[0] = 1u;
-  // (a few attempts: every new stream is dealt onto the next hardware queue)
-  bool ok = false;
-  std::vector<hipStream_t> rejected;
-  for (int attempt = 0; attempt < 4 && !ok; ++attempt) {
-    if (hipExtStreamCreateWithCUMask(&s->sB, words, mask.data()) != hipSuccess) { s->sB = nullptr; break; }
-    ok = StreamsRunConcurrently(s->sB, s->stream);
-    if (!ok) { rejected.push_back(s->sB); s->sB = nullptr; }
-  }
-  for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+  // A side stream with a hardware queue of its own (hipExtStreamCreateWithCUMask, all CUs) that passes `probe`; a few attempts:
+  // every new stream is dealt onto the next hardware queue.  (Streams from HIP's pool — hipStreamCreateWithFlags — were tried
+  // for the multi-GPU pipeline, round 3: they pass the probe at set-up and are dealt onto other queues later; once in ~30 steps
+  // the communication stream then sat behind the waiting factorisation and the step timed out.)
+  auto side_stream = [&](hipStream_t* out, const std::function<bool(hipStream_t)>& probe) {
+    std::vector<hipStream_t> rejected;
+    bool got = false;
+    for (int attempt = 0; attempt < 6 && !got; ++attempt) {
+      if (hipExtStreamCreateWithCUMask(out, words, mask.data()) != hipSuccess) { *out = nullptr; break; }
+      got = probe(*out);
+      if (!got) { rejected.push_back(*out); *out = nullptr; }
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    return got;
+  };
+  bool ok = side_stream(&s->sB, [&](hipStream_t c) { return StreamsRunConcurrently(c, s->stream); });
   if (!ok && getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: the side stream does not run beside the main stream, solve not pipelined\n");
   ok = ok && hipMalloc((void**)&s->chol_waited, 2 * sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, 2 * sizeof(long long)) == hipSuccess;
   if (ok && mg) {
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    ok = hipStreamCreateWithPriority(&s->sR, hipStreamNonBlocking, prio_hi) == hipSuccess &&
-         hipEventCreateWithFlags(&s->ev_bs, hipEventDisableTiming) == hipSuccess &&
-         hipMalloc((void**)&s->ready_global, 16 * sizeof(int)) == hipSuccess && hipMemset(s->ready_global, 0, 16 * sizeof(int)) == hipSuccess;
+    // The communication stream carries kernels that WAIT (k_wait_stage, for the Schur kernel on the main stream) and kernels
+    // others wait for (k_set_flag, for the factorisation on sB): it must run beside both, probed in every direction that
+    // occurs.  (Seen when it shared sB's queue: the first stage's exchange sat behind the factorisation that was waiting for
+    // it, and every pipelined step timed out.)
+    const bool got = side_stream(&s->sR, [&](hipStream_t c) {
+      return StreamsRunConcurrently(s->sB, c) && StreamsRunConcurrently(c, s->stream) && StreamsRunConcurrently(s->stream, c);
+    });
+    ok = got && hipMalloc((void**)&s->ready_global, 16 * sizeof(int)) == hipSuccess && hipMemset(s->ready_global, 0, 16 * sizeof(int)) == hipSuccess;
     s->pipelined_mg = ok;
   }
   if (!ok) { (void)hipGetLastError(); if (getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: CU-masked stream unavailable, solve not pipelined\n"); }
@@ -887,7 +906,7 @@ static int UploadPoints(rsba_solver* s) {
     const char* e = getenv("RSBA_CHOL_WGS");
     const bool want_diag = !(getenv("RSBA_CHOL_DIAG") && atoi(getenv("RSBA_CHOL_DIAG")) == 0);
     const int want = e ? atoi(e) : (want_diag ? 6 : 4);
-    if (want > 1 && s->opt.schur_impl != 0 && s->nc >= 6 * RSBA_PB && s->nc <= RSBA_CHOL_MAXN && !s->pipelined_mg) {
+    if (want > 1 && s->opt.schur_impl != 0 && s->nc >= 6 * RSBA_PB && s->nc <= RSBA_CHOL_MAXN) {
       s->chol_wgs = std::min(want, want_diag ? 8 : RSBA_MC_MAXG);
       if ((rc = DevAlloc(&s->mc_flags, 64))) return rc;
       HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
@@ -897,7 +916,9 @@ static int UploadPoints(rsba_solver* s) {
       s->chol_diag = want_diag && s->chol_wgs >= 2 && (np_d - 2 + s->chol_wgs - 2) / (s->chol_wgs - 1) <= 4;
       if (!s->chol_diag) s->chol_wgs = std::min(s->chol_wgs, RSBA_MC_MAXG);
       if (s->chol_diag && (rc = DevAlloc(&s->mc_dg, (size_t)2 * (np_d + 1) * 1024))) return rc;   // look-ahead sums | blocks as handed over
-      HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag, hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(DiagCholLdsDoubles(s->nc) * sizeof(double))));
+      HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(DiagCholLdsDoubles(s->nc) * sizeof(double))));
       if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, 8 * 16 * 8))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, 8 * 16 * 8 * sizeof(long long))); }
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1084,6 +1105,8 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   KernelTimer& T = s->timer;
 
   if (s->trace) s->host_t[0] = std::chrono::steady_clock::now();
+  auto hp = [&](int k) { if (s->hostprof) { const auto now = std::chrono::steady_clock::now(); s->hp_sum[k] += std::chrono::duration<double, std::micro>(now - s->hp_t).count(); s->hp_t = now; } };
+  if (s->hostprof) { s->hp_t = std::chrono::steady_clock::now(); if (s->hp_n++ > 0) s->hp_sum[0] += std::chrono::duration<double, std::micro>(s->hp_t - s->hp_result).count(); }
   T.NextStep();
   DebugSync(st, "enter PointsStep");
   // camera constants at x: only the first step of a run computes them; afterwards x is either unchanged (rejected step)
@@ -1153,21 +1176,28 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     int* resident_word = (ip.first || s->pipe_check_resident) ? reinterpret_cast<int*>(s->res_host + RES_SIZE) : nullptr;
     s->pipe_check_resident = false;
     T.Begin("k_reduced_system_solve", s->sB);
-    if (s->chol_wgs > 1 && !mg && s->chol_diag)
-      k_reduced_system_solve_diag<<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
-          C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
-          StageGate{ts.ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0, ts.ready + 16, resident_word, s->chol_wgs, all_diag},
-          DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024}, tag, s->mc_trace);
-    else if (s->chol_wgs > 1 && !mg)
+    // multi-GPU: the gates open on the flags k_stage_unpack publishes behind each stage's all-reduce, and a wait may last as
+    // long as the slowest rank
+    const int* gate_ready = mg ? s->ready_global : ts.ready;
+    const long long gate_budget = mg ? 10 * RSBA_STALL_TICKS : 0;
+    if (s->chol_wgs > 1 && s->chol_diag) {
+      const StageGate sg{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + 16, resident_word, s->chol_wgs, all_diag, mg ? 1 : 0};
+      const DiagCholFlags df{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024};
+      if (mg) k_reduced_system_solve_diag<true><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
+          C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok, sg, df, tag, s->mc_trace);
+      else k_reduced_system_solve_diag<false><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
+          C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok, sg, df, tag, s->mc_trace);
+    }
+    else if (s->chol_wgs > 1 && !mg)   // (the round-robin kernel has no transposed source: multi-GPU, it is the one-workgroup kernel)
       k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
-          StageGate{ts.ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, 0, ts.ready + 16, resident_word, s->chol_wgs},
+          StageGate{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + 16, resident_word, s->chol_wgs},
           MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48}, tag, s->mc_trace);
     else
     k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
-                                                     s->camc[c], s->dcam, s->gmax, s->res, ip, (mg || getenv("RSBA_TRANSPOSED_SOURCE")) ? 2 : 1,
-                                                     s->chol_ok, StageGate{mg ? s->ready_global : ts.ready, gate_tag, 6 * RSBA_TG, ts.ready + 15,
-                                                                           T.all_kernels() ? s->chol_waited : nullptr, s->trace, mg ? 10 * RSBA_STALL_TICKS : 0,
+                                                     s->camc[c], s->dcam, s->gmax, s->res, ip, mg ? 2 : 1,
+                                                     s->chol_ok, StageGate{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15,
+                                                                           T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget,
                                                                            ts.ready + 16, resident_word, 1});
     T.End(s->sB);
     rr_k4.End();
@@ -1176,11 +1206,13 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       const auto t_res = std::chrono::steady_clock::now();
       while (*w != gate_tag && std::chrono::steady_clock::now() - t_res < std::chrono::milliseconds(20)) __builtin_ia32_pause();
     }
+    hp(1);   // point side + factorisation launched
     ts.LaunchTiles(s, ip, T, st, tag, first_staged);
+    hp(2);   // Schur kernel launched
     if (mg) {
       // communication stream: stage by stage, as the Schur kernel publishes them locally — the row slab of S of the
-      // stage's camera group (complete once the stage is: the mirror blocks in it were written by earlier stages) and
-      // the group's ranges of g_c, rhs correction and diag U; the scalars and max |g_p| ride with the last stage
+      // stage's camera group and the group's ranges of g_c, rhs correction and diag U, as one grouped collective; the
+      // scalars and max |g_p| ride with the last stage
       const RedLayout& L = s->L;
       for (int g = 0; g < ts.nstages; ++g) {
         const int r0 = 6 * RSBA_TG * g, r1 = std::min(6 * RSBA_TG * (g + 1), n), rows = r1 - r0;
@@ -1199,6 +1231,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       }
     }
   }
+  hp(3);   // the stages' collectives issued
   HIPCHK(hipGetLastError());
   DebugSync(st, "linearize+schur");
 
@@ -1218,7 +1251,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(s->nc)) * sizeof(double);
     T.Begin("k_reduced_system_solve", st);
     if (s->chol_wgs > 1 && !keep_system_copy && s->chol_diag)
-      k_reduced_system_solve_diag<<<s->chol_wgs, 512, DiagCholLdsDoubles(s->nc) * sizeof(double), st>>>(
+      k_reduced_system_solve_diag<false><<<s->chol_wgs, 512, DiagCholLdsDoubles(s->nc) * sizeof(double), st>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
           StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0}, DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024},
           s->step_tag, s->mc_trace);
@@ -1275,9 +1308,21 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   rr_k4s.End();
   RoctxRange rr_k5("K5 back-substitution + candidate (K1 at the candidate, fused re-linearisation)");
   DebugSync(st, "k_reduced_system_solve");
+  if (s->comm && s->inject_stall_step != 0 && s->step_tag == s->inject_stall_step) {
+    // (test hook: what a factorisation whose in-kernel wait ran out of its budget leaves in the result block)
+    k_set_double<<<1, 1, 0, st>>>(s->res + RES_STALL, 1.0);
+    s->inject_stall_step = 0;
+  }
   T.Begin("k_backsub_candidate", st);
-  // single GPU: the kernel's last workgroup finishes the step (sums, result block, post to the host)
-  int* fin_cnt = s->comm ? nullptr : s->chol_ok + 1;
+  // single GPU: the kernel's last workgroup finishes the step (sums, result block, post to the host); with a communicator the
+  // projective kernel's last workgroup leaves the rank's sums for the all-reduce (FusedLin::sums_only), the other kernels their
+  // per-block sums for k_finish_candidate
+  // (RSBA_BACKSUB_PROJ=0: the form that reads the camera constants themselves, for comparison)
+  static const bool proj_form = !(getenv("RSBA_BACKSUB_PROJ") && atoi(getenv("RSBA_BACKSUB_PROJ")) == 0);
+  const bool use_proj = s->opt.schur_impl != 0 && s->fused_lin && proj_form && C <= 256;
+  const bool comm_tail = s->comm != nullptr;
+  int* fin_cnt = (comm_tail && !use_proj) ? nullptr : s->chol_ok + 1;
+  LmNext lm_publish;   // with a communicator: the decision is k_publish_result's, behind the all-reduce
   int grid_bs = s->grid_pts;   // workgroups of the back-substitution = blocks of partial sums the finisher adds
   {
     const size_t lds_b = (size_t)C * (2 * RSBA_CC_LDS + 6) * sizeof(double);
@@ -1289,9 +1334,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     long long* waited = pipe && T.all_kernels() ? s->chol_waited + 1 : nullptr;
 #define RSBA_BACKSUB_ARGS C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x], s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, \
                           s->res, s->res_host, s->res_seq + 1.0, solve_done, solve_tag, waited, s->chol_ok + 2, fl
-    // (RSBA_BACKSUB_PROJ=0: the form that reads the camera constants themselves, for comparison)
-    static const bool proj_form = !(getenv("RSBA_BACKSUB_PROJ") && atoi(getenv("RSBA_BACKSUB_PROJ")) == 0);
-    if (fused && proj_form && C <= 256) {
+    if (use_proj) {
       // slices of 64 points dealt to two workgroups per CU (k_backsub_candidate_proj); ten slots of a lane's observation
       // records in registers, ten (<= 64 cameras) or six (<= 128) more in LDS, both tables + records <= 72 KB per workgroup;
       // up to 256 cameras one workgroup per CU (tables 80 KB + ten LDS slots)
@@ -1318,9 +1361,12 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       static const bool decided = !(getenv("RSBA_DECIDED_DAMP") && atoi(getenv("RSBA_DECIDED_DAMP")) == 0);
       s->dec_step = decided && !spec && fin_cnt != nullptr;
       if (s->dec_step) {
-        fl.lm.dec = s->dec; fl.lm.radius = ip.radius; fl.lm.decrease_factor = s->lm_decrease_factor;
-        fl.lm.min_relative_decrease = s->opt.min_relative_decrease; fl.lm.max_radius = s->opt.max_trust_region_radius;
+        LmNext lm;
+        lm.dec = s->dec; lm.radius = ip.radius; lm.decrease_factor = s->lm_decrease_factor;
+        lm.min_relative_decrease = s->opt.min_relative_decrease; lm.max_radius = s->opt.max_trust_region_radius;
+        if (comm_tail) lm_publish = lm; else fl.lm = lm;
       }
+      fl.sums_only = comm_tail ? 1 : 0;
       // (more than 48 KB of dynamic LDS has to be asked for, once per kernel)
       // <cameras, slots in registers, slots in LDS, loss>: the robust instances keep fewer records in registers — the loss'
       // square roots and the store of sqrt(rho') need the registers, and a spilled value is a trip to memory per slot
@@ -1352,7 +1398,8 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (fused) s->tiled.lin_valid = true;
   }
   T.End(st);
-  if (s->dec_step) {
+  auto queue_damping = [&]() {
+    // the damping kernel of the NEXT step, on the device's decision (LmNext)
     TiledSchur& ts = s->tiled;
     IterParams ipn = ip; ipn.first = 0;
     T.Begin("k_point_damp", st);
@@ -1360,35 +1407,33 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
                                              s->dec, s->pts[c], ts.lin2[c], s->camc[c]);
     T.End(st);
     ts.pt_valid = false;   // (until the decision is in: below)
-  }
+  };
+  if (s->dec_step && !comm_tail) queue_damping();
   rr_k5.End();
   DebugSync(st, "k_backsub_candidate");
-  if (s->comm) {
+  if (comm_tail) {
     const bool mg = pipe && s->pipelined_mg;
-    if (s->inject_stall_step != 0 && s->step_tag == s->inject_stall_step) {
-      k_set_double<<<1, 1, 0, st>>>(s->res + RES_STALL, 1.0);
-      s->inject_stall_step = 0;
+    if (!use_proj) {
+      T.Begin("k_finish_candidate", st);
+      // res_stall: with a communicator the stall flag of the factorisation (multi-workgroup / persistent tiles: in-kernel
+      // waits) and of the pipeline rides in small_red[5] and is SUMMED over the ranks in every schedule, so that all ranks
+      // take the same fallback below and keep issuing the same collectives
+      k_finish_candidate<<<1, 256, 0, st>>>(grid_bs, s->block_part, s->small_red, nullptr, nullptr, 0.0, s->res, s->trace, mg ? s->chol_ok + 2 : nullptr);
+      T.End(st);
     }
-    T.Begin("k_finish_candidate", st);
-    // res_stall: with a communicator the stall flag of the factorisation (multi-workgroup / persistent tiles: in-kernel
-    // waits) and of the pipeline rides in small_red[5] and is SUMMED over the ranks in every schedule, so that all ranks
-    // take the same fallback below and keep issuing the same collectives
-    k_finish_candidate<<<1, 256, 0, st>>>(grid_bs, s->block_part, s->small_red, nullptr, nullptr, 0.0, s->res, s->trace, mg ? s->chol_ok + 2 : nullptr);
-    T.End(st);
-    // the candidate's sums and the stall flags; pipelined, all RCCL traffic stays on the communication stream
-    hipStream_t sc = st;
-    if (mg) {
-      HIPCHK(hipEventRecord(s->ev_bs, st));
-      HIPCHK(hipStreamWaitEvent(s->sR, s->ev_bs, 0));
-      sc = s->sR;
-    }
-    COMMCHK(s->comm->SumDoubles(s->small_red, 8, sc));
-    k_publish_result<<<1, 64, 0, sc>>>(s->small_red, s->res, s->res_host, s->res_seq + 1.0, 1, s->trace);
+    // the candidate's sums and the stall flags — on the main stream, right behind the kernel that formed them — then the
+    // result block, the decision and the post to the host
+    COMMCHK(s->comm->SumDoubles(s->small_red, 8, st));
+    k_publish_result<<<1, 64, 0, st>>>(s->small_red, s->res, s->res_host, s->res_seq + 1.0, 1, s->trace, lm_publish);
+    if (s->dec_step) queue_damping();
   }
   HIPCHK(hipGetLastError());
+  hp(4);   // everything launched
   if (s->trace) s->host_t[2] = std::chrono::steady_clock::now();
   RoctxRange rr_k6("K6 LM bookkeeping: wait for the step's result block");
-  { const int rcw = WaitResult(s, s->comm && pipe && s->pipelined_mg ? s->sR : st); if (rcw != RSBA_OK) return rcw; }
+  { const int rcw = WaitResult(s, st); if (rcw != RSBA_OK) return rcw; }
+  hp(5);   // result in
+  if (s->hostprof) s->hp_result = s->hp_t;
   if (s->trace && !s->trace_ring) {
     const auto now = std::chrono::steady_clock::now();
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -1713,6 +1758,7 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
   rsba::CommScope device_turn(comm_keep.get());
   if (s->comm && getenv("RSBA_TEST_STALL_STEP") && (!getenv("RSBA_TEST_STALL_RANK") || atoi(getenv("RSBA_TEST_STALL_RANK")) == opt.rank))
     s->inject_stall_step = atoi(getenv("RSBA_TEST_STALL_STEP"));
+  s->hostprof = getenv("RSBA_HOSTPROF") != nullptr;
   if (hipHostMalloc((void**)&s->res_host, (RES_SIZE + 8) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { rsba::FreeSolver(s); return RSBA_ERR_HIP; }
   memset(s->res_host, 0, (RES_SIZE + 8) * sizeof(double));   // [RES_SIZE]: the factorisation's "resident" word (StageGate)
   if (p->model == RSBA_MODEL_POINTS) rc = rsba::UploadPoints(s);
@@ -1750,6 +1796,12 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
                             [&]() { s->cur = 1 - s->cur; }, [&]() { return rsba::PointsGradient(s, cur_radius); });
     sum.minimizer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     rsba::TraceRingDump(s);
+    if (s->hostprof && s->hp_n > 1) {
+      const double n = (double)s->hp_n;
+      fprintf(stderr, "rsba[hostprof] %ld steps, host us per step: previous result -> enter %.1f | -> point side + factorisation launched %.1f | -> Schur kernel launched %.1f | -> stage collectives issued %.1f | -> all launched %.1f | -> result %.1f\n",
+              s->hp_n, s->hp_sum[0] / (n - 1), s->hp_sum[1] / n, s->hp_sum[2] / n, s->hp_sum[3] / n, s->hp_sum[4] / n, s->hp_sum[5] / n);
+      for (double& v : s->hp_sum) v = 0.0; s->hp_n = 0;
+    }
     if (rc == RSBA_OK && s->tiled.tree_error) {
       // a reducer workgroup of the Schur kernel gave up waiting for its tile (cannot happen by construction): the sums
       // it produced are garbage, so is the result

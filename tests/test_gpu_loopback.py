@@ -94,6 +94,19 @@ def test_sharded_solves_match_the_unsharded_oracle(oracle, C, P, k, huber, world
     _sharded_solve_matches_oracle(oracle, whole, _shards(C, P, k, 400 + C, world, outl), huber=huber)
 
 
+@pytest.mark.parametrize("C,P,k,world", [(40, 5000, 9, 2), (64, 6000, 12, 3)])
+def test_pipelined_multi_gpu_schedule_sharded(oracle, C, P, k, world):
+    """RSBA_PIPELINE_MG=1: the factorisation launched ahead and gated stage by stage on flags published behind each stage's
+    all-reduce (the group's row slab of S, read transposed), the candidate's sums all-reduced behind the back-substitution, the
+    decision taken by k_publish_result on every rank alike — with real shards, not a 1-rank communicator."""
+    whole = syn.make_problem(C, P, k, 500 + C)
+    os.environ["RSBA_PIPELINE_MG"] = "1"
+    try:
+        _sharded_solve_matches_oracle(oracle, whole, _shards(C, P, k, 500 + C, world))
+    finally:
+        del os.environ["RSBA_PIPELINE_MG"]
+
+
 def test_a_stall_on_one_rank_is_everybodys_stall(oracle, capfd):
     """Step 2 of rank 1 reports a stalled factorisation (test hook RSBA_TEST_STALL_STEP / _RANK: what an in-kernel wait that ran
     out of its budget leaves in the result block).  The flag travels in the candidate's sum all-reduce, so BOTH ranks repeat the
