@@ -45,6 +45,7 @@ struct IterParams {
   const double* cam_free = nullptr;   // per camera 1.0 / 0.0 (constant block: SetParameterBlockConstant); nullptr: all free
 };
 
+
 // Result block the host reads back once per iteration (and RCCL reduces in part).
 enum {
   RES_COST_X = 0,        // 1/2 sum rho at x

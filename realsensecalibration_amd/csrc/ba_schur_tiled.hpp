@@ -103,6 +103,11 @@ struct TiledSchur {
   int pt_state = -1, scal_blocks = 0;
   double pt_radius = 0.0;
   double *u_cm = nullptr, *v_cm = nullptr;  // [N] observations in camera-major order (self tiles need the pixel)
+  // more than 64 cameras: the pair segments' hit lists (PairSegmentSparse); nullptr below that
+  unsigned *hits = nullptr, *hit_off = nullptr;
+  int* hit_trips = nullptr;
+  size_t hit_entries = 0;
+
   int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
             const std::vector<int>& sliced_q /* sliced slot -> CSR position, -1 pads */, bool staged);
   // stages of the pipelined solve: pair tiles with ga == g are contiguous (tiles [stage_tile[g], stage_tile[g+1])), the
@@ -664,6 +669,10 @@ struct SchurArgs {
   int epoch;                       // launch number, never 0
   long long* trace;   // diagnostic (RSBA_TRACE=1)
   long long* wg_trace;  // diagnostic (RSBA_TRACE=2): start / end / compute-end stamp of every block
+  // more than 64 cameras: the pair segments' hit lists, built once at set-up (PairSegmentSparse); nullptr: the masks are searched
+  const unsigned* __restrict__ hits;       // [entry][3]: point, camera-major observation index on the a side, on the b side
+  const unsigned* __restrict__ hit_off;    // [pair segment][4 waves]: first entry of the wave's list (64 entries per trip, lane-interleaved)
+  const int* __restrict__ hit_trips;       // [pair segment][4 waves]: trips = the longest of the wave's 64 lists
 };
 
 template <bool kLoss, bool kSmall>
@@ -809,6 +818,138 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
     }
   }
   // slot of pair (ia, ib) in the workgroup's partial block is ia*16+ib whatever lane computed it
+  double* out = partial + (size_t)seg_index * RSBA_PART * 256;
+  if (!diag_tile || tid < 120) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) __hip_atomic_store(&out[i * 256 + pr], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();
+  double v[36];
+  if (!GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v, a.grp_flag, a.epoch)) return;
+  FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L, a.cam_free);
+  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
+  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pair segment above 64 cameras: SPARSE.  At 256 cameras x 20 views a camera pair shares 0.6 % of the points: a lane of the
+// masked search above finds 3 hits in a 512-point chunk, a wave runs as many trips as its busiest lane (~8), and every
+// workgroup stages every chunk (48 KB) to find them — the kernel spent its time staging and searching (680 us for 2.9 GFLOP,
+// 5 % of the fp64 peak, round 2).  Which points a pair shares never changes, so the lists are built ONCE at set-up
+// (TiledSchur::BuildHitLists): per pair segment and wavefront, lane-interleaved — entry n of lane l at [n * 64 + l], as many
+// trips as the longest of the 64 lists (one segment is ~1/8 of the points: ~48 hits per lane, busiest lane ~60) — each entry
+// the point and the two observations' places in the camera-major arrays (sqrt(rho')).  The point record (X, damped inverse
+// block: 72 bytes) is gathered from ptdata one trip ahead of the arithmetic, the entries two.  No chunk staging, no barrier, no
+// mask.  Same per-hit arithmetic as PairSegment, same partial blocks, same reduction tree.  A trip takes a wavefront ~1.8 us
+// — what it takes in the 64-camera kernel (two wavefronts per SIMD, dependent fp64 chains) — and nothing about the gather
+// moved that (round 3, each measured at the config-5 shard and taken out again): records fetched cooperatively, five 16-byte
+// pieces per record on consecutive lanes through LDS (19 cache lines per load instruction instead of 64); a second copy of
+// the records in 128-byte aligned slots (one line per hit instead of 1.5); the work list cut into one list per XCD so that
+// a point range is always gathered through the same L2.
+// A diagonal tile's 120 pairs sit in both halves of the workgroup as above; the halves split the hits by the parity of the
+// point's 64-point word.
+// ------------------------------------------------------------------------------------------------
+#define RSBA_HIT_NONE 0xffffffffu
+template <bool kLoss, bool kSmall>
+__device__ __forceinline__ void PairSegmentSparse(const SchurArgs& a, const SchurSeg& sg, int seg_index, int ticket, double* pt, double* sc) {
+  const int C = a.C;
+  const double* __restrict__ camc = a.camc;
+  const double* __restrict__ ptdata = a.ptdata;
+  const double* __restrict__ sq_cm = a.sq_cm;
+  double* __restrict__ partial = a.partial;
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const bool diag_tile = sg.ga == sg.gb;
+  const int dt = diag_tile ? (tid & 127) : tid;
+  const int pr = diag_tile ? (dt < 120 ? kDiagPair[dt] : 0) : tid;
+  const int ia = pr >> 4, ib = pr & 15;
+  // this wave's list: first entry, trips
+  const unsigned* __restrict__ hl = a.hits + 3 * ((size_t)a.hit_off[4 * seg_index + wv] + ln);
+  const int ntrip = a.hit_trips[4 * seg_index + wv];
+  // entries run TWO trips ahead of the arithmetic, point records one: the record's address depends on the entry, and an entry
+  // fetched in the same trip as its record is a round trip to memory per trip with nothing to overlap it
+  unsigned e0 = RSBA_HIT_NONE, e1 = 0, e2 = 0, f0 = RSBA_HIT_NONE, f1 = 0, f2 = 0;
+  if (ntrip > 0) { e0 = hl[0]; e1 = hl[1]; e2 = hl[2]; }
+  if (ntrip > 1) { f0 = hl[3 * 64]; f1 = hl[3 * 64 + 1]; f2 = hl[3 * 64 + 2]; }
+  // camera constants of the tile's 32 cameras: two values per thread
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = tid + 256 * u;
+    const int row = i / RSBA_SC_STRIDE, e = i - row * RSBA_SC_STRIDE;
+    const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
+    const double* cc = camc + (size_t)(cam < C ? cam : 0) * CC_STRIDE;
+    const int src = e < 9 ? CC_R + e : (e < 12 ? CC_T + e - 9 : (e == 12 ? CC_FX : (e == 13 ? CC_FY : CC_SMALL)));
+    sc[i] = e < 15 ? cc[src] : 0.0;
+  }
+  const double* ca = sc + ia * RSBA_SC_STRIDE;
+  const double* cb = sc + (RSBA_TG + ib) * RSBA_SC_STRIDE;
+  // the first entry's point record and loss factors
+  double pn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sqn[2] = {1.0, 1.0};
+  auto fetch = [&](unsigned j, unsigned oa, unsigned ob) {
+    const double* pd = ptdata + (size_t)j * RSBA_PT_STRIDE;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) pn[i] = pd[i];
+    if (kLoss) { sqn[0] = sq_cm[oa]; sqn[1] = sq_cm[ob]; }
+  };
+  if (e0 != RSBA_HIT_NONE) fetch(e0, e1, e2);
+  __syncthreads();   // (the camera constants)
+  double acc[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll 1
+  for (int n = 0; n < ntrip; ++n) {
+    const bool hit = e0 != RSBA_HIT_NONE;
+    const double X[3] = {pn[0], pn[1], pn[2]};
+    const double v0 = pn[3], v1 = pn[4], v2 = pn[5], v3 = pn[6], v4 = pn[7], v5 = pn[8];
+    const double sqa = sqn[0], sqb = sqn[1];
+    // the next trip's records (its entries came in during the previous trip) and the entries after that go out before this
+    // trip's arithmetic
+    e0 = f0; e1 = f1; e2 = f2;
+    if (n + 2 < ntrip) {
+      const unsigned* __restrict__ hn = hl + 3 * 64 * (size_t)(n + 2);
+      f0 = hn[0]; f1 = hn[1]; f2 = hn[2];
+    } else {
+      f0 = RSBA_HIT_NONE;
+    }
+    if (e0 != RSBA_HIT_NONE) fetch(e0, e1, e2);
+    if (!hit) continue;
+    double ea0[4], ea1[4], na0[3], na1[3], da[2];
+    SideRowsUnscaledLds<kSmall>(ca, X, sqa, ea0, ea1, na0, na1, da);
+    const double t00 = na0[0] * v0 + na0[1] * v1 + na0[2] * v2, t01 = na0[0] * v1 + na0[1] * v3 + na0[2] * v4, t02 = na0[0] * v2 + na0[1] * v4 + na0[2] * v5;
+    const double t10 = na1[0] * v0 + na1[1] * v1 + na1[2] * v2, t11 = na1[0] * v1 + na1[1] * v3 + na1[2] * v4, t12 = na1[0] * v2 + na1[1] * v4 + na1[2] * v5;
+    double eb0[4], eb1[4], nb0[3], nb1[3], db[2];
+    SideRowsUnscaledLds<kSmall>(cb, X, sqb, eb0, eb1, nb0, nb1, db);
+    const double m00 = (t00 * nb0[0] + t01 * nb0[1] + t02 * nb0[2]) * (da[0] * db[0]), m01 = (t00 * nb1[0] + t01 * nb1[1] + t02 * nb1[2]) * (da[0] * db[1]);
+    const double m10 = (t10 * nb0[0] + t11 * nb0[1] + t12 * nb0[2]) * (da[1] * db[0]), m11 = (t10 * nb1[0] + t11 * nb1[1] + t12 * nb1[2]) * (da[1] * db[1]);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const int pp = p == 5 ? 3 : p;
+      double z0, z1;
+      if (p == 3) { z0 = m00; z1 = m01; }
+      else if (p == 4) { z0 = m10; z1 = m11; }
+      else { z0 = ea0[pp] * m00 + ea1[pp] * m10; z1 = ea0[pp] * m01 + ea1[pp] * m11; }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int qq = q == 5 ? 3 : q;
+        if (q == 3) acc[6 * p + q] += z0;
+        else if (q == 4) acc[6 * p + q] += z1;
+        else acc[6 * p + q] = Fma2(z0, eb0[qq], z1, eb1[qq], acc[6 * p + q]);
+      }
+    }
+  }
+  if (diag_tile) {
+    // odd-word half (waves 2/3) -> LDS -> even-word half
+    __syncthreads();
+    if (tid >= 128 && dt < 120) {
+#pragma unroll
+      for (int i = 0; i < 36; ++i) pt[i * 128 + dt] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 120) {
+#pragma unroll
+      for (int i = 0; i < 36; ++i) acc[i] += pt[i * 128 + tid];
+    }
+  }
   double* out = partial + (size_t)seg_index * RSBA_PART * 256;
   if (!diag_tile || tid < 120) {
 #pragma unroll
@@ -1105,7 +1246,10 @@ k_schur_tiles(SchurArgs a) {
   else {
     // two instances of the pair tile: the small-angle selects of the Jacobian rows (12 instructions per hit) are compiled in
     // only when some camera takes that branch this iteration (a rotation of exactly zero: the reference's test2 fixture)
-    if (s_small) PairSegment<kLoss, true>(a, sg, seg_index, b, pt, mk, sc);
+    if (a.hits != nullptr) {
+      if (s_small) PairSegmentSparse<kLoss, true>(a, sg, seg_index, b, pt, sc);
+      else PairSegmentSparse<kLoss, false>(a, sg, seg_index, b, pt, sc);
+    } else if (s_small) PairSegment<kLoss, true>(a, sg, seg_index, b, pt, mk, sc);
     else PairSegment<kLoss, false>(a, sg, seg_index, b, pt, mk, sc);
   }
   if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b + 1] = wall_clock64();

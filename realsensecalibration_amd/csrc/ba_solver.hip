@@ -272,12 +272,12 @@ static int DeviceCUs() {
   }();
   return cached;
 }
-static std::vector<int> SegmentBounds(int nW, int ns) {
-  // Optional tapered segments (RSBA_TAPER > 1: the first of a tile is that many times as long as the last).  A stage is
-  // over when its last block is, so long-blocks-first should end it earlier; measured, it does not (a stage is only
-  // ~1-2 "rounds" of slots deep and two blocks share a CU's VALU, so a block's duration follows its CU-mate more than
-  // its own length).  Default off.
-  const double taper = getenv("RSBA_TAPER") ? atof(getenv("RSBA_TAPER")) : 1.0;
+static std::vector<int> SegmentBounds(int nW, int ns, double taper = 1.0) {
+  // Tapered segments (taper > 1: the first of a tile is that many times as long as the last).  A launch is over when its last
+  // block is, so long blocks first, short ones last.  At 64 cameras, pipelined, it measured nothing (a stage is only ~1-2
+  // "rounds" of slots deep and two blocks share a CU's VALU, so a block's duration follows its CU-mate more than its own
+  // length): 1.  Above 64 cameras (sparse pair segments, handed out by point range: the last ranges are the short ones)
+  // the launch is 2.6 rounds of ~110 us blocks deep and its tail was 100 us long: 4 (419 -> 385 us at the config-5 shard).
   std::vector<int> bound(ns + 1, 0);
   const double hi = 2.0 * taper / (taper + 1.0), lo = 2.0 - hi;
   double cum = 0.0;
@@ -294,7 +294,7 @@ static int PairSegmentsPerTile(int C, int P, bool staged) {
   for (int ga = 0; ga < ngroups; ++ga) for (int gb = ga; gb < ngroups; ++gb) if (!(ga == gb && std::min(RSBA_TG, C - RSBA_TG * ga) < 2)) ++npair_tiles;
   // measured at 64 cameras: the pipelined schedule likes shorter workgroups (a stage ends with its last one), the
   // sequential one fewer partial sums
-  const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : (staged ? 8 : 4);
+  const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : (staged ? 8 : (6 * C > RSBA_CHOL_MAXN ? 6 : 4));
   const int target = seg_per_cu * DeviceCUs();
   const int nW = (P + 63) / 64;
   const int ns = (int)std::lround((double)target / std::max(1, npair_tiles));
@@ -458,8 +458,10 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   for (int t = 0; t < ntiles; ++t) {
     const bool self = tab[3 * t + 2] != 0;
     const int nW = (P + 63) / 64;  // mask words that hold points
-    const int ns = self ? std::max(1, std::min((2 * cus + ngroups - 1) / ngroups, nW)) : PairSegmentsPerTile(C, P, staged);
-    const std::vector<int> bound = SegmentBounds(nW, ns);
+    // (more than 64 cameras: at most 16 self segments per tile — two reduction groups, no reducer workgroups)
+    const int ns_self = std::max(1, std::min((2 * cus + ngroups - 1) / ngroups, nW));
+    const int ns = self ? (6 * C > RSBA_CHOL_MAXN && !staged ? std::min(ns_self, 16) : ns_self) : PairSegmentsPerTile(C, P, staged);
+    const std::vector<int> bound = SegmentBounds(nW, ns, (!self && !staged && 6 * C > RSBA_CHOL_MAXN) ? 4.0 : 1.0);
     for (int i = 0; i < ns; ++i) {
       SchurSeg e; memset(&e, 0, sizeof(e));
       e.ga = tab[3 * t]; e.gb = tab[3 * t + 1]; e.self = tab[3 * t + 2];
@@ -521,6 +523,10 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   // the (much shorter) self workgroups last, where they fill the tail of the last round of pair workgroups (at 256
   // cameras a pair workgroup runs 220 us and the launch is ~3 rounds deep), reducers behind everything.
   std::vector<int> border; border.reserve(nblocks);
+  // More than 64 cameras: the pair segments' hit lists (PairSegmentSparse, ba_schur_tiled.hpp).  RSBA_SPARSE_PAIRS=0: the
+  // masked search of the 512-point chunks, as below 65 cameras.
+  static const bool sparse_on = !(getenv("RSBA_SPARSE_PAIRS") && atoi(getenv("RSBA_SPARSE_PAIRS")) == 0);
+  const bool sparse = sparse_on && 6 * C > RSBA_CHOL_MAXN && !staged;
   if (staged) {
     for (int g = 0; g < nstages; ++g) {
       std::vector<int> tiles_g;
@@ -534,6 +540,18 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       for (const auto& o : ord) border.push_back(o.second);
       for (int t : tiles_g) for (int q : red_of_tile[t]) border.push_back(q);
     }
+  } else if (sparse) {
+    // More than 64 cameras (sparse pair segments, PairSegmentSparse): the short self segments first — behind the pair segments
+    // their reducers sat in 112 of the 512 slots for 80 us each, waiting for them (there are no reducers any more: at most
+    // 16 self segments per tile, two groups, finished by the last arrival) — then the pair segments by POINT RANGE (segment i
+    // of every tile, then segment i + 1, ...): the workgroups running at any time gather their point records from a few
+    // neighbouring ranges (pair segment 133 -> 110 us)
+    for (int q = 0; q < nseg; ++q) if (sg[q].self == 1) border.push_back(q);
+    for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2]) for (int q : red_of_tile[t]) border.push_back(q);
+    int ns_pair = 0;
+    for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) ns_pair = std::max(ns_pair, tsp[t + 1] - tsp[t]);
+    for (int i = 0; i < ns_pair; ++i) for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2] && i < tsp[t + 1] - tsp[t]) border.push_back(tsp[t] + i);
+    for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) for (int q : red_of_tile[t]) border.push_back(q);
   } else {
     for (int q = 0; q < nseg; ++q) border.push_back(q);   // segments are stored pair tiles first, self tiles after them
     for (int t = 0; t < ntiles; ++t) for (int q : red_of_tile[t]) border.push_back(q);
@@ -602,6 +620,71 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     HIPCHK(hipMemset(small_flag, 0, sizeof(int)));
   }
   HIPCHK(hipMemcpy(cam_mask, mask.data(), mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  if (sparse && nseg_pair > 0) {
+    const auto th0 = std::chrono::steady_clock::now();
+    std::vector<int> tile_of((size_t)ngroups * ngroups, -1);
+    for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) tile_of[(size_t)tab[3 * t] * ngroups + tab[3 * t + 1]] = t;
+    const int nW = (P + 63) / 64;
+    // word -> segment of a pair tile (the same bounds for every pair tile)
+    std::vector<int> seg_of_word(nW, 0);
+    {
+      int t0 = -1;
+      for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) { t0 = t; break; }
+      for (int q = tsp[t0]; q < tsp[t0 + 1]; ++q) for (int w = sg[q].word_begin; w < sg[q].word_end && w < nW; ++w) seg_of_word[w] = q - tsp[t0];
+    }
+    // (thread of the workgroup that owns pair (a, b) of point j: see PairSegmentSparse)
+    auto owner = [&](int a, int b, int j, int* seg, int* tid) {
+      const int ga = a / RSBA_TG, gb = b / RSBA_TG, ia = a - RSBA_TG * ga, ib = b - RSBA_TG * gb;
+      const int t = tile_of[(size_t)ga * ngroups + gb];
+      const int w = j >> 6;
+      *seg = tsp[t] + seg_of_word[w];
+      if (ga != gb) { *tid = ia * RSBA_TG + ib; return; }
+      const int dt = ia * 15 - ia * (ia - 1) / 2 + ib - ia - 1;           // index of (ia, ib), ia < ib, in kDiagPair
+      const int half = (w - sg[*seg].word_begin) & 1;
+      *tid = half * 128 + dt;
+    };
+    std::vector<unsigned> count((size_t)nseg_pair * 256, 0u);
+    for (int j = 0; j < P; ++j)
+      for (int qa = pt_ptr[j]; qa < pt_ptr[j + 1]; ++qa)
+        for (int qb = qa + 1; qb < pt_ptr[j + 1]; ++qb) {
+          int seg, tid;
+          owner(obs_cam[qa], obs_cam[qb], j, &seg, &tid);
+          ++count[(size_t)seg * 256 + tid];
+        }
+    std::vector<unsigned> off((size_t)nseg_pair * 4, 0u);
+    std::vector<int> trips((size_t)nseg_pair * 4, 0);
+    size_t entries = 0;
+    for (int q = 0; q < nseg_pair; ++q)
+      for (int wv = 0; wv < 4; ++wv) {
+        unsigned m = 0;
+        for (int l = 0; l < 64; ++l) m = std::max(m, count[(size_t)q * 256 + wv * 64 + l]);
+        off[(size_t)q * 4 + wv] = (unsigned)entries; trips[(size_t)q * 4 + wv] = (int)m;
+        entries += (size_t)m * 64;
+      }
+    if (entries < (size_t)1 << 32) {
+      std::vector<unsigned> h(3 * std::max<size_t>(entries, 1), RSBA_HIT_NONE);
+      std::fill(count.begin(), count.end(), 0u);
+      for (int j = 0; j < P; ++j)
+        for (int qa = pt_ptr[j]; qa < pt_ptr[j + 1]; ++qa)
+          for (int qb = qa + 1; qb < pt_ptr[j + 1]; ++qb) {
+            int seg, tid;
+            owner(obs_cam[qa], obs_cam[qb], j, &seg, &tid);
+            const unsigned n = count[(size_t)seg * 256 + tid]++;
+            const size_t e = (size_t)off[(size_t)seg * 4 + (tid >> 6)] + (size_t)n * 64 + (tid & 63);
+            h[3 * e] = (unsigned)j; h[3 * e + 1] = (unsigned)cmpos[qa]; h[3 * e + 2] = (unsigned)cmpos[qb];
+          }
+      if ((rc = DevAlloc(&hits, h.size())) || (rc = DevAlloc(&hit_off, off.size())) || (rc = DevAlloc(&hit_trips, trips.size()))) return rc;
+      HIPCHK(hipMemcpy(hits, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(hit_off, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(hit_trips, trips.data(), trips.size() * sizeof(int), hipMemcpyHostToDevice));
+      hit_entries = entries;
+      if (getenv("RSBA_DEBUG")) {
+        size_t nh = 0; for (unsigned c2 : count) nh += c2;
+        fprintf(stderr, "rsba: hit lists of %d pair segments: %zu hits in %zu entries (%.0f %% of the lane-trips), %.1f MB, built in %.3f s\n", nseg_pair, nh, entries,
+                100.0 * nh / std::max<size_t>(entries, 1), h.size() * 4e-6, std::chrono::duration<double>(std::chrono::steady_clock::now() - th0).count());
+      }
+    }
+  }
   HIPCHK(hipMemcpy(segs, sg.data(), sg.size() * sizeof(SchurSeg), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_prefix, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cam_ptr, cptr.data(), cptr.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -614,9 +697,9 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, segs_ordered, segs_ordered_first, segs_ordered_self, small_flag, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm};
+  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, segs_ordered, segs_ordered_first, segs_ordered_self, small_flag, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm, hits, hit_off, hit_trips};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  cam_mask = nullptr;
+  cam_mask = nullptr; hits = nullptr; hit_off = nullptr; hit_trips = nullptr;
 }
 
 static void FreeSolver(rsba_solver* s) {
@@ -791,6 +874,9 @@ static int UploadPoints(rsba_solver* s) {
     if (dup) s->opt.schur_impl = 0;
   }
   if (s->opt.schur_impl != 0) {
+    if (getenv("RSBA_TRACE") && atoi(getenv("RSBA_TRACE")) == 2 && s->nc > RSBA_CHOL_MAXN) {
+      if (hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;   // (the block timeline alone)
+    }
     if (getenv("RSBA_TRACE") && s->nc <= RSBA_CHOL_MAXN) {   // the 32 slots are laid out for at most four stages (64 cameras)
       // diagnostics: wall-clock stamps of the step (1) and of every block of the Schur kernel (2)
       s->trace_ring = atoi(getenv("RSBA_TRACE")) == 3 ? 256 : 0;
@@ -1018,6 +1104,7 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   a.ready = ts.ready; a.tag = tag; a.self_only = 0; { static const int nt = getenv("RSBA_NO_TICKET") ? atoi(getenv("RSBA_NO_TICKET")) : 0; a.no_ticket = nt; } a.red = s->red; a.L = s->L; a.nblocks_pp = ts.scal_blocks; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
   a.grp_flag = ts.grp_flag; a.epoch = ++ts.epoch;
+  a.hits = ts.hits; a.hit_off = ts.hit_off; a.hit_trips = ts.hit_trips;
   a.all_self = 0;
   return a;
 }
@@ -1473,22 +1560,25 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
             (h[32] - h[28]) * 0.01, (h[33] - h[28]) * 0.01, (h[34] - h[28]) * 0.01, (h[35] - h[28]) * 0.01, (h[36] - h[28]) * 0.01);
     s->trace_prev_post = h[29];
     fprintf(stderr, "\n");
-    if (s->wg_trace && s->step_tag == 5) {
-      // one step's block timeline: block, segment, tile, self, stage, words, start, compute end, end (us)
-      const int nb = s->tiled.nblocks;
-      std::vector<long long> w((size_t)3 * nb);
-      std::vector<SchurSeg> hs(nb); std::vector<int> bs(nb);
-      HIPCHK(hipMemcpy(w.data(), s->wg_trace, w.size() * sizeof(long long), hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(hs.data(), s->tiled.segs, nb * sizeof(SchurSeg), hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(bs.data(), s->tiled.block_seg, nb * sizeof(int), hipMemcpyDeviceToHost));
-      if (FILE* f = fopen(getenv("RSBA_TRACE_FILE") ? getenv("RSBA_TRACE_FILE") : "wgtrace.txt", "w")) {
-        for (int b = 0; b < nb; ++b) {
-          const SchurSeg& e = hs[bs[b]];
-          fprintf(f, "%d %d %d %d %d %d %.2f %.2f %.2f\n", b, bs[b], e.tile, e.self, e.stage, e.word_end - e.word_begin, (w[3 * b] - t0) * 0.01,
-                  (w[3 * b + 2] - t0) * 0.01, (w[3 * b + 1] - t0) * 0.01);
-        }
-        fclose(f);
+  }
+  if (s->wg_trace && s->step_tag == 5) {
+    // RSBA_TRACE=2: one step's block timeline of the Schur kernel — list position, segment, tile, type, stage, words, start,
+    // sums stored, end (us after the first block to start); tools/schur_timeline_summary.py
+    const int nb = s->tiled.nblocks;
+    std::vector<long long> w((size_t)3 * nb);
+    std::vector<SchurSeg> hs(nb); std::vector<int> bs(nb);
+    HIPCHK(hipMemcpy(w.data(), s->wg_trace, w.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hs.data(), s->tiled.segs, nb * sizeof(SchurSeg), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(bs.data(), s->tiled.block_seg, nb * sizeof(int), hipMemcpyDeviceToHost));
+    long long t0 = w[0];
+    for (int b = 0; b < nb; ++b) t0 = std::min(t0, w[3 * b]);
+    if (FILE* f = fopen(getenv("RSBA_TRACE_FILE") ? getenv("RSBA_TRACE_FILE") : "wgtrace.txt", "w")) {
+      for (int b = 0; b < nb; ++b) {
+        const SchurSeg& e = hs[bs[b]];
+        fprintf(f, "%d %d %d %d %d %d %.2f %.2f %.2f\n", b, bs[b], e.tile, e.self, e.stage, e.word_end - e.word_begin, (w[3 * b] - t0) * 0.01,
+                (w[3 * b + 2] - t0) * 0.01, (w[3 * b + 1] - t0) * 0.01);
       }
+      fclose(f);
     }
   }
   if (!pipe && s->tc_tiles > 0 && s->res_host[RES_STALL] != 0.0) {
