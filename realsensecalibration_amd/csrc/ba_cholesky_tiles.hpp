@@ -31,9 +31,58 @@ struct TileCholFlags {
   int* xdone;    // [np][nrt]       == tag: X of panel p for tile row I is in F
   int* error;    // != 0: somebody gave up
   int nrt;
+  // The chain from one tile column's last factorisation to the next one's first: the sub-diagonal tile (J + 1, J) hands its
+  // rows' columns of the column's SECOND panel over as soon as they are final (after the first panel's update) — unsolved,
+  // ah[J + 1] (64 x 32), flag adone[J + 1] — and the next diagonal tile forms X = Ahat T' itself the moment T is published,
+  // instead of waiting for the sub-diagonal tile to load T, solve, store X, have the stores acknowledged and raise its flag
+  // (the lesson of ba_cholesky_diag.hpp: a block is handed over unsolved).  nullptr: everybody waits for xdone.
+  int* adone = nullptr;      // [nrt] == tag
+  double* ah = nullptr;      // [nrt][64 * 32]
 };
 
 __host__ __device__ inline size_t TileCholLdsDoubles() { return (size_t)64 * RSBA_TL + 64 * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD + 64; }
+
+// The next diagonal tile's last update (TileCholFlags::adone): the sub-diagonal tile's rows as handed over -> XJ, T of the
+// panel -> T, X = Ahat T' -> XI, with the sub-diagonal tile's own sequence of matrix-core operations on the same operands:
+// the same bits.  Out of line: its own register allocation (inlined, the kernel went from 254 registers to 256 with 32 spilled).
+// Whole workgroup; false: a flag did not come.
+static __device__ __noinline__ bool DiagTileFormsX(const int* adone_flag, const int* tdone_flag, const int* error, int tag, long long budget,
+                                                   const double* __restrict__ ah, const double* __restrict__ F, int n, int kb,
+                                                   double* XJ, double* T, double* XI) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mi = lane & 15, kk = lane >> 4;
+  if (!WaitFlagWG(adone_flag, tag, error, budget)) return false;
+  {
+    double av[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) av[u] = ah[tid + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int e = tid + u * 256; XJ[(e >> 5) * RSBA_PLD + (e & 31)] = av[u]; }
+  }
+  if (!WaitFlagWG(tdone_flag, tag, error, budget)) return false;
+  {
+    double tv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + u * 256, r = e >> 5, c = e & 31;   // T[r][c], r >= c
+      tv[u] = (kb + r < n && kb + c < n) ? (r > c ? F[(size_t)(kb + c) * n + kb + r] : (r == c ? F[(size_t)(n + 1) * n + kb + c] : 0.0))
+                                          : (r == c ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; T[(e >> 5) * RSBA_PLD + (e & 31)] = tv[u]; }
+  }
+  __syncthreads();
+  d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  const int row = 16 * wave + mi;
+#pragma unroll
+  for (int qs = 0; qs < RSBA_PB; qs += 4) {
+    const double a = XJ[row * RSBA_PLD + qs + kk];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[mi * RSBA_PLD + qs + kk], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[(16 + mi) * RSBA_PLD + qs + kk], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) { const int r = 16 * wave + kk + 4 * tt; XI[r * RSBA_PLD + mi] = acc0[tt]; XI[r * RSBA_PLD + 16 + mi] = acc1[tt]; }
+  return true;
+}
 
 __global__ void __launch_bounds__(256, 2)
 k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scaled, damped system + rhs row (k_sys_build) */,
@@ -102,7 +151,11 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
         }
         if (tid < RSBA_PB && kb + tid < n) StoreShared(&F[(size_t)(n + 1) * n + kb + tid], invd[tid]);
         if (tid == 0 && !s_good) __hip_atomic_store(ok_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        PublishFlagWG(f.tdone + p, tag);
+        // second half: T is what the next tile column waits for — out at once; nothing of this tile lies below the block, so
+        // there is no X to form and nobody waits for this tile's xdone.  First half: the column tiles have the whole second
+        // factorisation's time to pick T up, so it is published together with X below (one wait for the stores' acknowledgements
+        // instead of two on this tile's own chain)
+        if (hf == 1 || 2 * J + 1 >= np) { PublishFlagWG(f.tdone + p, tag); if (hf == 1) continue; }
       } else {
         if (!WaitFlagWG(f.tdone + p, tag, f.error, budget)) { stalled = true; break; }
         {
@@ -142,7 +195,14 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
           }
         }
       }
-      PublishFlagWG(f.xdone + (size_t)p * f.nrt + I, tag);
+      if (I == J && hf == 0 && 2 * J + 1 < np) {
+        // (T and X of the first half together)
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) { __hip_atomic_store(f.tdone + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(f.xdone + (size_t)p * f.nrt + I, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      } else {
+        PublishFlagWG(f.xdone + (size_t)p * f.nrt + I, tag);
+      }
       // ---- first half done: this tile's columns 32..63 take -X_I X_Jp[rows 32..63]'
       if (hf == 0 && 2 * J + 1 < np) {
         if (I != J) {
@@ -170,9 +230,19 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
           Tl[r * RSBA_TL + 48 + mi] -= a1[tt];
         }
         __syncthreads();
+        if (f.adone != nullptr && I == J + 1) {
+          // the sub-diagonal tile: its rows' columns of the second panel are final — hand them over unsolved
+          double* ah = f.ah + (size_t)I * 64 * 32;
+          for (int e = tid; e < 64 * 32; e += 256) StoreShared(&ah[e], Tl[(e >> 5) * RSBA_TL + 32 + (e & 31)]);
+          PublishFlagWG(f.adone + I, tag);
+        }
       }
     } else {
       // ---- trailing tile: tile -= X_I X_J'
+      const bool own_x = f.adone != nullptr && I == J && Jp == J - 1 && hf == 1;   // the diagonal tile's last update: it forms X itself
+      if (own_x) {
+        if (!DiagTileFormsX(f.adone + I, f.tdone + p, f.error, tag, budget, f.ah + (size_t)I * 64 * 32, F, n, kb, XJ, T, XI)) { stalled = true; break; }
+      } else {
       if (!WaitFlagWG(f.xdone + (size_t)p * f.nrt + I, tag, f.error, budget)) { stalled = true; break; }
       if (I != J && !WaitFlagWG(f.xdone + (size_t)p * f.nrt + J, tag, f.error, budget)) { stalled = true; break; }
       {
@@ -189,6 +259,7 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
           XI[r * RSBA_PLD + c] = xi[u];
           if (I != J) XJ[r * RSBA_PLD + c] = xj[u];
         }
+      }
       }
       __syncthreads();
       const double* XB = (I == J) ? XI : XJ;
@@ -272,8 +343,10 @@ k_backsub_multi(int C, const double* __restrict__ red, RedLayout L, const double
   __shared__ double xg[32 * RSBA_BSM_BPG];   // the x of another workgroup's three blocks, fetched at once
   for (int b = btop; b >= w * RSBA_BSM_BPG && !stalled; --b) {   // blocks below this workgroup's columns do not touch them
     const int owner = b / RSBA_BSM_BPG, kb = 32 * b;
-    load_strip(b - 3, l3);
+    // (the flag first: its wait for the x stores' acknowledgement is a wait for EVERYTHING this wavefront has in flight, and
+    //  behind the strip loads of this iteration that was a round trip to memory per block of the owner's own chain)
     publish_pending();
+    load_strip(b - 3, l3);
     if (w == owner) {
       if (tid < RSBA_PB) {
         const double* Tj = Tb[b - owner * RSBA_BSM_BPG];

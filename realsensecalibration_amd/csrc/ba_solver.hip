@@ -180,6 +180,8 @@ struct rsba_solver {
   bool chol_diag = false;    // ... with the diagonal chain in workgroup 0 (ba_cholesky_diag.hpp; RSBA_CHOL_DIAG=0: blocks dealt round-robin, ba_cholesky_multi.hpp)
   int* mc_flags = nullptr;   // tdone[16] | strip_ready[16] | wg_done[8] | error
   int* tc_flags = nullptr;   // persistent tiled factorisation (more than 64 cameras): tdone[np] | xdone[np][nrt] | error
+  int* tc_adone = nullptr;   // ... and the sub-diagonal tiles' hand-over (TileCholFlags::adone / ah)
+  double* tc_ah = nullptr;
   int tc_np = 0, tc_nrt = 0, tc_tiles = 0;   // 0 tiles: the multi-launch path
   double* mc_dg = nullptr;         // look-ahead sums and unsolved blocks handed over between the workgroups of k_reduced_system_solve_diag
   long long* mc_trace = nullptr;   // RSBA_MC_TRACE=1: stamps of the latest multi-workgroup factorisation
@@ -708,7 +710,7 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags};
+                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_adone, s->tc_ah};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
@@ -1021,6 +1023,8 @@ static int UploadPoints(rsba_solver* s) {
           const size_t nflags = (size_t)s->tc_np * (nrt + 2) + 1;   // tdone | xdone | error | xdone of the back-substitution
           if ((rc = DevAlloc(&s->tc_flags, nflags))) return rc;
           HIPCHK(hipMemset(s->tc_flags, 0, nflags * sizeof(int)));
+          if ((rc = DevAlloc(&s->tc_adone, (size_t)nrt + 1)) || (rc = DevAlloc(&s->tc_ah, (size_t)(nrt + 1) * 64 * 32))) return rc;
+          HIPCHK(hipMemset(s->tc_adone, 0, ((size_t)nrt + 1) * sizeof(int)));
           HIPCHK(hipFuncSetAttribute((const void*)k_chol_tiles_persistent, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(TileCholLdsDoubles() * sizeof(double))));
         }
@@ -1363,7 +1367,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (s->tc_tiles > 0) {
       T.Begin("k_chol_tiles_persistent", st);
       k_chol_tiles_persistent<<<s->tc_tiles, 256, TileCholLdsDoubles() * sizeof(double), st>>>(
-          n, s->W, s->A, s->chol_ok, TileCholFlags{s->tc_flags, s->tc_flags + s->tc_np, s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1), s->tc_nrt},
+          n, s->W, s->A, s->chol_ok, TileCholFlags{s->tc_flags, s->tc_flags + s->tc_np, s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1), s->tc_nrt, s->tc_adone, s->tc_ah},
           s->step_tag, s->res);
       T.End(st);
     } else {
