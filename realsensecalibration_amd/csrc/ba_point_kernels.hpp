@@ -640,14 +640,6 @@ struct FusedLin {
   const int* __restrict__ cm_pos;     // sliced slot -> camera-major position (robust loss only)
   double* __restrict__ sq_cm_c;
   long long* trace;                   // diagnostic (RSBA_TRACE=1): [28] workgroup 0 past the solve's flag, [29] result posted
-  // k_backsub_candidate_proj only.  The candidate damped ahead of the decision: an accepted step whose radius update is
-  // clamped (rho >= 0.94, the usual case) continues with radius / (1/3); its damped inverse point blocks, V^-1 g_p and
-  // the per-block scalars — what k_point_damp would compute from lin_c at the head of the next step — are written here,
-  // and the next step starts with the Schur kernel.  nullptr: not this time.
-  double* ptdata_next = nullptr;      // [P][RSBA_PT_STRIDE]
-  double* block_scal_next = nullptr;  // [gridDim.x][4]: cost, |X|^2, singular point blocks, max |g_p|
-  int* small_flag_next = nullptr;     // does any camera of the candidate take the small-angle branch
-  double radius_next = 0.0;
   LmNext lm;                          // k_backsub_candidate_proj, single GPU: see LmNext
   // k_backsub_candidate_proj with a communicator: the last workgroup leaves this rank's sums (and stall flags) in small_red for
   // the all-reduce and touches neither the result block nor the host — k_publish_result completes the step behind the collective
@@ -887,7 +879,7 @@ k_backsub_candidate(int C, int P, ObsSliced obs,
 // ------------------------------------------------------------------------------------------------
 #define RSBA_PJ_NX 26      // rows of the table at x: A (12), B (12), ppx, ppy
 #define RSBA_PJ_NC 16      // rows of the table at the candidate: R (9), t (3), fx, fy, ppx, ppy — ProjectResidual's operands
-#define RSBA_BS_REG_LOSS 7  // observation records a lane of a robust instance keeps in registers (ten without a loss)
+#define RSBA_BS_REG_LOSS 9  // observation records a lane of a robust instance keeps in registers (ten without a loss)
 
 // (1 / x: RcpNewton, ba_math.hpp)
 
@@ -1053,12 +1045,6 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
   // the solve's half of the result block, in registers of every workgroup: whoever turns out to be the last one completes
   // and posts it without another trip to memory for it
   const double res_pre = (done_cnt != nullptr && tid < RES_SIZE) ? LoadFresh(res + tid) : 0.0;
-  if (fl.small_flag_next != nullptr && blockIdx.x == 0) {
-    int f = 0;
-    for (int c = tid; c < C; c += blockDim.x) f |= LoadFresh(camc_cg + (size_t)c * CC_STRIDE + CC_SMALL) != 0.0 ? 1 : 0;
-    f = __syncthreads_or(f);
-    if (tid == 0) *fl.small_flag_next = f;
-  }
   // (sequential schedule: the kernel boundary has made the solve's output visible; the agent-scope loads cost nothing extra)
   for (int c = tid; c < C; c += blockDim.x) {
     // this camera's column of the constants at x, the camera step, the candidate's constants — all loads first
@@ -1098,7 +1084,7 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
   __syncthreads();
   if (fl.trace != nullptr && blockIdx.x == 0 && tid == 0) fl.trace[32] = wall_clock64();
   const unsigned lx_ad = (unsigned)(size_t)(lds_double*)lx, lc_ad = (unsigned)(size_t)(lds_double*)lc;   // LDS byte addresses
-  double mcc = 0, cost_c = 0, dp2 = 0, xc2 = 0, ss_c = 0, fail_n = 0, gmax_n = 0;
+  double mcc = 0, cost_c = 0, dp2 = 0, xc2 = 0, ss_c = 0;
   for (bool first = true; slice < nslices; slice += 4 * (int)gridDim.x, j = slice * 64 + lane, first = false) {
     if (!first) load_point();
     const int nslot = te - tb;   // the same for the 64 lanes
@@ -1219,24 +1205,6 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
 #pragma unroll
       for (int i = 0; i < 6; ++i) ln[i] = Vc[i];
       ln[6] = gc[0]; ln[7] = gc[1]; ln[8] = gc[2]; ln[9] = costj_c;
-      if (fl.ptdata_next != nullptr) {
-        // k_point_damp's arithmetic on the candidate's linearisation, for the radius a clamped update gives
-        const bool anyc = Vc[0] != 0.0 || Vc[3] != 0.0 || Vc[5] != 0.0;
-        double Vn[6];
-        if (!PointBlockInverse(Vc, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, fl.radius_next, Vn)) {
-#pragma unroll
-          for (int i = 0; i < 6; ++i) Vn[i] = 0.0;
-          if (anyc) fail_n += 1.0;
-        }
-        double y[3];
-        Sym3MulVec(Vn, gc, y);
-        double* pd = fl.ptdata_next + (size_t)j * RSBA_PT_STRIDE;
-        pd[0] = Xc[0]; pd[1] = Xc[1]; pd[2] = Xc[2];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) pd[3 + i] = Vn[i];
-        pd[9] = y[0]; pd[10] = y[1]; pd[11] = y[2];
-        gmax_n = fmax(gmax_n, fmax(fabs(gc[0]), fmax(fabs(gc[1]), fabs(gc[2]))));
-      }
     }
   }
   // block reduction in a fixed order (in the records' LDS, once every wavefront is through with its own), then (single
@@ -1247,18 +1215,16 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
   double (*s)[256] = reinterpret_cast<double (*)[256]>(lds + L::kTables);
   {
     // every wavefront its 64 sums by butterfly, thread q the four wavefronts' sums of quantity q
-    const double w7[7] = {WaveSum(mcc), WaveSum(cost_c), WaveSum(dp2), WaveSum(xc2), WaveSum(ss_c), WaveSum(fail_n), WaveMax(gmax_n)};
+    const double w5[5] = {WaveSum(mcc), WaveSum(cost_c), WaveSum(dp2), WaveSum(xc2), WaveSum(ss_c)};
     if (lane == 0) {
 #pragma unroll
-      for (int q = 0; q < 7; ++q) s[q][wv] = w7[q];
+      for (int q = 0; q < 5; ++q) s[q][wv] = w5[q];
     }
   }
   __syncthreads();
-  if (tid < 6) s[tid][0] = ((s[tid][0] + s[tid][1]) + s[tid][2]) + s[tid][3];
-  if (tid == 6) s[6][0] = fmax(fmax(s[6][0], s[6][1]), fmax(s[6][2], s[6][3]));
+  if (tid < 5) s[tid][0] = ((s[tid][0] + s[tid][1]) + s[tid][2]) + s[tid][3];
   __syncthreads();
   if (tid < 5) __hip_atomic_store(&block_part[8 * blockIdx.x + tid], s[tid][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (fl.block_scal_next != nullptr && tid < 4) fl.block_scal_next[4 * blockIdx.x + tid] = tid == 0 ? s[1][0] : (tid == 1 ? s[3][0] : (tid == 2 ? s[5][0] : s[6][0]));
   if (done_cnt != nullptr) {
     __shared__ int s_last;
     __builtin_amdgcn_s_waitcnt(0);

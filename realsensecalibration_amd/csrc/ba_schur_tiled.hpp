@@ -656,7 +656,6 @@ struct SchurArgs {
   int* __restrict__ ready;
   int tag;            // 0: nobody is waiting (sequential schedule)
   int self_only;      // 1: the work list holds the self tiles only (gradient evaluation): no stage bookkeeping
-  int no_ticket;      // RSBA_NO_TICKET=1 (experiment): entry = block index
   double* __restrict__ red;
   RedLayout L;
   int nblocks_pp;
@@ -1226,10 +1225,7 @@ k_schur_tiles(SchurArgs a) {
   // word for the whole problem, fetched with the ticket, and everything an entry stages is in flight before the first
   // LDS store (PairSegment / SelfSegment).
   __shared__ int s_ticket, s_small;
-  if (a.no_ticket) {
-    // (experiment: work handed out by block index — one dependent round trip less per entry, at the mercy of the dispatcher)
-    if (threadIdx.x == 0) { s_ticket = blockIdx.x; s_small = __hip_atomic_load(a.small_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  } else if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) {
     const int sm = __hip_atomic_load(a.small_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_ticket = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_small = sm;

@@ -477,14 +477,14 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       // reduction tree of this tile: groups of RSBA_GRP consecutive segments, but the last segments in groups of 4, 2,
       // 1, 1: a tile is over when its last group has been added, and that group is usually the last one in order (its
       // finisher's own sum is 14 us for 8 partial blocks, measured, at the tail of every stage)
-      const int GRP = std::max(1, getenv("RSBA_GRP") ? atoi(getenv("RSBA_GRP")) : RSBA_GRP);
+      const int GRP = RSBA_GRP;
       const int s0 = tsp[t], ns_t = tsp[t + 1] - tsp[t], g0 = ngrp;
       std::vector<int> gsize;
       {
         int left = ns_t;
         const int tail[4] = {1, 1, 2, 4};
         std::vector<int> last;
-        if (ns_t >= 4 * GRP && !getenv("RSBA_FLAT_GROUPS")) for (int k = 0; k < 4 && left > tail[k]; ++k) { last.push_back(tail[k]); left -= tail[k]; }
+        if (ns_t >= 4 * GRP) for (int k = 0; k < 4 && left > tail[k]; ++k) { last.push_back(tail[k]); left -= tail[k]; }
         while (left > 0) { const int g = std::min(GRP, left); gsize.push_back(g); left -= g; }
         for (int k = (int)last.size() - 1; k >= 0; --k) gsize.push_back(last[k]);
       }
@@ -507,8 +507,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   for (int t = 0; t < ntiles; ++t) {
     const bool self = tab[3 * t + 2] != 0;
     const SchurSeg first = sg[tsp[t]];
-    const int rc_env = getenv("RSBA_RED_COMPS") ? atoi(getenv("RSBA_RED_COMPS")) : RSBA_RED_COMPS;
-    const int red_comps = std::max(1, std::min(rc_env, RSBA_RED_COMPS));
+    const int red_comps = RSBA_RED_COMPS;
     const int nv = self ? RSBA_PART : 36, nred = first.tile_ngrp <= RSBA_DIRECT_GROUPS ? 0 : (nv + red_comps - 1) / red_comps;
     for (int q = tsp[t]; q < tsp[t + 1]; ++q) sg[q].nred = nred;
     for (int r = 0; r < nred; ++r) {
@@ -1105,7 +1104,7 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   a.cam_prefix = ts.cam_prefix; a.cam_ptr = ts.cam_ptr; a.sq_cm = ts.sq_cm2[x]; a.u_cm = ts.u_cm; a.v_cm = ts.v_cm; a.partial = ts.partial;
   a.grp_sum = ts.grp_sum; a.sync_cnt = ts.sync_cnt; a.ngrp = ts.ngrp; a.ntiles = ts.ntiles; a.segs_ordered = ts.segs_ordered; a.small_flag = ts.small_flag; a.last_group = ts.ngroups - 1; a.tile_sum = ts.tile_sum;
   a.tree_error = ts.tree_error; a.ticket = ts.tree_error + 1;
-  a.ready = ts.ready; a.tag = tag; a.self_only = 0; { static const int nt = getenv("RSBA_NO_TICKET") ? atoi(getenv("RSBA_NO_TICKET")) : 0; a.no_ticket = nt; } a.red = s->red; a.L = s->L; a.nblocks_pp = ts.scal_blocks; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
+  a.ready = ts.ready; a.tag = tag; a.self_only = 0; a.red = s->red; a.L = s->L; a.nblocks_pp = ts.scal_blocks; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
   a.grp_flag = ts.grp_flag; a.epoch = ++ts.epoch;
   a.hits = ts.hits; a.hit_off = ts.hit_off; a.hit_trips = ts.hit_trips;
@@ -1433,24 +1432,12 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       //  has to wait for a slot starts behind the solve, without its records)
       // (more than 128 cameras: the tables alone are 80 KB, one workgroup per CU)
       grid_bs = std::max(1, std::min(C <= 128 ? 2 * DeviceCUs() - 16 : DeviceCUs() - 8, (P + 63) / 64));
-      // RSBA_SPEC_DAMP=1: the candidate damped for the radius an accepted step with a clamped update continues with
-      // (MinimizeLoop: radius / max(1/3, ...)), so that the next step launches no point-side kernel.  Off by default: the
-      // damping kernel runs while the host is still launching the factorisation and the Schur kernel, i.e. it is not on
-      // the step's critical path, and the extra work in this kernel is (measured on one box: 0.438 vs 0.431 ms at the
-      // noise floor of a converged run, where half of the steps are rejected; no difference on converging steps)
-      static const bool spec = getenv("RSBA_SPEC_DAMP") && atoi(getenv("RSBA_SPEC_DAMP")) != 0;
       FusedLin fl = fl0;
-      if (spec) {
-        TiledSchur& ts = s->tiled;
-        fl.ptdata_next = ts.ptdata; fl.block_scal_next = ts.block_scal; fl.small_flag_next = ts.small_flag;
-        fl.radius_next = std::min(s->opt.max_trust_region_radius, ip.radius / (1.0 / 3.0));
-        ts.pt_valid = true; ts.pt_state = c; ts.pt_radius = fl.radius_next; ts.scal_blocks = grid_bs;
-      }
       // single GPU: the workgroup that completes the result block takes the step's decision as well, and the damping
       // kernel of the NEXT step is queued right here, behind this kernel, on that decision (LmNext; RSBA_DECIDED_DAMP=0:
       // the host launches it once it has decided itself)
       static const bool decided = !(getenv("RSBA_DECIDED_DAMP") && atoi(getenv("RSBA_DECIDED_DAMP")) == 0);
-      s->dec_step = decided && !spec && fin_cnt != nullptr;
+      s->dec_step = decided && fin_cnt != nullptr;
       if (s->dec_step) {
         LmNext lm;
         lm.dec = s->dec; lm.radius = ip.radius; lm.decrease_factor = s->lm_decrease_factor;

@@ -1,0 +1,40 @@
+"""Child process of tests/test_gpu_switches.py: solves a few problems through the C ABI with whatever RSBA_* switches the
+environment carries (they are read once per process) and prints, as one JSON line, how each solve compares with the oracle.
+Test infrastructure: the oracle is the checker."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+import oracle_lib  # noqa: E402
+from oracle_spread import block_rel  # noqa: E402
+from realsensecalibration_amd import capi, synthetic as syn  # noqa: E402
+
+CASES = {"c40": (40, 3000, 9, 340, 0.0), "c64_huber": (64, 4000, 12, 364, 1.0), "c70_huber": (70, 1500, 10, 5, 1.0), "c130": (130, 1500, 12, 430, 0.0)}
+
+
+def main():
+    oracle = oracle_lib.load()
+    out = {}
+    for name in sys.argv[1:]:
+        C, P, k, seed, huber = CASES[name]
+        prob = syn.make_problem(C, P, k, seed=seed, outlier_frac=0.05 if huber else 0.0)
+        ref, s_ref, log_ref = oracle.solve_points(prob, oracle.options(huber_delta=huber))
+        got, s, log = capi.solve_points(prob, capi.default_options(schur_impl=1, huber_delta=huber))
+        again, s2, _ = capi.solve_points(prob, capi.default_options(schur_impl=1, huber_delta=huber))
+        out[name] = dict(iterations=int(s.num_iterations), iterations_ref=int(s_ref.num_iterations),
+                         same_decisions=bool(len(log) == len(log_ref) and np.array_equal(log[:, 7], log_ref[:, 7])),
+                         stop=int(s.stop_reason), stop_ref=int(s_ref.stop_reason), raw=float(block_rel(got, ref, C)),
+                         final_cost_rel=float(abs(s.final_cost - s_ref.final_cost) / s_ref.final_cost),
+                         iterate_costs=float(np.abs(log[:, 1] - log_ref[:, 1]).max() / log_ref[:, 1].max()) if len(log) == len(log_ref) else 1.0,
+                         reproducible=bool(np.array_equal(got, again)))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
