@@ -217,13 +217,22 @@ def main():
         nc = 6 * C
         chol_flops = nc ** 3 / 3.0 + 2.0 * nc ** 2
         b_iter = syn.algorithmic_bytes_per_iteration(C, P_rank, N_rank)
-        pmc = {}
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc.json", "r01_pmc.json")) if os.path.exists(q)), "")
-        if pmc_path:
-            try:
-                pmc = json.load(open(pmc_path))
-            except Exception:
-                pmc = {}
+        # HBM traffic per launch: PMC counters of separate rocprofv3 --pmc passes over THIS configuration (tools/profile_r03.sh
+        # writes profiles/r03_pmc_<workload>.json); a line for a workload without such a file carries traffic = null
+        pmc, pmc_source = {}, None
+        wl = args.config if args.points is None else "%s_%d" % (args.config, args.points)
+        for cand in ("r03_pmc_%s.json" % wl,) + (("r02_pmc.json",) if wl == "cfg3" else ()):
+            q = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(q):
+                try:
+                    pmc = json.load(open(q))
+                    pmc_source = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py` on this workload, "
+                                  "SEQUENTIAL schedule (counter collection serialises kernels; the pipelined factorisation would only "
+                                  "time out), FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes; a committed constant, "
+                                  "not collected by this run" % cand)
+                    break
+                except Exception:
+                    pmc = {}
 
         def roof(name):
             ms = per[name][1]
@@ -236,7 +245,8 @@ def main():
                 ach = schur_flops / lpi / (ms * 1e-3) / 1e12
                 return {"kernel": name, "bound": "mfma", "pipe": "v_fma_f64 (fp64 VALU issue; the kernel executes no MFMA)",
                         "achieved": ach, "peak": FP64_PEAK_TFLOPS, "peak_source": PEAK_SOURCE, "unit": "TFLOP/s",
-                        "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "avg_launch_us": 1e3 * ms,
+                        "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": pmc_source if traffic is not None else None,
+                        "avg_launch_us": 1e3 * ms,
                         "algorithmic_flops_per_launch": schur_flops / lpi, "launches_per_iteration": lpi,
                         "note": "compute-bound point elimination on the fp64 vector pipe: sum_j k_j(k_j+1)/2 blocks x 216 flop (+rhs); "
                                 "\"bound\" keeps the schema's compute label, \"pipe\" names the real one (PMC: zero MFMA ops in this kernel)"}
@@ -244,14 +254,16 @@ def main():
                 ach = chol_flops / lpi / (ms * 1e-3) / 1e12
                 return {"kernel": name, "bound": "mfma", "pipe": "v_mfma_f64_16x16x4_f64", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
                         "peak_source": PEAK_SOURCE, "unit": "TFLOP/s",
-                        "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "avg_launch_us": 1e3 * ms,
+                        "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": pmc_source if traffic is not None else None,
+                        "avg_launch_us": 1e3 * ms,
                         "algorithmic_flops_per_launch": chol_flops / lpi, "launches_per_iteration": lpi,
                         "note": "dense (6C)^3/3 + 2(6C)^2 Cholesky solve on six workgroups (a chain of 32 x 32 factorisations: latency-bound by construction)"}
             share = {"k_point_pass": 24 * N_rank + 48 * P_rank, "k_backsub_candidate": 24 * N_rank + 48 * P_rank}.get(name, b_iter)
             ach = share / lpi / (ms * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s",
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic, "avg_launch_us": 1e3 * ms, "algorithmic_bytes_per_launch": share / lpi,
+                    "traffic": traffic, "traffic_source": pmc_source if traffic is not None else None,
+                    "avg_launch_us": 1e3 * ms, "algorithmic_bytes_per_launch": share / lpi,
                     "launches_per_iteration": lpi}
 
         # dominant kernel = most CU-time: duration x share of the chip it occupies (the one-workgroup kernels hold 1 of
@@ -291,8 +303,8 @@ def main():
         res = {}
         # 1 thread is what the reference runs (Solver::Options::num_threads default, bundle_adjustment_manager.cpp:90-92);
         # all host cores is SURVEY 8(d)'s second figure
-        # (64 as well on bigger hosts: the per-thread copies of S make the all-core run reduction-bound)
-        for nt in sorted({1, min(ncpu, 64), ncpu}):
+        # (and 64 / 128 threads on bigger hosts: beyond the physical cores the elimination no longer scales)
+        for nt in sorted({1, min(ncpu, 64), min(ncpu, 128), ncpu}):
             oo = o.options(max_num_iterations=args.cpu_iters, num_threads=nt, function_tolerance=-1.0, parameter_tolerance=-1.0,
                            gradient_tolerance=-1.0, huber_delta=huber)
             x_cpu, s_cpu, log_cpu = o.solve_points(prob, oo)
@@ -315,8 +327,8 @@ def main():
                                    "note": "all camera blocks and every %d-th point block; tolerance of the parity tests: 1e-6" % max(1, P_rank // 2000)}
         out["cpu_baseline"] = {"value": res[best], "unit": "LM iterations/s", "cores": int(best), "kind": "port",
                                "sample": "%d LM iterations of the same %s problem (oracle/: Jet AutoDiff + Schur + dense LLT, "
-                                         "-O3 -march=native, OpenMP over points); single thread = %.4f it/s"
-                                         % (args.cpu_iters, args.config, res[1]),
+                                         "-O3 -march=native, OpenMP over points), the best of %s threads; single thread = %.4f it/s"
+                                         % (args.cpu_iters, args.config, " / ".join(str(k_) for k_ in sorted(res)), res[1]),
                                "single_thread_value": res[1], "all_cores_value": res.get(ncpu), "all_cores_threads": ncpu,
                                "by_threads": {str(k_): v_ for k_, v_ in sorted(res.items())}, "host_cores": ncpu}
         out["speedup_vs_cpu_baseline"] = iters_per_s / res[best]

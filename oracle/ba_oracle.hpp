@@ -643,7 +643,9 @@ class PointSchurModel {
       std::vector<double>& St = Sl[tid]; std::vector<double>& rt = rl[tid];
       St.assign((size_t)nc * nc, 0.0); rt.assign(nc, 0.0);
       std::vector<double> W, Y; std::vector<int> cam;
-#pragma omp for schedule(dynamic, 256)
+      // (chunks of P / (8 threads) points: with a fixed 256, 100k points were 390 chunks for 256 threads)
+      const int chunk = std::max(16, p_.P / (8 * nt));
+#pragma omp for schedule(dynamic, chunk)
       for (int j = 0; j < p_.P; ++j) {
         const int64_t b = pt_ptr_[j], e = pt_ptr_[j + 1];
         const int k = (int)(e - b);
@@ -688,8 +690,18 @@ class PointSchurModel {
       }
     }
     std::fill(rhs, rhs + nc, 0.0);
+    // the threads' copies of S, added in thread order, a tile of 2048 entries at a time: every thread streams nt short runs
+    // instead of walking nt copies at once (one entry per copy and step touched nt pages per entry: at 256 threads the sum
+    // took twenty times as long as the elimination it follows)
+    {
+      const int64_t total = (int64_t)nc * nc, tile = 2048, ntile = (total + tile - 1) / tile;
 #pragma omp parallel for schedule(static) num_threads(nt)
-    for (int64_t q = 0; q < (int64_t)nc * nc; ++q) { double a = 0; for (int t = 0; t < nt; ++t) if (!Sl[t].empty()) a += Sl[t][q]; S[q] = a; }
+      for (int64_t b = 0; b < ntile; ++b) {
+        const int64_t q0 = b * tile, q1 = std::min(total, q0 + tile);
+        for (int64_t q = q0; q < q1; ++q) S[q] = 0.0;
+        for (int t = 0; t < nt; ++t) { if (Sl[t].empty()) continue; const double* src = Sl[t].data(); for (int64_t q = q0; q < q1; ++q) S[q] += src[q]; }
+      }
+    }
     for (int t = 0; t < nt; ++t) { if (rl[t].empty()) continue; for (int q = 0; q < nc; ++q) rhs[q] += rl[t][q]; }
     for (int q = 0; q < nc; ++q) S[(size_t)q * nc + q] += D[q] * D[q];
     if (ete_inv_out) ete_inv_out->swap(ete_inv);

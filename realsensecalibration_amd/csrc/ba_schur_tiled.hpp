@@ -1205,7 +1205,10 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
 // g's columns.  Two workgroups
 // per CU: the accumulators are the only long-lived per-lane state; point data, visibility rows and camera constants sit
 // in LDS.
-template <bool kLoss>
+// kSparse: the instance for more than 64 cameras (PairSegmentSparse instead of PairSegment) — a kernel of its own: compiled into
+// one kernel beside the masked search, the sparse path cost the 64-camera kernel 50 us (284 -> 337 us: the same registers, but
+// more scalar spills and a longer hot loop around the same arithmetic)
+template <bool kLoss, bool kSparse>
 __global__ void __launch_bounds__(256, 2)
 k_schur_tiles(SchurArgs a) {
   __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];            // 48 KB
@@ -1242,7 +1245,7 @@ k_schur_tiles(SchurArgs a) {
   else {
     // two instances of the pair tile: the small-angle selects of the Jacobian rows (12 instructions per hit) are compiled in
     // only when some camera takes that branch this iteration (a rotation of exactly zero: the reference's test2 fixture)
-    if (a.hits != nullptr) {
+    if (kSparse) {
       if (s_small) PairSegmentSparse<kLoss, true>(a, sg, seg_index, b, pt, sc);
       else PairSegmentSparse<kLoss, false>(a, sg, seg_index, b, pt, sc);
     } else if (s_small) PairSegment<kLoss, true>(a, sg, seg_index, b, pt, mk, sc);

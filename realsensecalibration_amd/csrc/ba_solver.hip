@@ -13,6 +13,7 @@
 // factors the identical system, so no broadcast is needed and all ranks take identical decisions.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -23,6 +24,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -265,14 +267,19 @@ namespace rsba {
 // Word bounds of the segments one PAIR tile's points are cut into (ns + 1 values, in 64-point mask words): the same for
 // every pair tile.  Shared by TiledSchur::Build and by the point ordering below (whose units are these segments' chunks).
 static int DeviceCUs() {
-  // (one device per process; asked once — the step asks for it as well)
-  static const int cached = []() {
-    int cus = 256;
-    hipDeviceProp_t prop; int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    return cus;
-  }();
-  return cached;
+  // (asked once per device: the step asks for it as well)
+  static std::mutex mu;
+  static std::map<int, int> cached;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cached.find(dev);
+  if (it != cached.end()) return it->second;
+  int cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  cached[dev] = cus;
+  return cus;
 }
 static std::vector<int> SegmentBounds(int nW, int ns, double taper = 1.0) {
   // Tapered segments (taper > 1: the first of a tile is that many times as long as the last).  A launch is over when its last
@@ -334,7 +341,8 @@ static std::vector<int> BalancedPointOrder(int C, int P, bool staged, const std:
       ucap.push_back(std::min(64 * we, P) - 64 * w);
     }
   const int nu = (int)ubeg.size();
-  if (nu < 2 || (double)nu * C * C > 3e8) return {};   // (the pair counters: 2 bytes per unit and camera pair)
+  // (the pair counters, 2 bytes per unit and camera pair: at most 64 MB of host memory — beyond that the file order is kept)
+  if (nu < 2 || (double)nu * C * C > 3.2e7) return {};
   const int64_t N = ptr[P];
   const double pairs_per_point = N > 0 ? 0.5 * ((double)N / P) * ((double)N / P) : 1.0;
   // candidates per point: bounded work (~6e8 counter reads), at least 2, at most 32 (or RSBA_BALANCE = number)
@@ -401,7 +409,11 @@ static std::vector<int> BalancedPointOrder(int C, int P, bool staged, const std:
     }
   };
   {
-    const int nthreads = std::max(1, std::min<int>(nstream, (int)std::thread::hardware_concurrency()));
+    // (as many threads as this process may run on — its affinity mask, not the machine's core count; the streams, and with
+    //  them the order, do not depend on it)
+    cpu_set_t aff;
+    const int ncpu = sched_getaffinity(0, sizeof(aff), &aff) == 0 ? CPU_COUNT(&aff) : 1;
+    const int nthreads = std::max(1, std::min<int>(nstream, ncpu));
     std::atomic<int> next_stream{0};
     auto worker = [&]() { for (int t = next_stream++; t < nstream; t = next_stream++) run_stream(t); };
     std::vector<std::thread> pool;
@@ -1117,8 +1129,11 @@ void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& 
   SchurArgs a = MakeSchurArgs(*this, s, tag);
   if (first_staged) { a.segs_ordered = segs_ordered_first; a.all_self = 1; }
   T.Begin("k_schur_tiles", st);
-  if (ip.huber_delta != 0.0) k_schur_tiles<true><<<nblocks, 256, 0, st>>>(a);
-  else k_schur_tiles<false><<<nblocks, 256, 0, st>>>(a);
+  if (a.hits != nullptr) {
+    if (ip.huber_delta != 0.0) k_schur_tiles<true, true><<<nblocks, 256, 0, st>>>(a);
+    else k_schur_tiles<false, true><<<nblocks, 256, 0, st>>>(a);
+  } else if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<nblocks, 256, 0, st>>>(a);
+  else k_schur_tiles<false, false><<<nblocks, 256, 0, st>>>(a);
   T.End(st);
 }
 
@@ -1127,8 +1142,8 @@ void TiledSchur::LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTime
   SchurArgs a = MakeSchurArgs(*this, s, 0);
   a.segs_ordered = segs_ordered_self; a.self_only = 1; a.trace = nullptr; a.wg_trace = nullptr;
   T.Begin("k_schur_tiles(self only)", st);
-  if (ip.huber_delta != 0.0) k_schur_tiles<true><<<nblocks_self, 256, 0, st>>>(a);
-  else k_schur_tiles<false><<<nblocks_self, 256, 0, st>>>(a);
+  if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<nblocks_self, 256, 0, st>>>(a);
+  else k_schur_tiles<false, false><<<nblocks_self, 256, 0, st>>>(a);
   T.End(st);
 }
 

@@ -200,8 +200,12 @@ def test_two_rank_solve_matches_unsharded_oracle(oracle, tmp_path):
     out = tmp_path / "mg.json"
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import socket
+    with socket.socket() as sk:   # a free ephemeral port, as bench.py picks one: a fixed one collides with a concurrent or stale run
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", os.path.join(ROOT, "tests", "mg_worker.py"), str(out)]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "mg_worker.py"), str(out)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = json.loads(out.read_text())

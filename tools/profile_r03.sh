@@ -1,0 +1,59 @@
+# Round-3 evidence, one gpurun call: bench lines, rocprofv3 kernel stats and PMC passes for the benchmark's workload (cfg3) and
+# for one rank's shard of the two 8-GPU configurations, timelines.  Everything lands in gpurun_out/r03/; the summaries are
+# copied into profiles/ by hand (tracked).  The PMC passes run the sequential schedule: counter collection serialises kernels,
+# and the pipelined factorisation (which waits inside the kernel for the Schur kernel launched after it) would only time out.
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+O=gpurun_out/r03
+mkdir -p $O
+# ---- bench lines
+python3 bench.py > $O/r03_bench_default.json 2> $O/r03_bench_default.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r03_bench_driver_cmd.json 2>/dev/null
+python3 bench.py --config cfg5 --points 62500 --steps 20 --cpu-iters 2 > $O/r03_bench_cfg5_shard.json 2>/dev/null
+python3 bench.py --config cfg4 --points 125000 --steps 30 --no-cpu-baseline > $O/r03_bench_cfg4_shard.json 2>/dev/null
+RSBA_FORCE_COMM=1 python3 bench.py --no-cpu-baseline --steps 30 > $O/r03_bench_comm1rank_sequential.json 2>/dev/null
+RSBA_FORCE_COMM=1 RSBA_PIPELINE_MG=1 python3 bench.py --no-cpu-baseline --steps 30 > $O/r03_bench_comm1rank_pipelined.json 2>/dev/null
+RSBA_PIPELINE=0 python3 bench.py --no-cpu-baseline --steps 30 > $O/r03_bench_sequential.json 2>/dev/null
+# ---- kernel stats
+prof() {  # name, bench args...
+  name=$1; shift
+  rm -rf gpurun_out/prof_tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_tmp -- python3 bench.py --no-cpu-baseline "$@" > $O/r03_bench_under_rocprof_$name.json 2> /dev/null
+  cp $(ls gpurun_out/prof_tmp/*/*kernel_stats.csv | head -1) $O/r03_kernel_stats_$name.csv
+  python3 tools/kernel_gaps.py gpurun_out/prof_tmp > $O/r03_step_gaps_$name.txt 2>/dev/null
+  python3 tools/step_timeline.py gpurun_out/prof_tmp > $O/r03_step_timeline_$name.txt 2>/dev/null
+  rm -rf gpurun_out/prof_tmp
+}
+prof cfg3
+prof cfg5_62500 --config cfg5 --points 62500 --steps 20
+prof cfg4_125000 --config cfg4 --points 125000 --steps 30
+RSBA_FORCE_COMM=1 RSBA_PIPELINE_MG=1 prof cfg3_comm1rank_pipelined --steps 30
+# ---- PMC (sequential schedule)
+export RSBA_PIPELINE=0
+pmc() {  # name, bench args...
+  name=$1; shift
+  rm -rf gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/pmc_s gpurun_out/pmc_s2
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pmc_s -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d gpurun_out/pmc_s2 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2>&1
+  python3 tools/pmc_to_json.py gpurun_out/pmc_f gpurun_out/pmc_w $O/r03_pmc_$name.json $name
+  python3 tools/pmc_summary.py gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/pmc_s gpurun_out/pmc_s2 > $O/r03_pmc_summary_$name.txt
+  rm -rf gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/pmc_s gpurun_out/pmc_s2
+}
+pmc cfg3
+pmc cfg5_62500 --config cfg5 --points 62500
+unset RSBA_PIPELINE
+# ---- timelines
+RSBA_TRACE=2 RSBA_TRACE_FILE=$O/wg_cfg3.txt python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 > /dev/null 2>&1
+python3 tools/schur_timeline_summary.py $O/wg_cfg3.txt > $O/r03_schur_block_timeline_cfg3.txt
+RSBA_TRACE=2 RSBA_TRACE_FILE=$O/wg_cfg5.txt python3 bench.py --config cfg5 --points 62500 --no-cpu-baseline --steps 8 --warmup 2 > /dev/null 2>&1
+python3 tools/schur_timeline_summary.py $O/wg_cfg5.txt > $O/r03_schur_block_timeline_cfg5_62500.txt
+RSBA_TRACE=3 python3 bench.py --no-cpu-baseline --steps 100 --warmup 5 --no-events 2>&1 | grep "rsba\[ring\]" | tail -1 > $O/r03_step_ring.txt
+RSBA_HOSTPROF=1 python3 bench.py --no-cpu-baseline --steps 100 --warmup 5 --no-events 2>&1 | grep "rsba\[hostprof\]" | tail -1 >> $O/r03_step_ring.txt
+rm -f $O/wg_cfg3.txt $O/wg_cfg5.txt
+for f in default driver_cmd cfg5_shard cfg4_shard comm1rank_sequential comm1rank_pipelined sequential; do python3 -c "
+import json
+d=json.loads(open('$O/r03_bench_$f.json').read().strip().splitlines()[-1])
+print('$f', round(d['ms_per_step'],4), {k:round(v['avg_us'],1) for k,v in d.get('kernels',{}).items()}, d.get('cpu_baseline',{}).get('by_threads'))"; done
