@@ -394,4 +394,211 @@ k_backsub_multi(int C, const double* __restrict__ red, RedLayout L, const double
   CameraStepEpilogue(C, red, L, scale_c, xsol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, ok, epi, cam_free);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Block back-substitution with the chain in ONE workgroup (round 3; k_backsub_multi above is its predecessor and fallback).
+// k_backsub_multi passes the chain from owner to owner: per owner's three blocks a hop (store x, acknowledgement, flag, poll,
+// fetch), three strip updates and three solves, ~11 us — 184 us at 256 cameras.  Here workgroup 0 solves EVERY block, in
+// order, with all of x in its LDS, and never waits for a store: per block it subtracts the nearest strips' blocks itself
+// (L(i, b) x_i for b < i <= top of its column range + RSBA_BSC_LAG: at most five 32 x 32 products, their entries of L prefetched one
+// block ahead, addresses known) and x_b = T_b' y_b; one wavefront publishes x_b while the others go on.  Everything FARTHER
+// above is the helpers' business: helper h owns 96 columns of y and applies the strip of every block i more than RSBA_BSC_LAG above
+// its range as soon as x_i is published (strips prefetched three ahead, as in k_backsub_multi), then hands its slice of y over
+// (ys, hdone) — three blocks before the chain gets there, so the chain finds it waiting.  Same sums per entry in a fixed order:
+// bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+#define RSBA_BSC_LAG 3
+__global__ void __launch_bounds__(256)
+k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double* __restrict__ F, double* __restrict__ xsol,
+                const double* __restrict__ scale_c, const double* __restrict__ cam_x, double* __restrict__ cam_c,
+                const double* __restrict__ intr, double* __restrict__ camc_c, double* __restrict__ dcam,
+                const double* __restrict__ gmax_p, double* __restrict__ res, const int* __restrict__ ok_flag,
+                const double* __restrict__ cam_free, int* __restrict__ xdone, int* __restrict__ hdone, double* __restrict__ ys,
+                int* __restrict__ error, int tag) {
+  const int n = L.nc, tid = threadIdx.x, w = blockIdx.x;
+  const int m = (n + RSBA_PB - 1) / RSBA_PB * RSBA_PB, nblk = m / RSBA_PB, btop = nblk - 1;
+  const long long budget = RSBA_STALL_TICKS;
+  __shared__ double part[8][RSBA_PB];
+  __shared__ double xb[RSBA_PB];
+  __shared__ double epi[4 * 256];
+  if (w > 0) {
+    // ---- helper: 96 columns of y, the strips of the blocks far above them
+    __shared__ double yown[96];
+    const int h = w - 1, c0 = 96 * h, b1 = min(btop, 3 * h + 2);
+    const int q = tid & 127, hp = tid >> 7;
+    for (int i = tid; i < 96; i += 256) yown[i] = c0 + i < n ? F[(size_t)n * n + c0 + i] : 0.0;
+    auto load_strip = [&](int b, double (&d)[16]) {
+      const int gq = c0 + q;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int gi = 32 * b + 16 * hp + c;
+        d[c] = (b > b1 + RSBA_BSC_LAG && q < 96 && gq < n && gi < n) ? F[(size_t)gi * n + gq] : 0.0;
+      }
+    };
+    double lv[16], l1[16], l2[16], l3[16];
+    load_strip(btop, lv); load_strip(btop - 1, l1); load_strip(btop - 2, l2);
+    __syncthreads();
+    bool stalled = false;
+    for (int b = btop; b > b1 + RSBA_BSC_LAG; --b) {
+      load_strip(b - 3, l3);
+      if (!WaitFlagWG(xdone + b, tag, error, budget)) { stalled = true; break; }
+      if (tid < RSBA_PB) xb[tid] = 32 * b + tid < n ? __hip_atomic_load(&xsol[32 * b + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      __syncthreads();
+      {
+        double sacc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sacc += lv[c] * xb[16 * hp + c];
+        epi[hp * 128 + q] = sacc;
+      }
+      __syncthreads();
+      if (tid < 96) yown[tid] -= epi[tid] + epi[128 + tid];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { lv[c] = l1[c]; l1[c] = l2[c]; l2[c] = l3[c]; }
+      __syncthreads();
+    }
+    if (stalled) { if (tid == 0) __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (tid < 96) StoreShared(&ys[96 * h + tid], yown[tid]);
+    PublishFlagWG(hdone + h, tag);
+    return;
+  }
+  // ---- the chain
+  extern __shared__ double xl[];                       // m: every x, as it is solved
+  __shared__ double yl[96];                            // the current helper range's slice of y
+  __shared__ double ybl[RSBA_PB];
+  const int c = tid & 31, p8 = tid >> 5;               // column of the block, eighth of its 32 rows (rows 4 p8 .. 4 p8 + 3)
+  // what block b needs from memory, fetched one block ahead: its near blocks of L (at most LAG + 2) and T_b.  Checked form: any
+  // block, padding rows and columns read as zero / identity.  Plain form (the loop's, whenever no padded row or column is in
+  // reach): ONE per-thread byte offset and a scalar row offset per load — the checked form's index arithmetic, 28 loads of it,
+  // was 1.65 us of the chain's 2.7 us per block.
+  constexpr int kNear = RSBA_BSC_LAG + 2;
+  auto fetch_checked = [&](int b, double (&ln)[kNear][4], double (&tn)[4]) {
+    const int h = b / 3, b1 = min(btop, 3 * h + 2), ihi = min(btop, b1 + RSBA_BSC_LAG), kb = 32 * b;
+#pragma unroll
+    for (int u = 0; u < kNear; ++u) {
+      const int i = b + 1 + u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = 32 * i + 4 * p8 + r, gj = kb + c;
+        ln[u][r] = (b >= 0 && i <= ihi && gi < n && gj < n) ? F[(size_t)gi * n + gj] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * p8 + r;   // T[i][c], i >= c: at F[kb + c][kb + i] for i > c, the diagonal in row n + 1; identity on the padding
+      tn[r] = b < 0 ? 0.0 : ((kb + i < n && kb + c < n) ? (i > c ? F[(size_t)(kb + c) * n + kb + i] : (i == c ? F[(size_t)(n + 1) * n + kb + c] : 0.0))
+                                                         : (i == c ? 1.0 : 0.0));
+    }
+  };
+  const char* Fb = reinterpret_cast<const char*>(F);
+  const unsigned rowb = 8u * (unsigned)n;                 // bytes per row of F; (n + 2) n doubles stay far below 4 GB
+  auto fetch_plain = [&](int b, double (&ln)[kNear][4], double (&tn)[4], double& dgn) {
+    // needs 0 <= b and every row 32 i + 31 of its near blocks and 32 b + 31 below n
+    const int h = b / 3, b1 = min(btop, 3 * h + 2), nu = min(btop, b1 + RSBA_BSC_LAG) - b;
+    const unsigned kb = 32u * (unsigned)b;
+    const unsigned o_l = (kb + 32u + 4u * p8) * rowb + 8u * (kb + c);       // L(b + 1, b)[4 p8][c]
+#pragma unroll
+    for (int u = 0; u < kNear; ++u) {
+      if (u < nu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ln[u][r] = *reinterpret_cast<const double*>(Fb + (size_t)(o_l + (unsigned)(32 * u + r) * rowb));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ln[u][r] = 0.0;
+      }
+    }
+    const unsigned o_t = (kb + c) * rowb + 8u * (kb + 4u * p8);             // row kb + c of F, columns kb + 4 p8 ..
+    // raw: row kb + c of F holds T[i][c] for i > c, the diagonal comes from row n + 1, the rest of the row belongs to other
+    // blocks — TEntry() picks when the values are used (picking here made the compiler wait for the loads here)
+    dgn = *reinterpret_cast<const double*>(Fb + (size_t)((unsigned)(n + 1) * rowb + 8u * (kb + c)));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tn[r] = *reinterpret_cast<const double*>(Fb + (size_t)(o_t + 8u * r));
+  };
+  auto fetch = [&](int b, double (&ln)[kNear][4], double (&tn)[4], double& dgn) {
+    const int b1 = min(btop, 3 * (b / 3) + 2);
+    if (b >= 0 && 32 * (min(btop, b1 + RSBA_BSC_LAG) + 1) <= n) { fetch_plain(b, ln, tn, dgn); return true; }
+    fetch_checked(b, ln, tn);
+    return false;
+  };
+  double lcur[kNear][4], tcur[4], lnext[kNear][4], tnext[4], dgcur = 0.0, dgnext = 0.0;
+  bool raw_cur = fetch(btop, lcur, tcur, dgcur), raw_next = false;
+  bool stalled = false;
+  for (int b = btop; b >= 0; --b) {
+    const int h = b / 3, b1 = min(btop, 3 * h + 2), ihi = min(btop, b1 + RSBA_BSC_LAG);
+    if (b < btop && tid >= 192) {
+      __builtin_amdgcn_s_waitcnt(0);
+      if (tid == 192) __hip_atomic_store(xdone + b + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    raw_next = fetch(b - 1, lnext, tnext, dgnext);
+    if (b == b1) {
+      // a new range of columns: its helper has applied every strip above b1 + LAG (or there are none)
+      if (!WaitFlagWG(hdone + h, tag, error, budget)) { stalled = true; break; }
+      if (tid < 96) yl[tid] = __hip_atomic_load(&ys[96 * h + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+    }
+    // the near blocks: sum_i L(i, b)' x_i over b < i <= ihi
+    {
+      double sacc = 0.0;
+#pragma unroll
+      for (int u = 0; u < kNear; ++u) {
+        const int i = b + 1 + u;
+        if (i <= ihi) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc += lcur[u][r] * xl[32 * i + 4 * p8 + r];
+        }
+      }
+      part[p8][c] = sacc;
+    }
+    __syncthreads();
+    if (tid < RSBA_PB) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sacc += part[q][tid];
+      ybl[tid] = yl[32 * (b - 3 * h) + tid] - sacc;
+    }
+    __syncthreads();
+    // x_b = T_b' y_b
+    {
+      double sacc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * p8 + r;
+        const double tv = raw_cur ? (i > c ? tcur[r] : (i == c ? dgcur : 0.0)) : tcur[r];
+        sacc += tv * ybl[i];
+      }
+      part[p8][c] = sacc;
+    }
+    __syncthreads();
+    if (tid < RSBA_PB) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sacc += part[q][tid];
+      xl[32 * b + tid] = sacc;
+    }
+    __syncthreads();
+    // x_b goes out now; its flag follows at the top of the next iteration (below): by then the store is acknowledged, and the
+    // wait for that is a wait for loads this wavefront needs there anyway.  (Flag right behind the store: every block the whole
+    // workgroup stood at the next barrier until the last wavefront's store AND its prefetches for the next block had come back.)
+    if (tid >= 192 && tid < 224) {
+      const int t = tid - 192;
+      if (32 * b + t < n) StoreShared(&xsol[32 * b + t], xl[32 * b + t]);
+    }
+#pragma unroll
+    for (int u = 0; u < kNear; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lcur[u][r] = lnext[u][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tcur[r] = tnext[r];
+    dgcur = dgnext;
+    raw_cur = raw_next;
+  }
+  if (stalled) { if (tid == 0) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 1.0; } return; }
+  // every x is in xsol (this workgroup stored them) — visible to its own plain loads behind the acknowledgements and one acquire
+  __builtin_amdgcn_s_waitcnt(0);
+  if (tid == 192) __hip_atomic_store(xdone + 0, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  int ok = 1;
+  if (tid == 0) ok = __hip_atomic_load(ok_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  CameraStepEpilogue(C, red, L, scale_c, xsol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, ok, epi, cam_free);
+}
+
 }  // namespace rsba

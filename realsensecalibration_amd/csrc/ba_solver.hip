@@ -184,6 +184,8 @@ struct rsba_solver {
   int* tc_flags = nullptr;   // persistent tiled factorisation (more than 64 cameras): tdone[np] | xdone[np][nrt] | error
   int* tc_adone = nullptr;   // ... and the sub-diagonal tiles' hand-over (TileCholFlags::adone / ah)
   double* tc_ah = nullptr;
+  int* tc_hdone = nullptr;   // k_backsub_chain: the helpers' slices of y (flag, 96 doubles each)
+  double* tc_ys = nullptr;
   int tc_np = 0, tc_nrt = 0, tc_tiles = 0;   // 0 tiles: the multi-launch path
   double* mc_dg = nullptr;         // look-ahead sums and unsolved blocks handed over between the workgroups of k_reduced_system_solve_diag
   long long* mc_trace = nullptr;   // RSBA_MC_TRACE=1: stamps of the latest multi-workgroup factorisation
@@ -721,7 +723,7 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_adone, s->tc_ah};
+                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_adone, s->tc_ah, s->tc_hdone, s->tc_ys};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
@@ -1036,6 +1038,11 @@ static int UploadPoints(rsba_solver* s) {
           HIPCHK(hipMemset(s->tc_flags, 0, nflags * sizeof(int)));
           if ((rc = DevAlloc(&s->tc_adone, (size_t)nrt + 1)) || (rc = DevAlloc(&s->tc_ah, (size_t)(nrt + 1) * 64 * 32))) return rc;
           HIPCHK(hipMemset(s->tc_adone, 0, ((size_t)nrt + 1) * sizeof(int)));
+          {
+            const int H = (s->tc_np + 2) / 3;
+            if ((rc = DevAlloc(&s->tc_hdone, (size_t)H)) || (rc = DevAlloc(&s->tc_ys, (size_t)H * 96))) return rc;
+            HIPCHK(hipMemset(s->tc_hdone, 0, (size_t)H * sizeof(int)));
+          }
           HIPCHK(hipFuncSetAttribute((const void*)k_chol_tiles_persistent, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(TileCholLdsDoubles() * sizeof(double))));
         }
@@ -1394,7 +1401,18 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     }
     T.End(st);
     }
-    if (s->tc_tiles > 0 && !(getenv("RSBA_BACKSUB_MULTI") && atoi(getenv("RSBA_BACKSUB_MULTI")) == 0)) {
+    // RSBA_BACKSUB_MULTI: 2 (default) the chain in one workgroup with helpers for the far strips (k_backsub_chain), 1 the chain
+    // passed from owner to owner (k_backsub_multi, round 2), 0 one workgroup for everything (k_chol_finish)
+    static const int bsm = getenv("RSBA_BACKSUB_MULTI") ? atoi(getenv("RSBA_BACKSUB_MULTI")) : 2;
+    if (s->tc_tiles > 0 && bsm >= 2 && s->tc_hdone != nullptr) {
+      const int nblk = s->tc_np, H = (nblk + 2) / 3;
+      int* fl = s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1);   // [error | xdone ...]
+      T.Begin("k_backsub_multi", st);
+      k_backsub_chain<<<1 + H, 256, (size_t)MultiCholPadded(n) * sizeof(double), st>>>(
+          C, s->red, s->L, s->A, s->W + (size_t)n * n, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, s->chol_ok, s->cam_free,
+          fl + 1, s->tc_hdone, s->tc_ys, fl, s->step_tag);
+      T.End(st);
+    } else if (s->tc_tiles > 0 && bsm >= 1) {
       // block back-substitution on several workgroups (three 32-column blocks each); x goes to row n of W (free by now)
       const int nblk = s->tc_np, G = (nblk + RSBA_BSM_BPG - 1) / RSBA_BSM_BPG;
       int* fl = s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1);   // [error | xdone ...]
