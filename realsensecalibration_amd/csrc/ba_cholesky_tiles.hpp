@@ -399,14 +399,19 @@ k_backsub_multi(int C, const double* __restrict__ red, RedLayout L, const double
 // k_backsub_multi passes the chain from owner to owner: per owner's three blocks a hop (store x, acknowledgement, flag, poll,
 // fetch), three strip updates and three solves, ~11 us — 184 us at 256 cameras.  Here workgroup 0 solves EVERY block, in
 // order, with all of x in its LDS, and never waits for a store: per block it subtracts the nearest strips' blocks itself
-// (L(i, b) x_i for b < i <= top of its column range + RSBA_BSC_LAG: at most five 32 x 32 products, their entries of L prefetched one
-// block ahead, addresses known) and x_b = T_b' y_b; one wavefront publishes x_b while the others go on.  Everything FARTHER
-// above is the helpers' business: helper h owns 96 columns of y and applies the strip of every block i more than RSBA_BSC_LAG above
-// its range as soon as x_i is published (strips prefetched three ahead, as in k_backsub_multi), then hands its slice of y over
-// (ys, hdone) — three blocks before the chain gets there, so the chain finds it waiting.  Same sums per entry in a fixed order:
+// (L(i, b) x_i for b < i <= top of its column range + RSBA_BSC_LAG: at most LAG + 2 products of 32 x 32, their entries of L
+// prefetched one block ahead, addresses known) and x_b = T_b' y_b; one wavefront sends x_b out while the others go on.
+// Everything FARTHER above is the helpers' business: helper h owns 96 columns of y and applies the strip of every block i more
+// than RSBA_BSC_LAG above its range as soon as x_i is published (strips prefetched three ahead, as in k_backsub_multi), then
+// hands its slice of y over (ys, hdone) — LAG + 1 blocks before the chain gets there.  Same sums per entry in a fixed order:
 // bitwise reproducible.
+// What bounds it: the chain's own loads.  One CU pulls ~70 GB/s through its L1, whether the lines sit in its XCD's L2 or not
+// (workgroups that touched the lines ahead of the chain changed nothing), so every near block costs ~0.12 us; with LAG = 3
+// the chain read 40 KB per block and took 117 us, LAG = 2: 110, LAG = 1: 106, LAG = 0 (the helper's hand-over on the chain): 111.
+// The loads must cover whole 128-byte lines per row (32 consecutive columns per half wavefront): with a column's eight row
+// groups in neighbouring lanes — which saves two of the four barriers per block — every line is asked for twice, 164 us.
 // ------------------------------------------------------------------------------------------------
-#define RSBA_BSC_LAG 3
+#define RSBA_BSC_LAG 1
 __global__ void __launch_bounds__(256)
 k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double* __restrict__ F, double* __restrict__ xsol,
                 const double* __restrict__ scale_c, const double* __restrict__ cam_x, double* __restrict__ cam_c,
