@@ -128,6 +128,56 @@ __device__ __forceinline__ bool WaitReady(const int* flag, int tag, long long* w
   return s_wait_ok != 0;
 }
 
+// T = L11^-1 from the padded factor in Lt (32 x 33, upper part zero) and its inverse pivots: the second part of
+// DiagFactorInverse, on its own for callers that hand L11 on first and invert behind the critical path.  One wavefront.
+__device__ __forceinline__ void DiagInverse(double* __restrict__ T, const double* __restrict__ Lt, const double* __restrict__ invd, int lane) {
+  const int lr = lane & 31;
+  // T = L11^-1 in 16 x 16 blocks: T = [[T11, 0], [-T22 L21 T11, T22]].  Lanes 0..15 invert the top-left block and
+  // lanes 16..31 the bottom-right one at the same time (column lr & 15 each, a 16-step chain instead of 32); the
+  // off-diagonal block is two 16x16x16 products on the matrix cores.
+  {
+    const int hb = lr & 16;          // 0: block (0,0), 16: block (1,1)
+    const int lc = lr & 15;          // column inside the block
+    double t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double sacc = (i == lc) ? 1.0 : 0.0, sacc2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (q < i) {
+          // L[hb + i][hb + q] from the tile just written: an LDS read with two distinct addresses per wave (one per
+          // block) instead of two v_readlane pairs and a select; the reads of a step are independent of the chain
+          const double lv = Lt[(hb + i) * RSBA_PLD + hb + q];
+          if (q & 1) sacc2 -= lv * t[q]; else sacc -= lv * t[q];
+        }
+      }
+      t[i] = (sacc + sacc2) * invd[hb + i];
+      asm volatile("" : "+v"(t[i]));
+    }
+    // diagonal blocks into the T tile; M1 scratch = T[0..15][16..31]
+    if (lane < RSBA_PB) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) T[(hb + i) * RSBA_PLD + hb + lc] = t[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int mi = lane & 15, mk = lane >> 4;
+    // M1 = L21 T11:  A[i][k] = L[16+i][k] (Lt), B[k][j] = T11[k][j]
+    d4_t m1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 4) m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[(16 + mi) * RSBA_PLD + ks + mk], T[(ks + mk) * RSBA_PLD + mi], m1, 0, 0, 0);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) T[(mk + 4 * tt) * RSBA_PLD + 16 + mi] = m1[tt];   // M1[row][col] -> scratch quadrant
+    __builtin_amdgcn_wave_barrier();
+    // T21 = -T22 M1:  A[i][k] = T22[i][k] = T[16+i][16+k], B[k][j] = M1[k][j]
+    d4_t t21 = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 4) t21 = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(16 + mi) * RSBA_PLD + 16 + ks + mk], T[(ks + mk) * RSBA_PLD + 16 + mi], t21, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) { T[(16 + mk + 4 * tt) * RSBA_PLD + mi] = -t21[tt]; T[(mk + 4 * tt) * RSBA_PLD + 16 + mi] = 0.0; }
+  }
+}
+
 // Factor the padded 32 x 32 diagonal block held in LDS (rows of `Pan`, stride RSBA_PLD) and invert it.  One wavefront.
 // Out: Pan rows < nb = L11 (upper part zeroed; kWritePan), Lt = padded L11, T = L11^-1 (kInverse), invd = 1/diag.  Returns
 // false on a non-positive pivot (no select sits on the pivot chain: the pivot's 1/sqrt and everything after it are NaN then,
@@ -285,50 +335,7 @@ __device__ __forceinline__ bool DiagFactorInverse(double* __restrict__ Pan, int 
       if (lane == 0) { long long _w1 = clock64(); g_phase_cycles[10] += _w1 - _w0; _w0 = _w1; }
 #endif
       if (!kInverse) return good;
-      // T = L11^-1 in 16 x 16 blocks: T = [[T11, 0], [-T22 L21 T11, T22]].  Lanes 0..15 invert the top-left block and
-      // lanes 16..31 the bottom-right one at the same time (column lr & 15 each, a 16-step chain instead of 32); the
-      // off-diagonal block is two 16x16x16 products on the matrix cores.
-      {
-        const int hb = lr & 16;          // 0: block (0,0), 16: block (1,1)
-        const int lc = lr & 15;          // column inside the block
-        double t[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          double sacc = (i == lc) ? 1.0 : 0.0, sacc2 = 0.0;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            if (q < i) {
-              // L[hb + i][hb + q] from the tile just written: an LDS read with two distinct addresses per wave (one per
-              // block) instead of two v_readlane pairs and a select; the reads of a step are independent of the chain
-              const double lv = Lt[(hb + i) * RSBA_PLD + hb + q];
-              if (q & 1) sacc2 -= lv * t[q]; else sacc -= lv * t[q];
-            }
-          }
-          t[i] = (sacc + sacc2) * invd[hb + i];
-          asm volatile("" : "+v"(t[i]));
-        }
-        // diagonal blocks into the T tile; M1 scratch = T[0..15][16..31]
-        if (lane < RSBA_PB) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) T[(hb + i) * RSBA_PLD + hb + lc] = t[i];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int mi = lane & 15, mk = lane >> 4;
-        // M1 = L21 T11:  A[i][k] = L[16+i][k] (Lt), B[k][j] = T11[k][j]
-        d4_t m1 = {0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < 16; ks += 4) m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[(16 + mi) * RSBA_PLD + ks + mk], T[(ks + mk) * RSBA_PLD + mi], m1, 0, 0, 0);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) T[(mk + 4 * tt) * RSBA_PLD + 16 + mi] = m1[tt];   // M1[row][col] -> scratch quadrant
-        __builtin_amdgcn_wave_barrier();
-        // T21 = -T22 M1:  A[i][k] = T22[i][k] = T[16+i][16+k], B[k][j] = M1[k][j]
-        d4_t t21 = {0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < 16; ks += 4) t21 = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(16 + mi) * RSBA_PLD + 16 + ks + mk], T[(ks + mk) * RSBA_PLD + 16 + mi], t21, 0, 0, 0);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) { T[(16 + mk + 4 * tt) * RSBA_PLD + mi] = -t21[tt]; T[(mk + 4 * tt) * RSBA_PLD + 16 + mi] = 0.0; }
-      }
+      DiagInverse(T, Lt, invd, lane);
 #ifdef RSBA_PROFILE_PHASES
       if (lane == 0) g_phase_cycles[11] += clock64() - _w0;
 #endif
@@ -342,6 +349,56 @@ __device__ __forceinline__ bool DiagFactorInverse(double* __restrict__ Pan, int 
 typedef __attribute__((address_space(3))) double lds_double;
 static __device__ __noinline__ bool DiagFactorInverseCall(lds_double* Pan, int nb, lds_double* T, lds_double* Lt, lds_double* invd, int lane) {
   return DiagFactorInverse<true, true>((double*)Pan, nb, (double*)T, (double*)Lt, (double*)invd, lane);
+}
+// ... the two parts separately (ba_cholesky_tiles.hpp: L11 is handed on before it is inverted)
+static __device__ __noinline__ bool DiagFactorOnlyCall(lds_double* Pan, int nb, lds_double* Tscratch, lds_double* Lt, lds_double* invd, int lane) {
+  return DiagFactorInverse<false, true>((double*)Pan, nb, (double*)Tscratch, (double*)Lt, (double*)invd, lane);
+}
+static __device__ __noinline__ void DiagInverseCall(lds_double* T, const lds_double* Lt, const lds_double* invd, int lane) {
+  DiagInverse((double*)T, (const double*)Lt, (const double*)invd, lane);
+}
+// X = A L^-T by substitution: x_j = a_j / l_jj, then a_c -= x_j l_cj for c > j, 32 steps — with neither the inverse of L (2.1 us on
+// the producer's critical path) nor the matrix cores.  Four lanes per row: lane q of a row keeps its columns c = 4 k + q in
+// eight registers; the lane that owns column j forms x_j, a quad broadcast (DPP) hands it to the row's other lanes, and each
+// applies it to its own later columns — at most eight multiply-adds per step and lane, the multipliers read from LDS a step
+// ahead.  (A row per lane, one wavefront: 496 multiply-adds in a row, 4 us with its call; left to itself the compiler also
+// read every multiplier right before its use, 9 us.)  src: the rows (nrows <= 64, a multiple of 16, `stride` apart) — thread t
+// works on row t >> 2; LtT: L transposed, LtT[j * RSBA_PLD + c] = l_cj for c > j, 1 / l_jj for c == j, 0 for c < j; dst: X, rows
+// RSBA_PLD apart.  The zero multipliers leave a row's finished columns alone, the owner's own column is set by a select.
+template <int K> __device__ __forceinline__ double QuadBroadcast(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), K * 0x55, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), K * 0x55, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void TrsmRowsQuad(const double* src, int stride, const double* LtT, double* dst, int tid, int nrows) {
+  const int row = tid >> 2, q = tid & 3;
+  if (row >= nrows) return;
+  double a[8], l0[8], l1[8], l2[8], l3[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = src[row * stride + 4 * k + q];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { l0[k] = LtT[4 * k + q]; l1[k] = LtT[RSBA_PLD + 4 * k + q]; l2[k] = LtT[2 * RSBA_PLD + 4 * k + q]; }
+  // a step is ~45 cycles, an LDS read ~100: the multipliers of step j + 3 are read in step j
+#define RSBA_TRSM_STEP(J, CUR, NXT)                                                                              \
+  {                                                                                                              \
+    constexpr int kj = (J) >> 2, qj = (J) & 3;                                                                   \
+    if ((J) + 3 < RSBA_PB) {                                                                                     \
+      _Pragma("unroll") for (int k = ((J) + 3) >> 2; k < 8; ++k) NXT[k] = LtT[((J) + 3) * RSBA_PLD + 4 * k + q]; \
+    }                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    const double x = QuadBroadcast<qj>(a[kj] * CUR[kj]);                                                         \
+    const double t = __builtin_fma(-x, CUR[kj], a[kj]);                                                          \
+    a[kj] = (q == qj) ? x : t;                                                                                   \
+    _Pragma("unroll") for (int k = kj + 1; k < 8; ++k) a[k] = __builtin_fma(-x, CUR[k], a[k]);                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+  }
+#define RSBA_TRSM_STEP4(J) RSBA_TRSM_STEP(J, l0, l3) RSBA_TRSM_STEP((J) + 1, l1, l0) RSBA_TRSM_STEP((J) + 2, l2, l1) RSBA_TRSM_STEP((J) + 3, l3, l2)
+  RSBA_TRSM_STEP4(0) RSBA_TRSM_STEP4(4) RSBA_TRSM_STEP4(8) RSBA_TRSM_STEP4(12)
+  RSBA_TRSM_STEP4(16) RSBA_TRSM_STEP4(20) RSBA_TRSM_STEP4(24) RSBA_TRSM_STEP4(28)
+#undef RSBA_TRSM_STEP4
+#undef RSBA_TRSM_STEP
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dst[row * RSBA_PLD + 4 * k + q] = a[k];
 }
 
 // Blocked back-substitution L' x = y with the stored block inverses; y (row n of A) is copied to LDS and holds x on

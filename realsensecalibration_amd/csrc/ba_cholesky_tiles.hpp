@@ -31,56 +31,357 @@ struct TileCholFlags {
   int* xdone;    // [np][nrt]       == tag: X of panel p for tile row I is in F
   int* error;    // != 0: somebody gave up
   int nrt;
-  // The chain from one tile column's last factorisation to the next one's first: the sub-diagonal tile (J + 1, J) hands its
-  // rows' columns of the column's SECOND panel over as soon as they are final (after the first panel's update) — unsolved,
-  // ah[J + 1] (64 x 32), flag adone[J + 1] — and the next diagonal tile forms X = Ahat T' itself the moment T is published,
-  // instead of waiting for the sub-diagonal tile to load T, solve, store X, have the stores acknowledged and raise its flag
-  // (the lesson of ba_cholesky_diag.hpp: a block is handed over unsolved).  nullptr: everybody waits for xdone.
-  int* adone = nullptr;      // [nrt] == tag
-  double* ah = nullptr;      // [nrt][64 * 32]
+  // The chain from one tile column's last factorisation to the next one's first runs through PRIVATE hand-over buffers, one
+  // producer and one consumer each, where the data is its own flag (TakeHandOver): the producer just stores, the consumer's
+  // threads poll their own elements until none is the sentinel.  No wait for the stores' acknowledgements, no flag, no
+  // second trip to memory — a hop of ~1.3 us instead of ~3.  Per tile row / column J (TileHand*):
+  //   T2   the factor of tile column J's second diagonal block (DenseLtT) diagonal tile J      -> diagonal tile J + 1
+  //   S1   ... of its first | the diagonal tile's rows 32..63 of X       diagonal tile J      -> sub-diagonal tile (J + 1, J)
+  //        (the FACTOR, not its inverse: the consumer solves its rows by substitution, TrsmRowsQuad, as fast as the product with
+  //        the inverse on the matrix cores — and the inversion, 2.1 us, leaves the chain: it is done behind the hand-over)
+  //   XH   X of tile row J for the first panel of column J - 1         tile (J, J - 1)      -> diagonal tile J
+  //   AH   tile row J's columns of column J - 1's SECOND panel, final but unsolved (after the first panel's update): the next
+  //        diagonal tile solves X = Ahat L22^-T itself the moment L22 arrives (the lesson of ba_cholesky_diag.hpp)
+  //                                                                    tile (J, J - 1)      -> diagonal tile J
+  // Two sets, used by launch parity: a consumer resets the OTHER set's slots at the start of every launch, a whole launch
+  // before they are written again — also behind a launch that gave up half-way.  Everybody else goes through tdone / xdone.
+  double* hand = nullptr;    // [2][nrt][kTileHandDoubles]
+  int parity = 0;
+  long long* trace = nullptr;   // RSBA_MC_TRACE=1: [nrt][24] stamps of the diagonal tiles' chain (wall clock, 10 ns)
 };
 
-__host__ __device__ inline size_t TileCholLdsDoubles() { return (size_t)64 * RSBA_TL + 64 * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD + 64; }
+constexpr int kTileHandT2 = 0, kTileHandAH = 1024, kTileHandS1 = 3072, kTileHandXH = 5120, kTileHandDoubles = 7168;
 
-// The next diagonal tile's last update (TileCholFlags::adone): the sub-diagonal tile's rows as handed over -> XJ, T of the
-// panel -> T, X = Ahat T' -> XI, with the sub-diagonal tile's own sequence of matrix-core operations on the same operands:
-// the same bits.  Out of line: its own register allocation (inlined, the kernel went from 254 registers to 256 with 32 spilled).
-// Whole workgroup; false: a flag did not come.
-static __device__ __noinline__ bool DiagTileFormsX(const int* adone_flag, const int* tdone_flag, const int* error, int tag, long long budget,
-                                                   const double* __restrict__ ah, const double* __restrict__ F, int n, int kb,
-                                                   double* XJ, double* T, double* XI) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mi = lane & 15, kk = lane >> 4;
-  if (!WaitFlagWG(adone_flag, tag, error, budget)) return false;
-  {
-    double av[8];
+__device__ __forceinline__ double* TileHandSlot(const TileCholFlags& f, int parity, int idx) { return f.hand + ((size_t)parity * f.nrt + idx) * kTileHandDoubles; }
+__device__ __forceinline__ bool HandThere(double v) { return __double_as_longlong(v) != -1LL; }   // the sentinel: all bits set (hipMemset 0xff)
+
+// v[u] = buf[tid + 256 u] once the producer's stores have arrived: every thread polls its own elements (agent-scope loads, the
+// wavefront leaves together).  false: the budget ran out or somebody gave up — the caller's barrier collects it (TakeFailed).
+template <int NV>
+__device__ __forceinline__ bool TakeHandOver(const double* __restrict__ buf, double (&v)[NV], const int* error, long long budget) {
+  const long long t0 = wall_clock64();
+  for (int round = 0;; ++round) {
+    bool all = true;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) av[u] = ah[tid + u * 256];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { const int e = tid + u * 256; XJ[(e >> 5) * RSBA_PLD + (e & 31)] = av[u]; }
+    for (int u = 0; u < NV; ++u) { v[u] = __hip_atomic_load(&buf[threadIdx.x + 256 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); all = all && HandThere(v[u]); }
+    if (__builtin_amdgcn_ballot_w64(!all) == 0) return true;
+    if ((round & 15) == 15 && (wall_clock64() - t0 > budget || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) return false;
+    __builtin_amdgcn_s_sleep(10);
   }
-  if (!WaitFlagWG(tdone_flag, tag, error, budget)) return false;
-  {
-    double tv[4];
+}
+
+// Dense copy of a factored diagonal block for TrsmRowsQuad: e = 32 j + c -> l_cj (c > j) | 1 / l_jj (c == j) | 0
+__device__ __forceinline__ double DenseLtT(const double* Lt, const double* invd, int e) {
+  const int j = e >> 5, c = e & 31;
+  return c > j ? Lt[c * RSBA_PLD + j] : (c == j ? invd[j] : 0.0);
+}
+
+// What the roles of the kernel share.  The diagonal tiles' and the sub-diagonal tiles' steps on the chain are OUT OF LINE
+// (DiagTileColumn, SubDiagFirstHalf): inlined, their registers (the substitution, the hand-overs' values) pushed the kernel to
+// 82 spilled registers, and the trailing update — every tile's bread and butter — reloaded a spilled pointer in front of
+// each of its loads, one trip to memory after the other: 7 us per update instead of 2.5.
+struct TileCtx {
+  int n, m, np, I, J, tag;
+  double* F;
+  int* ok_flag;
+  TileCholFlags f;
+  long long budget;
+};
+struct TileLds {
+  double *Tl, *XI, *T, *Pan, *Lt, *XJ, *invd;
+  int* flags;   // [0] the factorisation's pivots were positive, [1] a hand-over did not come
+};
+__device__ __forceinline__ TileLds TileLdsOf(double* lds) {
+  TileLds L;
+  L.Tl = lds;                              // the tile, 64 x 65
+  L.XI = L.Tl + 64 * RSBA_TL;              // 64 x 33: X of this tile's rows for the current panel
+  L.T = L.XI + 64 * RSBA_PLD;              // 32 x 33
+  L.Pan = L.T + RSBA_PB * RSBA_PLD;        // 32 x 33 (diagonal tiles)   |  together: XJ, 64 x 33 (the others)
+  L.Lt = L.Pan + RSBA_PB * RSBA_PLD;       // 32 x 33 (diagonal tiles)   |
+  L.XJ = L.Pan;
+  L.invd = L.Lt + RSBA_PB * RSBA_PLD;      // 64
+  L.flags = reinterpret_cast<int*>(L.invd + 64);
+  return L;
+}
+__host__ __device__ inline size_t TileCholLdsDoubles() { return (size_t)64 * RSBA_TL + 64 * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD + 64 + 2; }
+
+__device__ __forceinline__ void TileStamp(const TileCholFlags& f, int tile, int k) { if (f.trace != nullptr && threadIdx.x == 0) f.trace[tile * 24 + k] = wall_clock64(); }
+// a value of L / y into F (real entries only; the rhs row m lands in row n)
+__device__ __forceinline__ void TileStoreF(double* __restrict__ F, int n, int m, int gi, int gj, double v) {
+  if (gj >= n) return;
+  if (gi < n) StoreShared(&F[(size_t)gi * n + gj], v);
+  else if (gi == m) StoreShared(&F[(size_t)n * n + gj], v);
+}
+// L entry (gi, gj) of the padded factor (padded columns: identity, nothing below the diagonal).  No branch around the load, and
+// none the compiler could make: a clamped address, the value multiplied by 0 or 1 (a select lets it sink the load into a
+// branch, and then the loads of a strip wait for each other — F[0] is finite, the product exact).
+__device__ __forceinline__ double TileLoadF(const double* __restrict__ F, int n, int m, int gi, int gj) {
+  const bool real = gj < n && (gi < n || gi == m);
+  const size_t idx = real ? (size_t)(gi < n ? gi : n) * n + gj : 0;
+  return F[idx] * (real ? 1.0 : 0.0);
+}
+// T[r][c] (r >= c) of the panel at kb as the diagonal tile left it in F: transposed above the diagonal of its block, the
+// diagonal in row n + 1; identity on the padding
+__device__ __forceinline__ double TileLoadT(const double* __restrict__ F, int n, int kb, int r, int c) {
+  const bool real = kb + r < n && kb + c < n, low = r > c, dia = r == c;
+  const bool use = real && (low || dia);
+  const size_t idx = use ? (low ? (size_t)(kb + c) * n + kb + r : (size_t)(n + 1) * n + kb + c) : 0;
+  return __builtin_fma(F[idx], use ? 1.0 : 0.0, (!real && dia) ? 1.0 : 0.0);
+}
+// tile -= XI XB' (64 x 64, K = 32) and tile[:, 32..63] -= XI XB[32..63]' on the matrix cores; wave w takes rows 16 w .. 16 w + 15
+__device__ __forceinline__ void TileUpdateFull(double* Tl, const double* XI, const double* XB) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, mi = lane & 15, kk = lane >> 4;
+  d4_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  const int row = 16 * wave + mi;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = tid + u * 256, r = e >> 5, c = e & 31;   // T[r][c], r >= c
-      tv[u] = (kb + r < n && kb + c < n) ? (r > c ? F[(size_t)(kb + c) * n + kb + r] : (r == c ? F[(size_t)(n + 1) * n + kb + c] : 0.0))
-                                          : (r == c ? 1.0 : 0.0);
-    }
+  for (int qs = 0; qs < RSBA_PB; qs += 4) {
+    const double a = XI[row * RSBA_PLD + qs + kk];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; T[(e >> 5) * RSBA_PLD + (e & 31)] = tv[u]; }
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, XB[(16 * jb + mi) * RSBA_PLD + qs + kk], acc[jb], 0, 0, 0);
   }
-  __syncthreads();
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) Tl[(16 * wave + kk + 4 * tt) * RSBA_TL + 16 * jb + mi] -= acc[jb][tt];
+}
+__device__ __forceinline__ void TileUpdateHalf(double* Tl, const double* XI, const double* XB) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, mi = lane & 15, kk = lane >> 4;
+  d4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+  const int row = 16 * wave + mi;
+#pragma unroll
+  for (int qs = 0; qs < RSBA_PB; qs += 4) {
+    const double a = XI[row * RSBA_PLD + qs + kk];
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, XB[(32 + mi) * RSBA_PLD + qs + kk], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, XB[(48 + mi) * RSBA_PLD + qs + kk], a1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int r = 16 * wave + kk + 4 * tt;
+    Tl[r * RSBA_TL + 32 + mi] -= a0[tt];
+    Tl[r * RSBA_TL + 48 + mi] -= a1[tt];
+  }
+}
+// X = Rows T' for the rows >= rlo of the tile's columns [lc, lc + 32): into XI (zero above rlo), the tile and F
+__device__ __forceinline__ void TileFormX(double* __restrict__ F, int n, int m, int I, const TileLds& L, int kb, int lc, int rlo) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, mi = lane & 15, kk = lane >> 4;
   d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
   const int row = 16 * wave + mi;
 #pragma unroll
   for (int qs = 0; qs < RSBA_PB; qs += 4) {
-    const double a = XJ[row * RSBA_PLD + qs + kk];
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[mi * RSBA_PLD + qs + kk], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[(16 + mi) * RSBA_PLD + qs + kk], acc1, 0, 0, 0);
+    const double a = L.Tl[row * RSBA_TL + lc + qs + kk];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, L.T[mi * RSBA_PLD + qs + kk], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, L.T[(16 + mi) * RSBA_PLD + qs + kk], acc1, 0, 0, 0);
   }
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) { const int r = 16 * wave + kk + 4 * tt; XI[r * RSBA_PLD + mi] = acc0[tt]; XI[r * RSBA_PLD + 16 + mi] = acc1[tt]; }
+  for (int tt = 0; tt < 4; ++tt) {
+    const int r = 16 * wave + kk + 4 * tt;
+    const bool below = r >= rlo;
+    const double x0 = below ? acc0[tt] : 0.0, x1 = below ? acc1[tt] : 0.0;
+    L.XI[r * RSBA_PLD + mi] = x0; L.XI[r * RSBA_PLD + 16 + mi] = x1;
+    if (below) {
+      L.Tl[r * RSBA_TL + lc + mi] = x0; L.Tl[r * RSBA_TL + lc + 16 + mi] = x1;
+      TileStoreF(F, n, m, 64 * I + r, kb + mi, x0); TileStoreF(F, n, m, 64 * I + r, kb + 16 + mi, x1);
+    }
+  }
+}
+// X (in XI, rows >= rlo) into the tile's columns [lc, lc + 32), into F, and straight to its consumer on the chain
+__device__ __forceinline__ void TileSpreadX(double* __restrict__ F, int n, int m, int I, const TileLds& L, int kb, int lc, int rlo, double* hx) {
+  for (int e = threadIdx.x + 32 * rlo; e < 64 * 32; e += 256) {
+    const int r = e >> 5, cc = e & 31;
+    const double x = L.XI[r * RSBA_PLD + cc];
+    L.Tl[r * RSBA_TL + lc + cc] = x;
+    StoreShared(&hx[e], x);
+    TileStoreF(F, n, m, 64 * I + r, kb + cc, x);
+  }
+}
+
+// ---- The diagonal tile (J, J) from its last-but-one update to the end: the chain.
+//   panel 2J - 2   tile -= X X' with X of its rows straight from the sub-diagonal tile (XH)
+//   panel 2J - 1   the sub-diagonal tile's rows as handed over (AH) and the factor of the panel's diagonal block (T2 slot) ->
+//                  X = Ahat L22^-T by substitution -> tile -= X X'
+//   panel 2J       factor the first block, hand L11 on (S1), solve the own rows 32..63 by substitution, hand them on, update
+//   panel 2J + 1   factor the second block — wavefront 1 inverts the FIRST one meanwhile, stores T and raises the first half's
+//                  flags for everybody off the chain — hand L22 on (T2), invert, store, publish
+// Buffers (32 x 33 each): first half Pan | T (scratch, then L11 transposed for the substitution) | Lt; second half Pan | XI rows
+// 0..31 (scratch, then T) | XI rows 32..63 (Lt), while T = inverse of the first block's Lt.  false: a hand-over did not come.
+static __device__ __noinline__ bool DiagTileColumn(const TileCtx& c) {
+  extern __shared__ double lds[];
+  const TileLds L = TileLdsOf(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = c.n, m = c.m, np = c.np, J = c.J, tag = c.tag;
+  const TileCholFlags f = c.f;   // (copies: the context itself lives in private memory, and a load from there in the middle
+  double* F = c.F;               //  of a run of loads or stores waits for all of them)
+  int* ok_flag = c.ok_flag;
+  const long long budget = c.budget;
+  if (J > 0) {
+    {
+      double v[8];
+      if (!TakeHandOver<8>(TileHandSlot(f, f.parity, J) + kTileHandXH, v, f.error, budget)) L.flags[1] = 1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = tid + u * 256; L.XI[(e >> 5) * RSBA_PLD + (e & 31)] = v[u]; }
+    }
+    __syncthreads();
+    if (L.flags[1]) return false;
+    TileUpdateFull(L.Tl, L.XI, L.XI);
+    __syncthreads();
+    TileStamp(f, J, 0);
+    {
+      double av[8], tv[4];
+      if (!TakeHandOver<8>(TileHandSlot(f, f.parity, J) + kTileHandAH, av, f.error, budget)) L.flags[1] = 1;
+      TileStamp(f, J, 10);
+      if (!TakeHandOver<4>(TileHandSlot(f, f.parity, J - 1) + kTileHandT2, tv, f.error, budget)) L.flags[1] = 1;
+      TileStamp(f, J, 11);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = tid + u * 256; L.XJ[(e >> 5) * RSBA_PLD + (e & 31)] = av[u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; L.T[(e >> 5) * RSBA_PLD + (e & 31)] = tv[u]; }
+    }
+    __syncthreads();
+    if (L.flags[1]) return false;
+    TileStamp(f, J, 12);
+    TrsmRowsQuad(L.XJ, RSBA_PLD, L.T, L.XI, tid, 64);
+    __syncthreads();
+    TileStamp(f, J, 1);
+    TileUpdateFull(L.Tl, L.XI, L.XI);
+    __syncthreads();
+  }
+  const bool two = 2 * J + 1 < np;
+  if (!two) {
+    // the last, one-panel column: factor and invert in one go, publish; X of the rows below (the right-hand side's) as everybody's
+    const int p = 2 * J, kb = p * RSBA_PB;
+    for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) { const int r = e >> 5, cc = e & 31; L.Pan[r * RSBA_PLD + cc] = L.Tl[r * RSBA_TL + cc]; }
+    __syncthreads();
+    if (wave == 0) {
+      const bool good = DiagFactorInverseCall((lds_double*)L.Pan, RSBA_PB, (lds_double*)L.T, (lds_double*)L.Lt, (lds_double*)L.invd, lane);
+      if (lane == 0) L.flags[0] = good ? 1 : 0;
+    }
+    __syncthreads();
+    for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) {
+      const int r = e >> 5, cc = e & 31;
+      if (kb + r < n && kb + cc < n) StoreShared(&F[(size_t)(kb + r) * n + kb + cc], cc > r ? L.T[cc * RSBA_PLD + r] : L.Pan[r * RSBA_PLD + cc]);
+    }
+    if (tid < RSBA_PB && kb + tid < n) StoreShared(&F[(size_t)(n + 1) * n + kb + tid], L.invd[tid]);
+    if (tid == 0 && !L.flags[0]) __hip_atomic_store(ok_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PublishFlagWG(f.tdone + p, tag);
+    TileFormX(F, n, m, J, L, kb, 0, RSBA_PB);
+    PublishFlagWG(f.xdone + (size_t)p * f.nrt + J, tag);
+    return true;
+  }
+  for (int hf = 0; hf < 2; ++hf) {
+    const int p = 2 * J + hf, kb = p * RSBA_PB, lc = 32 * hf;
+    double* Tscr = hf ? L.XI : L.T;
+    double* Ltx = hf ? L.XI + 32 * RSBA_PLD : L.Lt;
+    double* ivx = L.invd + 32 * hf;
+    TileStamp(f, J, hf ? 6 : 2);
+    for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) { const int r = e >> 5, cc = e & 31; L.Pan[r * RSBA_PLD + cc] = L.Tl[(lc + r) * RSBA_TL + lc + cc]; }
+    __syncthreads();
+    if (wave == 0) {
+      const bool good = DiagFactorOnlyCall((lds_double*)L.Pan, RSBA_PB, (lds_double*)Tscr, (lds_double*)Ltx, (lds_double*)ivx, lane);   // (inlined here: slower, 546 vs 520 us)
+      if (lane == 0) L.flags[0] = good ? 1 : 0;
+    } else if (wave == 1 && hf == 1) {
+      // the first block's inverse, its place in F, the first half's flags (every wavefront's stores of L11 and X were
+      // acknowledged before the barrier above)
+      DiagInverseCall((lds_double*)L.T, (const lds_double*)L.Lt, (const lds_double*)L.invd, lane);
+      __builtin_amdgcn_wave_barrier();
+      const int kb1 = kb - RSBA_PB;
+      for (int e = lane; e < RSBA_PB * RSBA_PB; e += 64) {
+        const int r = e >> 5, cc = e & 31;
+        if (cc > r && kb1 + cc < n) StoreShared(&F[(size_t)(kb1 + r) * n + kb1 + cc], L.T[cc * RSBA_PLD + r]);
+      }
+      if (lane < RSBA_PB && kb1 + lane < n) StoreShared(&F[(size_t)(n + 1) * n + kb1 + lane], L.invd[lane]);
+      __builtin_amdgcn_s_waitcnt(0);
+      if (lane == 0) {
+        __hip_atomic_store(f.tdone + p - 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(f.xdone + (size_t)(p - 1) * f.nrt + J, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    TileStamp(f, J, hf ? 7 : 3);
+    {
+      // the factor first, to whoever waits on the chain: the next diagonal tile (second half), the sub-diagonal tile (first)
+      double* hs = TileHandSlot(f, f.parity, J) + (hf ? kTileHandT2 : kTileHandS1);
+      const bool wanted = hf == 1 ? 64 * (J + 1) < m : true;
+      for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) {
+        const double v = DenseLtT(Ltx, ivx, e);
+        if (wanted) StoreShared(&hs[e], v);
+        if (hf == 0) L.T[(e >> 5) * RSBA_PLD + (e & 31)] = v;
+      }
+    }
+    for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) {
+      const int r = e >> 5, cc = e & 31;
+      if (cc <= r && kb + r < n) StoreShared(&F[(size_t)(kb + r) * n + kb + cc], L.Pan[r * RSBA_PLD + cc]);
+    }
+    if (tid == 0 && !L.flags[0]) __hip_atomic_store(ok_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (hf == 1) {
+      // nothing of this tile lies below the block: no X, nobody waits for this tile's xdone; what is left is T for the others
+      if (wave == 0) DiagInverseCall((lds_double*)Tscr, (const lds_double*)Ltx, (const lds_double*)ivx, lane);
+      __syncthreads();
+      for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) {
+        const int r = e >> 5, cc = e & 31;
+        if (cc > r && kb + cc < n) StoreShared(&F[(size_t)(kb + r) * n + kb + cc], Tscr[cc * RSBA_PLD + r]);
+      }
+      if (tid < RSBA_PB && kb + tid < n) StoreShared(&F[(size_t)(n + 1) * n + kb + tid], ivx[tid]);
+      PublishFlagWG(f.tdone + p, tag);
+      TileStamp(f, J, 8);
+      break;
+    }
+    __syncthreads();                                 // L11 transposed is in T
+    TrsmRowsQuad(L.Tl + 32 * RSBA_TL, RSBA_TL, L.T, L.XI + 32 * RSBA_PLD, tid, 32);   // (wavefronts 0 and 1)
+    for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) L.XI[(e >> 5) * RSBA_PLD + (e & 31)] = 0.0;   // rows above the block: no X
+    __syncthreads();
+    TileSpreadX(F, n, m, J, L, kb, 0, 32, TileHandSlot(f, f.parity, J) + kTileHandS1);   // (rows 32..63 land behind L11's 1024)
+    TileStamp(f, J, 4);
+    TileUpdateHalf(L.Tl, L.XI, L.XI);
+    // every wavefront's stores so far are acknowledged behind this barrier: wavefront 1 raises the first half's flags in the second
+    __builtin_amdgcn_s_waitcnt(0);
+    TileStamp(f, J, 5);
+    __syncthreads();
+  }
+  return true;
+}
+
+// ---- The sub-diagonal tile (J + 1, J) in the first half of its column, on the chain: L11 (transposed, with the inverse pivots)
+// straight from the diagonal tile, its 64 rows solved by substitution (L11 comes ~3 us before the diagonal tile's rows of X:
+// the substitution does not wait for them), X on to the next diagonal tile (XH), the update of its columns 32..63, those
+// columns — final but unsolved — on to the next diagonal tile as well (AH); xdone for everybody else at the end.
+static __device__ __noinline__ bool SubDiagFirstHalf(const TileCtx& c) {
+  extern __shared__ double lds[];
+  const TileLds L = TileLdsOf(lds);
+  const int tid = threadIdx.x, n = c.n, m = c.m, I = c.I, J = c.J, p = 2 * c.J, kb = p * RSBA_PB, tag = c.tag;
+  const TileCholFlags f = c.f;
+  double* F = c.F;
+  const long long budget = c.budget;
+  TileStamp(f, I, 16);
+  {
+    double v[4];
+    if (!TakeHandOver<4>(TileHandSlot(f, f.parity, J) + kTileHandS1, v, f.error, budget)) L.flags[1] = 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; L.T[(e >> 5) * RSBA_PLD + (e & 31)] = v[u]; }
+  }
+  __syncthreads();
+  if (L.flags[1]) return false;
+  TileStamp(f, I, 13);
+  TrsmRowsQuad(L.Tl, RSBA_TL, L.T, L.XI, tid, 64);
+  TileStamp(f, I, 14);
+  {
+    double v[4];
+    if (!TakeHandOver<4>(TileHandSlot(f, f.parity, J) + kTileHandS1 + 1024, v, f.error, budget)) L.flags[1] = 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; L.XJ[(32 + (e >> 5)) * RSBA_PLD + (e & 31)] = v[u]; }
+  }
+  __syncthreads();
+  if (L.flags[1]) return false;
+  TileStamp(f, I, 15);
+  TileSpreadX(F, n, m, I, L, kb, 0, 0, TileHandSlot(f, f.parity, I) + kTileHandXH);
+  TileStamp(f, I, 17);
+  TileUpdateHalf(L.Tl, L.XI, L.XJ);
+  TileStamp(f, I, 18);
+  __syncthreads();
+  double* ah = TileHandSlot(f, f.parity, I) + kTileHandAH;
+  for (int e = tid; e < 64 * 32; e += 256) StoreShared(&ah[e], L.Tl[(e >> 5) * RSBA_TL + 32 + (e & 31)]);
+  TileStamp(f, I, 9);
+  PublishFlagWG(f.xdone + (size_t)p * f.nrt + I, tag);
   return true;
 }
 
@@ -89,18 +390,9 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
                         double* __restrict__ F /* (n + 2) x n */, int* __restrict__ ok_flag, TileCholFlags f, int tag,
                         double* __restrict__ res) {
   extern __shared__ double lds[];
-  double* Tl = lds;                              // the tile, 64 x 65
-  double* XI = Tl + 64 * RSBA_TL;                // 64 x 33: X of this tile's rows for the current panel
-  double* T = XI + 64 * RSBA_PLD;                // 32 x 33
-  double* Pan = T + RSBA_PB * RSBA_PLD;          // 32 x 33 (diagonal tiles)   |  together: XJ, 64 x 33 (the others)
-  double* Lt = Pan + RSBA_PB * RSBA_PLD;         // 32 x 33 (diagonal tiles)   |
-  double* XJ = Pan;
-  double* invd = Lt + RSBA_PB * RSBA_PLD;        // 64
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mi = lane & 15, kk = lane >> 4;
+  const TileLds L = TileLdsOf(lds);
+  const int tid = threadIdx.x;
   const int m = (n + RSBA_PB - 1) / RSBA_PB * RSBA_PB, np = m / RSBA_PB;
-  const long long budget = RSBA_STALL_TICKS;
-  __shared__ int s_good;
   // tile (I, J), I >= J, from the linear index
   const int t = blockIdx.x;
   int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -109,6 +401,19 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
   const int J = t - I * (I + 1) / 2;
   const int r0 = 64 * I, c0 = 64 * J;
   if (c0 >= m) return;   // (the tile row of the rhs row reaches one column past the matrix when m is a multiple of 64)
+  if (tid == 0) L.flags[1] = 0;
+  {
+    // the hand-over slots this tile consumes, in the set the NEXT launch uses: back to the sentinel
+    const double sent = __longlong_as_double(-1LL);
+    if (I == J) {
+      double* o = TileHandSlot(f, f.parity ^ 1, I);
+      for (int e = tid; e < 2048; e += 256) { StoreShared(&o[kTileHandAH + e], sent); StoreShared(&o[kTileHandXH + e], sent); }
+      if (J > 0) { double* q = TileHandSlot(f, f.parity ^ 1, J - 1); for (int e = tid; e < 1024; e += 256) StoreShared(&q[kTileHandT2 + e], sent); }
+    } else if (I == J + 1) {
+      double* q = TileHandSlot(f, f.parity ^ 1, J);
+      for (int e = tid; e < 2048; e += 256) StoreShared(&q[kTileHandS1 + e], sent);
+    }
+  }
   // entry (gi, gj) of the padded system; row m is the right-hand side
   auto sysv = [&](int gi, int gj) {
     if (gi > m || gj >= m) return 0.0;
@@ -116,165 +421,94 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
     if (gi >= n || gj >= n) return gi == gj ? 1.0 : 0.0;
     return W[(size_t)gi * n + gj];
   };
-  for (int e = tid; e < 64 * 64; e += 256) { const int r = e >> 6, c = e & 63; Tl[r * RSBA_TL + c] = sysv(r0 + r, c0 + c); }
+  for (int e = tid; e < 64 * 64; e += 256) { const int r = e >> 6, c = e & 63; L.Tl[r * RSBA_TL + c] = sysv(r0 + r, c0 + c); }
   if (t == 0 && tid == 0) { __hip_atomic_store(ok_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 0.0; }   // (a stall, half a second later, sets it)
   __syncthreads();
-  // store a value of L / y into F (real entries only; the rhs row m lands in row n)
-  auto storeF = [&](int gi, int gj, double v) {
-    if (gj >= n) return;
-    if (gi < n) StoreShared(&F[(size_t)gi * n + gj], v);
-    else if (gi == m) StoreShared(&F[(size_t)n * n + gj], v);
-  };
-  auto loadF = [&](int gi, int gj) -> double {   // L entry (gi, gj) of the padded factor, gi > gj's panel
-    if (gj >= n) return 0.0;                     // padded columns: identity, nothing below the diagonal
-    if (gi < n) return F[(size_t)gi * n + gj];
-    if (gi == m) return F[(size_t)n * n + gj];
-    return 0.0;
-  };
+  const TileCtx ctx{n, m, np, I, J, tag, F, ok_flag, f, RSBA_STALL_TICKS};
+  const long long budget = RSBA_STALL_TICKS;
   bool stalled = false;
   const int plast = min(2 * J + 1, np - 1);
   for (int p = 0; p <= plast && !stalled; ++p) {
     const int Jp = p >> 1, hf = p & 1, kb = p * RSBA_PB, lc = 32 * hf;   // lc: the panel's first column inside a tile of column Jp
+    const bool second_follows = hf == 0 && 2 * J + 1 < np;   // this tile column has a second panel and this is its first
+    // (the thread's index, opaque per iteration: otherwise the loads' addresses are computed once in front of the loop, do not fit
+    //  into the registers that survive the calls below, and come back from private memory in the middle of every run of loads)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    if (I == J && p == max(0, 2 * J - 2)) {
+      // the diagonal tile's last steps, out of line
+      stalled = !DiagTileColumn(ctx);
+      break;
+    }
     if (J == Jp) {
-      if (I == J) {
-        // ---- diagonal tile: factor the block at [lc, lc + 32)^2
-        for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) { const int r = e >> 5, c = e & 31; Pan[r * RSBA_PLD + c] = Tl[(lc + r) * RSBA_TL + lc + c]; }
-        __syncthreads();
-        if (wave == 0) {
-          const bool good = DiagFactorInverseCall((lds_double*)Pan, RSBA_PB, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane);
-          if (lane == 0) s_good = good ? 1 : 0;
+      if (I == J + 1 && second_follows) {
+        if (!SubDiagFirstHalf(ctx)) stalled = true;
+        continue;
+      }
+      // ---- column tile: T from the diagonal tile through F, X = Rows T' on the matrix cores
+      if (!WaitFlagWG(f.tdone + p, tag, f.error, budget)) { stalled = true; break; }
+      // first half: the diagonal tile published its rows 32..63 of X together with T (one flag covers both), and this tile's
+      // columns 32..63 need them right after its own X — fetched in the same trip to memory.  (Two straight-line variants: a
+      // uniform branch around some of the loads makes each of them wait for the ones before.)
+      if (second_follows) {
+        double tv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = tid + u * 256, r = e >> 5, c = e & 31;
+          tv[u] = TileLoadT(F, n, kb, r, c);
+          xv[u] = TileLoadF(F, n, m, c0 + 32 + r, kb + c);
         }
-        __syncthreads();
-        for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) {
-          const int r = e >> 5, c = e & 31;
-          if (kb + r < n && kb + c < n) StoreShared(&F[(size_t)(kb + r) * n + kb + c], c > r ? T[c * RSBA_PLD + r] : Pan[r * RSBA_PLD + c]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = tid + u * 256;
+          L.T[(e >> 5) * RSBA_PLD + (e & 31)] = tv[u];
+          L.XJ[(32 + (e >> 5)) * RSBA_PLD + (e & 31)] = xv[u];
         }
-        if (tid < RSBA_PB && kb + tid < n) StoreShared(&F[(size_t)(n + 1) * n + kb + tid], invd[tid]);
-        if (tid == 0 && !s_good) __hip_atomic_store(ok_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // second half: T is what the next tile column waits for — out at once; nothing of this tile lies below the block, so
-        // there is no X to form and nobody waits for this tile's xdone.  First half: the column tiles have the whole second
-        // factorisation's time to pick T up, so it is published together with X below (one wait for the stores' acknowledgements
-        // instead of two on this tile's own chain)
-        if (hf == 1 || 2 * J + 1 >= np) { PublishFlagWG(f.tdone + p, tag); if (hf == 1) continue; }
       } else {
-        if (!WaitFlagWG(f.tdone + p, tag, f.error, budget)) { stalled = true; break; }
-        {
-          double tv[4];
+        double tv[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int e = tid + u * 256, r = e >> 5, c = e & 31;   // T[r][c], r >= c
-            tv[u] = (kb + r < n && kb + c < n) ? (r > c ? F[(size_t)(kb + c) * n + kb + r] : (r == c ? F[(size_t)(n + 1) * n + kb + c] : 0.0))
-                                                : (r == c ? 1.0 : 0.0);
-          }
+        for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; tv[u] = TileLoadT(F, n, kb, e >> 5, e & 31); }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; T[(e >> 5) * RSBA_PLD + (e & 31)] = tv[u]; }
-        }
-        __syncthreads();
+        for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; L.T[(e >> 5) * RSBA_PLD + (e & 31)] = tv[u]; }
       }
-      // ---- X = Rows T' for this tile's rows below the diagonal block: wave w takes rows 16 w .. 16 w + 15
-      {
-        const int rlo = (I == J) ? lc + RSBA_PB : 0;     // first tile row that is below the diagonal block
-        d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-        const int row = 16 * wave + mi;
-#pragma unroll
-        for (int qs = 0; qs < RSBA_PB; qs += 4) {
-          const double a = Tl[row * RSBA_TL + lc + qs + kk];
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[mi * RSBA_PLD + qs + kk], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[(16 + mi) * RSBA_PLD + qs + kk], acc1, 0, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          const int r = 16 * wave + kk + 4 * tt;
-          const bool below = r >= rlo;
-          const double x0 = below ? acc0[tt] : 0.0, x1 = below ? acc1[tt] : 0.0;
-          XI[r * RSBA_PLD + mi] = x0; XI[r * RSBA_PLD + 16 + mi] = x1;
-          if (below) {
-            Tl[r * RSBA_TL + lc + mi] = x0; Tl[r * RSBA_TL + lc + 16 + mi] = x1;
-            storeF(r0 + r, kb + mi, x0); storeF(r0 + r, kb + 16 + mi, x1);
-          }
-        }
-      }
-      if (I == J && hf == 0 && 2 * J + 1 < np) {
-        // (T and X of the first half together)
-        __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      TileFormX(F, n, m, I, L, kb, lc, 0);
+      PublishFlagWG(f.xdone + (size_t)p * f.nrt + I, tag);
+      // ---- first half done: this tile's columns 32..63 take -X_I X_Jp[rows 32..63]'  (the barrier in PublishFlagWG: XI complete)
+      if (second_follows) {
+        TileUpdateHalf(L.Tl, L.XI, L.XJ);
         __syncthreads();
-        if (tid == 0) { __hip_atomic_store(f.tdone + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(f.xdone + (size_t)p * f.nrt + I, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-      } else {
-        PublishFlagWG(f.xdone + (size_t)p * f.nrt + I, tag);
-      }
-      // ---- first half done: this tile's columns 32..63 take -X_I X_Jp[rows 32..63]'
-      if (hf == 0 && 2 * J + 1 < np) {
-        if (I != J) {
-          if (!WaitFlagWG(f.xdone + (size_t)p * f.nrt + J, tag, f.error, budget)) { stalled = true; break; }
-          double xv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { const int e = tid + u * 256, r = 32 + (e >> 5), c = e & 31; xv[u] = loadF(c0 + r, kb + c); }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; XJ[(32 + (e >> 5)) * RSBA_PLD + (e & 31)] = xv[u]; }
-          __syncthreads();
-        }
-        const double* XB = (I == J) ? XI : XJ;
-        d4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-        const int row = 16 * wave + mi;
-#pragma unroll
-        for (int qs = 0; qs < RSBA_PB; qs += 4) {
-          const double a = XI[row * RSBA_PLD + qs + kk];
-          a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, XB[(32 + mi) * RSBA_PLD + qs + kk], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, XB[(48 + mi) * RSBA_PLD + qs + kk], a1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          const int r = 16 * wave + kk + 4 * tt;
-          Tl[r * RSBA_TL + 32 + mi] -= a0[tt];
-          Tl[r * RSBA_TL + 48 + mi] -= a1[tt];
-        }
-        __syncthreads();
-        if (f.adone != nullptr && I == J + 1) {
-          // the sub-diagonal tile: its rows' columns of the second panel are final — hand them over unsolved
-          double* ah = f.ah + (size_t)I * 64 * 32;
-          for (int e = tid; e < 64 * 32; e += 256) StoreShared(&ah[e], Tl[(e >> 5) * RSBA_TL + 32 + (e & 31)]);
-          PublishFlagWG(f.adone + I, tag);
-        }
       }
     } else {
       // ---- trailing tile: tile -= X_I X_J'
-      const bool own_x = f.adone != nullptr && I == J && Jp == J - 1 && hf == 1;   // the diagonal tile's last update: it forms X itself
-      if (own_x) {
-        if (!DiagTileFormsX(f.adone + I, f.tdone + p, f.error, tag, budget, f.ah + (size_t)I * 64 * 32, F, n, kb, XJ, T, XI)) { stalled = true; break; }
-      } else {
+      const bool sdt = I == J + 1 && Jp == J - 1;   // (trace: the sub-diagonal tile's last two updates)
+      if (sdt) TileStamp(f, I, hf ? 21 : 19);
       if (!WaitFlagWG(f.xdone + (size_t)p * f.nrt + I, tag, f.error, budget)) { stalled = true; break; }
       if (I != J && !WaitFlagWG(f.xdone + (size_t)p * f.nrt + J, tag, f.error, budget)) { stalled = true; break; }
-      {
+      if (sdt) TileStamp(f, I, hf ? 23 : 20);
+      if (I != J) {
         double xi[8], xj[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int e = tid + u * 256, r = e >> 5, c = e & 31;
-          xi[u] = loadF(r0 + r, kb + c);
-          xj[u] = I != J ? loadF(c0 + r, kb + c) : 0.0;
+          xi[u] = TileLoadF(F, n, m, r0 + r, kb + c);
+          xj[u] = TileLoadF(F, n, m, c0 + r, kb + c);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int e = tid + u * 256, r = e >> 5, c = e & 31;
-          XI[r * RSBA_PLD + c] = xi[u];
-          if (I != J) XJ[r * RSBA_PLD + c] = xj[u];
+          L.XI[r * RSBA_PLD + c] = xi[u];
+          L.XJ[r * RSBA_PLD + c] = xj[u];
         }
-      }
+      } else {
+        double xi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = tid + u * 256; xi[u] = TileLoadF(F, n, m, r0 + (e >> 5), kb + (e & 31)); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = tid + u * 256; L.XI[(e >> 5) * RSBA_PLD + (e & 31)] = xi[u]; }
       }
       __syncthreads();
-      const double* XB = (I == J) ? XI : XJ;
-      d4_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-      const int row = 16 * wave + mi;
-#pragma unroll
-      for (int qs = 0; qs < RSBA_PB; qs += 4) {
-        const double a = XI[row * RSBA_PLD + qs + kk];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, XB[(16 * jb + mi) * RSBA_PLD + qs + kk], acc[jb], 0, 0, 0);
-      }
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) Tl[(16 * wave + kk + 4 * tt) * RSBA_TL + 16 * jb + mi] -= acc[jb][tt];
+      TileUpdateFull(L.Tl, L.XI, (I == J) ? L.XI : L.XJ);
       __syncthreads();
     }
   }
