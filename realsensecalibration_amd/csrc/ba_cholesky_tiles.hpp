@@ -19,6 +19,8 @@
 // All tiles must be resident at once (two workgroups per CU): the host checks the tile count and falls back to the
 // multi-launch path otherwise; every wait has the budget of WaitReady and gives up instead of hanging.
 #pragma once
+#include <algorithm>
+#include <vector>
 #include "ba_cholesky_large.hpp"
 #include "ba_cholesky_multi.hpp"
 
@@ -47,6 +49,7 @@ struct TileCholFlags {
   // before they are written again — also behind a launch that gave up half-way.  Everybody else goes through tdone / xdone.
   double* hand = nullptr;    // [2][nrt][kTileHandDoubles]
   int parity = 0;
+  const int* tile_map = nullptr;   // [tiles] I << 8 | J of the workgroup with that index (TileOrder); nullptr: row by row
   long long* trace = nullptr;   // RSBA_MC_TRACE=1: [nrt][24] stamps of the diagonal tiles' chain (wall clock, 10 ns)
 };
 
@@ -104,6 +107,33 @@ __device__ __forceinline__ TileLds TileLdsOf(double* lds) {
   return L;
 }
 __host__ __device__ inline size_t TileCholLdsDoubles() { return (size_t)64 * RSBA_TL + 64 * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD + 64 + 2; }
+
+// Which tile the workgroup with index t works on.  With more tiles than CUs, the workgroups t and t + (number of CUs) end up
+// on the same CU (measured: RSBA_MC_TRACE=1 lists the pairs), and a diagonal tile that shares its CU with a tile busy
+// updating takes ~6 us longer per tile column: row by row, the first eleven diagonal tiles of 256 cameras were paired with
+// tiles of the last three tile rows, busy from the first panel to the last.  So: the first `extra` indices go to tiles that
+// retire early and are off the chain (I >= J + 2 of the first tile columns), their partners at the end of the launch are the
+// tiles of the LAST tile columns (idle until late), everybody else — every early diagonal and sub-diagonal tile — has a CU alone.
+inline std::vector<int> TileOrder(int nrt, int num_cus) {
+  const int ntiles = nrt * (nrt + 1) / 2, extra = std::max(0, std::min(ntiles - num_cus, ntiles / 2));
+  std::vector<int> order;
+  order.reserve(ntiles);
+  if (extra == 0 || nrt > 255) {
+    for (int I = 0; I < nrt; ++I) for (int J = 0; J <= I; ++J) order.push_back(I << 8 | J);
+    return order;
+  }
+  std::vector<char> taken((size_t)nrt * nrt, 0);
+  std::vector<int> first, last;
+  for (int J = 0; J < nrt && (int)first.size() < extra; ++J)
+    for (int I = J + 2; I < nrt && (int)first.size() < extra; ++I) { first.push_back(I << 8 | J); taken[(size_t)I * nrt + J] = 1; }
+  for (int J = nrt - 1; J >= 0 && (int)last.size() < (int)first.size(); --J)
+    for (int I = nrt - 1; I >= J && (int)last.size() < (int)first.size(); --I)
+      if (!taken[(size_t)I * nrt + J]) { last.push_back(I << 8 | J); taken[(size_t)I * nrt + J] = 1; }
+  order = first;
+  for (int I = 0; I < nrt; ++I) for (int J = 0; J <= I; ++J) if (!taken[(size_t)I * nrt + J]) order.push_back(I << 8 | J);
+  order.insert(order.end(), last.begin(), last.end());
+  return order;
+}
 
 __device__ __forceinline__ void TileStamp(const TileCholFlags& f, int tile, int k) { if (f.trace != nullptr && threadIdx.x == 0) f.trace[tile * 24 + k] = wall_clock64(); }
 // a value of L / y into F (real entries only; the rhs row m lands in row n)
@@ -395,13 +425,26 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
   const int m = (n + RSBA_PB - 1) / RSBA_PB * RSBA_PB, np = m / RSBA_PB;
   // tile (I, J), I >= J, from the linear index
   const int t = blockIdx.x;
-  int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-  while (I * (I + 1) / 2 > t) --I;
-  while ((I + 1) * (I + 2) / 2 <= t) ++I;
-  const int J = t - I * (I + 1) / 2;
+  int I, J;
+  if (f.tile_map != nullptr) {
+    const int code = f.tile_map[t];
+    I = code >> 8; J = code & 255;
+  } else {
+    I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (I * (I + 1) / 2 > t) --I;
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    J = t - I * (I + 1) / 2;
+  }
   const int r0 = 64 * I, c0 = 64 * J;
   if (c0 >= m) return;   // (the tile row of the rhs row reaches one column past the matrix when m is a multiple of 64)
   if (tid == 0) L.flags[1] = 0;
+  if (f.trace != nullptr && tid == 0) {
+    // (trace: where this tile runs — XCC | SE | CU — behind the diagonal tiles' stamps)
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    f.trace[(size_t)(f.nrt + 1) * 24 + t] = ((long long)(xcc & 0xf) << 32) | hw;
+  }
   {
     // the hand-over slots this tile consumes, in the set the NEXT launch uses: back to the sentinel
     const double sent = __longlong_as_double(-1LL);
@@ -422,7 +465,7 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
     return W[(size_t)gi * n + gj];
   };
   for (int e = tid; e < 64 * 64; e += 256) { const int r = e >> 6, c = e & 63; L.Tl[r * RSBA_TL + c] = sysv(r0 + r, c0 + c); }
-  if (t == 0 && tid == 0) { __hip_atomic_store(ok_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 0.0; }   // (a stall, half a second later, sets it)
+  if (I == 0 && J == 0 && tid == 0) { __hip_atomic_store(ok_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 0.0; }   // (a stall, half a second later, sets it)
   __syncthreads();
   const TileCtx ctx{n, m, np, I, J, tag, F, ok_flag, f, RSBA_STALL_TICKS};
   const long long budget = RSBA_STALL_TICKS;

@@ -636,13 +636,14 @@ struct MarkerSchurDevice {
   int cur = 0;
   int* tc_flags = nullptr;   // persistent tiled factorisation of a large reduced system (ba_cholesky_tiles.hpp)
   double* tc_hand = nullptr; // ... its diagonal chain's hand-over buffers
+  int* tc_map = nullptr;     // ... which tile each workgroup takes (TileOrder)
   int tc_np = 0, tc_nrt = 0, tc_tiles = 0, tc_tag = 0;
   size_t lds_elim = 0;
   bool lds_s = false;   // the chunk sums of S live in LDS
 
   void Free() {
     void* ptrs[] = {mo, ts, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ok_flag, obs8, intr, params[0], params[1],
-                    params0, posec, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res, tc_flags, tc_hand};
+                    params0, posec, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res, tc_flags, tc_hand, tc_map};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     mo = nullptr; ts = nullptr;
   }
@@ -800,6 +801,10 @@ struct MarkerSchurDevice {
           const size_t nflags = (size_t)tc_np * (nrt + 1) + 1;
           if (!al((void**)&tc_flags, nflags * sizeof(int)) || hipMemset(tc_flags, 0, nflags * sizeof(int)) != hipSuccess) return RSBA_ERR_HIP;
           const size_t hand_bytes = (size_t)2 * nrt * kTileHandDoubles * sizeof(double);   // the diagonal chain's hand-overs: the sentinel everywhere
+          {
+            const std::vector<int> order = TileOrder(nrt, prop.multiProcessorCount);
+            if (!al((void**)&tc_map, order.size() * sizeof(int)) || hipMemcpy(tc_map, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return RSBA_ERR_HIP;
+          }
           if (!al((void**)&tc_hand, hand_bytes) || hipMemset(tc_hand, 0xff, hand_bytes) != hipSuccess) return RSBA_ERR_HIP;
           if (hipFuncSetAttribute((const void*)k_chol_tiles_persistent, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(TileCholLdsDoubles() * sizeof(double))) != hipSuccess) return RSBA_ERR_HIP;
@@ -854,7 +859,7 @@ struct MarkerSchurDevice {
       if (tc_tiles > 0) {
         Tm.Begin("k_chol_tiles_persistent", st);
         k_chol_tiles_persistent<<<tc_tiles, 256, TileCholLdsDoubles() * sizeof(double), st>>>(
-            nr, Wm, A, ok_flag, TileCholFlags{tc_flags, tc_flags + tc_np, tc_flags + (size_t)tc_np * (tc_nrt + 1), tc_nrt, tc_hand, tc_tag & 1}, tc_tag + 1, res);
+            nr, Wm, A, ok_flag, TileCholFlags{tc_flags, tc_flags + tc_np, tc_flags + (size_t)tc_np * (tc_nrt + 1), tc_nrt, tc_hand, tc_tag & 1, tc_map}, tc_tag + 1, res);
         ++tc_tag;
         Tm.End(st);
       } else {

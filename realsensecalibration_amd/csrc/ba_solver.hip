@@ -182,6 +182,7 @@ struct rsba_solver {
   bool chol_diag = false;    // ... with the diagonal chain in workgroup 0 (ba_cholesky_diag.hpp; RSBA_CHOL_DIAG=0: blocks dealt round-robin, ba_cholesky_multi.hpp)
   int* mc_flags = nullptr;   // tdone[16] | strip_ready[16] | wg_done[8] | error
   int* tc_flags = nullptr;   // persistent tiled factorisation (more than 64 cameras): tdone[np] | xdone[np][nrt] | error
+  int* tc_map = nullptr;     // ... which tile each of its workgroups takes (TileOrder)
   double* tc_hand = nullptr; // ... and the private hand-over buffers of its diagonal chain (TileCholFlags::hand), two sets
   int tc_launches = 0;       //     used by launch parity
   int* tc_hdone = nullptr;   // k_backsub_chain: the helpers' slices of y (flag, 96 doubles each)
@@ -723,7 +724,7 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_hand, s->tc_hdone, s->tc_ys};
+                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_map, s->tc_hand, s->tc_hdone, s->tc_ys};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
@@ -1036,9 +1037,17 @@ static int UploadPoints(rsba_solver* s) {
           const size_t nflags = (size_t)s->tc_np * (nrt + 2) + 1;   // tdone | xdone | error | xdone of the back-substitution
           if ((rc = DevAlloc(&s->tc_flags, nflags))) return rc;
           HIPCHK(hipMemset(s->tc_flags, 0, nflags * sizeof(int)));
+          {
+            const char* e3 = getenv("RSBA_TILE_ORDER");   // 0: row by row (the pairing of tiles on shared CUs left to chance)
+            if (!(e3 && atoi(e3) == 0)) {
+              const std::vector<int> order = TileOrder(nrt, prop.multiProcessorCount);
+              if ((rc = DevAlloc(&s->tc_map, order.size()))) return rc;
+              HIPCHK(hipMemcpy(s->tc_map, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+            }
+          }
           if ((rc = DevAlloc(&s->tc_hand, (size_t)2 * nrt * kTileHandDoubles))) return rc;
           HIPCHK(hipMemset(s->tc_hand, 0xff, (size_t)2 * nrt * kTileHandDoubles * sizeof(double)));   // the sentinel everywhere
-          if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, (size_t)(nrt + 1) * 24))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, (size_t)(nrt + 1) * 24 * sizeof(long long))); }
+          if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, (size_t)(nrt + 1) * 24 + ntiles))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, ((size_t)(nrt + 1) * 24 + ntiles) * sizeof(long long))); }
           {
             const int H = (s->tc_np + 2) / 3;
             if ((rc = DevAlloc(&s->tc_hdone, (size_t)H)) || (rc = DevAlloc(&s->tc_ys, (size_t)H * 96))) return rc;
@@ -1389,7 +1398,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (s->tc_tiles > 0) {
       T.Begin("k_chol_tiles_persistent", st);
       k_chol_tiles_persistent<<<s->tc_tiles, 256, TileCholLdsDoubles() * sizeof(double), st>>>(
-          n, s->W, s->A, s->chol_ok, TileCholFlags{s->tc_flags, s->tc_flags + s->tc_np, s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1), s->tc_nrt, s->tc_hand, s->tc_launches++ & 1, s->mc_trace},
+          n, s->W, s->A, s->chol_ok, TileCholFlags{s->tc_flags, s->tc_flags + s->tc_np, s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1), s->tc_nrt, s->tc_hand, s->tc_launches++ & 1, s->tc_map, s->mc_trace},
           s->step_tag, s->res);
       T.End(st);
     } else {
@@ -2070,7 +2079,7 @@ void rsba_solver_destroy(rsba_solver* s) {
     // diagnostic: the diagonal tiles' chain of the latest persistent tiled factorisation, microseconds since its first stamp.
     // 0 last update entered | 10 sub-diagonal rows there | 11 T there | 12 T in LDS | 1 X formed | 2 update done, first half |
     // 3 factored | 4 T, X published | 5 own update | 6 second half | 7 factored | 8 T published | 9 (sub-diagonal tile) rows handed over
-    std::vector<long long> h((size_t)(s->tc_nrt + 1) * 24);
+    std::vector<long long> h((size_t)(s->tc_nrt + 1) * 24 + s->tc_tiles);
     if (hipMemcpy(h.data(), s->mc_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
       long long t0 = 0; for (long long v : h) if (v && (!t0 || v < t0)) t0 = v;
       static const int order[24] = {19, 20, 21, 22, 23, 16, 13, 14, 15, 17, 18, 9, 0, 10, 11, 12, 1, 2, 3, 4, 5, 6, 7, 8};   // 13..15: the sub-diagonal tile of this row: L11 there, solved, X rows there
@@ -2079,6 +2088,19 @@ void rsba_solver_destroy(rsba_solver* s) {
         for (int k : order) { const long long v = h[(size_t)J * 24 + k]; fprintf(stderr, " %7.2f", v ? (v - t0) / 100.0 : -1.0); }
         fprintf(stderr, "\n");
       }
+      // which tiles share a CU (HW_ID: cu_id bits 11:8, sh_id 12, se_id 15:13 on gfx9; XCC_ID)
+      std::map<long long, std::vector<int>> where;
+      std::vector<int> tiles_of = TileOrder(s->tc_nrt, s->tc_map ? DeviceCUs() : 1 << 30);
+      for (int t = 0; t < s->tc_tiles; ++t) {
+        const long long v = h[(size_t)(s->tc_nrt + 1) * 24 + t];
+        if (v) where[((v >> 32) << 16) | ((v >> 8) & 0xff)].push_back(t);
+      }
+      for (const auto& kv : where) if (kv.second.size() > 1) {
+        fprintf(stderr, "rsba[tc] cu %llx:", (unsigned long long)kv.first);
+        for (int t : kv.second) fprintf(stderr, " (%d,%d)", tiles_of[t] >> 8, tiles_of[t] & 255);
+        fprintf(stderr, "\n");
+      }
+      fprintf(stderr, "rsba[tc] %zu CUs hold the %d tiles\n", where.size(), s->tc_tiles);
     }
     (void)hipFree(s->mc_trace);
   } else if (s && s->mc_trace) {
