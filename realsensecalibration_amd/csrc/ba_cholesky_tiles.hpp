@@ -73,6 +73,25 @@ __device__ __forceinline__ bool TakeHandOver(const double* __restrict__ buf, dou
   }
 }
 
+// WaitFlagWG without its acquire fences: this kernel reads what other workgroups wrote with agent-scope loads (TileLoadF, TileLoadT,
+// TakeHandOver), element by element past the caches that could hold an old copy.  The fence (buffer_inv sc1) throws away
+// the XCD's whole L2 — 300 workgroups at two waits per panel kept every L2 of the chip empty, also for the workgroups on the
+// chain (their instruction fetches, their saved registers).
+__device__ __forceinline__ bool WaitFlagPlainWG(const int* flag, int tag, const int* error, long long budget) {
+  __shared__ int s_ok3;
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > budget) { ok = 0; break; }
+    }
+    s_ok3 = ok;
+  }
+  __syncthreads();
+  return s_ok3 != 0;
+}
+
 // Dense copy of a factored diagonal block for TrsmRowsQuad: e = 32 j + c -> l_cj (c > j) | 1 / l_jj (c == j) | 0
 __device__ __forceinline__ double DenseLtT(const double* Lt, const double* invd, int e) {
   const int j = e >> 5, c = e & 31;
@@ -148,7 +167,7 @@ __device__ __forceinline__ void TileStoreF(double* __restrict__ F, int n, int m,
 __device__ __forceinline__ double TileLoadF(const double* __restrict__ F, int n, int m, int gi, int gj) {
   const bool real = gj < n && (gi < n || gi == m);
   const size_t idx = real ? (size_t)(gi < n ? gi : n) * n + gj : 0;
-  return F[idx] * (real ? 1.0 : 0.0);
+  return __hip_atomic_load(&F[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (real ? 1.0 : 0.0);
 }
 // T[r][c] (r >= c) of the panel at kb as the diagonal tile left it in F: transposed above the diagonal of its block, the
 // diagonal in row n + 1; identity on the padding
@@ -156,7 +175,7 @@ __device__ __forceinline__ double TileLoadT(const double* __restrict__ F, int n,
   const bool real = kb + r < n && kb + c < n, low = r > c, dia = r == c;
   const bool use = real && (low || dia);
   const size_t idx = use ? (low ? (size_t)(kb + c) * n + kb + r : (size_t)(n + 1) * n + kb + c) : 0;
-  return __builtin_fma(F[idx], use ? 1.0 : 0.0, (!real && dia) ? 1.0 : 0.0);
+  return __builtin_fma(__hip_atomic_load(&F[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), use ? 1.0 : 0.0, (!real && dia) ? 1.0 : 0.0);
 }
 // tile -= XI XB' (64 x 64, K = 32) and tile[:, 32..63] -= XI XB[32..63]' on the matrix cores; wave w takes rows 16 w .. 16 w + 15
 __device__ __forceinline__ void TileUpdateFull(double* Tl, const double* XI, const double* XB) {
@@ -489,7 +508,7 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
         continue;
       }
       // ---- column tile: T from the diagonal tile through F, X = Rows T' on the matrix cores
-      if (!WaitFlagWG(f.tdone + p, tag, f.error, budget)) { stalled = true; break; }
+      if (!WaitFlagPlainWG(f.tdone + p, tag, f.error, budget)) { stalled = true; break; }
       // first half: the diagonal tile published its rows 32..63 of X together with T (one flag covers both), and this tile's
       // columns 32..63 need them right after its own X — fetched in the same trip to memory.  (Two straight-line variants: a
       // uniform branch around some of the loads makes each of them wait for the ones before.)
@@ -526,8 +545,8 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
       // ---- trailing tile: tile -= X_I X_J'
       const bool sdt = I == J + 1 && Jp == J - 1;   // (trace: the sub-diagonal tile's last two updates)
       if (sdt) TileStamp(f, I, hf ? 21 : 19);
-      if (!WaitFlagWG(f.xdone + (size_t)p * f.nrt + I, tag, f.error, budget)) { stalled = true; break; }
-      if (I != J && !WaitFlagWG(f.xdone + (size_t)p * f.nrt + J, tag, f.error, budget)) { stalled = true; break; }
+      if (!WaitFlagPlainWG(f.xdone + (size_t)p * f.nrt + I, tag, f.error, budget)) { stalled = true; break; }
+      if (I != J && !WaitFlagPlainWG(f.xdone + (size_t)p * f.nrt + J, tag, f.error, budget)) { stalled = true; break; }
       if (sdt) TileStamp(f, I, hf ? 23 : 20);
       if (I != J) {
         double xi[8], xj[8];
