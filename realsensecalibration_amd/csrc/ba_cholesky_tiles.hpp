@@ -69,7 +69,7 @@ __device__ __forceinline__ bool TakeHandOver(const double* __restrict__ buf, dou
     for (int u = 0; u < NV; ++u) { v[u] = __hip_atomic_load(&buf[threadIdx.x + 256 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); all = all && HandThere(v[u]); }
     if (__builtin_amdgcn_ballot_w64(!all) == 0) return true;
     if ((round & 15) == 15 && (wall_clock64() - t0 > budget || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) return false;
-    __builtin_amdgcn_s_sleep(10);
+    __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -111,7 +111,7 @@ struct TileCtx {
 };
 struct TileLds {
   double *Tl, *XI, *T, *Pan, *Lt, *XJ, *invd;
-  int* flags;   // [0] the factorisation's pivots were positive, [1] a hand-over did not come
+  int* flags;   // [0] the factorisation's pivots were positive, [1] a hand-over did not come, [2] wavefronts whose late stores of X are acknowledged
 };
 __device__ __forceinline__ TileLds TileLdsOf(double* lds) {
   TileLds L;
@@ -125,7 +125,7 @@ __device__ __forceinline__ TileLds TileLdsOf(double* lds) {
   L.flags = reinterpret_cast<int*>(L.invd + 64);
   return L;
 }
-__host__ __device__ inline size_t TileCholLdsDoubles() { return (size_t)64 * RSBA_TL + 64 * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD + 64 + 2; }
+__host__ __device__ inline size_t TileCholLdsDoubles() { return (size_t)64 * RSBA_TL + 64 * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD + 64 + 2; }   // (+ 2: four ints of flags)
 
 // Which tile the workgroup with index t works on.  With more tiles than CUs, the workgroups t and t + (number of CUs) end up
 // on the same CU (measured: RSBA_MC_TRACE=1 lists the pairs), and a diagonal tile that shares its CU with a tile busy
@@ -317,6 +317,7 @@ static __device__ __noinline__ bool DiagTileColumn(const TileCtx& c) {
     PublishFlagWG(f.xdone + (size_t)p * f.nrt + J, tag);
     return true;
   }
+  double xr[8];   // (wavefronts 2 and 3: X of the first half, on its way out while wavefront 0 factors the second block)
   for (int hf = 0; hf < 2; ++hf) {
     const int p = 2 * J + hf, kb = p * RSBA_PB, lc = 32 * hf;
     double* Tscr = hf ? L.XI : L.T;
@@ -341,9 +342,24 @@ static __device__ __noinline__ bool DiagTileColumn(const TileCtx& c) {
       if (lane < RSBA_PB && kb1 + lane < n) StoreShared(&F[(size_t)(n + 1) * n + kb1 + lane], L.invd[lane]);
       __builtin_amdgcn_s_waitcnt(0);
       if (lane == 0) {
+        // (X of the rows 32..63 went out behind the barrier, from wavefronts 2 and 3: the inversion above takes longer than their
+        // stores, this wait is a formality)
+        while (__hip_atomic_load(&L.flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 2) __builtin_amdgcn_s_sleep(1);
         __hip_atomic_store(f.tdone + p - 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(f.xdone + (size_t)(p - 1) * f.nrt + J, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+    } else if (wave >= 2 && hf == 1) {
+      // X of the first half: to the sub-diagonal tile (behind L11's 1024 in S1) and into F
+      double* hx = TileHandSlot(f, f.parity, J) + kTileHandS1;
+      const int kb1 = kb - RSBA_PB;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = 1024 + (tid - 128) + 128 * u, r = e >> 5, cc = e & 31;
+        StoreShared(&hx[e], xr[u]);
+        TileStoreF(F, n, m, 64 * J + r, kb1 + cc, xr[u]);
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      if (lane == 0) __hip_atomic_fetch_add(&L.flags[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     TileStamp(f, J, hf ? 7 : 3);
@@ -378,8 +394,13 @@ static __device__ __noinline__ bool DiagTileColumn(const TileCtx& c) {
     __syncthreads();                                 // L11 transposed is in T
     TrsmRowsQuad(L.Tl + 32 * RSBA_TL, RSBA_TL, L.T, L.XI + 32 * RSBA_PLD, tid, 32);   // (wavefronts 0 and 1)
     for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) L.XI[(e >> 5) * RSBA_PLD + (e & 31)] = 0.0;   // rows above the block: no X
+    if (tid == 0) L.flags[2] = 0;
     __syncthreads();
-    TileSpreadX(F, n, m, J, L, kb, 0, 32, TileHandSlot(f, f.parity, J) + kTileHandS1);   // (rows 32..63 land behind L11's 1024)
+    // X (XI rows 32..63) leaves from registers of the wavefronts 2 and 3 in the second half: nothing waits for its stores here
+    if (wave >= 2) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = 1024 + (tid - 128) + 128 * u; xr[u] = L.XI[(e >> 5) * RSBA_PLD + (e & 31)]; }
+    }
     TileStamp(f, J, 4);
     TileUpdateHalf(L.Tl, L.XI, L.XI);
     // every wavefront's stores so far are acknowledged behind this barrier: wavefront 1 raises the first half's flags in the second

@@ -2081,7 +2081,10 @@ void rsba_solver_destroy(rsba_solver* s) {
     // 3 factored | 4 T, X published | 5 own update | 6 second half | 7 factored | 8 T published | 9 (sub-diagonal tile) rows handed over
     std::vector<long long> h((size_t)(s->tc_nrt + 1) * 24 + s->tc_tiles);
     if (hipMemcpy(h.data(), s->mc_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
-      long long t0 = 0; for (long long v : h) if (v && (!t0 || v < t0)) t0 = v;
+      // (stamps of an earlier launch survive where this one wrote none: only what lies within 10 ms of the latest counts)
+      long long tmax = 0, t0 = 0;
+      for (size_t i = 0; i < (size_t)(s->tc_nrt + 1) * 24; ++i) tmax = std::max(tmax, h[i]);
+      for (size_t i = 0; i < (size_t)(s->tc_nrt + 1) * 24; ++i) { if (h[i] < tmax - 1000000) h[i] = 0; if (h[i] && (!t0 || h[i] < t0)) t0 = h[i]; }
       static const int order[24] = {19, 20, 21, 22, 23, 16, 13, 14, 15, 17, 18, 9, 0, 10, 11, 12, 1, 2, 3, 4, 5, 6, 7, 8};   // 13..15: the sub-diagonal tile of this row: L11 there, solved, X rows there
       for (int J = 0; J < s->tc_nrt; ++J) {
         fprintf(stderr, "rsba[tc] tile %2d:", J);
