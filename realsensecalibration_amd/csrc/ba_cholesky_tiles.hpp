@@ -252,11 +252,18 @@ __device__ __forceinline__ void TileSpreadX(double* __restrict__ F, int n, int m
 //   panel 2J       factor the first block, hand L11 on (S1), solve the own rows 32..63 by substitution, hand them on, update
 //   panel 2J + 1   factor the second block — wavefront 1 inverts the FIRST one meanwhile, stores T and raises the first half's
 //                  flags for everybody off the chain — hand L22 on (T2), invert, store, publish
+// Measured and dropped (256 cameras, same box, 460 us as it stands): the last update split around the first factorisation (only the
+// first diagonal block before it, the rows 32..63 next to it on the wavefronts 1 to 3): 495; the first block's inverse next to the
+// substitution (wavefront 3) instead of next to the second factorisation: the substitution's barrier waits 1.5 us for it; the
+// inverse inlined instead of called: 656; the factorisation inlined: 546; the rows 32..63 eliminated WITH the first block (64 lanes,
+// no substitution): the factorisation 1.1 us longer, 535.
 // Buffers (32 x 33 each): first half Pan | T (scratch, then L11 transposed for the substitution) | Lt; second half Pan | XI rows
 // 0..31 (scratch, then T) | XI rows 32..63 (Lt), while T = inverse of the first block's Lt.  false: a hand-over did not come.
-static __device__ __noinline__ bool DiagTileColumn(const TileCtx& c) {
-  extern __shared__ double lds[];
-  const TileLds L = TileLdsOf(lds);
+static __device__ __noinline__ bool DiagTileColumn(const TileCtx& c, lds_double* lds_base) {
+  // (the LDS base comes as an argument: `extern __shared__` in a function that is not a kernel is a look-up in a table in
+  //  memory, redone wherever the compiler finds it convenient — seen in the middle of the substitution, with a wait for every
+  //  store and load in flight in front of it)
+  const TileLds L = TileLdsOf((double*)lds_base);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = c.n, m = c.m, np = c.np, J = c.J, tag = c.tag;
   const TileCholFlags f = c.f;   // (copies: the context itself lives in private memory, and a load from there in the middle
@@ -415,9 +422,8 @@ static __device__ __noinline__ bool DiagTileColumn(const TileCtx& c) {
 // straight from the diagonal tile, its 64 rows solved by substitution (L11 comes ~3 us before the diagonal tile's rows of X:
 // the substitution does not wait for them), X on to the next diagonal tile (XH), the update of its columns 32..63, those
 // columns — final but unsolved — on to the next diagonal tile as well (AH); xdone for everybody else at the end.
-static __device__ __noinline__ bool SubDiagFirstHalf(const TileCtx& c) {
-  extern __shared__ double lds[];
-  const TileLds L = TileLdsOf(lds);
+static __device__ __noinline__ bool SubDiagFirstHalf(const TileCtx& c, lds_double* lds_base) {
+  const TileLds L = TileLdsOf((double*)lds_base);
   const int tid = threadIdx.x, n = c.n, m = c.m, I = c.I, J = c.J, p = 2 * c.J, kb = p * RSBA_PB, tag = c.tag;
   const TileCholFlags f = c.f;
   double* F = c.F;
@@ -520,12 +526,12 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
     asm volatile("" : "+v"(tid));
     if (I == J && p == max(0, 2 * J - 2)) {
       // the diagonal tile's last steps, out of line
-      stalled = !DiagTileColumn(ctx);
+      stalled = !DiagTileColumn(ctx, (lds_double*)lds);
       break;
     }
     if (J == Jp) {
       if (I == J + 1 && second_follows) {
-        if (!SubDiagFirstHalf(ctx)) stalled = true;
+        if (!SubDiagFirstHalf(ctx, (lds_double*)lds)) stalled = true;
         continue;
       }
       // ---- column tile: T from the diagonal tile through F, X = Rows T' on the matrix cores
