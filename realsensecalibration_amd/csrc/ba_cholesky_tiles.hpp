@@ -744,7 +744,7 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
                 int* __restrict__ error, int tag) {
   const int n = L.nc, tid = threadIdx.x, w = blockIdx.x;
   const int m = (n + RSBA_PB - 1) / RSBA_PB * RSBA_PB, nblk = m / RSBA_PB, btop = nblk - 1;
-  const long long budget = RSBA_STALL_TICKS;
+  const long long budget = RSBA_STALL_TICKS;   // (the waits below carry no acquire fence: x and the helpers' slices are read with agent-scope loads)
   __shared__ double part[8][RSBA_PB];
   __shared__ double xb[RSBA_PB];
   __shared__ double epi[4 * 256];
@@ -768,7 +768,7 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
     bool stalled = false;
     for (int b = btop; b > b1 + RSBA_BSC_LAG; --b) {
       load_strip(b - 3, l3);
-      if (!WaitFlagWG(xdone + b, tag, error, budget)) { stalled = true; break; }
+      if (!WaitFlagPlainWG(xdone + b, tag, error, budget)) { stalled = true; break; }
       if (tid < RSBA_PB) xb[tid] = 32 * b + tid < n ? __hip_atomic_load(&xsol[32 * b + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       __syncthreads();
       {
@@ -858,7 +858,7 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
     raw_next = fetch(b - 1, lnext, tnext, dgnext);
     if (b == b1) {
       // a new range of columns: its helper has applied every strip above b1 + LAG (or there are none)
-      if (!WaitFlagWG(hdone + h, tag, error, budget)) { stalled = true; break; }
+      if (!WaitFlagPlainWG(hdone + h, tag, error, budget)) { stalled = true; break; }
       if (tid < 96) yl[tid] = __hip_atomic_load(&ys[96 * h + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
     }
