@@ -81,6 +81,7 @@ struct TiledSchur {
   int* ready = nullptr;                     // ready[1 + g] = step tag once stage g (self tile g + pair tiles (g, g' >= g)) is in S
   int* block_seg = nullptr;                 // [nseg] launch order: block -> segment (host-side diagnostics)
   SchurSeg* segs_ordered = nullptr;         // [nblocks] the entries in launch order (what a ticket indexes)
+  unsigned ticket_base = 0;                 // where the next launch's tickets start (SchurArgs::ticket_base)
   SchurSeg* segs_ordered_self = nullptr;    // [nblocks_self] the self segments and their reducers only (gradient evaluation)
   int* small_flag = nullptr;                // != 0: some camera takes the small-angle branch this linearisation (point side kernels)
   int nblocks_self = 0;
@@ -430,6 +431,16 @@ __device__ __constant__ unsigned char kDiagPair[128] = {
 // v[i] = sum over q < n of block q's entry i (this thread's slot), blocks RSBA_PART*256 doubles apart, in block order.
 // Plain loads after the caller's acquire (see TileTreeReduce); two blocks are in flight at a time when the registers
 // allow it (the sums sit at the tail of a tile, where only memory-level parallelism shortens them).
+// The thread's index as something the compiler cannot see through: the entries' functions run in a loop now (resident
+// workgroups), and with a plain threadIdx.x every address they derive from it is computed once in front of the loop and kept —
+// 50 to 60 registers more than there are, spilled into the hot loops.
+__device__ __forceinline__ int OpaqueTid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  __builtin_assume(t >= 0 && t < 256);
+  return t;
+}
+
 template <int NV>
 __device__ __forceinline__ void TreeSum(const double* __restrict__ in, int n, double* v) {
 #pragma unroll
@@ -473,7 +484,7 @@ template <int NV>
 __device__ __forceinline__ bool GroupReduce(const SchurSeg& sg, const double* __restrict__ partial, double* __restrict__ grp_sum,
                                             int* __restrict__ sync_cnt, int ngrp, double* v, int* __restrict__ grp_flag, int epoch) {
   __shared__ int s_last;
-  const int tid = threadIdx.x;
+  const int tid = OpaqueTid();
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0) s_last = __hip_atomic_fetch_add(&sync_cnt[sg.grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.grp_nseg - 1;
@@ -530,7 +541,7 @@ __device__ __forceinline__ void SelfTileArrive(int* __restrict__ sync_cnt, int n
 // Adds the 16 slices in a fixed tree order, then K factors, diagonal S block, diag(U), g_c and the rhs correction.
 __device__ __forceinline__ void FinishSelfSlot(int C, int ga, double* v, const double* __restrict__ camc, double* __restrict__ red, RedLayout L,
                                                const double* __restrict__ cam_free) {
-  const int tid = threadIdx.x, ia = tid >> 4, ib = tid & 15, cam_a = RSBA_TG * ga + ia;
+  const int tid = OpaqueTid(), ia = tid >> 4, ib = tid & 15, cam_a = RSBA_TG * ga + ia;
   // sum the 16 slices of a row (lanes ia*16 .. ia*16+15 are contiguous inside a wave) in a fixed tree order
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) {
@@ -663,7 +674,9 @@ struct SchurArgs {
   double* __restrict__ gmax_p;
   double* __restrict__ tile_sum;   // [ntiles][42][256]
   int* tree_error;                 // set when a reducer gave up waiting (cannot happen; never hang)
-  int* ticket;                     // next entry of the work list (block_seg)
+  int* ticket;                     // next entry of the work list (block_seg): counts on from launch to launch, ticket_base is where this one starts
+  unsigned ticket_base;
+  int total;                       // entries of this launch's work list (the workgroups loop over tickets until they draw one past it)
   int* grp_flag;                   // [ngrp] = epoch once the group's sum is in grp_sum (the reducers add groups as they arrive)
   int epoch;                       // launch number, never 0
   long long* trace;   // diagnostic (RSBA_TRACE=1)
@@ -684,7 +697,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
   const int* __restrict__ cam_ptr = a.cam_ptr;
   const double* __restrict__ sq_cm = a.sq_cm;
   double* __restrict__ partial = a.partial;
-  const int tid = threadIdx.x;
+  const int tid = OpaqueTid();
   const bool diag_tile = sg.ga == sg.gb;
   // off-diagonal tile: lane = (ia, ib) directly.  Diagonal tile: the 120 pairs ia < ib sit in lanes 0..119 of BOTH halves of
   // the workgroup; waves 0/1 walk the even mask words of a chunk, waves 2/3 the odd ones, and the two partial blocks are
@@ -857,7 +870,7 @@ __device__ __forceinline__ void PairSegmentSparse(const SchurArgs& a, const Schu
   const double* __restrict__ ptdata = a.ptdata;
   const double* __restrict__ sq_cm = a.sq_cm;
   double* __restrict__ partial = a.partial;
-  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int tid = OpaqueTid(), wv = tid >> 6, ln = tid & 63;
   const bool diag_tile = sg.ga == sg.gb;
   const int dt = diag_tile ? (tid & 127) : tid;
   const int pr = diag_tile ? (dt < 120 ? kDiagPair[dt] : 0) : tid;
@@ -986,7 +999,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   const double* __restrict__ u_cm = a.u_cm;
   const double* __restrict__ v_cm = a.v_cm;
   double* __restrict__ partial = a.partial;
-  const int tid = threadIdx.x, ia = tid >> 4, ib = tid & 15;
+  const int tid = OpaqueTid(), ia = tid >> 4, ib = tid & 15;
   const int cam_a = RSBA_TG * sg.ga + ia;
   const bool live = cam_a < C;
   const double* cca = camc + (size_t)(live ? cam_a : 0) * CC_STRIDE;
@@ -1114,7 +1127,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
 // columns.  The self tile of the last group also folds the point pass' per-block scalars (cost, |X|^2, failures, max|g_p|).
 __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSeg& sg, int ticket) {
   __shared__ int s_flag;
-  const int tid = threadIdx.x;
+  const int tid = OpaqueTid();
   int* cnt_groups = a.sync_cnt + a.ngrp + sg.tile;
   int* cnt_red = a.sync_cnt + a.ngrp + a.ntiles + 16 + sg.tile;
   // The groups are added in group order AS THEY ARRIVE (per-group flags), four at a time: when the tile's last group is
@@ -1227,31 +1240,38 @@ k_schur_tiles(SchurArgs a) {
   // camera constants, point data); now the entry is ONE load off the ticket (segs_ordered), the small-angle flag is one
   // word for the whole problem, fetched with the ticket, and everything an entry stages is in flight before the first
   // LDS store (PairSegment / SelfSegment).
+  // kSparse (more than 64 cameras): the workgroups are RESIDENT and draw tickets until the list is through (one launch = as
+  // many workgroups as the chip holds, not one per entry): between two entries of a slot lay the end of a workgroup, the
+  // dispatch of the next and its first round trips, 12 us per entry of ~85 us at 256 cameras (377 -> 351 us).  Not so at up
+  // to 64 cameras: the same loop around the masked search costs that instance 40 us (281 -> 321 us, more scalar spills in
+  // the hot loop), more than the 6.8 us per entry it saves.  The counter is never reset: a launch moves it by its draws —
+  // the entries, plus one draw past the end per resident workgroup — and the host passes where it starts.
   __shared__ int s_ticket, s_small;
-  if (threadIdx.x == 0) {
-    const int sm = __hip_atomic_load(a.small_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_ticket = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_small = sm;
-    if (s_ticket == (int)gridDim.x - 1) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) s_small = __hip_atomic_load(a.small_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    if (threadIdx.x == 0) s_ticket = (int)((unsigned)__hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ticket_base);
+    __syncthreads();
+    const int b = s_ticket;
+    if (kSparse && b >= a.total) break;
+    const SchurSeg sg = a.segs_ordered[b];
+    const int seg_index = sg.index;
+    if (a.trace && b == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
+    if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b] = wall_clock64();
+    if (sg.self >= 2) ReducerSegment(a, sg, b);
+    else if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, b, pt, mk, lst, cnt);
+    else {
+      // two instances of the pair tile: the small-angle selects of the Jacobian rows (12 instructions per hit) are compiled in
+      // only when some camera takes that branch this iteration (a rotation of exactly zero: the reference's test2 fixture)
+      if (kSparse) {
+        if (s_small) PairSegmentSparse<kLoss, true>(a, sg, seg_index, b, pt, sc);
+        else PairSegmentSparse<kLoss, false>(a, sg, seg_index, b, pt, sc);
+      } else if (s_small) PairSegment<kLoss, true>(a, sg, seg_index, b, pt, mk, sc);
+      else PairSegment<kLoss, false>(a, sg, seg_index, b, pt, mk, sc);
+    }
+    if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b + 1] = wall_clock64();
+    if (!kSparse) break;   // one entry per workgroup
+    __syncthreads();       // (the next entry reuses the staging buffers and s_ticket)
   }
-  __syncthreads();
-  const int b = s_ticket;
-  const SchurSeg sg = a.segs_ordered[b];
-  const int seg_index = sg.index;
-  if (a.trace && b == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
-  if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b] = wall_clock64();
-  if (sg.self >= 2) ReducerSegment(a, sg, b);
-  else if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, b, pt, mk, lst, cnt);
-  else {
-    // two instances of the pair tile: the small-angle selects of the Jacobian rows (12 instructions per hit) are compiled in
-    // only when some camera takes that branch this iteration (a rotation of exactly zero: the reference's test2 fixture)
-    if (kSparse) {
-      if (s_small) PairSegmentSparse<kLoss, true>(a, sg, seg_index, b, pt, sc);
-      else PairSegmentSparse<kLoss, false>(a, sg, seg_index, b, pt, sc);
-    } else if (s_small) PairSegment<kLoss, true>(a, sg, seg_index, b, pt, mk, sc);
-    else PairSegment<kLoss, false>(a, sg, seg_index, b, pt, mk, sc);
-  }
-  if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b + 1] = wall_clock64();
 }
 
 

@@ -1126,6 +1126,10 @@ static void LaunchPointSide(TiledSchur& ts, rsba_solver* s, const IterParams& ip
 
 // The Schur elimination launch: self segments first, then the pair tiles stage by stage; results land in s->red.
 // tag != 0: the ready flags are published for a Cholesky that is already waiting (pipelined schedule).
+// Workgroups of a launch of the Schur kernel.  More than 64 cameras (the sparse instance): as many as the chip holds at once (two
+// per CU), each drawing tickets until the work list is through; otherwise one per entry.
+static int SchurGrid(int entries, bool sparse) { return sparse ? std::min(entries, 2 * DeviceCUs()) : entries; }
+
 static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   const int x = s->cur;
   SchurArgs a;
@@ -1145,12 +1149,15 @@ void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& 
   RoctxRange rr("K2+K3 camera-side rows + Schur elimination into the reduced system");
   SchurArgs a = MakeSchurArgs(*this, s, tag);
   if (first_staged) { a.segs_ordered = segs_ordered_first; a.all_self = 1; }
+  const bool sparse = a.hits != nullptr;
+  const int grid = SchurGrid(nblocks, sparse);
+  a.total = nblocks; a.ticket_base = ticket_base; ticket_base += (unsigned)(nblocks + (sparse ? grid : 0));
   T.Begin("k_schur_tiles", st);
   if (a.hits != nullptr) {
-    if (ip.huber_delta != 0.0) k_schur_tiles<true, true><<<nblocks, 256, 0, st>>>(a);
-    else k_schur_tiles<false, true><<<nblocks, 256, 0, st>>>(a);
-  } else if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<nblocks, 256, 0, st>>>(a);
-  else k_schur_tiles<false, false><<<nblocks, 256, 0, st>>>(a);
+    if (ip.huber_delta != 0.0) k_schur_tiles<true, true><<<grid, 256, 0, st>>>(a);
+    else k_schur_tiles<false, true><<<grid, 256, 0, st>>>(a);
+  } else if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<grid, 256, 0, st>>>(a);
+  else k_schur_tiles<false, false><<<grid, 256, 0, st>>>(a);
   T.End(st);
 }
 
@@ -1158,9 +1165,11 @@ void TiledSchur::LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTime
   RoctxRange rr("K2 camera gradient only (self tiles)");
   SchurArgs a = MakeSchurArgs(*this, s, 0);
   a.segs_ordered = segs_ordered_self; a.self_only = 1; a.trace = nullptr; a.wg_trace = nullptr;
+  const int grid = SchurGrid(nblocks_self, false);   // (the self-only pass runs the masked instance at any size)
+  a.total = nblocks_self; a.ticket_base = ticket_base; ticket_base += (unsigned)nblocks_self;
   T.Begin("k_schur_tiles(self only)", st);
-  if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<nblocks_self, 256, 0, st>>>(a);
-  else k_schur_tiles<false, false><<<nblocks_self, 256, 0, st>>>(a);
+  if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<grid, 256, 0, st>>>(a);
+  else k_schur_tiles<false, false><<<grid, 256, 0, st>>>(a);
   T.End(st);
 }
 
@@ -1640,6 +1649,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(s->tiled.sync_cnt, 0, (size_t)s->tiled.nsync * sizeof(int)));
     HIPCHK(hipMemset(s->tiled.tree_error + 1, 0, sizeof(int)));
+    s->tiled.ticket_base = 0;
     if (s->mc_flags) HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
     // the repeat runs sequentially; a solver that has timed out three times stays there
     ++s->pipe_stalls;
