@@ -52,6 +52,15 @@ RSBA_TRACE=2 RSBA_TRACE_FILE=$O/wg_cfg5.txt python3 bench.py --config cfg5 --poi
 python3 tools/schur_timeline_summary.py $O/wg_cfg5.txt > $O/r03_schur_block_timeline_cfg5_62500.txt
 RSBA_TRACE=3 python3 bench.py --no-cpu-baseline --steps 100 --warmup 5 --no-events 2>&1 | grep "rsba\[ring\]" | tail -1 > $O/r03_step_ring.txt
 RSBA_HOSTPROF=1 python3 bench.py --no-cpu-baseline --steps 100 --warmup 5 --no-events 2>&1 | grep "rsba\[hostprof\]" | tail -1 >> $O/r03_step_ring.txt
+# the diagonal chain of the tiled Cholesky (256 cameras): stamps per tile column, then the tiles that share a CU
+{
+  echo "# k_chol_tiles_persistent, 256 cameras: the diagonal chain's stamps of the latest launch (us since its first stamp), one row per tile row J."
+  echo "# columns: the sub-diagonal tile (J, J-1): 19 last-but-one update entered | 20 its operands there | 21 last update entered | 22 - | 23 its operands there |"
+  echo "#   16 first half entered | 13 L11 there | 14 rows solved | 15 the diagonal tile's rows of X there | 17 X spread | 18 columns 32..63 updated | 9 handed over (AH);"
+  echo "#   the diagonal tile (J, J): 0 last update entered | 10 AH there | 11 L22 there | 12 both in LDS | 1 X solved | 2 updated | 3 first block factored |"
+  echo "#   4 own rows solved | 5 second block updated | 6 second half entered | 7 second block factored | 8 T published.  Then: the tiles that share a CU."
+  RSBA_MC_TRACE=1 python3 bench.py --config cfg5 --points 62500 --steps 4 --warmup 2 --no-cpu-baseline 2>&1 | grep "rsba\[tc\]" | tail -96
+} > $O/r03_chol_tiles_chain_cfg5_62500.txt
 rm -f $O/wg_cfg3.txt $O/wg_cfg5.txt
 for f in default driver_cmd cfg5_shard cfg4_shard comm1rank_sequential comm1rank_pipelined sequential; do python3 -c "
 import json
