@@ -15,7 +15,8 @@ import oracle_lib  # noqa: E402
 from oracle_spread import block_rel  # noqa: E402
 from realsensecalibration_amd import capi, synthetic as syn  # noqa: E402
 
-CASES = {"c40": (40, 3000, 9, 340, 0.0), "c64_huber": (64, 4000, 12, 364, 1.0), "c70_huber": (70, 1500, 10, 5, 1.0), "c130": (130, 1500, 12, 430, 0.0)}
+CASES = {"c40": (40, 3000, 9, 340, 0.0), "c64_huber": (64, 4000, 12, 364, 1.0), "c70_huber": (70, 1500, 10, 5, 1.0), "c130": (130, 1500, 12, 430, 0.0),
+         "c240": (240, 1200, 14, 77, 0.0)}   # 240 cameras: 276 tiles of the reduced system on 256 CUs (the tiles' placement, TileOrder, matters)
 
 
 def main():

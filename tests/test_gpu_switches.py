@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SETTINGS = [
-    ({}, ["c40", "c64_huber", "c70_huber", "c130"]),
+    ({}, ["c40", "c64_huber", "c70_huber", "c130", "c240"]),
     ({"RSBA_PIPELINE": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_CHOL_DIAG": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_CHOL_WGS": "1"}, ["c40", "c64_huber"]),
@@ -31,6 +31,7 @@ SETTINGS = [
     ({"RSBA_SEG_PER_CU": "4"}, ["c64_huber", "c130"]),
     ({"RSBA_SPARSE_PAIRS": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_CHOL_TILES": "0"}, ["c70_huber", "c130"]),
+    ({"RSBA_TILE_ORDER": "0"}, ["c130", "c240"]),
     ({"RSBA_BACKSUB_MULTI": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_BACKSUB_MULTI": "1"}, ["c70_huber", "c130"]),
     ({"RSBA_FORCE_COMM": "1"}, ["c40", "c64_huber", "c70_huber"]),
