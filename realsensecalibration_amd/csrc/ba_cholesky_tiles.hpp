@@ -127,6 +127,19 @@ __device__ __forceinline__ TileLds TileLdsOf(double* lds) {
 }
 __host__ __device__ inline size_t TileCholLdsDoubles() { return (size_t)64 * RSBA_TL + 64 * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD + 64 + 2; }   // (+ 2: four ints of flags)
 
+// Where a tile finds its entries of the system.  fused = 0: in W, as k_sys_build left it (scaled, damped, mirrored, rhs in row n).
+// fused = 1: k_sys_build's arithmetic on the way into LDS, straight from the Schur kernel's payload `red` — the (n + 1) x n
+// intermediate is neither written nor read back and a launch is gone (10 us of a 1 ms step at 256 cameras).  On the first
+// iteration the Jacobi scales are defined here (from diag U): the diagonal tiles store them for the rest of the solve.
+struct TileSysSource {
+  int fused = 0;
+  const double* red = nullptr;
+  RedLayout L;
+  double* scale_c = nullptr;
+  IterParams ip;
+  int sym_full = 0;
+};
+
 // Which tile the workgroup with index t works on.  With more tiles than CUs, the workgroups t and t + (number of CUs) end up
 // on the same CU (measured: RSBA_MC_TRACE=1 lists the pairs), and a diagonal tile that shares its CU with a tile busy
 // updating takes ~6 us longer per tile column: row by row, the first eleven diagonal tiles of 256 cameras were paired with
@@ -464,7 +477,7 @@ static __device__ __noinline__ bool SubDiagFirstHalf(const TileCtx& c, lds_doubl
 __global__ void __launch_bounds__(256, 2)
 k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scaled, damped system + rhs row (k_sys_build) */,
                         double* __restrict__ F /* (n + 2) x n */, int* __restrict__ ok_flag, TileCholFlags f, int tag,
-                        double* __restrict__ res) {
+                        double* __restrict__ res, TileSysSource src) {
   extern __shared__ double lds[];
   const TileLds L = TileLdsOf(lds);
   const int tid = threadIdx.x;
@@ -510,7 +523,38 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
     if (gi >= n || gj >= n) return gi == gj ? 1.0 : 0.0;
     return W[(size_t)gi * n + gj];
   };
-  for (int e = tid; e < 64 * 64; e += 256) { const int r = e >> 6, c = e & 63; L.Tl[r * RSBA_TL + c] = sysv(r0 + r, c0 + c); }
+  if (src.fused) {
+    // k_sys_build's arithmetic (ba_cholesky_large.hpp), entry by entry: the scales of the tile's rows and columns first
+    const double* __restrict__ red = src.red;
+    const RedLayout RL = src.L;
+    double* sc_r = L.XI;        // 64 + 64 scales (XI is free until the first panel)
+    double* sc_c = L.XI + 64;
+    if (tid < 128) {
+      const int g = (tid < 64 ? r0 : c0 - 64) + tid;
+      double v = 0.0;
+      if (g < n) v = src.ip.first ? (src.ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(red[RL.diagU() + g])) : 1.0) : src.scale_c[g];
+      L.XI[tid] = v;
+      if (src.ip.first && I == J && tid < 64 && g < n) src.scale_c[g] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63, gi = r0 + r, gj = c0 + c;
+      double v;
+      if (gi > m || gj >= m) v = 0.0;
+      else if (gi == m) v = gj < n ? sc_c[c] * (red[RL.gc() + gj] + red[RL.corr() + gj]) : 0.0;
+      else if (gi >= n || gj >= n) v = gi == gj ? 1.0 : 0.0;
+      else {
+        const int bi = gi / 6, bj = gj / 6;
+        const bool upper = src.sym_full || (bi < bj) || (bi == bj && gi <= gj);
+        const double raw = upper ? red[RL.S() + (size_t)gi * n + gj] : red[RL.S() + (size_t)gj * n + gi];
+        v = raw * (sc_r[r] * sc_c[c]);
+        if (gi == gj) v += fmin(fmax(sc_r[r] * sc_r[r] * red[RL.diagU() + gi], src.ip.min_lm_diagonal), src.ip.max_lm_diagonal) / src.ip.radius;
+      }
+      L.Tl[r * RSBA_TL + c] = v;
+    }
+  } else {
+    for (int e = tid; e < 64 * 64; e += 256) { const int r = e >> 6, c = e & 63; L.Tl[r * RSBA_TL + c] = sysv(r0 + r, c0 + c); }
+  }
   if (I == 0 && J == 0 && tid == 0) { __hip_atomic_store(ok_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 0.0; }   // (a stall, half a second later, sets it)
   __syncthreads();
   const TileCtx ctx{n, m, np, I, J, tag, F, ok_flag, f, RSBA_STALL_TICKS};

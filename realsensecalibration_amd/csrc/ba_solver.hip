@@ -1400,15 +1400,23 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   } else {
     // more than 64 cameras: right-looking factorisation over the whole chip, one launch per 32-wide panel
     const int n = s->nc;
-    T.Begin("k_sys_build", st);
-    k_sys_build<<<n + 1, 256, 0, st>>>(s->red, s->L, s->W, keep_system_copy ? s->S_copy : nullptr, keep_system_copy ? s->rhs_copy : nullptr,
-                                       s->scale_c, ip, s->opt.schur_impl != 0 ? 1 : 0, s->chol_ok);
-    T.End(st);
+    // the resident tiles build their entries of the system themselves (TileSysSource); k_sys_build only where its output is
+    // wanted for itself (the copies of the system a caller asked for) or the multi-launch factorisation reads it
+    static const int fuse_env = getenv("RSBA_SYS_FUSED") ? atoi(getenv("RSBA_SYS_FUSED")) : 1;
+    const bool fused = s->tc_tiles > 0 && !keep_system_copy && fuse_env != 0;
+    if (!fused) {
+      T.Begin("k_sys_build", st);
+      k_sys_build<<<n + 1, 256, 0, st>>>(s->red, s->L, s->W, keep_system_copy ? s->S_copy : nullptr, keep_system_copy ? s->rhs_copy : nullptr,
+                                         s->scale_c, ip, s->opt.schur_impl != 0 ? 1 : 0, s->chol_ok);
+      T.End(st);
+    }
     if (s->tc_tiles > 0) {
+      TileSysSource src;
+      if (fused) { src.fused = 1; src.red = s->red; src.L = s->L; src.scale_c = s->scale_c; src.ip = ip; src.sym_full = s->opt.schur_impl != 0 ? 1 : 0; }
       T.Begin("k_chol_tiles_persistent", st);
       k_chol_tiles_persistent<<<s->tc_tiles, 256, TileCholLdsDoubles() * sizeof(double), st>>>(
           n, s->W, s->A, s->chol_ok, TileCholFlags{s->tc_flags, s->tc_flags + s->tc_np, s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1), s->tc_nrt, s->tc_hand, s->tc_launches++ & 1, s->tc_map, s->mc_trace},
-          s->step_tag, s->res);
+          s->step_tag, s->res, src);
       T.End(st);
     } else {
     const size_t lds_s = CholStepLdsDoubles() * sizeof(double);

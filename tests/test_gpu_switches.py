@@ -32,6 +32,7 @@ SETTINGS = [
     ({"RSBA_SPARSE_PAIRS": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_CHOL_TILES": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_TILE_ORDER": "0"}, ["c130", "c240"]),
+    ({"RSBA_SYS_FUSED": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_BACKSUB_MULTI": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_BACKSUB_MULTI": "1"}, ["c70_huber", "c130"]),
     ({"RSBA_FORCE_COMM": "1"}, ["c40", "c64_huber", "c70_huber"]),
