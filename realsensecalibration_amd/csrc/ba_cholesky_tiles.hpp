@@ -49,6 +49,7 @@ struct TileCholFlags {
   // before they are written again — also behind a launch that gave up half-way.  Everybody else goes through tdone / xdone.
   double* hand = nullptr;    // [2][nrt][kTileHandDoubles]
   int parity = 0;
+  int test_stall = 0;              // RSBA_TEST_STALL=3: the diagonal tiles look for their hand-over in the set nobody writes
   const int* tile_map = nullptr;   // [tiles] I << 8 | J of the workgroup with that index (TileOrder); nullptr: row by row
   long long* trace = nullptr;   // RSBA_MC_TRACE=1: [nrt][24] stamps of the diagonal tiles' chain (wall clock, 10 ns)
 };
@@ -286,7 +287,7 @@ static __device__ __noinline__ bool DiagTileColumn(const TileCtx& c, lds_double*
   if (J > 0) {
     {
       double v[8];
-      if (!TakeHandOver<8>(TileHandSlot(f, f.parity, J) + kTileHandXH, v, f.error, budget)) L.flags[1] = 1;
+      if (!TakeHandOver<8>(TileHandSlot(f, f.parity ^ f.test_stall, J) + kTileHandXH, v, f.error, budget)) L.flags[1] = 1;
 #pragma unroll
       for (int u = 0; u < 8; ++u) { const int e = tid + u * 256; L.XI[(e >> 5) * RSBA_PLD + (e & 31)] = v[u]; }
     }

@@ -173,7 +173,8 @@ struct rsba_solver {
   // queue restricted to one CU (sB), and waits inside the kernel for ready flags; the pair kernel (on the main stream)
   // publishes each camera group's columns as its last workgroups reduce them, the self tiles are the first blocks of the same launch.
   bool pipelined = false;
-  int test_stall = 0;        // RSBA_TEST_STALL=1: the Cholesky waits for a tag nobody publishes, =2: the back-substitution does
+  int test_stall = 0;        // RSBA_TEST_STALL=1: the Cholesky waits for a tag nobody publishes, =2: the back-substitution does,
+                             // =3: a diagonal tile of the persistent tiled factorisation waits for a hand-over nobody writes
                              // (both exercise the fallback to the sequential schedule)
   int step_tag = 0;
   int inject_stall_step = 0; // RSBA_TEST_STALL_STEP=k (with a communicator; RSBA_TEST_STALL_RANK=r: on that rank only): step k reports a
@@ -1415,7 +1416,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       if (fused) { src.fused = 1; src.red = s->red; src.L = s->L; src.scale_c = s->scale_c; src.ip = ip; src.sym_full = s->opt.schur_impl != 0 ? 1 : 0; }
       T.Begin("k_chol_tiles_persistent", st);
       k_chol_tiles_persistent<<<s->tc_tiles, 256, TileCholLdsDoubles() * sizeof(double), st>>>(
-          n, s->W, s->A, s->chol_ok, TileCholFlags{s->tc_flags, s->tc_flags + s->tc_np, s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1), s->tc_nrt, s->tc_hand, s->tc_launches++ & 1, s->tc_map, s->mc_trace},
+          n, s->W, s->A, s->chol_ok, TileCholFlags{s->tc_flags, s->tc_flags + s->tc_np, s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1), s->tc_nrt, s->tc_hand, s->tc_launches++ & 1, s->test_stall == 3 ? 1 : 0, s->tc_map, s->mc_trace},
           s->step_tag, s->res, src);
       T.End(st);
     } else {

@@ -742,6 +742,28 @@ def test_multi_workgroup_cholesky_stall_falls_back(oracle, capfd):
     assert np.array_equal(got, ref) and np.array_equal(log, log_ref)
 
 
+def test_tiled_cholesky_stall_falls_back_to_the_multi_launch_factorisation(oracle, capfd):
+    """RSBA_TEST_STALL=3: a diagonal tile of the persistent tiled factorisation looks for its hand-over in the set nobody
+    writes this launch (the data is its own flag there: nothing ever arrives).  It must give up inside its budget, every
+    other workgroup with it, the step must be repeated with the multi-launch factorisation — for the rest of the solve — and the
+    result must be the one of the multi-launch factorisation (same arithmetic per entry in both: identical bits are not
+    promised between them, the parity bar is)."""
+    prob = syn.make_problem(130, 1500, 12, seed=430)
+    ref, s_ref, log_ref = oracle.solve_points(prob)
+    os.environ["RSBA_TEST_STALL"] = "3"
+    try:
+        got, s, log = capi.solve_points(prob)
+    finally:
+        del os.environ["RSBA_TEST_STALL"]
+    err = capfd.readouterr().err
+    assert err.count("persistent tiled Cholesky stalled") == 1, err
+    assert s.num_iterations == s_ref.num_iterations and np.array_equal(log[:, 7], log_ref[:, 7])
+    assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
+    C = prob["C"]
+    for a, b in ((got[:6 * C].reshape(-1, 6), ref[:6 * C].reshape(-1, 6)), (got[6 * C:].reshape(-1, 3), ref[6 * C:].reshape(-1, 3))):
+        assert (np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-12)).max() < 1e-6
+
+
 # ------------------------------------------------------------------ persistent tiled Cholesky (more than 64 cameras)
 @pytest.mark.parametrize("C,P,k", [(65, 1400, 9), (100, 2200, 10), (128, 2600, 10)])
 def test_persistent_tiled_cholesky_matches_oracle_and_multi_launch(oracle, C, P, k):
