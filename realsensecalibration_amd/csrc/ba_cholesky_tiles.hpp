@@ -766,30 +766,38 @@ k_backsub_multi(int C, const double* __restrict__ red, RedLayout L, const double
 // Block back-substitution with the chain in ONE workgroup (round 3; k_backsub_multi above is its predecessor and fallback).
 // k_backsub_multi passes the chain from owner to owner: per owner's three blocks a hop (store x, acknowledgement, flag, poll,
 // fetch), three strip updates and three solves, ~11 us — 184 us at 256 cameras.  Here workgroup 0 solves EVERY block, in
-// order, with all of x in its LDS, and never waits for a store: per block it subtracts the nearest strips' blocks itself
-// (L(i, b) x_i for b < i <= top of its column range + RSBA_BSC_LAG: at most LAG + 2 products of 32 x 32, their entries of L
-// prefetched one block ahead, addresses known) and x_b = T_b' y_b; one wavefront sends x_b out while the others go on.
-// Everything FARTHER above is the helpers' business: helper h owns 96 columns of y and applies the strip of every block i more
-// than RSBA_BSC_LAG above its range as soon as x_i is published (strips prefetched three ahead, as in k_backsub_multi), then
-// hands its slice of y over (ys, hdone) — LAG + 1 blocks before the chain gets there.  Same sums per entry in a fixed order:
-// bitwise reproducible.
-// What bounds it: the chain's own loads.  One CU pulls ~70 GB/s through its L1, whether the lines sit in its XCD's L2 or not
-// (workgroups that touched the lines ahead of the chain changed nothing), so every near block costs ~0.12 us; with LAG = 3
-// the chain read 40 KB per block and took 117 us, LAG = 2: 110, LAG = 1: 106, LAG = 0 (the helper's hand-over on the chain): 111.
-// The loads must cover whole 128-byte lines per row (32 consecutive columns per half wavefront): with a column's eight row
-// groups in neighbouring lanes — which saves two of the four barriers per block — every line is asked for twice, 164 us.
+// order, and never waits for a store: per block it subtracts the nearest strips' blocks itself (L(i, b) x_i for b < i <= top
+// of its column range + RSBA_BSC_LAG: at most LAG + 2 products of 32 x 32, their entries of L prefetched one block ahead, x of
+// those blocks in registers) and x_b = T_b' y_b; one wavefront sends x_b out.  Everything FARTHER above is the helpers'
+// business: helper h owns 96 columns of y and applies the strip of every block i more than RSBA_BSC_LAG above its range as soon
+// as x_i arrives (strips prefetched three ahead, as in k_backsub_multi), then hands its slice of y over.  x and the slices travel
+// with the data as its own flag (below).  Same sums per entry in a fixed order: bitwise reproducible.
+// What bounds it (94 us at 256 cameras, 48 blocks): the chain's own loads — one CU pulls ~70 GB/s through its L1, whether the
+// lines sit in its XCD's L2 or not (workgroups that touched the lines ahead of the chain changed nothing) — 0.4 us per block,
+// the two products with their two barriers 0.6, the hand-over of a slice every three blocks.  Measured: with LAG = 3 the chain
+// read 40 KB per block and took 117 us, LAG = 2: 110, LAG = 1: 106 (all with flags); with the sentinel hand-overs LAG = 1: 94,
+// LAG = 0: 96.5; four barriers per block instead of two: no difference (the row groups' sums met in LDS behind a barrier each);
+// a column's eight row groups in neighbouring lanes (the loads then ask for every line twice): 164 us.
 // ------------------------------------------------------------------------------------------------
 #define RSBA_BSC_LAG 1
 __global__ void __launch_bounds__(256)
-k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double* __restrict__ F, double* __restrict__ xsol,
+k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double* __restrict__ F, double* __restrict__ xs2 /* [2][m] */,
                 const double* __restrict__ scale_c, const double* __restrict__ cam_x, double* __restrict__ cam_c,
                 const double* __restrict__ intr, double* __restrict__ camc_c, double* __restrict__ dcam,
                 const double* __restrict__ gmax_p, double* __restrict__ res, const int* __restrict__ ok_flag,
-                const double* __restrict__ cam_free, int* __restrict__ xdone, int* __restrict__ hdone, double* __restrict__ ys,
-                int* __restrict__ error, int tag) {
+                const double* __restrict__ cam_free, double* __restrict__ ys2 /* [2][96 helpers] */, int* __restrict__ error, int parity) {
   const int n = L.nc, tid = threadIdx.x, w = blockIdx.x;
   const int m = (n + RSBA_PB - 1) / RSBA_PB * RSBA_PB, nblk = m / RSBA_PB, btop = nblk - 1;
-  const long long budget = RSBA_STALL_TICKS;   // (the waits below carry no acquire fence: x and the helpers' slices are read with agent-scope loads)
+  const int nhelp = (nblk + 2) / 3;
+  // x and the helpers' slices of y travel as in the tiled factorisation (TakeHandOver): the data is its own flag — the sentinel
+  // until the producer's store arrives — in two sets by launch parity, the chain resetting the other set at the start.  With
+  // flags the way from a solved x_b to the slice that needs it was six microseconds (the store's acknowledgement, the flag, the
+  // helper's poll and fetch, its store, acknowledgement and flag, the chain's poll and fetch): three blocks of the chain.
+  double* __restrict__ xsol = xs2 + (size_t)parity * m;
+  double* __restrict__ ys = ys2 + (size_t)parity * nhelp * 96;
+  const long long budget = RSBA_STALL_TICKS;
+  __shared__ int s_fail;
+  if (tid == 0) s_fail = 0;
   __shared__ double part[8][RSBA_PB];
   __shared__ double xb[RSBA_PB];
   __shared__ double epi[4 * 256];
@@ -813,9 +821,21 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
     bool stalled = false;
     for (int b = btop; b > b1 + RSBA_BSC_LAG; --b) {
       load_strip(b - 3, l3);
-      if (!WaitFlagPlainWG(xdone + b, tag, error, budget)) { stalled = true; break; }
-      if (tid < RSBA_PB) xb[tid] = 32 * b + tid < n ? __hip_atomic_load(&xsol[32 * b + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      if (tid < RSBA_PB) {
+        double v = 0.0;
+        if (32 * b + tid < n) {
+          const long long t0 = wall_clock64();
+          for (int round = 0;; ++round) {
+            v = __hip_atomic_load(&xsol[32 * b + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (HandThere(v)) break;
+            if ((round & 15) == 15 && (wall_clock64() - t0 > budget || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { s_fail = 1; v = 0.0; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        xb[tid] = v;
+      }
       __syncthreads();
+      if (s_fail) { stalled = true; break; }
       {
         double sacc = 0.0;
 #pragma unroll
@@ -830,13 +850,18 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
     }
     if (stalled) { if (tid == 0) __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     if (tid < 96) StoreShared(&ys[96 * h + tid], yown[tid]);
-    PublishFlagWG(hdone + h, tag);
     return;
   }
+  {
+    // the other set back to the sentinel (nobody touches it during this launch)
+    const double sent = __longlong_as_double(-1LL);
+    double* xo = xs2 + (size_t)(parity ^ 1) * m;
+    double* yo = ys2 + (size_t)(parity ^ 1) * nhelp * 96;
+    for (int i = tid; i < m; i += 256) StoreShared(&xo[i], sent);
+    for (int i = tid; i < nhelp * 96; i += 256) StoreShared(&yo[i], sent);
+  }
   // ---- the chain
-  extern __shared__ double xl[];                       // m: every x, as it is solved
   __shared__ double yl[96];                            // the current helper range's slice of y
-  __shared__ double ybl[RSBA_PB];
   const int c = tid & 31, p8 = tid >> 5;               // column of the block, eighth of its 32 rows (rows 4 p8 .. 4 p8 + 3)
   // what block b needs from memory, fetched one block ahead: its near blocks of L (at most LAG + 2) and T_b.  Checked form: any
   // block, padding rows and columns read as zero / identity.  Plain form (the loop's, whenever no padded row or column is in
@@ -892,40 +917,51 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
     return false;
   };
   double lcur[kNear][4], tcur[4], lnext[kNear][4], tnext[4], dgcur = 0.0, dgnext = 0.0;
+  double xq[kNear][4];                                 // this thread's four rows of x of the last kNear blocks (nearest first)
+#pragma unroll
+  for (int u = 0; u < kNear; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xq[u][r] = 0.0;
+  __shared__ double p4[4][RSBA_PB], q4[4][RSBA_PB];   // the wavefronts' partial sums of the two products of a block
   bool raw_cur = fetch(btop, lcur, tcur, dgcur), raw_next = false;
   bool stalled = false;
+  double ypre = __longlong_as_double(-1LL);            // the next range's slice as last seen (the sentinel: not asked for yet / not there yet)
   for (int b = btop; b >= 0; --b) {
     const int h = b / 3, b1 = min(btop, 3 * h + 2), ihi = min(btop, b1 + RSBA_BSC_LAG);
-    if (b < btop && tid >= 192) {
-      __builtin_amdgcn_s_waitcnt(0);
-      if (tid == 192) __hip_atomic_store(xdone + b + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     raw_next = fetch(b - 1, lnext, tnext, dgnext);
     if (b == b1) {
-      // a new range of columns: its helper has applied every strip above b1 + LAG (or there are none)
-      if (!WaitFlagPlainWG(hdone + h, tag, error, budget)) { stalled = true; break; }
-      if (tid < 96) yl[tid] = __hip_atomic_load(&ys[96 * h + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // a new range of columns: its helper has applied every strip above b1 + LAG (or there are none) and stored its slice —
+      // asked for one block ago (ypre), asked again here until it is there
+      if (tid < 96) {
+        double v = ypre;
+        const long long t0 = wall_clock64();
+        for (int round = 0; !HandThere(v); ++round) {
+          if ((round & 15) == 15 && (wall_clock64() - t0 > budget || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { s_fail = 1; v = 0.0; break; }
+          __builtin_amdgcn_s_sleep(1);
+          v = __hip_atomic_load(&ys[96 * h + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        yl[tid] = v;
+      }
       __syncthreads();
+      if (s_fail) { stalled = true; break; }
     }
-    // the near blocks: sum_i L(i, b)' x_i over b < i <= ihi
+    // the next range's slice: asked for while this range's last block is solved
+    if (b == 3 * h && h > 0 && tid < 96) ypre = __hip_atomic_load(&ys[96 * (h - 1) + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Two barriers per block.  The near blocks: sum_i L(i, b)' x_i over b < i <= ihi, with x of the
+    // last kNear blocks in registers (this thread's four rows of each); the wavefront's two row groups meet in a lane exchange,
+    // the four wavefronts' sums in LDS — and every thread adds up the four partial sums of the rows IT needs next (sixteen
+    // LDS reads) instead of waiting for one wavefront to do it behind another barrier.  Every sum in a fixed order.
     {
       double sacc = 0.0;
 #pragma unroll
       for (int u = 0; u < kNear; ++u) {
-        const int i = b + 1 + u;
-        if (i <= ihi) {
+        if (b + 1 + u <= ihi) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sacc += lcur[u][r] * xl[32 * i + 4 * p8 + r];
+          for (int r = 0; r < 4; ++r) sacc += lcur[u][r] * xq[u][r];
         }
       }
-      part[p8][c] = sacc;
-    }
-    __syncthreads();
-    if (tid < RSBA_PB) {
-      double sacc = 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) sacc += part[q][tid];
-      ybl[tid] = yl[32 * (b - 3 * h) + tid] - sacc;
+      sacc += __shfl_xor(sacc, 32, 64);
+      if ((tid & 63) < 32) p4[tid >> 6][c] = sacc;
     }
     __syncthreads();
     // x_b = T_b' y_b
@@ -934,25 +970,24 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 4 * p8 + r;
+        const double yv = yl[32 * (b - 3 * h) + i] - (((p4[0][i] + p4[1][i]) + p4[2][i]) + p4[3][i]);
         const double tv = raw_cur ? (i > c ? tcur[r] : (i == c ? dgcur : 0.0)) : tcur[r];
-        sacc += tv * ybl[i];
+        sacc += tv * yv;
       }
-      part[p8][c] = sacc;
+      sacc += __shfl_xor(sacc, 32, 64);
+      if ((tid & 63) < 32) q4[tid >> 6][c] = sacc;
     }
     __syncthreads();
-    if (tid < RSBA_PB) {
-      double sacc = 0.0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) sacc += part[q][tid];
-      xl[32 * b + tid] = sacc;
-    }
-    __syncthreads();
-    // x_b goes out now; its flag follows at the top of the next iteration (below): by then the store is acknowledged, and the
-    // wait for that is a wait for loads this wavefront needs there anyway.  (Flag right behind the store: every block the whole
-    // workgroup stood at the next barrier until the last wavefront's store AND its prefetches for the next block had come back.)
+    for (int u = kNear - 1; u > 0; --u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xq[u][r] = xq[u - 1][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int i = 4 * p8 + r; xq[0][r] = ((q4[0][i] + q4[1][i]) + q4[2][i]) + q4[3][i]; }
+    // x_b goes out (no flag behind it: the helpers poll the values themselves)
     if (tid >= 192 && tid < 224) {
       const int t = tid - 192;
-      if (32 * b + t < n) StoreShared(&xsol[32 * b + t], xl[32 * b + t]);
+      if (32 * b + t < n) StoreShared(&xsol[32 * b + t], ((q4[0][t] + q4[1][t]) + q4[2][t]) + q4[3][t]);
     }
 #pragma unroll
     for (int u = 0; u < kNear; ++u)
@@ -966,7 +1001,6 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
   if (stalled) { if (tid == 0) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 1.0; } return; }
   // every x is in xsol (this workgroup stored them) — visible to its own plain loads behind the acknowledgements and one acquire
   __builtin_amdgcn_s_waitcnt(0);
-  if (tid == 192) __hip_atomic_store(xdone + 0, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   int ok = 1;

@@ -186,8 +186,9 @@ struct rsba_solver {
   int* tc_map = nullptr;     // ... which tile each of its workgroups takes (TileOrder)
   double* tc_hand = nullptr; // ... and the private hand-over buffers of its diagonal chain (TileCholFlags::hand), two sets
   int tc_launches = 0;       //     used by launch parity
-  int* tc_hdone = nullptr;   // k_backsub_chain: the helpers' slices of y (flag, 96 doubles each)
+  double* tc_xs = nullptr;   // k_backsub_chain: x as it is solved | the helpers' slices of y (two sets each, ba_cholesky_tiles.hpp)
   double* tc_ys = nullptr;
+  int tc_bs_launches = 0;
   int tc_np = 0, tc_nrt = 0, tc_tiles = 0;   // 0 tiles: the multi-launch path
   double* mc_dg = nullptr;         // look-ahead sums and unsolved blocks handed over between the workgroups of k_reduced_system_solve_diag
   long long* mc_trace = nullptr;   // RSBA_MC_TRACE=1: stamps of the latest multi-workgroup factorisation
@@ -725,7 +726,7 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_map, s->tc_hand, s->tc_hdone, s->tc_ys};
+                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_map, s->tc_hand, s->tc_xs, s->tc_ys};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
@@ -1051,8 +1052,10 @@ static int UploadPoints(rsba_solver* s) {
           if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, (size_t)(nrt + 1) * 24 + ntiles))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, ((size_t)(nrt + 1) * 24 + ntiles) * sizeof(long long))); }
           {
             const int H = (s->tc_np + 2) / 3;
-            if ((rc = DevAlloc(&s->tc_hdone, (size_t)H)) || (rc = DevAlloc(&s->tc_ys, (size_t)H * 96))) return rc;
-            HIPCHK(hipMemset(s->tc_hdone, 0, (size_t)H * sizeof(int)));
+            // k_backsub_chain's hand-overs, two sets each, the sentinel everywhere: x and the helpers' slices of y
+            if ((rc = DevAlloc(&s->tc_xs, (size_t)2 * m)) || (rc = DevAlloc(&s->tc_ys, (size_t)2 * H * 96))) return rc;
+            HIPCHK(hipMemset(s->tc_xs, 0xff, (size_t)2 * m * sizeof(double)));
+            HIPCHK(hipMemset(s->tc_ys, 0xff, (size_t)2 * H * 96 * sizeof(double)));
           }
           HIPCHK(hipFuncSetAttribute((const void*)k_chol_tiles_persistent, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(TileCholLdsDoubles() * sizeof(double))));
@@ -1432,13 +1435,13 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // RSBA_BACKSUB_MULTI: 2 (default) the chain in one workgroup with helpers for the far strips (k_backsub_chain), 1 the chain
     // passed from owner to owner (k_backsub_multi, round 2), 0 one workgroup for everything (k_chol_finish)
     static const int bsm = getenv("RSBA_BACKSUB_MULTI") ? atoi(getenv("RSBA_BACKSUB_MULTI")) : 2;
-    if (s->tc_tiles > 0 && bsm >= 2 && s->tc_hdone != nullptr) {
+    if (s->tc_tiles > 0 && bsm >= 2 && s->tc_xs != nullptr) {
       const int nblk = s->tc_np, H = (nblk + 2) / 3;
       int* fl = s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1);   // [error | xdone ...]
       T.Begin("k_backsub_multi", st);
-      k_backsub_chain<<<1 + H, 256, (size_t)MultiCholPadded(n) * sizeof(double), st>>>(
-          C, s->red, s->L, s->A, s->W + (size_t)n * n, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, s->chol_ok, s->cam_free,
-          fl + 1, s->tc_hdone, s->tc_ys, fl, s->step_tag);
+      k_backsub_chain<<<1 + H, 256, 0, st>>>(
+          C, s->red, s->L, s->A, s->tc_xs, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, s->chol_ok, s->cam_free,
+          s->tc_ys, fl, s->tc_bs_launches++ & 1);
       T.End(st);
     } else if (s->tc_tiles > 0 && bsm >= 1) {
       // block back-substitution on several workgroups (three 32-column blocks each); x goes to row n of W (free by now)
