@@ -772,11 +772,11 @@ k_backsub_multi(int C, const double* __restrict__ red, RedLayout L, const double
 // business: helper h owns 96 columns of y and applies the strip of every block i more than RSBA_BSC_LAG above its range as soon
 // as x_i arrives (strips prefetched three ahead, as in k_backsub_multi), then hands its slice of y over.  x and the slices travel
 // with the data as its own flag (below).  Same sums per entry in a fixed order: bitwise reproducible.
-// What bounds it (94 us at 256 cameras, 48 blocks): the chain's own loads — one CU pulls ~70 GB/s through its L1, whether the
+// What bounds it (84 us at 256 cameras, 48 blocks): the chain's own loads — one CU pulls ~70 GB/s through its L1, whether the
 // lines sit in its XCD's L2 or not (workgroups that touched the lines ahead of the chain changed nothing) — 0.4 us per block,
 // the two products with their two barriers 0.6, the hand-over of a slice every three blocks.  Measured: with LAG = 3 the chain
 // read 40 KB per block and took 117 us, LAG = 2: 110, LAG = 1: 106 (all with flags); with the sentinel hand-overs LAG = 1: 94,
-// LAG = 0: 96.5; four barriers per block instead of two: no difference (the row groups' sums met in LDS behind a barrier each);
+// LAG = 0: 96.5; T_b fetched along the rows of F it is stored in and transposed through LDS (fetch_plain): 94 -> 84; four barriers per block instead of two: no difference (the row groups' sums met in LDS behind a barrier each);
 // a column's eight row groups in neighbouring lanes (the loads then ask for every line twice): 164 us.
 // ------------------------------------------------------------------------------------------------
 #define RSBA_BSC_LAG 1
@@ -881,9 +881,11 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = 4 * p8 + r;   // T[i][c], i >= c: at F[kb + c][kb + i] for i > c, the diagonal in row n + 1; identity on the padding
-      tn[r] = b < 0 ? 0.0 : ((kb + i < n && kb + c < n) ? (i > c ? F[(size_t)(kb + c) * n + kb + i] : (i == c ? F[(size_t)(n + 1) * n + kb + c] : 0.0))
-                                                         : (i == c ? 1.0 : 0.0));
+      // T[i][cc] for i = this thread's c, cc = 4 p8 + r (see fetch_plain): at F[kb + cc][kb + i] for i > cc, the diagonal in row n + 1;
+      // identity on the padding
+      const int i = c, cc = 4 * p8 + r;
+      tn[r] = b < 0 ? 0.0 : ((kb + i < n && kb + cc < n) ? (i > cc ? F[(size_t)(kb + cc) * n + kb + i] : (i == cc ? F[(size_t)(n + 1) * n + kb + cc] : 0.0))
+                                                          : (i == cc ? 1.0 : 0.0));
     }
   };
   const char* Fb = reinterpret_cast<const char*>(F);
@@ -903,12 +905,16 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
         for (int r = 0; r < 4; ++r) ln[u][r] = 0.0;
       }
     }
-    const unsigned o_t = (kb + c) * rowb + 8u * (kb + 4u * p8);             // row kb + c of F, columns kb + 4 p8 ..
-    // raw: row kb + c of F holds T[i][c] for i > c, the diagonal comes from row n + 1, the rest of the row belongs to other
-    // blocks — TEntry() picks when the values are used (picking here made the compiler wait for the loads here)
+    // T: the block is stored TRANSPOSED (T[i][cc] at row kb + cc, column kb + i of F), and the product below wants T[4 p8 + r][c]
+    // per thread — fetched that way every lane of a load sits in a row of F of its own (64 lines per instruction, 0.3 us per
+    // block).  So the roles are swapped for the fetch: this thread brings T[i = c][cc = 4 p8 + r] (32 consecutive columns per half
+    // wavefront), and the block goes through LDS once, transposed, beside the first product.  Raw here: row kb + cc holds T[i][cc]
+    // for i > cc, the diagonal comes from row n + 1 (this thread's: column c), the rest of the row belongs to other blocks — picked
+    // when the values are stored to LDS (picking here made the compiler wait for the loads here).
+    const unsigned o_t = (kb + 4u * p8) * rowb + 8u * (kb + c);
     dgn = *reinterpret_cast<const double*>(Fb + (size_t)((unsigned)(n + 1) * rowb + 8u * (kb + c)));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tn[r] = *reinterpret_cast<const double*>(Fb + (size_t)(o_t + 8u * r));
+    for (int r = 0; r < 4; ++r) tn[r] = *reinterpret_cast<const double*>(Fb + (size_t)(o_t + (unsigned)r * rowb));
   };
   auto fetch = [&](int b, double (&ln)[kNear][4], double (&tn)[4], double& dgn) {
     const int b1 = min(btop, 3 * (b / 3) + 2);
@@ -923,6 +929,7 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
 #pragma unroll
     for (int r = 0; r < 4; ++r) xq[u][r] = 0.0;
   __shared__ double p4[4][RSBA_PB], q4[4][RSBA_PB];   // the wavefronts' partial sums of the two products of a block
+  __shared__ double Tt[RSBA_PB * RSBA_PLD];           // T_b: Tt[cc * RSBA_PLD + i] = T[i][cc]
   bool raw_cur = fetch(btop, lcur, tcur, dgcur), raw_next = false;
   bool stalled = false;
   double ypre = __longlong_as_double(-1LL);            // the next range's slice as last seen (the sentinel: not asked for yet / not there yet)
@@ -962,6 +969,11 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
       }
       sacc += __shfl_xor(sacc, 32, 64);
       if ((tid & 63) < 32) p4[tid >> 6][c] = sacc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cc = 4 * p8 + r;   // (this thread fetched T[c][cc])
+        Tt[cc * RSBA_PLD + c] = raw_cur ? (c > cc ? tcur[r] : (c == cc ? dgcur : 0.0)) : tcur[r];
+      }
     }
     __syncthreads();
     // x_b = T_b' y_b
@@ -971,8 +983,7 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
       for (int r = 0; r < 4; ++r) {
         const int i = 4 * p8 + r;
         const double yv = yl[32 * (b - 3 * h) + i] - (((p4[0][i] + p4[1][i]) + p4[2][i]) + p4[3][i]);
-        const double tv = raw_cur ? (i > c ? tcur[r] : (i == c ? dgcur : 0.0)) : tcur[r];
-        sacc += tv * yv;
+        sacc += Tt[c * RSBA_PLD + i] * yv;
       }
       sacc += __shfl_xor(sacc, 32, 64);
       if ((tid & 63) < 32) q4[tid >> 6][c] = sacc;
