@@ -83,7 +83,7 @@ __device__ __forceinline__ double* BackSubstituteBlocksPrefetch(int n, double* _
   __syncthreads();
   const int kb_last = n - RSBA_PB;
   auto fetch_T = [&](int kb, int slot) {
-    const int e = tid + slot * nt, i = e >> 5, c = e & 31;
+    const int e = tid + slot * nt, i = e & 31, c = e >> 5;   // (lanes along i: T[i][c] lies in row kb + c of A — whole lines, not a line per lane)
     // T[i][c] for i > c sits at A[kb+c][kb+i]; the diagonal in row n+1
     return (i > c) ? A[(size_t)(kb + c) * n + kb + i] : (i == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
   };
@@ -96,7 +96,7 @@ __device__ __forceinline__ double* BackSubstituteBlocksPrefetch(int n, double* _
 #pragma unroll
   for (int c = 0; c < RSBA_PB; ++c) lv[c] = q < kb_last ? A[(size_t)(kb_last + c) * n + q] : 0.0;
   for (int kb = kb_last; kb >= 0; kb -= RSBA_PB) {
-    for (int sl = 0; sl < 2; ++sl) { const int e = tid + sl * nt; Tb[(e >> 5) * RSBA_PLD + (e & 31)] = tpre[sl]; }
+    for (int sl = 0; sl < 2; ++sl) { const int e = tid + sl * nt; Tb[(e & 31) * RSBA_PLD + (e >> 5)] = tpre[sl]; }
     if (kb >= RSBA_PB) {
       const int kn = kb - RSBA_PB;
 #pragma unroll

@@ -589,21 +589,21 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int e = tid + u * 256, r = e >> 5, c = e & 31;
-          tv[u] = TileLoadT(F, n, kb, r, c);
+          tv[u] = TileLoadT(F, n, kb, c, r);   // (T[c][r]: lanes along the row of F it is stored in, transposed on the way into LDS)
           xv[u] = TileLoadF(F, n, m, c0 + 32 + r, kb + c);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int e = tid + u * 256;
-          L.T[(e >> 5) * RSBA_PLD + (e & 31)] = tv[u];
+          L.T[(e & 31) * RSBA_PLD + (e >> 5)] = tv[u];
           L.XJ[(32 + (e >> 5)) * RSBA_PLD + (e & 31)] = xv[u];
         }
       } else {
         double tv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; tv[u] = TileLoadT(F, n, kb, e >> 5, e & 31); }
+        for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; tv[u] = TileLoadT(F, n, kb, e & 31, e >> 5); }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; L.T[(e >> 5) * RSBA_PLD + (e & 31)] = tv[u]; }
+        for (int u = 0; u < 4; ++u) { const int e = tid + u * 256; L.T[(e & 31) * RSBA_PLD + (e >> 5)] = tv[u]; }
       }
       __syncthreads();
       TileFormX(F, n, m, I, L, kb, lc, 0);
