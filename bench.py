@@ -258,7 +258,11 @@ def main():
                         "avg_launch_us": 1e3 * ms,
                         "algorithmic_flops_per_launch": chol_flops / lpi, "launches_per_iteration": lpi,
                         "note": "dense (6C)^3/3 + 2(6C)^2 Cholesky solve: a chain of 32 x 32 factorisations with matrix-core updates around it (six workgroups up to 64 cameras, one resident workgroup per 64 x 64 tile above), latency-bound by construction"}
-            share = {"k_point_pass": 24 * N_rank + 48 * P_rank, "k_backsub_candidate": 24 * N_rank + 48 * P_rank}.get(name, b_iter)
+            n_red = 6 * C
+            # the block back-substitution of the reduced system reads the factor's lower triangle once (and x, y)
+            share = {"k_point_pass": 24 * N_rank + 48 * P_rank, "k_backsub_candidate": 24 * N_rank + 48 * P_rank,
+                     "k_backsub_chain": 8 * (n_red * (n_red + 1) // 2 + 3 * n_red), "k_backsub_multi": 8 * (n_red * (n_red + 1) // 2 + 3 * n_red),
+                     "k_chol_finish": 8 * (n_red * (n_red + 1) // 2 + 3 * n_red)}.get(name, b_iter)
             ach = share / lpi / (ms * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "peak_source": "MI355X_MICROARCH.md: HBM3E 8.0 TB/s",
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

@@ -1438,7 +1438,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (s->tc_tiles > 0 && bsm >= 2 && s->tc_xs != nullptr) {
       const int nblk = s->tc_np, H = (nblk + 2) / 3;
       int* fl = s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1);   // [error | xdone ...]
-      T.Begin("k_backsub_multi", st);
+      T.Begin("k_backsub_chain", st);
       k_backsub_chain<<<1 + H, 256, 0, st>>>(
           C, s->red, s->L, s->A, s->tc_xs, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, s->chol_ok, s->cam_free,
           s->tc_ys, fl, s->tc_bs_launches++ & 1);
