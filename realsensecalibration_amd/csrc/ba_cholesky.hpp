@@ -378,7 +378,9 @@ __device__ __forceinline__ void TrsmRowsQuad(const double* src, int stride, cons
   for (int k = 0; k < 8; ++k) a[k] = src[row * stride + 4 * k + q];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { l0[k] = LtT[4 * k + q]; l1[k] = LtT[RSBA_PLD + 4 * k + q]; l2[k] = LtT[2 * RSBA_PLD + 4 * k + q]; }
-  // a step is ~45 cycles, an LDS read ~100: the multipliers of step j + 3 are read in step j
+  // a step is ~45 cycles of issue, an LDS read ~100: the multipliers of step j + 3 are read in step j.  (Measured 125 cycles per step.
+  // Laying the step's chain out with its other multiply-adds between the links — the next pivot's column first, its product, two
+  // multiply-adds, the broadcast, the rest — made the tiled factorisation 7 us slower, not faster.)
 #define RSBA_TRSM_STEP(J, CUR, NXT)                                                                              \
   {                                                                                                              \
     constexpr int kj = (J) >> 2, qj = (J) & 3;                                                                   \
