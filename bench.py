@@ -80,6 +80,12 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU" % (args.gpus, world))
 
+    if world > 1 or os.environ.get("RSBA_FORCE_COMM"):
+        # With a communicator in the process (RCCL's queues beside the solver's three streams) the runtime's default of four
+        # hardware queues for its stream pool put ~40 us between a launch of the next step's kernels and their start; with
+        # eight (or one, or two) it is gone: 0.471 -> 0.426 ms per iteration for the pipelined multi-GPU schedule at one rank,
+        # nothing for a solver without a communicator.  Read by the HIP runtime when it initialises — below.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():

@@ -12,7 +12,7 @@ python3 bench.py > $O/r03_bench_default.json 2> $O/r03_bench_default.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r03_bench_driver_cmd.json 2>/dev/null
 python3 bench.py --config cfg5 --points 62500 --steps 20 --cpu-iters 2 > $O/r03_bench_cfg5_shard.json 2>/dev/null
 python3 bench.py --config cfg4 --points 125000 --steps 30 --no-cpu-baseline > $O/r03_bench_cfg4_shard.json 2>/dev/null
-RSBA_FORCE_COMM=1 python3 bench.py --no-cpu-baseline --steps 30 > $O/r03_bench_comm1rank_sequential.json 2>/dev/null
+RSBA_FORCE_COMM=1 python3 bench.py --no-cpu-baseline --steps 30 > $O/r03_bench_comm1rank_sequential.json 2>/dev/null   # (bench.py sets GPU_MAX_HW_QUEUES=8 when a communicator will exist)
 RSBA_FORCE_COMM=1 RSBA_PIPELINE_MG=1 python3 bench.py --no-cpu-baseline --steps 30 > $O/r03_bench_comm1rank_pipelined.json 2>/dev/null
 RSBA_PIPELINE=0 python3 bench.py --no-cpu-baseline --steps 30 > $O/r03_bench_sequential.json 2>/dev/null
 # ---- kernel stats
