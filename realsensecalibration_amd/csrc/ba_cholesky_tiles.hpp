@@ -776,10 +776,10 @@ k_backsub_multi(int C, const double* __restrict__ red, RedLayout L, const double
 // lines sit in its XCD's L2 or not (workgroups that touched the lines ahead of the chain changed nothing) — 0.4 us per block,
 // the two products with their two barriers 0.6, the hand-over of a slice every three blocks.  Measured: with LAG = 3 the chain
 // read 40 KB per block and took 117 us, LAG = 2: 110, LAG = 1: 106 (all with flags); with the sentinel hand-overs LAG = 1: 94,
-// LAG = 0: 96.5; T_b fetched along the rows of F it is stored in and transposed through LDS (fetch_plain): 94 -> 84; four barriers per block instead of two: no difference (the row groups' sums met in LDS behind a barrier each);
+// LAG = 0: 96.5 (LAG = 2 in the end: the loop 68.6 against 70.5 us, the helpers' slices there when asked for; 3: 75); T_b fetched along the rows of F it is stored in and transposed through LDS (fetch_plain): 94 -> 84; four barriers per block instead of two: no difference (the row groups' sums met in LDS behind a barrier each);
 // a column's eight row groups in neighbouring lanes (the loads then ask for every line twice): 164 us.
 // ------------------------------------------------------------------------------------------------
-#define RSBA_BSC_LAG 1
+#define RSBA_BSC_LAG 2
 __global__ void __launch_bounds__(256)
 k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double* __restrict__ F, double* __restrict__ xs2 /* [2][m] */,
                 const double* __restrict__ scale_c, const double* __restrict__ cam_x, double* __restrict__ cam_c,

@@ -320,7 +320,11 @@ __device__ __forceinline__ void CameraStepEpilogue(int C, const double* __restri
   for (int c = tid; c < C; c += nt) {
     double cc[CC_STRIDE];
     CameraConstants(cam_c + 6 * c, intr + 4 * c, cc);
-    for (int i = 0; i < CC_STRIDE; ++i) camc_c[(size_t)c * CC_STRIDE + i] = cc[i];
+    // (a camera's 32 constants are 256 contiguous bytes per lane: 16-byte stores, half the instructions)
+    typedef double d2s_t __attribute__((ext_vector_type(2)));
+    d2s_t* out2 = reinterpret_cast<d2s_t*>(camc_c + (size_t)c * CC_STRIDE);
+#pragma unroll
+    for (int i = 0; i < CC_STRIDE / 2; ++i) { d2s_t v = {cc[2 * i], cc[2 * i + 1]}; out2[i] = v; }
   }
   if (tid == 0) {
     res[RES_COST_X] = 0.5 * red[L.scal() + 0];
