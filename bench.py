@@ -80,6 +80,10 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU" % (args.gpus, world))
 
+    # Kernel arguments in device memory instead of host memory: every workgroup of a launch reads its arguments first thing, and
+    # the step's kernels are short — 0.422 -> 0.418 ms per iteration here (a runtime setting, read when HIP initialises, below;
+    # DESIGN.md section 7).
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     if world > 1 or os.environ.get("RSBA_FORCE_COMM"):
         # With a communicator in the process (RCCL's queues beside the solver's three streams) the runtime's default of four
         # hardware queues for its stream pool put ~40 us between a launch of the next step's kernels and their start; with
