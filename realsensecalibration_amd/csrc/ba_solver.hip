@@ -1934,13 +1934,22 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
   rsba::CommScope device_turn(s->comm.get());
   struct AbortOnError { rsba_solver* s; int* rc; ~AbortOnError() { if (*rc != RSBA_OK && s->comm) s->comm->Abort(); } } abort_guard{s, &rc};
   if (s->prob->model == RSBA_MODEL_POINTS) {
+    const auto tr0 = std::chrono::steady_clock::now();
     if ((rc = rsba::ResetPoints(s)) != RSBA_OK) return rc;
+    const auto tr1 = std::chrono::steady_clock::now();
     if (hipStreamSynchronize(s->stream) != hipSuccess) return RSBA_ERR_HIP;
     const auto t0 = std::chrono::steady_clock::now();
     double cur_radius = s->opt.initial_trust_region_radius;
     rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { cur_radius = radius; return rsba::PointsStep(s, radius, first, false); },
                             [&]() { s->cur = 1 - s->cur; }, [&]() { return rsba::PointsGradient(s, cur_radius); });
     sum.minimizer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("RSBA_RUNPROF")) {
+      auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      fprintf(stderr, "rsba[runprof] reset issued %.1f us | its sync %.1f | loop %.1f (%d iterations) ", us(tr0, tr1), us(tr1, t0), 1e6 * sum.minimizer_seconds, sum.num_iterations);
+      for (size_t i = 0; i < s->iters.size() && i < 3; ++i) fprintf(stderr, "| it %zu: %.1f ", i, 1e6 * s->iters[i].iteration_time_in_seconds);
+      if (s->iters.size() > 1) fprintf(stderr, "| last it: %.1f", 1e6 * s->iters.back().iteration_time_in_seconds);
+      fprintf(stderr, "\n");
+    }
     rsba::TraceRingDump(s);
     if (s->hostprof && s->hp_n > 1) {
       const double n = (double)s->hp_n;
