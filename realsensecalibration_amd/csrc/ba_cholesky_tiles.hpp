@@ -798,7 +798,6 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
   const long long budget = RSBA_STALL_TICKS;
   __shared__ int s_fail;
   if (tid == 0) s_fail = 0;
-  __shared__ double part[8][RSBA_PB];
   __shared__ double xb[RSBA_PB];
   __shared__ double epi[4 * 256];
   if (w > 0) {

@@ -593,6 +593,21 @@ def test_marker_chain_time_elimination_matches_oracle(oracle, shape):
     assert np.all(got[:6] == prob["params"][:6]) and np.all(got[6 * (C_ + T_):6 * (C_ + T_) + 6] == prob["params"][6 * (C_ + T_):6 * (C_ + T_) + 6])
 
 
+@pytest.mark.parametrize("chunks", ["1", "7", "1000"])
+def test_marker_chain_chunk_count_does_not_change_the_answer(oracle, chunks):
+    """RSBA_MT_CHUNKS: how many workgroups share the times of the elimination (one partial system each, summed in chunk order).
+    One chunk, a number that does not divide the times, more chunks than times: the oracle's solution each time."""
+    prob = syn.make_marker_chain(8, 120, 12, seed=140)
+    os.environ["RSBA_MT_CHUNKS"] = chunks
+    try:
+        ref, s_ref, got, s = _solve_marker_chain_both(oracle, prob, 2)
+    finally:
+        del os.environ["RSBA_MT_CHUNKS"]
+    assert s.num_iterations == s_ref.num_iterations and s.num_successful_steps == s_ref.num_successful_steps
+    assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
+    assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
+
+
 def test_marker_chain_automatic_choice_and_dense_cross_check(oracle):
     """schur_impl 1 (default) eliminates once the dense system outgrows one workgroup's solver; the one-workgroup dense
     path (schur_impl 0) on the same problem is the on-device cross-check."""
