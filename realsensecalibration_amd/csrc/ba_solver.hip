@@ -824,8 +824,7 @@ static bool SetupPipeline(rsba_solver* s) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) return false;
   const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
-  std::vector<uint32_t> mask(words, mode == 3 ? 0u : 0xffffffffu);
-  if (mode == 3) mask[0] = 1u;
+  std::vector<uint32_t> mask(words, 0xffffffffu);
   // A side stream with a hardware queue of its own (hipExtStreamCreateWithCUMask, all CUs) that passes `probe`; a few attempts:
   // every new stream is dealt onto the next hardware queue.  (Streams from HIP's pool — hipStreamCreateWithFlags — were tried
   // for the multi-GPU pipeline, round 3: they pass the probe at set-up and are dealt onto other queues later; once in ~30 steps
