@@ -500,7 +500,8 @@ __device__ __forceinline__ bool GroupReduce(const SchurSeg& sg, const double* __
   __syncthreads();
   if (tid == 0) {
     __hip_atomic_store(&grp_flag[sg.grp], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the group's sum is acknowledged (s_waitcnt above)
-    s_last = __hip_atomic_fetch_add(&sync_cnt[ngrp + sg.tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.tile_ngrp - 1;
+    // (a tile with reducers does not count its groups: the reducers follow the flags)
+    s_last = sg.nred == 0 && __hip_atomic_fetch_add(&sync_cnt[ngrp + sg.tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.tile_ngrp - 1;
   }
   __syncthreads();
   // tiles of a few groups only (many cameras: 136 pair tiles at 256 cameras) have no reducers: the workgroup that
@@ -1122,10 +1123,103 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
 
+// Reducer workgroup of a PAIR tile: quadrant (qr, qc) = (word_begin >> 1, word_begin & 1) of every camera pair's 6 x 6 block.
+// The K factors (blkdiag(J_l, I) on either side) couple nothing across the four 3 x 3 quadrants, so a reducer that adds the
+// quadrant's nine components over the tile's groups can finish them itself: no tile sum, no election of a last reducer, no
+// second fetch — three dependent trips to memory less at the tail of every stage (the tile sum's acknowledgement, the arrival
+// counter, the finisher's fetch: ~8 of the 32 - 36 us between a stage's last partial block and its flag).  Its blocks of S
+// leave with agent-scope stores whose acknowledgements it awaits before it arrives at the stage counter: no fence either.
+// Same sums in the same order as the tile finisher's (groups in order, four at a time), same products.
+__device__ __forceinline__ void ReducerQuadrant(const SchurArgs& a, const SchurSeg& sg, int ticket) {
+  __shared__ int s_qflag;
+  const int tid = OpaqueTid();
+  const int qr = sg.word_begin >> 1, qc = sg.word_begin & 1;
+  const int cbase = 18 * qr + 3 * qc;   // component 6 (3 qr + i) + 3 qc + j = cbase + 6 i + j
+  const int* gf = a.grp_flag + sg.tile_grp0;
+  const long long t_begin = wall_clock64();
+  auto wait_groups = [&](int q0, int q1) {   // whole workgroup; false: gave up (cannot happen, see GroupReduce; never hang)
+    if (tid == 0) {
+      int ok = 1;
+      for (int q = q0; q < q1 && ok; ++q)
+        while (__hip_atomic_load(&gf[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+          __builtin_amdgcn_s_sleep(4);
+          if (wall_clock64() - t_begin > RSBA_STALL_TICKS) { ok = 0; break; }
+        }
+      s_qflag = ok;
+    }
+    __syncthreads();
+    const int ok = s_qflag;
+    __syncthreads();
+    return ok != 0;
+  };
+  const int ia = tid >> 4, ib = tid & 15;
+  const int cam_a = RSBA_TG * sg.ga + ia, cam_b = RSBA_TG * sg.gb + ib;
+  const bool live = cam_a < a.C && cam_b < a.C && !(sg.ga == sg.gb && ia >= ib);
+  // the K factors ahead of the wait (camera constants: written before the launch)
+  double Ka[9], Kb[9];
+  {
+    const double* pa = a.camc + (size_t)(live ? cam_a : 0) * CC_STRIDE + CC_K;
+    const double* pb = a.camc + (size_t)(live ? cam_b : 0) * CC_STRIDE + CC_K;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { Ka[i] = pa[i]; Kb[i] = pb[i]; }
+  }
+  double keep = 1.0;
+  if (a.cam_free != nullptr && live) keep = a.cam_free[cam_a] * a.cam_free[cam_b] == 0.0 ? 0.0 : 1.0;   // a constant camera couples to nobody
+  bool all_ok = true;
+  double v[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) v[k] = 0.0;
+  const double* in = a.grp_sum + (size_t)sg.tile_grp0 * RSBA_PART * 256 + (size_t)cbase * 256 + tid;
+  int q = 0;
+  for (; q + 3 < sg.tile_ngrp; q += 4) {
+    all_ok = wait_groups(q, q + 4) && all_ok;
+    double x[4][9];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        x[u][k] = __hip_atomic_load(&in[(size_t)(q + u) * RSBA_PART * 256 + (6 * (k / 3) + k % 3) * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = (((v[k] + x[0][k]) + x[1][k]) + x[2][k]) + x[3][k];
+  }
+  if (q < sg.tile_ngrp) all_ok = wait_groups(q, sg.tile_ngrp) && all_ok;
+  for (; q < sg.tile_ngrp; ++q)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] += __hip_atomic_load(&in[(size_t)q * RSBA_PART * 256 + (6 * (k / 3) + k % 3) * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();   // the tile's groups are complete and added
+  if (!all_ok && tid == 0) __hip_atomic_store(a.tree_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (live) {
+    // rows: Ta' core (the first three rows mixed by Ka'), columns: (.) Tb — FinishPairSlot's products, quadrant by quadrant
+    double t[9], blk[9];
+#pragma unroll
+    for (int qq = 0; qq < 3; ++qq)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) t[3 * p + qq] = qr == 0 ? Ka[0 * 3 + p] * v[0 * 3 + qq] + Ka[1 * 3 + p] * v[1 * 3 + qq] + Ka[2 * 3 + p] * v[2 * 3 + qq] : v[3 * p + qq];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int qq = 0; qq < 3; ++qq) blk[3 * p + qq] = keep * (qc == 0 ? t[3 * p + 0] * Kb[0 * 3 + qq] + t[3 * p + 1] * Kb[1 * 3 + qq] + t[3 * p + 2] * Kb[2 * 3 + qq] : t[3 * p + qq]);
+    double* Sb = a.red + a.L.S() + (size_t)(6 * cam_a + 3 * qr) * a.L.nc + 6 * cam_b + 3 * qc;
+    double* St = a.red + a.L.S() + (size_t)(6 * cam_b + 3 * qc) * a.L.nc + 6 * cam_a + 3 * qr;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int qq = 0; qq < 3; ++qq) {
+        __hip_atomic_store(&Sb[(size_t)p * a.L.nc + qq], -blk[3 * p + qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&St[(size_t)qq * a.L.nc + p], -blk[3 * p + qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+  }
+  __builtin_amdgcn_s_waitcnt(0);   // the blocks are in memory (StageArrive's barrier collects everybody's)
+  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, false)) return;
+  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
+}
+
 // Reducer workgroup `part` of tile sg.tile (see GroupReduce): components [word_begin, word_end) of the tile sums; the
 // last reducer finishes the tile, the last tile of a stage publishes it for the Cholesky that may be waiting for these
 // columns.  The self tile of the last group also folds the point pass' per-block scalars (cost, |X|^2, failures, max|g_p|).
 __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSeg& sg, int ticket) {
+  if (sg.self == 2) { ReducerQuadrant(a, sg, ticket); return; }
   __shared__ int s_flag;
   const int tid = OpaqueTid();
   int* cnt_groups = a.sync_cnt + a.ngrp + sg.tile;
@@ -1223,7 +1317,11 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
 // more scalar spills and a longer hot loop around the same arithmetic)
 template <bool kLoss, bool kSparse>
 __global__ void __launch_bounds__(256, 2)
-k_schur_tiles(SchurArgs a) {
+k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const int* __restrict__ small_flag_p, const SchurSeg* __restrict__ segs_p, SchurArgs a) {
+  // (what a workgroup needs FIRST — the ticket counter, where this launch's tickets start, the work list — comes as separate leading
+  //  arguments: the build preloads the first sixteen argument words into scalar registers at wave launch
+  //  (-mllvm -amdgpu-kernarg-preload-count=16), a structure passed by value is not among them, and the ticket used to wait for
+  //  a scalar load of its own address)
   __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];            // 48 KB
   __shared__ unsigned long long mk[2 * RSBA_TG][RSBA_CW];       // 2 KB
   __shared__ double sc[2 * RSBA_TG * RSBA_SC_STRIDE];           // 4 KB
@@ -1247,13 +1345,13 @@ k_schur_tiles(SchurArgs a) {
   // the hot loop), more than the 6.8 us per entry it saves.  The counter is never reset: a launch moves it by its draws —
   // the entries, plus one draw past the end per resident workgroup — and the host passes where it starts.
   __shared__ int s_ticket, s_small;
-  if (threadIdx.x == 0) s_small = __hip_atomic_load(a.small_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) s_small = __hip_atomic_load(small_flag_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (;;) {
-    if (threadIdx.x == 0) s_ticket = (int)((unsigned)__hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ticket_base);
+    if (threadIdx.x == 0) s_ticket = (int)((unsigned)__hip_atomic_fetch_add(ticket_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base);
     __syncthreads();
     const int b = s_ticket;
-    if (kSparse && b >= a.total) break;
-    const SchurSeg sg = a.segs_ordered[b];
+    if (kSparse && b >= total) break;
+    const SchurSeg sg = segs_p[b];
     const int seg_index = sg.index;
     if (a.trace && b == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
     if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b] = wall_clock64();

@@ -525,14 +525,24 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     const bool self = tab[3 * t + 2] != 0;
     const SchurSeg first = sg[tsp[t]];
     const int red_comps = RSBA_RED_COMPS;
-    const int nv = self ? RSBA_PART : 36, nred = first.tile_ngrp <= RSBA_DIRECT_GROUPS ? 0 : (nv + red_comps - 1) / red_comps;
+    // a pair tile: one reducer per 3 x 3 quadrant of the pairs' blocks, each finishing its own (ReducerQuadrant); a self tile:
+    // slices of its 42 components, the last reducer finishes the tile
+    const int nv = self ? RSBA_PART : 36, nred = first.tile_ngrp <= RSBA_DIRECT_GROUPS ? 0 : (self ? (nv + red_comps - 1) / red_comps : 4);
     for (int q = tsp[t]; q < tsp[t + 1]; ++q) sg[q].nred = nred;
     for (int r = 0; r < nred; ++r) {
       SchurSeg e = first;
-      e.self = self ? 3 : 2; e.word_begin = r * red_comps; e.word_end = std::min(nv, (r + 1) * red_comps); e.nred = nred;
+      e.self = self ? 3 : 2; e.nred = nred;
+      if (self) { e.word_begin = r * red_comps; e.word_end = std::min(nv, (r + 1) * red_comps); }
+      else { e.word_begin = r; e.word_end = r + 9; }   // (quadrant r; nine components)
       red_of_tile[t].push_back((int)sg.size());
       sg.push_back(e);
     }
+  }
+  // arrivals at a stage's counter: its self tile, and per pair tile the finisher — or each of the four quadrant reducers
+  {
+    std::vector<int> arrivals(ngroups, 1);
+    for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) arrivals[tab[3 * t]] += sg[tsp[t]].nred != 0 ? 4 : 1;
+    for (auto& e : sg) e.stage_ntiles = arrivals[e.stage];
   }
   nblocks = (int)sg.size();
   nsync = ngrp + 2 * ntiles + 16;
@@ -1157,10 +1167,10 @@ void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& 
   a.total = nblocks; a.ticket_base = ticket_base; ticket_base += (unsigned)(nblocks + (sparse ? grid : 0));
   T.Begin("k_schur_tiles", st);
   if (a.hits != nullptr) {
-    if (ip.huber_delta != 0.0) k_schur_tiles<true, true><<<grid, 256, 0, st>>>(a);
-    else k_schur_tiles<false, true><<<grid, 256, 0, st>>>(a);
-  } else if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<grid, 256, 0, st>>>(a);
-  else k_schur_tiles<false, false><<<grid, 256, 0, st>>>(a);
+    if (ip.huber_delta != 0.0) k_schur_tiles<true, true><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
+    else k_schur_tiles<false, true><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
+  } else if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
+  else k_schur_tiles<false, false><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
   T.End(st);
 }
 
@@ -1171,8 +1181,8 @@ void TiledSchur::LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTime
   const int grid = SchurGrid(nblocks_self, false);   // (the self-only pass runs the masked instance at any size)
   a.total = nblocks_self; a.ticket_base = ticket_base; ticket_base += (unsigned)nblocks_self;
   T.Begin("k_schur_tiles(self only)", st);
-  if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<grid, 256, 0, st>>>(a);
-  else k_schur_tiles<false, false><<<grid, 256, 0, st>>>(a);
+  if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
+  else k_schur_tiles<false, false><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
   T.End(st);
 }
 
