@@ -60,7 +60,8 @@ struct SchurSeg {
   // index: the entry's own number (segs_ordered, the copy in launch order, is what the kernel reads: one load per ticket)
   // self: 0 pair segment, 1 self segment, 2 / 3 reducer of a pair / self tile (word_begin..word_end = its components)
 };
-#define RSBA_GRP 8          // segments per reduction group
+#define RSBA_GRP 8          // segments per reduction group (more than 64 cameras)
+#define RSBA_GRP_SMALL 4    // ... up to 64 cameras
 #define RSBA_RED_COMPS 6     // components per reducer workgroup: 6 reducers per pair tile (36), 7 per self tile (42)
 #define RSBA_DIRECT_GROUPS 4  // tiles with at most this many groups are finished by their last group, without reducers
 
@@ -480,6 +481,15 @@ __device__ __forceinline__ void TreeSum(const double* __restrict__ in, int n, do
 // agent-scope (sc1) stores that go through to memory, ordered by waiting for the stores' acknowledgements before a
 // counter is bumped; only the workgroups that read other workgroups' sums invalidate their L2 first, and only the tile
 // finishers, whose results are written with ordinary stores, write theirs back.
+// Where a compute workgroup's 256 x 42 sums go: its partial block — or, a group of ONE segment in a tile with reducers, straight
+// into the group's sum (GroupReduce then only waits for the stores and raises the group's flag: no arrival counter, no second
+// fetch, no second store — three dependent trips to memory; the host puts such groups at the end of every tile, where the
+// stage's flag waits for them).
+__device__ __forceinline__ bool SingleSegmentGroup(const SchurSeg& sg) { return sg.grp_nseg == 1 && sg.nred != 0; }
+__device__ __forceinline__ double* SegmentOut(const SchurSeg& sg, double* __restrict__ partial, double* __restrict__ grp_sum, int seg_index) {
+  return SingleSegmentGroup(sg) ? grp_sum + (size_t)sg.grp * RSBA_PART * 256 : partial + (size_t)seg_index * RSBA_PART * 256;
+}
+
 template <int NV>
 __device__ __forceinline__ bool GroupReduce(const SchurSeg& sg, const double* __restrict__ partial, double* __restrict__ grp_sum,
                                             int* __restrict__ sync_cnt, int ngrp, double* v, int* __restrict__ grp_flag, int epoch) {
@@ -487,6 +497,10 @@ __device__ __forceinline__ bool GroupReduce(const SchurSeg& sg, const double* __
   const int tid = OpaqueTid();
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
+  if (SingleSegmentGroup(sg)) {   // the sums are the group's (SegmentOut) and acknowledged
+    if (tid == 0) __hip_atomic_store(&grp_flag[sg.grp], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+  }
   if (tid == 0) s_last = __hip_atomic_fetch_add(&sync_cnt[sg.grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.grp_nseg - 1;
   __syncthreads();
   if (!s_last) return false;
@@ -831,7 +845,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
     }
   }
   // slot of pair (ia, ib) in the workgroup's partial block is ia*16+ib whatever lane computed it
-  double* out = partial + (size_t)seg_index * RSBA_PART * 256;
+  double* out = SegmentOut(sg, partial, a.grp_sum, seg_index);
   if (!diag_tile || tid < 120) {
 #pragma unroll
     for (int i = 0; i < 36; ++i) __hip_atomic_store(&out[i * 256 + pr], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -963,7 +977,7 @@ __device__ __forceinline__ void PairSegmentSparse(const SchurArgs& a, const Schu
       for (int i = 0; i < 36; ++i) acc[i] += pt[i * 128 + tid];
     }
   }
-  double* out = partial + (size_t)seg_index * RSBA_PART * 256;
+  double* out = SegmentOut(sg, partial, a.grp_sum, seg_index);
   if (!diag_tile || tid < 120) {
 #pragma unroll
     for (int i = 0; i < 36; ++i) __hip_atomic_store(&out[i * 256 + pr], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1107,7 +1121,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
       }
     }
   }
-  double* out = partial + (size_t)seg_index * RSBA_PART * 256;
+  double* out = SegmentOut(sg, partial, a.grp_sum, seg_index);
 #pragma unroll
   for (int i = 0; i < RSBA_PART; ++i) __hip_atomic_store(&out[i * 256 + tid], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();

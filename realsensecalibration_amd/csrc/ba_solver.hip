@@ -491,17 +491,23 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     // pair tiles are ordered by ga: stage g ends after its last tile
     if (!self) for (int g = tab[3 * t]; g < nstages; ++g) { stage_tile[g + 1] = t + 1; stage_seg[g + 1] = tsp[t + 1]; }
     {
-      // reduction tree of this tile: groups of RSBA_GRP consecutive segments, but the last segments in groups of 4, 2,
-      // 1, 1: a tile is over when its last group has been added, and that group is usually the last one in order (its
-      // finisher's own sum is 14 us for 8 partial blocks, measured, at the tail of every stage)
-      const int GRP = RSBA_GRP;
+      // reduction tree of this tile: groups of RSBA_GRP consecutive segments, but the last segments in groups of 2, 2,
+      // 1, 1, 1, 1: a tile is over when its last group has been added, and that group is usually one of the last in order.
+      // Up to 64 cameras (both schedules: they add in the same order) the groups are smaller: the last arriver of a group adds it
+      // through ONE compute unit (~30 GB/s beside the rest of the kernel: 22 us for eight partial blocks, measured), and a
+      // group whose last segment ends late in its stage is what the stage's flag waits for
+      // (measured at 64 cameras x 100k points, ms per iteration: groups of 8: 0.411, 6: 0.408, 5: 0.407, 4: 0.406, 3: 0.412, 2: 0.428
+      //  — the reducers then read twice the group sums and fall behind)
+      const int GRP = 6 * C > RSBA_CHOL_MAXN ? RSBA_GRP : RSBA_GRP_SMALL;
       const int s0 = tsp[t], ns_t = tsp[t + 1] - tsp[t], g0 = ngrp;
       std::vector<int> gsize;
       {
         int left = ns_t;
-        const int tail[4] = {1, 1, 2, 4};
+        // (a group of one segment goes straight into the group sum, SegmentOut in ba_schur_tiled.hpp; four of them and two pairs
+        //  at the end: 0.4057 ms against 0.4087 with 1, 1, 2, 4 and 0.409 with eight or more single segments)
+        const std::vector<int> tail = {1, 1, 1, 1, 2, 2};
         std::vector<int> last;
-        if (ns_t >= 4 * GRP) for (int k = 0; k < 4 && left > tail[k]; ++k) { last.push_back(tail[k]); left -= tail[k]; }
+        if (ns_t >= 4 * GRP) for (size_t k = 0; k < tail.size() && left > tail[k]; ++k) { last.push_back(tail[k]); left -= tail[k]; }
         while (left > 0) { const int g = std::min(GRP, left); gsize.push_back(g); left -= g; }
         for (int k = (int)last.size() - 1; k >= 0; --k) gsize.push_back(last[k]);
       }

@@ -30,6 +30,15 @@ for s in np.unique(d[:, 4]):
     m = d[:, 4] == s
     comp = m & (d[:, 3] < 2)
     print("  %d: sums stored %.1f -> published %.1f  = %.1f us" % (s, ce[comp].max(), en[m].max(), en[m].max() - ce[comp].max()))
+# tile by tile: the last compute entry's sums stored -> the tile's reducers have the last group added (the latest of them) -> the
+# tile's last entry ends (its blocks of S are written, it has arrived at the stage counter)
+print("tiles: stage, type | last sums stored -> reducers' last group added -> last entry ends")
+for t in np.unique(d[:, 2]):
+    m = d[:, 2] == t
+    comp, red = m & (d[:, 3] < 2), m & (d[:, 3] >= 2)
+    if red.any():
+        print("  tile %2d stage %d %-4s | %.1f -> %.1f (+%.1f) -> %.1f (+%.1f)" % (t, d[m, 4][0], "self" if (d[m, 3] == 1).any() else "pair", ce[comp].max(),
+              ce[red].max(), ce[red].max() - ce[comp].max(), en[red].max(), en[red].max() - ce[red].max()))
 print("entries running at t (us):", " ".join("%d:%d" % (t, ((st <= t) & (en > t)).sum()) for t in range(20, int(en.max()), 40)))
 order_s, order_e = np.sort(st), np.sort(en)
 nslots = int(((st <= 20) & (en > 20)).sum())
