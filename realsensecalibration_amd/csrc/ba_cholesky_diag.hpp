@@ -93,7 +93,9 @@ struct DiagConst {
   int trs;  // 1: entry (i, j) of S is read as S[j][i] (multi-GPU pipeline: only camera group g's ROW slab is all-reduced when its panels start)
   lds_double* Bst; lds_double* t_tile[2]; lds_double* xprev; lds_double* scl;
   lds_int* s_wb; lds_int* ok_lds;
-  lds_int* acq;   // [0]: the newest block some update wave has claimed to acquire for the workgroup, [1]: the newest one acquired
+  lds_int* acq;   // [0]: the newest block some update wave has claimed to acquire for the workgroup, [1]: the newest one acquired,
+                  // [2]: 1 when the stage of that block's own columns of S was published by then (DiagUpdateWave, step 1)
+  lds_double* snext;   // 32 x 32: the next diagonal block's scaled, damped entries of S on their way into pre_n
   long long* tr;
 };
 typedef __attribute__((address_space(3))) const DiagConst lds_DiagConst;
@@ -123,6 +125,7 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
   // normally both are up and nobody waits for anybody.
   // One wave acquires for the workgroup (caches are per CU and per XCD: WaitFlagWG, ba_cholesky_multi.hpp): the first to get
   // here claims block p + 1, looks for the flags and issues the one agent-scope acquire; the others wait for it in LDS.
+  const bool gate_panel = do_unit && dc->gated && nb0 % dc->gate_cols == 0;
   if (lane == 0) {
     const int want = p + 1;
     if (__hip_atomic_fetch_max(dc->acq, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
@@ -131,14 +134,14 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
         __builtin_amdgcn_s_sleep(2);
         if (__hip_atomic_load(dc->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > dc->budget) { __hip_atomic_store(ok_lds, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
       }
-      if (do_unit && dc->gated && nb0 % dc->gate_cols == 0) {
-        const long long t1 = wall_clock64();
-        while (__hip_atomic_load(dc->gate_ready + 1 + nb0 / dc->gate_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != dc->gate_tag) {
-          __builtin_amdgcn_s_sleep(16);
-          if (wall_clock64() - t1 > (dc->gate_budget > 0 ? dc->gate_budget : RSBA_STALL_TICKS)) { __hip_atomic_store(ok_lds, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
-        }
-      }
+      // the stage of block p + 1's own columns of S is NOT waited for here: only the next diagonal block's entries come from
+      // it, and they are added to the block last, in the panel's tail — this panel's update needs nothing of that stage.  (Waiting
+      // here put the whole update of the panels 2, 5 and 8 behind the stage's flag: 6 - 10 us of the step whichever stage it waits
+      // for.)
+      int stage_up = 1;
+      if (gate_panel) stage_up = __hip_atomic_load(dc->gate_ready + 1 + nb0 / dc->gate_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == dc->gate_tag ? 1 : 0;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(dc->acq + 2, stage_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_store(dc->acq + 1, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
       while (__hip_atomic_load(dc->acq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
@@ -146,6 +149,7 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const bool s_now = __hip_atomic_load(dc->acq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;   // (uniform: written before acq[1])
   if (tr && wk == 0 && lane == 0) tr[2] = wall_clock64();
   if (!do_unit) { meet(wb_target); meet(wb_target + 6); meet(wb_target + 12); return; }   // (the last panel: the caller goes on to the right-hand-side row, barrier [A] is his)
   // 2. everything in one round trip
@@ -160,8 +164,10 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
   for (int u = 0; u < 3; ++u) {
     const int e = wk * 64 + lane + u * 384, r = e >> 5, c = e & 31;
     if (e < RSBA_PB * RSBA_PB) {
-      if (nb0 + r < nreal && nb0 + c < nreal) ns[u] = S[dc->trs ? (size_t)(nb0 + c) * nreal + nb0 + r : (size_t)(nb0 + r) * nreal + nb0 + c];
-      if (r == c && nb0 + r < nreal) ndu = dc->diag_u[nb0 + r];
+      if (s_now) {
+        if (nb0 + r < nreal && nb0 + c < nreal) ns[u] = __hip_atomic_load(&S[dc->trs ? (size_t)(nb0 + c) * nreal + nb0 + r : (size_t)(nb0 + r) * nreal + nb0 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (r == c && nb0 + r < nreal) ndu = __hip_atomic_load(&dc->diag_u[nb0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       ndd[u] = dc->dg[(size_t)(p + 1) * 1024 + r * 32 + c];
     }
   }
@@ -192,12 +198,18 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
   for (int u = 0; u < 3; ++u) {
     const int e = wk * 64 + lane + u * 384, r = e >> 5, c = e & 31, gi = nb0 + r, gj = nb0 + c;
     if (e < RSBA_PB * RSBA_PB) {
-      double v = gi == gj ? 1.0 : 0.0;   // padding
-      if (gi < nreal && gj < nreal) {
-        v = ns[u] * (scl[gi] * scl[gj]);
-        if (gi == gj) v += fmin(fmax(scl[gi] * scl[gi] * ndu, dc->min_diag), dc->max_diag) * dc->inv_radius;
+      // pre_n = -(look-ahead sum as handed over) now, - X X' of the newest panel (below), - X X' of this one and + the entry of S
+      // (dc->snext, or fetched there if the stage is not up yet) in the panel's tail: the same terms in the same order whether the
+      // stage was up or not
+      pre_n[r * RSBA_PLD + c] = -ndd[u];
+      if (s_now) {
+        double v = gi == gj ? 1.0 : 0.0;   // padding
+        if (gi < nreal && gj < nreal) {
+          v = ns[u] * (scl[gi] * scl[gj]);
+          if (gi == gj) v += fmin(fmax(scl[gi] * scl[gi] * ndu, dc->min_diag), dc->max_diag) * dc->inv_radius;
+        }
+        dc->snext[e] = v;
       }
-      pre_n[r * RSBA_PLD + c] = v - ndd[u];
     }
   }
   if (tr && wk == 0 && lane == 0) tr[5] = wall_clock64();
@@ -406,7 +418,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   const int G = gridDim.x, w = blockIdx.x;
   const int np = n / RSBA_PB;              // column panels; blocks 0 .. np (block np: the rhs row alone, workgroup 0's)
   const long long budget = gate.budget > 0 ? gate.budget : RSBA_STALL_TICKS;
-  __shared__ int s_ok, s_wb, s_w7ok, s_fdone, s_acq[2];
+  __shared__ int s_ok, s_wb, s_w7ok, s_fdone, s_acq[3];
   int wb_gen = 0;
   // LDS: strip (32 p rows of 33) | this workgroup's blocks of the panel (32 x 33 each) | T | Lt | Xl | invd | scale | Pre | Pre2 | scratch
   const int max_rows = n + RSBA_PB;
@@ -420,7 +432,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   double* scratch = PreB + RSBA_PB * RSBA_PLD;     // 1024 doubles
   double* Pre = PreA;        // the diagonal block being factored
   double* PreN = PreB;       // the next one, built during this panel
-  if (tid == 0) { s_ok = 1; s_wb = 0; s_w7ok = 1; s_fdone = 0; s_acq[0] = -1; s_acq[1] = -1; }
+  if (tid == 0) { s_ok = 1; s_wb = 0; s_w7ok = 1; s_fdone = 0; s_acq[0] = -1; s_acq[1] = -1; s_acq[2] = 1; }
   if (gate.trace && tid == 0 && w == 0) gate.trace[0] = wall_clock64();
   AnnounceResident(gate);
   bool stalled = false;
@@ -501,7 +513,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     s_dc.gated = staged ? 1 : 0; s_dc.trs = kTr ? 1 : 0;
     s_dc.Bst = (lds_double*)lds; s_dc.t_tile[0] = (lds_double*)T; s_dc.t_tile[1] = (lds_double*)(lds + (size_t)32 * (n - 30) + RSBA_PB * RSBA_PLD); s_dc.xprev = (lds_double*)(lds + (n - 30 - RSBA_PB)); s_dc.scl = (lds_double*)scl;
     s_dc.s_wb = (lds_int*)&s_wb; s_dc.ok_lds = (lds_int*)&s_w7ok; s_dc.acq = (lds_int*)&s_acq[0];
-    s_dc.tr = mtrace;
+    s_dc.tr = mtrace; s_dc.snext = (lds_double*)scratch;
   }
   __syncthreads();
   // a row workgroup's look-ahead tiles: 4 block slots x 3 tiles x 256 doubles where workgroup 0 keeps Pre / PreN / scratch
@@ -675,6 +687,11 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
           StoreShared(&A[(size_t)(kb + r) * n + kb + c], c > r ? Tc[c * RSBA_PLD + r] : Pre[r * RSBA_PLD + c]);
         }
         if (lane < RSBA_PB) StoreShared(&A[(size_t)(n + 1) * n + kb + lane], invd[lane]);
+        // ... and published as soon as they are acknowledged — not behind barrier [A], where the row workgroups' T(p) waited for
+        // whatever the update waves were waiting for (a block handed over late, a stage), finished their panel late and handed the
+        // next block over late in turn
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) __hip_atomic_store(f.tdone + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (idle4 && has_next && p > 0) {
         // ... and X(p+1, p-1) as soon as the update waves have formed it (their first meeting)
@@ -702,10 +719,6 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
         else if (wave == 3) solve_half(np, 0, 0, 0);
         T = Tsave;
       }
-      if (idle4) {
-        __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0) __hip_atomic_store(f.tdone + p, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
       __syncthreads();   // [C] Xl
       if (has_next) {
         // X X' straight off PreN (tiles by waves 1, 2, 3, 5); X(p+1, p) into the next strip's image, behind the columns the update
@@ -722,10 +735,43 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
 #pragma unroll
           for (int qs = 0; qs < RSBA_PB; qs += 4)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xl[(16 * ti + mi) * RSBA_PLD + qs + kk], Xl[(16 * tj + mi) * RSBA_PLD + qs + kk], acc, 0, 0, 0);
+          // ... and, last, the block's own (scaled, damped) entries of S: DiagUpdateWave left them in `scratch` if their stage of the
+          // Schur kernel was published when the panel began; if not, THIS is where the factorisation waits for the stage — behind
+          // everything of panel p, which needs nothing of it (agent-scope loads: no fence, nothing else is read behind this flag)
+          double vv[4] = {0.0, 0.0, 0.0, 0.0};
+          if (p > 0) {
+            if (s_acq[2] != 0) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) PreN[(16 * ti + kk + 4 * t) * RSBA_PLD + 16 * tj + mi] -= acc[t];
+              for (int t = 0; t < 4; ++t) vv[t] = scratch[(16 * ti + kk + 4 * t) * RSBA_PB + 16 * tj + mi];
+            } else {
+              if (lane == 0) {
+                const long long t1 = wall_clock64();
+                while (__hip_atomic_load(gate.ready + 1 + nb0 / gate.cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gate.tag) {
+                  __builtin_amdgcn_s_sleep(4);
+                  if (wall_clock64() - t1 > (gate.budget > 0 ? gate.budget : RSBA_STALL_TICKS)) { __hip_atomic_store(&s_w7ok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+                }
+              }
+              __builtin_amdgcn_wave_barrier();
+              double raw[4], du[4];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const int gi = nb0 + 16 * ti + kk + 4 * t, gj = nb0 + 16 * tj + mi;
+                const bool in = gi < nreal && gj < nreal;
+                raw[t] = in ? __hip_atomic_load(&S[trs ? (size_t)gj * nreal + gi : (size_t)gi * nreal + gj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                du[t] = in && gi == gj ? __hip_atomic_load(&red[L.diagU() + gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+              }
+#pragma unroll
+              for (int t = 0; t < 4; ++t) vv[t] = sys_pre(nb0 + 16 * ti + kk + 4 * t, nb0 + 16 * tj + mi, raw[t], du[t]);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            double* e = &PreN[(16 * ti + kk + 4 * t) * RSBA_PLD + 16 * tj + mi];
+            *e = p > 0 ? (*e - acc[t]) + vv[t] : *e - acc[t];
+          }
         }
         __syncthreads();   // [E] the next diagonal block is ready: wave 0 goes on
+        if (s_w7ok == 0) { stalled = true; break; }   // (a stage that did not come)
       }
       // X(p+1, p) is on its way to memory: wave 4 waits for the acknowledgements and tells the row workgroups;
       // nobody else does (this workgroup's next strip does not come from those stores)
