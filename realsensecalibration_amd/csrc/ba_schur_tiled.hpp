@@ -1137,6 +1137,69 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
 
+// A reducer's sum over its tile's groups, in group order: v[k] += group q's component comp(k) of this thread's slot, q = 0, 1, ...
+// The groups are taken as they arrive, and the flags of up to 64 groups ahead are looked at in ONE trip to memory (a wavefront,
+// a flag per lane): a poll per batch of four, as it used to be, was a second dependent trip per batch — fourteen batches of ~5 us
+// were as long as a whole stage, so the reducers ran behind the groups all the time and the stage's flag waited 15 - 27 us for
+// them after its last partial block.  Batches of eight, four, or — among the tile's last eight groups — whatever is there; the
+// additions are sequential in q whatever the batches, so the sum does not depend on them.  false: gave up (cannot happen, see
+// GroupReduce; never hang).
+template <int NC, typename CompOf>
+__device__ __forceinline__ bool ReduceGroupsInOrder(const SchurArgs& a, const SchurSeg& sg, const double* __restrict__ in, CompOf comp, double* v, int nc_live) {
+  __shared__ int s_run;
+  const int tid = OpaqueTid();
+  const int* gf = a.grp_flag + sg.tile_grp0;
+  const int ng = sg.tile_ngrp;
+  const long long t_begin = wall_clock64();
+  int known = 0, q = 0;
+  bool all_ok = true;
+  while (q < ng) {
+    const int want = ng - q > 8 ? q + 4 : q + 1;
+    while (known < want) {
+      if (tid < 64) {
+        const int idx = known + tid;
+        const int up = idx < ng && __hip_atomic_load(&gf[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch ? 1 : 0;
+        const unsigned long long m = __ballot(up);
+        int run = m == ~0ull ? 64 : __builtin_ctzll(~m);
+        if (known + run < want && wall_clock64() - t_begin > RSBA_STALL_TICKS) run = -1;
+        if (tid == 0) s_run = run;
+      }
+      __syncthreads();
+      const int run = s_run;
+      __syncthreads();
+      if (run < 0) { all_ok = false; known = ng; break; }
+      known += run;
+      if (known < want) __builtin_amdgcn_s_sleep(4);
+    }
+    const int avail = known - q;
+    if (avail >= 8) {
+      double x[8][NC];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) x[u][k] = k < nc_live ? __hip_atomic_load(&in[(size_t)(q + u) * RSBA_PART * 256 + comp(k) * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) v[k] += x[u][k];
+      q += 8;
+    } else {
+      const int nb = avail < 4 ? avail : 4;
+      double x[4][NC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) x[u][k] = (u < nb && k < nc_live) ? __hip_atomic_load(&in[(size_t)(q + u) * RSBA_PART * 256 + comp(k) * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) if (u < nb) v[k] += x[u][k];
+      q += nb;
+    }
+  }
+  return all_ok;
+}
+
 // Reducer workgroup of a PAIR tile: quadrant (qr, qc) = (word_begin >> 1, word_begin & 1) of every camera pair's 6 x 6 block.
 // The K factors (blkdiag(J_l, I) on either side) couple nothing across the four 3 x 3 quadrants, so a reducer that adds the
 // quadrant's nine components over the tile's groups can finish them itself: no tile sum, no election of a last reducer, no
@@ -1145,27 +1208,9 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
 // leave with agent-scope stores whose acknowledgements it awaits before it arrives at the stage counter: no fence either.
 // Same sums in the same order as the tile finisher's (groups in order, four at a time), same products.
 __device__ __forceinline__ void ReducerQuadrant(const SchurArgs& a, const SchurSeg& sg, int ticket) {
-  __shared__ int s_qflag;
   const int tid = OpaqueTid();
   const int qr = sg.word_begin >> 1, qc = sg.word_begin & 1;
   const int cbase = 18 * qr + 3 * qc;   // component 6 (3 qr + i) + 3 qc + j = cbase + 6 i + j
-  const int* gf = a.grp_flag + sg.tile_grp0;
-  const long long t_begin = wall_clock64();
-  auto wait_groups = [&](int q0, int q1) {   // whole workgroup; false: gave up (cannot happen, see GroupReduce; never hang)
-    if (tid == 0) {
-      int ok = 1;
-      for (int q = q0; q < q1 && ok; ++q)
-        while (__hip_atomic_load(&gf[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
-          __builtin_amdgcn_s_sleep(4);
-          if (wall_clock64() - t_begin > RSBA_STALL_TICKS) { ok = 0; break; }
-        }
-      s_qflag = ok;
-    }
-    __syncthreads();
-    const int ok = s_qflag;
-    __syncthreads();
-    return ok != 0;
-  };
   const int ia = tid >> 4, ib = tid & 15;
   const int cam_a = RSBA_TG * sg.ga + ia, cam_b = RSBA_TG * sg.gb + ib;
   const bool live = cam_a < a.C && cam_b < a.C && !(sg.ga == sg.gb && ia >= ib);
@@ -1179,27 +1224,11 @@ __device__ __forceinline__ void ReducerQuadrant(const SchurArgs& a, const SchurS
   }
   double keep = 1.0;
   if (a.cam_free != nullptr && live) keep = a.cam_free[cam_a] * a.cam_free[cam_b] == 0.0 ? 0.0 : 1.0;   // a constant camera couples to nobody
-  bool all_ok = true;
   double v[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) v[k] = 0.0;
   const double* in = a.grp_sum + (size_t)sg.tile_grp0 * RSBA_PART * 256 + (size_t)cbase * 256 + tid;
-  int q = 0;
-  for (; q + 3 < sg.tile_ngrp; q += 4) {
-    all_ok = wait_groups(q, q + 4) && all_ok;
-    double x[4][9];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int k = 0; k < 9; ++k)
-        x[u][k] = __hip_atomic_load(&in[(size_t)(q + u) * RSBA_PART * 256 + (6 * (k / 3) + k % 3) * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) v[k] = (((v[k] + x[0][k]) + x[1][k]) + x[2][k]) + x[3][k];
-  }
-  if (q < sg.tile_ngrp) all_ok = wait_groups(q, sg.tile_ngrp) && all_ok;
-  for (; q < sg.tile_ngrp; ++q)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) v[k] += __hip_atomic_load(&in[(size_t)q * RSBA_PART * 256 + (6 * (k / 3) + k % 3) * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool all_ok = ReduceGroupsInOrder<9>(a, sg, in, [](int k) { return 6 * (k / 3) + k % 3; }, v, 9);
   if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();   // the tile's groups are complete and added
   if (!all_ok && tid == 0) __hip_atomic_store(a.tree_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (live) {
@@ -1238,53 +1267,19 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
   const int tid = OpaqueTid();
   int* cnt_groups = a.sync_cnt + a.ngrp + sg.tile;
   int* cnt_red = a.sync_cnt + a.ngrp + a.ntiles + 16 + sg.tile;
-  // The groups are added in group order AS THEY ARRIVE (per-group flags), four at a time: when the tile's last group is
-  // summed, a reducer has one batch left to read instead of all ~30 group sums (that read sat at the tail of every stage,
-  // and the stages are what the Cholesky waits for).  The sums are read with agent-scope loads (like the flags: coherent
-  // without invalidating this XCD's L2 under the pair tiles running beside); the order of the additions is the old one.
+  // The groups are added in group order AS THEY ARRIVE (ReduceGroupsInOrder): when the tile's last group is summed, a reducer has
+  // one batch left to read instead of all ~30 group sums (that read sat at the tail of every stage, and the stages are what the
+  // Cholesky waits for).  The sums are read with agent-scope loads (like the flags: coherent without invalidating this XCD's L2
+  // under the pair tiles running beside).
   const int c0 = sg.word_begin, c1 = sg.word_end;
   double* ts = a.tile_sum + (size_t)sg.tile * RSBA_PART * 256 + tid;
-  const int* gf = a.grp_flag + sg.tile_grp0;
-  const long long t_begin = wall_clock64();
-  auto wait_groups = [&](int q0, int q1) {   // whole workgroup; false: gave up (cannot happen, see GroupReduce; never hang)
-    if (tid == 0) {
-      int ok = 1;
-      for (int q = q0; q < q1 && ok; ++q)
-        while (__hip_atomic_load(&gf[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
-          __builtin_amdgcn_s_sleep(4);
-          if (wall_clock64() - t_begin > RSBA_STALL_TICKS) { ok = 0; break; }
-        }
-      s_flag = ok;
-    }
-    __syncthreads();
-    const int ok = s_flag;
-    __syncthreads();
-    return ok != 0;
-  };
   bool all_ok = true;
   {
-    // up to RSBA_RED_COMPS components of this slot over all groups, in group order, four groups in flight
     double v[RSBA_RED_COMPS];
 #pragma unroll
     for (int i = 0; i < RSBA_RED_COMPS; ++i) v[i] = 0.0;
     const double* in = a.grp_sum + (size_t)sg.tile_grp0 * RSBA_PART * 256 + (size_t)c0 * 256 + tid;
-    int q = 0;
-    for (; q + 3 < sg.tile_ngrp; q += 4) {
-      all_ok = wait_groups(q, q + 4) && all_ok;
-      double x[4][RSBA_RED_COMPS];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int i = 0; i < RSBA_RED_COMPS; ++i)
-          x[u][i] = (c0 + i < c1) ? __hip_atomic_load(&in[(size_t)(q + u) * RSBA_PART * 256 + i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-      for (int i = 0; i < RSBA_RED_COMPS; ++i) v[i] = (((v[i] + x[0][i]) + x[1][i]) + x[2][i]) + x[3][i];
-    }
-    if (q < sg.tile_ngrp) all_ok = wait_groups(q, sg.tile_ngrp) && all_ok;
-    for (; q < sg.tile_ngrp; ++q)
-#pragma unroll
-      for (int i = 0; i < RSBA_RED_COMPS; ++i)
-        if (c0 + i < c1) v[i] += __hip_atomic_load(&in[(size_t)q * RSBA_PART * 256 + i * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    all_ok = ReduceGroupsInOrder<RSBA_RED_COMPS>(a, sg, in, [](int k) { return k; }, v, c1 - c0);
     if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();   // the tile's groups are complete and added
 #pragma unroll
     for (int i = 0; i < RSBA_RED_COMPS; ++i) if (c0 + i < c1) __hip_atomic_store(&ts[(c0 + i) * 256], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1301,21 +1296,16 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
     __hip_atomic_store(cnt_red, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (sg.self == 3) {
+  {   // (a self tile: the pair tiles' reducers are ReducerQuadrant)
     double v[RSBA_PART];
 #pragma unroll
     for (int i = 0; i < RSBA_PART; ++i) v[i] = ts[i * 256];
     FinishSelfSlot(a.C, sg.ga, v, a.camc, a.red, a.L, a.cam_free);
     if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
     if (a.self_only) return;
-  } else {
-    double v[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) v[i] = ts[i * 256];
-    FinishPairSlot(a.C, sg.ga, sg.gb, tid, v, a.camc, a.red, a.L, a.cam_free);
   }
   const bool stage_done = StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0);
-  if (sg.self == 3 && a.all_self && a.tag && tid == 0) SelfTileArrive(a.sync_cnt, a.ngrp, a.ntiles, a.last_group + 1, a.ready, a.tag);
+  if (a.all_self && a.tag && tid == 0) SelfTileArrive(a.sync_cnt, a.ngrp, a.ntiles, a.last_group + 1, a.ready, a.tag);
   if (!stage_done) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();

@@ -568,6 +568,8 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       for (int t = stage_tile[g]; t < stage_tile[g + 1]; ++t) tiles_g.push_back(t);
       // the stage's tiles interleaved by position, so that the stage as a whole runs long blocks first, short ones last
       // and all its tiles end together
+      // (the self tile's segments ahead of the pair tiles', so that its slower finish — seven reducers, a tile sum — ends early: 0.400
+      //  against 0.3975 ms, the stage's pair segments then all sit at its end)
       std::vector<std::pair<double, int>> ord;
       for (int t : tiles_g) for (int q = tsp[t]; q < tsp[t + 1]; ++q) ord.push_back({(q - tsp[t] + 0.5) / (tsp[t + 1] - tsp[t]), q});
       std::stable_sort(ord.begin(), ord.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
