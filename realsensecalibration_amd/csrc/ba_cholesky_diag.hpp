@@ -801,7 +801,10 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       }
       RSBA_DC_STAMP(3);
       if (staged && kb % gate.cols == 0) {
-        if (!WaitReady(gate.ready + 1 + kb / gate.cols, gate.tag, nullptr, gate.budget)) { stalled = true; break; }
+        // (the stage's flag, then ONE acquire by the wavefront that saw it — WaitFlagWG; WaitReady's __threadfence() is a write-back
+        //  and an invalidate of the L2 in each of the eight wavefronts: the panels 3, 6 and 9 of the row workgroups took 4 - 7 us
+        //  longer than the others, and the blocks they hand over were late)
+        if (!WaitFlagWG(gate.ready + 1 + kb / gate.cols, gate.tag, f.error, gate.budget > 0 ? gate.budget : RSBA_STALL_TICKS)) { stalled = true; break; }
       }
       {
         const int nsplit = (p > 0 && nh <= 2) ? 4 : ((p > 0 && nh <= 4) ? 2 : 1);
