@@ -52,6 +52,10 @@ RSBA_TRACE=2 RSBA_TRACE_FILE=$O/wg_cfg5.txt python3 bench.py --config cfg5 --poi
 python3 tools/schur_timeline_summary.py $O/wg_cfg5.txt > $O/r03_schur_block_timeline_cfg5_62500.txt
 RSBA_TRACE=3 python3 bench.py --no-cpu-baseline --steps 100 --warmup 5 --no-events 2>&1 | grep "rsba\[ring\]" | tail -1 > $O/r03_step_ring.txt
 RSBA_HOSTPROF=1 python3 bench.py --no-cpu-baseline --steps 100 --warmup 5 --no-events 2>&1 | grep "rsba\[hostprof\]" | tail -1 >> $O/r03_step_ring.txt
+# the panels of the 64-camera factorisation beside the Schur kernel (tools/mc_chain.py: workgroup 0's chain, then the row workgroups)
+RSBA_MC_TRACE=1 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | grep "rsba\[mc\]" | tail -72 > $O/mc_raw.txt
+python3 tools/mc_chain.py $O/mc_raw.txt > $O/r03_cholesky_diag_timeline_pipelined.txt 2>&1
+rm -f $O/mc_raw.txt
 # the diagonal chain of the tiled Cholesky (256 cameras): stamps per tile column, then the tiles that share a CU
 {
   echo "# k_chol_tiles_persistent, 256 cameras: the diagonal chain's stamps of the latest launch (us since its first stamp), one row per tile row J."
