@@ -29,6 +29,10 @@
 // workgroups need 13 - 15 us per panel (every global round trip costs 2.3 - 8 us beside the Schur kernel), so it waits for
 // rows_ready in about half of the panels.  DESIGN.md section 4, "round 2", item 5 has the measurements and what was dropped.
 //
+// Round 3: the stage of block p + 1's own columns of S is waited for where it is needed — in the panel's tail, for the next diagonal
+// block's entries — not in front of panel p's update; T(p) is published as soon as its stores are acknowledged; a row workgroup
+// acquires once behind a stage's flag.  0.4055 -> 0.3936 ms per LM iteration at 64 cameras ("Round 3").
+//
 // Same arithmetic per entry as the multi kernel's (products over fixed K slices, added in a fixed order): bitwise
 // reproducible, identical on every rank.  All waits carry a budget: a stall gives up (RES_STALL), never hangs.
 #pragma once

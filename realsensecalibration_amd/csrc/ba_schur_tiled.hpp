@@ -21,8 +21,9 @@
 //   * block(a,b) = E_a' (N_a Vinv N_b') E_b with E = [A K | Pj]; the per-camera 3x3 factor K (left Jacobian
 //     of SO(3)) is pulled out of the sum over points and applied once per pair by the tile's finisher.
 //   * every workgroup writes its 256 x 42 partial sums; they are added inside the same launch, in a fixed order
-//     (bitwise reproducible): groups of RSBA_GRP segments by their last arriver, tiles by reducer workgroups, whose
-//     last one applies K and writes the tile's blocks of S (GroupReduce / ReducerSegment below).
+//     (bitwise reproducible): groups of RSBA_GRP (RSBA_GRP_SMALL up to 64 cameras) segments by their last arriver, tiles by
+//     reducer workgroups — a pair tile's one per 3 x 3 quadrant of its blocks, each applying K and writing its part of S itself
+//     (ReducerQuadrant); a self tile's by slices of the components, the last one finishing the tile (ReducerSegment).
 //   * everything that is a sum over ONE camera's observations (diagonal blocks, damping diagonal, g_c, rhs
 //     correction) is a "self" segment of the same launch (SelfSegment).
 //   * the launch works through a list ordered by camera group ("stage") and publishes ready[1 + g] when group g's
