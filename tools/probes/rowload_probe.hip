@@ -6,7 +6,8 @@
 //   pattern 1: lane (mi, kk) takes doubles 4 kk .. 4 kk + 3 of each 16-column half slab in two 16-byte loads back to back: an
 //              instruction touches one line per row, a line is touched by two instructions;
 //   pattern 2: pattern 0's addresses, all first touches first (v2-major);
-//   pattern 3: row-wise (8 lanes per line, every line touched once): what the memory system can do for this volume.
+//   pattern 3: row-wise (8 lanes per line, every line touched once): what the memory system can do for this volume;
+//   pattern 4: the rows stored k-major, fetched in the lane layout of the matrix cores (four whole lines per instruction).
 // Optionally beside a chip-filling streaming kernel on another stream (argv[1] = 1).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -63,6 +64,16 @@ __global__ void __launch_bounds__(512) k_rows(const double* __restrict__ mats, i
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (sa + i < sb) { const d2_t x = *reinterpret_cast<const d2_t*>(arow + (sa + i) * 32 + 2 * v2); pf[i][2 * v2] = x[0]; pf[i][2 * v2 + 1] = x[1]; }
+      } else if (kPattern == 4) {
+        // the rows stored k-major (AT[k][row]): lane (mi, kk) takes k = 8 kk + u of row mi in eight 8-byte loads — an instruction
+        // touches four whole lines (sixteen consecutive rows of four k)
+        const double* acol = A + (size_t)(8 * kk) * n + nb0 + h * 16 + mi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (sa + i < sb) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pf[i][u] = acol[(size_t)((sa + i) * 32 + u) * n];
+          }
       } else {
         // 16 rows x (sb - sa) slabs x 256 bytes: an instruction takes 8 rows x one line (lane & 7: the 16-byte chunk)
 #pragma unroll
@@ -99,13 +110,14 @@ int main(int argc, char** argv) {
   if (noise) { CK(hipMalloc(&src, big * 8)); CK(hipMemset(src, 0, big * 8)); }
   std::vector<long long> ht(nmat);
   for (int p : {4, 8, 10}) {
-    for (int pat = 0; pat < 4; ++pat) {
+    for (int pat = 0; pat < 5; ++pat) {
       CK(hipDeviceSynchronize());
       if (noise) k_stream<<<512, 256, 0, A>>>(src, big, out, noise);
       if (pat == 0) k_rows<0><<<1, 512, 0, B>>>(mats, nmat, n, p, t, out);
       if (pat == 1) k_rows<1><<<1, 512, 0, B>>>(mats, nmat, n, p, t, out);
       if (pat == 2) k_rows<2><<<1, 512, 0, B>>>(mats, nmat, n, p, t, out);
       if (pat == 3) k_rows<3><<<1, 512, 0, B>>>(mats, nmat, n, p, t, out);
+      if (pat == 4) k_rows<4><<<1, 512, 0, B>>>(mats, nmat, n, p, t, out);
       CK(hipStreamSynchronize(B));
       CK(hipMemcpy(ht.data(), t, nmat * 8, hipMemcpyDeviceToHost));
       CK(hipDeviceSynchronize());
