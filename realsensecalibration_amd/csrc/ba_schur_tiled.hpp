@@ -76,6 +76,7 @@ struct TiledSchur {
   double* grp_sum = nullptr;                // [ngrp][42][256] sums of RSBA_GRP consecutive segments
   double* tile_sum = nullptr;               // [ntiles][42][256]
   int* tree_error = nullptr;
+  int* error_flag = nullptr;                // where the reducers report a time-out when the solver has a host-mapped result block (else tree_error[0])
   int* grp_flag = nullptr;                  // [ngrp] launch number of the latest complete group sum (reducers)
   int epoch = 0;                            // launches so far
   int* sync_cnt = nullptr;                  // arrival counters, self-resetting: [ngrp] group members, [ntiles] groups done, [16] stage tiles, [ntiles] reducers done

@@ -105,7 +105,9 @@ class KernelTimer {
   void Add(const char* name, double ms) { auto& st = stats_[name]; st.first += 1; st.second += ms; }
   void Reset() { Collect(); stats_.clear(); for (hipEvent_t e : pool_) (void)hipEventDestroy(e); pool_.clear(); }
   void Reserve(int n) { while ((int)pool_.size() < n) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) break; pool_.push_back(e); } }
-  const std::map<std::string, std::pair<int64_t, double>>& stats() const { return stats_; }
+  // (the events of the last run are read HERE, when somebody asks — not at the end of the run, where ~5 us per pair were part of
+  //  what a caller times around rsba_solver_run)
+  const std::map<std::string, std::pair<int64_t, double>>& stats() const { const_cast<KernelTimer*>(this)->Collect(); return stats_; }
  private:
   hipEvent_t Get() {
     if (pool_.empty()) Reserve(64);
@@ -1157,7 +1159,7 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   a.C = ts.C; a.P = ts.P; a.nwords = ts.nwords; a.camc = s->camc[x]; a.cam_free = s->cam_free; a.segs = ts.segs; a.cam_mask = ts.cam_mask; a.ptdata = ts.ptdata;
   a.cam_prefix = ts.cam_prefix; a.cam_ptr = ts.cam_ptr; a.sq_cm = ts.sq_cm2[x]; a.u_cm = ts.u_cm; a.v_cm = ts.v_cm; a.partial = ts.partial;
   a.grp_sum = ts.grp_sum; a.sync_cnt = ts.sync_cnt; a.ngrp = ts.ngrp; a.ntiles = ts.ntiles; a.segs_ordered = ts.segs_ordered; a.small_flag = ts.small_flag; a.last_group = ts.ngroups - 1; a.tile_sum = ts.tile_sum;
-  a.tree_error = ts.tree_error; a.ticket = ts.tree_error + 1;
+  a.tree_error = ts.error_flag ? ts.error_flag : ts.tree_error; a.ticket = ts.tree_error + 1;
   a.ready = ts.ready; a.tag = tag; a.self_only = 0; a.red = s->red; a.L = s->L; a.nblocks_pp = ts.scal_blocks; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
   a.grp_flag = ts.grp_flag; a.epoch = ++ts.epoch;
@@ -1368,7 +1370,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       const RedLayout& L = s->L;
       for (int g = 0; g < ts.nstages; ++g) {
         const int r0 = 6 * RSBA_TG * g, r1 = std::min(6 * RSBA_TG * (g + 1), n), rows = r1 - r0;
-        k_wait_stage<<<1, 64, 0, s->sR>>>(ts.ready + 1 + g, tag, ts.tree_error);
+        k_wait_stage<<<1, 64, 0, s->sR>>>(ts.ready + 1 + g, tag, ts.error_flag ? ts.error_flag : ts.tree_error);
         COMMCHK(s->comm->GroupStart());
         COMMCHK(s->comm->SumDoubles(s->red + L.S() + (size_t)r0 * n, (size_t)rows * n, s->sR));
         COMMCHK(s->comm->SumDoubles(s->red + L.gc() + r0, rows, s->sR));
@@ -1924,8 +1926,10 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
   s->hostprof = getenv("RSBA_HOSTPROF") != nullptr;
   if (hipHostMalloc((void**)&s->res_host, (RES_SIZE + 8) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { rsba::FreeSolver(s); return RSBA_ERR_HIP; }
   memset(s->res_host, 0, (RES_SIZE + 8) * sizeof(double));   // [RES_SIZE]: the factorisation's "resident" word (StageGate)
-  if (p->model == RSBA_MODEL_POINTS) rc = rsba::UploadPoints(s);
-  else {
+  if (p->model == RSBA_MODEL_POINTS) {
+    rc = rsba::UploadPoints(s);
+    if (rc == RSBA_OK && s->tiled.tree_error) s->tiled.error_flag = reinterpret_cast<int*>(s->res_host + RES_SIZE + 4);   // (zeroed above)
+  } else {
     s->eliminate_times = rsba::MarkerSchurDevice::Wanted(*p, opt.schur_impl);
     rc = s->eliminate_times ? s->marker_schur.Upload(*p) : s->marker.Upload(*p);
     if (s->eliminate_times && rc == RSBA_ERR_UNSUPPORTED) {
@@ -1977,8 +1981,12 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
     if (rc == RSBA_OK && s->tiled.tree_error) {
       // a reducer workgroup of the Schur kernel gave up waiting for its tile (cannot happen by construction): the sums
       // it produced are garbage, so is the result
+      // (the flag sits in the host-mapped result block: every kernel that could raise it has completed before the last result
+      //  was posted; a blocking 4-byte copy here was ~20 us of every run)
       int bad = 0;
-      if (hipMemcpy(&bad, s->tiled.tree_error, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || bad) {
+      if (s->tiled.error_flag) bad = *(volatile int*)s->tiled.error_flag;
+      else if (hipMemcpy(&bad, s->tiled.tree_error, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
+      if (bad) {
         fprintf(stderr, "rsba: in-kernel reduction timed out\n");
         rc = RSBA_ERR_HIP;
       }
@@ -1999,7 +2007,6 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
                               [&]() { return s->marker.Step(s->stream, s->opt, mk_radius, false, s->res_host, s->timer); });
     sum.minimizer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
-  s->timer.Collect();
   s->final_cost = sum.final_cost;
   s->last_summary = sum; s->has_run = true;
   if (sum_out) *sum_out = sum;
