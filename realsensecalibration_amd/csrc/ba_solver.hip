@@ -1102,9 +1102,20 @@ static int DownloadPoints(const rsba_solver* s, const double* dev, double* dst) 
   return RSBA_OK;
 }
 
+// The uploaded start back into the working state: cameras and points in ONE launch (two hipMemcpyAsync cost the host 25 - 30 us at
+// the start of every run — the runtime's copy path — where a kernel launch is 3)
+__global__ void __launch_bounds__(256) k_reset_state(double* __restrict__ cam, const double* __restrict__ cam0, size_t ncam,
+                                                     double* __restrict__ pts, const double* __restrict__ pts0, size_t npts) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < ncam + npts; i += (size_t)gridDim.x * 256) {
+    if (i < ncam) cam[i] = cam0[i];
+    else pts[i - ncam] = pts0[i - ncam];
+  }
+}
+
 static int ResetPoints(rsba_solver* s) {
-  HIPCHK(hipMemcpyAsync(s->cam[0], s->cam0, 6 * s->C * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  HIPCHK(hipMemcpyAsync(s->pts[0], s->pts0, 3 * (size_t)s->P * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  const size_t ncam = 6 * (size_t)s->C, npts = 3 * (size_t)s->P;
+  k_reset_state<<<(unsigned)std::min<size_t>((ncam + npts + 255) / 256, 2048), 256, 0, s->stream>>>(s->cam[0], s->cam0, ncam, s->pts[0], s->pts0, npts);
+  HIPCHK(hipGetLastError());
   s->cur = 0;
   s->tiled.lin_valid = false;   // a run starts with a full point pass at the uploaded point
   s->tiled.pt_valid = false;
