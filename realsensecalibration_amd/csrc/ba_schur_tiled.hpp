@@ -63,7 +63,7 @@ struct SchurSeg {
 };
 #define RSBA_GRP 8          // segments per reduction group (more than 64 cameras)
 #define RSBA_GRP_SMALL 4    // ... up to 64 cameras
-#define RSBA_RED_COMPS 6     // components per reducer workgroup: 6 reducers per pair tile (36), 7 per self tile (42)
+#define RSBA_SELF_SETS 6      // reducers of a self tile: the sets of its 42 components that the K factors do not couple (ReducerSelfSet)
 #define RSBA_DIRECT_GROUPS 4  // tiles with at most this many groups are finished by their last group, without reducers
 
 struct TiledSchur {
@@ -74,8 +74,8 @@ struct TiledSchur {
   double* ptdata = nullptr;                 // [P][12]
   double* partial = nullptr;                // [nseg][42][256]
   double* grp_sum = nullptr;                // [ngrp][42][256] sums of RSBA_GRP consecutive segments
-  double* tile_sum = nullptr;               // [ntiles][42][256]
   int* tree_error = nullptr;
+  int self_arrivals = 0;                    // arrivals the self tiles make at the first step's counter (SelfTileArrive): one per tile, or one per reducer
   int* error_flag = nullptr;                // where the reducers report a time-out when the solver has a host-mapped result block (else tree_error[0])
   int* grp_flag = nullptr;                  // [ngrp] launch number of the latest complete group sum (reducers)
   int epoch = 0;                            // launches so far
@@ -474,10 +474,11 @@ __device__ __forceinline__ void TreeSum(const double* __restrict__ in, int n, do
 //     to arrive adds the group's blocks in segment order (the sums do not depend on who arrives last) into grp_sum and
 //     counts the group as done.
 //  2. One CU pulls ~30 GB/s out of memory, so a single workgroup adding a tile's 30-40 group sums (2-3 MB) was measured
-//     at 65-105 us, at the tail of every stage.  Instead each tile has RSBA_NRED reducer workgroups, placed in block order
-//     right behind the stage's compute blocks (so everything they wait for has been dispatched before them: they can
-//     spin without deadlock).  Each waits for the tile's groups, adds a slice of the components over all groups into
-//     tile_sum, and the last reducer to finish applies the K factors and writes the tile's blocks of S.
+//     at 65-105 us, at the tail of every stage.  Instead each tile has reducer workgroups (four per pair tile, six per self
+//     tile), placed in block order right behind the stage's compute blocks (so everything they wait for has been dispatched
+//     before them: they can spin without deadlock).  Each adds, over the tile's groups as they arrive, a set of components the
+//     K factors do not couple with the others — a 3 x 3 quadrant of the pairs' blocks, a part of a camera's own sums — applies K
+//     and writes its part of S (ReducerQuadrant, ReducerSelfSet).
 // The eight XCDs' L2s are not coherent with each other inside a kernel, and an agent-scope fence costs a write-back /
 // invalidate of a whole L2 (measured: 2x on this kernel when every workgroup fenced).  So partial sums are written with
 // agent-scope (sc1) stores that go through to memory, ordered by waiting for the stores' acknowledgements before a
@@ -677,6 +678,7 @@ struct SchurArgs {
   double* __restrict__ grp_sum;
   int* __restrict__ sync_cnt;
   int ngrp, ntiles, last_group;
+  int self_arrivals;               // how many arrivals complete the self tiles (all_self)
   int all_self;                    // 1: the self tiles' finishers count themselves and the last one publishes ready[9] (first step: every
                                    // camera's diag U is known -> the factorisation's Jacobi scale, see TiledSchur::segs_ordered_first)
   const SchurSeg* __restrict__ segs_ordered;   // the work list in launch order
@@ -689,7 +691,6 @@ struct SchurArgs {
   int nblocks_pp;
   const double* __restrict__ block_scal;
   double* __restrict__ gmax_p;
-  double* __restrict__ tile_sum;   // [ntiles][42][256]
   int* tree_error;                 // set when a reducer gave up waiting (cannot happen; never hang)
   int* ticket;                     // next entry of the work list (block_seg): counts on from launch to launch, ticket_base is where this one starts
   unsigned ticket_base;
@@ -1133,7 +1134,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
   if (a.self_only) return;
   const bool stage_done = StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0);
-  if (a.all_self && a.tag && tid == 0) SelfTileArrive(a.sync_cnt, a.ngrp, a.ntiles, a.last_group + 1, a.ready, a.tag);
+  if (a.all_self && a.tag && tid == 0) SelfTileArrive(a.sync_cnt, a.ngrp, a.ntiles, a.self_arrivals, a.ready, a.tag);
   if (!stage_done) return;
   if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
@@ -1260,57 +1261,126 @@ __device__ __forceinline__ void ReducerQuadrant(const SchurArgs& a, const SchurS
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
 
-// Reducer workgroup `part` of tile sg.tile (see GroupReduce): components [word_begin, word_end) of the tile sums; the
-// last reducer finishes the tile, the last tile of a stage publishes it for the Cholesky that may be waiting for these
-// columns.  The self tile of the last group also folds the point pass' per-block scalars (cost, |X|^2, failures, max|g_p|).
-__device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSeg& sg, int ticket) {
-  if (sg.self == 2) { ReducerQuadrant(a, sg, ticket); return; }
-  __shared__ int s_flag;
+// Reducer workgroup of a SELF tile: set word_begin of the tile's 42 components (per camera, in 16 slices: lane (ia, s)).  The K
+// factor — T' . T with T = blkdiag(K, I) on the symmetric core, K' on the rotation halves of g_c and the right-hand-side correction,
+// K' U K on the rotation block of U — couples nothing across these six sets, so the reducer that adds a set over the tile's groups
+// finishes it itself, as ReducerQuadrant does for the pair tiles (no tile sum, no last reducer, no second fetch: the self tile's
+// finish was 11 - 13 us behind its reducers, and at the last stage the kernel ended with it):
+//   0: core rows / columns 0..2 (6)   1: core rows 0..2 x columns 3..5 (9)   2: core rows / columns 3..5 (6)
+//   3: U rotation block (6)   4: g_c and correction, rotation halves (3 + 3)   5: diag U, g_c, correction, translation halves (9)
+// Same sums in the same order as FinishSelfSlot's (groups in order, then the sixteen slices by the same shuffle tree), same products.
+__device__ const int kSelfSetComp[RSBA_SELF_SETS][9] = {
+    {0, 1, 2, 6, 7, 11, 0, 0, 0}, {3, 4, 5, 8, 9, 10, 12, 13, 14}, {15, 16, 17, 18, 19, 20, 0, 0, 0},
+    {21, 22, 23, 24, 25, 26, 0, 0, 0}, {30, 31, 32, 36, 37, 38, 0, 0, 0}, {27, 28, 29, 33, 34, 35, 39, 40, 41}};
+__device__ __forceinline__ void ReducerSelfSet(const SchurArgs& a, const SchurSeg& sg, int ticket) {
   const int tid = OpaqueTid();
-  int* cnt_groups = a.sync_cnt + a.ngrp + sg.tile;
-  int* cnt_red = a.sync_cnt + a.ngrp + a.ntiles + 16 + sg.tile;
-  // The groups are added in group order AS THEY ARRIVE (ReduceGroupsInOrder): when the tile's last group is summed, a reducer has
-  // one batch left to read instead of all ~30 group sums (that read sat at the tail of every stage, and the stages are what the
-  // Cholesky waits for).  The sums are read with agent-scope loads (like the flags: coherent without invalidating this XCD's L2
-  // under the pair tiles running beside).
-  const int c0 = sg.word_begin, c1 = sg.word_end;
-  double* ts = a.tile_sum + (size_t)sg.tile * RSBA_PART * 256 + tid;
-  bool all_ok = true;
+  const int set = sg.word_begin, nc = sg.word_end - sg.word_begin;
+  const int ia = tid >> 4, ib = tid & 15, cam_a = RSBA_TG * sg.ga + ia;
+  const bool live = cam_a < a.C;
+  double K[9];
   {
-    double v[RSBA_RED_COMPS];
+    const double* pk = a.camc + (size_t)(live ? cam_a : 0) * CC_STRIDE + CC_K;   // (camera constants: written before the launch)
 #pragma unroll
-    for (int i = 0; i < RSBA_RED_COMPS; ++i) v[i] = 0.0;
-    const double* in = a.grp_sum + (size_t)sg.tile_grp0 * RSBA_PART * 256 + (size_t)c0 * 256 + tid;
-    all_ok = ReduceGroupsInOrder<RSBA_RED_COMPS>(a, sg, in, [](int k) { return k; }, v, c1 - c0);
-    if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();   // the tile's groups are complete and added
-#pragma unroll
-    for (int i = 0; i < RSBA_RED_COMPS; ++i) if (c0 + i < c1) __hip_atomic_store(&ts[(c0 + i) * 256], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 9; ++i) K[i] = pk[i];
   }
+  const bool is_free = !(a.cam_free != nullptr && live && a.cam_free[cam_a] == 0.0);
+  int comp[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) comp[k] = kSelfSetComp[set][k];
+  double v[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) v[k] = 0.0;
+  const double* in = a.grp_sum + (size_t)sg.tile_grp0 * RSBA_PART * 256 + tid;
+  const bool all_ok = ReduceGroupsInOrder<9>(a, sg, in, [&](int k) { return comp[k]; }, v, nc);
+  if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();   // the tile's groups are complete and added
   if (!all_ok && tid == 0) __hip_atomic_store(a.tree_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (tid == 0) s_flag = __hip_atomic_fetch_add(cnt_red, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sg.nred - 1;
-  __syncthreads();
-  if (!s_flag) return;
-  // last reducer of the tile: every other reducer is past its wait, so both counters can go back to zero
-  if (tid == 0) {
-    __hip_atomic_store(cnt_groups, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(cnt_red, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  {   // (a self tile: the pair tiles' reducers are ReducerQuadrant)
-    double v[RSBA_PART];
+  // the sixteen slices of a camera (lanes ia * 16 .. ia * 16 + 15, contiguous inside a wave) in the fixed tree order of FinishSelfSlot
 #pragma unroll
-    for (int i = 0; i < RSBA_PART; ++i) v[i] = ts[i * 256];
-    FinishSelfSlot(a.C, sg.ga, v, a.camc, a.red, a.L, a.cam_free);
-    if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
-    if (a.self_only) return;
+  for (int off = 8; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] += __shfl_down(v[k], off, 16);
   }
-  const bool stage_done = StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0);
-  if (a.all_self && a.tag && tid == 0) SelfTileArrive(a.sync_cnt, a.ngrp, a.ntiles, a.last_group + 1, a.ready, a.tag);
+  if (ib == 0 && live) {
+    if (!is_free) {
+      // constant camera: zero block, gradient and damping diagonal (FinishSelfSlot)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v[k] = 0.0;
+    }
+    const size_t nc_s = a.L.nc;
+    double* Sd = a.red + a.L.S() + (size_t)(6 * cam_a) * nc_s + 6 * cam_a;
+    auto put = [&](double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    if (set == 0) {
+      const double c[9] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5]};
+      double tmp[9], blk[9];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) tmp[3 * p + q] = K[0 * 3 + p] * c[0 * 3 + q] + K[1 * 3 + p] * c[1 * 3 + q] + K[2 * 3 + p] * c[2 * 3 + q];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) blk[3 * p + q] = tmp[3 * p + 0] * K[0 * 3 + q] + tmp[3 * p + 1] * K[1 * 3 + q] + tmp[3 * p + 2] * K[2 * 3 + q];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = p; q < 3; ++q) { const double x = 0.5 * (blk[3 * p + q] + blk[3 * q + p]); put(&Sd[(size_t)p * nc_s + q], x); put(&Sd[(size_t)q * nc_s + p], x); }
+    } else if (set == 1) {
+      // c[k][j] = core (k, 3 + j) = v[3 k + j]: rows through K' on one side of the diagonal, columns through K on the other
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const double up = K[0 * 3 + p] * v[0 * 3 + j] + K[1 * 3 + p] * v[1 * 3 + j] + K[2 * 3 + p] * v[2 * 3 + j];   // block (p, 3 + j)
+          const double lo = v[0 * 3 + j] * K[0 * 3 + p] + v[1 * 3 + j] * K[1 * 3 + p] + v[2 * 3 + j] * K[2 * 3 + p];   // block (3 + j, p)
+          const double x = 0.5 * (up + lo);
+          put(&Sd[(size_t)p * nc_s + 3 + j], x); put(&Sd[(size_t)(3 + j) * nc_s + p], x);
+        }
+    } else if (set == 2) {
+      int t = 0;
+#pragma unroll
+      for (int p = 3; p < 6; ++p)
+#pragma unroll
+        for (int q = p; q < 6; ++q) { const double x = 0.5 * (v[t] + v[t]); put(&Sd[(size_t)p * nc_s + q], x); put(&Sd[(size_t)q * nc_s + p], x); ++t; }
+    } else if (set == 3) {
+      const double u00 = v[0], u01 = v[1], u02 = v[2], u11 = v[3], u12 = v[4], u22 = v[5];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const double k0 = K[0 * 3 + p], k1 = K[1 * 3 + p], k2 = K[2 * 3 + p];
+        put(&a.red[a.L.diagU() + 6 * cam_a + p], k0 * (u00 * k0 + u01 * k1 + u02 * k2) + k1 * (u01 * k0 + u11 * k1 + u12 * k2) + k2 * (u02 * k0 + u12 * k1 + u22 * k2));
+      }
+    } else if (set == 4) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        put(&a.red[a.L.gc() + 6 * cam_a + p], K[0 * 3 + p] * v[0] + K[1 * 3 + p] * v[1] + K[2 * 3 + p] * v[2]);
+        put(&a.red[a.L.corr() + 6 * cam_a + p], -(K[0 * 3 + p] * v[3] + K[1 * 3 + p] * v[4] + K[2 * 3 + p] * v[5]));
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        put(&a.red[a.L.diagU() + 6 * cam_a + 3 + p], v[p]);
+        put(&a.red[a.L.gc() + 6 * cam_a + 3 + p], v[3 + p]);
+        put(&a.red[a.L.corr() + 6 * cam_a + 3 + p], -v[6 + p]);
+      }
+    }
+  }
+  const bool lin = set == RSBA_SELF_SETS - 1 && sg.ga == a.last_group;   // this reducer also folds the point pass' per-block scalars
+  if (lin) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
+  if (a.self_only) return;
+  __builtin_amdgcn_s_waitcnt(0);   // the results are in memory (StageArrive's barrier collects everybody's; its fence: FinishLinearize's plain stores)
+  const bool stage_done = StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, lin && a.tag != 0);
+  if (a.all_self && a.tag && tid == 0) SelfTileArrive(a.sync_cnt, a.ngrp, a.ntiles, a.self_arrivals, a.ready, a.tag);
   if (!stage_done) return;
-  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
+}
+
+// A reducer workgroup of tile sg.tile (see GroupReduce): a quadrant of a pair tile's blocks or a set of a self tile's components, each
+// finished by the reducer that adds it; the last arrival of a stage publishes it for the Cholesky that may be waiting for these
+// columns.  (Until round 3 a reducer added a slice of the components into a tile sum and the last one fetched it back and
+// finished the tile: three dependent trips to memory more at the tail of every stage.)
+__device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSeg& sg, int ticket) {
+  if (sg.self == 2) ReducerQuadrant(a, sg, ticket);
+  else ReducerSelfSet(a, sg, ticket);
 }
 
 // K_A2: the Schur elimination kernel.  One workgroup per segment (a range of 64-point words of one tile), in block order

@@ -532,24 +532,28 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   for (int t = 0; t < ntiles; ++t) {
     const bool self = tab[3 * t + 2] != 0;
     const SchurSeg first = sg[tsp[t]];
-    const int red_comps = RSBA_RED_COMPS;
     // a pair tile: one reducer per 3 x 3 quadrant of the pairs' blocks, each finishing its own (ReducerQuadrant); a self tile:
     // slices of its 42 components, the last reducer finishes the tile
-    const int nv = self ? RSBA_PART : 36, nred = first.tile_ngrp <= RSBA_DIRECT_GROUPS ? 0 : (self ? (nv + red_comps - 1) / red_comps : 4);
+    // ... a self tile: one reducer per set of components the K factors do not couple (ReducerSelfSet: six sets of six or nine)
+    const int nred = first.tile_ngrp <= RSBA_DIRECT_GROUPS ? 0 : (self ? RSBA_SELF_SETS : 4);
     for (int q = tsp[t]; q < tsp[t + 1]; ++q) sg[q].nred = nred;
     for (int r = 0; r < nred; ++r) {
       SchurSeg e = first;
       e.self = self ? 3 : 2; e.nred = nred;
-      if (self) { e.word_begin = r * red_comps; e.word_end = std::min(nv, (r + 1) * red_comps); }
-      else { e.word_begin = r; e.word_end = r + 9; }   // (quadrant r; nine components)
+      e.word_begin = r; e.word_end = r + (self ? (r == 1 || r == 5 ? 9 : 6) : 9);   // (set / quadrant r and its number of components)
       red_of_tile[t].push_back((int)sg.size());
       sg.push_back(e);
     }
   }
   // arrivals at a stage's counter: its self tile, and per pair tile the finisher — or each of the four quadrant reducers
   {
-    std::vector<int> arrivals(ngroups, 1);
-    for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) arrivals[tab[3 * t]] += sg[tsp[t]].nred != 0 ? 4 : 1;
+    std::vector<int> arrivals(ngroups, 0);
+    self_arrivals = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      const int n_t = sg[tsp[t]].nred != 0 ? sg[tsp[t]].nred : 1;
+      arrivals[tab[3 * t]] += n_t;
+      if (tab[3 * t + 2]) self_arrivals += n_t;
+    }
     for (auto& e : sg) e.stage_ntiles = arrivals[e.stage];
   }
   nblocks = (int)sg.size();
@@ -625,7 +629,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
       (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered_first, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered_self, (size_t)nblocks_self)) || (rc = DevAlloc(&small_flag, 1)) ||
-      (rc = DevAlloc(&tile_sum, (size_t)ntiles * RSBA_PART * 256)) || (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 24)) || (rc = DevAlloc(&block_scal, (size_t)4 * std::max(grid_pp, 2 * cus))) ||
+      (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 24)) || (rc = DevAlloc(&block_scal, (size_t)4 * std::max(grid_pp, 2 * cus))) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm2[0], cmpos.size())) || (rc = DevAlloc(&sq_cm2[1], cmpos.size())) ||
       (rc = DevAlloc(&lin2[0], (size_t)P * RSBA_LIN_STRIDE)) || (rc = DevAlloc(&lin2[1], (size_t)P * RSBA_LIN_STRIDE)) ||
@@ -735,7 +739,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
 }
 
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tile_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, segs_ordered, segs_ordered_first, segs_ordered_self, small_flag, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm, hits, hit_off, hit_trips};
+  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, segs_ordered, segs_ordered_first, segs_ordered_self, small_flag, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm, hits, hit_off, hit_trips};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   cam_mask = nullptr; hits = nullptr; hit_off = nullptr; hit_trips = nullptr;
 }
@@ -1169,13 +1173,13 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   SchurArgs a;
   a.C = ts.C; a.P = ts.P; a.nwords = ts.nwords; a.camc = s->camc[x]; a.cam_free = s->cam_free; a.segs = ts.segs; a.cam_mask = ts.cam_mask; a.ptdata = ts.ptdata;
   a.cam_prefix = ts.cam_prefix; a.cam_ptr = ts.cam_ptr; a.sq_cm = ts.sq_cm2[x]; a.u_cm = ts.u_cm; a.v_cm = ts.v_cm; a.partial = ts.partial;
-  a.grp_sum = ts.grp_sum; a.sync_cnt = ts.sync_cnt; a.ngrp = ts.ngrp; a.ntiles = ts.ntiles; a.segs_ordered = ts.segs_ordered; a.small_flag = ts.small_flag; a.last_group = ts.ngroups - 1; a.tile_sum = ts.tile_sum;
+  a.grp_sum = ts.grp_sum; a.sync_cnt = ts.sync_cnt; a.ngrp = ts.ngrp; a.ntiles = ts.ntiles; a.segs_ordered = ts.segs_ordered; a.small_flag = ts.small_flag; a.last_group = ts.ngroups - 1;
   a.tree_error = ts.error_flag ? ts.error_flag : ts.tree_error; a.ticket = ts.tree_error + 1;
   a.ready = ts.ready; a.tag = tag; a.self_only = 0; a.red = s->red; a.L = s->L; a.nblocks_pp = ts.scal_blocks; a.block_scal = ts.block_scal; a.gmax_p = s->gmax;
   a.trace = s->trace; a.wg_trace = s->wg_trace;
   a.grp_flag = ts.grp_flag; a.epoch = ++ts.epoch;
   a.hits = ts.hits; a.hit_off = ts.hit_off; a.hit_trips = ts.hit_trips;
-  a.all_self = 0;
+  a.all_self = 0; a.self_arrivals = ts.self_arrivals;
   return a;
 }
 
