@@ -8,9 +8,12 @@ A *step* is one Levenberg-Marquardt iteration of the hot path: linearise (residu
 blocks), eliminate the points into the 6C x 6C reduced camera system, Cholesky-solve it, back-substitute the
 points, evaluate the candidate, decide.  Inputs are resident in HBM before the timed region starts.  The timed
 region runs exactly K iterations from the uploaded start (tolerances off so that the count is exact),
-bracketed by barrier + torch.cuda.synchronize; the maximum over ranks is reported.  In front of the W warm-up iterations the
-GPU runs untimed iterations until it has done --preload (80) in all: the clocks take ~30 ms of load to come up, and a short
-command line (--steps 20 --warmup 5) would otherwise be timed on that ramp ("untimed_filler_iterations" in the JSON line).
+bracketed by barrier + torch.cuda.synchronize; the maximum over ranks is reported.  TWO such regions are timed and both are
+in the line: the first right behind the W warm-up iterations ("ms_per_step_without_filler" — exactly what the command line
+says), the second after untimed filler iterations have brought the solver to --preload (80) iterations in all
+("ms_per_step", which `value` is quoted on: the clocks take ~30 ms of load to come up, and a short command line such as
+--steps 20 --warmup 5 is otherwise timed on that ramp).  "warmup" in the line is what really ran in front of the second
+region, "warmup_requested" is W, "untimed_filler_iterations" the filler.
 
 N > 1 (launched by torch.distributed.run): weak scaling.  Every rank holds all 64 cameras and its own block
 of 100k points (the global problem has N x 100k points); per iteration the packed reduced camera system is
@@ -165,36 +168,52 @@ def main():
     # `--steps 20 --warmup 5` put 25 in front of it — 10 ms — and its timed iterations ran from 405 down to 396 us, still on the
     # ramp, where the 50-iteration default, with 53 in front, runs at 392).  Untimed like the per-kernel pass; the W warm-up
     # iterations follow, then exactly K are timed.
-    preload = max(0, args.preload - ((0 if args.no_events else args.steps) + args.warmup))
-    if preload > 0:
-        sv_k.configure_run(preload, 0)
-        s_p = sv_k.run()
-        assert s_p.num_iterations == preload, (s_p.num_iterations, preload)
-    if args.warmup > 0:
-        sv_k.configure_run(args.warmup, 0)
-        s_w = sv_k.run()
-        assert s_w.num_iterations == args.warmup, (s_w.num_iterations, args.warmup)
-    sv_k.configure_run(args.steps, 0 if args.no_events else 2)
-    # the communicator the timed solver all-reduces over must span exactly --gpus ranks (1 = no communicator)
-    rccl_nranks = sv_k.comm_nranks()
-    if rccl_nranks != args.gpus:
-        raise SystemExit("RCCL communicator spans %d rank(s), --gpus %d" % (rccl_nranks, args.gpus))
-
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    sync()
-    t0 = time.perf_counter()
-    s_k = sv_k.run()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_run():
+        """Exactly K iterations, bracketed by barrier + synchronize; the maximum over the ranks."""
+        sv_k.configure_run(args.steps, 0 if args.no_events else 2)
+        sync()
+        t0 = time.perf_counter()
+        s = sv_k.run()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert s.num_iterations == args.steps, (s.num_iterations, args.steps)
+        return s, dt
+
+    if args.warmup > 0:
+        sv_k.configure_run(args.warmup, 0)
+        s_w = sv_k.run()
+        assert s_w.num_iterations == args.warmup, (s_w.num_iterations, args.warmup)
+    # the communicator the timed solver all-reduces over must span exactly --gpus ranks (1 = no communicator)
+    rccl_nranks = sv_k.comm_nranks()
+    if rccl_nranks != args.gpus:
+        raise SystemExit("RCCL communicator spans %d rank(s), --gpus %d" % (rccl_nranks, args.gpus))
+    # Two timed regions of exactly K iterations each, both reported.  The first right behind the W warm-up iterations, as the
+    # command line says ("ms_per_step_without_filler"); then untimed filler iterations until the GPU has run --preload (80)
+    # untimed-or-earlier iterations in all, and the second, which `value` is quoted on: steady-state throughput.  "warmup" in
+    # the line is the number of iterations that really ran on this solver in front of that second region.
+    ran_before = (0 if args.no_events else args.steps) + args.warmup
+    elapsed_nofill = None
+    preload = 0
+    if args.preload > 0:
+        _, elapsed_nofill = timed_run()
+        ran_before += args.steps
+        preload = max(0, args.preload - ran_before)
+        if preload > 0:
+            sv_k.configure_run(preload, 0)
+            s_p = sv_k.run()
+            assert s_p.num_iterations == preload, (s_p.num_iterations, preload)
+            ran_before += preload
+    s_k, elapsed = timed_run()
     assert s_k.num_iterations == args.steps, (s_k.num_iterations, args.steps)
     stats_timed = sv_k.kernel_stats()
     sv_k.close()
@@ -211,7 +230,9 @@ def main():
     out = {
         "metric": "LM iterations/sec (64 cams x 100k pts point model; + final reprojection RMS px)",
         "value": value, "unit": "LM iterations/s (of the 2M-observation workload)", "n_gpus": world, "rccl_nranks": rccl_nranks,
-        "steps": args.steps, "warmup": args.warmup, "untimed_filler_iterations": preload, "ms_per_step": 1e3 * elapsed / args.steps,
+        "steps": args.steps, "warmup": ran_before, "warmup_requested": args.warmup, "untimed_filler_iterations": preload,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step_without_filler": (1e3 * elapsed_nofill / args.steps) if elapsed_nofill is not None else 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d cams x %d points, %d observations (%d views/point), point model <2,6,3>, "
                                "DENSE_SCHUR-equivalent; %d points per GPU" % (args.config, C, P_total, N_total, k, P_rank),
@@ -245,15 +266,16 @@ def main():
         # writes profiles/r03_pmc_<workload>.json); a line for a workload without such a file carries traffic = null
         pmc, pmc_source = {}, None
         wl = args.config if args.points is None else "%s_%d" % (args.config, args.points)
-        for cand in ("r03_pmc_%s.json" % wl,) + (("r02_pmc.json",) if wl == "cfg3" else ()):
+        for cand in ("r04_pmc_%s.json" % wl, "r03_pmc_%s.json" % wl) + (("r02_pmc.json",) if wl == "cfg3" else ()):
             q = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(q):
                 try:
                     pmc = json.load(open(q))
-                    pmc_source = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py` on this workload, "
-                                  "SEQUENTIAL schedule (counter collection serialises kernels; the pipelined factorisation would only "
-                                  "time out), FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes; a committed constant, "
-                                  "not collected by this run" % cand)
+                    sched = pmc.pop("__schedule__", "SEQUENTIAL schedule (counter collection serialises kernels; the pipelined factorisation "
+                                                    "would only time out)")
+                    pmc_source = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py` on this workload, %s; "
+                                  "FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes; a committed constant, not collected by "
+                                  "this run" % (cand, sched))
                     break
                 except Exception:
                     pmc = {}

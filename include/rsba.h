@@ -53,7 +53,7 @@ enum { RSBA_CONVERGENCE = 0, RSBA_NO_CONVERGENCE = 1, RSBA_FAILURE = 2 };
 enum {
   RSBA_STOP_NONE = 0, RSBA_STOP_GRADIENT = 1, RSBA_STOP_PARAMETER = 2, RSBA_STOP_FUNCTION = 3,
   RSBA_STOP_MAX_ITERATIONS = 4, RSBA_STOP_MIN_RADIUS = 5, RSBA_STOP_INVALID_STEPS = 6,
-  RSBA_STOP_INITIAL_FAILURE = 7
+  RSBA_STOP_INITIAL_FAILURE = 7, RSBA_STOP_MAX_TIME = 8
 };
 
 enum rsba_loss { RSBA_LOSS_HUBER = 0, RSBA_LOSS_CAUCHY = 1 };
@@ -94,6 +94,12 @@ typedef struct rsba_options {
                            /* corrector scales residual and Jacobians by sqrt(rho') (corrector.cc)      */
   const void* comm_unique_id; /* world_size > 1: the 128-byte id from rsba_comm_unique_id (rank 0's) */
   void* stream;               /* hipStream_t to run on, NULL = a private stream                    */
+  double max_solver_time_in_seconds; /* 1e9 (Ceres' default; Solver::Options, left alone by bundle_adjustment_manager.cpp:90-92): checked
+                                        once per iteration behind the iteration limit, as TrustRegionMinimizer does -> NO_CONVERGENCE,
+                                        RSBA_STOP_MAX_TIME.  One rank only: several ranks would each read their own clock and part
+                                        (rsba_solver_create returns RSBA_ERR_UNSUPPORTED for a finite limit with world_size > 1).
+                                        Solver::Options::use_nonmonotonic_steps has no field: the reference leaves it false, and the
+                                        device-side step decision (DecideStep) implements the monotonic rule only. */
 } rsba_options;
 
 typedef struct rsba_summary {

@@ -38,7 +38,8 @@ class Options(C.Structure):
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double), ("function_tolerance", C.c_double),
                 ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double), ("huber_delta", C.c_double),
                 ("device", C.c_int32), ("schur_impl", C.c_int32), ("profile_kernels", C.c_int32), ("rank", C.c_int32),
-                ("world_size", C.c_int32), ("loss_type", C.c_int32), ("comm_unique_id", C.c_void_p), ("stream", C.c_void_p)]
+                ("world_size", C.c_int32), ("loss_type", C.c_int32), ("comm_unique_id", C.c_void_p), ("stream", C.c_void_p),
+                ("max_solver_time_in_seconds", C.c_double)]
 
 
 class Summary(C.Structure):

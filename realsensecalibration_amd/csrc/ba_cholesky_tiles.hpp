@@ -90,6 +90,7 @@ __device__ __forceinline__ bool WaitFlagPlainWG(const int* flag, int tag, const 
     s_ok3 = ok;
   }
   __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the produced data is read with agent-scope loads behind this: ordered after the flag for the compiler and the wavefront)
   return s_ok3 != 0;
 }
 

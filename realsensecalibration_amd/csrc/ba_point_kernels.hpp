@@ -265,9 +265,10 @@ k_linearize_schur_ref(int C, int P, const double* __restrict__ obs_u, const doub
 }
 
 // Second stage of the scalar reductions of K_A, fixed order -> red scalars (sum part) and gmax (max part).
+// `s`: 256 x 4 doubles of LDS nobody else is using (the Schur kernel passes its staging buffer: a static array here
+// would come on top of the kernel's own 80 KB)
 __device__ __forceinline__ void FinishLinearize(int nblocks, const double* __restrict__ block_scal, double* __restrict__ red,
-                                                RedLayout L, double* __restrict__ gmax_p) {
-  __shared__ double s[256][4];
+                                                RedLayout L, double* __restrict__ gmax_p, double (*s)[4]) {
   const int tid = threadIdx.x;
   double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
   for (int i = tid; i < nblocks; i += blockDim.x) {
@@ -287,7 +288,8 @@ __device__ __forceinline__ void FinishLinearize(int nblocks, const double* __res
 }
 __global__ void k_finish_linearize(int nblocks, const double* __restrict__ block_scal, double* __restrict__ red,
                                    RedLayout L, double* __restrict__ gmax_p) {
-  FinishLinearize(nblocks, block_scal, red, L, gmax_p);
+  __shared__ double s[256][4];
+  FinishLinearize(nblocks, block_scal, red, L, gmax_p, s);
 }
 
 // Camera step from the solution of the scaled system: delta_c = -s_c y, candidate cameras and their constants, the

@@ -47,6 +47,7 @@ namespace rsba {
 class KernelTimer;
 
 #define RSBA_TG 16          // cameras per group
+#define RSBA_PRIO(p) __builtin_amdgcn_s_setprio(p)   // wavefront priority (see k_schur_tiles)
 #define RSBA_CHUNK 512      // points per LDS chunk
 #define RSBA_CW (RSBA_CHUNK / 64)
 // (RSBA_PT_STRIDE, the record of a point — X(3) Vinv(6) y(3) — is defined in ba_point_kernels.hpp, whose back-substitution writes it too)
@@ -54,13 +55,43 @@ class KernelTimer;
 
 // A segment is a range of 64-point mask words of one tile (not necessarily chunk-aligned: small problems get as many
 // workgroups as they have words).
+// Up to 64 cameras the pair segments walk STATIC hit lists (PairSegmentListed): a segment's point range is cut into blocks of at
+// most RSBA_CHUNK points and at most RSBA_LIST_TRIPS hits per lane; a block's four wavefronts each have a lane-interleaved list
+// (row n = the n-th hit of each of the 64 lanes: the point's index in the block, RSBA_LIST_NONE where a lane has none left).
+#define RSBA_LIST_TRIPS 66     // rows of a wavefront's list that fit in LDS beside the block's point records (two workgroups per CU)
+#define RSBA_LIST_NONE 512u    // "no hit": index of the spare record behind the block's 512
+struct PairBlk {
+  int word0, nwords;           // the block's 64-point mask words
+  unsigned off0, off1, off2, off3;   // first row of each wavefront's list (rows of 64 entries, in TiledSchur::hl)
+  unsigned trips01, trips23;         // rows per wavefront, 16 bits each (even numbers: the hit loop takes two rows per round)
+  // (named fields, not arrays: with arrays the compiler turned the kernel's per-wavefront selects back into an indexed load, which
+  //  needs the entry in memory — scratch)
+  __host__ __device__ unsigned& off(int wv) { return wv == 0 ? off0 : wv == 1 ? off1 : wv == 2 ? off2 : off3; }
+};
 struct SchurSeg {
   int ga, gb, word_begin, word_end, self;
   // in-kernel reduction tree of the pair tiles: segment -> group of RSBA_GRP consecutive segments -> tile -> stage
   int tile, grp, grp_seg0, grp_nseg, tile_grp0, tile_ngrp, stage, stage_ntiles, nred, index, pad2;
   // index: the entry's own number (segs_ordered, the copy in launch order, is what the kernel reads: one load per ticket)
   // self: 0 pair segment, 1 self segment, 2 / 3 reducer of a pair / self tile (word_begin..word_end = its components)
+  int blk_begin, nblk;         // listed pair segments: the segment's blocks in TiledSchur::pblk ...
+  PairBlk blk0;                // ... and a copy of the first (nearly always the only) one: no second dependent load per entry
 };
+// An entry of the work list, field by field into scalar registers.  (Copied as a struct, the 104 bytes went through vector
+// registers into SCRATCH and were read back from there field by field — and a kernel that uses scratch at all pays for it in
+// the launch latency of every workgroup: end of an entry -> start of the next on its slot 7.6 instead of 6.1 us.)
+__device__ __forceinline__ SchurSeg LoadSeg(const SchurSeg* __restrict__ p) {
+  SchurSeg s;
+#define RSBA_F(f) s.f = __builtin_amdgcn_readfirstlane(p->f)
+  RSBA_F(ga); RSBA_F(gb); RSBA_F(word_begin); RSBA_F(word_end); RSBA_F(self); RSBA_F(tile); RSBA_F(grp); RSBA_F(grp_seg0); RSBA_F(grp_nseg);
+  RSBA_F(tile_grp0); RSBA_F(tile_ngrp); RSBA_F(stage); RSBA_F(stage_ntiles); RSBA_F(nred); RSBA_F(index); RSBA_F(pad2); RSBA_F(blk_begin); RSBA_F(nblk);
+  RSBA_F(blk0.word0); RSBA_F(blk0.nwords);
+#undef RSBA_F
+#define RSBA_F(f) s.f = (unsigned)__builtin_amdgcn_readfirstlane((int)p->f)
+  RSBA_F(blk0.off0); RSBA_F(blk0.off1); RSBA_F(blk0.off2); RSBA_F(blk0.off3); RSBA_F(blk0.trips01); RSBA_F(blk0.trips23);
+#undef RSBA_F
+  return s;
+}
 #define RSBA_GRP 8          // segments per reduction group (more than 64 cameras)
 #define RSBA_GRP_SMALL 4    // ... up to 64 cameras
 #define RSBA_SELF_SETS 6      // reducers of a self tile: the sets of its 42 components that the K factors do not couple (ReducerSelfSet)
@@ -111,6 +142,11 @@ struct TiledSchur {
   unsigned *hits = nullptr, *hit_off = nullptr;
   int* hit_trips = nullptr;
   size_t hit_entries = 0;
+  // up to 64 cameras: the listed pair segments' blocks and hit lists (PairSegmentListed); nullptr: the masks are searched
+  PairBlk* pblk = nullptr;
+  unsigned short* hl = nullptr;
+  size_t hl_rows = 0;
+  int BuildPairLists(const std::vector<unsigned long long>& mask, std::vector<SchurSeg>& sg);
 
   int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
             const std::vector<int>& sliced_q /* sliced slot -> CSR position, -1 pads */, bool staged);
@@ -390,10 +426,13 @@ __device__ __forceinline__ void SideRowsLds(const double* __restrict__ c, const 
 template <bool kSmall>
 __device__ __forceinline__ void SideRowsUnscaledLds(const double* __restrict__ c, const double X[3], double sq, double e0[4], double e1[4],
                                                     double n0[3], double n1[3], double d2[2]) {
+  // (every multiply-add written out: left to the compiler, a sum of three products is contracted as mul + fma + fma starting from
+  //  WHICHEVER product it likes — it differed between the two halves of one unrolled loop — and the pair segments' three
+  //  implementations, which must add the same bits, would each round their own way)
   const double r0 = c[0], r1 = c[1], r2 = c[2], r3 = c[3], r4 = c[4], r5 = c[5], r6 = c[6], r7 = c[7], r8 = c[8];
-  const double q0 = r0 * X[0] + r1 * X[1] + r2 * X[2];
-  const double q1 = r3 * X[0] + r4 * X[1] + r5 * X[2];
-  const double q2 = r6 * X[0] + r7 * X[1] + r8 * X[2];
+  const double q0 = fma(r2, X[2], fma(r1, X[1], r0 * X[0]));
+  const double q1 = fma(r5, X[2], fma(r4, X[1], r3 * X[0]));
+  const double q2 = fma(r8, X[2], fma(r7, X[1], r6 * X[0]));
   const double p0 = q0 + c[9], p1 = q1 + c[10], p2 = q2 + c[11];
   const double iz = RcpNewton(p2);
   const double al = c[12] * iz * sq, be = c[13] * iz * sq;
@@ -545,6 +584,15 @@ __device__ __forceinline__ bool StageArrive(const SchurSeg& sg, int* __restrict_
   return s_last != 0;
 }
 
+// A stage's flag, ONE store per stage and launch (the last arrival of the stage): a RELEASE at agent scope.  What the stage
+// publishes left its workgroups as agent-scope (write-through) stores whose acknowledgements each of them awaited before it
+// arrived at the stage counter, so on this hardware the data is in memory before the flag either way — round 3 made the
+// reducers' flag stores relaxed on that ground (no measurable difference: 0.420 against 0.417 ms).  But then the hand-over is
+// correct by the property of every store on the path, not by the memory model: one plain store among them (FinishLinearize's
+// are, covered by StageArrive's fence) would leave a stale line in another XCD's L2 silently.  The release costs one L2
+// write-back per stage, off every per-tile path; the consumers acquire behind the flag (WaitFlagWG / WaitFlagPlainWG).
+__device__ __forceinline__ void PublishStage(int* flag, int tag) { __hip_atomic_store(flag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
 // A self tile is finished (its diag U, g_c, diagonal block are written and — StageArrive's fence, pipelined schedule —
 // visible): the last of the ngroups self tiles publishes ready[9].  Thread 0 only; call behind StageArrive.
 __device__ __forceinline__ void SelfTileArrive(int* __restrict__ sync_cnt, int ngrp, int ntiles, int ngroups, int* __restrict__ ready, int tag) {
@@ -660,6 +708,41 @@ __device__ __forceinline__ void FinishPairSlot(int C, int ga, int gb, int slot, 
   }
 }
 
+// One hit of a camera pair: acc += E~a' [ Da^2 (N~a Vinv N~b') Db^2 ] E~b for the point X with damped inverse block v0..v5 (the
+// arithmetic of PairSegment's loop body, operation for operation: the masked, the sparse and the listed pair segments add the
+// same bits).  ca / cb: the two cameras' 15 constants (R, t, fx, fy, small-angle flag).
+template <bool kSmall>
+__device__ __forceinline__ void PairHit(const double* __restrict__ ca, const double* __restrict__ cb, const double X[3], double v0, double v1, double v2,
+                                        double v3, double v4, double v5, double sqa, double sqb, double* acc) {
+  double ea0[4], ea1[4], na0[3], na1[3], da[2];
+  SideRowsUnscaledLds<kSmall>(ca, X, sqa, ea0, ea1, na0, na1, da);
+  // t = N~a Vinv (2x3), then the b side, M = D_a^2 (t N~b') D_b^2 (2x2), Z = E~a' M (6x2)
+  auto dot3 = [](double a0, double b0, double a1, double b1, double a2, double b2) { return fma(a2, b2, fma(a1, b1, a0 * b0)); };
+  const double t00 = dot3(na0[0], v0, na0[1], v1, na0[2], v2), t01 = dot3(na0[0], v1, na0[1], v3, na0[2], v4), t02 = dot3(na0[0], v2, na0[1], v4, na0[2], v5);
+  const double t10 = dot3(na1[0], v0, na1[1], v1, na1[2], v2), t11 = dot3(na1[0], v1, na1[1], v3, na1[2], v4), t12 = dot3(na1[0], v2, na1[1], v4, na1[2], v5);
+  double eb0[4], eb1[4], nb0[3], nb1[3], db[2];
+  SideRowsUnscaledLds<kSmall>(cb, X, sqb, eb0, eb1, nb0, nb1, db);
+  const double m00 = dot3(t00, nb0[0], t01, nb0[1], t02, nb0[2]) * (da[0] * db[0]), m01 = dot3(t00, nb1[0], t01, nb1[1], t02, nb1[2]) * (da[0] * db[1]);
+  const double m10 = dot3(t10, nb0[0], t11, nb0[1], t12, nb0[2]) * (da[1] * db[0]), m11 = dot3(t10, nb1[0], t11, nb1[1], t12, nb1[2]) * (da[1] * db[1]);
+  // Z = E~a' M, acc += Z E~b.  Columns 3 / 4 of E~ are (1, 0)' and (0, 1)': rows 3 / 4 of Z are the rows of M, columns
+  // 3 / 4 of the update are Z itself.  Rows / columns 0, 1, 2, 5 take entry 0, 1, 2, 3 of the packed e~.
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    const int pp = p == 5 ? 3 : p;
+    double z0, z1;
+    if (p == 3) { z0 = m00; z1 = m01; }
+    else if (p == 4) { z0 = m10; z1 = m11; }
+    else { z0 = fma(ea1[pp], m10, ea0[pp] * m00); z1 = fma(ea1[pp], m11, ea0[pp] * m01); }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int qq = q == 5 ? 3 : q;
+      if (q == 3) acc[6 * p + q] += z0;
+      else if (q == 4) acc[6 * p + q] += z1;
+      else acc[6 * p + q] = Fma2(z0, eb0[qq], z1, eb1[qq], acc[6 * p + q]);
+    }
+  }
+}
+
 // Pair tiles (ga <= gb, a != b).  Two workgroups per CU: the accumulators (72 VGPRs) are the only long-lived
 // per-lane state; camera constants sit in LDS (broadcast within a 16-lane row / replicated across rows).
 struct SchurArgs {
@@ -703,6 +786,9 @@ struct SchurArgs {
   const unsigned* __restrict__ hits;       // [entry][3]: point, camera-major observation index on the a side, on the b side
   const unsigned* __restrict__ hit_off;    // [pair segment][4 waves]: first entry of the wave's list (64 entries per trip, lane-interleaved)
   const int* __restrict__ hit_trips;       // [pair segment][4 waves]: trips = the longest of the wave's 64 lists
+  // up to 64 cameras: the listed pair segments (PairSegmentListed); nullptr: the masked search (PairSegment)
+  const PairBlk* __restrict__ pblk;
+  const unsigned short* __restrict__ hl;
 };
 
 template <bool kLoss, bool kSmall>
@@ -786,6 +872,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
     // runs max-over-lanes(hits in 512 points) trips, not the sum over words of the per-word maxima
     // one flat loop per lane: (w, h) is the lane's cursor into its hit list; the cursor advance is a tiny inner loop
     // that does not touch the accumulators
+    RSBA_PRIO(0);
     int w = w0;
     unsigned long long h = live ? (mk[ia][w0] & mk[RSBA_TG + ib][w0]) : 0ull;
     if (live) { while (h == 0ull && w + wstep < RSBA_CW) { w += wstep; h = mk[ia][w] & mk[RSBA_TG + ib][w]; } }
@@ -806,33 +893,9 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
         sqa = sq_cm[cam_ptr[cam_a] + cam_prefix[(size_t)cam_a * nwords + gw] + __popcll(mk[ia][wcur] & below)];
         sqb = sq_cm[cam_ptr[cam_b] + cam_prefix[(size_t)cam_b * nwords + gw] + __popcll(mk[RSBA_TG + ib][wcur] & below)];
       }
-      double ea0[4], ea1[4], na0[3], na1[3], da[2];
-      SideRowsUnscaledLds<kSmall>(ca, X, sqa, ea0, ea1, na0, na1, da);
-      // t = N~a Vinv (2x3), then the b side, M = D_a^2 (t N~b') D_b^2 (2x2), Z = E~a' M (6x2)
-      const double t00 = na0[0] * v0 + na0[1] * v1 + na0[2] * v2, t01 = na0[0] * v1 + na0[1] * v3 + na0[2] * v4, t02 = na0[0] * v2 + na0[1] * v4 + na0[2] * v5;
-      const double t10 = na1[0] * v0 + na1[1] * v1 + na1[2] * v2, t11 = na1[0] * v1 + na1[1] * v3 + na1[2] * v4, t12 = na1[0] * v2 + na1[1] * v4 + na1[2] * v5;
-      double eb0[4], eb1[4], nb0[3], nb1[3], db[2];
-      SideRowsUnscaledLds<kSmall>(cb, X, sqb, eb0, eb1, nb0, nb1, db);
-      const double m00 = (t00 * nb0[0] + t01 * nb0[1] + t02 * nb0[2]) * (da[0] * db[0]), m01 = (t00 * nb1[0] + t01 * nb1[1] + t02 * nb1[2]) * (da[0] * db[1]);
-      const double m10 = (t10 * nb0[0] + t11 * nb0[1] + t12 * nb0[2]) * (da[1] * db[0]), m11 = (t10 * nb1[0] + t11 * nb1[1] + t12 * nb1[2]) * (da[1] * db[1]);
-      // Z = E~a' M, acc += Z E~b.  Columns 3 / 4 of E~ are (1, 0)' and (0, 1)': rows 3 / 4 of Z are the rows of M, columns
-      // 3 / 4 of the update are Z itself.  Rows / columns 0, 1, 2, 5 take entry 0, 1, 2, 3 of the packed e~.
-#pragma unroll
-      for (int p = 0; p < 6; ++p) {
-        const int pp = p == 5 ? 3 : p;
-        double z0, z1;
-        if (p == 3) { z0 = m00; z1 = m01; }
-        else if (p == 4) { z0 = m10; z1 = m11; }
-        else { z0 = ea0[pp] * m00 + ea1[pp] * m10; z1 = ea0[pp] * m01 + ea1[pp] * m11; }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          const int qq = q == 5 ? 3 : q;
-          if (q == 3) acc[6 * p + q] += z0;
-          else if (q == 4) acc[6 * p + q] += z1;
-          else acc[6 * p + q] = Fma2(z0, eb0[qq], z1, eb1[qq], acc[6 * p + q]);
-        }
-      }
+      PairHit<kSmall>(ca, cb, X, v0, v1, v2, v3, v4, v5, sqa, sqb, acc);
     }
+    RSBA_PRIO(3);
   }
   if (diag_tile) {
     // odd-word half (waves 2/3) -> LDS -> even-word half; the point buffer is free once every lane has left the chunk loop
@@ -858,7 +921,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
   if (!GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v, a.grp_flag, a.epoch)) return;
   FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L, a.cam_free);
   if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
-  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0 && a.tag) PublishStage(a.ready + 1 + sg.stage, a.tag);
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
 
@@ -926,6 +989,7 @@ __device__ __forceinline__ void PairSegmentSparse(const SchurArgs& a, const Schu
   double acc[36];
 #pragma unroll
   for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+  RSBA_PRIO(0);
 #pragma unroll 1
   for (int n = 0; n < ntrip; ++n) {
     const bool hit = e0 != RSBA_HIT_NONE;
@@ -943,30 +1007,9 @@ __device__ __forceinline__ void PairSegmentSparse(const SchurArgs& a, const Schu
     }
     if (e0 != RSBA_HIT_NONE) fetch(e0, e1, e2);
     if (!hit) continue;
-    double ea0[4], ea1[4], na0[3], na1[3], da[2];
-    SideRowsUnscaledLds<kSmall>(ca, X, sqa, ea0, ea1, na0, na1, da);
-    const double t00 = na0[0] * v0 + na0[1] * v1 + na0[2] * v2, t01 = na0[0] * v1 + na0[1] * v3 + na0[2] * v4, t02 = na0[0] * v2 + na0[1] * v4 + na0[2] * v5;
-    const double t10 = na1[0] * v0 + na1[1] * v1 + na1[2] * v2, t11 = na1[0] * v1 + na1[1] * v3 + na1[2] * v4, t12 = na1[0] * v2 + na1[1] * v4 + na1[2] * v5;
-    double eb0[4], eb1[4], nb0[3], nb1[3], db[2];
-    SideRowsUnscaledLds<kSmall>(cb, X, sqb, eb0, eb1, nb0, nb1, db);
-    const double m00 = (t00 * nb0[0] + t01 * nb0[1] + t02 * nb0[2]) * (da[0] * db[0]), m01 = (t00 * nb1[0] + t01 * nb1[1] + t02 * nb1[2]) * (da[0] * db[1]);
-    const double m10 = (t10 * nb0[0] + t11 * nb0[1] + t12 * nb0[2]) * (da[1] * db[0]), m11 = (t10 * nb1[0] + t11 * nb1[1] + t12 * nb1[2]) * (da[1] * db[1]);
-#pragma unroll
-    for (int p = 0; p < 6; ++p) {
-      const int pp = p == 5 ? 3 : p;
-      double z0, z1;
-      if (p == 3) { z0 = m00; z1 = m01; }
-      else if (p == 4) { z0 = m10; z1 = m11; }
-      else { z0 = ea0[pp] * m00 + ea1[pp] * m10; z1 = ea0[pp] * m01 + ea1[pp] * m11; }
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const int qq = q == 5 ? 3 : q;
-        if (q == 3) acc[6 * p + q] += z0;
-        else if (q == 4) acc[6 * p + q] += z1;
-        else acc[6 * p + q] = Fma2(z0, eb0[qq], z1, eb1[qq], acc[6 * p + q]);
-      }
-    }
+    PairHit<kSmall>(ca, cb, X, v0, v1, v2, v3, v4, v5, sqa, sqb, acc);
   }
+  RSBA_PRIO(3);
   if (diag_tile) {
     // odd-word half (waves 2/3) -> LDS -> even-word half
     __syncthreads();
@@ -990,7 +1033,208 @@ __device__ __forceinline__ void PairSegmentSparse(const SchurArgs& a, const Schu
   if (!GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v, a.grp_flag, a.epoch)) return;
   FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L, a.cam_free);
   if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
-  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0 && a.tag) PublishStage(a.ready + 1 + sg.stage, a.tag);
+  if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pair segment up to 64 cameras: LISTED (round 4).  Which points a camera pair shares never changes, so PairSegment's search — per
+// hit a find-first-set on the AND of two mask words, a cursor of (word, remaining bits) per lane, and, whenever ANY lane of the
+// wavefront runs out of bits in its word (nearly every trip), a divergent inner loop of two LDS reads and a wait — is done once, at
+// set-up (TiledSchur::BuildPairLists): per block of a segment (<= 512 points, <= RSBA_LIST_TRIPS hits per lane) and wavefront a
+// lane-interleaved list of 16-bit point indices, staged into LDS with the block's point records.  The hit loop is then: read the
+// lane's next-but-one index, fetch the NEXT hit's point record (five ds_read_b128 from 80-byte records: X, the damped inverse
+// block, one pad) while this hit's arithmetic runs, and PairHit — ~185 vector instructions per trip instead of ~225, and neither
+// LDS round trip of the old loop (cursor, then record, then arithmetic) is on the lane's critical path.  Same hits in the same
+// order with the same arithmetic as PairSegment: the same bits (RSBA_LISTED=0 runs the masked search; the tests compare them).
+// The camera constants are loaded straight into registers (the compiler hoisted them out of the loop anyway; their 4 KB of LDS
+// are list rows now).  kLoss: the rank of the point in either camera's observation list (-> sqrt(rho')) from the block's mask
+// words and prefix counts in LDS, fetched one trip ahead as well.
+// ------------------------------------------------------------------------------------------------
+#define RSBA_LPT 10                                             // doubles per point record in LDS: X(3), damped inverse block (6), pad
+#define RSBA_LPT_BYTES ((RSBA_CHUNK + 1) * RSBA_LPT * 8)        // 513 records (the last one is where RSBA_LIST_NONE points)
+#define RSBA_LIST_ROWS (RSBA_LIST_TRIPS + 2)                    // two rows of RSBA_LIST_NONE behind a list: the loop reads two trips ahead
+#define RSBA_LISTED_LDS(loss) (RSBA_LPT_BYTES + ((loss) ? 3072 : 0) + 4 * RSBA_LIST_ROWS * 128)
+template <bool kLoss, bool kSmall>
+__device__ __forceinline__ void PairSegmentListed(const SchurArgs& a, const SchurSeg& sg, int seg_index, int ticket, char* lds, int b0_word0, int b0_nwords,
+                                                  unsigned b0_off0, unsigned b0_off1, unsigned b0_off2, unsigned b0_off3, unsigned b0_trips01, unsigned b0_trips23) {
+  // (the first block's descriptor comes as scalars, not as sg.blk0: read through the reference, the per-wavefront selects below
+  //  became an indexed load of the entry, which then had to live in memory — scratch)
+  const int C = a.C, P = a.P, nwords = a.nwords;
+  const double* __restrict__ camc = a.camc;
+  const double* __restrict__ ptdata = a.ptdata;
+  const double* __restrict__ sq_cm = a.sq_cm;
+  double* __restrict__ partial = a.partial;
+  double* pt = reinterpret_cast<double*>(lds);
+  unsigned long long (*mk)[RSBA_CW] = reinterpret_cast<unsigned long long (*)[RSBA_CW]>(lds + RSBA_LPT_BYTES);   // kLoss only
+  int (*pre)[RSBA_CW] = reinterpret_cast<int (*)[RSBA_CW]>(lds + RSBA_LPT_BYTES + 2048);                         // kLoss only
+  unsigned short* hl = reinterpret_cast<unsigned short*>(lds + RSBA_LPT_BYTES + (kLoss ? 3072 : 0));
+  const int tid = OpaqueTid(), ln = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool diag_tile = sg.ga == sg.gb;
+  // lane -> pair as in PairSegment: off-diagonal tile lane = (ia, ib); diagonal tile: the 120 pairs ia < ib in lanes 0..119 of BOTH
+  // halves of the workgroup, the halves split the hits by the parity of the point's mask word within the segment
+  const int dt = diag_tile ? (tid & 127) : tid;
+  const int pr = diag_tile ? (dt < 120 ? kDiagPair[dt] : 0) : tid;
+  const int ia = pr >> 4, ib = pr & 15;
+  const int cam_a = RSBA_TG * sg.ga + ia, cam_b = RSBA_TG * sg.gb + ib;
+  double ca[15], cb[15];
+  {
+    const double* pa = camc + (size_t)(cam_a < C ? cam_a : 0) * CC_STRIDE;
+    const double* pb = camc + (size_t)(cam_b < C ? cam_b : 0) * CC_STRIDE;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { ca[i] = pa[CC_R + i]; cb[i] = pb[CC_R + i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ca[9 + i] = pa[CC_T + i]; cb[9 + i] = pb[CC_T + i]; }
+    ca[12] = pa[CC_FX]; ca[13] = pa[CC_FY]; cb[12] = pb[CC_FX]; cb[13] = pb[CC_FY];
+    ca[14] = kSmall ? pa[CC_SMALL] : 0.0; cb[14] = kSmall ? pb[CC_SMALL] : 0.0;
+  }
+  // Staging of a block: its point records and this wavefront's list, every load in flight before the first LDS store (one round
+  // trip).  The first block is staged BEFORE the accumulators exist (72 registers the staging loads can use: staged inside the
+  // block loop, the first version spilled 117 registers around it); a segment has more than one block only on large or dense
+  // problems.
+  int ntrip = 0;
+  {
+    const int wb = b0_word0, nwc = b0_nwords;
+    const int j0 = wb * 64;
+    const int np = max(0, min(nwc * 64, P - j0));
+    const unsigned tr01 = b0_trips01, tr23 = b0_trips23;
+    ntrip = (int)(wv == 0 ? (tr01 & 0xffffu) : wv == 1 ? (tr01 >> 16) : wv == 2 ? (tr23 & 0xffffu) : (tr23 >> 16));
+    const unsigned off = wv == 0 ? b0_off0 : wv == 1 ? b0_off1 : wv == 2 ? b0_off2 : b0_off3;
+    constexpr int kPtPerThread = RSBA_CHUNK * RSBA_PT_STRIDE / 256;
+    double pv[kPtPerThread];
+#pragma unroll
+    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; pv[u] = i < np * RSBA_PT_STRIDE ? ptdata[(size_t)j0 * RSBA_PT_STRIDE + i] : 0.0; }
+    constexpr int kPieces = (RSBA_LIST_TRIPS * 8 + 63) / 64;   // 16-byte pieces of a list per lane
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.hl + (size_t)off * 64);
+    uint4 lp[kPieces];
+#pragma unroll
+    for (int k = 0; k < kPieces; ++k) { const int pc = ln + 64 * k; lp[k] = pc < ntrip * 8 ? src[pc] : make_uint4(0u, 0u, 0u, 0u); }
+    unsigned long long mv = 0ull; int pv_i = 0;
+    if (kLoss) {
+      const int row = tid >> 3, w = tid & 7;  // 32 rows x 8 words = 256 threads
+      const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
+      const bool in = cam < C && w < nwc;
+      mv = in ? a.cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
+      pv_i = in ? a.cam_ptr[cam] + a.cam_prefix[(size_t)cam * nwords + (size_t)wb + w] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kPtPerThread; ++u) {
+      const int i = tid + 256 * u, j = i / RSBA_PT_STRIDE, e = i - j * RSBA_PT_STRIDE;
+      if (i < np * RSBA_PT_STRIDE && e < 9) pt[j * RSBA_LPT + e] = pv[u];
+    }
+    uint4* dst = reinterpret_cast<uint4*>(hl + wv * (RSBA_LIST_ROWS * 64));
+#pragma unroll
+    for (int k = 0; k < kPieces; ++k) { const int pc = ln + 64 * k; if (pc < ntrip * 8) dst[pc] = lp[k]; }
+    hl[wv * (RSBA_LIST_ROWS * 64) + ntrip * 64 + ln] = (unsigned short)RSBA_LIST_NONE;
+    hl[wv * (RSBA_LIST_ROWS * 64) + (ntrip + 1) * 64 + ln] = (unsigned short)RSBA_LIST_NONE;
+    if (kLoss) { mk[tid >> 3][tid & 7] = mv; pre[tid >> 3][tid & 7] = pv_i; }
+    __syncthreads();
+  }
+  double acc[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll 1
+  for (int bi = 0;;) {
+    const unsigned short* myl = hl + wv * (RSBA_LIST_ROWS * 64) + ln;
+    // rank of point `idx` of the block in the observation list of the camera of mask row `row` (-> its sqrt(rho'))
+    auto sq_of = [&](unsigned idx, int row) -> double {
+      const unsigned ic = idx < (unsigned)RSBA_CHUNK ? idx : 0u;
+      const unsigned long long below = (1ull << (ic & 63u)) - 1ull;
+      return sq_cm[pre[row][ic >> 6] + __popcll(mk[row][ic >> 6] & below)];
+    };
+    RSBA_PRIO(0);
+    unsigned iA = myl[0], iB = myl[64];
+    double PA[9], PB[9], sA[2] = {1.0, 1.0}, sB[2] = {1.0, 1.0};
+    {
+      const double* pd = pt + iA * RSBA_LPT;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) PA[i] = pd[i];
+      if (kLoss) { sA[0] = sq_of(iA, ia); sA[1] = sq_of(iA, RSBA_TG + ib); }
+    }
+#pragma unroll 1
+    for (int n = 0; n < ntrip; n += 2) {
+      {
+        const double* pd = pt + iB * RSBA_LPT;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) PB[i] = pd[i];
+        if (kLoss) { sB[0] = sq_of(iB, ia); sB[1] = sq_of(iB, RSBA_TG + ib); }
+      }
+      const unsigned iA2 = myl[(n + 2) * 64];
+      if (iA != RSBA_LIST_NONE) PairHit<kSmall>(ca, cb, PA, PA[3], PA[4], PA[5], PA[6], PA[7], PA[8], sA[0], sA[1], acc);
+      iA = iA2;
+      {
+        const double* pd = pt + iA * RSBA_LPT;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) PA[i] = pd[i];
+        if (kLoss) { sA[0] = sq_of(iA, ia); sA[1] = sq_of(iA, RSBA_TG + ib); }
+      }
+      const unsigned iB2 = myl[(n + 3) * 64];
+      if (iB != RSBA_LIST_NONE) PairHit<kSmall>(ca, cb, PB, PB[3], PB[4], PB[5], PB[6], PB[7], PB[8], sB[0], sB[1], acc);
+      iB = iB2;
+    }
+    RSBA_PRIO(3);
+    if (++bi >= sg.nblk) break;
+    __syncthreads();   // (every wavefront is through with the block's records and lists)
+    {
+      // a later block of a long segment (large or dense problems only): staged with plain loops — the accumulators and both
+      // cameras' constants are live here, and the first block's form (every load in a register before the first store: 84
+      // registers) spilled 65 registers into scratch, which every dispatch of the kernel then pays for in launch latency
+      // (end of an entry -> start of the next on its slot: 7.6 against 6.1 us)
+      const PairBlk blk = a.pblk[sg.blk_begin + bi];
+      const int tid2 = OpaqueTid(), ln2 = tid2 & 63;
+      const int j0 = blk.word0 * 64;
+      const int np = max(0, min(blk.nwords * 64, P - j0));
+      const unsigned tr01 = blk.trips01, tr23 = blk.trips23;
+      ntrip = (int)(wv == 0 ? (tr01 & 0xffffu) : wv == 1 ? (tr01 >> 16) : wv == 2 ? (tr23 & 0xffffu) : (tr23 >> 16));
+      const unsigned off = wv == 0 ? blk.off0 : wv == 1 ? blk.off1 : wv == 2 ? blk.off2 : blk.off3;
+#pragma unroll 4
+      for (int i = tid2; i < np * RSBA_PT_STRIDE; i += 256) {
+        const int j = i / RSBA_PT_STRIDE, e = i - j * RSBA_PT_STRIDE;
+        const double v = ptdata[(size_t)j0 * RSBA_PT_STRIDE + i];
+        if (e < 9) pt[j * RSBA_LPT + e] = v;
+      }
+      const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.hl + (size_t)off * 64);
+      uint4* dst = reinterpret_cast<uint4*>(hl + wv * (RSBA_LIST_ROWS * 64));
+#pragma unroll 2
+      for (int pc = ln2; pc < ntrip * 8; pc += 64) dst[pc] = src[pc];
+      hl[wv * (RSBA_LIST_ROWS * 64) + ntrip * 64 + ln2] = (unsigned short)RSBA_LIST_NONE;
+      hl[wv * (RSBA_LIST_ROWS * 64) + (ntrip + 1) * 64 + ln2] = (unsigned short)RSBA_LIST_NONE;
+      if (kLoss) {
+        const int row = tid2 >> 3, w = tid2 & 7;
+        const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
+        const bool in = cam < C && w < blk.nwords;
+        mk[row][w] = in ? a.cam_mask[(size_t)cam * nwords + (size_t)blk.word0 + w] : 0ull;
+        pre[row][w] = in ? a.cam_ptr[cam] + a.cam_prefix[(size_t)cam * nwords + (size_t)blk.word0 + w] : 0;
+      }
+      __syncthreads();
+    }
+  }
+  if (diag_tile) {
+    // odd-word half (waves 2/3) -> LDS -> even-word half; the record buffer is free once every lane has left the hit loop
+    __syncthreads();
+    if (tid >= 128 && dt < 120) {
+#pragma unroll
+      for (int i = 0; i < 36; ++i) pt[i * 128 + dt] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 120) {
+#pragma unroll
+      for (int i = 0; i < 36; ++i) acc[i] += pt[i * 128 + tid];
+    }
+  }
+  // slot of pair (ia, ib) in the workgroup's partial block is ia*16+ib whatever lane computed it
+  double* out = SegmentOut(sg, partial, a.grp_sum, seg_index);
+  if (!diag_tile || tid < 120) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) __hip_atomic_store(&out[i * 256 + pr], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();
+  double v[36];
+  if (!GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v, a.grp_flag, a.epoch)) return;
+  FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L, a.cam_free);
+  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
+  if (tid == 0 && a.tag) PublishStage(a.ready + 1 + sg.stage, a.tag);
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
 
@@ -1073,6 +1317,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
     __syncthreads();
     const int n_a = live ? cnt[ia] : 0;
     const int obs_chunk = live ? obs0 + obs_chunk_pre : 0;
+    RSBA_PRIO(0);
 #pragma unroll 1
     for (int i = ib; i < n_a; i += 16) {
       const double* pd = pt + (size_t)lst[ia][i] * RSBA_PT_STRIDE;
@@ -1081,6 +1326,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
       const int oi = obs_chunk + i;   // rank of this point in the camera's own observation list
       const double sqa = kLoss ? sq_cm[oi] : 1.0;
       const double uu = u_cm[oi], vv = v_cm[oi];
+      // (fetching the next hit's pixel one trip ahead was measured, round 4: the self segments take as long — they wait elsewhere)
       double e0[6], e1[6], n0[3], n1[3];
       SideRows(A, X, sqa, e0, e1, n0, n1);
       // the residual: ProjectResidual (ba_math.hpp), the one sequence of roundings g_p was formed with as well
@@ -1123,6 +1369,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
         else { acc[30 + p] = Fma2(e0[p], r0, e1[p], r1, acc[30 + p]); acc[36 + p] = Fma2(e0[p], f0, e1[p], f1, acc[36 + p]); }
       }
     }
+    RSBA_PRIO(3);
   }
   double* out = SegmentOut(sg, partial, a.grp_sum, seg_index);
 #pragma unroll
@@ -1131,12 +1378,12 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
   double v[RSBA_PART];
   if (!GroupReduce<RSBA_PART>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v, a.grp_flag, a.epoch)) return;
   FinishSelfSlot(C, sg.ga, v, camc, a.red, a.L, a.cam_free);
-  if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
+  if (sg.ga == a.last_group) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p, reinterpret_cast<double (*)[4]>(pt));   // (the chunk buffer is free: GroupReduce's barriers)
   if (a.self_only) return;
   const bool stage_done = StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0);
   if (a.all_self && a.tag && tid == 0) SelfTileArrive(a.sync_cnt, a.ngrp, a.ntiles, a.self_arrivals, a.ready, a.tag);
   if (!stage_done) return;
-  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0 && a.tag) PublishStage(a.ready + 1 + sg.stage, a.tag);
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
 
@@ -1172,6 +1419,7 @@ __device__ __forceinline__ bool ReduceGroupsInOrder(const SchurArgs& a, const Sc
       __syncthreads();
       if (run < 0) { all_ok = false; known = ng; break; }
       known += run;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (orders the group sums' loads below behind the flags' — the loads themselves are agent-scope)
       if (known < want) __builtin_amdgcn_s_sleep(4);
     }
     const int avail = known - q;
@@ -1257,7 +1505,7 @@ __device__ __forceinline__ void ReducerQuadrant(const SchurArgs& a, const SchurS
   }
   __builtin_amdgcn_s_waitcnt(0);   // the blocks are in memory (StageArrive's barrier collects everybody's)
   if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, false)) return;
-  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0 && a.tag) PublishStage(a.ready + 1 + sg.stage, a.tag);
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
 
@@ -1272,7 +1520,7 @@ __device__ __forceinline__ void ReducerQuadrant(const SchurArgs& a, const SchurS
 __device__ const int kSelfSetComp[RSBA_SELF_SETS][9] = {
     {0, 1, 2, 6, 7, 11, 0, 0, 0}, {3, 4, 5, 8, 9, 10, 12, 13, 14}, {15, 16, 17, 18, 19, 20, 0, 0, 0},
     {21, 22, 23, 24, 25, 26, 0, 0, 0}, {30, 31, 32, 36, 37, 38, 0, 0, 0}, {27, 28, 29, 33, 34, 35, 39, 40, 41}};
-__device__ __forceinline__ void ReducerSelfSet(const SchurArgs& a, const SchurSeg& sg, int ticket) {
+__device__ __forceinline__ void ReducerSelfSet(const SchurArgs& a, const SchurSeg& sg, int ticket, char* lds) {
   const int tid = OpaqueTid();
   const int set = sg.word_begin, nc = sg.word_end - sg.word_begin;
   const int ia = tid >> 4, ib = tid & 15, cam_a = RSBA_TG * sg.ga + ia;
@@ -1364,13 +1612,13 @@ __device__ __forceinline__ void ReducerSelfSet(const SchurArgs& a, const SchurSe
     }
   }
   const bool lin = set == RSBA_SELF_SETS - 1 && sg.ga == a.last_group;   // this reducer also folds the point pass' per-block scalars
-  if (lin) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p);
+  if (lin) FinishLinearize(a.nblocks_pp, a.block_scal, a.red, a.L, a.gmax_p, reinterpret_cast<double (*)[4]>(lds));
   if (a.self_only) return;
   __builtin_amdgcn_s_waitcnt(0);   // the results are in memory (StageArrive's barrier collects everybody's; its fence: FinishLinearize's plain stores)
   const bool stage_done = StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, lin && a.tag != 0);
   if (a.all_self && a.tag && tid == 0) SelfTileArrive(a.sync_cnt, a.ngrp, a.ntiles, a.self_arrivals, a.ready, a.tag);
   if (!stage_done) return;
-  if (tid == 0 && a.tag) __hip_atomic_store(&a.ready[1 + sg.stage], a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0 && a.tag) PublishStage(a.ready + 1 + sg.stage, a.tag);
   if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
 }
 
@@ -1378,9 +1626,9 @@ __device__ __forceinline__ void ReducerSelfSet(const SchurArgs& a, const SchurSe
 // finished by the reducer that adds it; the last arrival of a stage publishes it for the Cholesky that may be waiting for these
 // columns.  (Until round 3 a reducer added a slice of the components into a tile sum and the last one fetched it back and
 // finished the tile: three dependent trips to memory more at the tail of every stage.)
-__device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSeg& sg, int ticket) {
+__device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSeg& sg, int ticket, char* lds) {
   if (sg.self == 2) ReducerQuadrant(a, sg, ticket);
-  else ReducerSelfSet(a, sg, ticket);
+  else ReducerSelfSet(a, sg, ticket, lds);
 }
 
 // K_A2: the Schur elimination kernel.  One workgroup per segment (a range of 64-point words of one tile), in block order
@@ -1391,18 +1639,31 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
 // kSparse: the instance for more than 64 cameras (PairSegmentSparse instead of PairSegment) — a kernel of its own: compiled into
 // one kernel beside the masked search, the sparse path cost the 64-camera kernel 50 us (284 -> 337 us: the same registers, but
 // more scalar spills and a longer hot loop around the same arithmetic)
-template <bool kLoss, bool kSparse>
+// kMode: RSBA_PAIRS_MASKED / _SPARSE / _LISTED — which pair segment the instance holds (one each: compiled into one kernel beside
+// another, a pair segment costs the other registers, scalar spills and a longer hot loop)
+#define RSBA_PAIRS_MASKED 0
+#define RSBA_PAIRS_SPARSE 1
+#define RSBA_PAIRS_LISTED 2
+#define RSBA_SCHUR_LDS_BYTES 80992   // two workgroups per CU: 2 x (this + the few static words below) <= 160 KB
+template <bool kLoss, int kMode>
 __global__ void __launch_bounds__(256, 2)
 k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const int* __restrict__ small_flag_p, const SchurSeg* __restrict__ segs_p, SchurArgs a) {
   // (what a workgroup needs FIRST — the ticket counter, where this launch's tickets start, the work list — comes as separate leading
   //  arguments: the build preloads the first sixteen argument words into scalar registers at wave launch
   //  (-mllvm -amdgpu-kernarg-preload-count=16), a structure passed by value is not among them, and the ticket used to wait for
   //  a scalar load of its own address)
-  __shared__ double pt[RSBA_CHUNK * RSBA_PT_STRIDE];            // 48 KB
-  __shared__ unsigned long long mk[2 * RSBA_TG][RSBA_CW];       // 2 KB
-  __shared__ double sc[2 * RSBA_TG * RSBA_SC_STRIDE];           // 4 KB
-  __shared__ unsigned short lst[RSBA_TG][RSBA_CHUNK];           // 16 KB: self tiles, a camera's points of the chunk
-  __shared__ int cnt[RSBA_TG];
+  // One raw LDS buffer, carved by the entry's role: masked / sparse pair segments and self segments: chunk records 48 KB | mask
+  // rows 2 KB | camera constants 4 KB | self tiles: a camera's points of the chunk 16 KB | 16 counters; listed pair segments:
+  // 513 records of 80 bytes | (loss: mask rows, prefix counts) | four lists (PairSegmentListed)
+  __shared__ __attribute__((aligned(16))) char lds_raw[RSBA_SCHUR_LDS_BYTES];
+  static_assert(RSBA_LISTED_LDS(true) <= RSBA_SCHUR_LDS_BYTES && RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK + 64 <= RSBA_SCHUR_LDS_BYTES, "LDS carve");
+  static_assert(2 * (RSBA_SCHUR_LDS_BYTES + 256) <= 160 * 1024, "two workgroups per CU");
+  constexpr bool kSparse = kMode == RSBA_PAIRS_SPARSE;
+  double* pt = reinterpret_cast<double*>(lds_raw);
+  unsigned long long (*mk)[RSBA_CW] = reinterpret_cast<unsigned long long (*)[RSBA_CW]>(lds_raw + RSBA_CHUNK * RSBA_PT_STRIDE * 8);
+  double* sc = reinterpret_cast<double*>(lds_raw + RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048);
+  unsigned short (*lst)[RSBA_CHUNK] = reinterpret_cast<unsigned short (*)[RSBA_CHUNK]>(lds_raw + RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048 + 4096);
+  int* cnt = reinterpret_cast<int*>(lds_raw + RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK);
   // Work is handed out by ticket, not by block index: blocks are assigned to the 8 XCDs round-robin and each XCD
   // dispatches its own in order, so an XCD that is a little slower (the one that lends a CU to the Cholesky has 62 slots
   // instead of 64) starts the last blocks of a stage tens of microseconds late, and the stage ends with them.  With
@@ -1421,17 +1682,23 @@ k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const
   // the hot loop), more than the 6.8 us per entry it saves.  The counter is never reset: a launch moves it by its draws —
   // the entries, plus one draw past the end per resident workgroup — and the host passes where it starts.
   __shared__ int s_ticket, s_small;
+  // Priorities: what a workgroup does outside its hit loop is a handful of instructions between trips to memory (ticket, entry,
+  // staging; partial sums, arrival counters) — but its CU-mate, if older, is in a hit loop that issues an fp64 instruction
+  // whenever it can, and the arbiter serves the older wavefront first: the newcomer's few hundred prologue instructions were
+  // served at the rate the other left slots free (~8 %), 6 - 8 us from the end of one entry to the start of the next on a slot.
+  // So: priority 3 outside the hit loops, 0 inside (RSBA_PRIO() compiles to s_setprio).
+  RSBA_PRIO(3);
   if (threadIdx.x == 0) s_small = __hip_atomic_load(small_flag_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (;;) {
     if (threadIdx.x == 0) s_ticket = (int)((unsigned)__hip_atomic_fetch_add(ticket_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base);
     __syncthreads();
-    const int b = s_ticket;
+    const int b = __builtin_amdgcn_readfirstlane(s_ticket);   // (uniform: the entry is read with scalar loads and stays in scalar registers)
     if (kSparse && b >= total) break;
-    const SchurSeg sg = segs_p[b];
+    const SchurSeg sg = LoadSeg(segs_p + b);
     const int seg_index = sg.index;
     if (a.trace && b == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
     if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b] = wall_clock64();
-    if (sg.self >= 2) ReducerSegment(a, sg, b);
+    if (sg.self >= 2) ReducerSegment(a, sg, b, lds_raw);
     else if (sg.self) SelfSegment<kLoss>(a, sg, seg_index, b, pt, mk, lst, cnt);
     else {
       // two instances of the pair tile: the small-angle selects of the Jacobian rows (12 instructions per hit) are compiled in
@@ -1439,6 +1706,10 @@ k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const
       if (kSparse) {
         if (s_small) PairSegmentSparse<kLoss, true>(a, sg, seg_index, b, pt, sc);
         else PairSegmentSparse<kLoss, false>(a, sg, seg_index, b, pt, sc);
+      } else if (kMode == RSBA_PAIRS_LISTED) {
+        const PairBlk& k0 = sg.blk0;
+        if (s_small) PairSegmentListed<kLoss, true>(a, sg, seg_index, b, lds_raw, k0.word0, k0.nwords, k0.off0, k0.off1, k0.off2, k0.off3, k0.trips01, k0.trips23);
+        else PairSegmentListed<kLoss, false>(a, sg, seg_index, b, lds_raw, k0.word0, k0.nwords, k0.off0, k0.off1, k0.off2, k0.off3, k0.trips01, k0.trips23);
       } else if (s_small) PairSegment<kLoss, true>(a, sg, seg_index, b, pt, mk, sc);
       else PairSegment<kLoss, false>(a, sg, seg_index, b, pt, mk, sc);
     }

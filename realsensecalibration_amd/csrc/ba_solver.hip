@@ -107,7 +107,10 @@ class KernelTimer {
   void Reserve(int n) { while ((int)pool_.size() < n) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) break; pool_.push_back(e); } }
   // (the events of the last run are read HERE, when somebody asks — not at the end of the run, where ~5 us per pair were part of
   //  what a caller times around rsba_solver_run)
-  const std::map<std::string, std::pair<int64_t, double>>& stats() const { const_cast<KernelTimer*>(this)->Collect(); return stats_; }
+  const std::map<std::string, std::pair<int64_t, double>>& Stats() { Collect(); return stats_; }
+  // the start of a run: a caller that never asks for the statistics would grow the list of pending pairs, and the event pool with
+  // it, run after run — beyond 4096 pairs they are collected here (not always: ~5 us per pair would land in what the caller times)
+  void BeginRun() { if (on_ && pending_.size() > 4096) Collect(); }
  private:
   hipEvent_t Get() {
     if (pool_.empty()) Reserve(64);
@@ -198,6 +201,8 @@ struct rsba_solver {
   // Multi-GPU pipeline: the stage flags the Cholesky waits on are published on the communication stream sR, each after
   // the RCCL all-reduce of that stage's row slab of S (k_wait_stage / k_set_flag, ba_schur_tiled.hpp)
   bool pipelined_mg = false;
+  bool pipe_serial = false;            // RSBA_PIPELINE=2: the pipelined schedule's kernels launched one after the other (counter collection)
+  hipEvent_t ev_serial[2] = {nullptr, nullptr};
   hipStream_t sR = nullptr;
   int* ready_global = nullptr;
   long long* chol_waited = nullptr;   // device: ticks the pipelined Cholesky spent waiting for its columns (cumulative)
@@ -252,6 +257,7 @@ struct rsba_solver {
   double *W = nullptr;     // working copy of the reduced system for the multi-launch Cholesky (nc > RSBA_CHOL_MAXN)
   int* chol_ok = nullptr;
   double *red = nullptr, *A = nullptr, *S_copy = nullptr, *rhs_copy = nullptr, *dcam = nullptr;
+  double* red_tri = nullptr;   // the all-reduce payload as lower triangle + vectors (several ranks, more than 64 cameras: TriangularPayload)
   double *block_scal = nullptr, *block_part = nullptr, *small_red = nullptr, *gmax = nullptr, *res = nullptr;
   double* res_host = nullptr;  // pinned, coherent: the last kernel of a step posts res[] here, sequence number in the last slot
   double res_seq = 0.0;
@@ -267,6 +273,9 @@ struct rsba_solver {
 };
 
 namespace rsba {
+
+// doubles of the triangular all-reduce payload (lower triangle of S, then g_c, corr, diag U, scalars: k_pack_lower below)
+__host__ __device__ inline size_t TriSize(int n) { return (size_t)n * (n + 1) / 2 + 3 * (size_t)n + 8; }
 
 // ------------------------------------------------------------------------------------------------
 // Static structure of the tiled Schur kernel: visibility bitsets, tiles, segments.
@@ -304,6 +313,13 @@ static std::vector<int> SegmentBounds(int nW, int ns, double taper = 1.0) {
   if (!ok) for (int i = 0; i <= ns; ++i) bound[i] = (int)((int64_t)nW * i / ns);
   return bound;
 }
+// The taper of a pair tile's segments and whether its pair segments walk the sparse hit lists — one place for both
+// TiledSchur::Build and the point ordering, whose balancing units must be the units the kernel really synchronises on.
+static double PairSegmentTaper(int C, bool staged) { return (!staged && 6 * C > RSBA_CHOL_MAXN) ? 4.0 : 1.0; }
+static bool SparsePairSegments(int C, bool staged) {
+  static const bool sparse_on = !(getenv("RSBA_SPARSE_PAIRS") && atoi(getenv("RSBA_SPARSE_PAIRS")) == 0);
+  return sparse_on && 6 * C > RSBA_CHOL_MAXN && !staged;
+}
 static int PairSegmentsPerTile(int C, int P, bool staged) {
   const int ngroups = (C + RSBA_TG - 1) / RSBA_TG;
   int npair_tiles = 0;
@@ -338,15 +354,21 @@ static std::vector<int> BalancedPointOrder(int C, int P, bool staged, const std:
   const int mode = env ? atoi(env) : 1;
   if (mode == 0 || C < 2 || P < 4 * RSBA_CHUNK) return {};
   const int nW = (P + 63) / 64;
-  const std::vector<int> bound = SegmentBounds(nW, PairSegmentsPerTile(C, P, staged));
-  // units: the chunks the pair tiles synchronise on
+  const std::vector<int> bound = SegmentBounds(nW, PairSegmentsPerTile(C, P, staged), PairSegmentTaper(C, staged));
+  // units: what the lanes of a pair tile's wavefront synchronise on — the 512-point chunks of the masked search, or, with the
+  // sparse hit lists (more than 64 cameras), the WHOLE pair segment: its lists run as many trips as the longest of a
+  // wavefront's 64, over all of the segment's points.  (Until round 4 the units were cut with taper 1 whatever Build used,
+  // and into chunks whatever the pair segments walked: above 64 cameras the balance was computed against the wrong partition.)
+  const bool whole_segments = SparsePairSegments(C, staged);
   std::vector<int> ubeg, ucap;
-  for (size_t i = 0; i + 1 < bound.size(); ++i)
-    for (int w = bound[i]; w < bound[i + 1]; w += RSBA_CW) {
-      const int we = std::min(w + RSBA_CW, bound[i + 1]);
+  for (size_t i = 0; i + 1 < bound.size(); ++i) {
+    const int step = whole_segments ? std::max(1, bound[i + 1] - bound[i]) : RSBA_CW;
+    for (int w = bound[i]; w < bound[i + 1]; w += step) {
+      const int we = std::min(w + step, bound[i + 1]);
       ubeg.push_back(64 * w);
       ucap.push_back(std::min(64 * we, P) - 64 * w);
     }
+  }
   const int nu = (int)ubeg.size();
   // (the pair counters, 2 bytes per unit and camera pair: at most 64 MB of host memory — beyond that the file order is kept)
   if (nu < 2 || (double)nu * C * C > 3.2e7) return {};
@@ -482,7 +504,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     // (more than 64 cameras: at most 16 self segments per tile — two reduction groups, no reducer workgroups)
     const int ns_self = std::max(1, std::min((2 * cus + ngroups - 1) / ngroups, nW));
     const int ns = self ? (6 * C > RSBA_CHOL_MAXN && !staged ? std::min(ns_self, 16) : ns_self) : PairSegmentsPerTile(C, P, staged);
-    const std::vector<int> bound = SegmentBounds(nW, ns, (!self && !staged && 6 * C > RSBA_CHOL_MAXN) ? 4.0 : 1.0);
+    const std::vector<int> bound = SegmentBounds(nW, ns, self ? 1.0 : PairSegmentTaper(C, staged));
     for (int i = 0; i < ns; ++i) {
       SchurSeg e; memset(&e, 0, sizeof(e));
       e.ga = tab[3 * t]; e.gb = tab[3 * t + 1]; e.self = tab[3 * t + 2];
@@ -565,8 +587,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   std::vector<int> border; border.reserve(nblocks);
   // More than 64 cameras: the pair segments' hit lists (PairSegmentSparse, ba_schur_tiled.hpp).  RSBA_SPARSE_PAIRS=0: the
   // masked search of the 512-point chunks, as below 65 cameras.
-  static const bool sparse_on = !(getenv("RSBA_SPARSE_PAIRS") && atoi(getenv("RSBA_SPARSE_PAIRS")) == 0);
-  const bool sparse = sparse_on && 6 * C > RSBA_CHOL_MAXN && !staged;
+  const bool sparse = SparsePairSegments(C, staged);
   if (staged) {
     for (int g = 0; g < nstages; ++g) {
       std::vector<int> tiles_g;
@@ -640,6 +661,13 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     for (int64_t q = 0; q < N; ++q) { ucm[cmpos[q]] = u[q]; vcm[cmpos[q]] = v[q]; }
     HIPCHK(hipMemcpy(u_cm, ucm.data(), ucm.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(v_cm, vcm.data(), vcm.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  {
+    // (opt-in, RSBA_LISTED=1: measured SLOWER than the masked search at 64 cameras x 100k points — 270 against 257 us, HISTORY.md —
+    //  although its hit loop is 6 % shorter; kept because its host-built lists are an independent enumeration of the hits the
+    //  device's bit search finds: tests/test_gpu_switches.py holds the two to the same bits)
+    static const bool listed_on = getenv("RSBA_LISTED") && atoi(getenv("RSBA_LISTED")) != 0;
+    if (listed_on && !sparse && nseg_pair > 0 && (rc = BuildPairLists(mask, sg))) return rc;
   }
   HIPCHK(hipMemset(sync_cnt, 0, (size_t)nsync * sizeof(int)));
   HIPCHK(hipMemset(grp_flag, 0, (size_t)std::max(ngrp, 1) * sizeof(int)));
@@ -738,10 +766,84 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   return RSBA_OK;
 }
 
+// The static hit lists of the pair segments up to 64 cameras (PairSegmentListed, ba_schur_tiled.hpp).  A segment's words are cut
+// into blocks the way PairSegment cuts them into chunks (RSBA_CW words from the segment's first word on); a block whose busiest
+// lane has more than RSBA_LIST_TRIPS hits (dense visibility: 8 cameras that all see every point share 512 points per chunk) is
+// halved until it fits — a single word holds at most 64.  Lane -> pair and, on diagonal tiles, half -> word parity as in the
+// kernel; a lane's hits in ascending point order, as the masked search finds them.
+int TiledSchur::BuildPairLists(const std::vector<unsigned long long>& mask, std::vector<SchurSeg>& sg) {
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<PairBlk> blks;
+  std::vector<unsigned short> rows;   // [row][64]
+  size_t nhits = 0;
+  unsigned char dpair[128];
+  { int t = 0; for (int x = 0; x < 16; ++x) for (int y = x + 1; y < 16; ++y) dpair[t++] = (unsigned char)(x * 16 + y); for (; t < 128; ++t) dpair[t] = 0; }
+  for (int q = 0; q < nseg; ++q) {
+    SchurSeg& e = sg[q];
+    if (e.self != 0) continue;
+    const bool diag = e.ga == e.gb;
+    // the two mask rows and the word parity (diagonal tiles) of thread tid; false: the lane owns no pair
+    auto lane = [&](int tid, const unsigned long long** ma, const unsigned long long** mb, int* parity) {
+      int pr = tid; *parity = -1;
+      if (diag) { const int dt = tid & 127; if (dt >= 120) return false; pr = dpair[dt]; *parity = tid >> 7; }
+      const int ca = RSBA_TG * e.ga + (pr >> 4), cb = RSBA_TG * e.gb + (pr & 15);
+      if (ca >= C || cb >= C) return false;
+      *ma = &mask[(size_t)ca * nwords]; *mb = &mask[(size_t)cb * nwords];
+      return true;
+    };
+    e.blk_begin = (int)blks.size();
+    std::function<void(int, int)> emit = [&](int w0, int w1) {
+      unsigned cnt[256];
+      unsigned trips[4] = {0, 0, 0, 0};
+      for (int tid = 0; tid < 256; ++tid) {
+        const unsigned long long *ma, *mb; int parity;
+        unsigned c = 0;
+        if (lane(tid, &ma, &mb, &parity))
+          for (int w = w0; w < w1; ++w) if (parity < 0 || ((w - e.word_begin) & 1) == parity) c += (unsigned)__builtin_popcountll(ma[w] & mb[w]);
+        cnt[tid] = c; trips[tid >> 6] = std::max(trips[tid >> 6], c);
+      }
+      if (*std::max_element(trips, trips + 4) > RSBA_LIST_TRIPS && w1 - w0 > 1) { const int mid = (w0 + w1) / 2; emit(w0, mid); emit(mid, w1); return; }
+      PairBlk b; memset(&b, 0, sizeof(b));
+      b.word0 = w0; b.nwords = w1 - w0;
+      for (int wv = 0; wv < 4; ++wv) {
+        const unsigned tr = (trips[wv] + 1u) & ~1u;   // two rows per round of the hit loop
+        b.off(wv) = (unsigned)(rows.size() / 64);
+        (wv < 2 ? b.trips01 : b.trips23) |= tr << (16 * (wv & 1));
+        rows.resize(rows.size() + (size_t)tr * 64, (unsigned short)RSBA_LIST_NONE);
+        for (int l = 0; l < 64; ++l) {
+          const int tid = wv * 64 + l;
+          const unsigned long long *ma, *mb; int parity;
+          if (!cnt[tid] || !lane(tid, &ma, &mb, &parity)) continue;
+          size_t r = (size_t)b.off(wv) * 64 + l;
+          for (int w = w0; w < w1; ++w) {
+            if (parity >= 0 && ((w - e.word_begin) & 1) != parity) continue;
+            for (unsigned long long h = ma[w] & mb[w]; h != 0ull; h &= h - 1ull) { rows[r] = (unsigned short)((w - w0) * 64 + __builtin_ctzll(h)); r += 64; ++nhits; }
+          }
+        }
+      }
+      blks.push_back(b);
+    };
+    for (int wb = e.word_begin; wb < e.word_end; wb += RSBA_CW) emit(wb, std::min(wb + RSBA_CW, e.word_end));
+    e.nblk = (int)blks.size() - e.blk_begin;
+    e.blk0 = blks[e.blk_begin];
+  }
+  if (rows.size() / 64 >= ((size_t)1 << 32)) return RSBA_OK;   // (offsets are 32-bit rows: keep the masked search)
+  if (rows.empty()) rows.resize(64, (unsigned short)RSBA_LIST_NONE);
+  int rc;
+  if ((rc = DevAlloc(&pblk, blks.size())) || (rc = DevAlloc(&hl, rows.size()))) return rc;
+  HIPCHK(hipMemcpy(pblk, blks.data(), blks.size() * sizeof(PairBlk), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(hl, rows.data(), rows.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  hl_rows = rows.size() / 64;
+  if (getenv("RSBA_DEBUG"))
+    fprintf(stderr, "rsba: hit lists of %d pair segments: %zu blocks, %zu hits in %zu rows (%.0f %% of the lane-trips), %.1f MB, built in %.3f s\n", nseg_pair, blks.size(),
+            nhits, hl_rows, 100.0 * nhits / std::max<size_t>(hl_rows * 64, 1), rows.size() * 2e-6, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  return RSBA_OK;
+}
+
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, segs_ordered, segs_ordered_first, segs_ordered_self, small_flag, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm, hits, hit_off, hit_trips};
+  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, segs_ordered, segs_ordered_first, segs_ordered_self, small_flag, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm, hits, hit_off, hit_trips, pblk, hl};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  cam_mask = nullptr; hits = nullptr; hit_off = nullptr; hit_trips = nullptr;
+  cam_mask = nullptr; hits = nullptr; hit_off = nullptr; hit_trips = nullptr; pblk = nullptr; hl = nullptr;
 }
 
 static void FreeSolver(rsba_solver* s) {
@@ -750,11 +852,12 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_map, s->tc_hand, s->tc_xs, s->tc_ys};
+                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->red_tri, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_map, s->tc_hand, s->tc_xs, s->tc_ys};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
   s->marker_schur.Free();
+  for (hipEvent_t e : s->ev_serial) if (e) (void)hipEventDestroy(e);
   if (s->res_host) (void)hipHostFree(s->res_host);
   if (s->trace_base) (void)hipFree(s->trace_base);
   if (s->wg_trace) (void)hipFree(s->wg_trace);
@@ -832,6 +935,10 @@ static bool SetupPipeline(rsba_solver* s) {
   const char* env = getenv("RSBA_PIPELINE");
   const int mode = env ? atoi(env) : 1;
   if (mode == 0) return false;
+  if (mode == 2) {
+    s->pipe_serial = hipEventCreateWithFlags(&s->ev_serial[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->ev_serial[1], hipEventDisableTiming) == hipSuccess;
+    if (!s->pipe_serial) return false;
+  }
   s->test_stall = getenv("RSBA_TEST_STALL") ? std::max(1, atoi(getenv("RSBA_TEST_STALL"))) : 0;
   const bool mg = s->comm != nullptr;
   // Multi-GPU pipeline: opt-in (RSBA_PIPELINE_MG=1).  Round 3: the same kernels as the single-GPU pipeline (diagonal-workgroup
@@ -843,7 +950,26 @@ static bool SetupPipeline(rsba_solver* s) {
   // launched both 7 us after the result in either case, RSBA_HOSTPROF=1) — the same 0.430 -> 0.470 ms is measured WITHOUT a
   // communicator when two more hardware queues merely exist in the process.  It could not be run on
   // several GPUs in this environment, so it stays opt-in.
-  if (mg && !(getenv("RSBA_PIPELINE_MG") && atoi(getenv("RSBA_PIPELINE_MG")) == 1)) return false;
+  // Round 4: ON by default with a communicator (RSBA_PIPELINE_MG=0: the sequential multi-GPU schedule) — tools/stress_pipeline.py
+  // passes under loopback groups of 2, 4 and 8 ranks at 64 cameras, and with a 1-rank communicator it is the faster schedule
+  // whatever the queue pool (0.405 ms with GPU_MAX_HW_QUEUES=8, 0.473 with the runtime's default pool, sequential 0.4725).  The one
+  // setting it cannot live with is a pool of THREE hardware queues (the waiting kernels land behind each other: every step times
+  // out): then the sequential schedule is used, and the library says so once.
+  if (mg) {
+    static std::once_flag warned;
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    const int nq = q ? atoi(q) : 0;
+    if (getenv("RSBA_PIPELINE_MG") && atoi(getenv("RSBA_PIPELINE_MG")) == 0) return false;
+    if (nq == 3) {
+      std::call_once(warned, [] { fprintf(stderr, "rsba: GPU_MAX_HW_QUEUES=3 puts the pipelined multi-GPU schedule's waiting kernels behind each other; "
+                                                   "using the sequential schedule (set GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises)\n"); });
+      return false;
+    }
+    if (nq != 8 && nq != 1 && nq != 2)
+      std::call_once(warned, [nq] { fprintf(stderr, "rsba: a communicator exists and GPU_MAX_HW_QUEUES is %s: the pipelined multi-GPU schedule starts each "
+                                                     "step's kernels ~40 us late with the runtime's default pool of hardware queues; set GPU_MAX_HW_QUEUES=8 before the "
+                                                     "HIP runtime initialises (INTEGRATION.md)\n", nq ? "not 1, 2 or 8" : "unset"); });
+  }
   if (s->nc > RSBA_CHOL_MAXN || s->C <= RSBA_TG) return false;        // one camera group: nothing to overlap
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) return false;
@@ -864,7 +990,9 @@ static bool SetupPipeline(rsba_solver* s) {
     for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
     return got;
   };
-  bool ok = side_stream(&s->sB, [&](hipStream_t c) { return StreamsRunConcurrently(c, s->stream); });
+  // (RSBA_PIPELINE=2 launches the kernels one after the other: nothing to probe — and under counter collection, which serialises
+  //  kernels, the probe's waiter would never see its flag)
+  bool ok = side_stream(&s->sB, [&](hipStream_t c) { return s->pipe_serial || StreamsRunConcurrently(c, s->stream); });
   if (!ok && getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: the side stream does not run beside the main stream, solve not pipelined\n");
   ok = ok && hipMalloc((void**)&s->chol_waited, 2 * sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, 2 * sizeof(long long)) == hipSuccess;
   if (ok && mg) {
@@ -935,7 +1063,7 @@ static int UploadPoints(rsba_solver* s) {
     // with duplicate observations runs schur_impl 0 and cannot pipeline); it is also the communicator's first
     // collective, so connection set-up happens here and not inside a step.
     const char* e1 = getenv("RSBA_PIPELINE"); const char* e2 = getenv("RSBA_PIPELINE_MG");
-    const bool mg_possible = s->comm && !(e1 && atoi(e1) == 0) && (e2 && atoi(e2) == 1);
+    const bool mg_possible = s->comm && !(e1 && atoi(e1) == 0) && !(e2 && atoi(e2) == 0);
     if (mg_possible) {
       int h = s->pipelined ? 1 : 0, *d = nullptr;
       if ((rc = DevAlloc(&d, 1))) return rc;
@@ -994,6 +1122,11 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
       (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)) || (rc = DevAlloc(&s->dec, 4)))
     return rc;
+  if (s->comm) {
+    // triangular all-reduce payload: by default where bytes bound the collective (more than 64 cameras), RSBA_TRI_PAYLOAD=1 / 0 forces / disables it
+    const char* tp = getenv("RSBA_TRI_PAYLOAD");
+    if (tp ? atoi(tp) != 0 : s->nc > RSBA_CHOL_MAXN) { if ((rc = DevAlloc(&s->red_tri, TriSize(s->nc)))) return rc; }
+  }
   HIPCHK(hipMemset(s->res, 0, RES_SIZE * sizeof(double)));   // (not every path writes every field: RES_STALL above 64 cameras)
   HIPCHK(hipMemset(s->small_red, 0, 8 * sizeof(double)));
   HIPCHK(hipMemset(s->chol_ok, 0, 3 * sizeof(int)));   // [0] Cholesky status, [1] arrival counter of the back-substitution's blocks, [2] its wait timed out
@@ -1168,6 +1301,48 @@ static void LaunchPointSide(TiledSchur& ts, rsba_solver* s, const IterParams& ip
 // per CU), each drawing tickets until the work list is through; otherwise one per entry.
 static int SchurGrid(int entries, bool sparse) { return sparse ? std::min(entries, 2 * DeviceCUs()) : entries; }
 
+// ------------------------------------------------------------------------------------------------
+// Several ranks, more than 64 cameras: the all-reduce payload as LOWER TRIANGLE + vectors (SURVEY 8e priced the
+// triangular 9.4 MB at 256 cameras; the full square S || g_c || corr || diag U || scalars is 18.9 MB, and an
+// all-reduce over a ring of point-to-point xGMI links is bound by bytes per link).  S is written symmetric to the bit by
+// the Schur kernel's finishers (every block and its mirror from the same registers), so summing the lower triangle over
+// the ranks and mirroring it gives exactly the bits the full all-reduce gives.  k_pack_lower: row i of the triangle =
+// S[i][0..i] behind each other, then the 3 n + 8 doubles behind S as they are; k_unpack_lower writes both halves back.
+// Up to 64 cameras the payload is 1.19 MB and the collective latency-bound: two more launches would cost more than the
+// bytes save (RSBA_TRI_PAYLOAD=1 forces the packed payload there too, =0 disables it; tests/test_gpu_loopback.py).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_lower(int n, const double* __restrict__ red, RedLayout L, double* __restrict__ tri) {
+  const size_t nt = (size_t)n * (n + 1) / 2, total = nt + 3 * (size_t)n + 8;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
+    if (k >= nt) { tri[k] = red[L.gc() + (k - nt)]; continue; }
+    // row of element k of the triangle: the largest i with i (i + 1) / 2 <= k (the root in floating point, corrected in integers)
+    size_t i = (size_t)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+    while (i * (i + 1) / 2 > k) --i;
+    while ((i + 1) * (i + 2) / 2 <= k) ++i;
+    const size_t j = k - i * (i + 1) / 2;
+    tri[k] = red[L.S() + i * (size_t)n + j];
+  }
+}
+__global__ void __launch_bounds__(256) k_unpack_lower(int n, const double* __restrict__ tri, double* __restrict__ red, RedLayout L) {
+  const size_t nn = (size_t)n * n, nt = (size_t)n * (n + 1) / 2, total = nn + 3 * (size_t)n + 8;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
+    if (k >= nn) { red[L.gc() + (k - nn)] = tri[nt + (k - nn)]; continue; }
+    const size_t i = k / n, j = k - i * n, hi = i > j ? i : j, lo = i > j ? j : i;
+    red[L.S() + k] = tri[hi * (hi + 1) / 2 + lo];
+  }
+}
+
+// The instance of the Schur kernel that holds the pair segments this problem runs: sparse hit lists above 64 cameras, static lists
+// up to 64 (RSBA_LISTED=0 or no lists: the masked search).
+static void LaunchSchurInstance(const SchurArgs& a, int grid, bool loss, hipStream_t st) {
+#define RSBA_LAUNCH_SCHUR(LOSS, MODE) k_schur_tiles<LOSS, MODE><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a)
+  if (a.hits != nullptr) { if (loss) RSBA_LAUNCH_SCHUR(true, RSBA_PAIRS_SPARSE); else RSBA_LAUNCH_SCHUR(false, RSBA_PAIRS_SPARSE); }
+  else if (a.hl != nullptr) { if (loss) RSBA_LAUNCH_SCHUR(true, RSBA_PAIRS_LISTED); else RSBA_LAUNCH_SCHUR(false, RSBA_PAIRS_LISTED); }
+  else if (loss) RSBA_LAUNCH_SCHUR(true, RSBA_PAIRS_MASKED);
+  else RSBA_LAUNCH_SCHUR(false, RSBA_PAIRS_MASKED);
+#undef RSBA_LAUNCH_SCHUR
+}
+
 static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   const int x = s->cur;
   SchurArgs a;
@@ -1179,6 +1354,7 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   a.trace = s->trace; a.wg_trace = s->wg_trace;
   a.grp_flag = ts.grp_flag; a.epoch = ++ts.epoch;
   a.hits = ts.hits; a.hit_off = ts.hit_off; a.hit_trips = ts.hit_trips;
+  a.pblk = ts.pblk; a.hl = ts.hl;
   a.all_self = 0; a.self_arrivals = ts.self_arrivals;
   return a;
 }
@@ -1187,15 +1363,11 @@ void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& 
   RoctxRange rr("K2+K3 camera-side rows + Schur elimination into the reduced system");
   SchurArgs a = MakeSchurArgs(*this, s, tag);
   if (first_staged) { a.segs_ordered = segs_ordered_first; a.all_self = 1; }
-  const bool sparse = a.hits != nullptr;
+  const bool sparse = a.hits != nullptr;   // (resident workgroups: as many as the chip holds, each drawing tickets until the list is through)
   const int grid = SchurGrid(nblocks, sparse);
   a.total = nblocks; a.ticket_base = ticket_base; ticket_base += (unsigned)(nblocks + (sparse ? grid : 0));
   T.Begin("k_schur_tiles", st);
-  if (a.hits != nullptr) {
-    if (ip.huber_delta != 0.0) k_schur_tiles<true, true><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
-    else k_schur_tiles<false, true><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
-  } else if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
-  else k_schur_tiles<false, false><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
+  LaunchSchurInstance(a, grid, ip.huber_delta != 0.0, st);
   T.End(st);
 }
 
@@ -1206,8 +1378,8 @@ void TiledSchur::LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTime
   const int grid = SchurGrid(nblocks_self, false);   // (the self-only pass runs the masked instance at any size)
   a.total = nblocks_self; a.ticket_base = ticket_base; ticket_base += (unsigned)nblocks_self;
   T.Begin("k_schur_tiles(self only)", st);
-  if (ip.huber_delta != 0.0) k_schur_tiles<true, false><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
-  else k_schur_tiles<false, false><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a);
+  a.hits = nullptr;   // (one entry per workgroup; a self segment is the same code in every instance)
+  LaunchSchurInstance(a, grid, ip.huber_delta != 0.0, st);
   T.End(st);
 }
 
@@ -1344,40 +1516,59 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const int* all_diag = first_staged ? ts.ready + 9 : nullptr;
     int* resident_word = (ip.first || s->pipe_check_resident) ? reinterpret_cast<int*>(s->res_host + RES_SIZE) : nullptr;
     s->pipe_check_resident = false;
-    T.Begin("k_reduced_system_solve", s->sB);
-    // multi-GPU: the gates open on the flags k_stage_unpack publishes behind each stage's all-reduce, and a wait may last as
-    // long as the slowest rank
-    const int* gate_ready = mg ? s->ready_global : ts.ready;
-    const long long gate_budget = mg ? 10 * RSBA_STALL_TICKS : 0;
-    if (s->chol_wgs > 1 && s->chol_diag) {
-      const StageGate sg{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + 16, resident_word, s->chol_wgs, all_diag, mg ? 1 : 0};
-      const DiagCholFlags df{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024};
-      if (mg) k_reduced_system_solve_diag<true><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
-          C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok, sg, df, tag, s->mc_trace);
-      else k_reduced_system_solve_diag<false><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
-          C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok, sg, df, tag, s->mc_trace);
-    }
-    else if (s->chol_wgs > 1 && !mg)   // (the round-robin kernel has no transposed source: multi-GPU, it is the one-workgroup kernel)
-      k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
-          C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
-          StageGate{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + 16, resident_word, s->chol_wgs},
-          MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48}, tag, s->mc_trace);
-    else
-    k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
-                                                     s->camc[c], s->dcam, s->gmax, s->res, ip, mg ? 2 : 1,
-                                                     s->chol_ok, StageGate{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15,
-                                                                           T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget,
-                                                                           ts.ready + 16, resident_word, 1});
-    T.End(s->sB);
-    rr_k4.End();
-    if (resident_word != nullptr) {
-      volatile int* w = resident_word;
-      const auto t_res = std::chrono::steady_clock::now();
-      while (*w != gate_tag && std::chrono::steady_clock::now() - t_res < std::chrono::milliseconds(20)) __builtin_ia32_pause();
-    }
+    // RSBA_PIPELINE=2 — for counter collection (rocprofv3 --pmc serialises kernels, and a factorisation that waits inside the
+    // kernel for a Schur kernel queued behind it would only run out its budget): the SAME kernels with the same work list,
+    // stage flags and publication fences, launched one after the other — Schur kernel, then (stream events) the factorisation,
+    // whose gates are all up by then, then the back-substitution.  Nothing overlaps; it is not a schedule anybody should time.
+    const bool serial = s->pipe_serial && !mg;
+    auto launch_factorisation = [&]() -> int {
+      T.Begin("k_reduced_system_solve", s->sB);
+      // multi-GPU: the gates open on the flags k_stage_unpack publishes behind each stage's all-reduce, and a wait may last as
+      // long as the slowest rank
+      const int* gate_ready = mg ? s->ready_global : ts.ready;
+      const long long gate_budget = mg ? 10 * RSBA_STALL_TICKS : 0;
+      if (s->chol_wgs > 1 && s->chol_diag) {
+        const StageGate sg{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + 16, resident_word, s->chol_wgs, all_diag, mg ? 1 : 0};
+        const DiagCholFlags df{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024};
+        if (mg) k_reduced_system_solve_diag<true><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
+            C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok, sg, df, tag, s->mc_trace);
+        else k_reduced_system_solve_diag<false><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
+            C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok, sg, df, tag, s->mc_trace);
+      }
+      else if (s->chol_wgs > 1 && !mg)   // (the round-robin kernel has no transposed source: multi-GPU, it is the one-workgroup kernel)
+        k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
+            C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
+            StageGate{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + 16, resident_word, s->chol_wgs},
+            MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48}, tag, s->mc_trace);
+      else
+      k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
+                                                       s->camc[c], s->dcam, s->gmax, s->res, ip, mg ? 2 : 1,
+                                                       s->chol_ok, StageGate{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15,
+                                                                             T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget,
+                                                                             ts.ready + 16, resident_word, 1});
+      T.End(s->sB);
+      rr_k4.End();
+      if (resident_word != nullptr) {
+        volatile int* w = resident_word;
+        const auto t_res = std::chrono::steady_clock::now();
+        while (*w != gate_tag && std::chrono::steady_clock::now() - t_res < std::chrono::milliseconds(20)) __builtin_ia32_pause();
+      }
+      return RSBA_OK;
+    };
+    if (serial) {
+      ts.LaunchTiles(s, ip, T, st, tag, first_staged);
+      HIPCHK(hipEventRecord(s->ev_serial[0], st));
+      HIPCHK(hipStreamWaitEvent(s->sB, s->ev_serial[0], 0));
+      { const int rcf = launch_factorisation(); if (rcf != RSBA_OK) return rcf; }
+      HIPCHK(hipEventRecord(s->ev_serial[1], s->sB));
+      HIPCHK(hipStreamWaitEvent(st, s->ev_serial[1], 0));
+      hp(1); hp(2);
+    } else {
+    { const int rcf = launch_factorisation(); if (rcf != RSBA_OK) return rcf; }
     hp(1);   // point side + factorisation launched
     ts.LaunchTiles(s, ip, T, st, tag, first_staged);
     hp(2);   // Schur kernel launched
+    }
     if (mg) {
       // communication stream: stage by stage, as the Schur kernel publishes them locally — the row slab of S of the
       // stage's camera group and the group's ranges of g_c, rhs correction and diag U, as one grouped collective; the
@@ -1407,10 +1598,21 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   if (s->comm && !(pipe && s->pipelined_mg)) {
     RoctxRange rr_k7("K7 RCCL all-reduce of the reduced system");
     // one group: the sum of the packed reduced system and the max of the point-gradient bound go out as one launch
-    COMMCHK(s->comm->GroupStart());
-    COMMCHK(s->comm->SumDoubles(s->red, s->L.size(), st));
-    COMMCHK(s->comm->MaxDoubles(s->gmax, 1, st));
-    COMMCHK(s->comm->GroupEnd());
+    if (s->red_tri != nullptr) {
+      const int n = s->nc;
+      const int grid_tri = std::max(1, std::min(2 * DeviceCUs(), (int)((TriSize(n) + 255) / 256)));
+      k_pack_lower<<<grid_tri, 256, 0, st>>>(n, s->red, s->L, s->red_tri);
+      COMMCHK(s->comm->GroupStart());
+      COMMCHK(s->comm->SumDoubles(s->red_tri, TriSize(n), st));
+      COMMCHK(s->comm->MaxDoubles(s->gmax, 1, st));
+      COMMCHK(s->comm->GroupEnd());
+      k_unpack_lower<<<grid_tri, 256, 0, st>>>(n, s->red_tri, s->red, s->L);
+    } else {
+      COMMCHK(s->comm->GroupStart());
+      COMMCHK(s->comm->SumDoubles(s->red, s->L.size(), st));
+      COMMCHK(s->comm->MaxDoubles(s->gmax, 1, st));
+      COMMCHK(s->comm->GroupEnd());
+    }
   }
 
   RoctxRange rr_k4s(pipe ? "K4 (already launched)" : "K4 reduced camera system: Cholesky + solve");
@@ -1801,6 +2003,7 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
     last.cost = x_cost; last.gradient_max_norm = gmax;
     x_moved = false;
   };
+  const auto t_loop0 = std::chrono::steady_clock::now();
   for (;;) {
     // checks of FinalizeIterationAndCheckIfMinimizerCanContinue for the previous iteration
     if (!first) {
@@ -1812,6 +2015,8 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
         settle_moved();
       }
       if (at_limit) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_ITERATIONS);
+      // "Maximum solver time reached" (trust_region_minimizer.cc, behind the iteration limit)
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count() >= o.max_solver_time_in_seconds) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_TIME);
       if (!x_moved && gmax <= o.gradient_tolerance) return finish(RSBA_CONVERGENCE, RSBA_STOP_GRADIENT);
       if (radius < o.min_trust_region_radius) return finish(RSBA_CONVERGENCE, RSBA_STOP_MIN_RADIUS);
     }
@@ -1916,6 +2121,8 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
   if (o) opt = *o; else rsba_options_default(&opt);
   if (opt.world_size > 1 && (!opt.comm_unique_id || opt.rank < 0 || opt.rank >= opt.world_size)) return RSBA_ERR_ARG;
   if (opt.world_size > 1 && p->model != RSBA_MODEL_POINTS) return RSBA_ERR_UNSUPPORTED;  // marker-chain: replicas only
+  if (opt.world_size > 1 && opt.max_solver_time_in_seconds < 1e9) return RSBA_ERR_UNSUPPORTED;  // (every rank its own clock: the ranks would part)
+  if (!(opt.max_solver_time_in_seconds >= 0.0)) return RSBA_ERR_ARG;
   const auto t0 = std::chrono::steady_clock::now();
   rsba_solver* s = new rsba_solver();
   s->prob = p; s->opt = opt;
@@ -1968,6 +2175,7 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
   if (hipSetDevice(s->device) != hipSuccess) return RSBA_ERR_HIP;
   int rc;
   rsba::CommScope device_turn(s->comm.get());
+  s->timer.BeginRun();
   struct AbortOnError { rsba_solver* s; int* rc; ~AbortOnError() { if (*rc != RSBA_OK && s->comm) s->comm->Abort(); } } abort_guard{s, &rc};
   if (s->prob->model == RSBA_MODEL_POINTS) {
     const auto tr0 = std::chrono::steady_clock::now();
@@ -2031,6 +2239,7 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
 int rsba_solver_configure_run(rsba_solver* s, int32_t max_num_iterations, int32_t profile_kernels) {
   if (!s || max_num_iterations < 0 || profile_kernels < 0 || profile_kernels > 2) return RSBA_ERR_ARG;
   if (hipSetDevice(s->device) != hipSuccess) return RSBA_ERR_HIP;
+  rsba::CommScope device_turn(s->comm.get());   // (event synchronisation: a loopback rank touches the device on its turn only)
   s->opt.max_num_iterations = max_num_iterations;
   s->opt.profile_kernels = profile_kernels;
   s->timer.Reset();
@@ -2042,6 +2251,7 @@ int rsba_solver_configure_run(rsba_solver* s, int32_t max_num_iterations, int32_
 int rsba_solver_download(rsba_solver* s) {
   if (!s) return RSBA_ERR_ARG;
   if (hipSetDevice(s->device) != hipSuccess) return RSBA_ERR_HIP;
+  rsba::CommScope device_turn(s->comm.get());   // (blocking copies are not limited to this rank's streams: on its turn only)
   rsba_problem& p = *s->prob;
   if (p.model == RSBA_MODEL_POINTS) {
     if (hipMemcpy(p.parameters.data(), s->cam[s->cur], 6 * s->C * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return RSBA_ERR_HIP;
@@ -2057,10 +2267,15 @@ int rsba_solver_iterations(const rsba_solver* s, rsba_iteration* out, int32_t ca
   return n;
 }
 
-int rsba_solver_kernel_stats(const rsba_solver* s, rsba_kernel_stat* out, int32_t capacity) {
-  if (!s) return 0;
+int rsba_solver_kernel_stats(const rsba_solver* s_in, rsba_kernel_stat* out, int32_t capacity) {
+  if (!s_in) return 0;
+  // (the accessor collects the pending event pairs of the last run: it synchronises events on the solver's device, and a
+  //  loopback rank touches the device on its turn only)
+  rsba_solver* s = const_cast<rsba_solver*>(s_in);
+  if (hipSetDevice(s->device) != hipSuccess) return 0;
+  rsba::CommScope device_turn(s->comm.get());
   int n = 0;
-  for (const auto& kv : s->timer.stats()) {
+  for (const auto& kv : s->timer.Stats()) {
     if (n >= capacity) break;
     memset(&out[n], 0, sizeof(out[n]));
     strncpy(out[n].name, kv.first.c_str(), sizeof(out[n].name) - 1);
@@ -2111,6 +2326,7 @@ int rsba_solver_full_report(const rsba_solver* s, char* buf, int32_t capacity) {
     case RSBA_STOP_MIN_RADIUS: snprintf(why, sizeof(why), "Minimum trust region radius reached. Trust region radius <= %e", s->opt.min_trust_region_radius); break;
     case RSBA_STOP_INVALID_STEPS: snprintf(why, sizeof(why), "Number of successive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d", s->opt.max_num_consecutive_invalid_steps); break;
     case RSBA_STOP_INITIAL_FAILURE: snprintf(why, sizeof(why), "Residual and Jacobian evaluation failed."); break;
+    case RSBA_STOP_MAX_TIME: snprintf(why, sizeof(why), "Maximum solver time reached. Total solver time: %e >= %e.", m.minimizer_seconds, s->opt.max_solver_time_in_seconds); break;
     default: break;
   }
   hipDeviceProp_t prop; memset(&prop, 0, sizeof(prop));
@@ -2145,6 +2361,10 @@ int rsba_solver_final_costs(const rsba_solver* s, double* cost, double* sum_sq) 
 }
 
 void rsba_solver_destroy(rsba_solver* s) {
+  // (hipFree and the diagnostics' blocking copies wait for the whole device: a loopback rank frees on its turn only, so that an
+  //  early finisher cannot stall another rank's in-kernel waits into their budget)
+  std::shared_ptr<rsba::Comm> comm_keep = s ? s->comm : nullptr;
+  rsba::CommScope device_turn(comm_keep.get());
   if (s && s->mc_trace && s->tc_tiles > 0) {
     // diagnostic: the diagonal tiles' chain of the latest persistent tiled factorisation, microseconds since its first stamp.
     // 0 last update entered | 10 sub-diagonal rows there | 11 T there | 12 T in LDS | 1 X formed | 2 update done, first half |

@@ -132,6 +132,7 @@ void rsba_options_default(rsba_options* o) {
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8; o->huber_delta = 0.0;
   o->device = -1; o->schur_impl = 1; o->profile_kernels = 0; o->rank = 0; o->world_size = 1; o->comm_unique_id = nullptr; o->stream = nullptr;
+  o->max_solver_time_in_seconds = 1e9;
 }
 
 int rsba_read_intrinsics_xml(const char* path, double* out4) { return rsba::ReadIntrinsicsXml(path, out4); }

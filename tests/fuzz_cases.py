@@ -9,7 +9,8 @@ oracle agrees with ITSELF ten times better than that under a change of roundings
 does not):
   * the costs of the first three iterates agree to 1e-12 — always (a defect shows at once, rounding shows late);
   * same termination, iteration count and accept / reject sequence as the oracle — unless the oracle's own runs part;
-  * every iterate's cost agrees to 1e-9 — up to three iterations before the oracle's own runs part, if they do;
+  * every iterate's cost agrees to 1e-9 — if the oracle's own runs part, up to THE MARGIN RULE's iterate (oracle_spread.py):
+    three iterations before they do, and never beyond the first iterate whose trust-region radius exceeds 1e13;
   * final cost to max(1e-9, 10 x spread), reprojection RMS to max(1e-4 px, 10 x spread);
   * parameters RAW, per block, to max(1e-6, 10 x spread) — no alignment along the gauge orbit.
 About one case in eight is of the second kind (robust loss, two to five views per point: the radius reaches 1e13 .. 1e16 and
@@ -35,6 +36,18 @@ def cases(n, seed):
         loss = str(rng.choice(["none", "none", "huber", "huber", "cauchy"]))
         scale = float(rng.choice([1.0, 2.5])) if loss != "none" else 0.0
         out.append(dict(index=i, C=C, P=P, k=k, seed=int(rng.integers(1, 1 << 30)), loss=loss, scale=scale))
+    return out
+
+
+def pinned():
+    """Cases of other sweeps (tools/fuzz_parity.py) pinned by their seeds: the one the end-of-round-3 sweep flagged — the HIP path
+    parts from the oracle three iterates before the oracle's own runs do, with the radius above 1e13 (THE MARGIN RULE) — and two of
+    the sensitive class above 64 cameras, through the tiled factorisation and the sparse pair segments."""
+    out = []
+    for n, seed, index in ((200, 31, 38), (210, 1, 178), (150, 7, 82)):
+        c = dict(cases(n, seed)[index])
+        c["sweep"] = seed
+        out.append(c)
     return out
 
 

@@ -76,7 +76,9 @@ def spread(oracle, prob, optkw, ref=None):
     runs.append((unreverse(a, C), sa, la))
     hd = optkw.get("huber_delta", 0.0)
     _, ss_ref = oracle.points_cost(prob, params, huber_delta=hd)
-    out = dict(same_trajectory=True, raw=0.0, aligned=0.0, final_cost=0.0, rms=0.0, part=-1)
+    # first iterate whose trust-region radius exceeds RADIUS_CAP (column 6 of the log: the radius after the step); -1: none
+    big = np.nonzero(log[:, 6] > RADIUS_CAP)[0]
+    out = dict(same_trajectory=True, raw=0.0, aligned=0.0, final_cost=0.0, rms=0.0, part=-1, radius_iter=int(big[0]) if len(big) else -1)
     for a, sa, la in runs:
         same = (sa.termination == s.termination and sa.stop_reason == s.stop_reason and sa.num_iterations == s.num_iterations and
                 np.array_equal(la[:, 7], log[:, 7]))
@@ -92,8 +94,22 @@ def spread(oracle, prob, optkw, ref=None):
     return out
 
 
+# THE MARGIN RULE for runs on which the oracle parts from itself.  The iterates' costs of the implementation under test have to
+# agree with the oracle's (1e-9) up to and including iterate
+#     agree_until = max(3, min(P - 3, R))
+# where P is the first iterate at which the oracle's own three executions part (1e-10) and R the first iterate whose trust-region
+# radius exceeds RADIUS_CAP = 1e13 (no such iterate: R = infinity); beyond it nothing is asked of single iterates, only of the end
+# state.  Why R: the damped system's eigenvalues along the 7-dof gauge orbit are diag / radius, so from 1e13 on a rounding error
+# of one ulp in the gradient moves the iterate along the orbit by more than the 1e-9 bar resolves, and the accept / reject
+# decision of a step whose cost change is at the rounding level (rho ~ 0 / 0) is decided by the roundings — two samples of the
+# oracle's own parting point (P) do not bound where a third execution parts, the radius does.  (Seed-31 sweep case 038, 2 cameras
+# x 69 points x 2 views, Cauchy: radius 1.2e13 at iterate 19, the oracle's runs part at 25, the HIP path at 22 with a final cost
+# equal to 1.6e-13 — pinned in tests/test_gpu_fuzz.py.)
+RADIUS_CAP = 1e13
+
+
 def bars(sp, n_obs):
-    """The tolerances a parity test may use on this problem (see the module docstring)."""
+    """The tolerances a parity test may use on this problem (see the module docstring and THE MARGIN RULE above)."""
     parted = sp["part"] >= 0 or not sp["same_trajectory"]
     # Runs whose iterates part (the oracle's own!) are chaotic from there on: two samples of the end state do not bound a third.
     # What is left to ask of the end of such a run is that it is as good a fit: cost within 1 %, RMS within 0.1 px.
@@ -101,4 +117,4 @@ def bars(sp, n_obs):
                 rms=max(1e-1 if parted else 1e-4, 10.0 * sp["rms"]), same_trajectory=sp["same_trajectory"],
                 # iterates whose costs have to agree to 1e-9: all of them, or — when the oracle's own runs part — the ones up to
                 # three iterations before they do
-                agree_until=None if sp["part"] < 0 else max(3, sp["part"] - 3))
+                agree_until=None if sp["part"] < 0 else max(3, min(sp["part"] - 3, sp["radius_iter"] if sp.get("radius_iter", -1) >= 0 else sp["part"])))

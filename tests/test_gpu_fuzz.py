@@ -33,6 +33,17 @@ def test_random_shape_matches_oracle(oracle, case):
     assert not bad, "; ".join(bad) + " | raw %.1e, oracle against itself %.1e" % (r["raw"], r["spread"]["raw"])
 
 
+@pytest.mark.parametrize("case", fuzz_cases.pinned(), ids=lambda c: "seed%d-%s" % (c["sweep"], fuzz_cases.label(c)))
+def test_pinned_sensitive_case_passes_the_margin_rule(oracle, case):
+    """Sensitive cases of other sweeps, by explicit seed (fuzz_cases.pinned): judged by the same criterion, whose margin is a
+    rule (oracle_spread.py, THE MARGIN RULE) — the suite decides, not a note in DESIGN.md."""
+    r = fuzz_cases.run(oracle, capi, case)
+    assert fuzz_cases.sensitive(r), "the case is pinned because the oracle parts from itself on it"
+    bad = fuzz_cases.verdict(r)
+    assert not bad, "; ".join(bad) + " | raw %.1e, oracle against itself %.1e" % (r["raw"], r["spread"]["raw"])
+    assert r["first3"] <= 1e-12
+
+
 def test_sweep_is_mostly_held_to_the_baseline_bars():
     """The looser bars must stay the exception, and the strict class must really have been strict."""
     if len(SEEN) < len(CASES):

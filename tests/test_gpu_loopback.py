@@ -94,17 +94,37 @@ def test_sharded_solves_match_the_unsharded_oracle(oracle, C, P, k, huber, world
     _sharded_solve_matches_oracle(oracle, whole, _shards(C, P, k, 400 + C, world, outl), huber=huber)
 
 
+@pytest.mark.parametrize("mode", ["1", "0"])
 @pytest.mark.parametrize("C,P,k,world", [(40, 5000, 9, 2), (64, 6000, 12, 3)])
-def test_pipelined_multi_gpu_schedule_sharded(oracle, C, P, k, world):
-    """RSBA_PIPELINE_MG=1: the factorisation launched ahead and gated stage by stage on flags published behind each stage's
-    all-reduce (the group's row slab of S, read transposed), the candidate's sums all-reduced behind the back-substitution, the
-    decision taken by k_publish_result on every rank alike — with real shards, not a 1-rank communicator."""
+def test_pipelined_multi_gpu_schedule_sharded(oracle, C, P, k, world, mode):
+    """The pipelined multi-GPU schedule (the default with a communicator since round 4; RSBA_PIPELINE_MG=0: the sequential one): the
+    factorisation launched ahead and gated stage by stage on flags published behind each stage's all-reduce (the group's row slab
+    of S, read transposed), the candidate's sums all-reduced behind the back-substitution, the decision taken by k_publish_result
+    on every rank alike — with real shards, not a 1-rank communicator.  Both schedules, explicitly."""
     whole = syn.make_problem(C, P, k, 500 + C)
-    os.environ["RSBA_PIPELINE_MG"] = "1"
+    os.environ["RSBA_PIPELINE_MG"] = mode
     try:
         _sharded_solve_matches_oracle(oracle, whole, _shards(C, P, k, 500 + C, world))
     finally:
         del os.environ["RSBA_PIPELINE_MG"]
+
+
+@pytest.mark.parametrize("C,P,k,world", [(40, 4000, 9, 2), (70, 3000, 10, 3)])
+def test_triangular_payload_adds_the_same_bits(C, P, k, world):
+    """The all-reduce payload as lower triangle + vectors (the default above 64 cameras with several ranks, forced here at 40 as
+    well: RSBA_TRI_PAYLOAD=1) against the full square (=0): S leaves the Schur kernel symmetric to the bit, so both must end in
+    identical bits on every rank (sequential multi-GPU schedule: the pipelined one all-reduces row slabs)."""
+    shards = _shards(C, P, k, 600 + C, world)
+    res = {}
+    os.environ["RSBA_PIPELINE_MG"] = "0"
+    try:
+        for tri in ("0", "1"):
+            os.environ["RSBA_TRI_PAYLOAD"] = tri
+            res[tri] = capi.solve_points_sharded_loopback(shards)
+    finally:
+        del os.environ["RSBA_TRI_PAYLOAD"], os.environ["RSBA_PIPELINE_MG"]
+    for (pa, sa, la, _), (pb, sb, lb, _) in zip(res["0"], res["1"]):
+        assert np.array_equal(pa, pb) and np.array_equal(la, lb) and sa.final_cost == sb.final_cost
 
 
 def test_a_stall_on_one_rank_is_everybodys_stall(oracle, capfd):

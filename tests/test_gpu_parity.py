@@ -301,6 +301,27 @@ def test_configure_run_changes_the_next_run_only():
     problem.close()
 
 
+def test_max_solver_time_ends_the_run_like_ceres():
+    """Solver::Options::max_solver_time_in_seconds (Ceres' default 1e9; the reference leaves it alone,
+    Main_Calibration/bundle_adjustment_manager.cpp:90-92): checked once per iteration behind the iteration limit — a run whose
+    budget is 0 s ends after its first iteration with NO_CONVERGENCE and the 'Maximum solver time reached' line in the report;
+    the default changes nothing; several ranks refuse a finite limit (each would read its own clock)."""
+    prob = syn.make_problem(24, 2500, 8, seed=78)
+    problem = capi.Problem.points(prob)
+    fixed = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0)
+    sv = capi.Solver(problem, capi.default_options(max_num_iterations=20, max_solver_time_in_seconds=0.0, **fixed))
+    s = sv.run()
+    assert (s.termination_type, s.stop_reason, s.num_iterations) == (capi.NO_CONVERGENCE, 8, 1)
+    assert "Maximum solver time reached" in sv.full_report()
+    sv.close()
+    sv = capi.Solver(problem, capi.default_options(max_num_iterations=6, **fixed))
+    assert capi.default_options().max_solver_time_in_seconds == 1e9 and sv.run().num_iterations == 6
+    sv.close()
+    with pytest.raises(capi.RsbaError):
+        capi.Solver(problem, capi.default_options(max_solver_time_in_seconds=-1.0))
+    problem.close()
+
+
 def test_solve_is_bitwise_reproducible():
     """The default path has no atomics: every reduction runs in a fixed order, so two solves of the same problem
     give bit-identical parameters and iteration logs (and every rank of a multi-GPU run factors identical bits)."""
@@ -549,7 +570,7 @@ def test_shard_payloads_add_up_to_the_payload_of_the_whole(huber):
 
 
 def test_multi_gpu_pipeline_opt_in_single_rank(oracle):
-    """RSBA_PIPELINE_MG=1 (opt-in): the pipelined schedule with RCCL in it — per-stage all-reduces of the row slabs of S
+    """RSBA_PIPELINE_MG=1 (the default with a communicator since round 4): the pipelined schedule with RCCL in it — per-stage all-reduces of the row slabs of S
     on a communication stream, the Cholesky gated on the flags published after them and reading its panels from the
     reduced slabs (transposed source), the ranks agreeing on the schedule and on stalls through all-reduces.  One rank
     here (RSBA_FORCE_COMM): the collectives are identities, everything around them runs."""

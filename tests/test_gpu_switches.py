@@ -30,13 +30,18 @@ SETTINGS = [
     ({"RSBA_BALANCE": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_SEG_PER_CU": "4"}, ["c64_huber", "c130"]),
     ({"RSBA_SPARSE_PAIRS": "0"}, ["c70_huber", "c130"]),
+    ({"RSBA_LISTED": "0"}, ["c40", "c64_huber", "c8_dense"]),
+    ({"RSBA_LISTED": "1"}, ["c8_dense", "c64_dense_huber"]),
+    ({"RSBA_LISTED": "1", "RSBA_SEG_PER_CU": "1"}, ["c33_long", "c64_huber"]),   # (segments of several blocks)
     ({"RSBA_CHOL_TILES": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_TILE_ORDER": "0"}, ["c130", "c240"]),
     ({"RSBA_SYS_FUSED": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_BACKSUB_MULTI": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_BACKSUB_MULTI": "1"}, ["c70_huber", "c130"]),
     ({"RSBA_FORCE_COMM": "1"}, ["c40", "c64_huber", "c70_huber"]),
-    ({"RSBA_FORCE_COMM": "1", "RSBA_PIPELINE_MG": "1"}, ["c40", "c64_huber"]),
+    ({"RSBA_FORCE_COMM": "1", "RSBA_PIPELINE_MG": "0"}, ["c40", "c64_huber"]),   # (the sequential multi-GPU schedule; the pipelined one is the default)
+    ({"RSBA_FORCE_COMM": "1", "RSBA_TRI_PAYLOAD": "1", "RSBA_PIPELINE_MG": "0"}, ["c40", "c70_huber"]),
+    ({"RSBA_FORCE_COMM": "1", "RSBA_TRI_PAYLOAD": "0"}, ["c70_huber"]),
     ({"RSBA_FORCE_COMM": "1", "RSBA_BACKSUB_PROJ": "0"}, ["c40"]),
 ]
 
@@ -55,3 +60,52 @@ def test_switch_selects_a_path_that_matches_the_oracle(env, cases):
         assert r["raw"] < 1e-6, (name, r)
         assert r["reproducible"], (name, r)
     assert "stalled" not in out.stderr, out.stderr[-2000:]
+
+
+def test_listed_pair_segments_add_the_same_bits_as_the_masked_search(tmp_path):
+    """Up to 64 cameras the pair segments walk static hit lists (PairSegmentListed, round 4) instead of searching the visibility
+    masks (PairSegment, RSBA_LISTED=0): the same hits in the same order through the same arithmetic, so whole solves — parameters
+    and every column of the iteration log — must agree bit for bit, with and without a loss, on sparse, dense (blocks cut down to
+    fit the list rows) and many-chunk problems (RSBA_SEG_PER_CU=1: long segments, several blocks each)."""
+    cases = ["c40", "c64_huber", "c8_dense", "c33_long", "c64_dense_huber"]
+    files = []
+    for listed in ("0", "1"):
+        env = dict(os.environ, RSBA_LISTED=listed, RSBA_SEG_PER_CU="1")
+        f = str(tmp_path / ("listed%s.npz" % listed))
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_worker.py"), "--dump", f] + cases, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        files.append(f)
+    import numpy as np
+    a, b = np.load(files[0]), np.load(files[1])
+    for name in a.files:
+        assert np.array_equal(a[name], b[name]), name
+
+
+def test_thousands_of_pipelined_steps_add_the_same_bits_as_the_sequential_schedule(tmp_path):
+    """The in-kernel hand-overs (stage flags between the Schur kernel and the factorisation beside it, the tiled factorisation's
+    data-as-flag transfers above 64 cameras) are ordered by agent-scope stores awaited before a counter or flag moves, one release
+    per stage and an acquire behind every flag: a stale line read once in thousands of steps would show as a different bit.  3000
+    forced LM steps at 64 cameras (pipelined) and 600 at 130 (tiled factorisation) against RSBA_PIPELINE=0, bit for bit in the
+    parameters and in every column of the iteration log."""
+    files = []
+    for pipe, steps in (("1", "3000"), ("0", "3000")):
+        # (the same segments in both schedules — the sequential one cuts four per CU by default, the pipelined one eight — so that
+        #  both add in the same order)
+        env = dict(os.environ, RSBA_PIPELINE=pipe, SWITCH_FORCED_STEPS=steps, RSBA_SEG_PER_CU="8")
+        f = str(tmp_path / ("pipe%s.npz" % pipe))
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_worker.py"), "--dump", f, "c64_long"], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "stalled" not in out.stderr, out.stderr[-2000:]
+        files.append(f)
+    for rep in ("a", "b"):
+        env = dict(os.environ, SWITCH_FORCED_STEPS="600")
+        f = str(tmp_path / ("tiled%s.npz" % rep))
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_worker.py"), "--dump", f, "c130_long"], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "stalled" not in out.stderr, out.stderr[-2000:]
+        files.append(f)
+    import numpy as np
+    for fa, fb in ((files[0], files[1]), (files[2], files[3])):
+        a, b = np.load(fa), np.load(fb)
+        for name in a.files:
+            assert a[name].shape == b[name].shape and np.array_equal(a[name], b[name]), name

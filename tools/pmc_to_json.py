@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> profiles/rNN_pmc_<workload>.json.
 
-usage: pmc_to_json.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [workload label]
+usage: pmc_to_json.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [workload label] [schedule the passes ran]
 Corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KB; on gfx950 FETCH_SIZE reports
 half the bytes of wide coalesced reads, so reads are counted twice (8-byte accesses are uncalibrated).  bench.py reads
 the result for the `traffic` field of its roofline objects."""
@@ -24,11 +24,13 @@ def avg(d, counter):
 
 fetch, write = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
 label = sys.argv[4] if len(sys.argv) > 4 else "cfg3"
+schedule = sys.argv[5] if len(sys.argv) > 5 else "sequential schedule (counter collection serialises kernels)"
 out = {}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     out[k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
               "note": "FETCH_SIZE x2 (gfx950 reports half the bytes of wide coalesced reads; 8-B accesses are uncalibrated) + "
-                      "WRITE_SIZE, separate --pmc passes, %s, sequential schedule (counter collection serialises kernels)" % label}
+                      "WRITE_SIZE, separate --pmc passes, %s, %s" % (label, schedule)}
+out["__schedule__"] = schedule
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], "kernels:", ", ".join(out))
