@@ -133,6 +133,25 @@ __host__ __device__ inline size_t TileCholLdsDoubles() { return (size_t)64 * RSB
 // fused = 1: k_sys_build's arithmetic on the way into LDS, straight from the Schur kernel's payload `red` — the (n + 1) x n
 // intermediate is neither written nor read back and a launch is gone (10 us of a 1 ms step at 256 cameras).  On the first
 // iteration the Jacobi scales are defined here (from diag U): the diagonal tiles store them for the rest of the solve.
+// Pipelined above 64 cameras (round 4): the kernel is launched BEFORE the Schur kernel and every tile waits, before it builds its
+// entries of the system, for the stage(s) of the Schur elimination that complete them — entry (i, j) of S, i >= j, is final once
+// the camera group of column j is published (the finishers write every block and its mirror), the damping diagonal, the gradient
+// and the right-hand-side correction of a column come with its group's self tile, and on the first step of a run the Jacobi scale
+// of a ROW needs that row's diag U: every self tile (all_diag).  The tiles of the first tile columns start at once, the
+// others sleep; a tile column's two panels take ~18 us, a stage arrives every ~25 us: the chain keeps up and ends a few tile
+// columns behind the last stage.  ready == nullptr: the sequential schedule (no waits).
+struct TileGate {
+  const int* ready = nullptr;      // TiledSchur::ready: [1 + g] == tag once camera group g's columns are in S
+  int tag = 0;
+  int cols = 96;                   // reduced columns per camera group
+  const int* all_diag = nullptr;   // first step of a run: == tag once every camera's diag U is written
+  int* started_cnt = nullptr;      // "every tile is resident" (see StageGate): device counter, host word, tiles
+  int* started_host = nullptr;
+  int started_need = 0;
+  long long* waited = nullptr;     // += ticks (100 MHz) the LAST diagonal tile slept on its stage: the kernel's span minus this is its own work
+  long long budget = 0;
+};
+
 struct TileSysSource {
   int fused = 0;
   const double* red = nullptr;
@@ -479,7 +498,7 @@ static __device__ __noinline__ bool SubDiagFirstHalf(const TileCtx& c, lds_doubl
 __global__ void __launch_bounds__(256, 2)
 k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scaled, damped system + rhs row (k_sys_build) */,
                         double* __restrict__ F /* (n + 2) x n */, int* __restrict__ ok_flag, TileCholFlags f, int tag,
-                        double* __restrict__ res, TileSysSource src) {
+                        double* __restrict__ res, TileSysSource src, TileGate gate) {
   extern __shared__ double lds[];
   const TileLds L = TileLdsOf(lds);
   const int tid = threadIdx.x;
@@ -497,6 +516,13 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
     J = t - I * (I + 1) / 2;
   }
   const int r0 = 64 * I, c0 = 64 * J;
+  // "every tile is resident" (pipelined schedule, first step of a run): counted by EVERY workgroup of the launch, also the one
+  // that has nothing to do
+  if (gate.ready != nullptr && tid == 0 && gate.started_host != nullptr &&
+      __hip_atomic_fetch_add(gate.started_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gate.started_need - 1) {
+    __hip_atomic_store(gate.started_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(gate.started_host, gate.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (c0 >= m) return;   // (the tile row of the rhs row reaches one column past the matrix when m is a multiple of 64)
   if (tid == 0) L.flags[1] = 0;
   if (f.trace != nullptr && tid == 0) {
@@ -517,6 +543,21 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
       double* q = TileHandSlot(f, f.parity ^ 1, J);
       for (int e = tid; e < 2048; e += 256) StoreShared(&q[kTileHandS1 + e], sent);
     }
+  }
+  // (gated = beside the Schur kernel, whose hit loops run at priority 0: the factorisation is a latency chain of a few instructions
+  //  between trips to memory — served first)
+  if (gate.ready != nullptr) __builtin_amdgcn_s_setprio(3);
+  bool gate_stalled = false;
+  int stall_code = 1;   // what RES_STALL carries: 1 a hand-over inside the factorisation, 2 the wait for every camera's diag U, 10 + g the wait for stage g
+  if (gate.ready != nullptr) {
+    const long long gb = gate.budget > 0 ? gate.budget : RSBA_STALL_TICKS;
+    const long long tw0 = wall_clock64();
+    if (gate.all_diag != nullptr && !WaitFlagWG(gate.all_diag, gate.tag, f.error, gb)) { gate_stalled = true; stall_code = 2; }
+    // (columns at or beyond n are identity padding; the right-hand-side row's entries come with their column's group)
+    const int g_lo = min(c0, n - 1) / gate.cols, g_hi = min(c0 + 63, n - 1) / gate.cols;
+    for (int g = g_lo; g <= g_hi && !gate_stalled; ++g)
+      if (!WaitFlagWG(gate.ready + 1 + g, gate.tag, f.error, gb)) { gate_stalled = true; stall_code = 10 + g; }
+    if (gate.waited != nullptr && tid == 0 && I == J && 64 * (J + 1) >= m) *gate.waited += wall_clock64() - tw0;
   }
   // entry (gi, gj) of the padded system; row m is the right-hand side
   auto sysv = [&](int gi, int gj) {
@@ -559,9 +600,10 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
   }
   if (I == 0 && J == 0 && tid == 0) { __hip_atomic_store(ok_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 0.0; }   // (a stall, half a second later, sets it)
   __syncthreads();
-  const TileCtx ctx{n, m, np, I, J, tag, F, ok_flag, f, RSBA_STALL_TICKS};
-  const long long budget = RSBA_STALL_TICKS;
-  bool stalled = false;
+  // (gated: a tile waits for tiles that wait for stages — the budget of a hand-over covers a stage's wait as well)
+  const long long budget = gate.ready != nullptr ? 3 * RSBA_STALL_TICKS : RSBA_STALL_TICKS;
+  const TileCtx ctx{n, m, np, I, J, tag, F, ok_flag, f, budget};
+  bool stalled = gate_stalled;
   const int plast = min(2 * J + 1, np - 1);
   for (int p = 0; p <= plast && !stalled; ++p) {
     const int Jp = p >> 1, hf = p & 1, kb = p * RSBA_PB, lc = 32 * hf;   // lc: the panel's first column inside a tile of column Jp
@@ -648,9 +690,10 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
     }
   }
   if (stalled && tid == 0) {
-    __hip_atomic_store(f.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the first to give up names its wait; the others follow the error flag)
+    const bool first_out = __hip_atomic_exchange(f.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
     __hip_atomic_store(ok_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    res[RES_STALL] = 1.0;   // the host repeats the step with the multi-launch factorisation
+    if (first_out || res[RES_STALL] == 0.0) res[RES_STALL] = (double)stall_code;   // the host repeats the step (sequential schedule / multi-launch factorisation)
   }
 }
 
@@ -754,7 +797,7 @@ k_backsub_multi(int C, const double* __restrict__ red, RedLayout L, const double
     __syncthreads();
   }
   publish_pending();
-  if (stalled) { if (tid == 0) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 1.0; } return; }
+  if (stalled) { if (tid == 0) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 5.0; } return; }
   if (w != 0) return;
   // workgroup 0: every block's x is in xsol and visible (it waited for, or produced, each of them)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -828,7 +871,7 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
           for (int round = 0;; ++round) {
             v = __hip_atomic_load(&xsol[32 * b + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (HandThere(v)) break;
-            if ((round & 15) == 15 && (wall_clock64() - t0 > budget || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { s_fail = 1; v = 0.0; break; }
+            if ((round & 15) == 15 && (wall_clock64() - t0 > budget || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { s_fail = 1 + b; v = 0.0; break; }
             __builtin_amdgcn_s_sleep(1);
           }
         }
@@ -848,7 +891,7 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
       for (int c = 0; c < 16; ++c) { lv[c] = l1[c]; l1[c] = l2[c]; l2[c] = l3[c]; }
       __syncthreads();
     }
-    if (stalled) { if (tid == 0) __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (stalled) { if (tid == 0) { if (__hip_atomic_exchange(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) res[RES_STALL] = 1000.0 + 100.0 * h + s_fail; } return; }
     if (tid < 96) StoreShared(&ys[96 * h + tid], yown[tid]);
     return;
   }
@@ -1009,7 +1052,7 @@ k_backsub_chain(int C, const double* __restrict__ red, RedLayout L, const double
     dgcur = dgnext;
     raw_cur = raw_next;
   }
-  if (stalled) { if (tid == 0) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 1.0; } return; }
+  if (stalled) { if (tid == 0) { if (__hip_atomic_exchange(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) res[RES_STALL] = 6.0; } return; }
   // every x is in xsol (this workgroup stored them) — visible to its own plain loads behind the acknowledgements and one acquire
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();

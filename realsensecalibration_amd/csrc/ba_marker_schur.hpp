@@ -859,7 +859,7 @@ struct MarkerSchurDevice {
       if (tc_tiles > 0) {
         Tm.Begin("k_chol_tiles_persistent", st);
         k_chol_tiles_persistent<<<tc_tiles, 256, TileCholLdsDoubles() * sizeof(double), st>>>(
-            nr, Wm, A, ok_flag, TileCholFlags{tc_flags, tc_flags + tc_np, tc_flags + (size_t)tc_np * (tc_nrt + 1), tc_nrt, tc_hand, tc_tag & 1, 0, tc_map}, tc_tag + 1, res, TileSysSource{});
+            nr, Wm, A, ok_flag, TileCholFlags{tc_flags, tc_flags + tc_np, tc_flags + (size_t)tc_np * (tc_nrt + 1), tc_nrt, tc_hand, tc_tag & 1, 0, tc_map}, tc_tag + 1, res, TileSysSource{}, TileGate{});
         ++tc_tag;
         Tm.End(st);
       } else {

@@ -47,6 +47,11 @@ namespace rsba {
 class KernelTimer;
 
 #define RSBA_TG 16          // cameras per group
+// Flags of a step in TiledSchur::ready (64 ints): [1 + g] stage g published (g < RSBA_MAX_STAGES), then the three below.
+#define RSBA_MAX_STAGES 32        // camera groups a pipelined solve can gate on (512 cameras)
+#define RSBA_READY_ALLDIAG 40     // = tag once every self tile is finished (first step of a run: every camera's diag U)
+#define RSBA_READY_SOLVED 41      // = tag when the reduced system is solved (the back-substitution waits for it inside the kernel)
+#define RSBA_READY_STARTED 42     // arrival counter of the factorisation's workgroups ("all resident")
 #define RSBA_PRIO(p) __builtin_amdgcn_s_setprio(p)   // wavefront priority (see k_schur_tiles)
 #define RSBA_CHUNK 512      // points per LDS chunk
 #define RSBA_CW (RSBA_CHUNK / 64)
@@ -596,10 +601,10 @@ __device__ __forceinline__ void PublishStage(int* flag, int tag) { __hip_atomic_
 // A self tile is finished (its diag U, g_c, diagonal block are written and — StageArrive's fence, pipelined schedule —
 // visible): the last of the ngroups self tiles publishes ready[9].  Thread 0 only; call behind StageArrive.
 __device__ __forceinline__ void SelfTileArrive(int* __restrict__ sync_cnt, int ngrp, int ntiles, int ngroups, int* __restrict__ ready, int tag) {
-  int* cnt = sync_cnt + ngrp + ntiles + 15;
+  int* cnt = sync_cnt + ngrp + ntiles + RSBA_MAX_STAGES;
   if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) {
     __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ready[9], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ready[RSBA_READY_ALLDIAG], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

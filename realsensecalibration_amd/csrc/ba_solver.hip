@@ -203,6 +203,8 @@ struct rsba_solver {
   bool pipelined_mg = false;
   bool pipe_serial = false;            // RSBA_PIPELINE=2: the pipelined schedule's kernels launched one after the other (counter collection)
   hipEvent_t ev_serial[2] = {nullptr, nullptr};
+  hipEvent_t ev_tiles = nullptr;       // tile pipeline (more than 64 cameras): the side stream's solve -> the main stream's back-substitution
+  size_t tc_nflags = 0, tc_hand_doubles = 0, tc_xs_doubles = 0, tc_ys_doubles = 0;   // sizes of the tiled factorisation's flags and hand-over buffers (reset after a stall)
   hipStream_t sR = nullptr;
   int* ready_global = nullptr;
   long long* chol_waited = nullptr;   // device: ticks the pipelined Cholesky spent waiting for its columns (cumulative)
@@ -315,10 +317,13 @@ static std::vector<int> SegmentBounds(int nW, int ns, double taper = 1.0) {
 }
 // The taper of a pair tile's segments and whether its pair segments walk the sparse hit lists — one place for both
 // TiledSchur::Build and the point ordering, whose balancing units must be the units the kernel really synchronises on.
-static double PairSegmentTaper(int C, bool staged) { return (!staged && 6 * C > RSBA_CHOL_MAXN) ? 4.0 : 1.0; }
+// (above 64 cameras in EITHER schedule: the pipelined one there — round 4, the tiled factorisation beside the Schur kernel — runs the
+//  same sparse, tapered pair segments in stage order)
+static double PairSegmentTaper(int C, bool staged) { (void)staged; return 6 * C > RSBA_CHOL_MAXN ? 4.0 : 1.0; }
 static bool SparsePairSegments(int C, bool staged) {
+  (void)staged;
   static const bool sparse_on = !(getenv("RSBA_SPARSE_PAIRS") && atoi(getenv("RSBA_SPARSE_PAIRS")) == 0);
-  return sparse_on && 6 * C > RSBA_CHOL_MAXN && !staged;
+  return sparse_on && 6 * C > RSBA_CHOL_MAXN;
 }
 static int PairSegmentsPerTile(int C, int P, bool staged) {
   const int ngroups = (C + RSBA_TG - 1) / RSBA_TG;
@@ -326,7 +331,7 @@ static int PairSegmentsPerTile(int C, int P, bool staged) {
   for (int ga = 0; ga < ngroups; ++ga) for (int gb = ga; gb < ngroups; ++gb) if (!(ga == gb && std::min(RSBA_TG, C - RSBA_TG * ga) < 2)) ++npair_tiles;
   // measured at 64 cameras: the pipelined schedule likes shorter workgroups (a stage ends with its last one), the
   // sequential one fewer partial sums
-  const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : (staged ? 8 : (6 * C > RSBA_CHOL_MAXN ? 6 : 4));
+  const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : (6 * C > RSBA_CHOL_MAXN ? 6 : (staged ? 8 : 4));
   const int target = seg_per_cu * DeviceCUs();
   const int nW = (P + 63) / 64;
   const int ns = (int)std::lround((double)target / std::max(1, npair_tiles));
@@ -503,7 +508,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     const int nW = (P + 63) / 64;  // mask words that hold points
     // (more than 64 cameras: at most 16 self segments per tile — two reduction groups, no reducer workgroups)
     const int ns_self = std::max(1, std::min((2 * cus + ngroups - 1) / ngroups, nW));
-    const int ns = self ? (6 * C > RSBA_CHOL_MAXN && !staged ? std::min(ns_self, 16) : ns_self) : PairSegmentsPerTile(C, P, staged);
+    const int ns = self ? (6 * C > RSBA_CHOL_MAXN ? std::min(ns_self, 16) : ns_self) : PairSegmentsPerTile(C, P, staged);
     const std::vector<int> bound = SegmentBounds(nW, ns, self ? 1.0 : PairSegmentTaper(C, staged));
     for (int i = 0; i < ns; ++i) {
       SchurSeg e; memset(&e, 0, sizeof(e));
@@ -579,7 +584,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     for (auto& e : sg) e.stage_ntiles = arrivals[e.stage];
   }
   nblocks = (int)sg.size();
-  nsync = ngrp + 2 * ntiles + 16;
+  nsync = ngrp + 2 * ntiles + RSBA_MAX_STAGES + 2;   // [ngrp] group members | [ntiles] groups done | [RSBA_MAX_STAGES] stage arrivals, [1] self tiles | [ntiles] spare
   // Block order of the launch.  Pipelined: stage by stage — the stage's self tile, its pair tiles, then their reducers —
   // so that camera group g's columns are complete as early as possible.  Sequential schedule: every pair tile first and
   // the (much shorter) self workgroups last, where they fill the tail of the last round of pair workgroups (at 256
@@ -650,7 +655,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       (rc = DevAlloc(&ptdata, (size_t)P * RSBA_PT_STRIDE)) ||
       (rc = DevAlloc(&partial, (size_t)nseg * RSBA_PART * 256)) || (rc = DevAlloc(&grp_sum, (size_t)std::max(ngrp, 1) * RSBA_PART * 256)) ||
       (rc = DevAlloc(&sync_cnt, (size_t)nsync)) || (rc = DevAlloc(&grp_flag, (size_t)ngrp)) || (rc = DevAlloc(&block_seg, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered_first, (size_t)nblocks)) || (rc = DevAlloc(&segs_ordered_self, (size_t)nblocks_self)) || (rc = DevAlloc(&small_flag, 1)) ||
-      (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 24)) || (rc = DevAlloc(&block_scal, (size_t)4 * std::max(grid_pp, 2 * cus))) ||
+      (rc = DevAlloc(&tree_error, 2)) || (rc = DevAlloc(&ready, 64)) || (rc = DevAlloc(&block_scal, (size_t)4 * std::max(grid_pp, 2 * cus))) ||
       (rc = DevAlloc(&cam_prefix, prefix.size())) || (rc = DevAlloc(&cam_ptr, cptr.size())) || (rc = DevAlloc(&cm_pos, sliced_q.size())) ||
       (rc = DevAlloc(&sq_cm2[0], cmpos.size())) || (rc = DevAlloc(&sq_cm2[1], cmpos.size())) ||
       (rc = DevAlloc(&lin2[0], (size_t)P * RSBA_LIN_STRIDE)) || (rc = DevAlloc(&lin2[1], (size_t)P * RSBA_LIN_STRIDE)) ||
@@ -672,7 +677,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   HIPCHK(hipMemset(sync_cnt, 0, (size_t)nsync * sizeof(int)));
   HIPCHK(hipMemset(grp_flag, 0, (size_t)std::max(ngrp, 1) * sizeof(int)));
   HIPCHK(hipMemset(tree_error, 0, 2 * sizeof(int)));   // [0] error flag, [1] ticket counter of the Schur kernel
-  HIPCHK(hipMemset(ready, 0, 24 * sizeof(int)));   // [0] unused, [1 + g] stage g published, [15] the solve's done flag, [16] its started counter
+  HIPCHK(hipMemset(ready, 0, 64 * sizeof(int)));   // [0] unused, [1 + g] stage g published, RSBA_READY_*: all self tiles, the solve's done flag, its started counter
   HIPCHK(hipMemcpy(block_seg, border.data(), border.size() * sizeof(int), hipMemcpyHostToDevice));
   {
     for (size_t q = 0; q < sg.size(); ++q) sg[q].index = (int)q;
@@ -858,6 +863,7 @@ static void FreeSolver(rsba_solver* s) {
   s->marker.Free();
   s->marker_schur.Free();
   for (hipEvent_t e : s->ev_serial) if (e) (void)hipEventDestroy(e);
+  if (s->ev_tiles) (void)hipEventDestroy(s->ev_tiles);
   if (s->res_host) (void)hipHostFree(s->res_host);
   if (s->trace_base) (void)hipFree(s->trace_base);
   if (s->wg_trace) (void)hipFree(s->wg_trace);
@@ -970,9 +976,24 @@ static bool SetupPipeline(rsba_solver* s) {
                                                      "step's kernels ~40 us late with the runtime's default pool of hardware queues; set GPU_MAX_HW_QUEUES=8 before the "
                                                      "HIP runtime initialises (INTEGRATION.md)\n", nq ? "not 1, 2 or 8" : "unset"); });
   }
-  if (s->nc > RSBA_CHOL_MAXN || s->C <= RSBA_TG) return false;        // one camera group: nothing to overlap
+  if (s->C <= RSBA_TG) return false;        // one camera group: nothing to overlap
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) != hipSuccess) return false;
+  if (s->nc > RSBA_CHOL_MAXN) {
+    // More than 64 cameras (round 4): the persistent TILED factorisation beside the Schur kernel — OPT-IN (RSBA_PIPELINE_TILES=1),
+    // because it is slower than the sequential schedule: 1.04 against 0.955 ms per iteration at 256 cameras x 62.5k points.  One
+    // resident workgroup per 64 x 64 tile is 325 of the chip's 512 workgroup slots from the first panel on; the elimination runs on
+    // the 187 left (a hit loop alone on its SIMDs is as fast as two, so that is ~73 % of its rate, and the holes retiring tiles
+    // leave only fit a Schur workgroup since the tiles ask for as much LDS), its stages come at 160 / 250 / 290 ... us instead of
+    // 60 / 100 / ..., and the chain of tile columns, which needs ~18 us per column alone, needs ~27 beside the hit loops: the
+    // factorisation ends ~250 us behind the last stage (HISTORY.md, round 4).  What an overlap above 64 cameras needs is a
+    // factorisation with a small resident footprint (left-looking, a tile column at a time).  One process / one GPU only, every
+    // tile resident at once, at most RSBA_MAX_STAGES camera groups to gate on.
+    const char* et = getenv("RSBA_PIPELINE_TILES");
+    const char* ec = getenv("RSBA_CHOL_TILES");
+    const int m = MultiCholPadded(s->nc), nrt = (m + 1 + 63) / 64, ntiles = nrt * (nrt + 1) / 2;
+    if (mg || !(et && atoi(et) == 1) || (ec && atoi(ec) == 0) || ntiles > 2 * prop.multiProcessorCount || (s->C + RSBA_TG - 1) / RSBA_TG > RSBA_MAX_STAGES) return false;
+  }
   const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
   std::vector<uint32_t> mask(words, 0xffffffffu);
   // A side stream with a hardware queue of its own (hipExtStreamCreateWithCUMask, all CUs) that passes `probe`; a few attempts:
@@ -995,6 +1016,7 @@ static bool SetupPipeline(rsba_solver* s) {
   bool ok = side_stream(&s->sB, [&](hipStream_t c) { return s->pipe_serial || StreamsRunConcurrently(c, s->stream); });
   if (!ok && getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: the side stream does not run beside the main stream, solve not pipelined\n");
   ok = ok && hipMalloc((void**)&s->chol_waited, 2 * sizeof(long long)) == hipSuccess && hipMemset(s->chol_waited, 0, 2 * sizeof(long long)) == hipSuccess;
+  if (ok && s->nc > RSBA_CHOL_MAXN) ok = hipEventCreateWithFlags(&s->ev_tiles, hipEventDisableTiming) == hipSuccess;
   if (ok && mg) {
     // The communication stream carries kernels that WAIT (k_wait_stage, for the Schur kernel on the main stream) and kernels
     // others wait for (k_set_flag, for the factorisation on sB): it must run beside both, probed in every direction that
@@ -1193,6 +1215,7 @@ static int UploadPoints(rsba_solver* s) {
         if (ntiles <= 2 * prop.multiProcessorCount) {
           s->tc_np = m / RSBA_PB; s->tc_nrt = nrt; s->tc_tiles = ntiles;
           const size_t nflags = (size_t)s->tc_np * (nrt + 2) + 1;   // tdone | xdone | error | xdone of the back-substitution
+          s->tc_nflags = nflags;
           if ((rc = DevAlloc(&s->tc_flags, nflags))) return rc;
           HIPCHK(hipMemset(s->tc_flags, 0, nflags * sizeof(int)));
           {
@@ -1203,22 +1226,25 @@ static int UploadPoints(rsba_solver* s) {
               HIPCHK(hipMemcpy(s->tc_map, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
             }
           }
+          s->tc_hand_doubles = (size_t)2 * nrt * kTileHandDoubles;
           if ((rc = DevAlloc(&s->tc_hand, (size_t)2 * nrt * kTileHandDoubles))) return rc;
           HIPCHK(hipMemset(s->tc_hand, 0xff, (size_t)2 * nrt * kTileHandDoubles * sizeof(double)));   // the sentinel everywhere
           if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, (size_t)(nrt + 1) * 24 + ntiles))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, ((size_t)(nrt + 1) * 24 + ntiles) * sizeof(long long))); }
           {
             const int H = (s->tc_np + 2) / 3;
             // k_backsub_chain's hand-overs, two sets each, the sentinel everywhere: x and the helpers' slices of y
+            s->tc_xs_doubles = (size_t)2 * m; s->tc_ys_doubles = (size_t)2 * H * 96;
             if ((rc = DevAlloc(&s->tc_xs, (size_t)2 * m)) || (rc = DevAlloc(&s->tc_ys, (size_t)2 * H * 96))) return rc;
             HIPCHK(hipMemset(s->tc_xs, 0xff, (size_t)2 * m * sizeof(double)));
             HIPCHK(hipMemset(s->tc_ys, 0xff, (size_t)2 * H * 96 * sizeof(double)));
           }
           HIPCHK(hipFuncSetAttribute((const void*)k_chol_tiles_persistent, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(TileCholLdsDoubles() * sizeof(double))));
+                                     (int)std::max(TileCholLdsDoubles() * sizeof(double), (size_t)RSBA_SCHUR_LDS_BYTES + 64)));
         }
       }
     }
   }
+  if (s->pipelined && s->nc > RSBA_CHOL_MAXN && s->tc_tiles == 0) s->pipelined = false;   // (the persistent tiles did not fit after all)
   if (s->opt.schur_impl != 0) {
     rc = s->tiled.Build(C, P, ptr, cam, u, v, sl_q, s->pipelined);
     if (rc != RSBA_OK) return rc;
@@ -1458,7 +1484,38 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     T.End(st);
   }
   DebugSync(st, "k_camera_constants");
-  const bool pipe = s->pipelined && s->opt.schur_impl != 0 && !keep_system_copy;
+  // (above 64 cameras the pipelined schedule needs the resident tiles building their own entries of the system, the chain
+  //  back-substitution, and — on the first step of a run — the work list that runs every self tile first)
+  static const int fuse_env = getenv("RSBA_SYS_FUSED") ? atoi(getenv("RSBA_SYS_FUSED")) : 1;
+  static const int bsm = getenv("RSBA_BACKSUB_MULTI") ? atoi(getenv("RSBA_BACKSUB_MULTI")) : 2;
+  static const bool first_staged_env = !(getenv("RSBA_FIRST_STAGED") && atoi(getenv("RSBA_FIRST_STAGED")) == 0);
+  const bool tiles_ok = s->nc <= RSBA_CHOL_MAXN ||
+                        (s->tc_tiles > 0 && fuse_env != 0 && bsm >= 2 && s->tc_xs != nullptr && s->ev_tiles != nullptr &&
+                         (!first || (first_staged_env && s->tiled.has_first_order)));
+  const bool pipe = s->pipelined && s->opt.schur_impl != 0 && !keep_system_copy && tiles_ok;
+  const bool pipe_tiles = pipe && s->nc > RSBA_CHOL_MAXN;
+  // the persistent tiled factorisation and the chain back-substitution behind it (more than 64 cameras), on stream sx
+  auto launch_tile_solve = [&](hipStream_t sx, const TileGate& gate) {
+    const int n = s->nc;
+    TileSysSource src;
+    src.fused = 1; src.red = s->red; src.L = s->L; src.scale_c = s->scale_c; src.ip = ip; src.sym_full = s->opt.schur_impl != 0 ? 1 : 0;
+    // (gated: a tile asks for as much LDS as a Schur workgroup — 81 KB instead of its 76 — so that the hole a retiring tile leaves is
+    //  one a Schur workgroup fits into: LDS is allocated contiguously, and behind 76 KB tiles the elimination ran on the 187 slots
+    //  the tiles had left it from the first block to the last, 710 us instead of 340)
+    const size_t tile_lds = gate.ready != nullptr ? std::max(TileCholLdsDoubles() * sizeof(double), (size_t)RSBA_SCHUR_LDS_BYTES + 64) : TileCholLdsDoubles() * sizeof(double);
+    T.Begin("k_chol_tiles_persistent", sx);
+    k_chol_tiles_persistent<<<s->tc_tiles, 256, tile_lds, sx>>>(
+        n, s->W, s->A, s->chol_ok, TileCholFlags{s->tc_flags, s->tc_flags + s->tc_np, s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1), s->tc_nrt, s->tc_hand, s->tc_launches++ & 1, s->test_stall == 3 ? 1 : 0, s->tc_map, s->mc_trace},
+        s->step_tag, s->res, src, gate);
+    T.End(sx);
+    const int nblk = s->tc_np, H = (nblk + 2) / 3;
+    int* fl = s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1);   // [error | xdone ...]
+    T.Begin("k_backsub_chain", sx);
+    k_backsub_chain<<<1 + H, 256, 0, sx>>>(
+        C, s->red, s->L, s->A, s->tc_xs, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, s->chol_ok, s->cam_free,
+        s->tc_ys, fl, s->tc_bs_launches++ & 1);
+    T.End(sx);
+  };
   ++s->step_tag;
   if (s->trace_ring) {
     if (s->trace_ring_first_tag == 0) s->trace_ring_first_tag = s->step_tag;
@@ -1485,6 +1542,56 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   } else if (!pipe) {
     int rc = s->tiled.Launch(s, ip, T);
     if (rc != RSBA_OK) return rc;
+  } else if (pipe_tiles) {
+    // Pipelined above 64 cameras (round 4).  The persistent tiled factorisation goes out FIRST on the side stream — one resident
+    // workgroup per 64 x 64 tile, 76 KB of LDS and one wavefront per SIMD each, so that a Schur workgroup (81 KB, one wavefront
+    // per SIMD) fits beside every one of them — and every tile sleeps until the Schur kernel, launched behind it on the main
+    // stream with the stage-ordered work list, has published the camera group(s) of its columns (TileGate).  A sleeping tile
+    // issues nothing; a hit loop alone on its SIMDs runs at 98 % of what two of them reach together (tools/probes/hit_probe.hip),
+    // so the elimination loses little, and the factorisation — a latency chain of ~18 us per tile column — ends a few tile
+    // columns behind the last stage instead of starting there.  The chain back-substitution follows it on the side stream; the
+    // point back-substitution waits for both behind a stream event.
+    TiledSchur& ts = s->tiled;
+    const int tag = s->step_tag;
+    LaunchPointSide(ts, s, ip, T, st);
+    if (s->trace) s->host_t[1] = std::chrono::steady_clock::now();
+    RoctxRange rr_k4("K4 reduced camera system: tiled Cholesky + solve (launched ahead, gated on the Schur stages)");
+    const bool first_staged = ip.first;   // (tiles_ok: the first-step work list exists)
+    int* resident_word = (ip.first || s->pipe_check_resident) ? reinterpret_cast<int*>(s->res_host + RES_SIZE) : nullptr;
+    s->pipe_check_resident = false;
+    TileGate gate;
+    gate.ready = ts.ready; gate.tag = s->test_stall == 1 ? tag + 1 : tag; gate.cols = 6 * RSBA_TG;
+    gate.all_diag = first_staged ? ts.ready + RSBA_READY_ALLDIAG : nullptr;
+    gate.started_cnt = ts.ready + RSBA_READY_STARTED; gate.started_host = resident_word; gate.started_need = s->tc_tiles;
+    gate.waited = T.all_kernels() ? s->chol_waited : nullptr;
+    if (s->pipe_serial) {
+      // RSBA_PIPELINE=2: the same kernels one after the other (counter collection)
+      ts.LaunchTiles(s, ip, T, st, tag, first_staged);
+      HIPCHK(hipEventRecord(s->ev_serial[0], st));
+      HIPCHK(hipStreamWaitEvent(s->sB, s->ev_serial[0], 0));
+      gate.started_host = nullptr;
+      launch_tile_solve(s->sB, gate);
+    } else {
+      // The tiles go out BEHIND the point side (a stream event, no host wait).  Launched beside it — as the 64-camera factorisation is —
+      // the first step of every run but a solver's first deadlocked: with all 325 tiles resident and asleep, the point pass on the
+      // main stream did not complete (and the Schur kernel queued behind it never started) until the tiles' waits ran out, 0.5 s
+      // later; in a solver's very first step the side stream's first launch starts ~150 us late, i.e. behind the point pass anyway.
+      // (Measured with device stamps: first Schur block 500 001 us after tile (0, 0)'s start; with the event: no stall in 3 x 5 runs.)
+      HIPCHK(hipEventRecord(s->ev_tiles, st));
+      HIPCHK(hipStreamWaitEvent(s->sB, s->ev_tiles, 0));
+      launch_tile_solve(s->sB, gate);
+      if (resident_word != nullptr) {
+        volatile int* w = resident_word;
+        const auto t_res = std::chrono::steady_clock::now();
+        while (*w != gate.tag && std::chrono::steady_clock::now() - t_res < std::chrono::milliseconds(20)) __builtin_ia32_pause();
+      }
+      hp(1);
+      ts.LaunchTiles(s, ip, T, st, tag, first_staged);
+      hp(2);
+    }
+    HIPCHK(hipEventRecord(s->ev_tiles, s->sB));
+    HIPCHK(hipStreamWaitEvent(st, s->ev_tiles, 0));
+    rr_k4.End();
   } else {
     // Pipelined.  Camera group g's columns of the reduced system are complete once the pair tiles (g, g' >= g) are
     // reduced, and the left-looking Cholesky needs nothing else for its panels 3g..3g+2.  The Cholesky kernel goes out
@@ -1513,7 +1620,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // self tile first and publishes ready[9] when all cameras' diag U are written (RSBA_FIRST_STAGED=0: wait for all stages)
     static const bool first_staged_on = !(getenv("RSBA_FIRST_STAGED") && atoi(getenv("RSBA_FIRST_STAGED")) == 0);
     const bool first_staged = ip.first && first_staged_on && ts.has_first_order && s->chol_wgs > 1 && !mg && s->chol_diag;
-    const int* all_diag = first_staged ? ts.ready + 9 : nullptr;
+    const int* all_diag = first_staged ? ts.ready + RSBA_READY_ALLDIAG : nullptr;
     int* resident_word = (ip.first || s->pipe_check_resident) ? reinterpret_cast<int*>(s->res_host + RES_SIZE) : nullptr;
     s->pipe_check_resident = false;
     // RSBA_PIPELINE=2 — for counter collection (rocprofv3 --pmc serialises kernels, and a factorisation that waits inside the
@@ -1528,7 +1635,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       const int* gate_ready = mg ? s->ready_global : ts.ready;
       const long long gate_budget = mg ? 10 * RSBA_STALL_TICKS : 0;
       if (s->chol_wgs > 1 && s->chol_diag) {
-        const StageGate sg{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + 16, resident_word, s->chol_wgs, all_diag, mg ? 1 : 0};
+        const StageGate sg{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + RSBA_READY_SOLVED, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + RSBA_READY_STARTED, resident_word, s->chol_wgs, all_diag, mg ? 1 : 0};
         const DiagCholFlags df{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024};
         if (mg) k_reduced_system_solve_diag<true><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
             C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok, sg, df, tag, s->mc_trace);
@@ -1538,14 +1645,14 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       else if (s->chol_wgs > 1 && !mg)   // (the round-robin kernel has no transposed source: multi-GPU, it is the one-workgroup kernel)
         k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
             C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
-            StageGate{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + 16, resident_word, s->chol_wgs},
+            StageGate{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + RSBA_READY_SOLVED, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + RSBA_READY_STARTED, resident_word, s->chol_wgs},
             MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48}, tag, s->mc_trace);
       else
       k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                        s->camc[c], s->dcam, s->gmax, s->res, ip, mg ? 2 : 1,
-                                                       s->chol_ok, StageGate{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + 15,
+                                                       s->chol_ok, StageGate{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + RSBA_READY_SOLVED,
                                                                              T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget,
-                                                                             ts.ready + 16, resident_word, 1});
+                                                                             ts.ready + RSBA_READY_STARTED, resident_word, 1});
       T.End(s->sB);
       rr_k4.End();
       if (resident_word != nullptr) {
@@ -1642,7 +1749,6 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const int n = s->nc;
     // the resident tiles build their entries of the system themselves (TileSysSource); k_sys_build only where its output is
     // wanted for itself (the copies of the system a caller asked for) or the multi-launch factorisation reads it
-    static const int fuse_env = getenv("RSBA_SYS_FUSED") ? atoi(getenv("RSBA_SYS_FUSED")) : 1;
     const bool fused = s->tc_tiles > 0 && !keep_system_copy && fuse_env != 0;
     if (!fused) {
       T.Begin("k_sys_build", st);
@@ -1656,7 +1762,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       T.Begin("k_chol_tiles_persistent", st);
       k_chol_tiles_persistent<<<s->tc_tiles, 256, TileCholLdsDoubles() * sizeof(double), st>>>(
           n, s->W, s->A, s->chol_ok, TileCholFlags{s->tc_flags, s->tc_flags + s->tc_np, s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1), s->tc_nrt, s->tc_hand, s->tc_launches++ & 1, s->test_stall == 3 ? 1 : 0, s->tc_map, s->mc_trace},
-          s->step_tag, s->res, src);
+          s->step_tag, s->res, src, TileGate{});
       T.End(st);
     } else {
     const size_t lds_s = CholStepLdsDoubles() * sizeof(double);
@@ -1670,7 +1776,6 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     }
     // RSBA_BACKSUB_MULTI: 2 (default) the chain in one workgroup with helpers for the far strips (k_backsub_chain), 1 the chain
     // passed from owner to owner (k_backsub_multi, round 2), 0 one workgroup for everything (k_chol_finish)
-    static const int bsm = getenv("RSBA_BACKSUB_MULTI") ? atoi(getenv("RSBA_BACKSUB_MULTI")) : 2;
     if (s->tc_tiles > 0 && bsm >= 2 && s->tc_xs != nullptr) {
       const int nblk = s->tc_np, H = (nblk + 2) / 3;
       int* fl = s->tc_flags + (size_t)s->tc_np * (s->tc_nrt + 1);   // [error | xdone ...]
@@ -1719,7 +1824,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const bool fused = s->opt.schur_impl != 0 && s->fused_lin;
     const FusedLin fl0 = fused ? FusedLin{s->tiled.lin2[x], s->tiled.lin2[c], s->tiled.cm_pos, s->tiled.sq_cm2[c], s->trace} : FusedLin{nullptr, nullptr, nullptr, nullptr, s->trace};
     const FusedLin& fl = fl0;
-    const int* solve_done = pipe ? s->tiled.ready + 15 : nullptr;
+    const int* solve_done = pipe && !pipe_tiles ? s->tiled.ready + RSBA_READY_SOLVED : nullptr;   // (tile pipeline: a stream event orders the back-substitution behind the solve)
     const int solve_tag = s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag;
     long long* waited = pipe && T.all_kernels() ? s->chol_waited + 1 : nullptr;
 #define RSBA_BACKSUB_ARGS C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x], s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, \
@@ -1830,7 +1935,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // the Cholesky's event span includes the time it slept on the ready flags: record that separately
     long long w[2] = {0, 0};
     HIPCHK(hipMemcpy(w, s->chol_waited, sizeof(w), hipMemcpyDeviceToHost));
-    T.Add("k_reduced_system_solve:waiting", (w[0] - s->chol_waited_seen) * 1e-5);
+    T.Add(pipe_tiles ? "k_chol_tiles_persistent:waiting" : "k_reduced_system_solve:waiting", (w[0] - s->chol_waited_seen) * 1e-5);
     T.Add("k_backsub_candidate:waiting", (w[1] - s->backsub_waited_seen) * 1e-5);
     s->chol_waited_seen = w[0]; s->backsub_waited_seen = w[1];
   }
@@ -1892,6 +1997,9 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // the waiting Cholesky never saw its columns (its producers were not running beside it): nothing of x has been
     // touched, so repeat the step with the plain schedule and stay there
     fprintf(stderr, "rsba: pipelined solve stalled (step %d: %s); falling back to the sequential schedule%s\n", s->step_tag,
+            s->res_host[RES_STALL] == 2.0 ? "the factorisation gave up waiting for every camera's diag U" :
+            s->res_host[RES_STALL] >= 1000.0 || s->res_host[RES_STALL] == 5.0 || s->res_host[RES_STALL] == 6.0 ? "the block back-substitution gave up waiting for a hand-over" :
+            s->res_host[RES_STALL] >= 10.0 ? "a tile of the factorisation gave up waiting for its stage" :
             s->res_host[RES_STALL] != 0.0 ? "the factorisation gave up waiting for its columns" : "the back-substitution gave up waiting for the solve",
             s->pipe_stalls + 1 < 3 && !s->test_stall ? " for this step" : "");
     HIPCHK(hipDeviceSynchronize());
@@ -1899,6 +2007,15 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     HIPCHK(hipMemset(s->tiled.tree_error + 1, 0, sizeof(int)));
     s->tiled.ticket_base = 0;
     if (s->mc_flags) HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
+    if (s->tc_tiles > 0) {
+      // the tiled factorisation gave up half-way: its flags, and the hand-over buffers whose slots are their own flags, back to
+      // their initial state
+      HIPCHK(hipMemset(s->tc_flags, 0, s->tc_nflags * sizeof(int)));
+      HIPCHK(hipMemset(s->tc_hand, 0xff, s->tc_hand_doubles * sizeof(double)));
+      if (s->tc_xs) HIPCHK(hipMemset(s->tc_xs, 0xff, s->tc_xs_doubles * sizeof(double)));
+      if (s->tc_ys) HIPCHK(hipMemset(s->tc_ys, 0xff, s->tc_ys_doubles * sizeof(double)));
+      HIPCHK(hipMemset(s->tiled.ready + RSBA_READY_STARTED, 0, sizeof(int)));
+    }
     // the repeat runs sequentially; a solver that has timed out three times stays there
     ++s->pipe_stalls;
     const bool was_mg = s->pipelined_mg;

@@ -30,6 +30,7 @@ SETTINGS = [
     ({"RSBA_BALANCE": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_SEG_PER_CU": "4"}, ["c64_huber", "c130"]),
     ({"RSBA_SPARSE_PAIRS": "0"}, ["c70_huber", "c130"]),
+    ({"RSBA_PIPELINE_TILES": "1"}, ["c70_huber", "c130", "c240"]),   # (the tiled factorisation launched ahead, gated on the Schur kernel's stages)
     ({"RSBA_LISTED": "0"}, ["c40", "c64_huber", "c8_dense"]),
     ({"RSBA_LISTED": "1"}, ["c8_dense", "c64_dense_huber"]),
     ({"RSBA_LISTED": "1", "RSBA_SEG_PER_CU": "1"}, ["c33_long", "c64_huber"]),   # (segments of several blocks)
