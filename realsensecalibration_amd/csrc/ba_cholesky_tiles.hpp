@@ -94,6 +94,26 @@ __device__ __forceinline__ bool WaitFlagPlainWG(const int* flag, int tag, const 
   return s_ok3 != 0;
 }
 
+// A stage's flag, waited for by up to 325 resident tiles at once: polled every ~3 us (the hand-overs above are polled every ~50 ns
+// by one or two workgroups each; 325 workgroups polling ONE cache line that often keep its memory channel busy for everybody
+// else).  One lane polls, then one acquire for the workgroup (as WaitFlagWG).
+__device__ __forceinline__ bool WaitStageCoarseWG(const int* flag, int tag, const int* error, long long budget) {
+  __shared__ int s_ok4;
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+      __builtin_amdgcn_s_sleep(127);
+      if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > budget) { ok = 0; break; }
+    }
+    s_ok4 = ok;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return s_ok4 != 0;
+}
+
 // Dense copy of a factored diagonal block for TrsmRowsQuad: e = 32 j + c -> l_cj (c > j) | 1 / l_jj (c == j) | 0
 __device__ __forceinline__ double DenseLtT(const double* Lt, const double* invd, int e) {
   const int j = e >> 5, c = e & 31;
@@ -552,11 +572,11 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
   if (gate.ready != nullptr) {
     const long long gb = gate.budget > 0 ? gate.budget : RSBA_STALL_TICKS;
     const long long tw0 = wall_clock64();
-    if (gate.all_diag != nullptr && !WaitFlagWG(gate.all_diag, gate.tag, f.error, gb)) { gate_stalled = true; stall_code = 2; }
+    if (gate.all_diag != nullptr && !WaitStageCoarseWG(gate.all_diag, gate.tag, f.error, gb)) { gate_stalled = true; stall_code = 2; }
     // (columns at or beyond n are identity padding; the right-hand-side row's entries come with their column's group)
     const int g_lo = min(c0, n - 1) / gate.cols, g_hi = min(c0 + 63, n - 1) / gate.cols;
     for (int g = g_lo; g <= g_hi && !gate_stalled; ++g)
-      if (!WaitFlagWG(gate.ready + 1 + g, gate.tag, f.error, gb)) { gate_stalled = true; stall_code = 10 + g; }
+      if (!WaitStageCoarseWG(gate.ready + 1 + g, gate.tag, f.error, gb)) { gate_stalled = true; stall_code = 10 + g; }
     if (gate.waited != nullptr && tid == 0 && I == J && 64 * (J + 1) >= m) *gate.waited += wall_clock64() - tw0;
   }
   // entry (gi, gj) of the padded system; row m is the right-hand side
