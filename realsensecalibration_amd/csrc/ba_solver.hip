@@ -847,6 +847,24 @@ int TiledSchur::BuildPairLists(const std::vector<unsigned long long>& mask, std:
   HIPCHK(hipMemcpy(pblk, blks.data(), blks.size() * sizeof(PairBlk), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(hl, rows.data(), rows.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   hl_rows = rows.size() / 64;
+  if (getenv("RSBA_DEBUG")) {
+    // (how well the point order balances the lanes, by position in the point range: tenths of the blocks of the first pair tile)
+    int nb0 = 0, t_off = -1, b_first = 0;
+    for (int q = 0; q < nseg; ++q) if (sg[q].self == 0 && sg[q].ga != sg[q].gb) { t_off = sg[q].tile; b_first = sg[q].blk_begin; break; }
+    for (int q = 0; q < nseg; ++q) if (sg[q].self == 0 && sg[q].tile == t_off) nb0 += sg[q].nblk;
+    std::string prof;
+    for (int d = 0; d < 10 && nb0 >= 10; ++d) {
+      size_t rws = 0, hts = 0;
+      for (int b = nb0 * d / 10; b < nb0 * (d + 1) / 10; ++b) {
+        const PairBlk& k = blks[b_first + b];
+        const unsigned tr[4] = {k.trips01 & 0xffffu, k.trips01 >> 16, k.trips23 & 0xffffu, k.trips23 >> 16};
+        const unsigned of[4] = {k.off0, k.off1, k.off2, k.off3};
+        for (int wv = 0; wv < 4; ++wv) { rws += tr[wv]; for (size_t e = (size_t)of[wv] * 64; e < ((size_t)of[wv] + tr[wv]) * 64; ++e) hts += rows[e] != RSBA_LIST_NONE; }
+      }
+      char buf[32]; snprintf(buf, sizeof(buf), " %.0f", 100.0 * hts / std::max<size_t>(rws * 64, 1)); prof += buf;
+    }
+    fprintf(stderr, "rsba: lane utilisation of the first pair tile (off-diagonal) by tenth of its point range (%%):%s\n", prof.c_str());
+  }
   if (getenv("RSBA_DEBUG"))
     fprintf(stderr, "rsba: hit lists of %d pair segments: %zu blocks, %zu hits in %zu rows (%.0f %% of the lane-trips), %.1f MB, built in %.3f s\n", nseg_pair, blks.size(),
             nhits, hl_rows, 100.0 * nhits / std::max<size_t>(hl_rows * 64, 1), rows.size() * 2e-6, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());

@@ -1,7 +1,6 @@
 # Round-4 evidence, one gpurun call: bench lines, rocprofv3 kernel stats and PMC passes for the benchmark's workload (cfg3) and
 # for one rank's shard of the two 8-GPU configurations, timelines.  Everything lands in gpurun_out/r04/; the summaries are
-# copied into profiles/ by hand (tracked).  The PMC passes run the sequential schedule: counter collection serialises kernels,
-# and the pipelined factorisation (which waits inside the kernel for the Schur kernel launched after it) would only time out.
+# copied into profiles/ by hand (tracked).  The PMC passes of the 64-camera workload run RSBA_PIPELINE=2 (below).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
