@@ -229,6 +229,7 @@ k_time_eliminate(ElimArgs a) {
     // ---- pass 1 (the only one over the Jacobians): V, g_t, W = J_t' J_r, reduced gradient, U
     for (int tile = 0; tile < ntile; ++tile) {
       const int nb = stage(tile);
+      RSBA_MT_STAMP(8);
       for (int e = tid; e < 7 * d; e += RSBA_MT_THREADS) {
         double acc = 0.0;
         if (e < 6 * d) {
@@ -249,6 +250,7 @@ k_time_eliminate(ElimArgs a) {
           Gr[col] += acc;
         }
       }
+      RSBA_MT_STAMP(9);
       // U: a diagonal block per slot (sum over the slot's residual blocks) and one (marker, camera) block per residual block
       // that has both (cameras have the lower columns); two different cameras (or markers) never meet in a residual.
       // Every (time, camera, marker) occurs once, so the cross blocks of different residual blocks never overlap.
