@@ -39,6 +39,7 @@ namespace rsba {
 
 #define RSBA_MT_THREADS 1024
 #define RSBA_MT_JLD 145        // LDS stride of a staged 8 x 18 Jacobian
+#define RSBA_MT_PW (RSBA_MT_JLD + 8)   // doubles of a residual block's products (they take the place of its rows and residuals)
 
 // A workgroup's partial system: S as packed lower triangle (row i, column j <= i at i (i + 1) / 2 + j), then the vectors.
 struct PartLayout {
@@ -58,9 +59,16 @@ struct TimeSlots {  // per residual block, in time order: where its camera / mar
   int camera, pad;             // camera index of the detection (its intrinsics), whether or not the camera pose is a parameter
 };
 
-// 6 x 6 SPD inverse through Cholesky; false when a pivot is not positive and finite.
-__device__ inline bool InvertSpd6(const double* A, double* E) {
-  double L[6][6], M[6][6];
+// LDS written by some lanes of a wavefront, read by others of the same wavefront.
+#define RSBA_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// 6 x 6 SPD inverse through Cholesky on the first 36 lanes of a wavefront (all 64 call it): A (LDS, row-major, the lower
+// triangle is read) -> E (LDS, both halves); Mx: 36 doubles of LDS scratch.  Every lane factors A (the same 21 entries of
+// L), lane j < 6 inverts column j of L, lane e < 36 forms entry e of E = M'M: the operations of one thread doing all of
+// it (sums padded with exact zeros), without the 200 registers that takes.  False (on every lane) when a pivot is not
+// positive and finite.
+__device__ inline bool InvertSpd6Lanes(int lane, const double* A, double* Mx, double* E) {
+  double L[6][6];
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -78,26 +86,31 @@ __device__ inline bool InvertSpd6(const double* A, double* E) {
       L[i][j] = t * inv;
     }
   }
+  {
+    // column j = lane of M = L^-1: zeros above the diagonal
+    const int j = lane;
+    double m[6];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    M[j][j] = 1.0 / L[j][j];
+    for (int i = 0; i < 6; ++i) {
+      double t = 0.0;
 #pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      double s = 0.0;
+      for (int k = 0; k < i; ++k) t -= L[i][k] * m[k];
+      m[i] = i < j ? 0.0 : (i == j ? 1.0 / L[i][i] : t / L[i][i]);
+    }
+    if (j < 6) {
 #pragma unroll
-      for (int k = j; k < i; ++k) s -= L[i][k] * M[k][j];
-      M[i][j] = s / L[i][i];
+      for (int i = 0; i < 6; ++i) Mx[i * 6 + j] = m[i];
     }
   }
+  RSBA_WAVE_LDS_SYNC();
+  if (lane < 36) {
+    const int r = lane / 6, c = lane - 6 * r, hi = r > c ? r : c, lo = r > c ? c : r;
+    double t = 0.0;
 #pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int b = 0; b <= a; ++b) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = a; k < 6; ++k) s += M[k][a] * M[k][b];
-      E[a * 6 + b] = s; E[b * 6 + a] = s;
-    }
+    for (int k = 0; k < 6; ++k) t += Mx[k * 6 + hi] * Mx[k * 6 + lo];
+    E[lane] = t;
+  }
+  RSBA_WAVE_LDS_SYNC();
   return ok;
 }
 
@@ -114,7 +127,7 @@ __global__ void __launch_bounds__(256) k_pose_constants(int nposes, const double
 }
 
 struct ElimArgs {
-  int nr, dmax;
+  int nr, dmax, nblocks;
   const int* __restrict__ chunk_ptr;   // [G + 1] times of each workgroup
   const int* __restrict__ time_ptr;    // [T + 1] residual blocks of each time
   const int* __restrict__ slot_ptr;    // [T + 1] slots (distinct camera / marker blocks) of each time
@@ -137,10 +150,14 @@ struct ElimArgs {
 };
 
 #ifdef RSBA_PROFILE_PHASES
-#define RSBA_MT_STAMP(k) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { long long _t = clock64(); g_phase_cycles[k] += _t - _t0; _t0 = _t; } } while (0)
+__device__ long long g_mt_cycles[16];
+#define RSBA_MT_STAMP(k) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { long long _t = clock64(); g_mt_cycles[k] += _t - _t0; _t0 = _t; } } while (0)
 #else
 #define RSBA_MT_STAMP(k) do {} while (0)
 #endif
+
+// Workgroup barrier that orders LDS only: the staging lanes' loads from HBM for the next tile stay in flight across it.
+#define RSBA_MT_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 
 __device__ __forceinline__ int LocalColumn(int slot, int q, int sc, int sm) { return slot == sc ? q : (slot == sm ? 12 + q : -1); }
 
@@ -157,18 +174,20 @@ k_time_eliminate(ElimArgs a) {
   double* Jt = Vs + 96;                   // [TILE][145]: odd stride, the lanes of pass 2 read different residual blocks
   double* rt = Jt + RSBA_MT_TILE * RSBA_MT_JLD;   // [TILE][8]
   double* sqv = rt + RSBA_MT_TILE * 8;    // [TILE] squared residual norms
+  double* PA = Jt;                        // [TILE][153] a residual block's products, in the place of its rows and residuals once those are read
   int* sl = (int*)(sqv + RSBA_MT_TILE);   // [TILE][2] slots, then per slot of the time [dmax / 6 + 1] each:
   int* scol = sl + 2 * RSBA_MT_TILE;      //   first reduced column
   int* mk = scol + dmax / 6 + 1;          //   bit i: staged residual block i has the slot
   int* kb = mk + dmax / 6 + 1;            //   where the slot's block sits in a residual's Jacobian: column 0 (camera) or 12 (marker)
-  // the chunk's sum of S (packed lower triangle): in LDS when it fits, else straight in the workgroup's partial system
+  // the chunk's sum of S (packed lower triangle) and of the three vectors: in LDS when they fit, else straight in the workgroup's partial system
   // pose constants of the current time: the time pose, then one per slot (camera / marker block of the time)
   double* pcl = (double*)(sl + ((2 * RSBA_MT_TILE + 3 * (dmax / 6 + 1) + 1) & ~1));   // [dmax / 6 + 2][CC_STRIDE]
   double* Sl = pcl + (size_t)(dmax / 6 + 2) * CC_STRIDE;
   double* P = a.part + (size_t)blockIdx.x * RL.size();
   double* Sacc = kLdsS ? Sl : P + RL.S();
-  for (size_t e = tid; e < RL.packed(); e += RSBA_MT_THREADS) Sacc[e] = 0.0;
-  for (size_t e = RL.packed() + tid; e < RL.size(); e += RSBA_MT_THREADS) P[e] = 0.0;
+  const size_t nacc = RL.packed() + 3 * (size_t)nr;   // S, then the three vectors behind it (PartLayout): all of them in LDS or none
+  for (size_t e = tid; e < nacc; e += RSBA_MT_THREADS) Sacc[e] = 0.0;
+  for (size_t e = nacc + tid; e < RL.size(); e += RSBA_MT_THREADS) P[e] = 0.0;
   double cost = 0.0, xn2 = 0.0, gmax = 0.0, fail = 0.0;   // thread 0's running sums over the chunk's times
 #ifdef RSBA_PROFILE_PHASES
   long long _t0 = clock64();
@@ -176,10 +195,23 @@ k_time_eliminate(ElimArgs a) {
   __threadfence_block();
   __syncthreads();
 
+  // staging lanes: part (camera, time, marker block of the rows) x residual block of the tile x corner
+  const int sp = tid >> 7, sb_i = (tid & 127) >> 2, sk = tid & 3;
+  int nsc = -1, nsm = -1, ncam = 0;
+  double nu = 0.0, nv = 0.0;
+  auto fetch = [&](int first) {   // what the lane needs of the tile that starts at residual block first
+    const int i = min(first + sb_i, a.nblocks - 1);
+    nsc = a.ts[i].slot_cam; nsm = a.ts[i].slot_marker; ncam = a.ts[i].camera;
+    nu = a.obs8[8 * (size_t)i + 2 * sk]; nv = a.obs8[8 * (size_t)i + 2 * sk + 1];
+  };
+  if (tid < 3 * 4 * RSBA_MT_TILE) fetch(a.time_ptr[a.chunk_ptr[blockIdx.x]]);
   RSBA_MT_STAMP(0);
   for (int t = a.chunk_ptr[blockIdx.x]; t < a.chunk_ptr[blockIdx.x + 1]; ++t) {
     const int o0 = a.time_ptr[t], nobs = a.time_ptr[t + 1] - o0;
     const int s0 = a.slot_ptr[t], nslot = a.slot_ptr[t + 1] - s0, d = 6 * nslot;
+    // the time's Jacobi scale and parameters, wanted after pass 1
+    double pre_scale = 1.0, pre_x = 0.0;
+    if (tid < 6) { if (!a.ip.first) pre_scale = a.scale_t[6 * t + tid]; pre_x = a.params_x[a.time_full[t] + tid]; }
     for (int e = tid; e < 6 * d; e += RSBA_MT_THREADS) W[e] = 0.0;
     for (int e = tid; e < d; e += RSBA_MT_THREADS) Gr[e] = 0.0;
     if (tid < 43) Vs[tid] = 0.0;
@@ -192,24 +224,27 @@ k_time_eliminate(ElimArgs a) {
     const int ntile = (nobs + RSBA_MT_TILE - 1) / RSBA_MT_TILE;
     auto stage = [&](int tile) {
       const int b0 = o0 + tile * RSBA_MT_TILE, nb = min(RSBA_MT_TILE, nobs - tile * RSBA_MT_TILE);
-      __syncthreads();   // the previous tile has been consumed
-      if (tid < nb * 4) {
-        // one corner of one residual block per thread: residuals (2) and Jacobian rows (2 x 18)
-        const int b = tid >> 2, k = tid & 3;
-        const TimeSlots sb = a.ts[b0 + b];
-        const double u = a.obs8[8 * (size_t)(b0 + b) + 2 * k], v = a.obs8[8 * (size_t)(b0 + b) + 2 * k + 1];
-        const double hs = a.half_side;
-        const double cx = (k == 0 || k == 3) ? -hs : hs, cy = k < 2 ? hs : -hs;
-        // (the rows go straight into the staged tile: a local 2 x 18 array would not fit the 128 registers of a
-        //  1024-thread workgroup; the poses' constants come from LDS, staged once per time)
-        MarkerCornerResidualJacobian(sb.slot_cam >= 0 ? pcl + (size_t)(1 + sb.slot_cam) * CC_STRIDE : nullptr, pcl,
-                                     sb.slot_marker >= 0 ? pcl + (size_t)(1 + sb.slot_marker) * CC_STRIDE : nullptr,
-                                     a.intr + 4 * sb.camera, cx, cy, u, v,
-                                     rt + b * 8 + 2 * k, Jt + b * RSBA_MT_JLD + 36 * k);
+      RSBA_MT_BARRIER();   // the previous tile has been consumed
+      if (tid < 3 * 4 * RSBA_MT_TILE) {
+        // one corner of one residual block per three lanes: the residuals (2) and one 2 x 6 block of the Jacobian rows each
+        // (the rows go straight into the staged tile; the poses' constants come from LDS, staged once per time).  What the
+        // lane read from HBM was fetched a tile ago; the next tile's (of this time or the first of the next: the residual
+        // blocks are in time order) is on its way while this one is consumed.
+        const int slot_cam = nsc, slot_marker = nsm;
+        const double* in = a.intr + 4 * ncam;   // a handful of cameras per chunk: from the L1
+        const double u = nu, v = nv, fx = in[0], fy = in[1], ppx = in[2], ppy = in[3];
+        fetch(b0 + nb);
+        if (sb_i < nb) {
+          const double hs = a.half_side;
+          const double cx = (sk == 0 || sk == 3) ? -hs : hs, cy = sk < 2 ? hs : -hs;
+          MarkerCornerJacobianPart(sp, slot_cam >= 0 ? pcl + (size_t)(1 + slot_cam) * CC_STRIDE : nullptr, pcl,
+                                   slot_marker >= 0 ? pcl + (size_t)(1 + slot_marker) * CC_STRIDE : nullptr,
+                                   fx, fy, ppx, ppy, cx, cy, u, v, rt + sb_i * 8 + 2 * sk, Jt + sb_i * RSBA_MT_JLD + 36 * sk);
+          if (sp == 0 && sk == 0) { sl[2 * sb_i] = slot_cam; sl[2 * sb_i + 1] = slot_marker; }
+        }
       }
-      for (int e = tid; e < nb; e += RSBA_MT_THREADS) { sl[2 * e] = a.ts[b0 + e].slot_cam; sl[2 * e + 1] = a.ts[b0 + e].slot_marker; }
       for (int e = tid; e < nslot; e += RSBA_MT_THREADS) mk[e] = 0;
-      __syncthreads();
+      RSBA_MT_BARRIER();
       if (tid < nb) {   // squared residual norm of a block, corner by corner
         double ss = 0.0;
 #pragma unroll
@@ -222,7 +257,7 @@ k_time_eliminate(ElimArgs a) {
         if (sc >= 0) { atomicOr(&mk[sc], 1 << tid); kb[sc] = 0; }
         if (sm >= 0) { atomicOr(&mk[sm], 1 << tid); kb[sm] = 12; }
       }
-      __syncthreads();
+      RSBA_MT_BARRIER();
       return nb;
     };
     RSBA_MT_STAMP(1);
@@ -230,100 +265,142 @@ k_time_eliminate(ElimArgs a) {
     for (int tile = 0; tile < ntile; ++tile) {
       const int nb = stage(tile);
       RSBA_MT_STAMP(8);
-      for (int e = tid; e < 7 * d; e += RSBA_MT_THREADS) {
-        double acc = 0.0;
-        if (e < 6 * d) {
-          const int x = e / d, col = e - x * d, s = col / 6, jc = kb[s] + col - 6 * s;
-          for (unsigned m = (unsigned)mk[s]; m; m &= m - 1) {
-            const int i = __ffs(m) - 1;
+      // Products of a residual block's rows J_i (8 x 18: camera, time, marker block), a column per lane (waves 0-2 the camera
+      // blocks' columns, 3-5 the time blocks', 6-8 the marker blocks'): with the time block (J_t' J_side = a block of W, or
+      // V), with the residuals (reduced gradient, g_t), with the lane's own block (U's diagonal blocks), marker with camera
+      // (U's cross block: every (time, camera, marker) occurs once, so it goes straight into the sum).  The rows are read
+      // once per residual block here, not once per entry of the sums; the products then take the rows' place in LDS.
+      double pt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, pu[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, pg = 0.0;
+      const int p_sd = tid / (6 * RSBA_MT_TILE), p_i = (tid - p_sd * 6 * RSBA_MT_TILE) / 6, p_c = tid - 6 * (tid / 6);
+      const bool p_on = tid < 18 * RSBA_MT_TILE && p_i < nb && (p_sd == 1 || sl[2 * p_i + (p_sd >> 1)] >= 0);
+      if (p_on) {
+        // row by row (q): the accumulators are what stays live, not 150 loads
+        double px[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        const double* Jq = Jt + p_i * RSBA_MT_JLD;
+        const double* ri = rt + p_i * 8;
+#pragma unroll 2
+        for (int q = 0; q < 8; ++q, Jq += 18) {
+          const double own = Jq[6 * p_sd + p_c];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += Jt[i * RSBA_MT_JLD + q * 18 + 6 + x] * Jt[i * RSBA_MT_JLD + q * 18 + jc];
-          }
-          W[e] += acc;
-        } else {
-          const int col = e - 6 * d, s = col / 6, jc = kb[s] + col - 6 * s;
-          for (unsigned m = (unsigned)mk[s]; m; m &= m - 1) {
-            const int i = __ffs(m) - 1;
+          for (int x = 0; x < 6; ++x) pt[x] = fma(Jq[6 + x], own, pt[x]);
+          pg = fma(own, ri[q], pg);
+          if (p_sd != 1) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += Jt[i * RSBA_MT_JLD + q * 18 + jc] * rt[i * 8 + q];
+            for (int r = 0; r < 6; ++r) pu[r] = fma(Jq[6 * p_sd + r], own, pu[r]);
           }
-          Gr[col] += acc;
+          if (p_sd == 2) {
+#pragma unroll
+            for (int cq = 0; cq < 6; ++cq) px[cq] = fma(own, Jq[cq], px[cq]);
+          }
+        }
+        if (p_sd == 2 && sl[2 * p_i] >= 0) {
+          const int gr = scol[sl[2 * p_i + 1]] + p_c, gc = scol[sl[2 * p_i]];
+#pragma unroll
+          for (int cq = 0; cq < 6; ++cq) Sacc[(size_t)gr * (gr + 1) / 2 + gc + cq] += px[cq];
         }
       }
+      RSBA_MT_BARRIER();   // the rows have been read
+      if (p_on) {
+        // per residual block (stride RSBA_MT_PW): camera W, g (42) | marker W, g (42) | camera U (21) | marker U (21) | V (21) | g_t (6);
+        // the symmetric blocks as lower triangles (row r >= column c at r (r + 1) / 2 + c)
+        double* out = PA + p_i * RSBA_MT_PW;
+        if (p_sd != 1) {
+          double* o1 = out + 42 * (p_sd >> 1) + p_c;
+#pragma unroll
+          for (int x = 0; x < 6; ++x) o1[6 * x] = pt[x];
+          o1[36] = pg;
+          double* o2 = out + 84 + 21 * (p_sd >> 1);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) if (r >= p_c) o2[r * (r + 1) / 2 + p_c] = pu[r];
+        } else {
+#pragma unroll
+          for (int x = 0; x < 6; ++x) if (x >= p_c) out[126 + x * (x + 1) / 2 + p_c] = pt[x];
+          out[147 + p_c] = pg;
+        }
+      }
+      RSBA_MT_BARRIER();
       RSBA_MT_STAMP(9);
-      // U: a diagonal block per slot (sum over the slot's residual blocks) and one (marker, camera) block per residual block
-      // that has both (cameras have the lower columns); two different cameras (or markers) never meet in a residual.
-      // Every (time, camera, marker) occurs once, so the cross blocks of different residual blocks never overlap.
-      for (int e = tid; e < nslot * 36; e += RSBA_MT_THREADS) {
-        const int sidx = e / 36, rq = (e - 36 * sidx) / 6, cq = e - 36 * sidx - 6 * rq;
-        if (cq > rq) continue;
-        double u = 0.0;
-        const int jb = kb[sidx];
-        for (unsigned m = (unsigned)mk[sidx]; m; m &= m - 1) {
-          const int i = __ffs(m) - 1;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) u += Jt[i * RSBA_MT_JLD + q * 18 + jb + rq] * Jt[i * RSBA_MT_JLD + q * 18 + jb + cq];
-        }
-        const int gr = scol[sidx] + rq, gc = scol[sidx] + cq;
-        if (rq == cq) P[RL.diagU() + gr] += u;
-        Sacc[(size_t)gr * (gr + 1) / 2 + gc] += u;
-      }
-      for (int e = tid; e < nb * 36; e += RSBA_MT_THREADS) {
-        const int i = e / 36, rq = (e - 36 * i) / 6, cq = e - 36 * i - 6 * rq;
-        const int sc = sl[2 * i], sm = sl[2 * i + 1];
-        if (sc < 0 || sm < 0) continue;
-        double u = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) u += Jt[i * RSBA_MT_JLD + q * 18 + 12 + rq] * Jt[i * RSBA_MT_JLD + q * 18 + cq];
-        const int gr = scol[sm] + rq, gc = scol[sc] + cq;
-        Sacc[(size_t)gr * (gr + 1) / 2 + gc] += u;
-      }
-      // V (36), g_t (6), cost (1): every staged residual block contributes; eight lanes per entry take every eighth block,
-      // a fixed shuffle tree adds them
-      if (tid < 43 * 8) {
-        const int ent = tid >> 3, k = tid & 7;
+      // W = J_t' J_r (row x of the time block, reduced column col) and the reduced gradient (x = 6): the products of the
+      // slot's residual blocks in block order
+      for (int e = tid; e < 7 * d; e += RSBA_MT_THREADS) {
+        const int x = e / d, col = e - x * d, s = col / 6;
+        const double* pw = PA + (kb[s] ? 42 : 0) + 6 * x + (col - 6 * s);
         double acc = 0.0;
-        if (ent < 36) {
-          const int x = ent / 6, y = ent - 6 * x;
-          for (int i = k; i < nb; i += 8)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc += Jt[i * RSBA_MT_JLD + q * 18 + 6 + x] * Jt[i * RSBA_MT_JLD + q * 18 + 6 + y];
-        } else if (ent < 42) {
-          const int x = ent - 36;
-          for (int i = k; i < nb; i += 8)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc += Jt[i * RSBA_MT_JLD + q * 18 + 6 + x] * rt[i * 8 + q];
-        } else {
-          for (int i = k; i < nb; i += 8) acc += sqv[i];
-        }
-        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
-        if (k == 0) Vs[ent] += acc;
+        for (unsigned m = (unsigned)mk[s]; m; m &= m - 1) acc += pw[(__ffs(m) - 1) * RSBA_MT_PW];
+        if (x < 6) W[e] += acc; else Gr[col] += acc;
       }
+      // U: a diagonal block per slot, the sum over the slot's residual blocks in block order (cameras have the lower
+      // columns; two different cameras (or markers) never meet in a residual)
+      for (int e = tid; e < nslot * 21; e += RSBA_MT_THREADS) {
+        const int sidx = e / 21, tri = e - 21 * sidx;
+        int rq = (int)((sqrtf(8.0f * (float)tri + 1.0f) - 1.0f) * 0.5f);
+        while (rq * (rq + 1) / 2 > tri) --rq;
+        while ((rq + 1) * (rq + 2) / 2 <= tri) ++rq;
+        const int cq = tri - rq * (rq + 1) / 2;
+        const double* pw = PA + 84 + (kb[sidx] ? 21 : 0) + tri;
+        double u = 0.0;
+        for (unsigned m = (unsigned)mk[sidx]; m; m &= m - 1) u += pw[(__ffs(m) - 1) * RSBA_MT_PW];
+        const int gr = scol[sidx] + rq, gc = scol[sidx] + cq;
+        if (rq == cq) Sacc[RL.diagU() + gr] += u;
+        Sacc[(size_t)gr * (gr + 1) / 2 + gc] += u;
+      }
+      // V (21, mirrored), g_t (6), cost (1): every staged residual block contributes; eight lanes per entry take every
+      // eighth block, a fixed shuffle tree adds them
+      {
+        const int t2 = tid - (RSBA_MT_THREADS - 28 * 8);   // the last waves: the first ones have the longest sums above
+        if (t2 >= 0) {
+          const int ent = t2 >> 3, k = t2 & 7;
+          double acc = 0.0;
+          if (ent < 27) { for (int i = k; i < nb; i += 8) acc += PA[i * RSBA_MT_PW + 126 + ent]; }
+          else { for (int i = k; i < nb; i += 8) acc += sqv[i]; }
+          acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+          if (k == 0) {
+            if (ent < 21) {
+              int x = (int)((sqrtf(8.0f * (float)ent + 1.0f) - 1.0f) * 0.5f);
+              while (x * (x + 1) / 2 > ent) --x;
+              while ((x + 1) * (x + 2) / 2 <= ent) ++x;
+              const int y = ent - x * (x + 1) / 2;
+              Vs[6 * x + y] += acc;
+              if (x != y) Vs[6 * y + x] += acc;
+            } else if (ent < 27) Vs[36 + ent - 21] += acc;
+            else Vs[42] += acc;
+          }
+        }
+      }
+      RSBA_MT_STAMP(10);
     }
     __syncthreads();
     RSBA_MT_STAMP(2);
-    // ---- E = (V + D)^-1, E g_t
-    if (tid == 0) {
-      double Vd[36], E[36];
-      const int tf = a.time_full[t];
+    // ---- E = (V + D)^-1, E g_t: the first wavefront (the residual blocks' products are dead: the damped block and the inverse's scratch)
+    if (tid < 64) {
+      double* Vd = PA + 36;
+      double sc = 1.0;
+      if (tid < 6) {
+        if (a.ip.first) { sc = a.ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(Vs[7 * tid])) : 1.0; a.scale_t[6 * t + tid] = sc; }
+        else sc = pre_scale;
+      }
+      const double s2 = sc * sc;
+      const double dd = tid < 6 ? fmin(fmax(s2 * Vs[7 * tid], a.ip.min_lm_diagonal), a.ip.max_lm_diagonal) / (a.ip.radius * s2) : 0.0;
+      {
+        const int x = tid < 36 ? tid / 6 : 0, y = tid - 6 * x;
+        const double dx = __shfl(dd, x, 64);
+        if (tid < 36) Vd[tid] = x == y ? Vs[tid] + dx : Vs[tid];
+      }
+#pragma unroll
       for (int x = 0; x < 6; ++x) {
-        double s;
-        if (a.ip.first) { s = a.ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(Vs[7 * x])) : 1.0; a.scale_t[6 * t + x] = s; }
-        else s = a.scale_t[6 * t + x];
-        for (int y = 0; y < 6; ++y) Vd[6 * x + y] = Vs[6 * x + y];
-        const double s2 = s * s;
-        Vd[7 * x] += fmin(fmax(s2 * Vs[7 * x], a.ip.min_lm_diagonal), a.ip.max_lm_diagonal) / (a.ip.radius * s2);
+        const double xv = __shfl(pre_x, x, 64);
         gmax = fmax(gmax, fabs(Vs[36 + x]));
-        const double xv = a.params_x[tf + x];
         xn2 += xv * xv;
       }
-      if (!InvertSpd6(Vd, E)) fail += 1.0;
-      for (int e = 0; e < 36; ++e) { Vs[48 + e] = E[e]; a.tdata[(size_t)t * 48 + e] = E[e]; }
-      for (int x = 0; x < 6; ++x) {
-        double s = 0.0;
-        for (int y = 0; y < 6; ++y) s += E[6 * x + y] * Vs[36 + y];
-        Vs[84 + x] = s;
-        a.tdata[(size_t)t * 48 + 36 + x] = Vs[36 + x];
+      RSBA_WAVE_LDS_SYNC();
+      if (!InvertSpd6Lanes(tid, Vd, PA, Vs + 48)) fail += 1.0;
+      if (tid < 36) a.tdata[(size_t)t * 48 + tid] = Vs[48 + tid];
+      if (tid < 6) {
+        double e = 0.0;
+#pragma unroll
+        for (int y = 0; y < 6; ++y) e += Vs[48 + 6 * tid + y] * Vs[36 + y];
+        Vs[84 + tid] = e;
+        a.tdata[(size_t)t * 48 + 36 + tid] = Vs[36 + tid];
       }
       cost += Vs[42];
     }
@@ -368,14 +445,14 @@ k_time_eliminate(ElimArgs a) {
       double c = 0.0;
 #pragma unroll
       for (int x = 0; x < 6; ++x) c += W[x * d + e] * Vs[84 + x];
-      P[RL.gc() + gcol] += Gr[e];
-      P[RL.corr() + gcol] -= c;
+      Sacc[RL.gc() + gcol] += Gr[e];
+      Sacc[RL.corr() + gcol] -= c;
     }
     __threadfence_block();
     __syncthreads();
     RSBA_MT_STAMP(6);
   }
-  if (kLdsS) for (size_t e = tid; e < RL.packed(); e += RSBA_MT_THREADS) P[RL.S() + e] = Sl[e];
+  if (kLdsS) for (size_t e = tid; e < nacc; e += RSBA_MT_THREADS) P[e] = Sl[e];
   if (tid == 0) { P[RL.scal() + 0] = cost; P[RL.scal() + 1] = xn2; P[RL.scal() + 2] = fail; P[RL.scal() + 3] = gmax; }
 }
 
@@ -736,8 +813,8 @@ struct MarkerSchurDevice {
     const RedLayout RL{nr};
     const PartLayout PL{nr};
     lds_elim = (size_t)(13 * dmax + 96 + RSBA_MT_TILE * (RSBA_MT_JLD + 9) + (dmax / 6 + 2) * CC_STRIDE) * sizeof(double) + (size_t)(2 * RSBA_MT_TILE + 3 * (dmax / 6 + 1) + 2) * sizeof(int);
-    lds_s = lds_elim + PL.packed() * sizeof(double) <= 156 * 1024;
-    if (lds_s) lds_elim += PL.packed() * sizeof(double);
+    lds_s = lds_elim + (PL.packed() + 3 * (size_t)nr) * sizeof(double) <= 156 * 1024;
+    if (lds_s) lds_elim += (PL.packed() + 3 * (size_t)nr) * sizeof(double);
     // Without the LDS accumulators every entry is a read-modify-write in the partial system: few enough workgroups that
     // their partial systems stay in the L2s (8 x 4 MB) then, as many as there are times otherwise (at most 1024).
     // With the sums in LDS a workgroup fills a CU: one chunk per CU (more chunks only add partial systems to write, to
@@ -840,7 +917,7 @@ struct MarkerSchurDevice {
     Tm.Begin("k_pose_constants", st);
     k_pose_constants<<<(nfull / 6 + 255) / 256, 256, 0, st>>>(nfull / 6, params[x], posec);
     Tm.End(st);
-    ElimArgs ea{nr, dmax, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ts, mo, obs8, intr, posec, half_side, params[x], scale_t, tdata, part, ip};
+    ElimArgs ea{nr, dmax, (int)N, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ts, mo, obs8, intr, posec, half_side, params[x], scale_t, tdata, part, ip};
     Tm.Begin("k_time_eliminate", st);
     if (lds_s) k_time_eliminate<true><<<G, RSBA_MT_THREADS, lds_elim, st>>>(ea);
     else k_time_eliminate<false><<<G, RSBA_MT_THREADS, lds_elim, st>>>(ea);

@@ -245,6 +245,79 @@ RSBA_HD void MarkerCornerResidualJacobian(const double* pc_cam, const double* pc
   }
 }
 
+// One of the three 2 x 6 blocks of MarkerCornerResidualJacobian's rows (part 0: camera block + the residuals, 1: time
+// block, 2: marker block), the same arithmetic: k_time_eliminate stages a corner on three lanes.  The intrinsics come by
+// value (the caller fetched them a tile ahead).  J has the row stride 18 of the full rows; a block whose pose is not a
+// parameter is written as zeros.
+RSBA_HD void MarkerCornerJacobianPart(int part, const double* pc_cam, const double* pc_time, const double* pc_marker,
+                                                double fx, double fy, double ppx, double ppy, double cx, double cy, double u, double v,
+                                                double* r, double* J) {
+  auto rot = [](const double* pc, const double in[3], double q[3], double out[3]) {
+    const double* R = pc + CC_R;
+    q[0] = R[0] * in[0] + R[1] * in[1] + R[2] * in[2];
+    q[1] = R[3] * in[0] + R[4] * in[1] + R[5] * in[2];
+    q[2] = R[6] * in[0] + R[7] * in[1] + R[8] * in[2];
+    out[0] = q[0] + pc[CC_T]; out[1] = q[1] + pc[CC_T + 1]; out[2] = q[2] + pc[CC_T + 2];
+  };
+  auto block = [](const double* pc, const double Q[6], const double pin[3], const double q[3], double* Jb) {
+    const bool small = pc[CC_SMALL] != 0.0;
+    const double w0 = small ? pin[0] : q[0], w1 = small ? pin[1] : q[1], w2 = small ? pin[2] : q[2];
+    const double* K = pc + CC_K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double q0 = Q[3 * i], q1 = Q[3 * i + 1], q2 = Q[3 * i + 2];
+      const double a0 = w1 * q2 - w2 * q1, a1 = w2 * q0 - w0 * q2, a2 = w0 * q1 - w1 * q0;
+      Jb[18 * i + 0] = a0 * K[0] + a1 * K[3] + a2 * K[6];
+      Jb[18 * i + 1] = a0 * K[1] + a1 * K[4] + a2 * K[7];
+      Jb[18 * i + 2] = a0 * K[2] + a1 * K[5] + a2 * K[8];
+      Jb[18 * i + 3] = q0; Jb[18 * i + 4] = q1; Jb[18 * i + 5] = q2;
+    }
+  };
+  auto zeros = [](double* Jb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) Jb[18 * i + j] = 0.0;
+  };
+  const double X[3] = {cx, cy, 0.0};
+  double qm[3] = {0, 0, 0}, pm[3] = {X[0], X[1], X[2]};
+  if (pc_marker) rot(pc_marker, X, qm, pm);
+  double qt[3], pt[3];
+  rot(pc_time, pm, qt, pt);
+  double qc[3] = {0, 0, 0}, pcm[3] = {pt[0], pt[1], pt[2]};
+  if (pc_cam) rot(pc_cam, pt, qc, pcm);
+  const double iz = 1.0 / pcm[2];
+  const double al = fx * iz, be = fy * iz;
+  const double ga = -al * pcm[0] * iz, de = -be * pcm[1] * iz;
+  if (part == 0) {
+    r[0] = fx * pcm[0] * iz + ppx - u;
+    r[1] = fy * pcm[1] * iz + ppy - v;
+    if (pc_cam) { const double Qc[6] = {al, 0.0, ga, 0.0, be, de}; block(pc_cam, Qc, pt, qc, J + 0); }
+    else zeros(J + 0);
+    return;
+  }
+  double Qt[6];
+  if (pc_cam) {
+    const double* R = pc_cam + CC_R;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { Qt[j] = al * R[j] + ga * R[6 + j]; Qt[3 + j] = be * R[3 + j] + de * R[6 + j]; }
+  } else {
+    Qt[0] = al; Qt[1] = 0.0; Qt[2] = ga; Qt[3] = 0.0; Qt[4] = be; Qt[5] = de;
+  }
+  if (part == 1) { block(pc_time, Qt, pm, qt, J + 6); return; }
+  if (pc_marker) {
+    const double* R = pc_time + CC_R;
+    double Qm[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Qm[3 * i + j] = Qt[3 * i] * R[j] + Qt[3 * i + 1] * R[3 + j] + Qt[3 * i + 2] * R[6 + j];
+    block(pc_marker, Qm, X, qm, J + 12);
+  } else {
+    zeros(J + 12);
+  }
+}
+
 // ceres::HuberLoss / CauchyLoss + Corrector for rho'' <= 0 (both): returns rho(s) and the factor sqrt(rho'(s)) that
 // scales the residual and both Jacobian blocks.  delta > 0: Huber with a = delta; delta < 0: Cauchy with a = -delta
 // (the sign is this implementation's internal encoding of rsba_options::loss_type); 0: no loss.

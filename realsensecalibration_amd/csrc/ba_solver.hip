@@ -2554,6 +2554,7 @@ void rsba_solver_destroy(rsba_solver* s) {
   }
 #ifdef RSBA_PROFILE_PHASES
   { long long h[16]; if (hipMemcpyFromSymbol(h, HIP_SYMBOL(rsba::g_phase_cycles), sizeof(h)) == hipSuccess) { fprintf(stderr, "rsba[phases]"); for (int i = 0; i < 16; ++i) fprintf(stderr, " %lld", h[i]); fprintf(stderr, "\n"); } }
+  { long long h[16]; if (hipMemcpyFromSymbol(h, HIP_SYMBOL(rsba::g_mt_cycles), sizeof(h)) == hipSuccess) { fprintf(stderr, "rsba[mt-phases]"); for (int i = 0; i < 16; ++i) fprintf(stderr, " %lld", h[i]); fprintf(stderr, "\n"); } }
 #endif
   rsba::FreeSolver(s);
 }
