@@ -71,6 +71,22 @@ struct PanelSource {
 
 // Columns of the matrix may still be in production when the factorisation starts (pipelined solve): gate.ready[1 + g]
 // becomes gate.tag when the columns of camera group g (gate.cols wide) are complete; ready == nullptr: no gating.
+// A factorisation launched AHEAD of its step (before the host knew the previous step's outcome, while that step's
+// back-substitution was still running): state and radius are the device's decision (LmNext, ba_point_kernels.hpp).  The kernel
+// waits for dec[3] == seq (the decision of exactly that step), then: dec[1] != 0 — accepted — the roles of the two camera
+// buffers are swapped (x is the former candidate; the new candidate and its constants go where x was: camc_x), radius = dec[2].
+// The host may still stop where the device went on (a tolerance, the time limit: tests the device does not run) — then x is the
+// state the host returns, and an accepted-step factorisation would have written its candidate over it: before it writes anything
+// the kernel saves x's cameras and constants (cam_backup: 6 C, camc_backup: C x CC_STRIDE doubles), and the host puts them back
+// when it lets such a step run out unused (DrainAhead).
+struct AheadSel {
+  const double* dec = nullptr;
+  double seq = 0.0;
+  double* camc_x = nullptr;
+  double* cam_backup = nullptr;
+  double* camc_backup = nullptr;
+};
+
 struct StageGate {
   const int* ready;
   int tag, cols;

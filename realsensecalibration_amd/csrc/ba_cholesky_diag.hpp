@@ -415,7 +415,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
                             const double* __restrict__ cam_x, double* __restrict__ cam_c, const double* __restrict__ intr,
                             double* __restrict__ camc_c, double* __restrict__ dcam, const double* __restrict__ gmax_p,
                             double* __restrict__ res, IterParams ip, int* __restrict__ chol_ok, StageGate gate, DiagCholFlags f, int tag,
-                            long long* __restrict__ mtrace /* diagnostic: [G][16][8] wall-clock stamps, or nullptr */) {
+                            long long* __restrict__ mtrace /* diagnostic: [G][16][8] wall-clock stamps, or nullptr */, AheadSel ahead = AheadSel{}) {
   extern __shared__ __attribute__((aligned(16))) double lds[];   // (16: the strip image is read and written 16 bytes at a time)
   const int nreal = L.nc, n = (nreal + RSBA_PB - 1) / RSBA_PB * RSBA_PB;
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
@@ -440,6 +440,30 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   if (gate.trace && tid == 0 && w == 0) gate.trace[0] = wall_clock64();
   AnnounceResident(gate);
   bool stalled = false;
+  if (ahead.dec != nullptr) {
+    // launched ahead: the previous step's decision (see AheadSel).  One lane polls, asleep in between; never hang.
+    __shared__ int s_dec_ok;
+    if (tid == 0) {
+      const long long t0 = wall_clock64();
+      int ok = 1;
+      while (__hip_atomic_load(ahead.dec + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ahead.seq) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > budget) { ok = 0; break; }
+      }
+      s_dec_ok = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (s_dec_ok == 0) stalled = true;
+    if (__hip_atomic_load(ahead.dec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) {
+      const double* t = cam_x; cam_x = cam_c; cam_c = const_cast<double*>(t); camc_c = ahead.camc_x;
+      if (w == 0) {   // (see AheadSel: what the candidate will overwrite at the end of this kernel)
+        for (int i = tid; i < 6 * C; i += nt) ahead.cam_backup[i] = cam_c[i];
+        for (int i = tid; i < C * CC_STRIDE; i += nt) ahead.camc_backup[i] = camc_c[i];
+      }
+    }
+    ip.radius = __hip_atomic_load(ahead.dec + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const double* S = red + L.S();
   const double inv_radius = 1.0 / ip.radius;
   const int mi = lane & 15, kk = lane >> 4;

@@ -91,6 +91,11 @@ __device__ __forceinline__ double* BackSubstituteBlocksPrefetch(int n, double* _
   // (two strips ahead instead of one — 96 doubles per thread — measured slower: 29.7 vs 25 us for the phase, twice, before
   //  and after the product above was spread over the workgroup; a strip's loads already keep this CU's address path busy
   //  for ~0.9 us)
+  // (round 4, RSBA_TRACE=1, factored -> back-substituted at 64 cameras: ONE barrier per block row instead of four — every
+  //  wavefront forming x_b for itself, its entries taken out of the lanes by v_readlane — 24 us; that with two block rows ahead,
+  //  three register sets copied round 27, taking turns without copies 28; one ahead, two sets taking turns 26.  Neither the
+  //  barriers nor the round trip: the phase moves all of L — 590 KB written by workgroups on other XCDs, every line from memory
+  //  — through ONE compute unit, which sustains ~24 GB/s of such loads)
   double tpre[2], lv[RSBA_PB], ln[RSBA_PB];
   for (int sl = 0; sl < 2; ++sl) tpre[sl] = fetch_T(kb_last, sl);
 #pragma unroll

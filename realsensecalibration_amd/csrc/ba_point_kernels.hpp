@@ -1292,6 +1292,8 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
             res[RES_DEC_GO + q] = d3[q];
             if (host != nullptr) __hip_atomic_store(&host[RES_DEC_GO + q], d3[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           }
+          // whose decision it is: a factorisation launched ahead of the next step is already resident and waits for this (AheadSel)
+          __hip_atomic_store(fl.lm.dec + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       if (host != nullptr && tid < 64 && !fl.sums_only) {

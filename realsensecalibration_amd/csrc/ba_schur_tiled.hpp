@@ -163,7 +163,7 @@ struct TiledSchur {
   void LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
   // the point pass of a step whose x already has its linearisation in lin2[cur] (every step but a run's first)
   void LaunchPointDamp(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
-  void LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag, bool first_staged = false);
+  void LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag, bool first_staged = false, bool ahead = false, long long* ahead_trace = nullptr);
   // the self tiles only: cost, g_c, max |g_p| at x (what HandleSuccessfulStep evaluates at the new point); S is not formed
   void LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
   void Free();
@@ -794,6 +794,12 @@ struct SchurArgs {
   // up to 64 cameras: the listed pair segments (PairSegmentListed); nullptr: the masked search (PairSegment)
   const PairBlk* __restrict__ pblk;
   const unsigned short* __restrict__ hl;
+  // launched AHEAD (queued behind the previous step's last kernel and the damping kernel, before the host knew that step's
+  // outcome): the state is the device's decision (LmNext, ba_point_kernels.hpp) — dec[1] != 0: the previous step was accepted,
+  // the camera constants and sqrt(rho') are the candidate's (the `_alt` pointers).  nullptr: the host chose
+  const double* dec = nullptr;
+  const double* camc_alt = nullptr;
+  const double* sq_cm_alt = nullptr;
 };
 
 template <bool kLoss, bool kSmall>
@@ -1694,6 +1700,7 @@ k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const
   // So: priority 3 outside the hit loops, 0 inside (RSBA_PRIO() compiles to s_setprio).
   RSBA_PRIO(3);
   if (threadIdx.x == 0) s_small = __hip_atomic_load(small_flag_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.dec != nullptr && a.dec[1] != 0.0) { a.camc = a.camc_alt; a.sq_cm = a.sq_cm_alt; }   // (uniform: scalar loads beside the ticket's round trip)
   for (;;) {
     if (threadIdx.x == 0) s_ticket = (int)((unsigned)__hip_atomic_fetch_add(ticket_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base);
     __syncthreads();

@@ -215,6 +215,16 @@ struct rsba_solver {
   double lm_decrease_factor = 2.0;
   double* dec = nullptr;
   bool dec_step = false;
+  // Launch-ahead (single GPU, pipelined, up to 64 cameras): the NEXT step's factorisation and Schur kernel are queued behind this
+  // step's back-substitution and the damping kernel, on the device's decision, before the host has this step's result (see
+  // launch_ahead in PointsStep).  ahead_ok: MinimizeLoop says another step may follow (the iteration limit is not reached);
+  // ahead_inflight / ahead_tag: such a pair is queued, with that step tag; ahead_state / ahead_radius: what the device decided
+  // (from the result block): the next PointsStep uses the pair if that is what the host asks for, else waits for it and
+  // launches its own.
+  bool ahead_ok = false, ahead_inflight = false;
+  int ahead_tag = 0, ahead_state = 0, ahead_x = 0;   // ahead_x: which buffers held x when the pair was launched
+  double ahead_radius = 0.0;
+  double* cam_backup = nullptr;    // [6 C + C x CC_STRIDE]: see AheadSel
   // pipelined schedule: steps that timed out (the step is repeated sequentially; the third time-out ends the pipelined
   // schedule for this solver), and "the next pipelined step waits until the factorisation is resident" (first step of a
   // run, first step after a time-out)
@@ -883,7 +893,7 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->red_tri, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_map, s->tc_hand, s->tc_xs, s->tc_ys};
+                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_backup, s->red_tri, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_map, s->tc_hand, s->tc_xs, s->tc_ys};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
@@ -1168,7 +1178,8 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(MultiCholPadded(s->nc) + 2) * MultiCholPadded(s->nc))) || (rc = DevAlloc(&s->W, s->nc > RSBA_CHOL_MAXN ? (size_t)(s->nc + 1) * s->nc : 1)) ||
       (rc = DevAlloc(&s->chol_ok, 3)) ||
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
-      (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)) || (rc = DevAlloc(&s->dec, 4)))
+      (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)) || (rc = DevAlloc(&s->dec, 4)) ||
+      (rc = DevAlloc(&s->cam_backup, (size_t)s->C * (6 + CC_STRIDE))))
     return rc;
   if (s->comm) {
     // triangular all-reduce payload: by default where bytes bound the collective (more than 64 cameras), RSBA_TRI_PAYLOAD=1 / 0 forces / disables it
@@ -1176,6 +1187,7 @@ static int UploadPoints(rsba_solver* s) {
     if (tp ? atoi(tp) != 0 : s->nc > RSBA_CHOL_MAXN) { if ((rc = DevAlloc(&s->red_tri, TriSize(s->nc)))) return rc; }
   }
   HIPCHK(hipMemset(s->res, 0, RES_SIZE * sizeof(double)));   // (not every path writes every field: RES_STALL above 64 cameras)
+  HIPCHK(hipMemset(s->dec, 0, 4 * sizeof(double)));          // (dec[3]: whose decision it is — no step's yet)
   HIPCHK(hipMemset(s->small_red, 0, 8 * sizeof(double)));
   HIPCHK(hipMemset(s->chol_ok, 0, 3 * sizeof(int)));   // [0] Cholesky status, [1] arrival counter of the back-substitution's blocks, [2] its wait timed out
   HIPCHK(hipMemcpy(s->obs_u, u.data(), N * sizeof(double), hipMemcpyHostToDevice));
@@ -1411,10 +1423,16 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   return a;
 }
 
-void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag, bool first_staged) {
+void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st, int tag, bool first_staged, bool ahead, long long* ahead_trace) {
   RoctxRange rr("K2+K3 camera-side rows + Schur elimination into the reduced system");
   SchurArgs a = MakeSchurArgs(*this, s, tag);
   if (first_staged) { a.segs_ordered = segs_ordered_first; a.all_self = 1; }
+  if (ahead) {
+    // the NEXT step's elimination, queued before this step's outcome is known: state by the device's decision (SchurArgs::dec)
+    const int c = 1 - s->cur;
+    a.dec = s->dec; a.camc_alt = s->camc[c]; a.sq_cm_alt = sq_cm2[c];
+    a.trace = ahead_trace; a.wg_trace = nullptr;
+  }
   const bool sparse = a.hits != nullptr;   // (resident workgroups: as many as the chip holds, each drawing tickets until the list is through)
   const int grid = SchurGrid(nblocks, sparse);
   a.total = nblocks; a.ticket_base = ticket_base; ticket_base += (unsigned)(nblocks + (sparse ? grid : 0));
@@ -1490,6 +1508,25 @@ static int WaitResult(rsba_solver* s, hipStream_t posting) {
 
 // One "solve at radius": linearise at x, reduce, factor, back-substitute, evaluate the candidate.
 // On return res_host holds the RES_* block (host has synchronised).
+// A factorisation + Schur kernel launched ahead that nobody will consume (the host stopped, or asks for something else): they
+// run to their end on the device's decision — the step tag they used is skipped.
+static int DrainAhead(rsba_solver* s) {
+  if (!s->ahead_inflight) return RSBA_OK;
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->sB) HIPCHK(hipStreamSynchronize(s->sB));
+  ++s->step_tag;
+  s->ahead_inflight = false;
+  if (s->ahead_state != s->ahead_x && s->cur == s->ahead_x) {
+    // the device had accepted the step, the host has not (it stopped on a tolerance or the time limit, which the device does not
+    // test): the factorisation launched ahead has written its candidate where x is — x's cameras and constants back (AheadSel)
+    const size_t nc6 = 6 * (size_t)s->C, ncc = (size_t)s->C * CC_STRIDE;
+    HIPCHK(hipMemcpyAsync(s->cam[s->ahead_x], s->cam_backup, nc6 * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->camc[s->ahead_x], s->cam_backup + nc6, ncc * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+  }
+  return RSBA_OK;
+}
+
 static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_system_copy) {
   const int C = s->C, P = s->P, x = s->cur, c = 1 - s->cur;
   hipStream_t st = s->stream;
@@ -1542,6 +1579,15 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
         s->tc_ys, fl, s->tc_bs_launches++ & 1);
     T.End(sx);
   };
+  // the factorisation + Schur kernel the previous step launched ahead (launch_ahead, below): they are this step's if they are what
+  // it would launch — the state and radius of the device's decision are the host's — else they run out unused
+  bool ahead_hit = false;
+  if (s->ahead_inflight) {
+    ahead_hit = pipe && !pipe_tiles && !first && !s->pipelined_mg && !s->pipe_serial && s->ahead_state == x && s->ahead_radius == radius &&
+                s->ahead_tag == s->step_tag + 1;
+    if (!ahead_hit) { const int rcd = DrainAhead(s); if (rcd != RSBA_OK) return rcd; }
+    s->ahead_inflight = false;
+  }
   ++s->step_tag;
   if (s->trace_ring) {
     if (s->trace_ring_first_tag == 0) s->trace_ring_first_tag = s->step_tag;
@@ -1618,6 +1664,9 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     HIPCHK(hipEventRecord(s->ev_tiles, s->sB));
     HIPCHK(hipStreamWaitEvent(st, s->ev_tiles, 0));
     rr_k4.End();
+  } else if (ahead_hit) {
+    // launched by the previous step (launch_ahead): damping kernel, factorisation (side stream) and Schur kernel are queued or running
+    hp(1); hp(2);
   } else {
     // Pipelined.  Camera group g's columns of the reduced system are complete once the pair tiles (g, g' >= g) are
     // reduced, and the left-looking Cholesky needs nothing else for its panels 3g..3g+2.  The Cholesky kernel goes out
@@ -1917,7 +1966,39 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     T.End(st);
     ts.pt_valid = false;   // (until the decision is in: below)
   };
-  if (s->dec_step && !comm_tail) queue_damping();
+  // Launch-ahead.  Between the result of one step and the first Schur workgroup of the next lay the host: the result's trip over
+  // PCIe, the decision, two launches — 23 us of a 390 us step at 64 cameras, the chip idle but for the damping kernel.  The device
+  // takes the decision itself (DecideStep, the host's arithmetic), so the NEXT step's factorisation (side stream: resident and asleep
+  // until the decision is in, AheadSel) and Schur kernel (main stream, behind the damping kernel; state by SchurArgs::dec) are queued
+  // right here, before this step's result exists.  The host takes the same decision from the same numbers and, in the next
+  // PointsStep, finds its launches done (ahead_hit) — or stops (a tolerance, the time limit) and lets them run out (DrainAhead); the
+  // step that reaches the iteration limit launches nothing ahead (MinimizeLoop: ahead_ok).
+  // OPT-IN (RSBA_LAUNCH_AHEAD=1).  Measured at 64 cameras (round 4, device stamps, 99 steps): result posted -> first Schur workgroup
+  // 13.1 us without, 12.1 us with — the host's share was already hidden behind the damping kernel (7.3 us) it queues on the device's
+  // decision, what is left is that kernel and the dispatch behind it; 0.3885 vs 0.3890 ms per step, inside the run-to-run spread.
+  // Against that microsecond per step stands a whole unused elimination (0.26 ms) at the end of every run a tolerance ends.
+  static const bool ahead_env = getenv("RSBA_LAUNCH_AHEAD") && atoi(getenv("RSBA_LAUNCH_AHEAD")) != 0;
+  auto launch_ahead = [&]() {
+    TiledSchur& ts = s->tiled;
+    const int n = s->nc, atag = s->step_tag + 1;
+    IterParams ipn = ip; ipn.first = 0;
+    long long* tr = s->trace_ring ? s->trace_base + 64 * (size_t)(atag % s->trace_ring) : nullptr;
+    const StageGate sg{ts.ready, atag, 6 * RSBA_TG, ts.ready + RSBA_READY_SOLVED, nullptr, tr, 0, ts.ready + RSBA_READY_STARTED, nullptr, s->chol_wgs, nullptr, 0};
+    const DiagCholFlags df{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024};
+    AheadSel ah; ah.dec = s->dec; ah.seq = s->res_seq + 1.0; ah.camc_x = s->camc[x]; ah.cam_backup = s->cam_backup; ah.camc_backup = s->cam_backup + 6 * (size_t)C;
+    T.Begin("k_reduced_system_solve", s->sB);
+    k_reduced_system_solve_diag<false><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
+        C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ipn, s->chol_ok, sg, df, atag, s->mc_trace, ah);
+    T.End(s->sB);
+    ts.LaunchTiles(s, ipn, T, st, atag, false, true, tr);
+    s->ahead_inflight = true; s->ahead_tag = atag; s->ahead_x = x;
+  };
+  if (s->dec_step && !comm_tail) {
+    queue_damping();
+    if (ahead_env && s->ahead_ok && pipe && !pipe_tiles && !s->pipelined_mg && !s->pipe_serial && s->chol_wgs > 1 && s->chol_diag && !keep_system_copy &&
+        !T.all_kernels() && !(s->trace && !s->trace_ring) && !s->wg_trace && !s->test_stall)
+      launch_ahead();
+  }
   rr_k5.End();
   DebugSync(st, "k_backsub_candidate");
   if (comm_tail) {
@@ -1955,6 +2036,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     TiledSchur& ts = s->tiled;
     const double* r = s->res_host;
     ts.pt_valid = r[RES_DEC_GO] != 0.0; ts.pt_state = r[RES_DEC_ACCEPT] != 0.0 ? c : x; ts.pt_radius = r[RES_DEC_RADIUS]; ts.scal_blocks = ts.grid_pp;
+    s->ahead_state = ts.pt_state; s->ahead_radius = ts.pt_radius;
     s->dec_step = false;
   }
   if (pipe && T.all_kernels()) {
@@ -2064,6 +2146,7 @@ static int PointsGradient(rsba_solver* s, double radius) {
   ip.cam_free = s->cam_free;
   KernelTimer& T = s->timer;
   T.NextStep();
+  { const int rcd = DrainAhead(s); if (rcd != RSBA_OK) return rcd; }
   if (s->opt.schur_impl == 0) {
     HIPCHK(hipMemsetAsync(s->red, 0, s->L.size() * sizeof(double), st));
     const bool stage = (size_t)C * (RSBA_ACC_PER_CAM + RSBA_CC_LDS) * sizeof(double) <= 96 * 1024;
@@ -2164,6 +2247,8 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
       if (radius < o.min_trust_region_radius) return finish(RSBA_CONVERGENCE, RSBA_STOP_MIN_RADIUS);
     }
     s->lm_decrease_factor = decrease_factor;
+    // (another step may follow this one unless it reaches the iteration limit: PointsStep may launch its head ahead)
+    s->ahead_ok = (first ? 1 : s->iters.back().iteration + 1) < o.max_num_iterations;
     int rc = step(radius, first);
     if (rc != RSBA_OK) return rc;
     const double* r = s->res_host;
@@ -2329,6 +2414,7 @@ int rsba_solver_run(rsba_solver* s, rsba_summary* sum_out) {
     double cur_radius = s->opt.initial_trust_region_radius;
     rc = rsba::MinimizeLoop(s, &sum, [&](double radius, bool first) { cur_radius = radius; return rsba::PointsStep(s, radius, first, false); },
                             [&]() { s->cur = 1 - s->cur; }, [&]() { return rsba::PointsGradient(s, cur_radius); });
+    if (rc == RSBA_OK) rc = rsba::DrainAhead(s);   // (a run that a tolerance ended: the step launched ahead runs out)
     sum.minimizer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (getenv("RSBA_RUNPROF")) {
       auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
