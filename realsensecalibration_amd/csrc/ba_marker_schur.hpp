@@ -674,6 +674,163 @@ k_time_backsub_terms(int T, const int* __restrict__ time_ptr, const int* __restr
   }
 }
 
+// Pose constants of the poses behind the reduced columns (cameras, markers) of a parameter array: the candidate's, once the
+// reduced solve has written them — k_time_backsub_wg rotates the candidate's corners with matrices instead of three
+// sin / cos per corner.
+__global__ void __launch_bounds__(64) k_pose_constants_reduced(int nred_poses, const int* __restrict__ col_full, const double* __restrict__ params,
+                                                               double* __restrict__ posec) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nred_poses) return;
+  const int pose = col_full[6 * k] / 6;
+  const double zero4[4] = {0.0, 0.0, 0.0, 0.0};
+  double cc[CC_STRIDE];
+  CameraConstants(params + 6 * (size_t)pose, zero4, cc);
+#pragma unroll
+  for (int q = 0; q < CC_STRIDE; ++q) posec[(size_t)pose * CC_STRIDE + q] = cc[q];
+}
+
+// k_time_backsub_terms with a WORKGROUP per time and a corner of a residual block per lane (round 4).  The wavefront-per-time
+// form evaluates every corner's Jacobian rows twice — once for W_t delta_r, once more for the model cost change, which needs
+// delta_t — on two residual blocks x four corners per lane one after the other, and rotates every candidate corner through three
+// angle-axis poses (a sin / cos pair each).  Here a lane keeps what the second pass needs of its (at most kPer) corners in
+// registers — J_r delta_r, the residual and the time block's two rows: 16 doubles a corner — so the rows are formed once; the
+// candidate's cameras and markers come as rotation matrices (k_pose_constants_reduced), the time's own is formed once per lane.
+// Sums in a fixed order: lanes by butterfly, the four wavefronts in order.  bpart: one entry (4 doubles) per time.
+template <int kPer, int kThreads>
+__global__ void __launch_bounds__(kThreads)
+k_time_backsub_wg(int T, const int* __restrict__ time_ptr, const int* __restrict__ time_full, const TimeSlots* __restrict__ ts,
+                  const MarkerObs* __restrict__ mo, const double* __restrict__ obs8, const double* __restrict__ intr, double half_side,
+                  const double* __restrict__ posec /* pose constants at x */, const double* __restrict__ posec_c /* candidate: cameras, markers */,
+                  const double* __restrict__ tdata, const double* __restrict__ delta_r, const double* __restrict__ params_x,
+                  double* __restrict__ params_c, double* __restrict__ delta_t, double* __restrict__ bpart /* T x 4 */) {
+  constexpr int kWaves = kThreads / 64;
+  __shared__ double s_h[kWaves][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.x;
+  const int o0 = time_ptr[t], o1 = time_ptr[t + 1], tf = time_full[t], ncorner = 4 * (o1 - o0);
+  double m1[kPer][2], rk[kPer][2], jt[kPer][2][6];
+  double h[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int e = tid + kThreads * u;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      m1[u][q] = 0.0; rk[u][q] = 0.0;
+#pragma unroll
+      for (int x = 0; x < 6; ++x) jt[u][q][x] = 0.0;
+    }
+    if (e < ncorner) {
+      const int i = o0 + (e >> 2), k = e & 3;
+      const TimeSlots sl = ts[i];
+      const MarkerObs o = mo[i];
+      double dc[6], dm[6];
+#pragma unroll
+      for (int x = 0; x < 6; ++x) { dc[x] = sl.col_cam >= 0 ? delta_r[sl.col_cam + x] : 0.0; dm[x] = sl.col_marker >= 0 ? delta_r[sl.col_marker + x] : 0.0; }
+      const double* pcc = o.full_cam >= 0 ? posec + (size_t)(o.full_cam / 6) * CC_STRIDE : nullptr;
+      const double* pct = posec + (size_t)(o.full_time / 6) * CC_STRIDE;
+      const double* pcm = o.full_marker >= 0 ? posec + (size_t)(o.full_marker / 6) * CC_STRIDE : nullptr;
+      double rr[2], Jc[36];
+      MarkerCornerResidualJacobian(pcc, pct, pcm, intr + 4 * o.camera, (k == 0 || k == 3) ? -half_side : half_side, k < 2 ? half_side : -half_side,
+                                   obs8[8 * (size_t)i + 2 * k], obs8[8 * (size_t)i + 2 * k + 1], rr, Jc);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        double m = 0.0;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) m += Jc[q * 18 + x] * dc[x] + Jc[q * 18 + 12 + x] * dm[x];
+        m1[u][q] = m; rk[u][q] = rr[q];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) { jt[u][q][x] = Jc[q * 18 + 6 + x]; h[x] += Jc[q * 18 + 6 + x] * m; }
+      }
+    }
+  }
+  // W_t delta_r: the lanes by butterfly (the same value in every lane), the wavefronts in order
+#pragma unroll
+  for (int x = 0; x < 6; ++x) {
+    for (int off = 32; off > 0; off >>= 1) h[x] += __shfl_xor(h[x], off, 64);
+    if (lane == 0) s_h[wave][x] = h[x];
+  }
+  __syncthreads();
+  // the time's step and candidate pose: entry a on lane a of the first wavefront, the candidate's rotation matrix on one lane —
+  // once per time, not once per lane (E h is 36 loads and as many FMAs, the matrix a sin / cos pair)
+  __shared__ double s_dt[6], s_tc[6], s_rt[9], s_n2[2];
+  if (tid < 6) {
+    double hh[6];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+      double sum = s_h[0][x];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) sum += s_h[w][x];
+      hh[x] = sum + tdata[(size_t)t * 48 + 36 + x];
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int y = 0; y < 6; ++y) sum += tdata[(size_t)t * 48 + 6 * tid + y] * hh[y];
+    const double d = -sum, c = params_x[tf + tid] + d;
+    s_dt[tid] = d; s_tc[tid] = c;
+    delta_t[6 * t + tid] = d;
+    params_c[tf + tid] = c;
+  }
+  __syncthreads();
+  double dt[6], tc[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) { dt[a] = s_dt[a]; tc[a] = s_tc[a]; }
+  if (tid == 0) {
+    const double zero4[4] = {0.0, 0.0, 0.0, 0.0};
+    double cct[CC_STRIDE];
+    CameraConstants(tc, zero4, cct);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s_rt[q] = cct[CC_R + q];
+    double d2 = 0.0, xc2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { d2 += dt[a] * dt[a]; xc2 += tc[a] * tc[a]; }
+    s_n2[0] = d2; s_n2[1] = xc2;
+  }
+  __syncthreads();
+  // pass 2: the model cost change from what the lane kept, the candidate's residuals with the candidate's rotation matrices
+  double mcc = 0.0, cc = 0.0;
+  double Rt[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) Rt[q] = s_rt[q];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int e = tid + kThreads * u;
+    if (e < ncorner) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        double m = m1[u][q];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) m += jt[u][q][x] * dt[x];
+        mcc -= m * (rk[u][q] + 0.5 * m);
+      }
+      const int i = o0 + (e >> 2), k = e & 3;
+      const MarkerObs o = mo[i];
+      const double fx = intr[4 * o.camera], fy = intr[4 * o.camera + 1], ppx = intr[4 * o.camera + 2], ppy = intr[4 * o.camera + 3];
+      double pt[3] = {(k == 0 || k == 3) ? -half_side : half_side, k < 2 ? half_side : -half_side, 0.0};
+      auto apply = [&](const double* R, const double* tr) {
+        const double a0 = R[0] * pt[0] + R[1] * pt[1] + R[2] * pt[2], a1 = R[3] * pt[0] + R[4] * pt[1] + R[5] * pt[2], a2 = R[6] * pt[0] + R[7] * pt[1] + R[8] * pt[2];
+        pt[0] = a0 + tr[0]; pt[1] = a1 + tr[1]; pt[2] = a2 + tr[2];
+      };
+      if (o.full_marker >= 0) { const double* pc = posec_c + (size_t)(o.full_marker / 6) * CC_STRIDE; apply(pc + CC_R, pc + CC_T); }
+      apply(Rt, tc + 3);
+      if (o.full_cam >= 0) { const double* pc = posec_c + (size_t)(o.full_cam / 6) * CC_STRIDE; apply(pc + CC_R, pc + CC_T); }
+      const double r0 = fx * pt[0] / pt[2] + ppx - obs8[8 * (size_t)i + 2 * k];
+      const double r1 = fy * pt[1] / pt[2] + ppy - obs8[8 * (size_t)i + 2 * k + 1];
+      cc += r0 * r0 + r1 * r1;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { mcc += __shfl_down(mcc, off, 64); cc += __shfl_down(cc, off, 64); }
+  __syncthreads();   // (s_h has been read)
+  if (lane == 0) { s_h[wave][0] = mcc; s_h[wave][1] = cc; }
+  __syncthreads();
+  if (tid == 0) {
+    bpart[4 * t + 0] = s_n2[0]; bpart[4 * t + 1] = s_n2[1];
+    double sm = s_h[0][0], sc = s_h[0][1];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) { sm += s_h[w][0]; sc += s_h[w][1]; }
+    bpart[4 * t + 2] = sm; bpart[4 * t + 3] = sc;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_marker_schur_finish(int nb_time, const double* __restrict__ bp_time, const double* __restrict__ red_scal,
                       const double* __restrict__ solve_out, double* __restrict__ res) {
@@ -703,6 +860,8 @@ k_marker_schur_finish(int nb_time, const double* __restrict__ bp_time, const dou
 
 struct MarkerSchurDevice {
   int N = 0, T = 0, nr = 0, nfull = 0, G = 0, dmax = 0, nb_time = 0;
+  bool backsub_wg = false;   // k_time_backsub_wg instead of k_time_backsub_terms
+  double* posec_c = nullptr; // pose constants of the candidate's cameras and markers
   double half_side = 0;
   MarkerObs* mo = nullptr;
   TimeSlots* ts = nullptr;
@@ -722,7 +881,7 @@ struct MarkerSchurDevice {
 
   void Free() {
     void* ptrs[] = {mo, ts, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ok_flag, obs8, intr, params[0], params[1],
-                    params0, posec, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res, tc_flags, tc_hand, tc_map};
+                    params0, posec, posec_c, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res, tc_flags, tc_hand, tc_map};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     mo = nullptr; ts = nullptr;
   }
@@ -839,7 +998,9 @@ struct MarkerSchurDevice {
       for (int k = 1; k <= G; ++k) if (cptr[k] > c2.back()) c2.push_back(cptr[k]);
       G = (int)c2.size() - 1; cptr = c2;
     }
-    nb_time = (T + 3) / 4;
+    // (k_time_backsub_wg: a corner of a residual block per lane, two per lane at most; wider times take the wavefront-per-time kernel)
+    { int widest = 0; for (int t = 0; t < T; ++t) widest = std::max(widest, tptr[t + 1] - tptr[t]); backsub_wg = widest <= 128 /* 4 x 128 corners = 512 lanes */ && !(getenv("RSBA_MT_BACKSUB_WG") && atoi(getenv("RSBA_MT_BACKSUB_WG")) == 0); }
+    nb_time = backsub_wg ? T : (T + 3) / 4;
     auto al = [](void** q, size_t bytes) { return hipMalloc(q, std::max<size_t>(bytes, 8)) == hipSuccess; };
     const size_t nA = (size_t)(nr + 2) * nr;
     if (!al((void**)&mo, N * sizeof(MarkerObs)) || !al((void**)&ts, N * sizeof(TimeSlots)) || !al((void**)&chunk_ptr, (G + 1) * 4) ||
@@ -847,6 +1008,7 @@ struct MarkerSchurDevice {
         !al((void**)&time_full, T * 4) || !al((void**)&col_full, nr * 4) || !al((void**)&ok_flag, 4) ||
         !al((void**)&obs8, 8 * (size_t)N * 8) || !al((void**)&intr, p.intrinsics.size() * 8) || !al((void**)&params[0], nfull * 8) ||
         !al((void**)&params[1], nfull * 8) || !al((void**)&params0, nfull * 8) || !al((void**)&posec, (size_t)(nfull / 6) * CC_STRIDE * 8) ||
+        !al((void**)&posec_c, (size_t)(nfull / 6) * CC_STRIDE * 8) ||
         !al((void**)&ss_x, N * 8) || !al((void**)&scale_t, 6 * (size_t)T * 8) ||
         !al((void**)&scale_r, nr * 8) || !al((void**)&tdata, 48 * (size_t)T * 8) || !al((void**)&part, (size_t)G * PL.size() * 8) ||
         !al((void**)&red, RL.size() * 8) || !al((void**)&A, nA * 8) || (nr > RSBA_CHOL_MAXN && !al((void**)&Wm, nA * 8)) ||
@@ -958,8 +1120,14 @@ struct MarkerSchurDevice {
     }
     if (!chk("reduced solve")) return RSBA_ERR_HIP;
     Tm.Begin("k_time_backsub_terms", st);
-    k_time_backsub_terms<<<nb_time, 256, 0, st>>>(T, time_ptr, time_full, ts, mo, obs8, intr, half_side, posec, tdata, delta_r, params[x],
-                                                  params[c], delta_t, bp_time);
+    if (backsub_wg) {
+      k_pose_constants_reduced<<<(nr / 6 + 63) / 64, 64, 0, st>>>(nr / 6, col_full, params[c], posec_c);
+      k_time_backsub_wg<2, 256><<<T, 256, 0, st>>>(T, time_ptr, time_full, ts, mo, obs8, intr, half_side, posec, posec_c, tdata, delta_r, params[x],
+                                              params[c], delta_t, bp_time);
+    } else {
+      k_time_backsub_terms<<<nb_time, 256, 0, st>>>(T, time_ptr, time_full, ts, mo, obs8, intr, half_side, posec, tdata, delta_r, params[x],
+                                                    params[c], delta_t, bp_time);
+    }
     Tm.End(st);
     Tm.Begin("k_marker_schur_finish", st);
     k_marker_schur_finish<<<1, 256, 0, st>>>(nb_time, bp_time, red + RL.scal(), solve_out, res);

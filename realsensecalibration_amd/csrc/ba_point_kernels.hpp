@@ -646,6 +646,7 @@ struct FusedLin {
   const int* __restrict__ cm_pos;     // sliced slot -> camera-major position (robust loss only)
   double* __restrict__ sq_cm_c;
   long long* trace;                   // diagnostic (RSBA_TRACE=1): [28] workgroup 0 past the solve's flag, [29] result posted
+  long long* bs_wg = nullptr;         // diagnostic (RSBA_TRACE=4): [workgroup][4] past the flag, tables staged, pass at x done, block sums out
   LmNext lm;                          // k_backsub_candidate_proj, single GPU: see LmNext
   // k_backsub_candidate_proj with a communicator: the last workgroup leaves this rank's sums (and stall flags) in small_red for
   // the all-reduce and touches neither the result block nor the host — k_publish_result completes the step behind the collective
@@ -1045,6 +1046,7 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
       }
       if (waited != nullptr && blockIdx.x == 0) *waited += wall_clock64() - t0;
       if (fl.trace != nullptr && blockIdx.x == 0) fl.trace[28] = wall_clock64();
+      if (fl.bs_wg != nullptr) fl.bs_wg[4 * blockIdx.x] = wall_clock64();
     }
   }
   __syncthreads();
@@ -1089,6 +1091,7 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
   }
   __syncthreads();
   if (fl.trace != nullptr && blockIdx.x == 0 && tid == 0) fl.trace[32] = wall_clock64();
+  if (fl.bs_wg != nullptr && tid == 0) fl.bs_wg[4 * blockIdx.x + 1] = wall_clock64();
   const unsigned lx_ad = (unsigned)(size_t)(lds_double*)lx, lc_ad = (unsigned)(size_t)(lds_double*)lc;   // LDS byte addresses
   double mcc = 0, cost_c = 0, dp2 = 0, xc2 = 0, ss_c = 0;
   for (bool first = true; slice < nslices; slice += 4 * (int)gridDim.x, j = slice * 64 + lane, first = false) {
@@ -1146,6 +1149,7 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
       at_x(obs.cam[qq], obs.uv[qq]);
     }
     if (fl.trace != nullptr && blockIdx.x == 0 && tid == 0) fl.trace[33] = wall_clock64();
+    if (fl.bs_wg != nullptr && tid == 0) fl.bs_wg[4 * blockIdx.x + 2] = wall_clock64();
     double Vi[6];
     const bool ok = PointBlockInverse(V, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, ip.radius, Vi);
     double tv[3] = {gp[0] + bv[0], gp[1] + bv[1], gp[2] + bv[2]}, dp[3] = {0, 0, 0};
@@ -1231,6 +1235,7 @@ k_backsub_candidate_proj(int C, int P, ObsSliced obs,
   if (tid < 5) s[tid][0] = ((s[tid][0] + s[tid][1]) + s[tid][2]) + s[tid][3];
   __syncthreads();
   if (tid < 5) __hip_atomic_store(&block_part[8 * blockIdx.x + tid], s[tid][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fl.bs_wg != nullptr && tid == 0) fl.bs_wg[4 * blockIdx.x + 3] = wall_clock64();
   if (done_cnt != nullptr) {
     __shared__ int s_last;
     __builtin_amdgcn_s_waitcnt(0);

@@ -242,6 +242,7 @@ struct rsba_solver {
   long hp_n = 0;
   std::chrono::steady_clock::time_point hp_t, hp_result;
   long long* wg_trace = nullptr;  // RSBA_TRACE=2: per-block stamps of the Schur kernel, dumped to RSBA_TRACE_FILE
+  long long* bs_wg = nullptr;     // RSBA_TRACE=4: per-workgroup stamps of the point back-substitution, dumped to RSBA_TRACE_FILE
   std::shared_ptr<Comm> comm;   // RCCL, or the one-GPU loopback group (ba_comm.hpp); null: single GPU
   KernelTimer timer;
   std::vector<rsba_iteration> iters;
@@ -903,6 +904,7 @@ static void FreeSolver(rsba_solver* s) {
   if (s->res_host) (void)hipHostFree(s->res_host);
   if (s->trace_base) (void)hipFree(s->trace_base);
   if (s->wg_trace) (void)hipFree(s->wg_trace);
+  if (s->bs_wg) (void)hipFree(s->bs_wg);
   if (s->chol_waited) (void)hipFree(s->chol_waited);
   if (s->sB) (void)hipStreamDestroy(s->sB);
   if (s->sR) (void)hipStreamDestroy(s->sR);
@@ -1111,6 +1113,8 @@ static int UploadPoints(rsba_solver* s) {
       if (hipMalloc((void**)&s->trace, nslot * sizeof(long long)) != hipSuccess || hipMemset(s->trace, 0, nslot * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
       s->trace_base = s->trace;
       if (atoi(getenv("RSBA_TRACE")) == 2 && hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;
+      // (4: every workgroup of the point back-substitution: past the solve's flag, tables staged, pass at x done, block sums out)
+      if (atoi(getenv("RSBA_TRACE")) == 4 && (hipMalloc((void**)&s->bs_wg, 4 * 1024 * sizeof(long long)) != hipSuccess || hipMemset(s->bs_wg, 0, 4 * 1024 * sizeof(long long)) != hipSuccess)) return RSBA_ERR_HIP;
     }
     s->pipelined = SetupPipeline(s);
     s->fused_lin = !(getenv("RSBA_FUSED_LIN") && atoi(getenv("RSBA_FUSED_LIN")) == 0);
@@ -1898,7 +1902,8 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const size_t lds_b = (size_t)C * (2 * RSBA_CC_LDS + 6) * sizeof(double);
     const bool fused = s->opt.schur_impl != 0 && s->fused_lin;
     const FusedLin fl0 = fused ? FusedLin{s->tiled.lin2[x], s->tiled.lin2[c], s->tiled.cm_pos, s->tiled.sq_cm2[c], s->trace} : FusedLin{nullptr, nullptr, nullptr, nullptr, s->trace};
-    const FusedLin& fl = fl0;
+    FusedLin fl0b = fl0; fl0b.bs_wg = s->bs_wg;
+    const FusedLin& fl = fl0b;
     const int* solve_done = pipe && !pipe_tiles ? s->tiled.ready + RSBA_READY_SOLVED : nullptr;   // (tile pipeline: a stream event orders the back-substitution behind the solve)
     const int solve_tag = s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag;
     long long* waited = pipe && T.all_kernels() ? s->chol_waited + 1 : nullptr;
@@ -1912,7 +1917,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       //  has to wait for a slot starts behind the solve, without its records)
       // (more than 128 cameras: the tables alone are 80 KB, one workgroup per CU)
       grid_bs = std::max(1, std::min(C <= 128 ? 2 * DeviceCUs() - 16 : DeviceCUs() - 8, (P + 63) / 64));
-      FusedLin fl = fl0;
+      FusedLin fl = fl0b;
       // single GPU: the workgroup that completes the result block takes the step's decision as well, and the damping
       // kernel of the NEXT step is queued right here, behind this kernel, on that decision (LmNext; RSBA_DECIDED_DAMP=0:
       // the host launches it once it has decided itself)
@@ -2064,6 +2069,17 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
             (h[32] - h[28]) * 0.01, (h[33] - h[28]) * 0.01, (h[34] - h[28]) * 0.01, (h[35] - h[28]) * 0.01, (h[36] - h[28]) * 0.01);
     s->trace_prev_post = h[29];
     fprintf(stderr, "\n");
+  }
+  if (s->bs_wg && s->step_tag == 8) {
+    std::vector<long long> w(4 * 1024);
+    HIPCHK(hipMemcpy(w.data(), s->bs_wg, w.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    long long t0 = 0;
+    for (int b = 0; b < grid_bs && b < 1024; ++b) if (w[4 * b] != 0 && (t0 == 0 || w[4 * b] < t0)) t0 = w[4 * b];
+    if (FILE* f = fopen(getenv("RSBA_TRACE_FILE") ? getenv("RSBA_TRACE_FILE") : "bswg.txt", "w")) {
+      for (int b = 0; b < grid_bs && b < 1024; ++b)
+        fprintf(f, "%d %.2f %.2f %.2f %.2f\n", b, (w[4 * b] - t0) * 0.01, (w[4 * b + 1] - t0) * 0.01, (w[4 * b + 2] - t0) * 0.01, (w[4 * b + 3] - t0) * 0.01);
+      fclose(f);
+    }
   }
   if (s->wg_trace && s->step_tag == 5) {
     // RSBA_TRACE=2: one step's block timeline of the Schur kernel — list position, segment, tile, type, stage, words, start,
