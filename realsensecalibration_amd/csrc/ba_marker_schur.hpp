@@ -265,35 +265,34 @@ k_time_eliminate(ElimArgs a) {
     for (int tile = 0; tile < ntile; ++tile) {
       const int nb = stage(tile);
       RSBA_MT_STAMP(8);
-      // Products of a residual block's rows J_i (8 x 18: camera, time, marker block), a column per lane (waves 0-2 the camera
-      // blocks' columns, 3-5 the time blocks', 6-8 the marker blocks'): with the time block (J_t' J_side = a block of W, or
+      // Products of a residual block's rows J_i (8 x 18: camera, time, marker block), a column per lane: with the time block (J_t' J_side = a block of W, or
       // V), with the residuals (reduced gradient, g_t), with the lane's own block (U's diagonal blocks), marker with camera
       // (U's cross block: every (time, camera, marker) occurs once, so it goes straight into the sum).  The rows are read
       // once per residual block here, not once per entry of the sums; the products then take the rows' place in LDS.
-      double pt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, pu[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, pg = 0.0;
-      const int p_sd = tid / (6 * RSBA_MT_TILE), p_i = (tid - p_sd * 6 * RSBA_MT_TILE) / 6, p_c = tid - 6 * (tid / 6);
-      const bool p_on = tid < 18 * RSBA_MT_TILE && p_i < nb && (p_sd == 1 || sl[2 * p_i + (p_sd >> 1)] >= 0);
+      // Five roles of 192 lanes (three wavefronts each, so a role's branch is uniform): 0 camera columns x time block + gradient,
+      // 1 time columns (V, g_t), 2 marker columns x time block + gradient + cross block, 3 camera block x itself, 4 marker block x itself.
+      double pt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, pg = 0.0;   // (roles 3, 4: pt holds the block's own products)
+      const int p_role = tid / (6 * RSBA_MT_TILE), p_in = tid - p_role * 6 * RSBA_MT_TILE, p_i = p_in / 6, p_c = p_in - 6 * p_i;
+      const int p_sd = p_role == 1 ? 1 : ((p_role == 0 || p_role == 3) ? 0 : 2);
+      const bool p_on = p_role < 5 && p_i < nb && (p_sd == 1 || sl[2 * p_i + (p_sd >> 1)] >= 0);
       if (p_on) {
-        // row by row (q): the accumulators are what stays live, not 150 loads
+        // row by row (q): the accumulators are what stays live, not a hundred loads
         double px[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         const double* Jq = Jt + p_i * RSBA_MT_JLD;
         const double* ri = rt + p_i * 8;
+        const int other = p_role >= 3 ? 6 * p_sd : 6;   // the block the lane's column is multiplied with
 #pragma unroll 2
         for (int q = 0; q < 8; ++q, Jq += 18) {
           const double own = Jq[6 * p_sd + p_c];
 #pragma unroll
-          for (int x = 0; x < 6; ++x) pt[x] = fma(Jq[6 + x], own, pt[x]);
-          pg = fma(own, ri[q], pg);
-          if (p_sd != 1) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r) pu[r] = fma(Jq[6 * p_sd + r], own, pu[r]);
-          }
-          if (p_sd == 2) {
+          for (int x = 0; x < 6; ++x) pt[x] = fma(Jq[other + x], own, pt[x]);
+          if (p_role < 3) pg = fma(own, ri[q], pg);
+          if (p_role == 2) {
 #pragma unroll
             for (int cq = 0; cq < 6; ++cq) px[cq] = fma(own, Jq[cq], px[cq]);
           }
         }
-        if (p_sd == 2 && sl[2 * p_i] >= 0) {
+        if (p_role == 2 && sl[2 * p_i] >= 0) {
           const int gr = scol[sl[2 * p_i + 1]] + p_c, gc = scol[sl[2 * p_i]];
 #pragma unroll
           for (int cq = 0; cq < 6; ++cq) Sacc[(size_t)gr * (gr + 1) / 2 + gc + cq] += px[cq];
@@ -304,14 +303,15 @@ k_time_eliminate(ElimArgs a) {
         // per residual block (stride RSBA_MT_PW): camera W, g (42) | marker W, g (42) | camera U (21) | marker U (21) | V (21) | g_t (6);
         // the symmetric blocks as lower triangles (row r >= column c at r (r + 1) / 2 + c)
         double* out = PA + p_i * RSBA_MT_PW;
-        if (p_sd != 1) {
+        if (p_role == 0 || p_role == 2) {
           double* o1 = out + 42 * (p_sd >> 1) + p_c;
 #pragma unroll
           for (int x = 0; x < 6; ++x) o1[6 * x] = pt[x];
           o1[36] = pg;
+        } else if (p_role >= 3) {
           double* o2 = out + 84 + 21 * (p_sd >> 1);
 #pragma unroll
-          for (int r = 0; r < 6; ++r) if (r >= p_c) o2[r * (r + 1) / 2 + p_c] = pu[r];
+          for (int r = 0; r < 6; ++r) if (r >= p_c) o2[r * (r + 1) / 2 + p_c] = pt[r];
         } else {
 #pragma unroll
           for (int x = 0; x < 6; ++x) if (x >= p_c) out[126 + x * (x + 1) / 2 + p_c] = pt[x];
