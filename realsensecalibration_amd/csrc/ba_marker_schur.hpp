@@ -38,6 +38,16 @@ namespace rsba {
 #define RSBA_MT_MAXD 1020      // widest local system of one time: 170 camera + marker blocks
 
 #define RSBA_MT_THREADS 1024
+// (ablation hooks of the profiling builds: tools/ablate_marker.sh)
+#ifndef RSBA_ABL_Q
+#define RSBA_ABL_Q 8
+#endif
+#ifndef RSBA_ABL_SUMS
+#define RSBA_ABL_SUMS 1
+#endif
+#ifndef RSBA_ABL_STAGE
+#define RSBA_ABL_STAGE 1
+#endif
 #define RSBA_MT_JLD 145        // LDS stride of a staged 8 x 18 Jacobian
 #define RSBA_MT_PW (RSBA_MT_JLD + 8)   // doubles of a residual block's products (they take the place of its rows and residuals)
 
@@ -234,7 +244,7 @@ k_time_eliminate(ElimArgs a) {
         const double* in = a.intr + 4 * ncam;   // a handful of cameras per chunk: from the L1
         const double u = nu, v = nv, fx = in[0], fy = in[1], ppx = in[2], ppy = in[3];
         fetch(b0 + nb);
-        if (sb_i < nb) {
+        if (sb_i < RSBA_ABL_STAGE * nb) {
           const double hs = a.half_side;
           const double cx = (sk == 0 || sk == 3) ? -hs : hs, cy = sk < 2 ? hs : -hs;
           MarkerCornerJacobianPart(sp, slot_cam >= 0 ? pcl + (size_t)(1 + slot_cam) * CC_STRIDE : nullptr, pcl,
@@ -245,19 +255,18 @@ k_time_eliminate(ElimArgs a) {
       }
       for (int e = tid; e < nslot; e += RSBA_MT_THREADS) mk[e] = 0;
       RSBA_MT_BARRIER();
-      if (tid < nb) {   // squared residual norm of a block, corner by corner
+      // the last wavefront (the products below keep the first fifteen busy), no barrier: wanted by the sums, two barriers on
+      const int mt = tid - (RSBA_MT_THREADS - 64);
+      if (mt >= 0 && mt < nb) {   // squared residual norm of a block, corner by corner (before the products take the residuals' place)
         double ss = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ss += rt[tid * 8 + 2 * k] * rt[tid * 8 + 2 * k] + rt[tid * 8 + 2 * k + 1] * rt[tid * 8 + 2 * k + 1];
-        sqv[tid] = ss;
+        for (int k = 0; k < 4; ++k) ss += rt[mt * 8 + 2 * k] * rt[mt * 8 + 2 * k] + rt[mt * 8 + 2 * k + 1] * rt[mt * 8 + 2 * k + 1];
+        sqv[mt] = ss;
+        // which staged residual blocks belong to a slot (bit order = block order: the sums below run in a fixed order)
+        const int sc = sl[2 * mt], sm = sl[2 * mt + 1];
+        if (sc >= 0) { atomicOr(&mk[sc], 1 << mt); kb[sc] = 0; }
+        if (sm >= 0) { atomicOr(&mk[sm], 1 << mt); kb[sm] = 12; }
       }
-      // which staged residual blocks belong to a slot (bit order = block order: the sums below run in a fixed order)
-      if (tid < nb) {
-        const int sc = sl[2 * tid], sm = sl[2 * tid + 1];
-        if (sc >= 0) { atomicOr(&mk[sc], 1 << tid); kb[sc] = 0; }
-        if (sm >= 0) { atomicOr(&mk[sm], 1 << tid); kb[sm] = 12; }
-      }
-      RSBA_MT_BARRIER();
       return nb;
     };
     RSBA_MT_STAMP(1);
@@ -282,7 +291,7 @@ k_time_eliminate(ElimArgs a) {
         const double* ri = rt + p_i * 8;
         const int other = p_role >= 3 ? 6 * p_sd : 6;   // the block the lane's column is multiplied with
 #pragma unroll 2
-        for (int q = 0; q < 8; ++q, Jq += 18) {
+        for (int q = 0; q < RSBA_ABL_Q; ++q, Jq += 18) {
           const double own = Jq[6 * p_sd + p_c];
 #pragma unroll
           for (int x = 0; x < 6; ++x) pt[x] = fma(Jq[other + x], own, pt[x]);
@@ -322,7 +331,7 @@ k_time_eliminate(ElimArgs a) {
       RSBA_MT_STAMP(9);
       // W = J_t' J_r (row x of the time block, reduced column col) and the reduced gradient (x = 6): the products of the
       // slot's residual blocks in block order
-      for (int e = tid; e < 7 * d; e += RSBA_MT_THREADS) {
+      for (int e = tid; e < RSBA_ABL_SUMS * 7 * d; e += RSBA_MT_THREADS) {
         const int x = e / d, col = e - x * d, s = col / 6;
         const double* pw = PA + (kb[s] ? 42 : 0) + 6 * x + (col - 6 * s);
         double acc = 0.0;
@@ -331,7 +340,7 @@ k_time_eliminate(ElimArgs a) {
       }
       // U: a diagonal block per slot, the sum over the slot's residual blocks in block order (cameras have the lower
       // columns; two different cameras (or markers) never meet in a residual)
-      for (int e = tid; e < nslot * 21; e += RSBA_MT_THREADS) {
+      for (int e = tid; e < RSBA_ABL_SUMS * nslot * 21; e += RSBA_MT_THREADS) {
         const int sidx = e / 21, tri = e - 21 * sidx;
         int rq = (int)((sqrtf(8.0f * (float)tri + 1.0f) - 1.0f) * 0.5f);
         while (rq * (rq + 1) / 2 > tri) --rq;
