@@ -14,6 +14,7 @@ python3 bench.py --config cfg4 --points 125000 --steps 30 --no-cpu-baseline > $O
 RSBA_FORCE_COMM=1 RSBA_PIPELINE_MG=0 python3 bench.py --no-cpu-baseline --steps 30 > $O/r04_bench_comm1rank_sequential.json 2>/dev/null   # (bench.py sets GPU_MAX_HW_QUEUES=8 when a communicator will exist)
 RSBA_FORCE_COMM=1 python3 bench.py --no-cpu-baseline --steps 30 > $O/r04_bench_comm1rank_pipelined.json 2>/dev/null   # (the default with a communicator since round 4)
 RSBA_PIPELINE=0 python3 bench.py --no-cpu-baseline --steps 30 > $O/r04_bench_sequential.json 2>/dev/null
+RSBA_LAUNCH_AHEAD=1 python3 bench.py --no-cpu-baseline --steps 30 > $O/r04_bench_launch_ahead.json 2>/dev/null   # (opt-in: the next step's factorisation and Schur kernel queued on the device's decision)
 build/hit_probe > $O/r04_hit_probe.txt 2>&1
 # ---- kernel stats
 prof() {  # name, bench args...
@@ -54,6 +55,15 @@ RSBA_TRACE=2 RSBA_TRACE_FILE=$O/wg_cfg5.txt python3 bench.py --config cfg5 --poi
 python3 tools/schur_timeline_summary.py $O/wg_cfg5.txt > $O/r04_schur_block_timeline_cfg5_62500.txt
 RSBA_TRACE=3 python3 bench.py --no-cpu-baseline --steps 100 --warmup 5 --no-events 2>&1 | grep "rsba\[ring\]" | tail -1 > $O/r04_step_ring.txt
 RSBA_HOSTPROF=1 python3 bench.py --no-cpu-baseline --steps 100 --warmup 5 --no-events 2>&1 | grep "rsba\[hostprof\]" | tail -1 >> $O/r04_step_ring.txt
+RSBA_LAUNCH_AHEAD=1 RSBA_TRACE=3 python3 bench.py --no-cpu-baseline --steps 100 --warmup 5 --no-events 2>&1 | grep "rsba\[ring\]" | tail -1 | sed "s/^/RSBA_LAUNCH_AHEAD=1: /" >> $O/r04_step_ring.txt
+RSBA_TRACE=4 RSBA_TRACE_FILE=$O/bswg.txt python3 bench.py --no-cpu-baseline --steps 12 --warmup 3 --preload 0 > /dev/null 2>&1
+python3 tools/backsub_wg_summary.py $O/bswg.txt > $O/r04_backsub_workgroups.txt 2>&1
+# ---- marker chain at scale
+python3 tools/marker_chain_scale.py 8 5000 16 > $O/r04_marker_chain_scale.json 2>/dev/null
+rm -rf gpurun_out/prof_tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_tmp -- python3 tools/marker_chain_scale.py 8 5000 16 > /dev/null 2>&1
+cp $(ls gpurun_out/prof_tmp/*/*kernel_stats.csv | head -1) $O/r04_marker_chain_kernel_stats.csv
+rm -rf gpurun_out/prof_tmp
 # the panels of the 64-camera factorisation beside the Schur kernel (tools/mc_chain.py: workgroup 0's chain, then the row workgroups)
 RSBA_MC_TRACE=1 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | grep "rsba\[mc\]" | tail -72 > $O/mc_raw.txt
 python3 tools/mc_chain.py $O/mc_raw.txt > $O/r04_cholesky_diag_timeline_pipelined.txt 2>&1
