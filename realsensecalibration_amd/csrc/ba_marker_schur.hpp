@@ -466,21 +466,20 @@ k_time_eliminate(ElimArgs a) {
 }
 
 // Partial systems -> red (full symmetric S | gc | corr | diagU | scal), chunk order.
-__global__ void __launch_bounds__(256)
+// A workgroup takes 64 consecutive entries of the PACKED partial systems, wavefront k the chunks g = k (mod 8) in ascending
+// order, eight loads in flight: every load of a wavefront is 512 contiguous bytes of one partial system (the round-3 form read
+// the packed triangle twice — once per half of the full square it writes — with eight partial systems per load instruction:
+// 29 us for 20 MB).  The eight wavefronts' sums meet in LDS in the order the eight lanes' did: ((0+1)+(2+3))+((4+5)+(6+7)) — the
+// same bits.  An entry of the triangle is written to both halves of S.
+__global__ void __launch_bounds__(512)
 k_marker_reduce(int nr, int G, const double* __restrict__ part, double* __restrict__ red) {
   const RedLayout RL{nr};
   const PartLayout PL{nr};
-  // eight lanes per entry: lane k takes the chunks g = k (mod 8) in ascending order, eight loads in flight, then a fixed
-  // shuffle tree (a single thread per entry is a dependent chain of G cache misses)
-  const int k = threadIdx.x & 7;
-  const size_t idx = (size_t)blockIdx.x * 32 + (threadIdx.x >> 3);
-  const bool live = idx < RL.size();
-  size_t src = 0;
-  if (live) {
-    if (idx < (size_t)nr * nr) { const size_t i = idx / nr, j = idx - i * nr; src = i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
-    else src = PL.packed() + (idx - (size_t)nr * nr);
-  }
-  const bool is_max = idx == RL.scal() + 3;
+  __shared__ double s_w[8][64];
+  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+  const size_t src = (size_t)blockIdx.x * 64 + lane;
+  const bool live = src < PL.size();
+  const bool is_max = src == PL.scal() + 3;
   double s = 0.0;
   if (live) {
     int g = k;
@@ -493,8 +492,21 @@ k_marker_reduce(int nr, int G, const double* __restrict__ part, double* __restri
     }
     for (; g < G; g += 8) { const double v = part[(size_t)g * PL.size() + src]; s = is_max ? fmax(s, v) : s + v; }
   }
-  for (int off = 1; off < 8; off <<= 1) { const double o = __shfl_xor(s, off, 64); s = is_max ? fmax(s, o) : s + o; }
-  if (live && k == 0) red[idx] = s;
+  s_w[k][lane] = s;
+  __syncthreads();
+  if (k != 0 || !live) return;
+  auto add = [&](double x, double y) { return is_max ? fmax(x, y) : x + y; };
+  const double t = add(add(add(s_w[0][lane], s_w[1][lane]), add(s_w[2][lane], s_w[3][lane])), add(add(s_w[4][lane], s_w[5][lane]), add(s_w[6][lane], s_w[7][lane])));
+  if (src < PL.packed()) {
+    size_t i = (size_t)((sqrt(8.0 * (double)src + 1.0) - 1.0) * 0.5);
+    while (i * (i + 1) / 2 > src) --i;
+    while ((i + 1) * (i + 2) / 2 <= src) ++i;
+    const size_t j = src - i * (i + 1) / 2;
+    red[i * nr + j] = t;
+    red[j * nr + i] = t;
+  } else {
+    red[(size_t)nr * nr + (src - PL.packed())] = t;
+  }
 }
 
 // Step of the reduced blocks from the solution y of the scaled system; candidate parameters; norms.
@@ -1095,7 +1107,7 @@ struct MarkerSchurDevice {
     Tm.End(st);
     if (!chk("k_time_eliminate")) return RSBA_ERR_HIP;
     Tm.Begin("k_marker_reduce", st);
-    k_marker_reduce<<<(unsigned)((RL.size() + 31) / 32), 256, 0, st>>>(nr, G, part, red);
+    k_marker_reduce<<<(unsigned)((PartLayout{nr}.size() + 63) / 64), 512, 0, st>>>(nr, G, part, red);
     Tm.End(st);
     if (nr <= RSBA_CHOL_MAXN) {
       const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(nr)) * sizeof(double);
