@@ -723,12 +723,40 @@ k_time_backsub_wg(int T, const int* __restrict__ time_ptr, const int* __restrict
                   const MarkerObs* __restrict__ mo, const double* __restrict__ obs8, const double* __restrict__ intr, double half_side,
                   const double* __restrict__ posec /* pose constants at x */, const double* __restrict__ posec_c /* candidate: cameras, markers */,
                   const double* __restrict__ tdata, const double* __restrict__ delta_r, const double* __restrict__ params_x,
-                  double* __restrict__ params_c, double* __restrict__ delta_t, double* __restrict__ bpart /* T x 4 */) {
+                  double* __restrict__ params_c, double* __restrict__ delta_t, double* __restrict__ bpart /* T x 4 */,
+                  const int* __restrict__ slot_ptr, const int* __restrict__ slot_col, const int* __restrict__ col_full) {
   constexpr int kWaves = kThreads / 64;
   __shared__ double s_h[kWaves][8];
+  extern __shared__ double s_tab[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = blockIdx.x;
   const int o0 = time_ptr[t], o1 = time_ptr[t + 1], tf = time_full[t], ncorner = 4 * (o1 - o0);
+  // the shot's tables, once per workgroup instead of three dependent trips to memory per lane (slot -> column -> pose -> constants):
+  // pose constants at x of the time (row 0) and of its slots' cameras / markers, the candidate's rotation and translation of
+  // the slots, the slots' part of delta_r
+  const int s0 = slot_ptr[t], nslot = slot_ptr[t + 1] - s0;
+  double* s_pc = s_tab;                                  // [(nslot + 1)][CC_STRIDE]
+  double* s_cd = s_pc + (size_t)(nslot + 1) * CC_STRIDE;   // [nslot][12]
+  double* s_dr = s_cd + (size_t)nslot * 12;               // [nslot][6]
+  for (int e = tid; e < (nslot + 1) * CC_STRIDE; e += kThreads) {
+    const int ps = e / CC_STRIDE, q = e - ps * CC_STRIDE;
+    const int pose = (ps == 0 ? tf : col_full[slot_col[s0 + ps - 1]]) / 6;
+    s_pc[e] = posec[(size_t)pose * CC_STRIDE + q];
+  }
+  for (int e = tid; e < nslot * 12; e += kThreads) {
+    const int ps = e / 12, q = e - 12 * ps;
+    const int pose = col_full[slot_col[s0 + ps]] / 6;
+    s_cd[e] = posec_c[(size_t)pose * CC_STRIDE + (q < 9 ? CC_R + q : CC_T + q - 9)];
+  }
+  for (int e = tid; e < nslot * 6; e += kThreads) { const int ps = e / 6; s_dr[e] = delta_r[slot_col[s0 + ps] + (e - 6 * ps)]; }
+  // (lanes 0..5: their row of E, g_t and the time's parameters, wanted between the passes)
+  double e_row[6] = {0, 0, 0, 0, 0, 0}, g_all[6] = {0, 0, 0, 0, 0, 0}, x_mine = 0.0;
+  if (tid < 6) {
+#pragma unroll
+    for (int y = 0; y < 6; ++y) { e_row[y] = tdata[(size_t)t * 48 + 6 * tid + y]; g_all[y] = tdata[(size_t)t * 48 + 36 + y]; }
+    x_mine = params_x[tf + tid];
+  }
+  __syncthreads();
   double m1[kPer][2], rk[kPer][2], jt[kPer][2][6];
   double h[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -743,15 +771,14 @@ k_time_backsub_wg(int T, const int* __restrict__ time_ptr, const int* __restrict
     if (e < ncorner) {
       const int i = o0 + (e >> 2), k = e & 3;
       const TimeSlots sl = ts[i];
-      const MarkerObs o = mo[i];
       double dc[6], dm[6];
 #pragma unroll
-      for (int x = 0; x < 6; ++x) { dc[x] = sl.col_cam >= 0 ? delta_r[sl.col_cam + x] : 0.0; dm[x] = sl.col_marker >= 0 ? delta_r[sl.col_marker + x] : 0.0; }
-      const double* pcc = o.full_cam >= 0 ? posec + (size_t)(o.full_cam / 6) * CC_STRIDE : nullptr;
-      const double* pct = posec + (size_t)(o.full_time / 6) * CC_STRIDE;
-      const double* pcm = o.full_marker >= 0 ? posec + (size_t)(o.full_marker / 6) * CC_STRIDE : nullptr;
+      for (int x = 0; x < 6; ++x) { dc[x] = sl.slot_cam >= 0 ? s_dr[6 * sl.slot_cam + x] : 0.0; dm[x] = sl.slot_marker >= 0 ? s_dr[6 * sl.slot_marker + x] : 0.0; }
+      const double* pcc = sl.slot_cam >= 0 ? s_pc + (size_t)(1 + sl.slot_cam) * CC_STRIDE : nullptr;
+      const double* pct = s_pc;
+      const double* pcm = sl.slot_marker >= 0 ? s_pc + (size_t)(1 + sl.slot_marker) * CC_STRIDE : nullptr;
       double rr[2], Jc[36];
-      MarkerCornerResidualJacobian(pcc, pct, pcm, intr + 4 * o.camera, (k == 0 || k == 3) ? -half_side : half_side, k < 2 ? half_side : -half_side,
+      MarkerCornerResidualJacobian(pcc, pct, pcm, intr + 4 * sl.camera, (k == 0 || k == 3) ? -half_side : half_side, k < 2 ? half_side : -half_side,
                                    obs8[8 * (size_t)i + 2 * k], obs8[8 * (size_t)i + 2 * k + 1], rr, Jc);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -781,12 +808,12 @@ k_time_backsub_wg(int T, const int* __restrict__ time_ptr, const int* __restrict
       double sum = s_h[0][x];
 #pragma unroll
       for (int w = 1; w < kWaves; ++w) sum += s_h[w][x];
-      hh[x] = sum + tdata[(size_t)t * 48 + 36 + x];
+      hh[x] = sum + g_all[x];
     }
     double sum = 0.0;
 #pragma unroll
-    for (int y = 0; y < 6; ++y) sum += tdata[(size_t)t * 48 + 6 * tid + y] * hh[y];
-    const double d = -sum, c = params_x[tf + tid] + d;
+    for (int y = 0; y < 6; ++y) sum += e_row[y] * hh[y];
+    const double d = -sum, c = x_mine + d;
     s_dt[tid] = d; s_tc[tid] = c;
     delta_t[6 * t + tid] = d;
     params_c[tf + tid] = c;
@@ -806,12 +833,9 @@ k_time_backsub_wg(int T, const int* __restrict__ time_ptr, const int* __restrict
     for (int a = 0; a < 6; ++a) { d2 += dt[a] * dt[a]; xc2 += tc[a] * tc[a]; }
     s_n2[0] = d2; s_n2[1] = xc2;
   }
-  __syncthreads();
-  // pass 2: the model cost change from what the lane kept, the candidate's residuals with the candidate's rotation matrices
+  // pass 2: the model cost change from what the lane kept (while one lane forms the candidate's rotation matrix), then the
+  // candidate's residuals with the candidate's rotation matrices
   double mcc = 0.0, cc = 0.0;
-  double Rt[9];
-#pragma unroll
-  for (int q = 0; q < 9; ++q) Rt[q] = s_rt[q];
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
     const int e = tid + kThreads * u;
@@ -823,17 +847,27 @@ k_time_backsub_wg(int T, const int* __restrict__ time_ptr, const int* __restrict
         for (int x = 0; x < 6; ++x) m += jt[u][q][x] * dt[x];
         mcc -= m * (rk[u][q] + 0.5 * m);
       }
+    }
+  }
+  __syncthreads();
+  double Rt[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) Rt[q] = s_rt[q];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int e = tid + kThreads * u;
+    if (e < ncorner) {
       const int i = o0 + (e >> 2), k = e & 3;
-      const MarkerObs o = mo[i];
-      const double fx = intr[4 * o.camera], fy = intr[4 * o.camera + 1], ppx = intr[4 * o.camera + 2], ppy = intr[4 * o.camera + 3];
+      const TimeSlots sl = ts[i];
+      const double fx = intr[4 * sl.camera], fy = intr[4 * sl.camera + 1], ppx = intr[4 * sl.camera + 2], ppy = intr[4 * sl.camera + 3];
       double pt[3] = {(k == 0 || k == 3) ? -half_side : half_side, k < 2 ? half_side : -half_side, 0.0};
       auto apply = [&](const double* R, const double* tr) {
         const double a0 = R[0] * pt[0] + R[1] * pt[1] + R[2] * pt[2], a1 = R[3] * pt[0] + R[4] * pt[1] + R[5] * pt[2], a2 = R[6] * pt[0] + R[7] * pt[1] + R[8] * pt[2];
         pt[0] = a0 + tr[0]; pt[1] = a1 + tr[1]; pt[2] = a2 + tr[2];
       };
-      if (o.full_marker >= 0) { const double* pc = posec_c + (size_t)(o.full_marker / 6) * CC_STRIDE; apply(pc + CC_R, pc + CC_T); }
+      if (sl.slot_marker >= 0) { const double* pc = s_cd + 12 * sl.slot_marker; apply(pc, pc + 9); }
       apply(Rt, tc + 3);
-      if (o.full_cam >= 0) { const double* pc = posec_c + (size_t)(o.full_cam / 6) * CC_STRIDE; apply(pc + CC_R, pc + CC_T); }
+      if (sl.slot_cam >= 0) { const double* pc = s_cd + 12 * sl.slot_cam; apply(pc, pc + 9); }
       const double r0 = fx * pt[0] / pt[2] + ppx - obs8[8 * (size_t)i + 2 * k];
       const double r1 = fy * pt[1] / pt[2] + ppy - obs8[8 * (size_t)i + 2 * k + 1];
       cc += r0 * r0 + r1 * r1;
@@ -1044,6 +1078,10 @@ struct MarkerSchurDevice {
         !up(params0, p.parameters.data(), nfull * 8))
       return RSBA_ERR_HIP;
     if (hipMemset(res, 0, RES_SIZE * 8) != hipSuccess) return RSBA_ERR_HIP;
+    if (backsub_wg) {
+      const size_t lds_bw = (size_t)(dmax / 6 + 1) * (CC_STRIDE + 12 + 6) * sizeof(double);
+      if (lds_bw > 48 * 1024 && hipFuncSetAttribute((const void*)k_time_backsub_wg<2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bw) != hipSuccess) return RSBA_ERR_HIP;
+    }
     if (lds_elim > 48 * 1024 &&
         hipFuncSetAttribute(lds_s ? (const void*)k_time_eliminate<true> : (const void*)k_time_eliminate<false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_elim) != hipSuccess) return RSBA_ERR_HIP;
@@ -1143,8 +1181,9 @@ struct MarkerSchurDevice {
     Tm.Begin("k_time_backsub_terms", st);
     if (backsub_wg) {
       k_pose_constants_reduced<<<(nr / 6 + 63) / 64, 64, 0, st>>>(nr / 6, col_full, params[c], posec_c);
-      k_time_backsub_wg<2, 256><<<T, 256, 0, st>>>(T, time_ptr, time_full, ts, mo, obs8, intr, half_side, posec, posec_c, tdata, delta_r, params[x],
-                                              params[c], delta_t, bp_time);
+      const size_t lds_bw = (size_t)(dmax / 6 + 1) * (CC_STRIDE + 12 + 6) * sizeof(double);   // the shot's tables (k_time_backsub_wg)
+      k_time_backsub_wg<2, 256><<<T, 256, lds_bw, st>>>(T, time_ptr, time_full, ts, mo, obs8, intr, half_side, posec, posec_c, tdata, delta_r, params[x],
+                                                   params[c], delta_t, bp_time, slot_ptr, slot_col, col_full);
     } else {
       k_time_backsub_terms<<<nb_time, 256, 0, st>>>(T, time_ptr, time_full, ts, mo, obs8, intr, half_side, posec, tdata, delta_r, params[x],
                                                     params[c], delta_t, bp_time);
