@@ -629,6 +629,23 @@ def test_marker_chain_chunk_count_does_not_change_the_answer(oracle, chunks):
     assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("wg", ["0", "1"])
+def test_marker_chain_both_back_substitution_kernels_match_the_oracle(oracle, wg):
+    """The shots' back-substitution: a workgroup per shot with a corner of a residual block per lane (k_time_backsub_wg, shots of
+    at most 128 residual blocks) or a wavefront per shot (k_time_backsub_terms, any width; RSBA_MT_BACKSUB_WG=0 forces it).  Both
+    against the oracle, on a shape with all cameras x markers in a shot (96 residual blocks) and on one with few."""
+    os.environ["RSBA_MT_BACKSUB_WG"] = wg
+    try:
+        for shape, seed in (((8, 60, 12), 5), ((3, 200, 4), 9)):
+            prob = syn.make_marker_chain(*shape, seed=seed)
+            ref, s_ref, got, s = _solve_marker_chain_both(oracle, prob, 2)
+            assert s.num_iterations == s_ref.num_iterations and s.num_successful_steps == s_ref.num_successful_steps, shape
+            assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost, shape
+            assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()), shape
+    finally:
+        del os.environ["RSBA_MT_BACKSUB_WG"]
+
+
 def test_marker_chain_automatic_choice_and_dense_cross_check(oracle):
     """schur_impl 1 (default) eliminates once the dense system outgrows one workgroup's solver; the one-workgroup dense
     path (schur_impl 0) on the same problem is the on-device cross-check."""
