@@ -932,15 +932,66 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (wave 0 has not acquired the row workgroups' stores yet)
   if (gate.trace && tid == 0) gate.trace[13] = wall_clock64();
-  double* ysol = A + (size_t)n * n;
+  // What the camera step needs from memory besides the solution — the Jacobi scale, x, the camera gradient, the intrinsics, the
+  // Schur kernel's scalars — is asked for HERE, ahead of the back-substitution (25 us), not behind it: CameraStepEpilogue's
+  // arithmetic (ba_point_kernels.hpp) on y where it lies in LDS, with the candidate cameras handed to the lanes that form their
+  // constants through LDS instead of a store and a load (the step's tail lost three dependent trips to memory: ~6 -> ~2.5 us).
+  // nreal <= nt: one entry per thread.
+  const bool e_on = tid < nreal;
+  double pf_scale = 0.0, pf_x = 0.0, pf_g = 0.0, pf_free = 1.0, pf_in[4] = {0.0, 0.0, 0.0, 0.0}, pf_s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (e_on) {
+    pf_scale = scale_c[tid]; pf_x = cam_x[tid]; pf_g = red[L.gc() + tid];
+    if (ip.cam_free != nullptr) pf_free = ip.cam_free[tid / 6];
+  }
+  if (tid < C) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pf_in[q] = intr[4 * tid + q];
+  }
+  if (tid == 0) { pf_s[0] = red[L.scal() + 0]; pf_s[1] = red[L.scal() + 1]; pf_s[2] = red[L.scal() + 2]; pf_s[3] = *gmax_p; }
   double* y = BackSubstituteBlocksPrefetch(n, A, lds);
-  for (int i = tid; i < n; i += nt) ysol[i] = y[i];
-  __threadfence_block();
-  __syncthreads();
   int ok = 1;
   if (tid == 0) { res[RES_STALL] = 0.0; ok = __hip_atomic_load(chol_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if (gate.trace && tid == 0) gate.trace[14] = wall_clock64();
-  CameraStepEpilogue(C, red, L, scale_c, ysol, cam_x, cam_c, intr, camc_c, dcam, gmax_p, res, ok, lds, ip.cam_free);
+  {
+    double* scr = lds + 2048;          // 4 x nt (the back-substitution's tables end below 2048 doubles; y stays at lds[0 .. n))
+    double* s_xc = lds + 2048 + 4 * 512;   // the candidate cameras
+    double d2 = 0.0, x2 = 0.0, xc2 = 0.0, gm = 0.0;
+    if (e_on) {
+      const double d = -pf_scale * y[tid];
+      dcam[tid] = d;
+      const double xc = pf_x + d;
+      cam_c[tid] = xc;
+      s_xc[tid] = xc;
+      if (pf_free != 0.0) { d2 += d * d; x2 += pf_x * pf_x; xc2 += xc * xc; }
+      gm = fmax(gm, fabs(pf_g));
+    }
+    // the norms: lanes by butterfly, the wavefronts in order — one barrier (CameraStepEpilogue's tree over the workgroup: nine)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      d2 += __shfl_xor(d2, off, 64); x2 += __shfl_xor(x2, off, 64); xc2 += __shfl_xor(xc2, off, 64); gm = fmax(gm, __shfl_xor(gm, off, 64));
+    }
+    if (lane == 0) { scr[4 * wave + 0] = d2; scr[4 * wave + 1] = x2; scr[4 * wave + 2] = xc2; scr[4 * wave + 3] = gm; }
+    __syncthreads();
+    if (tid < C) {
+      double cc[CC_STRIDE];
+      CameraConstants(s_xc + 6 * tid, pf_in, cc);
+      typedef double d2s_t __attribute__((ext_vector_type(2)));
+      d2s_t* out2 = reinterpret_cast<d2s_t*>(camc_c + (size_t)tid * CC_STRIDE);
+#pragma unroll
+      for (int i = 0; i < CC_STRIDE / 2; ++i) { d2s_t v = {cc[2 * i], cc[2 * i + 1]}; out2[i] = v; }
+    }
+    if (tid == 0) {
+      double t4[4] = {scr[0], scr[1], scr[2], scr[3]};
+      for (int w8 = 1; w8 < nwave; ++w8) { t4[0] += scr[4 * w8]; t4[1] += scr[4 * w8 + 1]; t4[2] += scr[4 * w8 + 2]; t4[3] = fmax(t4[3], scr[4 * w8 + 3]); }
+      res[RES_COST_X] = 0.5 * pf_s[0];
+      res[RES_GMAX] = fmax(pf_s[3], t4[3]);
+      res[RES_XNORM2] = pf_s[1] + t4[1];
+      res[RES_POINT_FAIL] = pf_s[2];
+      res[RES_CHOL_OK] = (ok && pf_s[2] == 0.0) ? 1.0 : 0.0;
+      res[RES_STEP2] = t4[0];
+      res[RES_XCNORM2] = t4[2];
+    }
+  }
   if (gate.trace && tid == 0) gate.trace[15] = wall_clock64();
   SolveDone(gate);
 }
