@@ -79,8 +79,6 @@ __device__ __forceinline__ double* BackSubstituteBlocksPrefetch(int n, double* _
   double* Tb = lds + ((n + 63) & ~63);             // 32 x 33: Tb[i][c] = T[i][c]
   double* xb = Tb + RSBA_PB * RSBA_PLD;            // 32
   double* xw = xb + RSBA_PB;                       // 16 x 32: the wavefronts' partial sums of x_b
-  for (int i = tid; i < n; i += nt) y[i] = A[(size_t)n * n + i];
-  __syncthreads();
   const int kb_last = n - RSBA_PB;
   auto fetch_T = [&](int kb, int slot) {
     const int e = tid + slot * nt, i = e & 31, c = e >> 5;   // (lanes along i: T[i][c] lies in row kb + c of A — whole lines, not a line per lane)
@@ -97,9 +95,13 @@ __device__ __forceinline__ double* BackSubstituteBlocksPrefetch(int n, double* _
   //  barriers nor the round trip: the phase moves all of L — 590 KB written by workgroups on other XCDs, every line from memory
   //  — through ONE compute unit, which sustains ~24 GB/s of such loads)
   double tpre[2], lv[RSBA_PB], ln[RSBA_PB];
+  // (the first T and strip are asked for BEFORE the right-hand side is waited for and stored: one trip to memory at the head of
+  //  the phase instead of two behind each other)
   for (int sl = 0; sl < 2; ++sl) tpre[sl] = fetch_T(kb_last, sl);
 #pragma unroll
   for (int c = 0; c < RSBA_PB; ++c) lv[c] = q < kb_last ? A[(size_t)(kb_last + c) * n + q] : 0.0;
+  for (int i = tid; i < n; i += nt) y[i] = A[(size_t)n * n + i];
+  __syncthreads();
   for (int kb = kb_last; kb >= 0; kb -= RSBA_PB) {
     for (int sl = 0; sl < 2; ++sl) { const int e = tid + sl * nt; Tb[(e & 31) * RSBA_PLD + (e >> 5)] = tpre[sl]; }
     if (kb >= RSBA_PB) {
