@@ -948,7 +948,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     for (int q = 0; q < 4; ++q) pf_in[q] = intr[4 * tid + q];
   }
   if (tid == 0) { pf_s[0] = red[L.scal() + 0]; pf_s[1] = red[L.scal() + 1]; pf_s[2] = red[L.scal() + 2]; pf_s[3] = *gmax_p; }
-  double* y = BackSubstituteBlocksPrefetch(n, A, lds);
+  double* y = BackSubstituteBlocksWaves(n, A, lds);
   int ok = 1;
   if (tid == 0) { res[RES_STALL] = 0.0; ok = __hip_atomic_load(chol_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if (gate.trace && tid == 0) gate.trace[14] = wall_clock64();

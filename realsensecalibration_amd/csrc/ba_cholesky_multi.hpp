@@ -142,6 +142,99 @@ __device__ __forceinline__ double* BackSubstituteBlocksPrefetch(int n, double* _
   return y;
 }
 
+// BackSubstituteBlocksPrefetch rewritten for INSTRUCTION COUNT (round 4).  The phase — 25 us of the 64-camera step's tail, 2.1 us per
+// block row — was taken for memory-bound (one compute unit pulling all of L): it is not.  Neither two block rows in flight, nor
+// helper workgroups on the same XCD pulling the strips into the shared L2 ahead of it (placement verified with XCC_ID), nor one
+// barrier instead of four moved it; the ISA did: ~450 instructions per block row and wavefront — every one of the 32 loads of a
+// strip under its own compare / exec-mask save / branch / restore with a 64-bit vector address computation, 64 v_readlane with
+// their hazard nops — on two wavefronts per SIMD.  Here: one branch around the strip's loads, their addresses a scalar row base
+// plus one lane offset, x_b = T_b' y_b formed by every wavefront for itself (lane (c, h): half of column c's 32 terms, the halves
+// meet by a lane exchange — the same operations in every wavefront, the same bits) and handed to its lanes through a
+// wavefront-private LDS row read back 16 bytes at a time (broadcast), one barrier per block row, T double-buffered.
+// x is returned in its own array.  512 threads, n a multiple of 32, n <= 512.
+__device__ __forceinline__ double* BackSubstituteBlocksWaves(int n, double* __restrict__ A, double* lds) {
+  typedef double d2b_t __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int n64 = (n + 63) & ~63;
+  double* y = lds;                                 // n
+  double* xs = lds + n64;                          // n
+  double* Tb0 = xs + n64;                          // 2 x (32 x 33): Tb[i][c] = T[i][c]
+  double* xwv = Tb0 + 2 * RSBA_PB * RSBA_PLD + 32 * wave;   // [8][32] a wavefront's copy of x_b (16-byte aligned: offsets are even)
+  const int kb_last = n - RSBA_PB;
+  auto fetch_T = [&](int kb, int slot) {
+    const int e = tid + slot * nt, i = e & 31, c = e >> 5;
+    return (i > c) ? A[(size_t)(kb + c) * n + kb + i] : (i == c ? A[(size_t)(n + 1) * n + kb + c] : 0.0);
+  };
+  const unsigned q = (unsigned)tid, qoff = 8u * (unsigned)tid;  // kb <= 352 < nt
+  typedef int v2i_t __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);   // (gfx9 raw buffer, no swizzle: dword 3 as composable_kernel sets it for gfx90a / gfx94x)
+  double ra[RSBA_PB], rb[RSBA_PB], ta[2], tb[2];
+  auto load_strip = [&](int kb, double (&r)[RSBA_PB], double (&t)[2]) {
+    for (int sl = 0; sl < 2; ++sl) t[sl] = kb >= 0 ? fetch_T(kb, sl) : 0.0;
+    if (kb >= 0 && (int)q < kb) {
+      // (buffer loads: the matrix as a raw buffer, the row a SCALAR offset that moves on by one row per load, the column one 32-bit
+      //  lane offset — one instruction per load; as plain pointers every load came with a 64-bit vector add and two scalar ones.
+      //  ONE branch around the 32 loads, not one per load.  Measured and dropped: the loads without any branch — every lane, every
+      //  block row — so that the compiler's wait for T leaves the strip in flight: 36 us, three times the bytes)
+      int soff = kb * n * (int)sizeof(double);
+      const int row_bytes = n * (int)sizeof(double);
+#pragma unroll
+      for (int cc = 0; cc < RSBA_PB; ++cc) {
+        const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, qoff, soff, 0);
+        r[cc] = __hiloint2double(v.y, v.x);
+        soff += row_bytes;
+      }
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < RSBA_PB; ++cc) r[cc] = 0.0;
+    }
+  };
+  auto store_T = [&](int b, const double* t) {
+    double* Tn = Tb0 + b * (RSBA_PB * RSBA_PLD);
+    for (int sl = 0; sl < 2; ++sl) { const int e = tid + sl * nt; Tn[(e & 31) * RSBA_PLD + (e >> 5)] = t[sl]; }
+  };
+  const int c = lane & 31, h = lane >> 5;
+  int buf = 0;
+  auto block_row = [&](int kb, const double (&cur)[RSBA_PB], double (&nxt)[RSBA_PB], double (&tnxt)[2]) {
+    const double* Tb = Tb0 + buf * (RSBA_PB * RSBA_PLD);
+    load_strip(kb - RSBA_PB, nxt, tnxt);
+    // (a wavefront all of whose rows lie at or beyond this block row has nothing to apply x_b to: wavefront 0 alone then forms it)
+    const bool wave_on = 64 * wave < kb || wave == 0;
+    double part = 0.0;
+    if (wave_on) {
+#pragma unroll
+      for (int i = 0; i < RSBA_PB / 2; ++i) part = fma(Tb[(16 * h + i) * RSBA_PLD + c], y[kb + 16 * h + i], part);
+      part += __shfl_xor(part, 32, 64);   // (a + b in one half, b + a in the other: the same bits)
+      if (lane < RSBA_PB) xwv[lane] = part;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if ((int)q < kb) {
+      double s4[4] = {0.0, 0.0, 0.0, 0.0};   // four chains of eight, added in a fixed order
+      const d2b_t* xv = reinterpret_cast<const d2b_t*>(xwv);
+#pragma unroll
+      for (int k2 = 0; k2 < RSBA_PB / 2; ++k2) {
+        const d2b_t v = xv[k2];
+        s4[(2 * k2) & 3] = fma(cur[2 * k2], v.x, s4[(2 * k2) & 3]);
+        s4[(2 * k2 + 1) & 3] = fma(cur[2 * k2 + 1], v.y, s4[(2 * k2 + 1) & 3]);
+      }
+      y[q] -= (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
+    if (tid < RSBA_PB) xs[kb + tid] = part;
+    buf ^= 1;
+    if (kb >= RSBA_PB) store_T(buf, tnxt);
+    __syncthreads();
+  };
+  load_strip(kb_last, ra, ta);
+  for (int i = tid; i < n; i += nt) y[i] = A[(size_t)n * n + i];
+  store_T(0, ta);
+  __syncthreads();
+  for (int kb = kb_last; kb >= 0; kb -= 2 * RSBA_PB) {
+    block_row(kb, ra, rb, tb);
+    if (kb - RSBA_PB >= 0) block_row(kb - RSBA_PB, rb, ra, ta);
+  }
+  return xs;
+}
+
 __global__ void __launch_bounds__(512)
 k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, double* __restrict__ A, double* __restrict__ scale_c,
                              const double* __restrict__ cam_x, double* __restrict__ cam_c, const double* __restrict__ intr,
