@@ -8,18 +8,25 @@ A *step* is one Levenberg-Marquardt iteration of the hot path: linearise (residu
 blocks), eliminate the points into the 6C x 6C reduced camera system, Cholesky-solve it, back-substitute the
 points, evaluate the candidate, decide.  Inputs are resident in HBM before the timed region starts.  The timed
 region runs exactly K iterations from the uploaded start (tolerances off so that the count is exact),
-bracketed by barrier + torch.cuda.synchronize; the maximum over ranks is reported.  TWO such regions are timed and both are
-in the line: the first right behind the W warm-up iterations ("ms_per_step_without_filler" — exactly what the command line
-says), the second after untimed filler iterations have brought the solver to --preload (80) iterations in all
-("ms_per_step", which `value` is quoted on: the clocks take ~30 ms of load to come up, and a short command line such as
---steps 20 --warmup 5 is otherwise timed on that ramp).  "warmup" in the line is what really ran in front of the second
-region, "warmup_requested" is W, "untimed_filler_iterations" the filler.
+bracketed by barrier + torch.cuda.synchronize; the maximum over ranks is reported.
 
-N > 1 (launched by torch.distributed.run): weak scaling.  Every rank holds all 64 cameras and its own block
-of 100k points (the global problem has N x 100k points); per iteration the packed reduced camera system is
-all-reduced over RCCL.  `value` is the whole-job rate in units of the N=1 workload:
+What runs, in this order, on ONE solver (same buffers, streams, communicator):
+  1. a solve with the reference's own options (iterations to converge, final RMS) on a solver of its own,
+  2. N > 1 only: a 2-iteration PREFLIGHT whose iteration logs are compared bit for bit across the ranks (a mismatch ends the job
+     with a non-zero exit; a stalled in-kernel wait selects the sequential multi-GPU schedule, and the line says so),
+  3. the per-kernel pass: K iterations with HIP events around every launch (untimed; fills "kernels"),
+  4. untimed filler up to --preload iterations in all, then a DIAGNOSTIC timed region of K iterations: "ms_per_step_steady",
+  5. W warm-up iterations, then THE timed region: exactly K iterations — "ms_per_step", and `value` is quoted on it; "warmup" = W.
+Round 4 quoted `value` on (4) and reported "warmup": 80 for a command that said 5; now the region the command line describes is
+the last thing that runs and the one the headline is quoted on, and everything in front of it is listed ("untimed_iterations_before").
+
+N > 1 (launched by torch.distributed.run): the default config (cfg3) scales WEAKLY — every rank holds all 64 cameras and its own
+block of 100k points; `--config cfg4|cfg5` run BASELINE's totals (1M / 500k points) divided over the ranks ("strong").  Per iteration
+the packed reduced camera system is all-reduced over RCCL.  `value` is the whole-job rate in units of the N=1 workload:
     value = LM iterations/s x (total observations / 2,000,000)
 so at N = 1 it is exactly LM iterations/s on BASELINE's 64-cam x 100k-point problem.
+`--comm shm`: the ranks' collectives go through shared memory instead of RCCL (csrc/ba_comm.hpp ShmComm) and the ranks share the
+visible GPUs round-robin — the launcher, the bootstrap and one process per rank end to end on a ONE-GPU box; it measures nothing.
 """
 import argparse
 import ctypes
@@ -53,6 +60,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--comm", choices=("rccl", "shm"), default="rccl",
+                    help="N > 1: rccl (one GPU per rank, the product) | shm (processes sharing the visible GPUs, collectives through shared memory: "
+                         "the whole multi-process path on a one-GPU box)")
+    ap.add_argument("--mg-pipeline", action="store_true", help="N > 1 over RCCL: opt into the pipelined multi-GPU schedule (RSBA_PIPELINE_MG=1); "
+                                                                 "the preflight falls back to the sequential one if it stalls")
     return ap.parse_args()
 
 
@@ -64,13 +76,16 @@ def launch_ranks(n):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < n:
-        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
+    if have < n and "shm" not in sys.argv[1:] and "--comm=shm" not in sys.argv[1:]:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (--comm shm shares them between the ranks)" % (n, have))
+    if have < 1:
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("RSBA_BENCH_JOB", "%d_%d" % (os.getpid(), int(time.time())))   # names the shared-memory group of --comm shm
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -102,10 +117,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
+    shm = world > 1 and args.comm == "shm"
+    device = local_rank % torch.cuda.device_count() if shm else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shm:   # (RCCL refuses two ranks of one communicator on one device: the plumbing goes over gloo)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.mg_pipeline and not shm:
+            os.environ["RSBA_PIPELINE_MG"] = "1"
 
     import __graft_entry__
     if rank == 0:
@@ -118,20 +140,34 @@ def main():
 
     # ---- workload: this rank's shard
     C, P_cfg, k, seed, outl, huber = syn.CONFIGS[args.config]
-    P_rank = args.points or P_cfg
-    P_total = P_rank * world
+    # cfg3 (the metric's config) scales weakly: P_cfg points PER RANK.  cfg4 / cfg5 are BASELINE's multi-GPU configs: their named
+    # totals (1M / 500k points) are divided over the ranks unless --points says otherwise (round 4 ran 8 x the total there).
+    strong = args.points is None and args.config in ("cfg4", "cfg5") and world > 1
+    if strong:
+        P_total = P_cfg
+        lo, hi = rd.shard_range(P_total, rank, world)
+        P_rank = hi - lo
+    else:
+        P_rank = args.points or P_cfg
+        P_total = P_rank * world
+        lo, hi = rd.shard_range(P_total, rank, world)
     t0 = time.time()
-    prob = syn.make_problem(C, P_total, k, seed, point_range=rd.shard_range(P_total, rank, world), outlier_frac=outl)
+    prob = syn.make_problem(C, P_total, k, seed, point_range=(lo, hi), outlier_frac=outl)
     prob["huber_delta"] = huber
     gen_s = time.time() - t0
-    N_rank, N_total = prob["N"], prob["N"] * world
+    N_rank, N_total = prob["N"], P_total * min(k, C)
 
     uid = None
     if world > 1:
-        uid = rd.broadcast_unique_id(dist, capi, rank)
+        if shm:
+            box = [os.environ.get("RSBA_BENCH_JOB", "job%d" % os.getppid()) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            uid = ctypes.create_string_buffer(capi.comm_shm_id("bench_%s" % box[0]), 128)
+        else:
+            uid = rd.broadcast_unique_id(dist, capi, rank)
 
     def options(**kw):
-        o = capi.default_options(device=local_rank, huber_delta=huber, rank=rank, world_size=world, **kw)
+        o = capi.default_options(device=device, huber_delta=huber, rank=rank, world_size=world, **kw)
         if args.schur_impl is not None:
             o.schur_impl = args.schur_impl
         if uid is not None:
@@ -151,28 +187,56 @@ def main():
     # negative tolerances: no convergence test can fire (0 would still stop on a bitwise-equal candidate cost)
     fixed = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
                  max_num_consecutive_invalid_steps=1 << 30, min_trust_region_radius=0.0)
-    # One solver for all of it (same device buffers, same streams, one communicator), three runs back to back:
-    #   1. the per-kernel pass: K iterations with HIP events around every launch (not timed; its table fills "kernels"),
-    #   2. W warm-up iterations,
-    #   3. the timed run: K iterations, events only around the kernel the roofline is quoted on, on every fourth step.
-    # The per-kernel pass comes FIRST so that the GPU has been under load for K + W steps when the timed region starts: after
-    # the host-side set-up the clocks take ~10-30 ms of work to come up (an iteration measured 0.455 ms in the first ten
-    # steps behind an idle gap and 0.415 ms forty steps later, tools/run_overhead.py), and with the pass behind the timed
-    # region a short timed region (--steps 20 --warmup 5) sat entirely inside that ramp.
-    sv_k = capi.Solver(problem, options(max_num_iterations=args.steps, profile_kernels=0 if args.no_events else 1, **fixed))
-    stats = {}
-    if not args.no_events:
-        sv_k.run()
-        stats = sv_k.kernel_stats()
-    # ... and so that this does not depend on K and W: at least ~80 untimed iterations in all before the timed region (the driver's
-    # `--steps 20 --warmup 5` put 25 in front of it — 10 ms — and its timed iterations ran from 405 down to 396 us, still on the
-    # ramp, where the 50-iteration default, with 53 in front, runs at 392).  Untimed like the per-kernel pass; the W warm-up
-    # iterations follow, then exactly K are timed.
+
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if shm else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    sv_k = capi.Solver(problem, options(max_num_iterations=args.steps, profile_kernels=0 if args.no_events else 1, **fixed))
+    # ---- N > 1: preflight.  Two forced iterations; every rank's iteration log must equal rank 0's bit for bit (the ranks factor the
+    # identical all-reduced system and take identical decisions — anything else is a broken collective), and a stalled in-kernel wait
+    # of the pipelined multi-GPU schedule selects the sequential one for the whole job: every rank takes the same decision from the
+    # same gathered facts.  A rank that fails inside (RCCL error, a peer gone: bounded waits, csrc/ba_comm.hpp) raises and the
+    # launcher ends the job with its exit code — never a re-exec of a process that has touched the GPU.
+    preflight = None
+    if world > 1:
+        sv_k.configure_run(2, 0)
+        s_pf = sv_k.run()
+        mine = dict(log=sv_k.iterations()[:, :8].tobytes(), info=sv_k.schedule_info(), iters=int(s_pf.num_iterations))
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        same = all(b["log"] == box[0]["log"] and b["iters"] == 2 for b in box)
+        stalls = sum(b["info"]["stalls"] for b in box)
+        preflight = {"iterations": 2, "logs_bitwise_equal_across_ranks": bool(same), "stalls": int(stalls),
+                     "schedule": box[0]["info"]["schedule"], "fell_back_to_sequential": False}
+        if not same:
+            if rank == 0:
+                print("bench.py: preflight FAILED: the ranks' iteration logs differ (schedules: %s)" % [b["info"]["schedule"] for b in box], file=sys.stderr, flush=True)
+            sys.exit(3)
+        if stalls > 0 and box[0]["info"]["schedule"] == "pipelined_mg":
+            os.environ["RSBA_PIPELINE_MG"] = "0"
+            sv_k.close()
+            sv_k = capi.Solver(problem, options(max_num_iterations=args.steps, profile_kernels=0 if args.no_events else 1, **fixed))
+            preflight["fell_back_to_sequential"] = True
+    # One solver for all of it (same device buffers, same streams, one communicator).  The per-kernel pass comes FIRST so that the
+    # GPU has been under load when the timed regions start: after the host-side set-up the clocks take ~10-30 ms of work to come
+    # up (an iteration measured 0.455 ms in the first ten steps behind an idle gap and 0.415 ms forty steps later).
+    stats = {}
+    ran_before = 2 if world > 1 and not (preflight or {}).get("fell_back_to_sequential") else 0
+    if not args.no_events:
+        sv_k.configure_run(args.steps, 1)
+        sv_k.run()
+        stats = sv_k.kernel_stats()
+        ran_before += args.steps
 
     def timed_run():
         """Exactly K iterations, bracketed by barrier + synchronize; the maximum over the ranks."""
@@ -181,47 +245,46 @@ def main():
         t0 = time.perf_counter()
         s = sv_k.run()
         sync()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = max_over_ranks(time.perf_counter() - t0)
         assert s.num_iterations == args.steps, (s.num_iterations, args.steps)
         return s, dt
 
-    if args.warmup > 0:
-        sv_k.configure_run(args.warmup, 0)
-        s_w = sv_k.run()
-        assert s_w.num_iterations == args.warmup, (s_w.num_iterations, args.warmup)
     # the communicator the timed solver all-reduces over must span exactly --gpus ranks (1 = no communicator)
     rccl_nranks = sv_k.comm_nranks()
     if rccl_nranks != args.gpus:
-        raise SystemExit("RCCL communicator spans %d rank(s), --gpus %d" % (rccl_nranks, args.gpus))
-    # Two timed regions of exactly K iterations each, both reported.  The first right behind the W warm-up iterations, as the
-    # command line says ("ms_per_step_without_filler"); then untimed filler iterations until the GPU has run --preload (80)
-    # untimed-or-earlier iterations in all, and the second, which `value` is quoted on: steady-state throughput.  "warmup" in
-    # the line is the number of iterations that really ran on this solver in front of that second region.
-    ran_before = (0 if args.no_events else args.steps) + args.warmup
-    elapsed_nofill = None
+        raise SystemExit("communicator spans %d rank(s), --gpus %d" % (rccl_nranks, args.gpus))
+    # diagnostic region ("ms_per_step_steady"): filler up to --preload untimed iterations in all, then K timed
+    elapsed_steady = None
     preload = 0
     if args.preload > 0:
-        _, elapsed_nofill = timed_run()
-        ran_before += args.steps
         preload = max(0, args.preload - ran_before)
         if preload > 0:
             sv_k.configure_run(preload, 0)
             s_p = sv_k.run()
             assert s_p.num_iterations == preload, (s_p.num_iterations, preload)
             ran_before += preload
+        _, elapsed_steady = timed_run()
+        ran_before += args.steps
+    # THE region the command line describes: W warm-up iterations, then exactly K timed ones — the last thing that runs
+    if args.warmup > 0:
+        sv_k.configure_run(args.warmup, 0)
+        s_w = sv_k.run()
+        assert s_w.num_iterations == args.warmup, (s_w.num_iterations, args.warmup)
     s_k, elapsed = timed_run()
     assert s_k.num_iterations == args.steps, (s_k.num_iterations, args.steps)
     stats_timed = sv_k.kernel_stats()
+    sched = sv_k.schedule_info()
     sv_k.close()
     if not args.no_events:
         stats.update(stats_timed)  # the roofline kernels: durations measured inside the timed region
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, sched)
+        sched = dict(box[0], stalls=sum(b["stalls"] for b in box), fallbacks=sum(b["fallbacks"] for b in box))
 
     if rank != 0:
         if world > 1:
+            capi.load().rsba_comm_finalize()
             dist.destroy_process_group()
         return
 
@@ -229,20 +292,23 @@ def main():
     value = iters_per_s * (N_total / 2_000_000.0) if args.config == "cfg3" else iters_per_s
     out = {
         "metric": "LM iterations/sec (64 cams x 100k pts point model; + final reprojection RMS px)",
-        "value": value, "unit": "LM iterations/s (of the 2M-observation workload)", "n_gpus": world, "rccl_nranks": rccl_nranks,
-        "steps": args.steps, "warmup": ran_before, "warmup_requested": args.warmup, "untimed_filler_iterations": preload,
+        "value": value, "unit": "LM iterations/s (of the 2M-observation workload)" if args.config == "cfg3" else "LM iterations/s", "n_gpus": world, "rccl_nranks": rccl_nranks,
+        "steps": args.steps, "warmup": args.warmup, "untimed_iterations_before": ran_before,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "ms_per_step_without_filler": (1e3 * elapsed_nofill / args.steps) if elapsed_nofill is not None else 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "ms_per_step_steady": (1e3 * elapsed_steady / args.steps) if elapsed_steady is not None else None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d cams x %d points, %d observations (%d views/point), point model <2,6,3>, "
                                "DENSE_SCHUR-equivalent; %d points per GPU" % (args.config, C, P_total, N_total, k, P_rank),
-                   "sharding": "points by contiguous block, cameras replicated, RCCL all-reduce of the reduced system" if world > 1 else "single GPU",
-                   "schur_impl": int(options().schur_impl), "seed": seed},
+                   "sharding": ("points by contiguous block, cameras replicated, %s all-reduce of the reduced system" % ("shared-memory (host-staged)" if shm else "RCCL")) if world > 1 else "single GPU",
+                   "schur_impl": int(sched["schur_impl"]), "seed": seed},
+        "schedule": sched["schedule"], "stalls": sched["stalls"], "fallbacks": sched["fallbacks"], "comm": sched["comm_kind"],
         "lm_iterations_per_s": iters_per_s, "observations_per_s": iters_per_s * N_total,
         "final_reprojection_rms_px": rms, "iterations_to_converge": int(s_conv.num_iterations),
         "converged_final_cost": s_conv.final_cost, "termination": int(s_conv.termination_type),
         "problem_generation_s": gen_s, "upload_s": s_k.setup_seconds,
     }
+    if preflight is not None:
+        out["preflight"] = preflight
 
     # ---- roofline of the dominant kernel, from HIP-event durations recorded in the timed region
     if stats:
@@ -257,8 +323,9 @@ def main():
             return v[1] / max(v[0], 1)
         stats = {n: (c, c * (avg((c, ms)) - avg(waiting[n]))) if n in waiting else (c, ms) for n, (c, ms) in spans.items()}
         per = {n: (c, ms / max(c, 1)) for n, (c, ms) in stats.items()}
-        views = np.full(P_rank, k, np.float64)
+        views = np.full(P_rank, min(k, C), np.float64)
         schur_flops = syn.schur_flops_per_iteration(views)
+        schur_flops_r04 = syn.schur_flops_per_iteration(views, full_diagonal_blocks=True)   # rounds 1-4 counted 216 flop for the diagonal blocks too
         nc = 6 * C
         chol_flops = nc ** 3 / 3.0 + 2.0 * nc ** 2
         b_iter = syn.algorithmic_bytes_per_iteration(C, P_rank, N_rank)
@@ -294,7 +361,10 @@ def main():
                         "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": pmc_source if traffic is not None else None,
                         "avg_launch_us": 1e3 * ms,
                         "algorithmic_flops_per_launch": schur_flops / lpi, "launches_per_iteration": lpi,
-                        "note": "compute-bound point elimination on the fp64 vector pipe: sum_j k_j(k_j+1)/2 blocks x 216 flop (+rhs); "
+                        "frac_with_full_diagonal_blocks": schur_flops_r04 / lpi / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                        "note": "compute-bound point elimination on the fp64 vector pipe: per point with k views k(k-1)/2 off-diagonal blocks "
+                                "x 216 flop + k diagonal blocks x 126 flop (their 21 unique entries) + k x 36 (rhs); rounds 1-4 counted the diagonal "
+                                "blocks at 216 as well (frac_with_full_diagonal_blocks, +4 %); "
                                 "\"bound\" keeps the schema's compute label, \"pipe\" names the real one (PMC: zero MFMA ops in this kernel)"}
             if "reduced_system" in name or "chol_tiles" in name or "chol_step" in name:
                 ach = chol_flops / lpi / (ms * 1e-3) / 1e12
@@ -402,6 +472,7 @@ def main():
     sys.stdout.flush()
     print(json.dumps(out), flush=True)
     if world > 1:
+        capi.load().rsba_comm_finalize()
         dist.destroy_process_group()
 
 

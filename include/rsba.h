@@ -95,8 +95,10 @@ typedef struct rsba_options {
   const void* comm_unique_id; /* world_size > 1: the 128-byte id from rsba_comm_unique_id (rank 0's) */
   void* stream;               /* hipStream_t to run on, NULL = a private stream                    */
   double max_solver_time_in_seconds; /* 1e9 (Ceres' default; Solver::Options, left alone by bundle_adjustment_manager.cpp:90-92): checked
-                                        once per iteration behind the iteration limit, as TrustRegionMinimizer does -> NO_CONVERGENCE,
-                                        RSBA_STOP_MAX_TIME.  One rank only: several ranks would each read their own clock and part
+                                        once per iteration IN FRONT OF the iteration limit and for the first time right behind
+                                        iteration 0, against minimiser + set-up (preprocessor) time, as TrustRegionMinimizer's
+                                        FinalizeIterationAndCheckIfMinimizerCanContinue does -> NO_CONVERGENCE, RSBA_STOP_MAX_TIME;
+                                        a budget of 0 returns the start with no step taken.  One rank only: several ranks would each read their own clock and part
                                         (rsba_solver_create returns RSBA_ERR_UNSUPPORTED for a finite limit with world_size > 1).
                                         Solver::Options::use_nonmonotonic_steps has no field: the reference leaves it false, and the
                                         device-side step decision (DecideStep) implements the monotonic rule only. */
@@ -125,6 +127,17 @@ typedef struct rsba_iteration {
   double iteration_time_in_seconds;  /* iter_time */
   double cumulative_time_in_seconds; /* total_time, since the start of the minimiser loop */
 } rsba_iteration;
+
+/* Which schedule a solver runs and what has gone wrong so far (bench.py prints it; a first run on new hardware reads it) */
+typedef struct rsba_schedule_info {
+  int32_t schedule;        /* 0 sequential, 1 pipelined (factorisation gated on the Schur kernel's stages), 2 pipelined multi-GPU */
+  int32_t stalls;          /* steps whose in-kernel wait ran out of its budget and were repeated sequentially */
+  int32_t fallbacks;       /* permanent fallbacks taken (third pipeline stall; one-workgroup / multi-launch factorisation) */
+  int32_t comm_nranks;     /* ranks of the communicator (1: none) */
+  int32_t chol_workgroups; /* workgroups of the reduced system's factorisation (resident tiles above 64 cameras) */
+  int32_t schur_impl;      /* as run: 0 when a shard with duplicate observations fell back to the atomic kernel */
+  char comm_kind[16];      /* "none" | "rccl" | "loopback" | "shm" */
+} rsba_schedule_info;
 
 typedef struct rsba_kernel_stat {
   char name[48];
@@ -266,9 +279,21 @@ int rsba_comm_unique_id(void* out128);
  * device, so it measures nothing; it is how the multi-rank code path is tested where only one GPU is visible.  The reference
  * has no counterpart (single-threaded: Main_Calibration/bundle_adjustment_manager.cpp:90-92). */
 int rsba_comm_loopback_id(void* out128);
+/* The same 128 bytes for a SHARED-MEMORY group (round 5): world_size PROCESSES of one host — on one GPU or several — whose
+ * collectives are staged through a POSIX shared-memory segment named after `name` ([A-Za-z0-9_.-], at most 80 characters, the
+ * same string on every rank, unique per group and run) and added on the host in rank order.  It is how one process per rank,
+ * bench.py's own launcher and the id bootstrap run end to end where RCCL cannot (two ranks on one device); sequential multi-GPU
+ * schedule only.  No counterpart in the reference (single process, single thread). */
+int rsba_comm_shm_id(const char* name, void* out128);
+/* Destroys every RCCL communicator this process still holds (ncclCommDestroy); call once, after the last solver is destroyed and
+ * before the process tears the HIP runtime down.  Optional: communicators otherwise live until exit. */
+void rsba_comm_finalize(void);
 /* ncclCommCount of the solver's communicator: the number of ranks its all-reduces really span (1 without a
  * communicator).  bench.py prints it as `rccl_nranks` and refuses to report a line when it differs from --gpus. */
 int rsba_solver_comm_nranks(const rsba_solver* s);
+/* The schedule in effect and the stalls / fallbacks so far (rsba_schedule_info).  The reference has no counterpart: Ceres runs
+ * one thread (bundle_adjustment_manager.cpp:90-92). */
+int rsba_solver_schedule_info(const rsba_solver* s, rsba_schedule_info* out);
 
 /* ------------------------------------------------------------------ files either side of the path */
 /* IO::GetIntrinsics (my_io.cpp:5-31) without OpenCV: reads <intrinsics> 3x3 from an OpenCV

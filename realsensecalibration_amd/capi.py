@@ -6,7 +6,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librsba.so")
+# RSBA_LIB: another build of the library (tools/ build diagnostic variants to a scratch path and point this at them — the packaged
+# library is never overwritten)
+LIB_PATH = os.environ.get("RSBA_LIB") or os.path.join(HERE, "librsba.so")
 
 OK, ERR_IO, ERR_FORMAT, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_COMM, ERR_UNSUPPORTED = range(8)
 MODEL_POINTS, MODEL_MARKER_CHAIN, MODEL_MARKER_CHAIN_TEST2 = 0, 1, 2
@@ -26,7 +28,7 @@ EXPORTS = [
     "rsba_write_outputs", "rsba_reprojection_error", "rsba_reprojection_check_files",
     "rsba_base_pose_from_marker_detection", "rsba_marker_pose_in_camera", "rsba_marker_corners_in_camera", "rsba_solve_pnp_epnp",
     "rsba_problem_initial_camera_poses", "rsba_problem_set_camera_constant", "rsba_solver_full_report", "rsba_solver_configure_run",
-    "rsba_solver_comm_nranks",
+    "rsba_solver_comm_nranks", "rsba_solver_schedule_info", "rsba_comm_shm_id", "rsba_comm_finalize",
 ]
 
 
@@ -59,6 +61,11 @@ class Iteration(C.Structure):
 
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
+class ScheduleInfo(C.Structure):
+    _fields_ = [("schedule", C.c_int32), ("stalls", C.c_int32), ("fallbacks", C.c_int32), ("comm_nranks", C.c_int32),
+                ("chol_workgroups", C.c_int32), ("schur_impl", C.c_int32), ("comm_kind", C.c_char * 16)]
 
 
 class RsbaError(RuntimeError):
@@ -115,6 +122,8 @@ def load():
     lib.rsba_solver_final_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rsba_solver_destroy.argtypes = [C.c_void_p]
     lib.rsba_solver_comm_nranks.argtypes = [C.c_void_p]
+    lib.rsba_solver_schedule_info.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rsba_comm_shm_id.argtypes = [C.c_char_p, C.c_void_p]
     lib.rsba_points_linearize_and_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 4
     lib.rsba_points_linearize_payload.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]
     lib.rsba_comm_unique_id.argtypes = [C.c_void_p]
@@ -288,6 +297,14 @@ class Solver:
         """ncclCommCount of the solver's communicator (1 without one)."""
         return int(load().rsba_solver_comm_nranks(self.h))
 
+    def schedule_info(self):
+        """Which schedule this solver runs and what stalled so far (rsba_schedule_info) as a dict."""
+        i = ScheduleInfo()
+        _chk(load().rsba_solver_schedule_info(self.h, C.byref(i)), "rsba_solver_schedule_info")
+        return {"schedule": ("sequential", "pipelined", "pipelined_mg")[i.schedule], "stalls": int(i.stalls), "fallbacks": int(i.fallbacks),
+                "comm_nranks": int(i.comm_nranks), "chol_workgroups": int(i.chol_workgroups), "schur_impl": int(i.schur_impl),
+                "comm_kind": i.comm_kind.decode()}
+
     def full_report(self):
         n = load().rsba_solver_full_report(self.h, None, 0)
         if n < 0:
@@ -364,6 +381,14 @@ def comm_loopback_id():
     """Id of a loopback group: the ranks are solvers of this process on one GPU (rsba.h)."""
     buf = (C.c_char * 128)()
     _chk(load().rsba_comm_loopback_id(buf), "rsba_comm_loopback_id")
+    return bytes(buf)
+
+
+def comm_shm_id(name):
+    """128-byte id of a SHARED-MEMORY group: the ranks are processes on one host (one GPU or several); `name` must be the same
+    string on every rank and unique per group (rsba_comm_shm_id)."""
+    buf = (C.c_char * 128)()
+    _chk(load().rsba_comm_shm_id(name.encode(), buf), "rsba_comm_shm_id")
     return bytes(buf)
 
 

@@ -229,6 +229,7 @@ struct rsba_solver {
   // schedule for this solver), and "the next pipelined step waits until the factorisation is resident" (first step of a
   // run, first step after a time-out)
   int pipe_stalls = 0;
+  int other_stalls = 0;      // stalls of the multi-workgroup / tiled factorisation in the sequential schedule (each is a permanent fallback)
   bool pipe_check_resident = false;
   long long* trace = nullptr;   // RSBA_TRACE=1: 64 wall-clock stamps of the pipelined step
   // RSBA_TRACE=3: the stamps of the last 256 steps in a ring (trace points at the current step's 64 slots), nothing is
@@ -1004,6 +1005,12 @@ static bool SetupPipeline(rsba_solver* s) {
     const char* q = getenv("GPU_MAX_HW_QUEUES");
     const int nq = q ? atoi(q) : 0;
     if (getenv("RSBA_PIPELINE_MG") && atoi(getenv("RSBA_PIPELINE_MG")) == 0) return false;
+    // Round 5 (ADVICE, medium): over REAL RCCL with more than one rank the pipelined schedule is opt-in (RSBA_PIPELINE_MG=1) until
+    // an N >= 2 run on hardware is on record — RCCL's own kernels then need CUs and hardware queues beside the resident waiters
+    // (k_wait_stage, the gated factorisation), and every stall costs ten stall budgets before the step is repeated.  Loopback and
+    // shared-memory groups and 1-rank communicators, where it has run thousands of steps, keep it as their default.
+    if (strcmp(s->comm->kind(), "rccl") == 0 && s->comm->nranks() > 1 && !(getenv("RSBA_PIPELINE_MG") && atoi(getenv("RSBA_PIPELINE_MG")) == 1)) return false;
+    if (!s->comm->AllowsResidentWaiters()) return false;
     if (nq == 3) {
       std::call_once(warned, [] { fprintf(stderr, "rsba: GPU_MAX_HW_QUEUES=3 puts the pipelined multi-GPU schedule's waiting kernels behind each other; "
                                                    "using the sequential schedule (set GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises)\n"); });
@@ -1131,7 +1138,7 @@ static int UploadPoints(rsba_solver* s) {
       if ((rc = DevAlloc(&d, 1))) return rc;
       HIPCHK(hipMemcpy(d, &h, sizeof(int), hipMemcpyHostToDevice));
       COMMCHK(s->comm->MinInts(d, 1, s->stream));
-      HIPCHK(hipStreamSynchronize(s->stream));
+      COMMCHK(s->comm->WaitStream(s->stream));
       HIPCHK(hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost));
       (void)hipFree(d);
       if (!h) { s->pipelined = false; s->pipelined_mg = false; }
@@ -1379,7 +1386,11 @@ static int SchurGrid(int entries, bool sparse) { return sparse ? std::min(entrie
 // Up to 64 cameras the payload is 1.19 MB and the collective latency-bound: two more launches would cost more than the
 // bytes save (RSBA_TRI_PAYLOAD=1 forces the packed payload there too, =0 disables it; tests/test_gpu_loopback.py).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pack_lower(int n, const double* __restrict__ red, RedLayout L, double* __restrict__ tri) {
+// sym_full == 0 (schur_impl 0: k_linearize_schur_ref accumulates the UPPER block triangle only, the lower half of S stays at the
+// memset's zeros): element (i, j), j <= i, of the triangle is read from its mirror (j, i), which that kernel does fill.  A group may
+// mix ranks of both kinds (a shard with duplicate observations runs schur_impl 0): each packs its own S correctly, the sum is right,
+// and k_unpack_lower writes both halves, which the consumers of either kind accept.
+__global__ void __launch_bounds__(256) k_pack_lower(int n, const double* __restrict__ red, RedLayout L, double* __restrict__ tri, int sym_full) {
   const size_t nt = (size_t)n * (n + 1) / 2, total = nt + 3 * (size_t)n + 8;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
     if (k >= nt) { tri[k] = red[L.gc() + (k - nt)]; continue; }
@@ -1388,7 +1399,7 @@ __global__ void __launch_bounds__(256) k_pack_lower(int n, const double* __restr
     while (i * (i + 1) / 2 > k) --i;
     while ((i + 1) * (i + 2) / 2 <= k) ++i;
     const size_t j = k - i * (i + 1) / 2;
-    tri[k] = red[L.S() + i * (size_t)n + j];
+    tri[k] = sym_full ? red[L.S() + i * (size_t)n + j] : red[L.S() + j * (size_t)n + i];
   }
 }
 __global__ void __launch_bounds__(256) k_unpack_lower(int n, const double* __restrict__ tri, double* __restrict__ red, RedLayout L) {
@@ -1501,7 +1512,10 @@ static int WaitResult(rsba_solver* s, hipStream_t posting) {
   while (*seq != s->res_seq) {
     __builtin_ia32_pause();
     if (std::chrono::steady_clock::now() - t_poll > std::chrono::seconds(2)) {
-      HIPCHK(hipStreamSynchronize(posting));
+      // (with a communicator the stream may sit in a collective whose peer is gone: a bounded wait that polls the communicator's
+      //  health and aborts it, ba_comm.hpp — the process then leaves with RSBA_ERR_COMM instead of hanging)
+      if (s->comm) { if (!s->comm->WaitStream(posting)) return RSBA_ERR_COMM; }
+      else HIPCHK(hipStreamSynchronize(posting));
       if (*seq != s->res_seq) { fprintf(stderr, "rsba: step finished without posting its result\n"); return RSBA_ERR_HIP; }
       t_poll = std::chrono::steady_clock::now();
     }
@@ -1787,7 +1801,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (s->red_tri != nullptr) {
       const int n = s->nc;
       const int grid_tri = std::max(1, std::min(2 * DeviceCUs(), (int)((TriSize(n) + 255) / 256)));
-      k_pack_lower<<<grid_tri, 256, 0, st>>>(n, s->red, s->L, s->red_tri);
+      k_pack_lower<<<grid_tri, 256, 0, st>>>(n, s->red, s->L, s->red_tri, s->opt.schur_impl != 0 ? 1 : 0);
       COMMCHK(s->comm->GroupStart());
       COMMCHK(s->comm->SumDoubles(s->red_tri, TriSize(n), st));
       COMMCHK(s->comm->MaxDoubles(s->gmax, 1, st));
@@ -2103,6 +2117,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   }
   if (!pipe && s->tc_tiles > 0 && s->res_host[RES_STALL] != 0.0) {
     fprintf(stderr, "rsba: persistent tiled Cholesky stalled; using the multi-launch factorisation\n");
+    ++s->other_stalls;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(s->res, 0, RES_SIZE * sizeof(double)));
     s->tc_tiles = 0;
@@ -2111,6 +2126,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   if (!pipe && s->chol_wgs > 1 && s->res_host[RES_STALL] != 0.0) {
     // the workgroups of the factorisation did not run side by side (cannot happen on an idle stream): one workgroup then
     fprintf(stderr, "rsba: multi-workgroup Cholesky stalled; using one workgroup\n");
+    ++s->other_stalls;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
     s->chol_wgs = 1;
@@ -2245,20 +2261,27 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
     last.cost = x_cost; last.gradient_max_norm = gmax;
     x_moved = false;
   };
+  // "Maximum solver time reached" (trust_region_minimizer.cc MaxSolverTimeReached): wall time since the minimiser started PLUS
+  // the preprocessor's (here: the upload, setup_seconds), tested in front of the iteration limit — and for the first time right
+  // behind iteration 0, so that a budget of zero ends the run with no step taken, as Ceres does
   const auto t_loop0 = std::chrono::steady_clock::now();
+  auto out_of_time = [&]() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count() + s->setup_seconds >= o.max_solver_time_in_seconds;
+  };
   for (;;) {
     // checks of FinalizeIterationAndCheckIfMinimizerCanContinue for the previous iteration
     if (!first) {
       const bool at_limit = s->iters.back().iteration >= o.max_num_iterations;
-      if (x_moved && (at_limit || radius < o.min_trust_region_radius)) {
+      const bool timed_out = out_of_time();
+      if (x_moved && (at_limit || timed_out || radius < o.min_trust_region_radius)) {
         int rc = eval();
         if (rc != RSBA_OK) return rc;
         x_cost = s->res_host[RES_COST_X]; gmax = s->res_host[RES_GMAX];
         settle_moved();
       }
+      // FinalizeIterationAndCheckIfMinimizerCanContinue's order: solver time, iterations, gradient, radius
+      if (timed_out) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_TIME);
       if (at_limit) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_ITERATIONS);
-      // "Maximum solver time reached" (trust_region_minimizer.cc, behind the iteration limit)
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count() >= o.max_solver_time_in_seconds) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_TIME);
       if (!x_moved && gmax <= o.gradient_tolerance) return finish(RSBA_CONVERGENCE, RSBA_STOP_GRADIENT);
       if (radius < o.min_trust_region_radius) return finish(RSBA_CONVERGENCE, RSBA_STOP_MIN_RADIUS);
     }
@@ -2277,6 +2300,7 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
       if (!std::isfinite(x_cost)) { sum->final_cost = x_cost; sum->termination_type = RSBA_FAILURE; sum->stop_reason = RSBA_STOP_INITIAL_FAILURE; sum->num_iterations = 0; flush_rows(); return RSBA_OK; }
       first = false;
       if (gmax <= o.gradient_tolerance) return finish(RSBA_CONVERGENCE, RSBA_STOP_GRADIENT);
+      if (out_of_time()) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_TIME);   // (this step's solve and candidate are discarded)
       if (o.max_num_iterations <= 0) return finish(RSBA_NO_CONVERGENCE, RSBA_STOP_MAX_ITERATIONS);
       if (radius < o.min_trust_region_radius) return finish(RSBA_CONVERGENCE, RSBA_STOP_MIN_RADIUS);
     } else if (x_moved) {
@@ -2352,10 +2376,30 @@ int rsba_comm_loopback_id(void* out128) {
   return RSBA_OK;
 }
 
+int rsba_comm_shm_id(const char* name, void* out128) {
+  if (!out128 || !rsba::ShmComm::NewId(name, out128)) return RSBA_ERR_ARG;
+  return RSBA_OK;
+}
+
+void rsba_comm_finalize(void) { rsba::RcclComm::FinalizeAll(); }
+
 int rsba_solver_comm_nranks(const rsba_solver* s) {
   if (!s) return 0;
   if (!s->comm) return 1;
   return s->comm->nranks();
+}
+
+int rsba_solver_schedule_info(const rsba_solver* s, rsba_schedule_info* out) {
+  if (!s || !out) return RSBA_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  out->schedule = s->pipelined_mg ? 2 : (s->pipelined ? 1 : 0);
+  out->stalls = s->pipe_stalls + s->other_stalls;
+  out->fallbacks = (s->pipe_stalls >= 3 ? 1 : 0) + s->other_stalls;
+  out->comm_nranks = s->comm ? s->comm->nranks() : 1;
+  out->chol_workgroups = s->nc > RSBA_CHOL_MAXN ? s->tc_tiles : s->chol_wgs;
+  out->schur_impl = s->opt.schur_impl;
+  strncpy(out->comm_kind, s->comm ? s->comm->kind() : "none", sizeof(out->comm_kind) - 1);
+  return RSBA_OK;
 }
 
 int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out) {
@@ -2380,8 +2424,12 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
   if (opt.world_size > 1 || getenv("RSBA_FORCE_COMM")) {
     // RCCL (one communicator per unique id and process; RSBA_FORCE_COMM=1: a 1-rank communicator, so that the collective
     // path can be exercised on a single GPU), or — an id from rsba_comm_loopback_id — the ranks of one process on one GPU
+    // or — rsba_comm_shm_id — processes of one host staging through shared memory (the slots sized for this problem's payload)
+    const size_t nc6 = 6 * (size_t)std::max(p->num_cameras, 1);
     s->comm = opt.world_size > 1 && rsba::LoopbackComm::IsLoopbackId(opt.comm_unique_id)
                   ? rsba::LoopbackComm::Create(opt.world_size, opt.rank, opt.comm_unique_id)
+              : opt.world_size > 1 && rsba::ShmComm::IsShmId(opt.comm_unique_id)
+                  ? rsba::ShmComm::Create(opt.world_size, opt.rank, opt.comm_unique_id, (nc6 * nc6 + 3 * nc6 + 64) * sizeof(double))
                   : rsba::RcclComm::Create(opt.world_size, opt.rank, opt.comm_unique_id);
     if (!s->comm) { rsba::FreeSolver(s); return RSBA_ERR_COMM; }
   }

@@ -22,7 +22,17 @@ def main():
     from realsensecalibration_amd import capi
     from realsensecalibration_amd import distributed as rd
     from realsensecalibration_amd import synthetic as syn
-    uid = rd.broadcast_unique_id(dist, capi, rank)
+    # RSBA_MG_COMM=shm: the ranks are processes SHARING the visible GPUs, their collectives staged through shared memory (ShmComm,
+    # csrc/ba_comm.hpp) — everything of this worker but the RCCL call itself, on a one-GPU box
+    shm = os.environ.get("RSBA_MG_COMM") == "shm"
+    if shm:
+        import torch
+        local = local % torch.cuda.device_count()
+        box = ["mgw_%d_%s" % (os.getppid(), os.path.basename(out_path).replace(".", "_")) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = ctypes.create_string_buffer(capi.comm_shm_id(box[0]), 128)
+    else:
+        uid = rd.broadcast_unique_id(dist, capi, rank)
     cases, nranks, cams_equal = [], None, True
     for (C, P, k, seed, huber, outl) in [(24, 4000, 8, 11, 0.0, 0.0), (64, 6000, 12, 12, 1.0, 0.05), (8, 3000, 6, 13, 0.0, 0.0)]:
         lo, hi = rd.shard_range(P, rank, world)
@@ -32,11 +42,12 @@ def main():
         problem = capi.Problem.points(shard)
         sv = capi.Solver(problem, o)
         nranks = sv.comm_nranks()
+        kind = sv.schedule_info()["comm_kind"]
         s = sv.run()
         sv.download()
         log = sv.iterations()
         mine = dict(params=np.array(problem.params, copy=True), iters=int(s.num_iterations), stop=int(s.stop_reason), cost=float(s.final_cost),
-                    log=log, nranks=nranks, lo=lo, hi=hi)
+                    log=log, nranks=nranks, lo=lo, hi=hi, kind=kind)
         sv.close()
         problem.close()
         box = [None] * world if rank == 0 else None
@@ -56,9 +67,9 @@ def main():
             cases.append(dict(C=C, P=P, same_iterations=box[0]["iters"] == s_ref.num_iterations, same_stop_reason=box[0]["stop"] == s_ref.stop_reason,
                               same_accept_reject=bool(np.array_equal(box[0]["log"][:, 7], log_ref[:, 7])), max_block_rel=worst,
                               cost_rel=abs(box[0]["cost"] - s_ref.final_cost) / s_ref.final_cost,
-                              nranks=[b["nranks"] for b in box]))
+                              nranks=[b["nranks"] for b in box], comm_kinds=[b["kind"] for b in box]))
     if rank == 0:
-        json.dump(dict(rccl_nranks=cases[-1]["nranks"], camera_blocks_bitwise_equal=cams_equal, cases=cases), open(out_path, "w"))
+        json.dump(dict(rccl_nranks=cases[-1]["nranks"], comm_kinds=cases[-1]["comm_kinds"], camera_blocks_bitwise_equal=cams_equal, cases=cases), open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -109,6 +109,7 @@ def spread(oracle, prob, optkw, ref=None):
 # x 69 points x 2 views, Cauchy: radius 1.2e13 at iterate 19, the oracle's runs part at 25, the HIP path at 22 with a final cost
 # equal to 1.6e-13 — pinned in tests/test_gpu_fuzz.py.)
 RADIUS_CAP = 1e13
+FIRST3_CEILING = 1e-10   # no first-three-iterates bar above this, whatever the oracle's own spread
 
 
 def bars(sp, n_obs):
@@ -119,7 +120,10 @@ def bars(sp, n_obs):
     # the first three iterates' costs: 1e-12 (a defect shows at once, rounding shows late) — or ten times what the oracle's own
     # executions differ by there, on the problems whose FIRST solves already amplify the roundings (points seen by two cameras:
     # nearly singular point blocks; seed-123 sweep, cases 080 / 218 / 289: the oracle's runs 0.8 - 5.7e-12 apart at iterates 1 - 3, the HIP path 1.7 - 6.0e-12 from the oracle)
-    return dict(first3=max(1e-12, 10.0 * sp.get("first3", 0.0)), raw=max(1e-6, 10.0 * sp["raw"]), final_cost=max(1e-2 if parted else 1e-9, 10.0 * sp["final_cost"]),
+    # ... with an ABSOLUTE ceiling of 1e-10 (the relaxed bar was derived from the cases a build had failed; beyond
+    # 1e-10 on the first three iterates nothing the oracle does to itself is an excuse), and tests/test_gpu_fuzz.py asserts that the
+    # relaxed bar stays the rare exception
+    return dict(first3=min(FIRST3_CEILING, max(1e-12, 10.0 * sp.get("first3", 0.0))), raw=max(1e-6, 10.0 * sp["raw"]), final_cost=max(1e-2 if parted else 1e-9, 10.0 * sp["final_cost"]),
                 rms=max(1e-1 if parted else 1e-4, 10.0 * sp["rms"]), same_trajectory=sp["same_trajectory"],
                 # iterates whose costs have to agree to 1e-9: all of them, or — when the oracle's own runs part — the ones up to
                 # three iterations before they do

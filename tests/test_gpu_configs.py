@@ -216,6 +216,67 @@ def test_two_rank_solve_matches_unsharded_oracle(oracle, tmp_path):
         assert case["max_block_rel"] < 1e-6 and case["cost_rel"] < 1e-9, case
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_two_processes_on_one_gpu_match_the_unsharded_oracle(oracle, tmp_path):
+    """The same rank program, two REAL processes (torch.distributed.run, gloo for the plumbing), on whatever GPUs are visible —
+    one is enough: the collectives go through shared memory (ShmComm) instead of ncclAllReduce, which refuses two ranks of a
+    communicator on one device.  Everything else is the multi-process path as an 8-GPU node runs it: one process per rank, the
+    id bootstrap through the process group, the sharded upload, three collectives per LM step, identical decisions."""
+    out = tmp_path / "mg_shm.json"
+    env = dict(os.environ, RSBA_MG_COMM="shm")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "mg_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.loads(out.read_text())
+    assert res["rccl_nranks"] == [2, 2] and res["comm_kinds"] == ["shm", "shm"]
+    assert res["camera_blocks_bitwise_equal"]
+    for case in res["cases"]:
+        assert case["same_iterations"] and case["same_stop_reason"] and case["same_accept_reject"], case
+        assert case["max_block_rel"] < 1e-6 and case["cost_rel"] < 1e-9, case
+
+
+def test_a_dead_rank_ends_the_job_instead_of_hanging_it():
+    """Rank 1 exits behind set-up; rank 0's first collective finds nobody.  The communicator's bounded wait (4 s here) aborts the
+    group and rsba_solver_run returns RSBA_ERR_COMM: the worker leaves with exit code 7 within seconds.  (Over RCCL the same
+    path polls ncclCommGetAsyncError and calls ncclCommAbort: RcclComm::WaitStream — needs two GPUs to run.)"""
+    import time
+    env = dict(os.environ, RSBA_COMM_TIMEOUT_S="4")
+    t0 = time.time()
+    procs = []
+    port = _free_port()
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mg_abort_worker.py")], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert procs[1].returncode == 0, outs[1][-2000:]
+    assert procs[0].returncode == 7, (procs[0].returncode, outs[0][-2000:])
+    assert time.time() - t0 < 120
+
+
+def test_bench_launcher_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's own multi-rank launcher end to end on a one-GPU box: `--gpus 2 --comm shm` starts two fresh rank processes (children,
+    never a re-exec), bootstraps the group, runs the preflight (iteration logs compared bit for bit across the ranks), the timed
+    regions with barrier + max over ranks, and rank 0 prints ONE JSON line that says which schedule ran and what stalled."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "shm", "--config", "cfg2", "--steps", "4", "--warmup", "1",
+                        "--preload", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_nranks"] == 2 and line["comm"] == "shm" and line["steps"] == 4 and line["warmup"] == 1
+    assert line["schedule"] == "sequential" and line["stalls"] == 0 and line["fallbacks"] == 0
+    assert line["preflight"]["logs_bitwise_equal_across_ranks"] is True and line["preflight"]["stalls"] == 0
+    assert line["value"] > 0 and line["scaling"] == "weak"
+
+
 # ------------------------------------------------------------------ internal point order
 @pytest.mark.parametrize("C,P,k,huber", [(24, 6000, 8, 0.0), (40, 9000, 10, 1.0), (70, 5000, 9, 0.0)])
 def test_balanced_point_order_is_internal(oracle, C, P, k, huber, monkeypatch):

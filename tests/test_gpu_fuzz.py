@@ -52,6 +52,10 @@ def test_sweep_is_mostly_held_to_the_baseline_bars():
     strict = [r for i, r in SEEN.items() if i not in sens]
     assert len(sens) <= len(CASES) // 5, sens
     assert all(r["raw"] < 1e-6 and r["final_cost"] <= max(1e-9, r["final_cost_tol"]) and r["rms"] <= 1e-4 and r["same_trajectory"] and r["part"] < 0 for r in strict)
+    # the first-three-iterates bar is the flat 1e-12 in all but a handful of cases (at most one in twenty), never above 1e-10
+    relaxed = [i for i, r in SEEN.items() if r["bars"]["first3"] > 1e-12]
+    assert len(relaxed) <= len(CASES) // 20, relaxed
+    assert all(r["bars"]["first3"] <= 1e-10 for r in SEEN.values())
     # no sensitive case without a robust loss and none with more than six views per point: the phenomenon is the one described
     for i in sens:
         c = CASES[i]

@@ -127,6 +127,31 @@ def test_triangular_payload_adds_the_same_bits(C, P, k, world):
         assert np.array_equal(pa, pb) and np.array_equal(la, lb) and sa.final_cost == sb.final_cost
 
 
+@pytest.mark.parametrize("C,P,k,world", [(40, 1500, 7, 2), (70, 1200, 8, 2)])
+def test_triangular_payload_with_the_atomic_schur_kernel(oracle, C, P, k, world):
+    """schur_impl 0 (k_linearize_schur_ref: also what a shard with duplicate observations runs) fills only the UPPER block triangle
+    of S.  The triangular payload (default above 64 cameras, forced at 40) must then be packed from the mirror elements — read as
+    the lower triangle it carried the memset's zeros and every rank lost the coupling between cameras.
+    Against the full-square payload (sums of atomics: tolerance, not bits) and against the oracle."""
+    whole = syn.make_problem(C, P, k, 640 + C)
+    shards = _shards(C, P, k, 640 + C, world)
+    res = {}
+    os.environ["RSBA_PIPELINE_MG"] = "0"
+    try:
+        for tri in ("0", "1"):
+            os.environ["RSBA_TRI_PAYLOAD"] = tri
+            res[tri] = capi.solve_points_sharded_loopback(shards, dict(schur_impl=0))
+    finally:
+        del os.environ["RSBA_TRI_PAYLOAD"], os.environ["RSBA_PIPELINE_MG"]
+    ref, s_ref, _ = oracle.solve_points(whole, oracle.options(num_threads=_threads()))
+    for tri in ("0", "1"):
+        got = np.concatenate([res[tri][0][0][:6 * C]] + [p[6 * C:] for p, _, _, _ in res[tri]])
+        assert res[tri][0][1].num_iterations == s_ref.num_iterations, tri
+        assert _block_rel(got, ref, C) < 1e-6, tri
+        for p, s, log, nranks in res[tri]:
+            assert nranks == world and np.array_equal(p[:6 * C], res[tri][0][0][:6 * C])
+
+
 def test_a_stall_on_one_rank_is_everybodys_stall(oracle, capfd):
     """Step 2 of rank 1 reports a stalled factorisation (test hook RSBA_TEST_STALL_STEP / _RANK: what an in-kernel wait that ran
     out of its budget leaves in the result block).  The flag travels in the candidate's sum all-reduce, so BOTH ranks repeat the

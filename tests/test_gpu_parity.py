@@ -303,16 +303,24 @@ def test_configure_run_changes_the_next_run_only():
 
 def test_max_solver_time_ends_the_run_like_ceres():
     """Solver::Options::max_solver_time_in_seconds (Ceres' default 1e9; the reference leaves it alone,
-    Main_Calibration/bundle_adjustment_manager.cpp:90-92): checked once per iteration behind the iteration limit — a run whose
-    budget is 0 s ends after its first iteration with NO_CONVERGENCE and the 'Maximum solver time reached' line in the report;
-    the default changes nothing; several ranks refuse a finite limit (each would read its own clock)."""
+    Main_Calibration/bundle_adjustment_manager.cpp:90-92): TrustRegionMinimizer tests it in FRONT of the iteration limit and for
+    the first time right behind iteration 0 (FinalizeIterationAndCheckIfMinimizerCanContinue), against minimiser + preprocessor
+    time — a run whose budget is 0 s returns its start with NO step taken, NO_CONVERGENCE and the 'Maximum solver time reached'
+    line in the report, even when the iteration limit is reached at the same moment; the default changes nothing; several
+    ranks refuse a finite limit (each would read its own clock)."""
     prob = syn.make_problem(24, 2500, 8, seed=78)
     problem = capi.Problem.points(prob)
     fixed = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0)
     sv = capi.Solver(problem, capi.default_options(max_num_iterations=20, max_solver_time_in_seconds=0.0, **fixed))
     s = sv.run()
-    assert (s.termination_type, s.stop_reason, s.num_iterations) == (capi.NO_CONVERGENCE, 8, 1)
-    assert "Maximum solver time reached" in sv.full_report()
+    assert (s.termination_type, s.stop_reason, s.num_iterations) == (capi.NO_CONVERGENCE, 8, 0)
+    assert s.final_cost == s.initial_cost and "Maximum solver time reached" in sv.full_report()
+    sv.download()
+    assert np.array_equal(problem.params, prob["params"]), "a zero budget must leave the start untouched"
+    sv.close()
+    # time is tested before the iteration count: with both exhausted the reason is the time
+    sv = capi.Solver(problem, capi.default_options(max_num_iterations=0, max_solver_time_in_seconds=0.0, **fixed))
+    assert sv.run().stop_reason == 8
     sv.close()
     sv = capi.Solver(problem, capi.default_options(max_num_iterations=6, **fixed))
     assert capi.default_options().max_solver_time_in_seconds == 1e9 and sv.run().num_iterations == 6
