@@ -465,7 +465,6 @@ def main():
     # RCCL prints a version banner through C stdio, which sits in libc's buffer until exit when stdout is a pipe and
     # would land AFTER the JSON line: push it out first so that the JSON is the last line of stdout
     try:
-        import ctypes
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
