@@ -69,6 +69,25 @@ def test_config3_full_size_forced_iterations(oracle):
     _forced_iterations_match(oracle, prob, 3)
 
 
+def test_config3_full_size_to_its_own_termination(oracle):
+    """The benchmark's workload solved with the REFERENCE's tolerances (bundle_adjustment_manager.cpp:90-92 leaves Ceres' defaults:
+    function 1e-6, gradient 1e-10, parameter 1e-8) to its own end, at full size: the STOP decision at 2M observations — which
+    test fires, after how many iterations — the whole iteration log column by column, every camera and point block (1e-6) and the
+    RMS (1e-4 px) against the oracle.  (Round 4 compared three forced iterations only.)"""
+    prob = syn.make_config("cfg3")
+    ref, s_ref, log_ref = oracle.solve_points(prob, oracle.options(num_threads=_threads()))
+    got, s_got, log_got = capi.solve_points(prob)
+    assert (s_got.termination_type, s_got.stop_reason, s_got.num_iterations) == (s_ref.termination, s_ref.stop_reason, s_ref.num_iterations)
+    assert s_ref.termination == 0 and s_ref.num_iterations >= 3, "the run is expected to converge on a tolerance"
+    assert (s_got.num_successful_steps, s_got.num_unsuccessful_steps) == (s_ref.num_successful_steps, s_ref.num_unsuccessful_steps)
+    _full_log_matches(log_got, log_ref)
+    assert abs(s_got.final_cost - s_ref.final_cost) < 1e-10 * s_ref.final_cost
+    assert _block_rel(got, ref, prob["C"]) < 1e-6
+    ss_ref = oracle.points_cost(prob, ref, num_threads=_threads())[1]
+    ss_got = oracle.points_cost(prob, got, num_threads=_threads())[1]
+    assert abs(np.sqrt(ss_ref / (2 * prob["N"])) - np.sqrt(ss_got / (2 * prob["N"]))) < 1e-4
+
+
 def test_config4_shard_forced_iterations(oracle):
     """BASELINE.json configs[3]: 64 cams x 1M points over 8 GPUs -> rank 3's shard, 125k points, 2.5M observations."""
     C, P, k, seed, outl, huber = syn.CONFIGS["cfg4"]
