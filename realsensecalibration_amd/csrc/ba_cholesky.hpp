@@ -79,6 +79,16 @@ struct PanelSource {
 // state the host returns, and an accepted-step factorisation would have written its candidate over it: before it writes anything
 // the kernel saves x's cameras and constants (cam_backup: 6 C, camc_backup: C x CC_STRIDE doubles), and the host puts them back
 // when it lets such a step run out unused (DrainAhead).
+// Experimental paths (measured slower than, or worth nothing over, the defaults; HISTORY.md round 4) are compiled in only with
+// -DRSBA_EXPERIMENTAL (tools/build_variant.sh exp -DRSBA_EXPERIMENTAL): the step launched ahead on the device's decision
+// (RSBA_LAUNCH_AHEAD), the tiled factorisation gated beside the Schur kernel above 64 cameras (RSBA_PIPELINE_TILES: hung the
+// suite once), the round-robin factorisation (RSBA_CHOL_DIAG=0).  RSBA_EXP(cond): `cond` there, a compile-time false in the
+// product — the kernels do not carry the code.
+#ifdef RSBA_EXPERIMENTAL
+#define RSBA_EXP(cond) (cond)
+#else
+#define RSBA_EXP(cond) (false)
+#endif
 struct AheadSel {
   const double* dec = nullptr;
   double seq = 0.0;

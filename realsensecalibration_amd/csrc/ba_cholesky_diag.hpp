@@ -440,7 +440,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   if (gate.trace && tid == 0 && w == 0) gate.trace[0] = wall_clock64();
   AnnounceResident(gate);
   bool stalled = false;
-  if (ahead.dec != nullptr) {
+  if (RSBA_EXP(ahead.dec != nullptr)) {
     // launched ahead: the previous step's decision (see AheadSel).  One lane polls, asleep in between; never hang.
     __shared__ int s_dec_ok;
     if (tid == 0) {

@@ -235,6 +235,7 @@ __device__ __forceinline__ double* BackSubstituteBlocksWaves(int n, double* __re
   return xs;
 }
 
+#ifdef RSBA_EXPERIMENTAL   // the round-robin factorisation (RSBA_CHOL_DIAG=0): superseded by ba_cholesky_diag.hpp, which keeps this file's helpers
 __global__ void __launch_bounds__(512)
 k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, double* __restrict__ A, double* __restrict__ scale_c,
                              const double* __restrict__ cam_x, double* __restrict__ cam_c, const double* __restrict__ intr,
@@ -788,6 +789,7 @@ k_reduced_system_solve_multi(int C, double* __restrict__ red, RedLayout L, doubl
   if (gate.trace && tid == 0) gate.trace[15] = wall_clock64();
   SolveDone(gate);
 }
+#endif   // RSBA_EXPERIMENTAL
 
 // n = the padded dimension
 __host__ __device__ inline int MultiCholPadded(int nc) { return (nc + RSBA_PB - 1) / RSBA_PB * RSBA_PB; }

@@ -538,7 +538,7 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
   const int r0 = 64 * I, c0 = 64 * J;
   // "every tile is resident" (pipelined schedule, first step of a run): counted by EVERY workgroup of the launch, also the one
   // that has nothing to do
-  if (gate.ready != nullptr && tid == 0 && gate.started_host != nullptr &&
+  if (RSBA_EXP(gate.ready != nullptr) && tid == 0 && gate.started_host != nullptr &&
       __hip_atomic_fetch_add(gate.started_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gate.started_need - 1) {
     __hip_atomic_store(gate.started_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(gate.started_host, gate.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -566,10 +566,10 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
   }
   // (gated = beside the Schur kernel, whose hit loops run at priority 0: the factorisation is a latency chain of a few instructions
   //  between trips to memory — served first)
-  if (gate.ready != nullptr) __builtin_amdgcn_s_setprio(3);
+  if (RSBA_EXP(gate.ready != nullptr)) __builtin_amdgcn_s_setprio(3);
   bool gate_stalled = false;
   int stall_code = 1;   // what RES_STALL carries: 1 a hand-over inside the factorisation, 2 the wait for every camera's diag U, 10 + g the wait for stage g
-  if (gate.ready != nullptr) {
+  if (RSBA_EXP(gate.ready != nullptr)) {
     const long long gb = gate.budget > 0 ? gate.budget : RSBA_STALL_TICKS;
     const long long tw0 = wall_clock64();
     if (gate.all_diag != nullptr && !WaitStageCoarseWG(gate.all_diag, gate.tag, f.error, gb)) { gate_stalled = true; stall_code = 2; }
@@ -621,7 +621,7 @@ k_chol_tiles_persistent(int n, const double* __restrict__ W /* (n + 1) x n: scal
   if (I == 0 && J == 0 && tid == 0) { __hip_atomic_store(ok_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); res[RES_STALL] = 0.0; }   // (a stall, half a second later, sets it)
   __syncthreads();
   // (gated: a tile waits for tiles that wait for stages — the budget of a hand-over covers a stage's wait as well)
-  const long long budget = gate.ready != nullptr ? 3 * RSBA_STALL_TICKS : RSBA_STALL_TICKS;
+  const long long budget = RSBA_EXP(gate.ready != nullptr) ? 3 * RSBA_STALL_TICKS : RSBA_STALL_TICKS;
   const TileCtx ctx{n, m, np, I, J, tag, F, ok_flag, f, budget};
   bool stalled = gate_stalled;
   const int plast = min(2 * J + 1, np - 1);

@@ -60,40 +60,21 @@ class KernelTimer;
 
 // A segment is a range of 64-point mask words of one tile (not necessarily chunk-aligned: small problems get as many
 // workgroups as they have words).
-// Up to 64 cameras the pair segments walk STATIC hit lists (PairSegmentListed): a segment's point range is cut into blocks of at
-// most RSBA_CHUNK points and at most RSBA_LIST_TRIPS hits per lane; a block's four wavefronts each have a lane-interleaved list
-// (row n = the n-th hit of each of the 64 lanes: the point's index in the block, RSBA_LIST_NONE where a lane has none left).
-#define RSBA_LIST_TRIPS 66     // rows of a wavefront's list that fit in LDS beside the block's point records (two workgroups per CU)
-#define RSBA_LIST_NONE 512u    // "no hit": index of the spare record behind the block's 512
-struct PairBlk {
-  int word0, nwords;           // the block's 64-point mask words
-  unsigned off0, off1, off2, off3;   // first row of each wavefront's list (rows of 64 entries, in TiledSchur::hl)
-  unsigned trips01, trips23;         // rows per wavefront, 16 bits each (even numbers: the hit loop takes two rows per round)
-  // (named fields, not arrays: with arrays the compiler turned the kernel's per-wavefront selects back into an indexed load, which
-  //  needs the entry in memory — scratch)
-  __host__ __device__ unsigned& off(int wv) { return wv == 0 ? off0 : wv == 1 ? off1 : wv == 2 ? off2 : off3; }
-};
 struct SchurSeg {
   int ga, gb, word_begin, word_end, self;
   // in-kernel reduction tree of the pair tiles: segment -> group of RSBA_GRP consecutive segments -> tile -> stage
   int tile, grp, grp_seg0, grp_nseg, tile_grp0, tile_ngrp, stage, stage_ntiles, nred, index, pad2;
   // index: the entry's own number (segs_ordered, the copy in launch order, is what the kernel reads: one load per ticket)
   // self: 0 pair segment, 1 self segment, 2 / 3 reducer of a pair / self tile (word_begin..word_end = its components)
-  int blk_begin, nblk;         // listed pair segments: the segment's blocks in TiledSchur::pblk ...
-  PairBlk blk0;                // ... and a copy of the first (nearly always the only) one: no second dependent load per entry
 };
-// An entry of the work list, field by field into scalar registers.  (Copied as a struct, the 104 bytes went through vector
+// An entry of the work list, field by field into scalar registers.  (Copied as a struct, the entry went through vector
 // registers into SCRATCH and were read back from there field by field — and a kernel that uses scratch at all pays for it in
 // the launch latency of every workgroup: end of an entry -> start of the next on its slot 7.6 instead of 6.1 us.)
 __device__ __forceinline__ SchurSeg LoadSeg(const SchurSeg* __restrict__ p) {
   SchurSeg s;
 #define RSBA_F(f) s.f = __builtin_amdgcn_readfirstlane(p->f)
   RSBA_F(ga); RSBA_F(gb); RSBA_F(word_begin); RSBA_F(word_end); RSBA_F(self); RSBA_F(tile); RSBA_F(grp); RSBA_F(grp_seg0); RSBA_F(grp_nseg);
-  RSBA_F(tile_grp0); RSBA_F(tile_ngrp); RSBA_F(stage); RSBA_F(stage_ntiles); RSBA_F(nred); RSBA_F(index); RSBA_F(pad2); RSBA_F(blk_begin); RSBA_F(nblk);
-  RSBA_F(blk0.word0); RSBA_F(blk0.nwords);
-#undef RSBA_F
-#define RSBA_F(f) s.f = (unsigned)__builtin_amdgcn_readfirstlane((int)p->f)
-  RSBA_F(blk0.off0); RSBA_F(blk0.off1); RSBA_F(blk0.off2); RSBA_F(blk0.off3); RSBA_F(blk0.trips01); RSBA_F(blk0.trips23);
+  RSBA_F(tile_grp0); RSBA_F(tile_ngrp); RSBA_F(stage); RSBA_F(stage_ntiles); RSBA_F(nred); RSBA_F(index); RSBA_F(pad2);
 #undef RSBA_F
   return s;
 }
@@ -147,11 +128,6 @@ struct TiledSchur {
   unsigned *hits = nullptr, *hit_off = nullptr;
   int* hit_trips = nullptr;
   size_t hit_entries = 0;
-  // up to 64 cameras: the listed pair segments' blocks and hit lists (PairSegmentListed); nullptr: the masks are searched
-  PairBlk* pblk = nullptr;
-  unsigned short* hl = nullptr;
-  size_t hl_rows = 0;
-  int BuildPairLists(const std::vector<unsigned long long>& mask, std::vector<SchurSeg>& sg);
 
   int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
             const std::vector<int>& sliced_q /* sliced slot -> CSR position, -1 pads */, bool staged);
@@ -791,9 +767,6 @@ struct SchurArgs {
   const unsigned* __restrict__ hits;       // [entry][3]: point, camera-major observation index on the a side, on the b side
   const unsigned* __restrict__ hit_off;    // [pair segment][4 waves]: first entry of the wave's list (64 entries per trip, lane-interleaved)
   const int* __restrict__ hit_trips;       // [pair segment][4 waves]: trips = the longest of the wave's 64 lists
-  // up to 64 cameras: the listed pair segments (PairSegmentListed); nullptr: the masked search (PairSegment)
-  const PairBlk* __restrict__ pblk;
-  const unsigned short* __restrict__ hl;
   // launched AHEAD (queued behind the previous step's last kernel and the damping kernel, before the host knew that step's
   // outcome): the state is the device's decision (LmNext, ba_point_kernels.hpp) — dec[1] != 0: the previous step was accepted,
   // the camera constants and sqrt(rho') are the candidate's (the `_alt` pointers).  nullptr: the host chose
@@ -1034,207 +1007,6 @@ __device__ __forceinline__ void PairSegmentSparse(const SchurArgs& a, const Schu
       for (int i = 0; i < 36; ++i) acc[i] += pt[i * 128 + tid];
     }
   }
-  double* out = SegmentOut(sg, partial, a.grp_sum, seg_index);
-  if (!diag_tile || tid < 120) {
-#pragma unroll
-    for (int i = 0; i < 36; ++i) __hip_atomic_store(&out[i * 256 + pr], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (a.wg_trace && tid == 0) a.wg_trace[3 * ticket + 2] = wall_clock64();
-  double v[36];
-  if (!GroupReduce<36>(sg, partial, a.grp_sum, a.sync_cnt, a.ngrp, v, a.grp_flag, a.epoch)) return;
-  FinishPairSlot(C, sg.ga, sg.gb, tid, v, camc, a.red, a.L, a.cam_free);
-  if (!StageArrive(sg, a.sync_cnt, a.ngrp, a.ntiles, a.tag != 0)) return;
-  if (tid == 0 && a.tag) PublishStage(a.ready + 1 + sg.stage, a.tag);
-  if (a.trace && tid == 0 && sg.stage < 7) a.trace[17 + sg.stage] = wall_clock64();
-}
-
-// ------------------------------------------------------------------------------------------------
-// Pair segment up to 64 cameras: LISTED (round 4).  Which points a camera pair shares never changes, so PairSegment's search — per
-// hit a find-first-set on the AND of two mask words, a cursor of (word, remaining bits) per lane, and, whenever ANY lane of the
-// wavefront runs out of bits in its word (nearly every trip), a divergent inner loop of two LDS reads and a wait — is done once, at
-// set-up (TiledSchur::BuildPairLists): per block of a segment (<= 512 points, <= RSBA_LIST_TRIPS hits per lane) and wavefront a
-// lane-interleaved list of 16-bit point indices, staged into LDS with the block's point records.  The hit loop is then: read the
-// lane's next-but-one index, fetch the NEXT hit's point record (five ds_read_b128 from 80-byte records: X, the damped inverse
-// block, one pad) while this hit's arithmetic runs, and PairHit — ~185 vector instructions per trip instead of ~225, and neither
-// LDS round trip of the old loop (cursor, then record, then arithmetic) is on the lane's critical path.  Same hits in the same
-// order with the same arithmetic as PairSegment: the same bits (RSBA_LISTED=0 runs the masked search; the tests compare them).
-// The camera constants are loaded straight into registers (the compiler hoisted them out of the loop anyway; their 4 KB of LDS
-// are list rows now).  kLoss: the rank of the point in either camera's observation list (-> sqrt(rho')) from the block's mask
-// words and prefix counts in LDS, fetched one trip ahead as well.
-// ------------------------------------------------------------------------------------------------
-#define RSBA_LPT 10                                             // doubles per point record in LDS: X(3), damped inverse block (6), pad
-#define RSBA_LPT_BYTES ((RSBA_CHUNK + 1) * RSBA_LPT * 8)        // 513 records (the last one is where RSBA_LIST_NONE points)
-#define RSBA_LIST_ROWS (RSBA_LIST_TRIPS + 2)                    // two rows of RSBA_LIST_NONE behind a list: the loop reads two trips ahead
-#define RSBA_LISTED_LDS(loss) (RSBA_LPT_BYTES + ((loss) ? 3072 : 0) + 4 * RSBA_LIST_ROWS * 128)
-template <bool kLoss, bool kSmall>
-__device__ __forceinline__ void PairSegmentListed(const SchurArgs& a, const SchurSeg& sg, int seg_index, int ticket, char* lds, int b0_word0, int b0_nwords,
-                                                  unsigned b0_off0, unsigned b0_off1, unsigned b0_off2, unsigned b0_off3, unsigned b0_trips01, unsigned b0_trips23) {
-  // (the first block's descriptor comes as scalars, not as sg.blk0: read through the reference, the per-wavefront selects below
-  //  became an indexed load of the entry, which then had to live in memory — scratch)
-  const int C = a.C, P = a.P, nwords = a.nwords;
-  const double* __restrict__ camc = a.camc;
-  const double* __restrict__ ptdata = a.ptdata;
-  const double* __restrict__ sq_cm = a.sq_cm;
-  double* __restrict__ partial = a.partial;
-  double* pt = reinterpret_cast<double*>(lds);
-  unsigned long long (*mk)[RSBA_CW] = reinterpret_cast<unsigned long long (*)[RSBA_CW]>(lds + RSBA_LPT_BYTES);   // kLoss only
-  int (*pre)[RSBA_CW] = reinterpret_cast<int (*)[RSBA_CW]>(lds + RSBA_LPT_BYTES + 2048);                         // kLoss only
-  unsigned short* hl = reinterpret_cast<unsigned short*>(lds + RSBA_LPT_BYTES + (kLoss ? 3072 : 0));
-  const int tid = OpaqueTid(), ln = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool diag_tile = sg.ga == sg.gb;
-  // lane -> pair as in PairSegment: off-diagonal tile lane = (ia, ib); diagonal tile: the 120 pairs ia < ib in lanes 0..119 of BOTH
-  // halves of the workgroup, the halves split the hits by the parity of the point's mask word within the segment
-  const int dt = diag_tile ? (tid & 127) : tid;
-  const int pr = diag_tile ? (dt < 120 ? kDiagPair[dt] : 0) : tid;
-  const int ia = pr >> 4, ib = pr & 15;
-  const int cam_a = RSBA_TG * sg.ga + ia, cam_b = RSBA_TG * sg.gb + ib;
-  double ca[15], cb[15];
-  {
-    const double* pa = camc + (size_t)(cam_a < C ? cam_a : 0) * CC_STRIDE;
-    const double* pb = camc + (size_t)(cam_b < C ? cam_b : 0) * CC_STRIDE;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { ca[i] = pa[CC_R + i]; cb[i] = pb[CC_R + i]; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { ca[9 + i] = pa[CC_T + i]; cb[9 + i] = pb[CC_T + i]; }
-    ca[12] = pa[CC_FX]; ca[13] = pa[CC_FY]; cb[12] = pb[CC_FX]; cb[13] = pb[CC_FY];
-    ca[14] = kSmall ? pa[CC_SMALL] : 0.0; cb[14] = kSmall ? pb[CC_SMALL] : 0.0;
-  }
-  // Staging of a block: its point records and this wavefront's list, every load in flight before the first LDS store (one round
-  // trip).  The first block is staged BEFORE the accumulators exist (72 registers the staging loads can use: staged inside the
-  // block loop, the first version spilled 117 registers around it); a segment has more than one block only on large or dense
-  // problems.
-  int ntrip = 0;
-  {
-    const int wb = b0_word0, nwc = b0_nwords;
-    const int j0 = wb * 64;
-    const int np = max(0, min(nwc * 64, P - j0));
-    const unsigned tr01 = b0_trips01, tr23 = b0_trips23;
-    ntrip = (int)(wv == 0 ? (tr01 & 0xffffu) : wv == 1 ? (tr01 >> 16) : wv == 2 ? (tr23 & 0xffffu) : (tr23 >> 16));
-    const unsigned off = wv == 0 ? b0_off0 : wv == 1 ? b0_off1 : wv == 2 ? b0_off2 : b0_off3;
-    constexpr int kPtPerThread = RSBA_CHUNK * RSBA_PT_STRIDE / 256;
-    double pv[kPtPerThread];
-#pragma unroll
-    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; pv[u] = i < np * RSBA_PT_STRIDE ? ptdata[(size_t)j0 * RSBA_PT_STRIDE + i] : 0.0; }
-    constexpr int kPieces = (RSBA_LIST_TRIPS * 8 + 63) / 64;   // 16-byte pieces of a list per lane
-    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.hl + (size_t)off * 64);
-    uint4 lp[kPieces];
-#pragma unroll
-    for (int k = 0; k < kPieces; ++k) { const int pc = ln + 64 * k; lp[k] = pc < ntrip * 8 ? src[pc] : make_uint4(0u, 0u, 0u, 0u); }
-    unsigned long long mv = 0ull; int pv_i = 0;
-    if (kLoss) {
-      const int row = tid >> 3, w = tid & 7;  // 32 rows x 8 words = 256 threads
-      const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
-      const bool in = cam < C && w < nwc;
-      mv = in ? a.cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
-      pv_i = in ? a.cam_ptr[cam] + a.cam_prefix[(size_t)cam * nwords + (size_t)wb + w] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < kPtPerThread; ++u) {
-      const int i = tid + 256 * u, j = i / RSBA_PT_STRIDE, e = i - j * RSBA_PT_STRIDE;
-      if (i < np * RSBA_PT_STRIDE && e < 9) pt[j * RSBA_LPT + e] = pv[u];
-    }
-    uint4* dst = reinterpret_cast<uint4*>(hl + wv * (RSBA_LIST_ROWS * 64));
-#pragma unroll
-    for (int k = 0; k < kPieces; ++k) { const int pc = ln + 64 * k; if (pc < ntrip * 8) dst[pc] = lp[k]; }
-    hl[wv * (RSBA_LIST_ROWS * 64) + ntrip * 64 + ln] = (unsigned short)RSBA_LIST_NONE;
-    hl[wv * (RSBA_LIST_ROWS * 64) + (ntrip + 1) * 64 + ln] = (unsigned short)RSBA_LIST_NONE;
-    if (kLoss) { mk[tid >> 3][tid & 7] = mv; pre[tid >> 3][tid & 7] = pv_i; }
-    __syncthreads();
-  }
-  double acc[36];
-#pragma unroll
-  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-#pragma unroll 1
-  for (int bi = 0;;) {
-    const unsigned short* myl = hl + wv * (RSBA_LIST_ROWS * 64) + ln;
-    // rank of point `idx` of the block in the observation list of the camera of mask row `row` (-> its sqrt(rho'))
-    auto sq_of = [&](unsigned idx, int row) -> double {
-      const unsigned ic = idx < (unsigned)RSBA_CHUNK ? idx : 0u;
-      const unsigned long long below = (1ull << (ic & 63u)) - 1ull;
-      return sq_cm[pre[row][ic >> 6] + __popcll(mk[row][ic >> 6] & below)];
-    };
-    RSBA_PRIO(0);
-    unsigned iA = myl[0], iB = myl[64];
-    double PA[9], PB[9], sA[2] = {1.0, 1.0}, sB[2] = {1.0, 1.0};
-    {
-      const double* pd = pt + iA * RSBA_LPT;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) PA[i] = pd[i];
-      if (kLoss) { sA[0] = sq_of(iA, ia); sA[1] = sq_of(iA, RSBA_TG + ib); }
-    }
-#pragma unroll 1
-    for (int n = 0; n < ntrip; n += 2) {
-      {
-        const double* pd = pt + iB * RSBA_LPT;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) PB[i] = pd[i];
-        if (kLoss) { sB[0] = sq_of(iB, ia); sB[1] = sq_of(iB, RSBA_TG + ib); }
-      }
-      const unsigned iA2 = myl[(n + 2) * 64];
-      if (iA != RSBA_LIST_NONE) PairHit<kSmall>(ca, cb, PA, PA[3], PA[4], PA[5], PA[6], PA[7], PA[8], sA[0], sA[1], acc);
-      iA = iA2;
-      {
-        const double* pd = pt + iA * RSBA_LPT;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) PA[i] = pd[i];
-        if (kLoss) { sA[0] = sq_of(iA, ia); sA[1] = sq_of(iA, RSBA_TG + ib); }
-      }
-      const unsigned iB2 = myl[(n + 3) * 64];
-      if (iB != RSBA_LIST_NONE) PairHit<kSmall>(ca, cb, PB, PB[3], PB[4], PB[5], PB[6], PB[7], PB[8], sB[0], sB[1], acc);
-      iB = iB2;
-    }
-    RSBA_PRIO(3);
-    if (++bi >= sg.nblk) break;
-    __syncthreads();   // (every wavefront is through with the block's records and lists)
-    {
-      // a later block of a long segment (large or dense problems only): staged with plain loops — the accumulators and both
-      // cameras' constants are live here, and the first block's form (every load in a register before the first store: 84
-      // registers) spilled 65 registers into scratch, which every dispatch of the kernel then pays for in launch latency
-      // (end of an entry -> start of the next on its slot: 7.6 against 6.1 us)
-      const PairBlk blk = a.pblk[sg.blk_begin + bi];
-      const int tid2 = OpaqueTid(), ln2 = tid2 & 63;
-      const int j0 = blk.word0 * 64;
-      const int np = max(0, min(blk.nwords * 64, P - j0));
-      const unsigned tr01 = blk.trips01, tr23 = blk.trips23;
-      ntrip = (int)(wv == 0 ? (tr01 & 0xffffu) : wv == 1 ? (tr01 >> 16) : wv == 2 ? (tr23 & 0xffffu) : (tr23 >> 16));
-      const unsigned off = wv == 0 ? blk.off0 : wv == 1 ? blk.off1 : wv == 2 ? blk.off2 : blk.off3;
-#pragma unroll 4
-      for (int i = tid2; i < np * RSBA_PT_STRIDE; i += 256) {
-        const int j = i / RSBA_PT_STRIDE, e = i - j * RSBA_PT_STRIDE;
-        const double v = ptdata[(size_t)j0 * RSBA_PT_STRIDE + i];
-        if (e < 9) pt[j * RSBA_LPT + e] = v;
-      }
-      const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.hl + (size_t)off * 64);
-      uint4* dst = reinterpret_cast<uint4*>(hl + wv * (RSBA_LIST_ROWS * 64));
-#pragma unroll 2
-      for (int pc = ln2; pc < ntrip * 8; pc += 64) dst[pc] = src[pc];
-      hl[wv * (RSBA_LIST_ROWS * 64) + ntrip * 64 + ln2] = (unsigned short)RSBA_LIST_NONE;
-      hl[wv * (RSBA_LIST_ROWS * 64) + (ntrip + 1) * 64 + ln2] = (unsigned short)RSBA_LIST_NONE;
-      if (kLoss) {
-        const int row = tid2 >> 3, w = tid2 & 7;
-        const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
-        const bool in = cam < C && w < blk.nwords;
-        mk[row][w] = in ? a.cam_mask[(size_t)cam * nwords + (size_t)blk.word0 + w] : 0ull;
-        pre[row][w] = in ? a.cam_ptr[cam] + a.cam_prefix[(size_t)cam * nwords + (size_t)blk.word0 + w] : 0;
-      }
-      __syncthreads();
-    }
-  }
-  if (diag_tile) {
-    // odd-word half (waves 2/3) -> LDS -> even-word half; the record buffer is free once every lane has left the hit loop
-    __syncthreads();
-    if (tid >= 128 && dt < 120) {
-#pragma unroll
-      for (int i = 0; i < 36; ++i) pt[i * 128 + dt] = acc[i];
-    }
-    __syncthreads();
-    if (tid < 120) {
-#pragma unroll
-      for (int i = 0; i < 36; ++i) acc[i] += pt[i * 128 + tid];
-    }
-  }
-  // slot of pair (ia, ib) in the workgroup's partial block is ia*16+ib whatever lane computed it
   double* out = SegmentOut(sg, partial, a.grp_sum, seg_index);
   if (!diag_tile || tid < 120) {
 #pragma unroll
@@ -1650,11 +1422,10 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
 // kSparse: the instance for more than 64 cameras (PairSegmentSparse instead of PairSegment) — a kernel of its own: compiled into
 // one kernel beside the masked search, the sparse path cost the 64-camera kernel 50 us (284 -> 337 us: the same registers, but
 // more scalar spills and a longer hot loop around the same arithmetic)
-// kMode: RSBA_PAIRS_MASKED / _SPARSE / _LISTED — which pair segment the instance holds (one each: compiled into one kernel beside
+// kMode: RSBA_PAIRS_MASKED / _SPARSE — which pair segment the instance holds (one each: compiled into one kernel beside
 // another, a pair segment costs the other registers, scalar spills and a longer hot loop)
 #define RSBA_PAIRS_MASKED 0
 #define RSBA_PAIRS_SPARSE 1
-#define RSBA_PAIRS_LISTED 2
 #define RSBA_SCHUR_LDS_BYTES 80992   // two workgroups per CU: 2 x (this + the few static words below) <= 160 KB
 template <bool kLoss, int kMode>
 __global__ void __launch_bounds__(256, 2)
@@ -1664,10 +1435,9 @@ k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const
   //  (-mllvm -amdgpu-kernarg-preload-count=16), a structure passed by value is not among them, and the ticket used to wait for
   //  a scalar load of its own address)
   // One raw LDS buffer, carved by the entry's role: masked / sparse pair segments and self segments: chunk records 48 KB | mask
-  // rows 2 KB | camera constants 4 KB | self tiles: a camera's points of the chunk 16 KB | 16 counters; listed pair segments:
-  // 513 records of 80 bytes | (loss: mask rows, prefix counts) | four lists (PairSegmentListed)
+  // rows 2 KB | camera constants 4 KB | self tiles: a camera's points of the chunk 16 KB | 16 counters
   __shared__ __attribute__((aligned(16))) char lds_raw[RSBA_SCHUR_LDS_BYTES];
-  static_assert(RSBA_LISTED_LDS(true) <= RSBA_SCHUR_LDS_BYTES && RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK + 64 <= RSBA_SCHUR_LDS_BYTES, "LDS carve");
+  static_assert(RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK + 64 <= RSBA_SCHUR_LDS_BYTES, "LDS carve");
   static_assert(2 * (RSBA_SCHUR_LDS_BYTES + 256) <= 160 * 1024, "two workgroups per CU");
   constexpr bool kSparse = kMode == RSBA_PAIRS_SPARSE;
   double* pt = reinterpret_cast<double*>(lds_raw);
@@ -1700,7 +1470,7 @@ k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const
   // So: priority 3 outside the hit loops, 0 inside (RSBA_PRIO() compiles to s_setprio).
   RSBA_PRIO(3);
   if (threadIdx.x == 0) s_small = __hip_atomic_load(small_flag_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.dec != nullptr && a.dec[1] != 0.0) { a.camc = a.camc_alt; a.sq_cm = a.sq_cm_alt; }   // (uniform: scalar loads beside the ticket's round trip)
+  if (RSBA_EXP(a.dec != nullptr) && a.dec[1] != 0.0) { a.camc = a.camc_alt; a.sq_cm = a.sq_cm_alt; }   // (uniform: scalar loads beside the ticket's round trip)
   for (;;) {
     if (threadIdx.x == 0) s_ticket = (int)((unsigned)__hip_atomic_fetch_add(ticket_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base);
     __syncthreads();
@@ -1718,10 +1488,6 @@ k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const
       if (kSparse) {
         if (s_small) PairSegmentSparse<kLoss, true>(a, sg, seg_index, b, pt, sc);
         else PairSegmentSparse<kLoss, false>(a, sg, seg_index, b, pt, sc);
-      } else if (kMode == RSBA_PAIRS_LISTED) {
-        const PairBlk& k0 = sg.blk0;
-        if (s_small) PairSegmentListed<kLoss, true>(a, sg, seg_index, b, lds_raw, k0.word0, k0.nwords, k0.off0, k0.off1, k0.off2, k0.off3, k0.trips01, k0.trips23);
-        else PairSegmentListed<kLoss, false>(a, sg, seg_index, b, lds_raw, k0.word0, k0.nwords, k0.off0, k0.off1, k0.off2, k0.off3, k0.trips01, k0.trips23);
       } else if (s_small) PairSegment<kLoss, true>(a, sg, seg_index, b, pt, mk, sc);
       else PairSegment<kLoss, false>(a, sg, seg_index, b, pt, mk, sc);
     }

@@ -687,13 +687,6 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     HIPCHK(hipMemcpy(u_cm, ucm.data(), ucm.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(v_cm, vcm.data(), vcm.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  {
-    // (opt-in, RSBA_LISTED=1: measured SLOWER than the masked search at 64 cameras x 100k points — 270 against 257 us, HISTORY.md —
-    //  although its hit loop is 6 % shorter; kept because its host-built lists are an independent enumeration of the hits the
-    //  device's bit search finds: tests/test_gpu_switches.py holds the two to the same bits)
-    static const bool listed_on = getenv("RSBA_LISTED") && atoi(getenv("RSBA_LISTED")) != 0;
-    if (listed_on && !sparse && nseg_pair > 0 && (rc = BuildPairLists(mask, sg))) return rc;
-  }
   HIPCHK(hipMemset(sync_cnt, 0, (size_t)nsync * sizeof(int)));
   HIPCHK(hipMemset(grp_flag, 0, (size_t)std::max(ngrp, 1) * sizeof(int)));
   HIPCHK(hipMemset(tree_error, 0, 2 * sizeof(int)));   // [0] error flag, [1] ticket counter of the Schur kernel
@@ -791,102 +784,10 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   return RSBA_OK;
 }
 
-// The static hit lists of the pair segments up to 64 cameras (PairSegmentListed, ba_schur_tiled.hpp).  A segment's words are cut
-// into blocks the way PairSegment cuts them into chunks (RSBA_CW words from the segment's first word on); a block whose busiest
-// lane has more than RSBA_LIST_TRIPS hits (dense visibility: 8 cameras that all see every point share 512 points per chunk) is
-// halved until it fits — a single word holds at most 64.  Lane -> pair and, on diagonal tiles, half -> word parity as in the
-// kernel; a lane's hits in ascending point order, as the masked search finds them.
-int TiledSchur::BuildPairLists(const std::vector<unsigned long long>& mask, std::vector<SchurSeg>& sg) {
-  const auto t0 = std::chrono::steady_clock::now();
-  std::vector<PairBlk> blks;
-  std::vector<unsigned short> rows;   // [row][64]
-  size_t nhits = 0;
-  unsigned char dpair[128];
-  { int t = 0; for (int x = 0; x < 16; ++x) for (int y = x + 1; y < 16; ++y) dpair[t++] = (unsigned char)(x * 16 + y); for (; t < 128; ++t) dpair[t] = 0; }
-  for (int q = 0; q < nseg; ++q) {
-    SchurSeg& e = sg[q];
-    if (e.self != 0) continue;
-    const bool diag = e.ga == e.gb;
-    // the two mask rows and the word parity (diagonal tiles) of thread tid; false: the lane owns no pair
-    auto lane = [&](int tid, const unsigned long long** ma, const unsigned long long** mb, int* parity) {
-      int pr = tid; *parity = -1;
-      if (diag) { const int dt = tid & 127; if (dt >= 120) return false; pr = dpair[dt]; *parity = tid >> 7; }
-      const int ca = RSBA_TG * e.ga + (pr >> 4), cb = RSBA_TG * e.gb + (pr & 15);
-      if (ca >= C || cb >= C) return false;
-      *ma = &mask[(size_t)ca * nwords]; *mb = &mask[(size_t)cb * nwords];
-      return true;
-    };
-    e.blk_begin = (int)blks.size();
-    std::function<void(int, int)> emit = [&](int w0, int w1) {
-      unsigned cnt[256];
-      unsigned trips[4] = {0, 0, 0, 0};
-      for (int tid = 0; tid < 256; ++tid) {
-        const unsigned long long *ma, *mb; int parity;
-        unsigned c = 0;
-        if (lane(tid, &ma, &mb, &parity))
-          for (int w = w0; w < w1; ++w) if (parity < 0 || ((w - e.word_begin) & 1) == parity) c += (unsigned)__builtin_popcountll(ma[w] & mb[w]);
-        cnt[tid] = c; trips[tid >> 6] = std::max(trips[tid >> 6], c);
-      }
-      if (*std::max_element(trips, trips + 4) > RSBA_LIST_TRIPS && w1 - w0 > 1) { const int mid = (w0 + w1) / 2; emit(w0, mid); emit(mid, w1); return; }
-      PairBlk b; memset(&b, 0, sizeof(b));
-      b.word0 = w0; b.nwords = w1 - w0;
-      for (int wv = 0; wv < 4; ++wv) {
-        const unsigned tr = (trips[wv] + 1u) & ~1u;   // two rows per round of the hit loop
-        b.off(wv) = (unsigned)(rows.size() / 64);
-        (wv < 2 ? b.trips01 : b.trips23) |= tr << (16 * (wv & 1));
-        rows.resize(rows.size() + (size_t)tr * 64, (unsigned short)RSBA_LIST_NONE);
-        for (int l = 0; l < 64; ++l) {
-          const int tid = wv * 64 + l;
-          const unsigned long long *ma, *mb; int parity;
-          if (!cnt[tid] || !lane(tid, &ma, &mb, &parity)) continue;
-          size_t r = (size_t)b.off(wv) * 64 + l;
-          for (int w = w0; w < w1; ++w) {
-            if (parity >= 0 && ((w - e.word_begin) & 1) != parity) continue;
-            for (unsigned long long h = ma[w] & mb[w]; h != 0ull; h &= h - 1ull) { rows[r] = (unsigned short)((w - w0) * 64 + __builtin_ctzll(h)); r += 64; ++nhits; }
-          }
-        }
-      }
-      blks.push_back(b);
-    };
-    for (int wb = e.word_begin; wb < e.word_end; wb += RSBA_CW) emit(wb, std::min(wb + RSBA_CW, e.word_end));
-    e.nblk = (int)blks.size() - e.blk_begin;
-    e.blk0 = blks[e.blk_begin];
-  }
-  if (rows.size() / 64 >= ((size_t)1 << 32)) return RSBA_OK;   // (offsets are 32-bit rows: keep the masked search)
-  if (rows.empty()) rows.resize(64, (unsigned short)RSBA_LIST_NONE);
-  int rc;
-  if ((rc = DevAlloc(&pblk, blks.size())) || (rc = DevAlloc(&hl, rows.size()))) return rc;
-  HIPCHK(hipMemcpy(pblk, blks.data(), blks.size() * sizeof(PairBlk), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(hl, rows.data(), rows.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-  hl_rows = rows.size() / 64;
-  if (getenv("RSBA_DEBUG")) {
-    // (how well the point order balances the lanes, by position in the point range: tenths of the blocks of the first pair tile)
-    int nb0 = 0, t_off = -1, b_first = 0;
-    for (int q = 0; q < nseg; ++q) if (sg[q].self == 0 && sg[q].ga != sg[q].gb) { t_off = sg[q].tile; b_first = sg[q].blk_begin; break; }
-    for (int q = 0; q < nseg; ++q) if (sg[q].self == 0 && sg[q].tile == t_off) nb0 += sg[q].nblk;
-    std::string prof;
-    for (int d = 0; d < 10 && nb0 >= 10; ++d) {
-      size_t rws = 0, hts = 0;
-      for (int b = nb0 * d / 10; b < nb0 * (d + 1) / 10; ++b) {
-        const PairBlk& k = blks[b_first + b];
-        const unsigned tr[4] = {k.trips01 & 0xffffu, k.trips01 >> 16, k.trips23 & 0xffffu, k.trips23 >> 16};
-        const unsigned of[4] = {k.off0, k.off1, k.off2, k.off3};
-        for (int wv = 0; wv < 4; ++wv) { rws += tr[wv]; for (size_t e = (size_t)of[wv] * 64; e < ((size_t)of[wv] + tr[wv]) * 64; ++e) hts += rows[e] != RSBA_LIST_NONE; }
-      }
-      char buf[32]; snprintf(buf, sizeof(buf), " %.0f", 100.0 * hts / std::max<size_t>(rws * 64, 1)); prof += buf;
-    }
-    fprintf(stderr, "rsba: lane utilisation of the first pair tile (off-diagonal) by tenth of its point range (%%):%s\n", prof.c_str());
-  }
-  if (getenv("RSBA_DEBUG"))
-    fprintf(stderr, "rsba: hit lists of %d pair segments: %zu blocks, %zu hits in %zu rows (%.0f %% of the lane-trips), %.1f MB, built in %.3f s\n", nseg_pair, blks.size(),
-            nhits, hl_rows, 100.0 * nhits / std::max<size_t>(hl_rows * 64, 1), rows.size() * 2e-6, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-  return RSBA_OK;
-}
-
 void TiledSchur::Free() {
-  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, segs_ordered, segs_ordered_first, segs_ordered_self, small_flag, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm, hits, hit_off, hit_trips, pblk, hl};
+  void* ptrs[] = {cam_mask, segs, ptdata, partial, grp_sum, tree_error, sync_cnt, grp_flag, ready, block_seg, segs_ordered, segs_ordered_first, segs_ordered_self, small_flag, block_scal, cam_prefix, cam_ptr, cm_pos, sq_cm2[0], sq_cm2[1], lin2[0], lin2[1], u_cm, v_cm, hits, hit_off, hit_trips};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  cam_mask = nullptr; hits = nullptr; hit_off = nullptr; hit_trips = nullptr; pblk = nullptr; hl = nullptr;
+  cam_mask = nullptr; hits = nullptr; hit_off = nullptr; hit_trips = nullptr;
 }
 
 static void FreeSolver(rsba_solver* s) {
@@ -1034,7 +935,11 @@ static bool SetupPipeline(rsba_solver* s) {
     // factorisation ends ~250 us behind the last stage (HISTORY.md, round 4).  What an overlap above 64 cameras needs is a
     // factorisation with a small resident footprint (left-looking, a tile column at a time).  One process / one GPU only, every
     // tile resident at once, at most RSBA_MAX_STAGES camera groups to gate on.
+#ifdef RSBA_EXPERIMENTAL
     const char* et = getenv("RSBA_PIPELINE_TILES");
+#else
+    const char* et = nullptr;   // (-DRSBA_EXPERIMENTAL builds only: slower than the sequential step, and it hung one run of the suite)
+#endif
     const char* ec = getenv("RSBA_CHOL_TILES");
     const int m = MultiCholPadded(s->nc), nrt = (m + 1 + 63) / 64, ntiles = nrt * (nrt + 1) / 2;
     if (mg || !(et && atoi(et) == 1) || (ec && atoi(ec) == 0) || ntiles > 2 * prop.multiProcessorCount || (s->C + RSBA_TG - 1) / RSBA_TG > RSBA_MAX_STAGES) return false;
@@ -1235,7 +1140,11 @@ static int UploadPoints(rsba_solver* s) {
     //  LM iteration with three row workgroups — fewer blocks per workgroup, more K slices per block; up to 8; the round-robin kernel
     //  RSBA_CHOL_DIAG=0: four, up to RSBA_MC_MAXG)
     const char* e = getenv("RSBA_CHOL_WGS");
+#ifdef RSBA_EXPERIMENTAL
     const bool want_diag = !(getenv("RSBA_CHOL_DIAG") && atoi(getenv("RSBA_CHOL_DIAG")) == 0);
+#else
+    const bool want_diag = true;   // (the round-robin kernel, RSBA_CHOL_DIAG=0, exists in -DRSBA_EXPERIMENTAL builds only)
+#endif
     const int want = e ? atoi(e) : (want_diag ? 6 : 4);
     if (want > 1 && s->opt.schur_impl != 0 && s->nc >= 6 * RSBA_PB && s->nc <= RSBA_CHOL_MAXN) {
       s->chol_wgs = std::min(want, want_diag ? 8 : RSBA_MC_MAXG);
@@ -1245,15 +1154,21 @@ static int UploadPoints(rsba_solver* s) {
       // most four blocks
       const int np_d = MultiCholPadded(s->nc) / RSBA_PB;
       s->chol_diag = want_diag && s->chol_wgs >= 2 && (np_d - 2 + s->chol_wgs - 2) / (s->chol_wgs - 1) <= 4;
+#ifdef RSBA_EXPERIMENTAL
       if (!s->chol_diag) s->chol_wgs = std::min(s->chol_wgs, RSBA_MC_MAXG);
+#else
+      if (!s->chol_diag) s->chol_wgs = 1;   // (more blocks per row workgroup than the diagonal-chain kernel keeps sums for: one workgroup)
+#endif
       if (s->chol_diag && (rc = DevAlloc(&s->mc_dg, (size_t)2 * (np_d + 1) * 1024))) return rc;   // look-ahead sums | blocks as handed over
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(DiagCholLdsDoubles(s->nc) * sizeof(double))));
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(DiagCholLdsDoubles(s->nc) * sizeof(double))));
       if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, 8 * 16 * 8))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, 8 * 16 * 8 * sizeof(long long))); }
+#ifdef RSBA_EXPERIMENTAL
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(MultiCholLdsDoubles(s->nc) * sizeof(double))));
+#endif
     }
     // more than 64 cameras: one resident workgroup per 64 x 64 tile, if they all fit on the chip at once
     const char* e2 = getenv("RSBA_CHOL_TILES");
@@ -1411,12 +1326,11 @@ __global__ void __launch_bounds__(256) k_unpack_lower(int n, const double* __res
   }
 }
 
-// The instance of the Schur kernel that holds the pair segments this problem runs: sparse hit lists above 64 cameras, static lists
-// up to 64 (RSBA_LISTED=0 or no lists: the masked search).
+// The instance of the Schur kernel that holds the pair segments this problem runs: sparse hit lists above 64 cameras, the masked
+// search up to 64.
 static void LaunchSchurInstance(const SchurArgs& a, int grid, bool loss, hipStream_t st) {
 #define RSBA_LAUNCH_SCHUR(LOSS, MODE) k_schur_tiles<LOSS, MODE><<<grid, 256, 0, st>>>(a.ticket, a.ticket_base, a.total, a.small_flag, a.segs_ordered, a)
   if (a.hits != nullptr) { if (loss) RSBA_LAUNCH_SCHUR(true, RSBA_PAIRS_SPARSE); else RSBA_LAUNCH_SCHUR(false, RSBA_PAIRS_SPARSE); }
-  else if (a.hl != nullptr) { if (loss) RSBA_LAUNCH_SCHUR(true, RSBA_PAIRS_LISTED); else RSBA_LAUNCH_SCHUR(false, RSBA_PAIRS_LISTED); }
   else if (loss) RSBA_LAUNCH_SCHUR(true, RSBA_PAIRS_MASKED);
   else RSBA_LAUNCH_SCHUR(false, RSBA_PAIRS_MASKED);
 #undef RSBA_LAUNCH_SCHUR
@@ -1433,7 +1347,6 @@ static SchurArgs MakeSchurArgs(TiledSchur& ts, rsba_solver* s, int tag) {
   a.trace = s->trace; a.wg_trace = s->wg_trace;
   a.grp_flag = ts.grp_flag; a.epoch = ++ts.epoch;
   a.hits = ts.hits; a.hit_off = ts.hit_off; a.hit_trips = ts.hit_trips;
-  a.pblk = ts.pblk; a.hl = ts.hl;
   a.all_self = 0; a.self_arrivals = ts.self_arrivals;
   return a;
 }
@@ -1735,11 +1648,13 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
         else k_reduced_system_solve_diag<false><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
             C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok, sg, df, tag, s->mc_trace);
       }
+#ifdef RSBA_EXPERIMENTAL
       else if (s->chol_wgs > 1 && !mg)   // (the round-robin kernel has no transposed source: multi-GPU, it is the one-workgroup kernel)
         k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(n) * sizeof(double), s->sB>>>(
             C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
             StageGate{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + RSBA_READY_SOLVED, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + RSBA_READY_STARTED, resident_word, s->chol_wgs},
             MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48}, tag, s->mc_trace);
+#endif
       else
       k_reduced_system_solve<<<1, 512, lds_c, s->sB>>>(C, s->red, s->L, s->A, nullptr, nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
                                                        s->camc[c], s->dcam, s->gmax, s->res, ip, mg ? 2 : 1,
@@ -1826,11 +1741,13 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
           StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0}, DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024},
           s->step_tag, s->mc_trace);
+#ifdef RSBA_EXPERIMENTAL
     else if (s->chol_wgs > 1 && !keep_system_copy)
       k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(s->nc) * sizeof(double), st>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
           StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0}, MultiCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48},
           s->step_tag, s->mc_trace);
+#endif
     else
     k_reduced_system_solve<<<1, 512, lds_c, st>>>(C, s->red, s->L, s->A, keep_system_copy ? s->S_copy : nullptr,
                                                   keep_system_copy ? s->rhs_copy : nullptr, s->scale_c, s->cam[x], s->cam[c], s->intr,
@@ -1996,7 +1913,11 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   // 13.1 us without, 12.1 us with — the host's share was already hidden behind the damping kernel (7.3 us) it queues on the device's
   // decision, what is left is that kernel and the dispatch behind it; 0.3885 vs 0.3890 ms per step, inside the run-to-run spread.
   // Against that microsecond per step stands a whole unused elimination (0.26 ms) at the end of every run a tolerance ends.
+#ifdef RSBA_EXPERIMENTAL
   static const bool ahead_env = getenv("RSBA_LAUNCH_AHEAD") && atoi(getenv("RSBA_LAUNCH_AHEAD")) != 0;
+#else
+  static const bool ahead_env = false;   // (-DRSBA_EXPERIMENTAL builds only: worth 1 us a step, costs an unused elimination at the end of a run)
+#endif
   auto launch_ahead = [&]() {
     TiledSchur& ts = s->tiled;
     const int n = s->nc, atag = s->step_tag + 1;

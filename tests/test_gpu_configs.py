@@ -320,7 +320,7 @@ def test_balanced_point_order_is_internal(oracle, C, P, k, huber, monkeypatch):
 
 
 # ------------------------------------------------------------------ both several-workgroup factorisations of the reduced system
-@pytest.mark.parametrize("diag", [1, 0])
+@pytest.mark.parametrize("diag", [1, 0] if os.environ.get("RSBA_TEST_EXPERIMENTAL") == "1" else [1])   # (0: -DRSBA_EXPERIMENTAL builds only)
 @pytest.mark.parametrize("C,P,k,huber", [(33, 2500, 8, 0.0), (48, 3000, 9, 1.0), (64, 4000, 12, 0.0)])
 def test_diagonal_and_round_robin_cholesky(oracle, C, P, k, huber, diag, monkeypatch):
     """ba_cholesky_diag.hpp (the default for 32 to 64 cameras: workgroup 0 keeps the chain of diagonal factorisations, the

@@ -20,20 +20,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SETTINGS = [
     ({}, ["c40", "c64_huber", "c70_huber", "c130", "c240"]),
     ({"RSBA_PIPELINE": "0"}, ["c40", "c64_huber"]),
-    ({"RSBA_CHOL_DIAG": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_CHOL_WGS": "1"}, ["c40", "c64_huber"]),
     ({"RSBA_CHOL_WGS": "3"}, ["c64_huber"]),
     ({"RSBA_BACKSUB_PROJ": "0"}, ["c40", "c64_huber", "c130"]),
     ({"RSBA_FUSED_LIN": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_DECIDED_DAMP": "0"}, ["c40", "c64_huber"]),
-    ({"RSBA_LAUNCH_AHEAD": "1"}, ["c40", "c64_huber", "c8_dense"]),   # (the next step's factorisation and Schur kernel queued on the device's decision)
     ({"RSBA_FIRST_STAGED": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_BALANCE": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_SEG_PER_CU": "4"}, ["c64_huber", "c130"]),
     ({"RSBA_SPARSE_PAIRS": "0"}, ["c70_huber", "c130"]),
-    ({"RSBA_LISTED": "0"}, ["c40", "c64_huber", "c8_dense"]),
-    ({"RSBA_LISTED": "1"}, ["c8_dense", "c64_dense_huber"]),
-    ({"RSBA_LISTED": "1", "RSBA_SEG_PER_CU": "1"}, ["c33_long", "c64_huber"]),   # (segments of several blocks)
+    ({"RSBA_SEG_PER_CU": "1"}, ["c33_long", "c64_huber", "c8_dense", "c64_dense_huber"]),   # (long segments of several chunks; dense visibility)
     ({"RSBA_CHOL_TILES": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_TILE_ORDER": "0"}, ["c130", "c240"]),
     ({"RSBA_SYS_FUSED": "0"}, ["c70_huber", "c130"]),
@@ -47,12 +43,13 @@ SETTINGS = [
 ]
 
 
-# Experimental paths (RSBA_TEST_EXPERIMENTAL=1 adds them): the tiled factorisation launched ahead of the elimination above 64
-# cameras (RSBA_PIPELINE_TILES=1, slower than the serial step and opt-in) passed this test in every targeted run and in all
-# but one run of the whole suite, where its child process hung until the 600 s limit — not reproduced in six repeats, cause
-# unknown, so it is not something the default suite may depend on.
+# Experimental paths — the step launched ahead on the device's decision (RSBA_LAUNCH_AHEAD), the tiled factorisation gated beside the
+# Schur kernel above 64 cameras (RSBA_PIPELINE_TILES), the round-robin factorisation (RSBA_CHOL_DIAG=0) — exist only in libraries built
+# with -DRSBA_EXPERIMENTAL (tools/build_variant.sh exp -DRSBA_EXPERIMENTAL; RSBA_LIB points the tests at such a build):
+# RSBA_TEST_EXPERIMENTAL=1 adds their settings.
 if os.environ.get("RSBA_TEST_EXPERIMENTAL") == "1":
-    SETTINGS.append(({"RSBA_PIPELINE_TILES": "1"}, ["c70_huber", "c130", "c240"]))
+    SETTINGS += [({"RSBA_PIPELINE_TILES": "1"}, ["c70_huber", "c130", "c240"]), ({"RSBA_CHOL_DIAG": "0"}, ["c40", "c64_huber"]),
+                 ({"RSBA_LAUNCH_AHEAD": "1"}, ["c40", "c64_huber", "c8_dense"])]
 
 
 @pytest.mark.parametrize("env,cases", SETTINGS, ids=[" ".join("%s=%s" % kv for kv in e.items()) or "defaults" for e, _ in SETTINGS])
@@ -71,25 +68,7 @@ def test_switch_selects_a_path_that_matches_the_oracle(env, cases):
     assert "stalled" not in out.stderr, out.stderr[-2000:]
 
 
-def test_listed_pair_segments_add_the_same_bits_as_the_masked_search(tmp_path):
-    """Up to 64 cameras the pair segments walk static hit lists (PairSegmentListed, round 4) instead of searching the visibility
-    masks (PairSegment, RSBA_LISTED=0): the same hits in the same order through the same arithmetic, so whole solves — parameters
-    and every column of the iteration log — must agree bit for bit, with and without a loss, on sparse, dense (blocks cut down to
-    fit the list rows) and many-chunk problems (RSBA_SEG_PER_CU=1: long segments, several blocks each)."""
-    cases = ["c40", "c64_huber", "c8_dense", "c33_long", "c64_dense_huber"]
-    files = []
-    for listed in ("0", "1"):
-        env = dict(os.environ, RSBA_LISTED=listed, RSBA_SEG_PER_CU="1")
-        f = str(tmp_path / ("listed%s.npz" % listed))
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_worker.py"), "--dump", f] + cases, env=env, capture_output=True, text=True, timeout=900)
-        assert out.returncode == 0, out.stderr[-2000:]
-        files.append(f)
-    import numpy as np
-    a, b = np.load(files[0]), np.load(files[1])
-    for name in a.files:
-        assert np.array_equal(a[name], b[name]), name
-
-
+@pytest.mark.skipif(os.environ.get("RSBA_TEST_EXPERIMENTAL") != "1", reason="launch-ahead exists in -DRSBA_EXPERIMENTAL builds only")
 def test_steps_launched_ahead_add_the_same_bits(tmp_path):
     """Up to 64 cameras on one GPU the NEXT step's factorisation and Schur kernel can be queued on the device's decision before the
     host has the step's result (launch_ahead in PointsStep, RSBA_LAUNCH_AHEAD=1; default: the host launches them once it has decided).
