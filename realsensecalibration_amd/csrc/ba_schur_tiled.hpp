@@ -53,8 +53,22 @@ class KernelTimer;
 #define RSBA_READY_SOLVED 41      // = tag when the reduced system is solved (the back-substitution waits for it inside the kernel)
 #define RSBA_READY_STARTED 42     // arrival counter of the factorisation's workgroups ("all resident")
 #define RSBA_PRIO(p) __builtin_amdgcn_s_setprio(p)   // wavefront priority (see k_schur_tiles)
-#define RSBA_CHUNK 512      // points per LDS chunk
+#ifndef RSBA_RESIDENT
+#define RSBA_RESIDENT 0     // 1: up to 64 cameras too, as many workgroups as the chip holds draw tickets until the work list is through
+#endif
+// Priority of a hit loop.  RSBA_RESIDENT: by STAGE — a wavefront working on an earlier camera group's columns wins the arbitration against
+// its SIMD-mate working on a later one (resident workgroups never change age, and the arbiter serves the older wavefront first: the
+// younger workgroup of a CU would sit on its stage's entries until the older one has left the kernel)
+#if RSBA_RESIDENT
+#define RSBA_PRIO_HITS(stage) do { if ((stage) == 0) RSBA_PRIO(2); else if ((stage) == 1) RSBA_PRIO(1); else RSBA_PRIO(0); } while (0)
+#else
+#define RSBA_PRIO_HITS(stage) RSBA_PRIO(0)
+#endif
+#ifndef RSBA_CHUNK
+#define RSBA_CHUNK 512      // points per LDS chunk (-DRSBA_CHUNK=256 builds and runs: measured only together with three workgroups per CU, HISTORY.md round 5)
+#endif
 #define RSBA_CW (RSBA_CHUNK / 64)
+
 // (RSBA_PT_STRIDE, the record of a point — X(3) Vinv(6) y(3) — is defined in ba_point_kernels.hpp, whose back-substitution writes it too)
 #define RSBA_PART 42        // 36 block + 6 corr
 
@@ -830,7 +844,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
     sc[tid] = scv[0]; sc[tid + 256] = scv[1];
 #pragma unroll
     for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; if (i < np * RSBA_PT_STRIDE) pt[i] = pv[u]; }
-    mk[tid >> 3][tid & 7] = mv;
+    if ((tid & 7) < RSBA_CW) mk[tid >> 3][tid & 7] = mv;
     __syncthreads();
   }
   double acc[36];
@@ -848,7 +862,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
       {
         const int row = tid >> 3, w = tid & 7;
         const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
-        mk[row][w] = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
+        if (w < RSBA_CW) mk[row][w] = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
       }
       __syncthreads();
     }
@@ -856,7 +870,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
     // runs max-over-lanes(hits in 512 points) trips, not the sum over words of the per-word maxima
     // one flat loop per lane: (w, h) is the lane's cursor into its hit list; the cursor advance is a tiny inner loop
     // that does not touch the accumulators
-    RSBA_PRIO(0);
+    RSBA_PRIO_HITS(sg.stage);
     int w = w0;
     unsigned long long h = live ? (mk[ia][w0] & mk[RSBA_TG + ib][w0]) : 0ull;
     if (live) { while (h == 0ull && w + wstep < RSBA_CW) { w += wstep; h = mk[ia][w] & mk[RSBA_TG + ib][w]; } }
@@ -1065,7 +1079,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
 #pragma unroll
     for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; pv[u] = i < np * RSBA_PT_STRIDE ? ptdata[(size_t)j0 * RSBA_PT_STRIDE + i] : 0.0; }
     unsigned long long mv = 0ull;
-    if (tid < RSBA_TG * RSBA_CW) {
+    if (tid < RSBA_TG * 8) {
       const int row = tid >> 3, w = tid & 7;
       const int cam = RSBA_TG * sg.ga + row;
       mv = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
@@ -1074,7 +1088,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; if (i < np * RSBA_PT_STRIDE) pt[i] = pv[u]; }
-    if (tid < RSBA_TG * RSBA_CW) mk[tid >> 3][tid & 7] = mv;
+    if (tid < RSBA_TG * 8 && (tid & 7) < RSBA_CW) mk[tid >> 3][tid & 7] = mv;
     __syncthreads();
     // The camera's points of this chunk as a list, dealt to its 16 lanes BY RANK (lane s takes entries s, s + 16, ...): every
     // lane of a camera gets the same number of hits to within one (dealing by bit position left the lanes of a wave at 62 %
@@ -1086,10 +1100,10 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
       int base = 0;
 #pragma unroll
       for (int x = 0; x < RSBA_CW; ++x) base += x < w ? __popcll(mk[row][x]) : 0;
-      const unsigned long long m = mk[row][w];
+      const unsigned long long m = w < RSBA_CW ? mk[row][w] : 0ull;   // (chunks of fewer than eight words: the threads beyond them idle)
       unsigned int my = half ? (unsigned int)(m >> 32) : (unsigned int)m;
       if (half) base += __popc((unsigned int)m);
-      if (j == 15) cnt[row] = base + __popc(my);
+      if (j == 2 * RSBA_CW - 1) cnt[row] = base + __popc(my);
       const int p0 = w * 64 + half * 32;
       while (my != 0u) {
         const int b = __ffs((int)my) - 1;
@@ -1100,7 +1114,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
     __syncthreads();
     const int n_a = live ? cnt[ia] : 0;
     const int obs_chunk = live ? obs0 + obs_chunk_pre : 0;
-    RSBA_PRIO(0);
+    RSBA_PRIO_HITS(sg.stage);
 #pragma unroll 1
     for (int i = ib; i < n_a; i += 16) {
       const double* pd = pt + (size_t)lst[ia][i] * RSBA_PT_STRIDE;
@@ -1426,7 +1440,9 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
 // another, a pair segment costs the other registers, scalar spills and a longer hot loop)
 #define RSBA_PAIRS_MASKED 0
 #define RSBA_PAIRS_SPARSE 1
-#define RSBA_SCHUR_LDS_BYTES 80992   // two workgroups per CU: 2 x (this + the few static words below) <= 160 KB
+// chunk records | mask rows 2 KB | camera constants 4 KB | a self tile's lists | counters.  512-point chunks: 81 024 bytes, two
+// workgroups per CU
+#define RSBA_SCHUR_LDS_BYTES (RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK + 96)
 template <bool kLoss, int kMode>
 __global__ void __launch_bounds__(256, 2)
 k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const int* __restrict__ small_flag_p, const SchurSeg* __restrict__ segs_p, SchurArgs a) {
@@ -1438,8 +1454,9 @@ k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const
   // rows 2 KB | camera constants 4 KB | self tiles: a camera's points of the chunk 16 KB | 16 counters
   __shared__ __attribute__((aligned(16))) char lds_raw[RSBA_SCHUR_LDS_BYTES];
   static_assert(RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK + 64 <= RSBA_SCHUR_LDS_BYTES, "LDS carve");
-  static_assert(2 * (RSBA_SCHUR_LDS_BYTES + 256) <= 160 * 1024, "two workgroups per CU");
+  static_assert(RSBA_CHUNK != 512 || 2 * (RSBA_SCHUR_LDS_BYTES + 256) <= 160 * 1024, "two workgroups per CU");
   constexpr bool kSparse = kMode == RSBA_PAIRS_SPARSE;
+  constexpr bool kResident = kSparse || RSBA_RESIDENT != 0;   // the workgroups draw tickets until the list is through
   double* pt = reinterpret_cast<double*>(lds_raw);
   unsigned long long (*mk)[RSBA_CW] = reinterpret_cast<unsigned long long (*)[RSBA_CW]>(lds_raw + RSBA_CHUNK * RSBA_PT_STRIDE * 8);
   double* sc = reinterpret_cast<double*>(lds_raw + RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048);
@@ -1475,7 +1492,7 @@ k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const
     if (threadIdx.x == 0) s_ticket = (int)((unsigned)__hip_atomic_fetch_add(ticket_p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base);
     __syncthreads();
     const int b = __builtin_amdgcn_readfirstlane(s_ticket);   // (uniform: the entry is read with scalar loads and stays in scalar registers)
-    if (kSparse && b >= total) break;
+    if (kResident && b >= total) break;
     const SchurSeg sg = LoadSeg(segs_p + b);
     const int seg_index = sg.index;
     if (a.trace && b == 0 && threadIdx.x == 0) a.trace[24] = wall_clock64();
@@ -1492,7 +1509,7 @@ k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const
       else PairSegment<kLoss, false>(a, sg, seg_index, b, pt, mk, sc);
     }
     if (a.wg_trace && threadIdx.x == 0) a.wg_trace[3 * b + 1] = wall_clock64();
-    if (!kSparse) break;   // one entry per workgroup
+    if (!kResident) break;   // one entry per workgroup
     __syncthreads();       // (the next entry reuses the staging buffers and s_ticket)
   }
 }

@@ -1289,7 +1289,12 @@ static void LaunchPointSide(TiledSchur& ts, rsba_solver* s, const IterParams& ip
 // tag != 0: the ready flags are published for a Cholesky that is already waiting (pipelined schedule).
 // Workgroups of a launch of the Schur kernel.  More than 64 cameras (the sparse instance): as many as the chip holds at once (two
 // per CU), each drawing tickets until the work list is through; otherwise one per entry.
-static int SchurGrid(int entries, bool sparse) { return sparse ? std::min(entries, 2 * DeviceCUs()) : entries; }
+static int SchurGrid(int entries, bool sparse) {
+  // (RSBA_RESIDENT builds: resident up to 64 cameras too — a few slots fewer than the chip holds: the factorisation's six workgroups, 160 KB
+  //  of LDS each, are resident beside the kernel, and a workgroup that found no slot would take its tickets late)
+  if (RSBA_RESIDENT != 0 && !sparse) { static const int spare = getenv("RSBA_RESIDENT_SPARE") ? atoi(getenv("RSBA_RESIDENT_SPARE")) : 12; return std::min(entries, std::max(1, 2 * DeviceCUs() - spare)); }
+  return sparse ? std::min(entries, 2 * DeviceCUs()) : entries;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Several ranks, more than 64 cameras: the all-reduce payload as LOWER TRIANGLE + vectors (SURVEY 8e priced the
@@ -1363,7 +1368,7 @@ void TiledSchur::LaunchTiles(rsba_solver* s, const IterParams& ip, KernelTimer& 
   }
   const bool sparse = a.hits != nullptr;   // (resident workgroups: as many as the chip holds, each drawing tickets until the list is through)
   const int grid = SchurGrid(nblocks, sparse);
-  a.total = nblocks; a.ticket_base = ticket_base; ticket_base += (unsigned)(nblocks + (sparse ? grid : 0));
+  a.total = nblocks; a.ticket_base = ticket_base; ticket_base += (unsigned)(nblocks + ((sparse || RSBA_RESIDENT != 0) ? grid : 0));
   T.Begin("k_schur_tiles", st);
   LaunchSchurInstance(a, grid, ip.huber_delta != 0.0, st);
   T.End(st);
@@ -1374,7 +1379,7 @@ void TiledSchur::LaunchSelfOnly(rsba_solver* s, const IterParams& ip, KernelTime
   SchurArgs a = MakeSchurArgs(*this, s, 0);
   a.segs_ordered = segs_ordered_self; a.self_only = 1; a.trace = nullptr; a.wg_trace = nullptr;
   const int grid = SchurGrid(nblocks_self, false);   // (the self-only pass runs the masked instance at any size)
-  a.total = nblocks_self; a.ticket_base = ticket_base; ticket_base += (unsigned)nblocks_self;
+  a.total = nblocks_self; a.ticket_base = ticket_base; ticket_base += (unsigned)(nblocks_self + (RSBA_RESIDENT != 0 ? grid : 0));
   T.Begin("k_schur_tiles(self only)", st);
   a.hits = nullptr;   // (one entry per workgroup; a self segment is the same code in every instance)
   LaunchSchurInstance(a, grid, ip.huber_delta != 0.0, st);
