@@ -506,6 +506,220 @@ class MarkerChainModel {
 };
 
 // ---------------------------------------------------------------------------------------------
+// The same marker-chain problem with a BLOCK-SPARSE Jacobian and the TIME blocks eliminated (round 5): the dense model above
+// holds an (8 N) x (6 blocks) Jacobian — 8 x 5000 x 16 would be 3e5 rows x 3e4 columns — so parity at the size the product's
+// time-eliminating path (csrc/ba_marker_schur.hpp) is benchmarked on needs the structure Ceres' DENSE_SCHUR exploits: every
+// residual block touches exactly ONE time block (bundle_adjustment.h:56-343: camera?, time, marker?), so the time blocks are
+// mutually independent given cameras and markers — the e-blocks of the automatic ordering.
+//   S = F'F + D_f^2 - sum_t (E_t'F)' (E_t'E_t + D_t^2)^-1 (E_t'F),  rhs likewise, dense LLT on S (6 (cameras + markers) wide),
+//   y_t = (E_t'E_t + D_t^2)^-1 (E_t'r - E_t'F y_f).
+// Same functors, same Jets, same minimiser as MarkerChainModel; identical parameter order (active blocks), so the two can be
+// run side by side: tests/test_oracle_golden.py holds them to each other on the reference's hongo and test2 inputs.
+// ---------------------------------------------------------------------------------------------
+class MarkerChainSparseModel {
+ public:
+  MarkerChainSparseModel(const MarkerChainProblem& p, const double* full_params, int num_threads = 1) : p_(p), nthreads_(num_threads) {
+    full_.assign(full_params, full_params + 6 * p.num_blocks());
+    block_to_active_.assign(p.num_blocks(), -1);
+    std::vector<char> used(p.num_blocks(), 0);
+    for (int i = 0; i < p.N; ++i) {
+      if (p.uses_camera(i)) used[p.camera_block(i)] = 1;
+      used[p.time_block(i)] = 1;
+      if (p.uses_marker(i)) used[p.marker_block(i)] = 1;
+    }
+    for (int b = 0; b < p.num_blocks(); ++b) if (used[b]) { block_to_active_[b] = (int)active_blocks_.size(); active_blocks_.push_back(b); }
+    const int na = (int)active_blocks_.size();
+    n_ = 6 * na;
+    // f-blocks: the active cameras and markers, in active order; e-blocks: the active times
+    f_of_.assign(na, -1); t_of_.assign(na, -1);
+    for (int a = 0; a < na; ++a) {
+      const int b = active_blocks_[a];
+      if (b >= p.C && b < p.C + p.T) t_of_[a] = nt_++; else f_of_[a] = nf_++;
+    }
+    obs_of_time_.assign(nt_, {});
+    for (int i = 0; i < p.N; ++i) obs_of_time_[t_of_[block_to_active_[p.time_block(i)]]].push_back(i);
+    r_.assign((size_t)8 * p.N, 0.0); J_.assign((size_t)8 * 18 * p.N, 0.0); g_.assign(n_, 0.0);
+  }
+  int num_parameters() const { return n_; }
+  void GetActive(double* x) const { for (size_t k = 0; k < active_blocks_.size(); ++k) std::memcpy(x + 6 * k, &full_[6 * active_blocks_[k]], 48); }
+  void Scatter(const double* x, double* full) const {
+    std::memcpy(full, full_.data(), sizeof(double) * full_.size());
+    for (size_t k = 0; k < active_blocks_.size(); ++k) std::memcpy(full + 6 * active_blocks_[k], x + 6 * k, 48);
+  }
+  // active index of observation i's camera / time / marker block (-1: the block is not a parameter of this residual)
+  int ac(int i) const { return p_.uses_camera(i) ? block_to_active_[p_.camera_block(i)] : -1; }
+  int at(int i) const { return block_to_active_[p_.time_block(i)]; }
+  int am(int i) const { return p_.uses_marker(i) ? block_to_active_[p_.marker_block(i)] : -1; }
+  bool Evaluate(const double* x, double* cost, bool with_jacobian) {
+    typedef Jet<18> J18;
+    double c = 0;
+    bool finite = true;
+#pragma omp parallel for schedule(static) num_threads(nthreads_) reduction(+ : c) reduction(&& : finite)
+    for (int i = 0; i < p_.N; ++i) {
+      const int bc = ac(i), bt = at(i), bm = am(i);
+      const Intrinsics& K = p_.intrinsics[p_.camera_idx[i]];
+      const double h = p_.marker_side / 2;
+      double res[8];
+      if (!with_jacobian) {
+        MarkerChainReprojectionError<double>(bc >= 0 ? x + 6 * bc : nullptr, x + 6 * bt, bm >= 0 ? x + 6 * bm : nullptr, h, K, p_.observations + 8 * i, res);
+      } else {
+        J18 cam[6], tim[6], mar[6], jr[8];
+        for (int k = 0; k < 6; ++k) {
+          if (bc >= 0) cam[k] = J18(x[6 * bc + k], k);
+          tim[k] = J18(x[6 * bt + k], 6 + k);
+          if (bm >= 0) mar[k] = J18(x[6 * bm + k], 12 + k);
+        }
+        MarkerChainReprojectionError<J18>(bc >= 0 ? cam : nullptr, tim, bm >= 0 ? mar : nullptr, h, K, p_.observations + 8 * i, jr);
+        double* Ji = &J_[(size_t)8 * 18 * i];
+        for (int r = 0; r < 8; ++r) {
+          res[r] = jr[r].a;
+          for (int k = 0; k < 18; ++k) Ji[18 * r + k] = ((k < 6 && bc < 0) || (k >= 12 && bm < 0)) ? 0.0 : jr[r].v[k];
+        }
+      }
+      for (int r = 0; r < 8; ++r) {
+        if (!std::isfinite(res[r])) finite = false;
+        if (with_jacobian) r_[(size_t)8 * i + r] = res[r];
+        c += res[r] * res[r];
+      }
+    }
+    if (!finite) return false;
+    *cost = 0.5 * c;
+    if (with_jacobian) {
+      std::fill(g_.begin(), g_.end(), 0.0);
+      for (int i = 0; i < p_.N; ++i) {
+        const int blk[3] = {ac(i), at(i), am(i)};
+        const double* Ji = &J_[(size_t)8 * 18 * i];
+        for (int r = 0; r < 8; ++r) {
+          const double rr = r_[(size_t)8 * i + r];
+          for (int s3 = 0; s3 < 3; ++s3) if (blk[s3] >= 0) for (int k = 0; k < 6; ++k) g_[6 * blk[s3] + k] += Ji[18 * r + 6 * s3 + k] * rr;
+        }
+      }
+    }
+    return true;
+  }
+  const double* gradient() const { return g_.data(); }
+  void SquaredColumnNorm(double* out) const {
+    for (int k = 0; k < n_; ++k) out[k] = 0;
+    for (int i = 0; i < p_.N; ++i) {
+      const int blk[3] = {ac(i), at(i), am(i)};
+      const double* Ji = &J_[(size_t)8 * 18 * i];
+      for (int r = 0; r < 8; ++r) for (int s3 = 0; s3 < 3; ++s3) if (blk[s3] >= 0) for (int k = 0; k < 6; ++k) { const double v = Ji[18 * r + 6 * s3 + k]; out[6 * blk[s3] + k] += v * v; }
+    }
+  }
+  void ScaleColumns(const double* s) {
+#pragma omp parallel for schedule(static) num_threads(nthreads_)
+    for (int i = 0; i < p_.N; ++i) {
+      const int blk[3] = {ac(i), at(i), am(i)};
+      double* Ji = &J_[(size_t)8 * 18 * i];
+      for (int r = 0; r < 8; ++r) for (int s3 = 0; s3 < 3; ++s3) if (blk[s3] >= 0) for (int k = 0; k < 6; ++k) Ji[18 * r + 6 * s3 + k] *= s[6 * blk[s3] + k];
+    }
+  }
+  bool Solve(const double* D, double* y) {
+    const int nr = 6 * nf_;
+    std::vector<double> S((size_t)nr * nr, 0.0), rhs(nr, 0.0);
+    // F'F, F'r and the damping of the f-blocks
+    for (int i = 0; i < p_.N; ++i) {
+      const int fb[2] = {ac(i) >= 0 ? f_of_[ac(i)] : -1, am(i) >= 0 ? f_of_[am(i)] : -1};
+      const int off[2] = {0, 12};
+      const double* Ji = &J_[(size_t)8 * 18 * i];
+      for (int a = 0; a < 2; ++a) if (fb[a] >= 0) {
+        for (int r = 0; r < 8; ++r) {
+          const double* ja = Ji + 18 * r + off[a];
+          for (int k = 0; k < 6; ++k) rhs[6 * fb[a] + k] += ja[k] * r_[(size_t)8 * i + r];
+          for (int b = 0; b < 2; ++b) if (fb[b] >= 0) {
+            const double* jb = Ji + 18 * r + off[b];
+            for (int k = 0; k < 6; ++k) for (int l = 0; l < 6; ++l) S[(size_t)(6 * fb[a] + k) * nr + 6 * fb[b] + l] += ja[k] * jb[l];
+          }
+        }
+      }
+    }
+    for (size_t a = 0; a < active_blocks_.size(); ++a) if (f_of_[a] >= 0) for (int k = 0; k < 6; ++k) { const double d = D[6 * a + k]; S[(size_t)(6 * f_of_[a] + k) * nr + 6 * f_of_[a] + k] += d * d; }
+    // eliminate the time blocks: per time V = E'E + D^2 (6 x 6), g = E'r, W_f = E'F_f for the f-blocks its residuals touch
+    struct TimeElim { double Vl[36]; double g[6]; std::vector<int> fs; std::vector<double> W; };   // W: fs.size() x (6 x 6), W_f[k][l] = sum E[.][k] F[.][l]
+    std::vector<TimeElim> te(nt_);
+    bool ok = true;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads_) reduction(&& : ok)
+    for (int t = 0; t < nt_; ++t) {
+      TimeElim& e = te[t];
+      double V[36] = {0}; for (int k = 0; k < 6; ++k) e.g[k] = 0;
+      int a_t = -1;
+      for (int i : obs_of_time_[t]) {
+        a_t = at(i);
+        const double* Ji = &J_[(size_t)8 * 18 * i];
+        const int fb[2] = {ac(i) >= 0 ? f_of_[ac(i)] : -1, am(i) >= 0 ? f_of_[am(i)] : -1};
+        const int off[2] = {0, 12};
+        int slot[2] = {-1, -1};
+        for (int a = 0; a < 2; ++a) if (fb[a] >= 0) {
+          size_t q = 0; for (; q < e.fs.size(); ++q) if (e.fs[q] == fb[a]) break;
+          if (q == e.fs.size()) { e.fs.push_back(fb[a]); e.W.resize(e.W.size() + 36, 0.0); }
+          slot[a] = (int)q;
+        }
+        for (int r = 0; r < 8; ++r) {
+          const double* jt = Ji + 18 * r + 6;
+          for (int k = 0; k < 6; ++k) { e.g[k] += jt[k] * r_[(size_t)8 * i + r]; for (int l = 0; l < 6; ++l) V[6 * k + l] += jt[k] * jt[l]; }
+          for (int a = 0; a < 2; ++a) if (slot[a] >= 0) { const double* jf = Ji + 18 * r + off[a]; double* W = &e.W[(size_t)36 * slot[a]]; for (int k = 0; k < 6; ++k) for (int l = 0; l < 6; ++l) W[6 * k + l] += jt[k] * jf[l]; }
+        }
+      }
+      for (int k = 0; k < 6; ++k) { const double d = D[6 * a_t + k]; V[6 * k + k] += d * d; }
+      std::memcpy(e.Vl, V, sizeof(V));
+      if (!CholeskyFactor(6, e.Vl)) ok = false;
+    }
+    if (!ok) return false;
+    // S -= W' V^-1 W, rhs -= W' V^-1 g  (in time order: a fixed summation order whatever the number of threads)
+    for (int t = 0; t < nt_; ++t) {
+      const TimeElim& e = te[t];
+      const int m = (int)e.fs.size();
+      std::vector<double> Z((size_t)36 * m);   // Z_f = V^-1 W_f (6 x 6), column by column
+      for (int q = 0; q < m; ++q) for (int l = 0; l < 6; ++l) {
+        double col[6]; for (int k = 0; k < 6; ++k) col[k] = e.W[(size_t)36 * q + 6 * k + l];
+        CholeskySolve(6, e.Vl, col);
+        for (int k = 0; k < 6; ++k) Z[(size_t)36 * q + 6 * k + l] = col[k];
+      }
+      double vg[6]; std::memcpy(vg, e.g, sizeof(vg)); CholeskySolve(6, e.Vl, vg);
+      for (int qa = 0; qa < m; ++qa) {
+        const double* Wa = &e.W[(size_t)36 * qa];
+        for (int k = 0; k < 6; ++k) { double sacc = 0; for (int j = 0; j < 6; ++j) sacc += Wa[6 * j + k] * vg[j]; rhs[6 * e.fs[qa] + k] -= sacc; }
+        for (int qb = 0; qb < m; ++qb) {
+          const double* Zb = &Z[(size_t)36 * qb];
+          for (int k = 0; k < 6; ++k) for (int l = 0; l < 6; ++l) { double sacc = 0; for (int j = 0; j < 6; ++j) sacc += Wa[6 * j + k] * Zb[6 * j + l]; S[(size_t)(6 * e.fs[qa] + k) * nr + 6 * e.fs[qb] + l] -= sacc; }
+        }
+      }
+    }
+    if (nr > 0) { if (!CholeskyFactor(nr, S.data())) return false; CholeskySolve(nr, S.data(), rhs.data()); }
+    for (size_t a = 0; a < active_blocks_.size(); ++a) if (f_of_[a] >= 0) for (int k = 0; k < 6; ++k) y[6 * a + k] = rhs[6 * f_of_[a] + k];
+    // back-substitute the times
+    for (size_t a = 0; a < active_blocks_.size(); ++a) if (t_of_[a] >= 0) {
+      const TimeElim& e = te[t_of_[a]];
+      double v[6]; std::memcpy(v, e.g, sizeof(v));
+      for (size_t q = 0; q < e.fs.size(); ++q) { const double* W = &e.W[(size_t)36 * q]; for (int k = 0; k < 6; ++k) for (int l = 0; l < 6; ++l) v[k] -= W[6 * k + l] * rhs[6 * e.fs[q] + l]; }
+      CholeskySolve(6, e.Vl, v);
+      for (int k = 0; k < 6; ++k) y[6 * a + k] = v[k];
+    }
+    return true;
+  }
+  double ModelCostChange(const double* step) const {
+    double s = 0;
+    for (int i = 0; i < p_.N; ++i) {
+      const int blk[3] = {ac(i), at(i), am(i)};
+      const double* Ji = &J_[(size_t)8 * 18 * i];
+      for (int r = 0; r < 8; ++r) {
+        double mr = 0;
+        for (int s3 = 0; s3 < 3; ++s3) if (blk[s3] >= 0) for (int k = 0; k < 6; ++k) mr += Ji[18 * r + 6 * s3 + k] * step[6 * blk[s3] + k];
+        s += mr * (r_[(size_t)8 * i + r] + mr / 2.0);
+      }
+    }
+    return -s;
+  }
+ private:
+  MarkerChainProblem p_;
+  int nthreads_ = 1;
+  std::vector<double> full_, r_, J_, g_;
+  std::vector<int> block_to_active_, active_blocks_, f_of_, t_of_;
+  std::vector<std::vector<int>> obs_of_time_;
+  int n_ = 0, nf_ = 0, nt_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
 // Point model (configs 2-5): block-sparse Jacobian (2x6 camera, 2x3 point per observation),
 // Schur elimination of all point blocks (schur_eliminator_impl.h), dense LLT of the reduced
 // camera system (schur_complement_solver.cc), back-substitution.

@@ -132,15 +132,29 @@ int oracle_solve_marker_chain(int variant, int T, int C, int M, int N, const int
   std::vector<Intrinsics> K(C);
   for (int c = 0; c < C; ++c) K[c] = Intrinsics{intrinsics4[4 * c], intrinsics4[4 * c + 1], intrinsics4[4 * c + 2], intrinsics4[4 * c + 3]};
   p.intrinsics = K.data(); p.marker_side = marker_side;
-  MarkerChainModel model(p, params);
-  std::vector<double> x(model.num_parameters());
-  model.GetActive(x.data());
+  // variant + 16: the block-sparse model with the time blocks eliminated (MarkerChainSparseModel) — the same problem, the same
+  // minimiser, at sizes the dense Jacobian cannot hold
   Summary s;
-  const auto t0 = std::chrono::steady_clock::now();
-  TrustRegionMinimize(model, ToOptions(oopt), x.data(), &s);
-  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::vector<double> full(6 * p.num_blocks());
-  model.Scatter(x.data(), full.data());
+  double sec = 0;
+  if (variant >= 16) {
+    p.variant = variant - 16;
+    MarkerChainSparseModel model(p, params, oopt && oopt->num_threads > 0 ? oopt->num_threads : 1);
+    std::vector<double> x(model.num_parameters());
+    model.GetActive(x.data());
+    const auto t0 = std::chrono::steady_clock::now();
+    TrustRegionMinimize(model, ToOptions(oopt), x.data(), &s);
+    sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    model.Scatter(x.data(), full.data());
+  } else {
+    MarkerChainModel model(p, params);
+    std::vector<double> x(model.num_parameters());
+    model.GetActive(x.data());
+    const auto t0 = std::chrono::steady_clock::now();
+    TrustRegionMinimize(model, ToOptions(oopt), x.data(), &s);
+    sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    model.Scatter(x.data(), full.data());
+  }
   std::memcpy(params, full.data(), sizeof(double) * full.size());
   FillSummary(s, sec, out, iter_log, max_log);
   return s.termination;

@@ -622,6 +622,35 @@ def test_marker_chain_time_elimination_matches_oracle(oracle, shape):
     assert np.all(got[:6] == prob["params"][:6]) and np.all(got[6 * (C_ + T_):6 * (C_ + T_) + 6] == prob["params"][6 * (C_ + T_):6 * (C_ + T_) + 6])
 
 
+@pytest.mark.parametrize("iters", [3, None])
+def test_marker_chain_at_its_benchmarked_size_matches_the_sparse_oracle(oracle, iters):
+    """8 cameras x 5000 shots x 16 markers — the size profiles/r0*_marker_chain_scale.json times (~0.5 M residual blocks, 30 000
+    unknowns) — against the oracle's block-sparse model with the time blocks eliminated (MarkerChainSparseModel, pinned to the
+    dense model and to the reference's XML in tests/test_oracle_golden.py).  Rounds 3-4 compared this size with the ground truth
+    only: the dense oracle cannot hold it.  Three forced iterations (every iterate's cost 1e-9, the accept / reject sequence,
+    every block 1e-6 relative) and the whole solve with the reference's tolerances (iteration count, stop reason, parameters)."""
+    import os as _os
+    prob = syn.make_marker_chain(8, 5000, 16, seed=11)
+    nt = max(1, min(len(_os.sched_getaffinity(0)), 32))
+    kw = dict(max_num_iterations=iters, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0) if iters else {}
+    ref, s_ref, log_ref = oracle.solve_marker_chain(prob, 16, prob["marker_side"], prob["intr"], oracle.options(num_threads=nt, **kw))
+    p = capi.Problem.marker_chain(prob)
+    sv = capi.Solver(p, capi.default_options(**kw))
+    s = sv.run()
+    sv.download()
+    log = sv.iterations()
+    got = p.params.copy()
+    sv.close()
+    p.close()
+    assert (s.termination_type, s.stop_reason, s.num_iterations, s.num_successful_steps) == (s_ref.termination, s_ref.stop_reason, s_ref.num_iterations, s_ref.num_successful_steps)
+    assert np.array_equal(log[:, 7], log_ref[:, 7])
+    assert np.abs(log[:, 1] - log_ref[:, 1]).max() <= 1e-9 * log_ref[:, 1].max()
+    assert abs(s.final_cost - s_ref.final_cost) <= 1e-9 * s_ref.final_cost
+    a, b = got.reshape(-1, 6), ref.reshape(-1, 6)
+    rel = (np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-12)).max()
+    assert rel < 1e-6, rel
+
+
 @pytest.mark.parametrize("chunks", ["1", "7", "1000"])
 def test_marker_chain_chunk_count_does_not_change_the_answer(oracle, chunks):
     """RSBA_MT_CHUNKS: how many workgroups share the times of the elimination (one partial system each, summed in chunk order).

@@ -117,3 +117,41 @@ def test_termination_rule_is_decisive(oracle):
     o = oracle.options(function_tolerance=0.0, max_num_iterations=8)
     params8, s8, _ = oracle.solve_marker_chain(prob, 0, ol.MARKER_SIDE_MAIN, intr, o)
     assert np.abs(params8 - params).max() > 1e-6
+
+
+# ------------------------------------------------------------------ the block-sparse marker-chain oracle (time blocks eliminated)
+def _sparse_against_dense_and_xml(oracle, prob, variant, side, intr):
+    dense, s_d, log_d = oracle.solve_marker_chain(prob, variant, side, intr)
+    sparse, s_s, log_s = oracle.solve_marker_chain(prob, variant + 16, side, intr)
+    assert (s_s.termination, s_s.stop_reason, s_s.num_iterations, s_s.num_successful_steps) == (s_d.termination, s_d.stop_reason, s_d.num_iterations, s_d.num_successful_steps)
+    assert np.array_equal(log_s[:, 7], log_d[:, 7])
+    assert np.abs(log_s[:, 1] - log_d[:, 1]).max() <= 1e-12 * log_d[:, 1].max()          # every iterate's cost
+    assert np.abs(log_s[:, 6] - log_d[:, 6]).max() <= 1e-9 * log_d[:, 6].max()           # radius
+    assert np.abs(sparse - dense).max() < 1e-11, np.abs(sparse - dense).max()
+    return sparse
+
+
+def test_sparse_marker_chain_oracle_on_the_reference_inputs(oracle):
+    """oracle/ba_oracle.hpp MarkerChainSparseModel (round 5: block-sparse Jacobian, the time blocks eliminated — what lets the
+    oracle run the marker-chain model at the size the product's path is benchmarked on) against the dense model on both inputs
+    the reference commits, AND against the reference's own committed output (hongo/Camera_Transform.xml, 1e-12; test2's rvec)."""
+    prob = ol.read_correspondence(os.path.join(G, "hongo", "correspondence.txt"))
+    intr = ol.read_intrinsics(ol.SERIALS_MAIN)
+    params = _sparse_against_dense_and_xml(oracle, prob, 0, ol.MARKER_SIDE_MAIN, intr)
+    xml = ol.read_opencv_xml(os.path.join(G, "hongo", "Camera_Transform.xml"))
+    for i in range(prob["C"]):
+        R = oracle.rodrigues(params[6 * i:6 * i + 3])
+        assert np.abs(R - xml["R%d" % i]).max() < 1e-12 and np.abs(params[6 * i + 3:6 * i + 6] - xml["t%d" % i].ravel()).max() < 1e-12
+    prob2 = ol.read_correspondence(os.path.join(G, "test2", "correspondence_test.txt"))
+    intr2 = ol.read_intrinsics(ol.SERIALS_TEST2)
+    params2 = _sparse_against_dense_and_xml(oracle, prob2, 1, ol.MARKER_SIDE_TEST2, intr2)
+    xml2 = ol.read_opencv_xml(os.path.join(G, "test2", "Camera_Transform.xml"))
+    assert np.abs(params2[6:9] - xml2["R1"].ravel()).max() < 1e-12 and np.abs(params2[9:12] - xml2["t1"].ravel()).max() < 1e-12
+
+
+def test_sparse_marker_chain_oracle_on_a_synthetic_rig(oracle):
+    """... and on a synthetic rig at the largest size the dense model still holds (6 cameras x 60 shots x 9 markers)."""
+    from realsensecalibration_amd import synthetic as syn
+    prob = syn.make_marker_chain(6, 60, 9, seed=4)
+    intr = prob["intr"].reshape(-1, 4)
+    _sparse_against_dense_and_xml(oracle, prob, 0, prob["marker_side"], intr)
