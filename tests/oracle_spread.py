@@ -116,7 +116,9 @@ def bars(sp, n_obs):
     """The tolerances a parity test may use on this problem (see the module docstring and THE MARGIN RULE above)."""
     parted = sp["part"] >= 0 or not sp["same_trajectory"]
     # Runs whose iterates part (the oracle's own!) are chaotic from there on: two samples of the end state do not bound a third.
-    # What is left to ask of the end of such a run is that it is as good a fit: cost within 1 %, RMS within 0.1 px.
+    # Round 5: the end state of such a run is no parity bar any more (rounds 3-4: cost within 1 %, RMS within 0.1 px) — fuzz_cases.run
+    # re-runs both solvers with the iteration limit at agree_until and compares THAT state at BASELINE's bars; final_cost / rms / raw
+    # below are what a caller without that second run may still use.
     # the first three iterates' costs: 1e-12 (a defect shows at once, rounding shows late) — or ten times what the oracle's own
     # executions differ by there, on the problems whose FIRST solves already amplify the roundings (points seen by two cameras:
     # nearly singular point blocks; seed-123 sweep, cases 080 / 218 / 289: the oracle's runs 0.8 - 5.7e-12 apart at iterates 1 - 3, the HIP path 1.7 - 6.0e-12 from the oracle)

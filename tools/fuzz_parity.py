@@ -20,6 +20,7 @@ for c in fuzz_cases.cases(ncase, seed):
     sp = r["spread"]
     print("%-34s iters %2d radius max %.0e | raw %.1e final cost %.1e rms %.0e first three %.0e part at %d | oracle vs itself: raw %.1e cost %.1e part at %d %s | %s" % (
         fuzz_cases.label(c), r["iterations"], r["radius_max"], r["raw"], r["final_cost"], r["rms"], r["first3"], r["part"],
-        sp["raw"], sp["final_cost"], sp["part"], "SENSITIVE" if sens else "", "ok" if not bad else "MISMATCH: " + "; ".join(bad)), flush=True)
+        sp["raw"], sp["final_cost"], sp["part"], ("SENSITIVE, at the last common iterate %d: raw %.1e cost %.1e rms %.0e" % (r["trunc"]["k"], r["trunc"]["raw"], r["trunc"]["final_cost"], r["trunc"]["rms"])) if r.get("trunc") else ("SENSITIVE" if sens else ""),
+        "ok" if not bad else "MISMATCH: " + "; ".join(bad)), flush=True)
 print("mismatches:", nbad, "of", ncase, "; cases on which the oracle parts from itself:", nsens)
 sys.exit(1 if nbad else 0)

@@ -31,6 +31,30 @@ for mode in (0, 1):
         out["kernels_us"] = {k: round(1e3 * ms / n, 1) for k, (n, ms) in s.kernel_stats().items()}
     s.download()
     s.close()
+# roofline entry of the dominant kernel (k_time_eliminate): ALGORITHMIC work per LM iteration.  Per residual block (8 residuals, a camera,
+# a time and a marker block of 6: J is 8 x 18) the normal-equation products J'J / J'r restricted to what the elimination needs —
+# V += Jt'Jt (8 x 21 unique), g_t (8 x 6), W_c = Jt'Jc and W_m = Jt'Jm (8 x 36 each), U_cc, U_mm (8 x 21 each), U_cm (8 x 36),
+# g_c, g_m (8 x 6 each): 1512 multiply-adds where all three blocks are parameters (camera 0 / marker 0 are not: those rows drop
+# their terms); per time block with f touched camera / marker blocks the Schur update W'V^-1 W: (6f)^2/2 x 6 + the 6 x 6 solve.
+# Bytes: a residual block's record (8 pixels + 3 indices: 76 B) once, every time block's parameters read and its step written (96 B).
+t_arr, c_arr, m_arr = prob["t"], prob["c"], prob["m"]
+fma = 0.0
+for has_c, has_m in ((True, True), (True, False), (False, True), (False, False)):
+    n = int(np.sum(((c_arr != 0) == has_c) & ((m_arr != 0) == has_m)))
+    fma += n * 8 * (21 + 6 + (36 + 21 + 6 if has_c else 0) + (36 + 21 + 6 if has_m else 0) + (36 if has_c and has_m else 0))
+key = t_arr.astype(np.int64) * 4096
+fc = np.unique(key[c_arr != 0] + c_arr[c_arr != 0]); fm = np.unique(key[m_arr != 0] + 2048 + m_arr[m_arr != 0])
+f_per_time = np.bincount((np.concatenate([fc, fm]) // 4096).astype(np.int64), minlength=T_).astype(float)
+fma += float(np.sum((6 * f_per_time) ** 2 / 2 * 6 + 6 ** 3 / 3))
+flops = 2.0 * fma
+nbytes = 76.0 * prob["N"] + 96.0 * T_
+if "kernels_us" in out and "k_time_eliminate" in out["kernels_us"]:
+    us = out["kernels_us"]["k_time_eliminate"]
+    out["roofline"] = {"kernel": "k_time_eliminate", "avg_launch_us": us, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
+                       "flops_per_residual_block": flops / prob["N"], "bytes_per_residual_block": nbytes / prob["N"],
+                       "achieved_TFLOPs": flops / (us * 1e-6) / 1e12, "frac_of_fp64_peak_78.6": flops / (us * 1e-6) / 1e12 / 78.6,
+                       "achieved_GBps": nbytes / (us * 1e-6) / 1e9, "frac_of_hbm_8000": nbytes / (us * 1e-6) / 1e9 / 8000.0,
+                       "bound": "neither roof: a latency chain of five barriers per 32-block tile inside one workgroup per chunk of shots (HISTORY.md round 4)"}
 err = np.abs(p.params - prob["truth"]).reshape(-1, 6)
 out["max_abs_error_vs_truth"] = float(err.max())
 print(json.dumps(out))
