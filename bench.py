@@ -333,7 +333,7 @@ def main():
         # writes profiles/r03_pmc_<workload>.json); a line for a workload without such a file carries traffic = null
         pmc, pmc_source = {}, None
         wl = args.config if args.points is None else "%s_%d" % (args.config, args.points)
-        for cand in ("r04_pmc_%s.json" % wl, "r03_pmc_%s.json" % wl) + (("r02_pmc.json",) if wl == "cfg3" else ()):
+        for cand in ("r05_pmc_%s.json" % wl, "r04_pmc_%s.json" % wl, "r03_pmc_%s.json" % wl) + (("r02_pmc.json",) if wl == "cfg3" else ()):
             q = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(q):
                 try:

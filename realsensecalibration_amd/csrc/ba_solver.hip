@@ -343,7 +343,8 @@ static int PairSegmentsPerTile(int C, int P, bool staged) {
   for (int ga = 0; ga < ngroups; ++ga) for (int gb = ga; gb < ngroups; ++gb) if (!(ga == gb && std::min(RSBA_TG, C - RSBA_TG * ga) < 2)) ++npair_tiles;
   // measured at 64 cameras: the pipelined schedule likes shorter workgroups (a stage ends with its last one), the
   // sequential one fewer partial sums
-  const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : (6 * C > RSBA_CHOL_MAXN ? 6 : (staged ? 8 : 4));
+  // (RSBA_SEG_TARGET: the same number through the whole-chunk rounding below, which RSBA_SEG_PER_CU bypasses)
+  const int seg_per_cu = getenv("RSBA_SEG_PER_CU") ? atoi(getenv("RSBA_SEG_PER_CU")) : getenv("RSBA_SEG_TARGET") ? atoi(getenv("RSBA_SEG_TARGET")) : (6 * C > RSBA_CHOL_MAXN ? 6 : (staged ? 8 : 4));
   const int target = seg_per_cu * DeviceCUs();
   const int nW = (P + 63) / 64;
   int ns = std::max(1, std::min((int)std::lround((double)target / std::max(1, npair_tiles)), nW));
