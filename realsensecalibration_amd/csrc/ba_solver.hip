@@ -184,6 +184,10 @@ struct rsba_solver {
   int step_tag = 0;
   int inject_stall_step = 0; // RSBA_TEST_STALL_STEP=k (with a communicator; RSBA_TEST_STALL_RANK=r: on that rank only): step k reports a
                              // stalled factorisation on this rank — the flag is summed over the ranks and ALL of them repeat the step
+  bool tiles_small = false;  // RSBA_TILES_SMALL=1 (opt-in, round 5): the persistent TILED factorisation + chain back-substitution (ba_cholesky_tiles.hpp)
+                             // for 17 .. 64 cameras in the SEQUENTIAL schedule: 130 + 26 us against the diagonal-chain kernel's 170 at 64 cameras
+                             // (0.436 against 0.449 ms per step).  Opt-in because its roundings are not the pipelined schedule's kernel's: the two
+                             // schedules — and a step repeated sequentially after a stall — would no longer add the same bits.
   int chol_wgs = 1;          // > 1: the reduced system is factored by this many workgroups (ba_cholesky_multi.hpp)
   bool chol_diag = false;    // ... with the diagonal chain in workgroup 0 (ba_cholesky_diag.hpp; RSBA_CHOL_DIAG=0: blocks dealt round-robin, ba_cholesky_multi.hpp)
   int* mc_flags = nullptr;   // tdone[16] | strip_ready[16] | wg_done[8] | error
@@ -987,6 +991,7 @@ static int UploadPoints(rsba_solver* s) {
   const rsba_problem& p = *s->prob;
   s->C = p.num_cameras; s->P = p.num_points; s->N = p.num_observations; s->nc = 6 * s->C; s->L = RedLayout{s->nc};
   const int C = s->C, P = s->P; const int64_t N = s->N;
+  s->tiles_small = getenv("RSBA_TILES_SMALL") && atoi(getenv("RSBA_TILES_SMALL")) != 0 && s->nc <= RSBA_CHOL_MAXN && C > RSBA_TG;
   if (std::find(p.camera_constant.begin(), p.camera_constant.end(), (uint8_t)1) != p.camera_constant.end()) {
     std::vector<double> fr(C, 1.0);
     for (int c = 0; c < C && c < (int)p.camera_constant.size(); ++c) if (p.camera_constant[c]) fr[c] = 0.0;
@@ -1092,7 +1097,7 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->intr, 4 * C)) || (rc = DevAlloc(&s->cam[0], 6 * C)) || (rc = DevAlloc(&s->cam[1], 6 * C)) || (rc = DevAlloc(&s->cam0, 6 * C)) ||
       (rc = DevAlloc(&s->pts[0], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts[1], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts0, 3 * (size_t)P)) ||
       (rc = DevAlloc(&s->camc[0], CC_STRIDE * C)) || (rc = DevAlloc(&s->camc[1], CC_STRIDE * C)) || (rc = DevAlloc(&s->scale_c, 6 * C)) ||
-      (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(MultiCholPadded(s->nc) + 2) * MultiCholPadded(s->nc))) || (rc = DevAlloc(&s->W, s->nc > RSBA_CHOL_MAXN ? (size_t)(s->nc + 1) * s->nc : 1)) ||
+      (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(MultiCholPadded(s->nc) + 2) * MultiCholPadded(s->nc))) || (rc = DevAlloc(&s->W, (s->nc > RSBA_CHOL_MAXN || s->tiles_small) ? (size_t)(s->nc + 1) * s->nc : 1)) ||
       (rc = DevAlloc(&s->chol_ok, 3)) ||
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
       (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)) || (rc = DevAlloc(&s->dec, 4)) ||
@@ -1173,7 +1178,7 @@ static int UploadPoints(rsba_solver* s) {
     }
     // more than 64 cameras: one resident workgroup per 64 x 64 tile, if they all fit on the chip at once
     const char* e2 = getenv("RSBA_CHOL_TILES");
-    if (s->nc > RSBA_CHOL_MAXN && !(e2 && atoi(e2) == 0)) {
+    if ((s->nc > RSBA_CHOL_MAXN || s->tiles_small) && !(e2 && atoi(e2) == 0)) {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) {
         const int m = MultiCholPadded(s->nc), nrt = (m + 1 + 63) / 64, ntiles = nrt * (nrt + 1) / 2;
@@ -1739,7 +1744,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   RoctxRange rr_k4s(pipe ? "K4 (already launched)" : "K4 reduced camera system: Cholesky + solve");
   if (pipe) {
     // issued at the top of the step (see below): nothing left to launch here
-  } else if (s->nc <= RSBA_CHOL_MAXN) {
+  } else if (s->nc <= RSBA_CHOL_MAXN && !(s->tiles_small && s->tc_tiles > 0 && !keep_system_copy)) {
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(s->nc)) * sizeof(double);
     T.Begin("k_reduced_system_solve", st);
     if (s->chol_wgs > 1 && !keep_system_copy && s->chol_diag)

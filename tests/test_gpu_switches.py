@@ -30,6 +30,7 @@ SETTINGS = [
     ({"RSBA_SEG_PER_CU": "4"}, ["c64_huber", "c130"]),
     ({"RSBA_SPARSE_PAIRS": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_SEG_PER_CU": "1"}, ["c33_long", "c64_huber", "c8_dense", "c64_dense_huber"]),   # (long segments of several chunks; dense visibility)
+    ({"RSBA_TILES_SMALL": "1", "RSBA_PIPELINE": "0"}, ["c40", "c64_huber", "c33_long"]),   # (the tiled factorisation up to 64 cameras, sequential schedule)
     ({"RSBA_CHOL_TILES": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_TILE_ORDER": "0"}, ["c130", "c240"]),
     ({"RSBA_SYS_FUSED": "0"}, ["c70_huber", "c130"]),
