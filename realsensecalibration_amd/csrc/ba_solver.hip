@@ -485,6 +485,40 @@ static std::vector<int> BalancedPointOrder(int C, int P, bool staged, const std:
   std::vector<int> next(ubeg), perm(P, -1);
   for (int j = 0; j < P; ++j) perm[next[unit_of[j]]++] = j;
   for (int q = 0; q < P; ++q) if (perm[q] < 0) return {};
+  // Inside every unit (round 5): which 64-point WORD a point sits in decides which half of a DIAGONAL tile's workgroup finds its
+  // hits — the tile's 120 pairs sit in both halves, one walks the even words of a chunk, the other the odd ones (PairSegment,
+  // PairSegmentSparse) — and the dealing above balances whole units only.  So the unit's points are dealt to its even / odd words
+  // such that every pair of cameras of ONE group gets about the same number of shared points in either half (greedy, in the
+  // unit's order: the half where the point's diagonal pairs have fewer hits so far, relative to the half's fill).  Measured offline
+  // on the 64 x 100k x 20 problem (the kernel's lane -> pair map replayed on the host): lane utilisation of the diagonal tiles'
+  // hit loops 69.8 % -> 75.3 %, of all pair tiles 81.9 % -> 83.6 %.
+  static const bool parity_on = !(getenv("RSBA_BALANCE_PARITY") && atoi(getenv("RSBA_BALANCE_PARITY")) == 0);
+  if (parity_on) {
+    std::vector<uint16_t> hc((size_t)C * C * 2);
+    std::vector<int> half[2];
+    for (int g = 0; g < nu; ++g) {
+      const int p0 = ubeg[g], np = ucap[g], nwu = (np + 63) / 64;
+      if (nwu < 2) continue;
+      int cap[2] = {0, 0};
+      for (int w = 0; w < nwu; ++w) cap[w & 1] += std::min(64, np - 64 * w);
+      std::fill(hc.begin(), hc.end(), (uint16_t)0);
+      half[0].clear(); half[1].clear();
+      for (int q = p0; q < p0 + np; ++q) {
+        const int j = perm[q], b = ptr[j], k = ptr[j + 1] - b;
+        const int* cj = cam.data() + b;
+        long sc[2] = {0, 0};
+        for (int x = 0; x < k; ++x) for (int y = x + 1; y < k; ++y) if (cj[x] / RSBA_TG == cj[y] / RSBA_TG) { const uint16_t* c = &hc[((size_t)cj[x] * C + cj[y]) * 2]; sc[0] += c[0]; sc[1] += c[1]; }
+        int h;
+        if ((int)half[0].size() >= cap[0]) h = 1;
+        else if ((int)half[1].size() >= cap[1]) h = 0;
+        else h = sc[0] * (long)(half[1].size() + 1) <= sc[1] * (long)(half[0].size() + 1) ? 0 : 1;
+        half[h].push_back(j);
+        for (int x = 0; x < k; ++x) for (int y = x + 1; y < k; ++y) if (cj[x] / RSBA_TG == cj[y] / RSBA_TG) { uint16_t& c = hc[((size_t)cj[x] * C + cj[y]) * 2 + h]; if (c != 0xFFFF) ++c; }
+      }
+      size_t i0 = 0, i1 = 0;
+      for (int w = 0; w < nwu; ++w) { const int n = std::min(64, np - 64 * w); for (int l = 0; l < n; ++l) perm[p0 + 64 * w + l] = (w & 1) ? half[1][i1++] : half[0][i0++]; }
+    }
+  }
   return perm;
 }
 
