@@ -37,6 +37,7 @@
 // reproducible, identical on every rank.  All waits carry a budget: a stall gives up (RES_STALL), never hangs.
 #pragma once
 #include "ba_cholesky_multi.hpp"
+#include "ba_cholesky_border.hpp"
 
 namespace rsba {
 
@@ -93,7 +94,7 @@ struct DiagConst {
   const int* rows_ready; const int* error; const int* gate_ready;
   long long budget, gate_budget;
   double min_diag, max_diag, inv_radius;
-  int n, nreal, SLD, tag, gate_tag, gate_cols, gated;
+  int n, nreal, ld, SLD, tag, gate_tag, gate_cols, gated;   // ld: columns of S in memory (> nreal when the last camera group is a border, ba_cholesky_border.hpp)
   int trs;  // 1: entry (i, j) of S is read as S[j][i] (multi-GPU pipeline: only camera group g's ROW slab is all-reduced when its panels start)
   lds_double* Bst; lds_double* t_tile[2]; lds_double* xprev; lds_double* scl;
   lds_int* s_wb; lds_int* ok_lds;
@@ -106,7 +107,7 @@ typedef __attribute__((address_space(3))) const DiagConst lds_DiagConst;
 static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, int wk, int sa, int sb, int p, int do_unit, lds_double* out, lds_double* pre_n) {
   const double* __restrict__ A = dc->A;
   const double* __restrict__ S = dc->S;
-  const int n = dc->n, nreal = dc->nreal, SLD = dc->SLD, tag = dc->tag;
+  const int n = dc->n, nreal = dc->nreal, ld = dc->ld, SLD = dc->SLD, tag = dc->tag;
   lds_double* Bst = dc->Bst; const lds_double* tprev = dc->t_tile[(p - 1) & 1]; lds_double* xprev = dc->xprev; const lds_double* scl = dc->scl;   // (T(p-1): the factorisation alternates between two tiles)
   lds_int* s_wb = dc->s_wb; lds_int* ok_lds = dc->ok_lds;
   const int wb_target = 18 * (p - 1) + 6;
@@ -169,7 +170,7 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
     const int e = wk * 64 + lane + u * 384, r = e >> 5, c = e & 31;
     if (e < RSBA_PB * RSBA_PB) {
       if (s_now) {
-        if (nb0 + r < nreal && nb0 + c < nreal) ns[u] = __hip_atomic_load(&S[dc->trs ? (size_t)(nb0 + c) * nreal + nb0 + r : (size_t)(nb0 + r) * nreal + nb0 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nb0 + r < nreal && nb0 + c < nreal) ns[u] = __hip_atomic_load(&S[dc->trs ? (size_t)(nb0 + c) * ld + nb0 + r : (size_t)(nb0 + r) * ld + nb0 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (r == c && nb0 + r < nreal) ndu = __hip_atomic_load(&dc->diag_u[nb0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       ndd[u] = dc->dg[(size_t)(p + 1) * 1024 + r * 32 + c];
@@ -178,7 +179,7 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
   // slice 0 also brings the rows' own entries of S (off the diagonal: scaled, no damping term)
   if (wk < 2 && sgi < nreal) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) sv8[u] = S[dc->trs ? (size_t)(kb + sc0 + u) * nreal + sgi : (size_t)sgi * nreal + kb + sc0 + u];
+    for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) sv8[u] = S[dc->trs ? (size_t)(kb + sc0 + u) * ld + sgi : (size_t)sgi * ld + kb + sc0 + u];
   }
   // (the slabs last: the loads return in order, and X(p+1, p-1) is formed while they are still arriving)
   {
@@ -307,7 +308,7 @@ static __device__ __noinline__ void DiagUpdateWave(lds_DiagConst* dc, int kb, in
 static __device__ __noinline__ void RowUpdateHalf(lds_DiagConst* dc, int kb, int do_strip, int has_unit, int b, int half, int ks, int nsplit, lds_double* Bst, lds_double* rows, lds_double* pdst) {
   const double* __restrict__ A = dc->A;
   const double* __restrict__ S = dc->S;
-  const int n = dc->n, nreal = dc->nreal;
+  const int n = dc->n, nreal = dc->nreal, ld = dc->ld;
   const lds_double* scl = dc->scl;
   const int lane = threadIdx.x & 63, mi = lane & 15, kk = lane >> 4;
   const int sr = lane >> 2, sc0 = (lane & 3) * 8;
@@ -333,7 +334,7 @@ static __device__ __noinline__ void RowUpdateHalf(lds_DiagConst* dc, int kb, int
   if (has_unit && ks == 0) {
     if (sgi < nreal) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) v[u] = S[dc->trs ? (size_t)(kb + sc0 + u) * nreal + sgi : (size_t)sgi * nreal + kb + sc0 + u];
+      for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) v[u] = S[dc->trs ? (size_t)(kb + sc0 + u) * ld + sgi : (size_t)sgi * ld + kb + sc0 + u];
     } else if (sgi == n) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) if (kb + sc0 + u < nreal) { v[u] = dc->gc[kb + sc0 + u]; v2[u] = dc->corr[kb + sc0 + u]; }
@@ -415,11 +416,14 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
                             const double* __restrict__ cam_x, double* __restrict__ cam_c, const double* __restrict__ intr,
                             double* __restrict__ camc_c, double* __restrict__ dcam, const double* __restrict__ gmax_p,
                             double* __restrict__ res, IterParams ip, int* __restrict__ chol_ok, StageGate gate, DiagCholFlags f, int tag,
-                            long long* __restrict__ mtrace /* diagnostic: [G][16][8] wall-clock stamps, or nullptr */, AheadSel ahead = AheadSel{}) {
+                            long long* __restrict__ mtrace /* diagnostic: [G][16][8] wall-clock stamps, or nullptr */, AheadSel ahead = AheadSel{},
+                            int border_cols = 0 /* > 0: the leading system's columns (a multiple of 96); the last camera group is the border, formed by the launch's last workgroup (ba_cholesky_border.hpp) */) {
   extern __shared__ __attribute__((aligned(16))) double lds[];   // (16: the strip image is read and written 16 bytes at a time)
-  const int nreal = L.nc, n = (nreal + RSBA_PB - 1) / RSBA_PB * RSBA_PB;
+  const int ld = L.nc;                                          // columns of S in memory
+  const int nreal = border_cols > 0 ? border_cols : ld, n = (nreal + RSBA_PB - 1) / RSBA_PB * RSBA_PB;
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6;
-  const int G = gridDim.x, w = blockIdx.x;
+  const int G = (int)gridDim.x - (border_cols > 0 ? 1 : 0), w = blockIdx.x;   // G: the diagonal workgroup and the row workgroups
+  const bool border_wg = border_cols > 0 && w == G;
   const int np = n / RSBA_PB;              // column panels; blocks 0 .. np (block np: the rhs row alone, workgroup 0's)
   const long long budget = gate.budget > 0 ? gate.budget : RSBA_STALL_TICKS;
   __shared__ int s_ok, s_wb, s_w7ok, s_fdone, s_acq[3];
@@ -467,6 +471,24 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   const double* S = red + L.S();
   const double inv_radius = 1.0 / ip.radius;
   const int mi = lane & 15, kk = lane >> 4;
+  if (border_wg) {
+    // (its constants at the end of ITS carve of the dynamic LDS: the kernel's static words plus the diagonal workgroup's carve fill the 160 KiB)
+    BorderCtx& s_bc = *reinterpret_cast<BorderCtx*>(lds + BorderLdsDoubles(ld) - RSBA_BORDER_CTX_DOUBLES);
+    if (tid == 0) {
+      s_bc.S = S; s_bc.diag_u = red + L.diagU(); s_bc.gc = red + L.gc(); s_bc.corr = red + L.corr(); s_bc.scal = red + L.scal();
+      s_bc.A = A; s_bc.XB = A + (size_t)(n + 2) * n; s_bc.scale_c = scale_c;
+      s_bc.gate_ready = gate.ready; s_bc.all_diag = gate.all_diag; s_bc.gate_tag = gate.tag; s_bc.gated = gate.ready != nullptr ? 1 : 0; s_bc.gate_budget = gate.budget;
+      s_bc.tdone = f.tdone; s_bc.strip_ready = f.strip_ready; s_bc.rows_ready = f.rows_ready; s_bc.a_done = f.error + 12; s_bc.error = f.error; s_bc.tag = tag; s_bc.budget = budget;
+      s_bc.nrow_wgs = G - 1; s_bc.ld = ld; s_bc.nA = nreal; s_bc.nB = ld - nreal; s_bc.B = nreal / RSBA_BW;
+      s_bc.min_diag = ip.min_lm_diagonal; s_bc.max_diag = ip.max_lm_diagonal; s_bc.inv_radius = inv_radius; s_bc.first = ip.first; s_bc.jacobi = ip.jacobi_scaling;
+      s_bc.C = C; s_bc.cam_x = cam_x; s_bc.cam_c = cam_c; s_bc.intr = intr; s_bc.camc_c = camc_c; s_bc.dcam = dcam; s_bc.gmax_p = gmax_p; s_bc.res = res; s_bc.cam_free = ip.cam_free;
+      s_bc.chol_ok = chol_ok; s_bc.done = gate.done; s_bc.trace = gate.trace;
+      s_bc.mtrace = mtrace ? mtrace + (size_t)w * 16 * 8 : nullptr;
+    }
+    __syncthreads();
+    BorderWorkgroup((lds_BorderCtx*)&s_bc, (lds_double*)lds);
+    return;
+  }
 
   // gated stage by stage: every iteration but a run's first — and the first one too when the Schur kernel ran every self
   // tile ahead of the pair tiles and says so (gate.all_diag)
@@ -513,7 +535,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     return v;
   };
   constexpr bool trs = kTr;
-  auto Sat = [&](int gi, int gj) { return (gi < nreal && gj < nreal) ? S[trs ? (size_t)gj * nreal + gi : (size_t)gi * nreal + gj] : 0.0; };
+  auto Sat = [&](int gi, int gj) { return (gi < nreal && gj < nreal) ? S[trs ? (size_t)gj * ld + gi : (size_t)gi * ld + gj] : 0.0; };
   if (w == 0 && !stalled) {   // the first diagonal block
     for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) { const int r = e >> 5, c = e & 31; Pre[r * RSBA_PLD + c] = sys(r, c, Sat(r, c)); }
     __syncthreads();
@@ -537,7 +559,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     s_dc.rows_ready = f.rows_ready; s_dc.error = f.error; s_dc.gate_ready = gate.ready;
     s_dc.budget = budget; s_dc.gate_budget = gate.budget;
     s_dc.min_diag = ip.min_lm_diagonal; s_dc.max_diag = ip.max_lm_diagonal; s_dc.inv_radius = inv_radius;
-    s_dc.n = n; s_dc.nreal = nreal; s_dc.SLD = n - 30; s_dc.tag = tag; s_dc.gate_tag = gate.tag; s_dc.gate_cols = gate.cols;
+    s_dc.n = n; s_dc.nreal = nreal; s_dc.ld = ld; s_dc.SLD = n - 30; s_dc.tag = tag; s_dc.gate_tag = gate.tag; s_dc.gate_cols = gate.cols;
     s_dc.gated = staged ? 1 : 0; s_dc.trs = kTr ? 1 : 0;
     s_dc.Bst = (lds_double*)lds; s_dc.t_tile[0] = (lds_double*)T; s_dc.t_tile[1] = (lds_double*)(lds + (size_t)32 * (n - 30) + RSBA_PB * RSBA_PLD); s_dc.xprev = (lds_double*)(lds + (n - 30 - RSBA_PB)); s_dc.scl = (lds_double*)scl;
     s_dc.s_wb = (lds_int*)&s_wb; s_dc.ok_lds = (lds_int*)&s_w7ok; s_dc.acq = (lds_int*)&s_acq[0];
@@ -568,7 +590,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
       double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (ks == 0 && sgi < nreal) {
         if (kb + sc0 + 8 <= nreal && !trs) {
-          const double2* sp = reinterpret_cast<const double2*>(S + (size_t)sgi * nreal + kb + sc0);
+          const double2* sp = reinterpret_cast<const double2*>(S + (size_t)sgi * ld + kb + sc0);
 #pragma unroll
           for (int u = 0; u < 4; ++u) { const double2 t = sp[u]; v[2 * u] = t.x; v[2 * u + 1] = t.y; }
         } else {
@@ -785,7 +807,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
               for (int t = 0; t < 4; ++t) {
                 const int gi = nb0 + 16 * ti + kk + 4 * t, gj = nb0 + 16 * tj + mi;
                 const bool in = gi < nreal && gj < nreal;
-                raw[t] = in ? __hip_atomic_load(&S[trs ? (size_t)gj * nreal + gi : (size_t)gi * nreal + gj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                raw[t] = in ? __hip_atomic_load(&S[trs ? (size_t)gj * ld + gi : (size_t)gi * ld + gj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
                 du[t] = in && gi == gj ? __hip_atomic_load(&red[L.diagU() + gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
               }
 #pragma unroll
@@ -922,11 +944,19 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
   }
 
   if (stalled) {
-    if (tid == 0) { __hip_atomic_store(f.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (w == 0) res[RES_STALL] = 1.0; }
-    if (w == 0) SolveDone(gate);
+    // (with a border the last workgroup ends the solve: it sees the error flag in whatever it waits for next)
+    if (tid == 0) { __hip_atomic_store(f.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (w == 0 && border_cols == 0) res[RES_STALL] = 1.0; }
+    if (w == 0 && border_cols == 0) SolveDone(gate);
     return;
   }
   if (w != 0) return;
+  if (border_cols > 0) {
+    // the leading system is factored and y_A = L_A^-1 b_A lies in its right-hand-side row: over to the border's workgroup
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(f.error + 12, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   // workgroup 0: every block's rows were handed over before its diagonal panel, so L is complete; L' x = y and the camera step
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();

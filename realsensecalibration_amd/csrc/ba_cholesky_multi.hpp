@@ -152,7 +152,8 @@ __device__ __forceinline__ double* BackSubstituteBlocksPrefetch(int n, double* _
 // meet by a lane exchange — the same operations in every wavefront, the same bits) and handed to its lanes through a
 // wavefront-private LDS row read back 16 bytes at a time (broadcast), one barrier per block row, T double-buffered.
 // x is returned in its own array.  512 threads, n a multiple of 32, n <= 512.
-__device__ __forceinline__ double* BackSubstituteBlocksWaves(int n, double* __restrict__ A, double* lds) {
+// y_in_place: the right-hand side already lies at lds[0 .. n) (ba_cholesky_border.hpp); otherwise it is row n of A.
+__device__ __forceinline__ double* BackSubstituteBlocksWaves(int n, double* __restrict__ A, double* lds, bool y_in_place = false) {
   typedef double d2b_t __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int n64 = (n + 63) & ~63;
@@ -225,7 +226,7 @@ __device__ __forceinline__ double* BackSubstituteBlocksWaves(int n, double* __re
     __syncthreads();
   };
   load_strip(kb_last, ra, ta);
-  for (int i = tid; i < n; i += nt) y[i] = A[(size_t)n * n + i];
+  if (!y_in_place) { for (int i = tid; i < n; i += nt) y[i] = A[(size_t)n * n + i]; }
   store_T(0, ta);
   __syncthreads();
   for (int kb = kb_last; kb >= 0; kb -= 2 * RSBA_PB) {

@@ -144,11 +144,9 @@ struct TiledSchur {
   size_t hit_entries = 0;
 
   int Build(int C, int P, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
-            const std::vector<int>& sliced_q /* sliced slot -> CSR position, -1 pads */, bool staged);
-  // stages of the pipelined solve: pair tiles with ga == g are contiguous (tiles [stage_tile[g], stage_tile[g+1])), the
-  // self tiles follow ([stage_tile[nstages], ntiles)); segments follow their tiles
+            const std::vector<int>& sliced_q /* sliced slot -> CSR position, -1 pads */, bool staged, bool bordered = false);
+  // stages of the pipelined solve (TiledSchur::Build: stage_of): camera groups, or 2 B + 1 with the last group as a border
   int nstages = 0;
-  std::vector<int> stage_tile, stage_seg;
   int Launch(rsba_solver* s, const IterParams& ip, KernelTimer& T);
   void LaunchPointPass(rsba_solver* s, const IterParams& ip, KernelTimer& T, hipStream_t st);
   // the point pass of a step whose x already has its linearisation in lin2[cur] (every step but a run's first)

@@ -190,7 +190,9 @@ struct rsba_solver {
                              // schedules — and a step repeated sequentially after a stall — would no longer add the same bits.
   int chol_wgs = 1;          // > 1: the reduced system is factored by this many workgroups (ba_cholesky_multi.hpp)
   bool chol_diag = false;    // ... with the diagonal chain in workgroup 0 (ba_cholesky_diag.hpp; RSBA_CHOL_DIAG=0: blocks dealt round-robin, ba_cholesky_multi.hpp)
-  int* mc_flags = nullptr;   // tdone[16] | strip_ready[16] | wg_done[8] | error
+  int border_cols = 0;       // > 0 (RSBA_BORDER=1; 33 .. 64 cameras, no communicator): the diagonal-chain kernel factors the leading 96 B columns and one more
+                             // workgroup forms the last camera group as their border (ba_cholesky_border.hpp); both schedules, so that they add the same bits
+  int* mc_flags = nullptr;   // tdone[16] | strip_ready[16] | wg_done[8] | error (error[12]: the leading system is through)
   int* tc_flags = nullptr;   // persistent tiled factorisation (more than 64 cameras): tdone[np] | xdone[np][nrt] | error
   int* tc_map = nullptr;     // ... which tile each of its workgroups takes (TileOrder)
   double* tc_hand = nullptr; // ... and the private hand-over buffers of its diagonal chain (TileCholFlags::hand), two sets
@@ -523,9 +525,15 @@ static std::vector<int> BalancedPointOrder(int C, int P, bool staged, const std:
 }
 
 int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std::vector<int>& obs_cam, const std::vector<double>& u, const std::vector<double>& v,
-                      const std::vector<int>& sliced_q, bool staged) {
+                      const std::vector<int>& sliced_q, bool staged, bool bordered) {
   C = C_; P = P_;
   ngroups = (C + RSBA_TG - 1) / RSBA_TG;
+  // Stage of a tile.  Plain: the camera group of its columns — self tile g and the pair tiles (g, g' >= g): what the left-looking
+  // factorisation needs for group g's panels.  With the last group Bg as a BORDER (ba_cholesky_border.hpp): the leading system's
+  // tiles first — stage g < Bg: self tile g, pair tiles (g, g') with g' < Bg —, then the border's rows, tile (g, Bg) = stage
+  // Bg + g, and last the border's own self and pair tile, stage 2 Bg.
+  const int Bg = bordered ? ngroups - 1 : -1;
+  auto stage_of = [&](int ga, int gb, bool self) { return !bordered ? ga : (ga == Bg ? 2 * Bg : (!self && gb == Bg ? Bg + ga : ga)); };
   nwords = ((P + 63) / 64 + RSBA_CW - 1) / RSBA_CW * RSBA_CW;
   nchunks = nwords / RSBA_CW;
   const int ncam = ngroups * RSBA_TG;
@@ -557,11 +565,17 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   // total.  (Sizing each stage's workgroups to whole rounds of slots was tried for the pipelined schedule: no gain, and
   // the two schedules would no longer add in the same order.)
   int npair_tiles = 0;
-  std::vector<int> tiles_of_stage(ngroups, 0);
-  for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) { ++npair_tiles; ++tiles_of_stage[tab[3 * t]]; }
+  nstages = bordered ? 2 * Bg + 1 : ngroups;
+  // the order the stages are worked through: a border's rows of group g, tile (g, Bg), right behind the leading system's stage g —
+  // the border's workgroup then has one group's time for them (everything it needs of the leading factor is there by then)
+  std::vector<int> stage_order;
+  if (bordered) { for (int g = 0; g < Bg; ++g) { stage_order.push_back(g); stage_order.push_back(Bg + g); } stage_order.push_back(2 * Bg); }
+  else for (int g = 0; g < nstages; ++g) stage_order.push_back(g);
+  std::vector<int> stage_of_tile(ntiles, 0), tiles_of_stage(nstages, 0);
+  for (int t = 0; t < ntiles; ++t) stage_of_tile[t] = stage_of(tab[3 * t], tab[3 * t + 1], tab[3 * t + 2] != 0);
+  for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2]) { ++npair_tiles; ++tiles_of_stage[stage_of_tile[t]]; }
   std::vector<SchurSeg> sg; std::vector<int> tsp(ntiles + 1, 0);
-  nstages = ngroups; ngrp = 0;
-  stage_tile.assign(nstages + 1, 0); stage_seg.assign(nstages + 1, 0);
+  ngrp = 0;
   for (int t = 0; t < ntiles; ++t) {
     const bool self = tab[3 * t + 2] != 0;
     const int nW = (P + 63) / 64;  // mask words that hold points
@@ -576,8 +590,6 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       sg.push_back(e);
     }
     tsp[t + 1] = (int)sg.size();
-    // pair tiles are ordered by ga: stage g ends after its last tile
-    if (!self) for (int g = tab[3 * t]; g < nstages; ++g) { stage_tile[g + 1] = t + 1; stage_seg[g + 1] = tsp[t + 1]; }
     {
       // reduction tree of this tile: groups of RSBA_GRP consecutive segments, but the last segments in groups of 2, 2,
       // 1, 1, 1, 1: a tile is over when its last group has been added, and that group is usually one of the last in order.
@@ -606,7 +618,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
           SchurSeg& e = sg[s0 + i];
           e.tile = t; e.grp = g0 + g; e.grp_seg0 = s0 + i - k; e.grp_nseg = gsize[g];
           e.tile_grp0 = g0; e.tile_ngrp = ng;
-          e.stage = tab[3 * t]; e.stage_ntiles = tiles_of_stage[tab[3 * t]] + 1;   // the stage's pair tiles + its self tile
+          e.stage = stage_of_tile[t]; e.stage_ntiles = tiles_of_stage[stage_of_tile[t]] + 1;   // (set for good below: the arrivals at the stage's counter)
         }
       }
       ngrp += ng;
@@ -633,11 +645,11 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   }
   // arrivals at a stage's counter: its self tile, and per pair tile the finisher — or each of the four quadrant reducers
   {
-    std::vector<int> arrivals(ngroups, 0);
+    std::vector<int> arrivals(nstages, 0);
     self_arrivals = 0;
     for (int t = 0; t < ntiles; ++t) {
       const int n_t = sg[tsp[t]].nred != 0 ? sg[tsp[t]].nred : 1;
-      arrivals[tab[3 * t]] += n_t;
+      arrivals[stage_of_tile[t]] += n_t;
       if (tab[3 * t + 2]) self_arrivals += n_t;
     }
     for (auto& e : sg) e.stage_ntiles = arrivals[e.stage];
@@ -653,10 +665,10 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   // masked search of the 512-point chunks, as below 65 cameras.
   const bool sparse = SparsePairSegments(C, staged);
   if (staged) {
-    for (int g = 0; g < nstages; ++g) {
-      std::vector<int> tiles_g;
-      for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2] && tab[3 * t] == g) tiles_g.push_back(t);
-      for (int t = stage_tile[g]; t < stage_tile[g + 1]; ++t) tiles_g.push_back(t);
+    for (int g : stage_order) {
+      std::vector<int> tiles_g;   // the stage's self tile, then its pair tiles
+      for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2] && stage_of_tile[t] == g) tiles_g.push_back(t);
+      for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2] && stage_of_tile[t] == g) tiles_g.push_back(t);
       // the stage's tiles interleaved by position, so that the stage as a whole runs long blocks first, short ones last
       // and all its tiles end together
       // (the self tile's segments ahead of the pair tiles', so that its slower finish — seven reducers, a tile sum — ends early: 0.400
@@ -693,12 +705,14 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     std::stable_sort(ord.begin(), ord.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
     for (const auto& o : ord) border_first.push_back(o.second);
     for (int t = 0; t < ntiles; ++t) if (tab[3 * t + 2]) for (int q : red_of_tile[t]) border_first.push_back(q);
-    for (int g = 0; g < nstages; ++g) {
+    for (int g : stage_order) {
+      std::vector<int> pair_g;
+      for (int t = 0; t < ntiles; ++t) if (!tab[3 * t + 2] && stage_of_tile[t] == g) pair_g.push_back(t);
       std::vector<std::pair<double, int>> op;
-      for (int t = stage_tile[g]; t < stage_tile[g + 1]; ++t) for (int q = tsp[t]; q < tsp[t + 1]; ++q) op.push_back({(q - tsp[t] + 0.5) / (tsp[t + 1] - tsp[t]), q});
+      for (int t : pair_g) for (int q = tsp[t]; q < tsp[t + 1]; ++q) op.push_back({(q - tsp[t] + 0.5) / (tsp[t + 1] - tsp[t]), q});
       std::stable_sort(op.begin(), op.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
       for (const auto& o : op) border_first.push_back(o.second);
-      for (int t = stage_tile[g]; t < stage_tile[g + 1]; ++t) for (int q : red_of_tile[t]) border_first.push_back(q);
+      for (int t : pair_g) for (int q : red_of_tile[t]) border_first.push_back(q);
     }
     if ((int)border_first.size() != nblocks) border_first.clear();   // (cannot happen)
   }
@@ -1131,7 +1145,7 @@ static int UploadPoints(rsba_solver* s) {
       (rc = DevAlloc(&s->intr, 4 * C)) || (rc = DevAlloc(&s->cam[0], 6 * C)) || (rc = DevAlloc(&s->cam[1], 6 * C)) || (rc = DevAlloc(&s->cam0, 6 * C)) ||
       (rc = DevAlloc(&s->pts[0], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts[1], 3 * (size_t)P)) || (rc = DevAlloc(&s->pts0, 3 * (size_t)P)) ||
       (rc = DevAlloc(&s->camc[0], CC_STRIDE * C)) || (rc = DevAlloc(&s->camc[1], CC_STRIDE * C)) || (rc = DevAlloc(&s->scale_c, 6 * C)) ||
-      (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(MultiCholPadded(s->nc) + 2) * MultiCholPadded(s->nc))) || (rc = DevAlloc(&s->W, (s->nc > RSBA_CHOL_MAXN || s->tiles_small) ? (size_t)(s->nc + 1) * s->nc : 1)) ||
+      (rc = DevAlloc(&s->scale_p, 3 * (size_t)P)) || (rc = DevAlloc(&s->red, s->L.size())) || (rc = DevAlloc(&s->A, (size_t)(MultiCholPadded(s->nc) + 2) * MultiCholPadded(s->nc) + (size_t)6 * RSBA_TG * s->nc /* the border's rows of L behind a smaller leading factor, ba_cholesky_border.hpp */)) || (rc = DevAlloc(&s->W, (s->nc > RSBA_CHOL_MAXN || s->tiles_small) ? (size_t)(s->nc + 1) * s->nc : 1)) ||
       (rc = DevAlloc(&s->chol_ok, 3)) ||
       (rc = DevAlloc(&s->S_copy, (size_t)s->nc * s->nc)) || (rc = DevAlloc(&s->rhs_copy, s->nc)) || (rc = DevAlloc(&s->dcam, s->nc)) ||
       (rc = DevAlloc(&s->small_red, 8)) || (rc = DevAlloc(&s->gmax, 2)) || (rc = DevAlloc(&s->res, RES_SIZE)) || (rc = DevAlloc(&s->dec, 4)) ||
@@ -1200,8 +1214,14 @@ static int UploadPoints(rsba_solver* s) {
       if (!s->chol_diag) s->chol_wgs = 1;   // (more blocks per row workgroup than the diagonal-chain kernel keeps sums for: one workgroup)
 #endif
       if (s->chol_diag && (rc = DevAlloc(&s->mc_dg, (size_t)2 * (np_d + 1) * 1024))) return rc;   // look-ahead sums | blocks as handed over
+      {
+        // the last camera group as a border: three camera groups or more, the tiled Schur kernel, one rank
+        static const bool border_env = getenv("RSBA_BORDER") && atoi(getenv("RSBA_BORDER")) != 0;
+        const int ngroups = (C + RSBA_TG - 1) / RSBA_TG;
+        if (border_env && s->chol_diag && !s->comm && ngroups >= 3) s->border_cols = 6 * RSBA_TG * (ngroups - 1);
+      }
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(DiagCholLdsDoubles(s->nc) * sizeof(double))));
+                                 (int)(std::max(DiagCholLdsDoubles(s->nc), BorderLdsDoubles(s->nc)) * sizeof(double))));
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(DiagCholLdsDoubles(s->nc) * sizeof(double))));
       if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, 8 * 16 * 8))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, 8 * 16 * 8 * sizeof(long long))); }
@@ -1250,7 +1270,7 @@ static int UploadPoints(rsba_solver* s) {
   }
   if (s->pipelined && s->nc > RSBA_CHOL_MAXN && s->tc_tiles == 0) s->pipelined = false;   // (the persistent tiles did not fit after all)
   if (s->opt.schur_impl != 0) {
-    rc = s->tiled.Build(C, P, ptr, cam, u, v, sl_q, s->pipelined);
+    rc = s->tiled.Build(C, P, ptr, cam, u, v, sl_q, s->pipelined, s->border_cols > 0);
     if (rc != RSBA_OK) return rc;
   } else if (maxk > 64) {
     fprintf(stderr, "rsba: schur_impl=0 handles at most 64 views per point (problem has %d)\n", maxk);
@@ -1686,12 +1706,14 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       const int* gate_ready = mg ? s->ready_global : ts.ready;
       const long long gate_budget = mg ? 10 * RSBA_STALL_TICKS : 0;
       if (s->chol_wgs > 1 && s->chol_diag) {
-        const StageGate sg{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + RSBA_READY_SOLVED, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + RSBA_READY_STARTED, resident_word, s->chol_wgs, all_diag, mg ? 1 : 0};
+        const int wgs = s->chol_wgs + (s->border_cols > 0 ? 1 : 0);   // (the border's workgroup is the launch's last)
+        const size_t lds_d = (s->border_cols > 0 ? std::max(DiagCholLdsDoubles(s->border_cols), BorderLdsDoubles(n)) : DiagCholLdsDoubles(n)) * sizeof(double);
+        const StageGate sg{gate_ready, gate_tag, 6 * RSBA_TG, ts.ready + RSBA_READY_SOLVED, T.all_kernels() ? s->chol_waited : nullptr, s->trace, gate_budget, ts.ready + RSBA_READY_STARTED, resident_word, wgs, all_diag, mg ? 1 : 0};
         const DiagCholFlags df{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024};
         if (mg) k_reduced_system_solve_diag<true><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
             C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok, sg, df, tag, s->mc_trace);
-        else k_reduced_system_solve_diag<false><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
-            C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok, sg, df, tag, s->mc_trace);
+        else k_reduced_system_solve_diag<false><<<wgs, 512, lds_d, s->sB>>>(
+            C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok, sg, df, tag, s->mc_trace, AheadSel{}, s->border_cols);
       }
 #ifdef RSBA_EXPERIMENTAL
       else if (s->chol_wgs > 1 && !mg)   // (the round-robin kernel has no transposed source: multi-GPU, it is the one-workgroup kernel)
@@ -1782,10 +1804,11 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(s->nc)) * sizeof(double);
     T.Begin("k_reduced_system_solve", st);
     if (s->chol_wgs > 1 && !keep_system_copy && s->chol_diag)
-      k_reduced_system_solve_diag<false><<<s->chol_wgs, 512, DiagCholLdsDoubles(s->nc) * sizeof(double), st>>>(
+      k_reduced_system_solve_diag<false><<<s->chol_wgs + (s->border_cols > 0 ? 1 : 0), 512,
+                                           (s->border_cols > 0 ? std::max(DiagCholLdsDoubles(s->border_cols), BorderLdsDoubles(s->nc)) : DiagCholLdsDoubles(s->nc)) * sizeof(double), st>>>(
           C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ip, s->chol_ok,
           StageGate{nullptr, 0, 0, nullptr, nullptr, nullptr, 0}, DiagCholFlags{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024},
-          s->step_tag, s->mc_trace);
+          s->step_tag, s->mc_trace, AheadSel{}, s->border_cols);
 #ifdef RSBA_EXPERIMENTAL
     else if (s->chol_wgs > 1 && !keep_system_copy)
       k_reduced_system_solve_multi<<<s->chol_wgs, 512, MultiCholLdsDoubles(s->nc) * sizeof(double), st>>>(
@@ -1980,7 +2003,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   };
   if (s->dec_step && !comm_tail) {
     queue_damping();
-    if (ahead_env && s->ahead_ok && pipe && !pipe_tiles && !s->pipelined_mg && !s->pipe_serial && s->chol_wgs > 1 && s->chol_diag && !keep_system_copy &&
+    if (ahead_env && s->ahead_ok && pipe && !pipe_tiles && !s->pipelined_mg && !s->pipe_serial && s->chol_wgs > 1 && s->chol_diag && s->border_cols == 0 && !keep_system_copy &&
         !T.all_kernels() && !(s->trace && !s->trace_ring) && !s->wg_trace && !s->test_stall)
       launch_ahead();
   }
@@ -2037,7 +2060,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     HIPCHK(hipMemcpy(h, s->trace, sizeof(h), hipMemcpyDeviceToHost));
     const long long t0 = h[24];
     fprintf(stderr, "rsba[trace] us since first tile block: chol start %.1f ready0 seen %.1f | gates (wait..pass)", (h[0] - t0) * 0.01, (h[1] - t0) * 0.01);
-    for (int g = 0; g < s->tiled.nstages; ++g) fprintf(stderr, " %.1f..%.1f", (h[2 + 2 * g] - t0) * 0.01, (h[3 + 2 * g] - t0) * 0.01);
+    for (int g = 0; g < std::min(s->tiled.nstages, 4); ++g) fprintf(stderr, " %.1f..%.1f", (h[2 + 2 * g] - t0) * 0.01, (h[3 + 2 * g] - t0) * 0.01);
     fprintf(stderr, " factored %.1f back-substituted %.1f end %.1f | published: self %.1f stages", (h[13] - t0) * 0.01, (h[14] - t0) * 0.01, (h[15] - t0) * 0.01, (h[16] - t0) * 0.01);
     for (int g = 0; g < s->tiled.nstages; ++g) fprintf(stderr, " %.1f", (h[17 + g] - t0) * 0.01);
     if (s->comm) fprintf(stderr, " | after the solve: candidate sums start +%.1f, publish +%.1f", (h[26] - h[15]) * 0.01, (h[27] - h[15]) * 0.01);
@@ -2663,6 +2686,11 @@ void rsba_solver_destroy(rsba_solver* s) {
       for (int w = 0; w < s->chol_wgs; ++w) for (int p = 0; p < s->nc / 32; ++p) {
         fprintf(stderr, "rsba[mc] wg %d panel %2d:", w, p);
         for (int k = 0; k < 8; ++k) { const long long v = h[((size_t)w * 16 + p) * 8 + k]; fprintf(stderr, " %7.2f", v ? (v - t0) / 100.0 : -1.0); }
+        fprintf(stderr, "\n");
+      }
+      if (s->border_cols > 0) {   // the border's workgroup: BorderWorkgroup's stamps (ba_cholesky_border.hpp)
+        fprintf(stderr, "rsba[mc] border:");
+        for (int k = 0; k < 20; ++k) { const long long v = h[(size_t)s->chol_wgs * 16 * 8 + k]; fprintf(stderr, " %d:%.2f", k, v ? (v - t0) / 100.0 : -1.0); }
         fprintf(stderr, "\n");
       }
     }
