@@ -53,11 +53,33 @@ struct BorderCtx {
 #define RSBA_BORDER_CTX_DOUBLES 64   // the workgroup's BorderCtx and its flag word, at the end of its carve
 static_assert(sizeof(BorderCtx) + 8 <= RSBA_BORDER_CTX_DOUBLES * sizeof(double), "BorderCtx");
 __host__ __device__ inline size_t BorderLdsDoubles(int nc) {
-  return (size_t)RSBA_BW * RSBA_BLD + 6 * RSBA_PB * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD + RSBA_BW + (size_t)nc + RSBA_BW + 2 * RSBA_BW + RSBA_BORDER_CTX_DOUBLES;
+  return (size_t)RSBA_BW * RSBA_BLD + 6 * RSBA_PB * RSBA_PLD + 3 * RSBA_PB * RSBA_PLD + RSBA_BW + (size_t)nc + RSBA_BW + 2 * RSBA_BW + (size_t)nc + RSBA_BORDER_CTX_DOUBLES;
 }
 
 // block (i, j), i >= j, of the border's 3 x 3 blocks in the packed lower block triangle
 __device__ __forceinline__ int BorderBlk(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// acc += A[oa + 4 k] * B[ob + 4 k], k < NK (one 16 x 16 tile over 4 NK columns of both operands, LDS): ALL the operands are asked for
+// before the first matrix-core instruction — read where they are used, every instruction waited for its own two LDS reads
+// (~100 cycles in front of 64 of arithmetic, in order), and the products ran at half the matrix cores' rate.
+template <int NK>
+__device__ __forceinline__ d4_t BorderMfmaStrip(const double* A, int oa, const double* B, int ob, d4_t acc) {
+  double av[NK], bv[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) { av[k] = A[oa + 4 * k]; bv[k] = B[ob + 4 * k]; }
+#pragma unroll
+  for (int k = 0; k < NK; ++k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], bv[k], acc, 0, 0, 0);
+  return acc;
+}
+// ... two tiles that share the A operand (B rows 16 apart)
+template <int NK>
+__device__ __forceinline__ void BorderMfmaStrip2(const double* A, int oa, const double* B, int ob, d4_t& a0, d4_t& a1) {
+  double av[NK], b0[NK], b1[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) { av[k] = A[oa + 4 * k]; b0[k] = B[ob + 4 * k]; b1[k] = B[ob + 16 * RSBA_PLD + 4 * k]; }
+#pragma unroll
+  for (int k = 0; k < NK; ++k) { a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], b0[k], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], b1[k], a1, 0, 0, 0); }
+}
 
 // (LDS pointers keep their address space across the call: ds_read / ds_write in here, not flat accesses)
 typedef __attribute__((address_space(3))) const BorderCtx lds_BorderCtx;
@@ -86,6 +108,7 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
   double* scl = invd + RSBA_BW;                      // nA + 96
   double* rB = scl + nA + RSBA_BW;                   // 96: right-hand side of the border, then y_C
   double* xB = rB + RSBA_BW;                         // 96
+  double* yA2 = xB + RSBA_BW;                        // nA: y_A = L_A^-1 b_A, once the leading system is through
   int& sb_ok = *(int*)((__attribute__((address_space(3))) int*)(bcp + 1));   // (behind the constants: no static LDS)
   if (tid == 0) sb_ok = 1;
   const long long gbudget = bc.gate_budget > 0 ? bc.gate_budget : RSBA_STALL_TICKS;
@@ -133,12 +156,7 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
       int oa = (i0 + mi) * RSBA_BLD + RSBA_PB * p + kk, ob = mi * RSBA_PLD + kk, oc = (i0 + kk) * RSBA_BLD + RSBA_PB * p + mi;
       RSBA_OPQ(oa); RSBA_OPQ(ob); RSBA_OPQ(oc);
       d4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-#pragma unroll
-      for (int qs = 0; qs < RSBA_PB; qs += 4) {
-        const double a = R[oa + qs];
-        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[ob + qs], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[ob + 16 * RSBA_PLD + qs], a1, 0, 0, 0);
-      }
+      BorderMfmaStrip2<8>(R, oa, T, ob, a0, a1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) { R[oc + 4 * q * RSBA_BLD] = a0[q]; R[oc + 4 * q * RSBA_BLD + 16] = a1[q]; }
     }
@@ -149,12 +167,7 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
       int oa = (i0 + mi) * RSBA_BLD + RSBA_PB * q + kk, ob = mi * RSBA_PLD + kk, oc = (i0 + kk) * RSBA_BLD + RSBA_PB * p + mi;
       RSBA_OPQ(oa); RSBA_OPQ(ob); RSBA_OPQ(oc);
       d4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-#pragma unroll
-      for (int qs = 0; qs < RSBA_PB; qs += 4) {
-        const double a = R[oa + qs];
-        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lb[ob + qs], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lb[ob + 16 * RSBA_PLD + qs], a1, 0, 0, 0);
-      }
+      BorderMfmaStrip2<8>(R, oa, Lb, ob, a0, a1);
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) { R[oc + 4 * t4 * RSBA_BLD] -= a0[t4]; R[oc + 4 * t4 * RSBA_BLD + 16] -= a1[t4]; }
     }
@@ -196,18 +209,32 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < 5; ++u) {
-        const int t = wave + 8 * u;
+        int t = wave + 8 * u;
+        RSBA_OPQ(t);   // (the tile's offsets formed HERE, every chunk: hoisted out of the chunk loop they are spilled, and the reload's wait also
+                       //  waits for the next chunk's loads from memory — nothing overlapped)
         if (t < 36) {
           const int ti = t / 6, tj = t - 6 * ti;
           int oa = (16 * ti + mi) * RSBA_BLD + k0 + kk, ob = (16 * tj + mi) * RSBA_PLD + kk;
           RSBA_OPQ(oa); RSBA_OPQ(ob);
-#pragma unroll
-          for (int qs = 0; qs < RSBA_PB; qs += 4)
-            P[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(R[oa + qs], AB[ob + qs], P[u], 0, 0, 0);
+          P[u] = BorderMfmaStrip<8>(R, oa, AB, ob, P[u]);
         }
       }
     }
     __syncthreads();
+  };
+  // sum X X' += X_g[:, k0:k1) X_g[:, k0:k1)': 24 tiles (the diagonal blocks whole), tile q = wave + 8 u
+  auto syrk = [&](int k0, int k1) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int q = wave + 8 * u, blk = q >> 2, ti = (q >> 1) & 1, tj = q & 1;
+      const int bi = blk == 0 ? 0 : (blk < 3 ? 1 : 2), bj = blk - bi * (bi + 1) / 2;
+      int oa = (RSBA_PB * bi + 16 * ti + mi) * RSBA_BLD + kk + k0, ob = (RSBA_PB * bj + 16 * tj + mi) * RSBA_BLD + kk + k0, oc = blk * RSBA_PB * RSBA_PLD + (16 * ti + kk) * RSBA_PLD + 16 * tj + mi;
+      RSBA_OPQ(oa); RSBA_OPQ(ob); RSBA_OPQ(oc);
+      d4_t xx = {0, 0, 0, 0};
+      for (int ks = 0; ks < k1 - k0; ks += RSBA_PB) xx = BorderMfmaStrip<8>(R, oa + ks, R, ob + ks, xx);
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) Cb[oc + 4 * t4 * RSBA_PLD] += xx[t4];
+    }
   };
   d4_t P1[5], P2[5];   // X[:, groups before] L_A[group, groups before]' of the next group and of the one after it (at most four groups: B <= 3)
 #pragma unroll
@@ -264,46 +291,56 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
 #pragma unroll
         for (int u = 0; u < 2; ++u) { const int e = tid + u * nt; l2[u] = A[(size_t)(c0 + RSBA_PB * pp + (e >> 5)) * nA + c0 + RSBA_PB * q + (e & 31)]; }
       };
-      double t0[2], t1[2], t2[2], l10[2], l20[2], l21[2];
+      double t0[2], t1[2], t2[2] = {0.0, 0.0}, l10[2], l20[2], l21[2];
+      // (is the last panel factored already?  Then its T rides with the others: the wait above ends in a barrier, the peek is one more)
+      if (tid == 0) sb_w = __hip_atomic_load(bc.tdone + 3 * g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag ? 1 : 0;
+      __syncthreads();
+      const bool all_up = sb_w != 0;
+      if (all_up) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       load_T(0, t0); load_L(1, 0, l10); load_L(2, 0, l20); load_T(1, t1); load_L(2, 1, l21);
+      if (all_up) load_T(2, t2);
       store_T(Tt, t0); store_L(Tt + RSBA_PB * RSBA_PLD, l10); store_L(Tt + 2 * RSBA_PB * RSBA_PLD, l20);
       __syncthreads();
+      if (g == B - 1) RSBA_BORDER_STAMP(20);
       solve_T(0, Tt); update_L(0, 1, Tt + RSBA_PB * RSBA_PLD); update_L(0, 2, Tt + 2 * RSBA_PB * RSBA_PLD);
       __syncthreads();
       store_T(Tt, t1); store_L(Tt + RSBA_PB * RSBA_PLD, l21);
+      if (all_up) store_T(Tt + 2 * RSBA_PB * RSBA_PLD, t2);
       __syncthreads();
       solve_T(1, Tt); update_L(1, 2, Tt + RSBA_PB * RSBA_PLD);
-      if (!WaitFlagWG(bc.tdone + 3 * g + 2, tag, bc.error, bc.budget)) { stalled = true; break; }
-      load_T(2, t2);
-      store_T(Tt, t2);
-      __syncthreads();
-      solve_T(2, Tt);
+      // (the first two panels' columns of X_g are final: their part of the sum while the last panel's T is on its way — the wait ends in
+      //  the barrier the sum needs in front of it)
+      if (!all_up) {
+        if (!WaitFlagWG(bc.tdone + 3 * g + 2, tag, bc.error, bc.budget)) { stalled = true; break; }
+        load_T(2, t2);
+      } else __syncthreads();
+      if (g == B - 1) RSBA_BORDER_STAMP(21);
+      syrk(0, 2 * RSBA_PB);
+      if (g == B - 1) RSBA_BORDER_STAMP(22);
+      if (!all_up) {
+        store_T(Tt + 2 * RSBA_PB * RSBA_PLD, t2);
+        __syncthreads();
+      }
+      solve_T(2, Tt + 2 * RSBA_PB * RSBA_PLD);
     }
     if (stalled) break;
     __syncthreads();
     RSBA_BORDER_STAMP(3 + 4 * g);
-    // X_g to memory (read back by the back-substitution's right-hand side; nobody waits for the stores here)
-    for (int e = tid; e < RSBA_BW * RSBA_BW; e += nt) { const int i = e / RSBA_BW, j = e - RSBA_BW * i; XB[(size_t)i * nA + c0 + j] = R[i * RSBA_BLD + j]; }
-    // the sum X X': 24 tiles (the diagonal blocks whole), tile q = wave + 8 u
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int q = wave + 8 * u, blk = q >> 2, ti = (q >> 1) & 1, tj = q & 1;
-      const int bi = blk == 0 ? 0 : (blk < 3 ? 1 : 2), bj = blk - bi * (bi + 1) / 2;
-      int oa = (RSBA_PB * bi + 16 * ti + mi) * RSBA_BLD + kk, ob = (RSBA_PB * bj + 16 * tj + mi) * RSBA_BLD + kk, oc = blk * RSBA_PB * RSBA_PLD + (16 * ti + kk) * RSBA_PLD + 16 * tj + mi;
-      RSBA_OPQ(oa); RSBA_OPQ(ob); RSBA_OPQ(oc);
-      d4_t xx = {0, 0, 0, 0};
-#pragma unroll
-      for (int ks = 0; ks < RSBA_BW; ks += 4) xx = __builtin_amdgcn_mfma_f64_16x16x4f64(R[oa + ks], R[ob + ks], xx, 0, 0, 0);
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) Cb[oc + 4 * t4 * RSBA_PLD] += xx[t4];
+    // the group's entries of y_A = L_A^-1 b_A (for r -= X_g y_g below): final once the right-hand-side row is through the group's panels — it is
+    // a row workgroup's (block np of the leading system) until the last two panels, the diagonal workgroup's then; asked for ahead of the sum
+    // (the last group's own: behind the last tile, below — its entries of the last panel come with the end of the leading system)
+    const bool last = g == B - 1;
+    double yg_v = 0.0;
+    if (!last) {
+      if (!wait_progress(1 + npA % gm, 3 * g + 3)) { stalled = true; break; }
+      if (tid < RSBA_BW) yg_v = A[(size_t)nA * nA + c0 + tid];
     }
-    // the border's right-hand side: r -= X_g y_g, once the group's entries of y_A = L_A^-1 b_A are final — the right-hand-side row
-    // is a row workgroup's (block np of the leading system) until the last two panels, the diagonal workgroup's then
-    {
-      const bool last = g == B - 1;
-      if (last ? !WaitFlagWG(bc.a_done, tag, bc.error, bc.budget) : !wait_progress(1 + npA % gm, 3 * g + 3)) { stalled = true; break; }
-      double* yg = Tt;   // 96
-      if (tid < RSBA_BW) yg[tid] = A[(size_t)nA * nA + c0 + tid];
+    syrk(2 * RSBA_PB, RSBA_BW);
+    if (g == B - 1) RSBA_BORDER_STAMP(23);
+    // the border's right-hand side: r -= X_g y_g
+    if (!last) {
+      double* yg = Tt;   // 96 (the tiles have been read: the barrier in front of the stamp above)
+      if (tid < RSBA_BW) yg[tid] = yg_v;
       __syncthreads();
       if (tid < 4 * RSBA_BW) {
         const int i = tid >> 2, part = tid & 3;
@@ -315,6 +352,8 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
         if (part == 0) rB[i] -= sum;
       }
     }
+    // X_g to memory (read back by the back-substitution's right-hand side; nobody waits for the stores here)
+    for (int e = tid; e < RSBA_BW * RSBA_BW; e += nt) { const int i = e / RSBA_BW, j = e - RSBA_BW * i; XB[(size_t)i * nA + c0 + j] = R[i * RSBA_BLD + j]; }
     RSBA_BORDER_STAMP(4 + 4 * g);
     // X_g's part of the later groups' products, as soon as those groups' rows of the leading factor hold the columns of group g:
     // the group after the next first (its rows have them since their row workgroups went through panel 3 g + 2), then the next
@@ -326,15 +365,17 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
     }
     if (g + 1 < B) {
       if (!WaitFlagWG(bc.strip_ready + 3 * (g + 1) + 1, tag, bc.error, bc.budget) || !WaitFlagWG(bc.rows_ready + 3 * (g + 1) + 2, tag, bc.error, bc.budget)) { stalled = true; break; }
+      if (g == B - 2) RSBA_BORDER_STAMP(24);
       product(P1, g + 1, c0);
+      if (g == B - 2) RSBA_BORDER_STAMP(25);
     }
   }
 
-  // ---- y_A into LDS (the back-substitution's right-hand side); the border's own gradient entries come with the last tile
-  double* yA = R;   // nA (stays at lds[0 ..)
+  // ---- y_A into LDS, once the leading system is through; the border's own gradient entries come with the last tile
+  double* yA = R;   // nA, at lds[0 ..): the back-substitution's right-hand side (R holds the last group's X until r has taken its part)
+  if (!stalled && !WaitFlagWG(bc.a_done, tag, bc.error, bc.budget)) stalled = true;
   if (!stalled) {
-    __syncthreads();   // (R has been read: the last group's right-hand-side product)
-    for (int j = tid; j < nA; j += nt) yA[j] = A[(size_t)nA * nA + j];
+    for (int j = tid; j < nA; j += nt) yA2[j] = A[(size_t)nA * nA + j];
     RSBA_BORDER_STAMP(14);
     // ---- the last tile: C' = C (scaled, damped; identity where the border is padded) - sum X X'
     if (bc.gated && !WaitFlagWG(bc.gate_ready + 1 + 2 * B, bc.gate_tag, bc.error, gbudget)) stalled = true;
@@ -371,6 +412,18 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
     if (tid < nB) rB[tid] += scl[nA + tid] * (bc.gc[nA + tid] + bc.corr[nA + tid]);
   }
   __builtin_amdgcn_s_waitcnt(0);   // (every thread's stores of X are performed: the wavefronts below read it back)
+  __syncthreads();
+  // r -= X_g y_g of the last group, X_g where it still lies in R
+  if (tid < 4 * RSBA_BW) {
+    const int i = tid >> 2, part = tid & 3;
+    const double* yg = yA2 + RSBA_BW * (B - 1);
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < 24; ++j) sum = fma(R[i * RSBA_BLD + 24 * part + j], yg[24 * part + j], sum);
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    if (part == 0) rB[i] -= sum;
+  }
   __syncthreads();
   // ---- L_C: three panels where they lie, then y_C = L_C^-1 r and x_C = L_C^-T y_C — wavefront 0.  The others form the products between
   // the panels and, before anything else, ask for all of X (96 x nA, 221 KB through this one compute unit: 8 us if waited for) — rows
@@ -450,12 +503,7 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
         int oa = (i0 + mi) * RSBA_PLD + kk, ob = mi * RSBA_PLD + kk, oc = (i0 + kk) * RSBA_PLD + mi;
         RSBA_OPQ(oa); RSBA_OPQ(ob); RSBA_OPQ(oc);
         d4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-#pragma unroll
-        for (int qs = 0; qs < RSBA_PB; qs += 4) {
-          const double a = X[oa + qs];
-          a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[ob + qs], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[ob + 16 * RSBA_PLD + qs], a1, 0, 0, 0);
-        }
+        BorderMfmaStrip2<8>(X, oa, T, ob, a0, a1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { X[oc + 4 * q * RSBA_PLD] = a0[q]; X[oc + 4 * q * RSBA_PLD + 16] = a1[q]; }
       }
@@ -470,8 +518,7 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
         int oa = (16 * ti + mi) * RSBA_PLD + kk, ob = (16 * tj + mi) * RSBA_PLD + kk, oc = BorderBlk(bi, bj) * RSBA_PB * RSBA_PLD + (16 * ti + kk) * RSBA_PLD + 16 * tj + mi;
         RSBA_OPQ(oa); RSBA_OPQ(ob); RSBA_OPQ(oc);
         d4_t xx = {0, 0, 0, 0};
-#pragma unroll
-        for (int qs = 0; qs < RSBA_PB; qs += 4) xx = __builtin_amdgcn_mfma_f64_16x16x4f64(Xi[oa + qs], Xj[ob + qs], xx, 0, 0, 0);
+        xx = BorderMfmaStrip<8>(Xi, oa, Xj, ob, xx);
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) Cb[oc + 4 * t4 * RSBA_PLD] -= xx[t4];
       }
@@ -494,7 +541,7 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
     double sum = vpart[tid];
 #pragma unroll
     for (int k = 1; k < 7; ++k) sum += vpart[k * nA + tid];
-    yA[tid] -= sum;
+    yA[tid] = yA2[tid] - sum;
   }
   // what the camera step needs from memory, asked for ahead of the back-substitution (see k_reduced_system_solve_diag)
   const int nreal = nA + nB;

@@ -1216,7 +1216,7 @@ static int UploadPoints(rsba_solver* s) {
       if (s->chol_diag && (rc = DevAlloc(&s->mc_dg, (size_t)2 * (np_d + 1) * 1024))) return rc;   // look-ahead sums | blocks as handed over
       {
         // the last camera group as a border: three camera groups or more, the tiled Schur kernel, one rank
-        static const bool border_env = getenv("RSBA_BORDER") && atoi(getenv("RSBA_BORDER")) != 0;
+        static const bool border_env = !(getenv("RSBA_BORDER") && atoi(getenv("RSBA_BORDER")) == 0);   // (RSBA_BORDER=0: all camera groups through the diagonal-chain kernel)
         const int ngroups = (C + RSBA_TG - 1) / RSBA_TG;
         if (border_env && s->chol_diag && !s->comm && ngroups >= 3) s->border_cols = 6 * RSBA_TG * (ngroups - 1);
       }
@@ -2690,7 +2690,7 @@ void rsba_solver_destroy(rsba_solver* s) {
       }
       if (s->border_cols > 0) {   // the border's workgroup: BorderWorkgroup's stamps (ba_cholesky_border.hpp)
         fprintf(stderr, "rsba[mc] border:");
-        for (int k = 0; k < 20; ++k) { const long long v = h[(size_t)s->chol_wgs * 16 * 8 + k]; fprintf(stderr, " %d:%.2f", k, v ? (v - t0) / 100.0 : -1.0); }
+        for (int k = 0; k < 26; ++k) { const long long v = h[(size_t)s->chol_wgs * 16 * 8 + k]; fprintf(stderr, " %d:%.2f", k, v ? (v - t0) / 100.0 : -1.0); }
         fprintf(stderr, "\n");
       }
     }
