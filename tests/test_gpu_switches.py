@@ -20,6 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SETTINGS = [
     ({}, ["c40", "c64_huber", "c70_huber", "c130", "c240"]),
     ({"RSBA_PIPELINE": "0"}, ["c40", "c64_huber"]),
+    ({"RSBA_BORDER": "0"}, ["c40", "c64_huber", "c33_long"]),   # (every camera group through the diagonal-chain kernel: the default before the border)
+    ({"RSBA_BORDER": "0", "RSBA_PIPELINE": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_CHOL_WGS": "1"}, ["c40", "c64_huber"]),
     ({"RSBA_CHOL_WGS": "3"}, ["c64_huber"]),
     ({"RSBA_BACKSUB_PROJ": "0"}, ["c40", "c64_huber", "c130"]),
