@@ -81,3 +81,17 @@ for f in default driver_cmd cfg5_shard cfg4_shard comm1rank_sequential comm1rank
 import json
 d=json.loads(open('$O/r05_bench_$f.json').read().strip().splitlines()[-1])
 print('$f', round(d['ms_per_step'],4), {k:round(v['avg_us'],1) for k,v in d.get('kernels',{}).items()}, d.get('cpu_baseline',{}).get('by_threads'))"; done
+# ---- the factorisation's chains: the diagonal workgroup's panels, the row workgroups, the border's workgroup (tools/mc_chain.py)
+RSBA_TRACE=1 RSBA_MC_TRACE=1 python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 --no-events > /dev/null 2> $O/mc_cfg3.err
+python3 tools/mc_chain.py $O/mc_cfg3.err > $O/r05_cholesky_diag_timeline_pipelined.txt
+grep "rsba\[trace\]" $O/mc_cfg3.err | tail -3 > $O/r05_step_stamps_cfg3.txt
+RSBA_BORDER=0 RSBA_TRACE=1 RSBA_MC_TRACE=1 python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 --no-events > /dev/null 2> $O/mc_cfg3_noborder.err
+python3 tools/mc_chain.py $O/mc_cfg3_noborder.err > $O/r05_cholesky_diag_timeline_pipelined_noborder.txt
+grep "rsba\[trace\]" $O/mc_cfg3_noborder.err | tail -3 > $O/r05_step_stamps_cfg3_noborder.txt
+# ---- the border against the diagonal-chain kernel alone, alternating on this box
+for i in 1 2 3; do
+  RSBA_BORDER=0 python3 bench.py --no-cpu-baseline --steps 50 --warmup 3 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('RSBA_BORDER=0', d['ms_per_step'], d['ms_per_step_steady'])" >> $O/r05_border_ab.txt
+  python3 bench.py --no-cpu-baseline --steps 50 --warmup 3 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('default      ', d['ms_per_step'], d['ms_per_step_steady'])" >> $O/r05_border_ab.txt
+done
+# ---- solver lifetimes and long runs at several camera counts (the border's workgroup, the flags' hand-overs)
+for c in 33 40 48 56 64; do python3 tools/stress_pipeline.py $c 2>&1 | grep -v "NCCL\|RCCL" | tail -3 >> $O/r05_stress_pipeline.txt; done
