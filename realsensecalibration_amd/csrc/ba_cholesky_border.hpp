@@ -352,8 +352,8 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
         if (part == 0) rB[i] -= sum;
       }
     }
-    // X_g to memory (read back by the back-substitution's right-hand side; nobody waits for the stores here)
-    for (int e = tid; e < RSBA_BW * RSBA_BW; e += nt) { const int i = e / RSBA_BW, j = e - RSBA_BW * i; XB[(size_t)i * nA + c0 + j] = R[i * RSBA_BLD + j]; }
+    // X_g to memory (read back for X' x_C; nobody waits for the stores here; the last group's leave behind the last tile's loads, below)
+    if (!last) { for (int e = tid; e < RSBA_BW * RSBA_BW; e += nt) { const int i = e / RSBA_BW, j = e - RSBA_BW * i; XB[(size_t)i * nA + c0 + j] = R[i * RSBA_BLD + j]; } }
     RSBA_BORDER_STAMP(4 + 4 * g);
     // X_g's part of the later groups' products, as soon as those groups' rows of the leading factor hold the columns of group g:
     // the group after the next first (its rows have them since their row workgroups went through panel 3 g + 2), then the next
@@ -375,7 +375,6 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
   double* yA = R;   // nA, at lds[0 ..): the back-substitution's right-hand side (R holds the last group's X until r has taken its part)
   if (!stalled && !WaitFlagWG(bc.a_done, tag, bc.error, bc.budget)) stalled = true;
   if (!stalled) {
-    for (int j = tid; j < nA; j += nt) yA2[j] = A[(size_t)nA * nA + j];
     RSBA_BORDER_STAMP(14);
     // ---- the last tile: C' = C (scaled, damped; identity where the border is padded) - sum X X'
     if (bc.gated && !WaitFlagWG(bc.gate_ready + 1 + 2 * B, bc.gate_tag, bc.error, gbudget)) stalled = true;
@@ -396,6 +395,10 @@ static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_doub
       sv[u] = S[(size_t)(nA + min(gi, nB - 1)) * ld + nA + min(gj, nB - 1)];   // (every lane a valid address: no branch per load)
       du[u] = gi == gj ? bc.diag_u[nA + min(gi, nB - 1)] : 0.0;
     }
+    // (behind the tile's loads, while they are on their way: y_A, and the last group's X to memory)
+    const double ya_v = tid < nA ? A[(size_t)nA * nA + tid] : 0.0;
+    { const int c0 = RSBA_BW * (B - 1); for (int e = tid; e < RSBA_BW * RSBA_BW; e += nt) { const int i = e / RSBA_BW, j = e - RSBA_BW * i; XB[(size_t)i * nA + c0 + j] = R[i * RSBA_BLD + j]; } }
+    if (tid < nA) yA2[tid] = ya_v;
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
       const int e = tid + u * nt, blk = e >> 10, r = (e >> 5) & 31, c = e & 31;
