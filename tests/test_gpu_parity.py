@@ -738,7 +738,9 @@ def test_golden_fixtures_through_time_elimination(oracle, tmp_path):
 
 # ------------------------------------------------------------------ constant camera blocks
 @pytest.mark.parametrize("shape,const,impl", [((8, 2000, 6), (0,), 1), ((24, 3000, 8), (0, 17), 1), ((8, 1500, 6), (3,), 0),
-                                              ((70, 1500, 10), (0, 69), 1), ((40, 20000, 8), (0, 21), 1)])
+                                              ((70, 1500, 10), (0, 69), 1), ((40, 20000, 8), (0, 21), 1),
+                                              # (a constant camera in the reduced system's BORDER — the last camera group, ba_cholesky_border.hpp — and in its leading part)
+                                              ((40, 6000, 8), (3, 37), 1), ((64, 4000, 10), (63,), 1), ((33, 3000, 7), (32,), 1)])
 def test_constant_cameras_match_oracle(oracle, shape, const, impl):
     """Problem::SetParameterBlockConstant on camera blocks: the cameras keep their bits, the rest follows the oracle's
     trajectory (Jacobian columns dropped, norms without the constant blocks).  (40 cameras x 20k points: every pair tile has
