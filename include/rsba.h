@@ -134,7 +134,7 @@ typedef struct rsba_schedule_info {
   int32_t stalls;          /* steps whose in-kernel wait ran out of its budget and were repeated sequentially */
   int32_t fallbacks;       /* permanent fallbacks taken (third pipeline stall; one-workgroup / multi-launch factorisation) */
   int32_t comm_nranks;     /* ranks of the communicator (1: none) */
-  int32_t chol_workgroups; /* workgroups of the reduced system's factorisation (resident tiles above 64 cameras) */
+  int32_t chol_workgroups; /* workgroups of the reduced system's factorisation (resident tiles above 64 cameras; 33 .. 64 cameras on one rank: six + the border's) */
   int32_t schur_impl;      /* as run: 0 when a shard with duplicate observations fell back to the atomic kernel */
   char comm_kind[16];      /* "none" | "rccl" | "loopback" | "shm" */
 } rsba_schedule_info;

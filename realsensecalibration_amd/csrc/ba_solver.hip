@@ -2385,7 +2385,7 @@ int rsba_solver_schedule_info(const rsba_solver* s, rsba_schedule_info* out) {
   out->stalls = s->pipe_stalls + s->other_stalls;
   out->fallbacks = (s->pipe_stalls >= 3 ? 1 : 0) + s->other_stalls;
   out->comm_nranks = s->comm ? s->comm->nranks() : 1;
-  out->chol_workgroups = s->nc > RSBA_CHOL_MAXN ? s->tc_tiles : s->chol_wgs;
+  out->chol_workgroups = s->nc > RSBA_CHOL_MAXN ? s->tc_tiles : s->chol_wgs + (s->border_cols > 0 ? 1 : 0);   // (the border's workgroup: ba_cholesky_border.hpp)
   out->schur_impl = s->opt.schur_impl;
   strncpy(out->comm_kind, s->comm ? s->comm->kind() : "none", sizeof(out->comm_kind) - 1);
   return RSBA_OK;
