@@ -302,6 +302,7 @@ def main():
                    "sharding": ("points by contiguous block, cameras replicated, %s all-reduce of the reduced system" % ("shared-memory (host-staged)" if shm else "RCCL")) if world > 1 else "single GPU",
                    "schur_impl": int(sched["schur_impl"]), "seed": seed},
         "schedule": sched["schedule"], "stalls": sched["stalls"], "fallbacks": sched["fallbacks"], "comm": sched["comm_kind"],
+        "factorisation_workgroups": sched["chol_workgroups"],   # (33 .. 64 cameras on one rank: six of the diagonal-chain kernel + the border's; resident tiles above 64 cameras)
         "lm_iterations_per_s": iters_per_s, "observations_per_s": iters_per_s * N_total,
         "final_reprojection_rms_px": rms, "iterations_to_converge": int(s_conv.num_iterations),
         "converged_final_cost": s_conv.final_cost, "termination": int(s_conv.termination_type),
