@@ -401,12 +401,13 @@ def test_camera_with_zero_rotation_takes_the_small_angle_branch(oracle, C, P, k,
     _compare_solve(oracle, prob, impl)
 
 
+@pytest.mark.parametrize("cameras", [24, 40])   # (40: the border's workgroup, ba_cholesky_border.hpp, is the one that ends the solve)
 @pytest.mark.parametrize("who", ["1", "2"])
-def test_pipeline_stall_falls_back_to_sequential_schedule(oracle, capfd, who):
+def test_pipeline_stall_falls_back_to_sequential_schedule(oracle, capfd, who, cameras):
     """RSBA_TEST_STALL=1 makes the waiting Cholesky look for a tag nobody publishes: it must give up after its 0.5 s
     budget (never hang the queue), the step must be repeated with the sequential schedule, and the result must not
     change."""
-    prob = syn.make_problem(24, 1500, 7, seed=77)
+    prob = syn.make_problem(cameras, 1500 if cameras == 24 else 3000, 7 if cameras == 24 else 9, seed=77)
     ref, s_ref, log_ref = capi.solve_points(prob)
     os.environ["RSBA_TEST_STALL"] = who   # 1: the Cholesky's wait, 2: the back-substitution's wait for the solve
     try:
