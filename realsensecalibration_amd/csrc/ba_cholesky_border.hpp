@@ -81,9 +81,13 @@ __device__ __forceinline__ void BorderMfmaStrip2(const double* A, int oa, const 
   for (int k = 0; k < NK; ++k) { a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], b0[k], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], b1[k], a1, 0, 0, 0); }
 }
 
-// (LDS pointers keep their address space across the call: ds_read / ds_write in here, not flat accesses)
+// INLINED into the kernel (it is the whole life of one workgroup, behind an early return): out of line — as the diagonal workgroup's
+// routines are, for THEIR registers — it ran 8 us slower per step (0.3645 against 0.356 ms): a callee saves what it uses of the
+// caller's registers in scratch, its own spills sat in the matrix-core loops (704 against 140 bytes of scratch a lane), and the
+// back-substitution inside it took 18 instead of 13 us.  The kernel's other paths did not move (panel period, the sequential
+// schedule, RSBA_BORDER=0, the multi-GPU instance: measured, same box).  The LDS pointers carry their address space in their types.
 typedef __attribute__((address_space(3))) const BorderCtx lds_BorderCtx;
-static __device__ __noinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_double* lds_in) {
+static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_double* lds_in) {
   double* const lds = (double*)lds_in;
   const BorderCtx& bc = *(const BorderCtx*)bcp;
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, mi = lane & 15, kk = lane >> 4;
