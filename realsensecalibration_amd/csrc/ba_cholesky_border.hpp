@@ -438,6 +438,33 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
   double* Lt = R + 1024;      // the factorisation's second tile (R is free but for y_A at its head)
   double* vpart = R + 2304;   // [7][nA] the wavefronts' partial sums of X' x_C
 #define RSBA_BORDER_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+  // One block of the forward substitution y_C = L_C^-1 r by one wavefront (lane (r, h) takes half of a row's terms, the halves meet by a
+  // lane exchange): t = r_p - sum_{q < p} X(p, q) y_q, then y_p = T_p t into r's place — or, while T_p does not exist yet, t itself.
+  // Blocks 0 and 1 and the last block's t are formed by a wavefront that has nothing to do BESIDE the factorisations (y_0 needs T_0,
+  // y_1 needs T_1 and X(1, 0), t_2 needs X(2, 0), X(2, 1)): behind the third factorisation stand y_2 = T_2 t_2 and the three blocks back.
+  auto forward_block = [&](int p, bool apply_T, double* tm) {
+    const int r = lane & 31, h = lane >> 5;
+    double t = 0.0;
+    for (int q = 0; q < p; ++q) {
+      const double* Xb = Cb + BorderBlk(p, q) * RSBA_PB * RSBA_PLD;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t = fma(Xb[r * RSBA_PLD + 16 * h + k], rB[RSBA_PB * q + 16 * h + k], t);
+    }
+    t += __shfl_xor(t, 32, 64);
+    const double tv = rB[RSBA_PB * p + r] - t;
+    RSBA_BORDER_WSYNC();
+    if (!apply_T) { if (lane < 32) rB[RSBA_PB * p + r] = tv; RSBA_BORDER_WSYNC(); return; }
+    if (lane < 32) tm[r] = tv;
+    RSBA_BORDER_WSYNC();
+    const double* T = Tt + p * RSBA_PB * RSBA_PLD;
+    double y = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y = fma(T[r * RSBA_PLD + 16 * h + k], tm[16 * h + k], y);
+    y += __shfl_xor(y, 32, 64);
+    RSBA_BORDER_WSYNC();
+    if (lane < 32) rB[RSBA_PB * p + r] = y;
+    RSBA_BORDER_WSYNC();
+  };
   if (wave == 0) {
     for (int p = 0; p < 3; ++p) {
       if (!DiagFactorInverseCall((lds_double*)(Cb + BorderBlk(p, p) * RSBA_PB * RSBA_PLD), RSBA_PB, (lds_double*)(Tt + p * RSBA_PB * RSBA_PLD), (lds_double*)Lt, (lds_double*)(invd + RSBA_PB * p), lane) && lane == 0) sb_ok = 0;
@@ -452,23 +479,17 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
     double* tmp = R + 2112;
     const int r = lane & 31, h = lane >> 5;
     RSBA_BORDER_WSYNC();
-    for (int p = 0; p < 3; ++p) {
-      double t = 0.0;
-      for (int q = 0; q < p; ++q) {
-        const double* Xb = Cb + BorderBlk(p, q) * RSBA_PB * RSBA_PLD;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t = fma(Xb[r * RSBA_PLD + 16 * h + k], rB[RSBA_PB * q + 16 * h + k], t);
-      }
-      t += __shfl_xor(t, 32, 64);
-      if (lane < 32) tmp[r] = rB[RSBA_PB * p + r] - t;
+    {
+      // y_2 = T_2 t_2 (t_2 stands in r's last block: the seventh wavefront put it there)
+      if (lane < 32) tmp[r] = rB[2 * RSBA_PB + r];
       RSBA_BORDER_WSYNC();
-      const double* T = Tt + p * RSBA_PB * RSBA_PLD;
+      const double* T = Tt + 2 * RSBA_PB * RSBA_PLD;
       double y = 0.0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) y = fma(T[r * RSBA_PLD + 16 * h + k], tmp[16 * h + k], y);
       y += __shfl_xor(y, 32, 64);
       RSBA_BORDER_WSYNC();
-      if (lane < 32) rB[RSBA_PB * p + r] = y;
+      if (lane < 32) rB[2 * RSBA_PB + r] = y;
       RSBA_BORDER_WSYNC();
     }
     for (int p = 2; p >= 0; --p) {
@@ -503,6 +524,7 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
     for (int p = 0; p < 2; ++p) {
       const double* T = Tt + p * RSBA_PB * RSBA_PLD;
       __syncthreads();   // T(p)
+      if (w7 == 6) forward_block(p, true, R + 2144);   // y_p (X(p, q < p) have been there since the last panel)
       // X(p', p) = C'(p', p) T(p)', in place: a 16-row half per wavefront
       if (w7 < 2 * (2 - p)) {
         const int pp = p + 1 + (w7 >> 1), i0 = 16 * (w7 & 1);
@@ -515,6 +537,7 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
         for (int q = 0; q < 4; ++q) { X[oc + 4 * q * RSBA_PLD] = a0[q]; X[oc + 4 * q * RSBA_PLD + 16] = a1[q]; }
       }
       __syncthreads();   // X(., p)
+      if (w7 == 6 && p == 1) forward_block(2, false, R + 2144);   // t_2 = r_2 - X(2, 0) y_0 - X(2, 1) y_1
       // C'(i, j) -= X(i, p) X(j, p)' for p < j <= i: twelve tiles behind panel 0, four behind panel 1
       const int ntile = p == 0 ? 12 : 4;
       for (int q = w7; q < ntile; q += 7) {
