@@ -399,9 +399,10 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
       sv[u] = S[(size_t)(nA + min(gi, nB - 1)) * ld + nA + min(gj, nB - 1)];   // (every lane a valid address: no branch per load)
       du[u] = gi == gj ? bc.diag_u[nA + min(gi, nB - 1)] : 0.0;
     }
-    // (behind the tile's loads, while they are on their way: y_A, and the last group's X to memory)
+    // (behind the tile's loads, while they are on their way: y_A, and the last group's X to memory — by the wavefronts that will read it
+    //  back, so that the factoring wavefront waits for nobody's stores)
     const double ya_v = tid < nA ? A[(size_t)nA * nA + tid] : 0.0;
-    { const int c0 = RSBA_BW * (B - 1); for (int e = tid; e < RSBA_BW * RSBA_BW; e += nt) { const int i = e / RSBA_BW, j = e - RSBA_BW * i; XB[(size_t)i * nA + c0 + j] = R[i * RSBA_BLD + j]; } }
+    if (wave != 0) { const int c0 = RSBA_BW * (B - 1); for (int e = tid - 64; e < RSBA_BW * RSBA_BW; e += nt - 64) { const int i = e / RSBA_BW, j = e - RSBA_BW * i; XB[(size_t)i * nA + c0 + j] = R[i * RSBA_BLD + j]; } }
     if (tid < nA) yA2[tid] = ya_v;
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
@@ -418,24 +419,12 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
     }
     if (tid < nB) rB[tid] += scl[nA + tid] * (bc.gc[nA + tid] + bc.corr[nA + tid]);
   }
-  __builtin_amdgcn_s_waitcnt(0);   // (every thread's stores of X are performed: the wavefronts below read it back)
   __syncthreads();
-  // r -= X_g y_g of the last group, X_g where it still lies in R
-  if (tid < 4 * RSBA_BW) {
-    const int i = tid >> 2, part = tid & 3;
-    const double* yg = yA2 + RSBA_BW * (B - 1);
-    double sum = 0.0;
-#pragma unroll
-    for (int j = 0; j < 24; ++j) sum = fma(R[i * RSBA_BLD + 24 * part + j], yg[24 * part + j], sum);
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    if (part == 0) rB[i] -= sum;
-  }
-  __syncthreads();
+  RSBA_BORDER_STAMP(26);
   // ---- L_C: three panels where they lie, then y_C = L_C^-1 r and x_C = L_C^-T y_C — wavefront 0.  The others form the products between
   // the panels and, before anything else, ask for all of X (96 x nA, 221 KB through this one compute unit: 8 us if waited for) — rows
   // w - 1, w + 6, ... of wavefront w, a row's columns over the lanes — so that X' x_C is a few multiply-adds once x_C is there.
-  double* Lt = R + 1024;      // the factorisation's second tile (R is free but for y_A at its head)
+  // (the factorisation's second tile: the third T's place while the first panel is factored — R still holds the last group's X then —, in R after)
   double* vpart = R + 2304;   // [7][nA] the wavefronts' partial sums of X' x_C
 #define RSBA_BORDER_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
   // One block of the forward substitution y_C = L_C^-1 r by one wavefront (lane (r, h) takes half of a row's terms, the halves meet by a
@@ -467,7 +456,9 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
   };
   if (wave == 0) {
     for (int p = 0; p < 3; ++p) {
+      double* Lt = p == 0 ? Tt + 2 * RSBA_PB * RSBA_PLD : R + 1024;
       if (!DiagFactorInverseCall((lds_double*)(Cb + BorderBlk(p, p) * RSBA_PB * RSBA_PLD), RSBA_PB, (lds_double*)(Tt + p * RSBA_PB * RSBA_PLD), (lds_double*)Lt, (lds_double*)(invd + RSBA_PB * p), lane) && lane == 0) sb_ok = 0;
+      RSBA_BORDER_STAMP(27 + p);
       if (p == 2) break;
       __syncthreads();   // T(p)
       __syncthreads();   // X(., p)
@@ -515,14 +506,30 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
     __syncthreads();   // x_C
   } else {
     const int w7 = wave - 1;
-    double xv[14][5];
+    // beside the first factorisation: r -= X_g y_g of the last group, X_g where it still lies in R
+    if (tid - 64 < 4 * RSBA_BW) {
+      const int i = (tid - 64) >> 2, part = tid & 3;
+      const double* yg = yA2 + RSBA_BW * (B - 1);
+      double sum = 0.0;
 #pragma unroll
-    for (int rr = 0; rr < 14; ++rr) {
-#pragma unroll
-      for (int c = 0; c < 5; ++c) xv[rr][c] = XB[(size_t)min(w7 + 7 * rr, RSBA_BW - 1) * nA + min(lane + 64 * c, nA - 1)];
+      for (int j = 0; j < 24; ++j) sum = fma(R[i * RSBA_BLD + 24 * part + j], yg[24 * part + j], sum);
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      if (part == 0) rB[i] -= sum;
     }
+    __builtin_amdgcn_s_waitcnt(0);   // (this thread's stores of X are performed; everybody's behind the barrier below)
+    double xv[14][5];
     for (int p = 0; p < 2; ++p) {
       const double* T = Tt + p * RSBA_PB * RSBA_PLD;
+      if (p == 1) {
+        // all of X, asked for while the second panel is factored (nothing for these wavefronts to do; behind the first barrier
+        // everybody's stores of X are performed): used behind x_C
+#pragma unroll
+        for (int rr = 0; rr < 14; ++rr) {
+#pragma unroll
+          for (int c = 0; c < 5; ++c) xv[rr][c] = XB[(size_t)min(w7 + 7 * rr, RSBA_BW - 1) * nA + min(lane + 64 * c, nA - 1)];
+        }
+      }
       __syncthreads();   // T(p)
       if (w7 == 6) forward_block(p, true, R + 2144);   // y_p (X(p, q < p) have been there since the last panel)
       // X(p', p) = C'(p', p) T(p)', in place: a 16-row half per wavefront

@@ -2690,7 +2690,7 @@ void rsba_solver_destroy(rsba_solver* s) {
       }
       if (s->border_cols > 0) {   // the border's workgroup: BorderWorkgroup's stamps (ba_cholesky_border.hpp)
         fprintf(stderr, "rsba[mc] border:");
-        for (int k = 0; k < 26; ++k) { const long long v = h[(size_t)s->chol_wgs * 16 * 8 + k]; fprintf(stderr, " %d:%.2f", k, v ? (v - t0) / 100.0 : -1.0); }
+        for (int k = 0; k < 30; ++k) { const long long v = h[(size_t)s->chol_wgs * 16 * 8 + k]; fprintf(stderr, " %d:%.2f", k, v ? (v - t0) / 100.0 : -1.0); }
         fprintf(stderr, "\n");
       }
     }

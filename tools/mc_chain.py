@@ -5,7 +5,8 @@ loads are there, 6 X(p+1, p-1) formed (first meeting), 3 wave 1's unit done, 4 b
 The border's workgroup (ba_cholesky_border.hpp, line "rsba[mc] border:"): 1 + 4 g group g begins (its product with the groups before
 is in registers), 2 + 4 g tile (g, B) seen, 3 + 4 g X_g solved, 4 + 4 g its sums / stores done; 14 y_A in LDS, 15 last tile seen, 16 L_C
 factored, 17 x_C, 13 the back-substitution's right-hand side, 19 back-substituted, 18 end; 20 .. 25: inside the last group (T / L blocks
-in LDS, panels 0 and 1 solved, first slice of X X', last slice) and the product formed after the group before it (24 -> 25).
+in LDS, panels 0 and 1 solved, first slice of X X', last slice) and the product formed after the group before it (24 -> 25); 26 C' formed, 27 .. 29
+the three 32 x 32 factorisations of the border's block done.
 usage: python tools/mc_chain.py log.txt"""
 import re
 import sys
