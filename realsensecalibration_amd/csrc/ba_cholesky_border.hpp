@@ -247,6 +247,7 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
   const int gm = bc.nrow_wgs, npA = 3 * B;
   for (int g = 0; g < B && !stalled; ++g) {
     const int c0 = RSBA_BW * g;
+    const bool last_g = g == B - 1;
     d4_t acc[5];
 #pragma unroll
     for (int u = 0; u < 5; ++u) { acc[u] = P1[u]; P1[u] = P2[u]; P2[u] = d4_t{0, 0, 0, 0}; }
@@ -319,7 +320,7 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
         load_T(2, t2);
       } else __syncthreads();
       if (g == B - 1) RSBA_BORDER_STAMP(21);
-      syrk(0, 2 * RSBA_PB);
+      if (!last_g) syrk(0, 2 * RSBA_PB);   // (the last group's X X': block (0, 0) behind the last tile's loads, the rest beside the first factorisation)
       if (g == B - 1) RSBA_BORDER_STAMP(22);
       if (!all_up) {
         store_T(Tt + 2 * RSBA_PB * RSBA_PLD, t2);
@@ -339,7 +340,7 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
       if (!wait_progress(1 + npA % gm, 3 * g + 3)) { stalled = true; break; }
       if (tid < RSBA_BW) yg_v = A[(size_t)nA * nA + c0 + tid];
     }
-    syrk(2 * RSBA_PB, RSBA_BW);
+    if (!last) syrk(2 * RSBA_PB, RSBA_BW);
     if (g == B - 1) RSBA_BORDER_STAMP(23);
     // the border's right-hand side: r -= X_g y_g
     if (!last) {
@@ -399,11 +400,21 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
       sv[u] = S[(size_t)(nA + min(gi, nB - 1)) * ld + nA + min(gj, nB - 1)];   // (every lane a valid address: no branch per load)
       du[u] = gi == gj ? bc.diag_u[nA + min(gi, nB - 1)] : 0.0;
     }
-    // (behind the tile's loads, while they are on their way: y_A, and the last group's X to memory — by the wavefronts that will read it
-    //  back, so that the factoring wavefront waits for nobody's stores)
+    // (behind the tile's loads, while they are on their way: y_A)
     const double ya_v = tid < nA ? A[(size_t)nA * nA + tid] : 0.0;
-    if (wave != 0) { const int c0 = RSBA_BW * (B - 1); for (int e = tid - 64; e < RSBA_BW * RSBA_BW; e += nt - 64) { const int i = e / RSBA_BW, j = e - RSBA_BW * i; XB[(size_t)i * nA + c0 + j] = R[i * RSBA_BLD + j]; } }
     if (tid < nA) yA2[tid] = ya_v;
+    // the last group's X X' (X_g in R): block (0, 0) — what the first factorisation needs — while the loads above are on their way; the other
+    // five blocks are subtracted beside that factorisation
+    if (wave < 4) {
+      const int ti = (wave >> 1) & 1, tj = wave & 1;
+      int oa = (16 * ti + mi) * RSBA_BLD + kk, ob = (16 * tj + mi) * RSBA_BLD + kk, oc = (16 * ti + kk) * RSBA_PLD + 16 * tj + mi;
+      RSBA_OPQ(oa); RSBA_OPQ(ob); RSBA_OPQ(oc);
+      d4_t xx = {0, 0, 0, 0};
+      for (int ks = 0; ks < RSBA_BW; ks += RSBA_PB) xx = BorderMfmaStrip<8>(R, oa + ks, R, ob + ks, xx);
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) Cb[oc + 4 * t4 * RSBA_PLD] += xx[t4];
+    }
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
       const int e = tid + u * nt, blk = e >> 10, r = (e >> 5) & 31, c = e & 31;
@@ -506,7 +517,9 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
     __syncthreads();   // x_C
   } else {
     const int w7 = wave - 1;
-    // beside the first factorisation: r -= X_g y_g of the last group, X_g where it still lies in R
+    // beside the first factorisation: the last group's X to memory (by the wavefronts that will read it back: the factoring wavefront waits
+    // for nobody's stores), r -= X_g y_g of the last group, X_g where it still lies in R
+    { const int c0 = RSBA_BW * (B - 1); for (int e = tid - 64; e < RSBA_BW * RSBA_BW; e += nt - 64) { const int i = e / RSBA_BW, j = e - RSBA_BW * i; XB[(size_t)i * nA + c0 + j] = R[i * RSBA_BLD + j]; } }
     if (tid - 64 < 4 * RSBA_BW) {
       const int i = (tid - 64) >> 2, part = tid & 3;
       const double* yg = yA2 + RSBA_BW * (B - 1);
@@ -516,6 +529,19 @@ static __device__ __forceinline__ void BorderWorkgroup(lds_BorderCtx* bcp, lds_d
       sum += __shfl_xor(sum, 1, 64);
       sum += __shfl_xor(sum, 2, 64);
       if (part == 0) rB[i] -= sum;
+    }
+    if (wave != 4) {
+      const int k6 = wave < 4 ? wave - 1 : wave - 2;
+      for (int q = 4 + k6; q < 24; q += 6) {
+        const int blk = q >> 2, ti = (q >> 1) & 1, tj = q & 1;
+        const int bi = blk < 3 ? 1 : 2, bj = blk - bi * (bi + 1) / 2;
+        int oa = (RSBA_PB * bi + 16 * ti + mi) * RSBA_BLD + kk, ob = (RSBA_PB * bj + 16 * tj + mi) * RSBA_BLD + kk, oc = blk * RSBA_PB * RSBA_PLD + (16 * ti + kk) * RSBA_PLD + 16 * tj + mi;
+        RSBA_OPQ(oa); RSBA_OPQ(ob); RSBA_OPQ(oc);
+        d4_t xx = {0, 0, 0, 0};
+        for (int ks = 0; ks < RSBA_BW; ks += RSBA_PB) xx = BorderMfmaStrip<8>(R, oa + ks, R, ob + ks, xx);
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) Cb[oc + 4 * t4 * RSBA_PLD] -= xx[t4];
+      }
     }
     __builtin_amdgcn_s_waitcnt(0);   // (this thread's stores of X are performed; everybody's behind the barrier below)
     double xv[14][5];
