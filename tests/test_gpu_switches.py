@@ -24,6 +24,7 @@ SETTINGS = [
     ({"RSBA_BORDER": "0", "RSBA_PIPELINE": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_CHOL_WGS": "1"}, ["c40", "c64_huber"]),
     ({"RSBA_CHOL_WGS": "3"}, ["c64_huber"]),
+    ({"RSBA_CHOL_WGS": "8"}, ["c40", "c64_huber"]),   # (seven row workgroups + the border's: nine workgroups)
     ({"RSBA_BACKSUB_PROJ": "0"}, ["c40", "c64_huber", "c130"]),
     ({"RSBA_FUSED_LIN": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_DECIDED_DAMP": "0"}, ["c40", "c64_huber"]),
