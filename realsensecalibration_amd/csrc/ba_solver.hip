@@ -1980,6 +1980,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   // OPT-IN (RSBA_LAUNCH_AHEAD=1).  Measured at 64 cameras (round 4, device stamps, 99 steps): result posted -> first Schur workgroup
   // 13.1 us without, 12.1 us with — the host's share was already hidden behind the damping kernel (7.3 us) it queues on the device's
   // decision, what is left is that kernel and the dispatch behind it; 0.3885 vs 0.3890 ms per step, inside the run-to-run spread.
+  // Round 5, with the border factorisation: 14.2 -> 13.2 us, 0.3523 - 0.3531 against 0.3516 - 0.3529 ms per step.
   // Against that microsecond per step stands a whole unused elimination (0.26 ms) at the end of every run a tolerance ends.
 #ifdef RSBA_EXPERIMENTAL
   static const bool ahead_env = getenv("RSBA_LAUNCH_AHEAD") && atoi(getenv("RSBA_LAUNCH_AHEAD")) != 0;
@@ -1991,19 +1992,21 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     const int n = s->nc, atag = s->step_tag + 1;
     IterParams ipn = ip; ipn.first = 0;
     long long* tr = s->trace_ring ? s->trace_base + 64 * (size_t)(atag % s->trace_ring) : nullptr;
-    const StageGate sg{ts.ready, atag, 6 * RSBA_TG, ts.ready + RSBA_READY_SOLVED, nullptr, tr, 0, ts.ready + RSBA_READY_STARTED, nullptr, s->chol_wgs, nullptr, 0};
+    const StageGate sg{ts.ready, atag, 6 * RSBA_TG, ts.ready + RSBA_READY_SOLVED, nullptr, tr, 0, ts.ready + RSBA_READY_STARTED, nullptr, s->chol_wgs + (s->border_cols > 0 ? 1 : 0), nullptr, 0};
     const DiagCholFlags df{s->mc_flags, s->mc_flags + 16, s->mc_flags + 32, s->mc_flags + 48, s->mc_dg, s->mc_dg + (size_t)(MultiCholPadded(s->nc) / RSBA_PB + 1) * 1024};
     AheadSel ah; ah.dec = s->dec; ah.seq = s->res_seq + 1.0; ah.camc_x = s->camc[x]; ah.cam_backup = s->cam_backup; ah.camc_backup = s->cam_backup + 6 * (size_t)C;
     T.Begin("k_reduced_system_solve", s->sB);
-    k_reduced_system_solve_diag<false><<<s->chol_wgs, 512, DiagCholLdsDoubles(n) * sizeof(double), s->sB>>>(
-        C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ipn, s->chol_ok, sg, df, atag, s->mc_trace, ah);
+    const int wgs = s->chol_wgs + (s->border_cols > 0 ? 1 : 0);   // (with the border's workgroup: ba_cholesky_border.hpp)
+    const size_t lds_d = (s->border_cols > 0 ? std::max(DiagCholLdsDoubles(s->border_cols), BorderLdsDoubles(n)) : DiagCholLdsDoubles(n)) * sizeof(double);
+    k_reduced_system_solve_diag<false><<<wgs, 512, lds_d, s->sB>>>(
+        C, s->red, s->L, s->A, s->scale_c, s->cam[x], s->cam[c], s->intr, s->camc[c], s->dcam, s->gmax, s->res, ipn, s->chol_ok, sg, df, atag, s->mc_trace, ah, s->border_cols);
     T.End(s->sB);
     ts.LaunchTiles(s, ipn, T, st, atag, false, true, tr);
     s->ahead_inflight = true; s->ahead_tag = atag; s->ahead_x = x;
   };
   if (s->dec_step && !comm_tail) {
     queue_damping();
-    if (ahead_env && s->ahead_ok && pipe && !pipe_tiles && !s->pipelined_mg && !s->pipe_serial && s->chol_wgs > 1 && s->chol_diag && s->border_cols == 0 && !keep_system_copy &&
+    if (ahead_env && s->ahead_ok && pipe && !pipe_tiles && !s->pipelined_mg && !s->pipe_serial && s->chol_wgs > 1 && s->chol_diag && !keep_system_copy &&
         !T.all_kernels() && !(s->trace && !s->trace_ring) && !s->wg_trace && !s->test_stall)
       launch_ahead();
   }
