@@ -68,6 +68,25 @@ class KernelTimer;
 #define RSBA_CHUNK 512      // points per LDS chunk (-DRSBA_CHUNK=256 builds and runs: measured only together with three workgroups per CU, HISTORY.md round 5)
 #endif
 #define RSBA_CW (RSBA_CHUNK / 64)
+// A point's record in the chunk's LDS copy: RSBA_PT_STRIDE (12) doubles at a stride of RSBA_PT_LDS.  Every lane of a hit loop reads the record
+// of ITS OWN hit — 64 random points per instruction, four 16-byte reads and an 8-byte one.  At a stride of 12 doubles (24 banks) the
+// records start on 8 of the 64 banks; at 14 (-DRSBA_PT_LDS=14: 28 banks, still 16-byte aligned, 80 KB of LDS a workgroup) on 16 —
+// measured (round 5, one box, twice each): 0.3492 - 0.3505 ms per step against 0.3479 - 0.3482 at 12.  The hit loop does not wait for
+// its LDS reads long enough for the conflicts to show; the larger carve costs what they give.
+#ifndef RSBA_PT_LDS
+#define RSBA_PT_LDS 12
+#endif
+// (16-byte piece p = tid + 256 u of the chunk's records as memory holds them — six pieces a record — -> its place in LDS, in pieces: one
+//  division per thread, then steps of 256 = 42 records + 4 pieces)
+static_assert(RSBA_PT_LDS % 2 == 0 && RSBA_PT_LDS >= 12, "records are staged and read in 16-byte pieces");
+struct PtLdsCursor {
+  int h, a;
+  __device__ __forceinline__ explicit PtLdsCursor(int tid) { const int r = tid / 6; h = tid - r * 6; a = r * (RSBA_PT_LDS / 2) + h; }
+  __device__ __forceinline__ void Next() {
+    h += 4; a += 42 * (RSBA_PT_LDS / 2) + 4;
+    if (h >= 6) { h -= 6; a += RSBA_PT_LDS / 2 - 6; }
+  }
+};
 
 // (RSBA_PT_STRIDE, the record of a point — X(3) Vinv(6) y(3) — is defined in ba_point_kernels.hpp, whose back-substitution writes it too)
 #define RSBA_PART 42        // 36 block + 6 corr
@@ -825,14 +844,19 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
   {
     // first chunk: point data and visibility rows through registers, every load (camera constants included) issued before
     // the first LDS store — one round trip.  (The accumulators are not live yet: 48 more registers here are free.)
+    // The records travel in 16-byte pieces (six a record): twelve loads and twelve LDS stores a thread instead of twenty-four
+    // 8-byte ones — 248 -> 227 registers, 53 -> 30 spilled scalars; the step 0.3498 - 0.3511 -> 0.3471 - 0.3493 ms (round 5, one box, three
+    // alternating runs each), the cfg5 shard 0.952 -> 0.948, the cfg4 shard 0.4036 -> 0.4018.
     const int wb = sg.word_begin;
     const int nwc = min(RSBA_CW, sg.word_end - wb);
     const int j0 = wb * 64;
     const int np = max(0, min(nwc * 64, P - j0));
-    constexpr int kPtPerThread = RSBA_CHUNK * RSBA_PT_STRIDE / 256;
-    double pv[kPtPerThread];
+    static_assert(RSBA_PT_STRIDE == 12, "six 16-byte pieces a record");
+    constexpr int kPtPerThread = RSBA_CHUNK * 6 / 256;
+    double2 pv[kPtPerThread];
+    const double2* __restrict__ src2 = reinterpret_cast<const double2*>(ptdata + (size_t)j0 * RSBA_PT_STRIDE);
 #pragma unroll
-    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; pv[u] = i < np * RSBA_PT_STRIDE ? ptdata[(size_t)j0 * RSBA_PT_STRIDE + i] : 0.0; }
+    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; pv[u] = i < np * 6 ? src2[i] : make_double2(0.0, 0.0); }
     unsigned long long mv;
     {
       const int row = tid >> 3, w = tid & 7;  // 32 rows x 8 words = 256 threads
@@ -840,8 +864,9 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
       mv = (cam < C && w < nwc) ? cam_mask[(size_t)cam * nwords + (size_t)wb + w] : 0ull;
     }
     sc[tid] = scv[0]; sc[tid + 256] = scv[1];
+    PtLdsCursor pc(tid);
 #pragma unroll
-    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; if (i < np * RSBA_PT_STRIDE) pt[i] = pv[u]; }
+    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; if (i < np * 6) reinterpret_cast<double2*>(pt)[pc.a] = pv[u]; pc.Next(); }
     if ((tid & 7) < RSBA_CW) mk[tid >> 3][tid & 7] = mv;
     __syncthreads();
   }
@@ -856,7 +881,8 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
       const int j0 = wb * 64;
       const int np = max(0, min(nwc * 64, P - j0));
       __syncthreads();
-      for (int i = tid; i < np * RSBA_PT_STRIDE; i += 256) pt[i] = ptdata[(size_t)j0 * RSBA_PT_STRIDE + i];
+      { PtLdsCursor pc(tid); const double2* __restrict__ src2 = reinterpret_cast<const double2*>(ptdata + (size_t)j0 * RSBA_PT_STRIDE);
+        for (int i = tid; i < np * 6; i += 256) { reinterpret_cast<double2*>(pt)[pc.a] = src2[i]; pc.Next(); } }
       {
         const int row = tid >> 3, w = tid & 7;
         const int cam = row < RSBA_TG ? RSBA_TG * sg.ga + row : RSBA_TG * sg.gb + (row - RSBA_TG);
@@ -878,7 +904,7 @@ __device__ __forceinline__ void PairSegment(const SchurArgs& a, const SchurSeg& 
       const int wcur = w;
       h &= h - 1;
       while (h == 0ull && w + wstep < RSBA_CW) { w += wstep; h = mk[ia][w] & mk[RSBA_TG + ib][w]; }
-      const double* pd = pt + (size_t)(wcur * 64 + bit) * RSBA_PT_STRIDE;
+      const double* pd = pt + (size_t)(wcur * 64 + bit) * RSBA_PT_LDS;
       const double X[3] = {pd[0], pd[1], pd[2]};
       const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
       double sqa = 1.0, sqb = 1.0;
@@ -1072,10 +1098,12 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
     const int j0 = wb * 64;
     const int np = max(0, min(nwc * 64, P - j0));
     // every load of the chunk (and, on the first chunk, the camera's constants above) in flight before the first LDS store
-    constexpr int kPtPerThread = RSBA_CHUNK * RSBA_PT_STRIDE / 256;
-    double pv[kPtPerThread];
+    static_assert(RSBA_PT_STRIDE == 12, "six 16-byte pieces a record");
+    constexpr int kPtPerThread = RSBA_CHUNK * 6 / 256;
+    double2 pv[kPtPerThread];
+    const double2* __restrict__ src2 = reinterpret_cast<const double2*>(ptdata + (size_t)j0 * RSBA_PT_STRIDE);
 #pragma unroll
-    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; pv[u] = i < np * RSBA_PT_STRIDE ? ptdata[(size_t)j0 * RSBA_PT_STRIDE + i] : 0.0; }
+    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; pv[u] = i < np * 6 ? src2[i] : make_double2(0.0, 0.0); }
     unsigned long long mv = 0ull;
     if (tid < RSBA_TG * 8) {
       const int row = tid >> 3, w = tid & 7;
@@ -1084,8 +1112,9 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
     }
     const int obs_chunk_pre = live ? cam_prefix[(size_t)cam_a * nwords + wb] : 0;
     __syncthreads();
+    PtLdsCursor pc(tid);
 #pragma unroll
-    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; if (i < np * RSBA_PT_STRIDE) pt[i] = pv[u]; }
+    for (int u = 0; u < kPtPerThread; ++u) { const int i = tid + 256 * u; if (i < np * 6) reinterpret_cast<double2*>(pt)[pc.a] = pv[u]; pc.Next(); }
     if (tid < RSBA_TG * 8 && (tid & 7) < RSBA_CW) mk[tid >> 3][tid & 7] = mv;
     __syncthreads();
     // The camera's points of this chunk as a list, dealt to its 16 lanes BY RANK (lane s takes entries s, s + 16, ...): every
@@ -1115,7 +1144,7 @@ __device__ __forceinline__ void SelfSegment(const SchurArgs& a, const SchurSeg& 
     RSBA_PRIO_HITS(sg.stage);
 #pragma unroll 1
     for (int i = ib; i < n_a; i += 16) {
-      const double* pd = pt + (size_t)lst[ia][i] * RSBA_PT_STRIDE;
+      const double* pd = pt + (size_t)lst[ia][i] * RSBA_PT_LDS;
       const double X[3] = {pd[0], pd[1], pd[2]};
       const double v0 = pd[3], v1 = pd[4], v2 = pd[5], v3 = pd[6], v4 = pd[7], v5 = pd[8];
       const int oi = obs_chunk + i;   // rank of this point in the camera's own observation list
@@ -1440,7 +1469,7 @@ __device__ __forceinline__ void ReducerSegment(const SchurArgs& a, const SchurSe
 #define RSBA_PAIRS_SPARSE 1
 // chunk records | mask rows 2 KB | camera constants 4 KB | a self tile's lists | counters.  512-point chunks: 81 024 bytes, two
 // workgroups per CU
-#define RSBA_SCHUR_LDS_BYTES (RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK + 96)
+#define RSBA_SCHUR_LDS_BYTES (RSBA_CHUNK * RSBA_PT_LDS * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK + 96)
 template <bool kLoss, int kMode>
 __global__ void __launch_bounds__(256, 2)
 k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const int* __restrict__ small_flag_p, const SchurSeg* __restrict__ segs_p, SchurArgs a) {
@@ -1451,15 +1480,15 @@ k_schur_tiles(int* __restrict__ ticket_p, unsigned ticket_base, int total, const
   // One raw LDS buffer, carved by the entry's role: masked / sparse pair segments and self segments: chunk records 48 KB | mask
   // rows 2 KB | camera constants 4 KB | self tiles: a camera's points of the chunk 16 KB | 16 counters
   __shared__ __attribute__((aligned(16))) char lds_raw[RSBA_SCHUR_LDS_BYTES];
-  static_assert(RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK + 64 <= RSBA_SCHUR_LDS_BYTES, "LDS carve");
+  static_assert(RSBA_CHUNK * RSBA_PT_LDS * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK + 64 <= RSBA_SCHUR_LDS_BYTES, "LDS carve");
   static_assert(RSBA_CHUNK != 512 || 2 * (RSBA_SCHUR_LDS_BYTES + 256) <= 160 * 1024, "two workgroups per CU");
   constexpr bool kSparse = kMode == RSBA_PAIRS_SPARSE;
   constexpr bool kResident = kSparse || RSBA_RESIDENT != 0;   // the workgroups draw tickets until the list is through
   double* pt = reinterpret_cast<double*>(lds_raw);
-  unsigned long long (*mk)[RSBA_CW] = reinterpret_cast<unsigned long long (*)[RSBA_CW]>(lds_raw + RSBA_CHUNK * RSBA_PT_STRIDE * 8);
-  double* sc = reinterpret_cast<double*>(lds_raw + RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048);
-  unsigned short (*lst)[RSBA_CHUNK] = reinterpret_cast<unsigned short (*)[RSBA_CHUNK]>(lds_raw + RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048 + 4096);
-  int* cnt = reinterpret_cast<int*>(lds_raw + RSBA_CHUNK * RSBA_PT_STRIDE * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK);
+  unsigned long long (*mk)[RSBA_CW] = reinterpret_cast<unsigned long long (*)[RSBA_CW]>(lds_raw + RSBA_CHUNK * RSBA_PT_LDS * 8);
+  double* sc = reinterpret_cast<double*>(lds_raw + RSBA_CHUNK * RSBA_PT_LDS * 8 + 2048);
+  unsigned short (*lst)[RSBA_CHUNK] = reinterpret_cast<unsigned short (*)[RSBA_CHUNK]>(lds_raw + RSBA_CHUNK * RSBA_PT_LDS * 8 + 2048 + 4096);
+  int* cnt = reinterpret_cast<int*>(lds_raw + RSBA_CHUNK * RSBA_PT_LDS * 8 + 2048 + 4096 + 2 * RSBA_TG * RSBA_CHUNK);
   // Work is handed out by ticket, not by block index: blocks are assigned to the 8 XCDs round-robin and each XCD
   // dispatches its own in order, so an XCD that is a little slower (the one that lends a CU to the Cholesky has 62 slots
   // instead of 64) starts the last blocks of a stage tens of microseconds late, and the stage ends with them.  With
