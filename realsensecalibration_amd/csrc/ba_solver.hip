@@ -1913,7 +1913,9 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       // records in registers, ten (<= 64 cameras) or six (<= 128) more in LDS, both tables + records <= 72 KB per workgroup;
       // up to 256 cameras one workgroup per CU (tables 80 KB + ten LDS slots)
       // (16 fewer than the chip holds: the factorisation's workgroups are resident beside this kernel, and a workgroup that
-      //  has to wait for a slot starts behind the solve, without its records)
+      //  has to wait for a slot starts behind the solve, without its records.  Measured again in round 5 with the border's seven
+      //  workgroups: 2 x CUs - 0 / 8 / 14 / 16 / 32: 0.3506 - 0.3516 / 0.3470 - 0.3482 / 0.3491 / 0.3486 - 0.3493 / 0.3465 - 0.3482 ms per
+      //  step — nothing beyond the run-to-run spread but the full grid, which is slower)
       // (more than 128 cameras: the tables alone are 80 KB, one workgroup per CU)
       grid_bs = std::max(1, std::min(C <= 128 ? 2 * DeviceCUs() - 16 : DeviceCUs() - 8, (P + 63) / 64));
       FusedLin fl = fl0b;
