@@ -664,6 +664,7 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
   // More than 64 cameras: the pair segments' hit lists (PairSegmentSparse, ba_schur_tiled.hpp).  RSBA_SPARSE_PAIRS=0: the
   // masked search of the 512-point chunks, as below 65 cameras.
   const bool sparse = SparsePairSegments(C, staged);
+  std::vector<int> red_pending;
   if (staged) {
     for (int g : stage_order) {
       std::vector<int> tiles_g;   // the stage's self tile, then its pair tiles
@@ -676,9 +677,24 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       std::vector<std::pair<double, int>> ord;
       for (int t : tiles_g) for (int q = tsp[t]; q < tsp[t + 1]; ++q) ord.push_back({(q - tsp[t] + 0.5) / (tsp[t + 1] - tsp[t]), q});
       std::stable_sort(ord.begin(), ord.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
-      for (const auto& o : ord) border.push_back(o.second);
-      for (int t : tiles_g) for (int q : red_of_tile[t]) border.push_back(q);
+      // The stage's reducers are drawn RSBA_RED_DELAY entries into the NEXT stage's compute entries, not right behind their own
+      // stage's: a reducer holds a workgroup slot (its registers, 72 KB of LDS) from its first poll to the tile's last group, and
+      // right behind the stage's last compute entries — which have 40 us to run — that was 46 - 63 us of waiting on 64 slots a launch,
+      // 3.5 % of the slot time.  Everything a reducer waits for still has its ticket before it (no deadlock), and who runs what does not
+      // change a sum.  Round 5, one box, six alternating runs each: 0 (as before) 0.3464 - 0.3523 (mean 0.3486), 250: 0.3446 - 0.3469
+      // (0.3457), 300: 0.3459 - 0.3482 (0.3467), 350: 0.3452 - 0.3573 (0.3485): later than ~300 the stage's flag waits for them.
+      static const int red_delay = getenv("RSBA_RED_DELAY") ? atoi(getenv("RSBA_RED_DELAY")) : 250;
+      int k = 0;
+      for (const auto& o : ord) {
+        if (k++ == red_delay) { for (int q : red_pending) border.push_back(q); red_pending.clear(); }
+        border.push_back(o.second);
+      }
+      for (int q : red_pending) border.push_back(q);
+      red_pending.clear();
+      for (int t : tiles_g) for (int q : red_of_tile[t]) red_pending.push_back(q);
+      if (red_delay <= 0) { for (int q : red_pending) border.push_back(q); red_pending.clear(); }
     }
+    for (int q : red_pending) border.push_back(q);
   } else if (sparse) {
     // More than 64 cameras (sparse pair segments, PairSegmentSparse): the short self segments first — behind the pair segments
     // their reducers sat in 112 of the 512 slots for 80 us each, waiting for them (there are no reducers any more: at most

@@ -30,6 +30,7 @@ SETTINGS = [
     ({"RSBA_DECIDED_DAMP": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_FIRST_STAGED": "0"}, ["c40", "c64_huber"]),
     ({"RSBA_BALANCE": "0"}, ["c40", "c64_huber"]),
+    ({"RSBA_RED_DELAY": "0"}, ["c40", "c64_huber"]),   # (a stage's reducers right behind its own compute entries: the order before round 5's last change)
     ({"RSBA_SEG_PER_CU": "4"}, ["c64_huber", "c130"]),
     ({"RSBA_SPARSE_PAIRS": "0"}, ["c70_huber", "c130"]),
     ({"RSBA_SEG_PER_CU": "1"}, ["c33_long", "c64_huber", "c8_dense", "c64_dense_huber"]),   # (long segments of several chunks; dense visibility)
