@@ -90,7 +90,14 @@ class RcclComm : public Comm {
     else if (ncclGetUniqueId(&id) != ncclSuccess) return nullptr;
     const std::string key = world_size > 1 ? std::string((const char*)&id, sizeof(id)) : std::string("single");
     auto it = comms.find(key);
-    if (it != comms.end()) { if (!static_cast<RcclComm*>(it->second.get())->dead_) return it->second; comms.erase(it); }
+    if (it != comms.end()) {
+      if (!static_cast<RcclComm*>(it->second.get())->dead_) return it->second;
+      // an aborted communicator: its id is spent (one ncclCommInitRank per id — the ranks whose communicator is still alive would
+      // hand out their cached one and this rank would hang in the bootstrap).  Several ranks: the caller needs a fresh id; one rank:
+      // the id above is fresh anyway.
+      if (world_size > 1) { fprintf(stderr, "rsba: the communicator of this id was aborted; a new job needs a new id\n"); return nullptr; }
+      comms.erase(it);
+    }
     ncclComm_t c = nullptr;
     if (ncclCommInitRank(&c, world_size > 1 ? world_size : 1, id, world_size > 1 ? rank : 0) != ncclSuccess) return nullptr;
     std::shared_ptr<Comm> p(new RcclComm(c));
@@ -126,6 +133,7 @@ class RcclComm : public Comm {
       const hipError_t q = hipStreamQuery(st);
       if (q == hipSuccess) return !dead_;
       if (q != hipErrorNotReady) { (void)hipGetLastError(); Abort(); return false; }
+      if ((spin & 63) == 63) sched_yield();   // (a wait of up to two minutes: not a core spinning flat out)
       if ((spin & 1023) == 1023) {
         if (!Healthy()) return false;
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > budget) {

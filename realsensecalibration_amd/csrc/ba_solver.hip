@@ -168,6 +168,9 @@ static int DevAlloc(T** p, size_t n) { return hipMalloc((void**)p, std::max<size
 
 using namespace rsba;
 
+// RSBA_MC_TRACE: [workgroup][panel 0..15][8] stamps of the diagonal-chain factorisation — up to eight workgroups and the border's
+static constexpr size_t kMcTraceWords = (8 + 1) * 16 * 8;
+
 struct rsba_solver {
   rsba_problem* prob = nullptr;
   rsba_options opt;
@@ -180,7 +183,12 @@ struct rsba_solver {
   bool pipelined = false;
   int test_stall = 0;        // RSBA_TEST_STALL=1: the Cholesky waits for a tag nobody publishes, =2: the back-substitution does,
                              // =3: a diagonal tile of the persistent tiled factorisation waits for a hand-over nobody writes
-                             // (both exercise the fallback to the sequential schedule)
+                             // (both exercise the fallback to the sequential schedule); =4: the DOUBLE fault — the first pipelined
+                             // step stalls as with 1, and its sequential repeat reports a stalled multi-workgroup factorisation once
+                             // (the one-workgroup fallback; later steps are NOT forced sequential, so the re-enable logic is what runs)
+  bool test_seq_stall_fired = false;
+  bool pipeline_off = false; // the one-workgroup fallback was taken with a bordered work list (or any other state the pipelined schedule's
+                             // gates do not describe): the solver stays sequential for good
   int step_tag = 0;
   int inject_stall_step = 0; // RSBA_TEST_STALL_STEP=k (with a communicator; RSBA_TEST_STALL_RANK=r: on that rank only): step k reports a
                              // stalled factorisation on this rank — the flag is summed over the ranks and ALL of them repeat the step
@@ -494,8 +502,11 @@ static std::vector<int> BalancedPointOrder(int C, int P, bool staged, const std:
   // unit's order: the half where the point's diagonal pairs have fewer hits so far, relative to the half's fill).  Measured offline
   // on the 64 x 100k x 20 problem (the kernel's lane -> pair map replayed on the host): lane utilisation of the diagonal tiles'
   // hit loops 69.8 % -> 75.3 %, of all pair tiles 81.9 % -> 83.6 %.
+  // The pass walks every point's camera pairs twice, O(P k^2) on one thread: bounded like the dealing above (~6e8 pair visits:
+  // 64 views x 1M points would add seconds of set-up, which count against max_solver_time_in_seconds) — beyond that the words stay as
+  // dealt, which costs speed only.
   static const bool parity_on = !(getenv("RSBA_BALANCE_PARITY") && atoi(getenv("RSBA_BALANCE_PARITY")) == 0);
-  if (parity_on) {
+  if (parity_on && 2.0 * pairs_per_point * P <= 6e8) {
     std::vector<uint16_t> hc((size_t)C * C * 2);
     std::vector<int> half[2];
     for (int g = 0; g < nu; ++g) {
@@ -1240,7 +1251,8 @@ static int UploadPoints(rsba_solver* s) {
                                  (int)(std::max(DiagCholLdsDoubles(s->nc), BorderLdsDoubles(s->nc)) * sizeof(double))));
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(DiagCholLdsDoubles(s->nc) * sizeof(double))));
-      if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, 8 * 16 * 8))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, 8 * 16 * 8 * sizeof(long long))); }
+      // (RSBA_CHOL_WGS allows eight workgroups, and the border's is one more: nine rows of [16][8] stamps)
+      if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, kMcTraceWords))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, kMcTraceWords * sizeof(long long))); }
 #ifdef RSBA_EXPERIMENTAL
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(MultiCholLdsDoubles(s->nc) * sizeof(double))));
@@ -1269,7 +1281,14 @@ static int UploadPoints(rsba_solver* s) {
           s->tc_hand_doubles = (size_t)2 * nrt * kTileHandDoubles;
           if ((rc = DevAlloc(&s->tc_hand, (size_t)2 * nrt * kTileHandDoubles))) return rc;
           HIPCHK(hipMemset(s->tc_hand, 0xff, (size_t)2 * nrt * kTileHandDoubles * sizeof(double)));   // the sentinel everywhere
-          if (getenv("RSBA_MC_TRACE")) { if ((rc = DevAlloc(&s->mc_trace, (size_t)(nrt + 1) * 24 + ntiles))) return rc; HIPCHK(hipMemset(s->mc_trace, 0, ((size_t)(nrt + 1) * 24 + ntiles) * sizeof(long long))); }
+          if (getenv("RSBA_MC_TRACE")) {
+            // (RSBA_TILES_SMALL: the diagonal-chain kernel was given a buffer above, and still stamps its [9][16][8] words on the steps it
+            //  runs — one buffer large enough for both)
+            const size_t words = std::max((size_t)(nrt + 1) * 24 + ntiles, s->mc_trace ? kMcTraceWords : (size_t)0);
+            if (s->mc_trace) { (void)hipFree(s->mc_trace); s->mc_trace = nullptr; }
+            if ((rc = DevAlloc(&s->mc_trace, words))) return rc;
+            HIPCHK(hipMemset(s->mc_trace, 0, words * sizeof(long long)));
+          }
           {
             const int H = (s->tc_np + 2) / 3;
             // k_backsub_chain's hand-overs, two sets each, the sentinel everywhere: x and the helpers' slices of y
@@ -1499,6 +1518,19 @@ static void TraceRingDump(rsba_solver* s) {
   s->trace_ring_first_tag = 0;
 }
 
+// Host-side wait for everything the solver has in flight (the stall handlers, before they reset flags and repeat a step).  With a
+// communicator every stream that may carry a collective is waited for through Comm::WaitStream — bounded, the communicator's health
+// polled beside it — so that a peer that is gone ends this rank with RSBA_ERR_COMM instead of leaving it in hipDeviceSynchronize for
+// ever.
+static int SyncSolver(rsba_solver* s) {
+  if (!s->comm) { HIPCHK(hipDeviceSynchronize()); return RSBA_OK; }
+  for (hipStream_t st : {s->stream, s->sB, s->sR}) {
+    if (st == nullptr) continue;
+    if (!s->comm->WaitStream(st)) return RSBA_ERR_COMM;
+  }
+  return RSBA_OK;
+}
+
 static int WaitResult(rsba_solver* s, hipStream_t posting) {
   s->res_seq += 1.0;
   volatile double* seq = s->res_host + (RES_SIZE - 1);
@@ -1644,7 +1676,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     int* resident_word = (ip.first || s->pipe_check_resident) ? reinterpret_cast<int*>(s->res_host + RES_SIZE) : nullptr;
     s->pipe_check_resident = false;
     TileGate gate;
-    gate.ready = ts.ready; gate.tag = s->test_stall == 1 ? tag + 1 : tag; gate.cols = 6 * RSBA_TG;
+    gate.ready = ts.ready; gate.tag = (s->test_stall == 1 || (s->test_stall == 4 && s->pipe_stalls == 0)) ? tag + 1 : tag; gate.cols = 6 * RSBA_TG;
     gate.all_diag = first_staged ? ts.ready + RSBA_READY_ALLDIAG : nullptr;
     gate.started_cnt = ts.ready + RSBA_READY_STARTED; gate.started_host = resident_word; gate.started_need = s->tc_tiles;
     gate.waited = T.all_kernels() ? s->chol_waited : nullptr;
@@ -1702,7 +1734,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     // while they wait for the solve — have left: with few points the step timed out (and fell back to the sequential
     // schedule for good) in three of four solver lifetimes.  Later steps launch the factorisation ~5 us ahead on an idle
     // stream.
-    const int gate_tag = s->test_stall == 1 ? tag + 1 : tag;
+    const int gate_tag = (s->test_stall == 1 || (s->test_stall == 4 && s->pipe_stalls == 0)) ? tag + 1 : tag;
     // the first step of a run gated stage by stage too (diagonal-workgroup factorisation only): the Schur kernel runs every
     // self tile first and publishes ready[9] when all cameras' diag U are written (RSBA_FIRST_STAGED=0: wait for all stages)
     static const bool first_staged_on = !(getenv("RSBA_FIRST_STAGED") && atoi(getenv("RSBA_FIRST_STAGED")) == 0);
@@ -1920,7 +1952,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     FusedLin fl0b = fl0; fl0b.bs_wg = s->bs_wg;
     const FusedLin& fl = fl0b;
     const int* solve_done = pipe && !pipe_tiles ? s->tiled.ready + RSBA_READY_SOLVED : nullptr;   // (tile pipeline: a stream event orders the back-substitution behind the solve)
-    const int solve_tag = s->test_stall ? s->step_tag + s->test_stall * s->test_stall : s->step_tag;
+    const int solve_tag = (s->test_stall && (s->test_stall != 4 || s->pipe_stalls == 0)) ? s->step_tag + s->test_stall * s->test_stall : s->step_tag;
     long long* waited = pipe && T.all_kernels() ? s->chol_waited + 1 : nullptr;
 #define RSBA_BACKSUB_ARGS C, P, s->sliced(), s->camc[x], s->camc[c], s->dcam, s->pts[x], s->pts[c], s->scale_p, s->block_part, ip, fin_cnt, s->small_red, \
                           s->res, s->res_host, s->res_seq + 1.0, solve_done, solve_tag, waited, s->chol_ok + 2, fl
@@ -2128,18 +2160,29 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   if (!pipe && s->tc_tiles > 0 && s->res_host[RES_STALL] != 0.0) {
     fprintf(stderr, "rsba: persistent tiled Cholesky stalled; using the multi-launch factorisation\n");
     ++s->other_stalls;
-    HIPCHK(hipDeviceSynchronize());
+    { const int rcs = SyncSolver(s); if (rcs != RSBA_OK) return rcs; }
     HIPCHK(hipMemset(s->res, 0, RES_SIZE * sizeof(double)));
     s->tc_tiles = 0;
     return PointsStep(s, radius, first, keep_system_copy);
   }
-  if (!pipe && s->chol_wgs > 1 && s->res_host[RES_STALL] != 0.0) {
+  if (!pipe && s->chol_wgs > 1 && (s->res_host[RES_STALL] != 0.0 || (s->test_stall == 4 && s->pipe_stalls > 0 && !s->test_seq_stall_fired))) {
     // the workgroups of the factorisation did not run side by side (cannot happen on an idle stream): one workgroup then
     fprintf(stderr, "rsba: multi-workgroup Cholesky stalled; using one workgroup\n");
+    s->test_seq_stall_fired = true;
     ++s->other_stalls;
-    HIPCHK(hipDeviceSynchronize());
+    { const int rcs = SyncSolver(s); if (rcs != RSBA_OK) return rcs; }
     HIPCHK(hipMemset(s->mc_flags, 0, 64 * sizeof(int)));
+    HIPCHK(hipMemset(s->res, 0, RES_SIZE * sizeof(double)));
     s->chol_wgs = 1;
+    if (s->border_cols > 0) {
+      // The Schur work list was built for the border (2 Bg + 1 stages, permuted: stage g holds the leading tiles only, tile (g, Bg) is
+      // stage Bg + g, the border's own tile stage 2 Bg).  The one-workgroup factorisation's gates read ready[1 + g] as "all columns of
+      // camera group g": pipelined again it would factor panels whose border rows are still being accumulated, silently.  No border,
+      // and no pipelined schedule for this solver any more (a kernel boundary needs no stages).
+      s->border_cols = 0;
+      s->pipeline_off = true;
+      s->pipelined = false; s->pipelined_mg = false;
+    }
     s->tiled.pt_valid = false;
     return PointsStep(s, radius, first, keep_system_copy);
   }
@@ -2151,8 +2194,8 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
             s->res_host[RES_STALL] >= 1000.0 || s->res_host[RES_STALL] == 5.0 || s->res_host[RES_STALL] == 6.0 ? "the block back-substitution gave up waiting for a hand-over" :
             s->res_host[RES_STALL] >= 10.0 ? "a tile of the factorisation gave up waiting for its stage" :
             s->res_host[RES_STALL] != 0.0 ? "the factorisation gave up waiting for its columns" : "the back-substitution gave up waiting for the solve",
-            s->pipe_stalls + 1 < 3 && !s->test_stall ? " for this step" : "");
-    HIPCHK(hipDeviceSynchronize());
+            s->pipe_stalls + 1 < 3 && (!s->test_stall || s->test_stall == 4) ? " for this step" : "");
+    { const int rcs = SyncSolver(s); if (rcs != RSBA_OK) return rcs; }
     HIPCHK(hipMemset(s->tiled.sync_cnt, 0, (size_t)s->tiled.nsync * sizeof(int)));
     HIPCHK(hipMemset(s->tiled.tree_error + 1, 0, sizeof(int)));
     s->tiled.ticket_base = 0;
@@ -2172,7 +2215,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     s->pipelined = false; s->pipelined_mg = false;
     s->tiled.pt_valid = false;
     const int rc_rep = PointsStep(s, radius, first, keep_system_copy);
-    if (s->pipe_stalls < 3 && !s->test_stall) { s->pipelined = true; s->pipelined_mg = was_mg; s->pipe_check_resident = true; }
+    if (s->pipe_stalls < 3 && (!s->test_stall || s->test_stall == 4) && !s->pipeline_off) { s->pipelined = true; s->pipelined_mg = was_mg; s->pipe_check_resident = true; }
     return rc_rep;
   }
   return RSBA_OK;
@@ -2629,7 +2672,7 @@ int rsba_solver_full_report(const rsba_solver* s, char* buf, int32_t capacity) {
     case RSBA_STOP_MIN_RADIUS: snprintf(why, sizeof(why), "Minimum trust region radius reached. Trust region radius <= %e", s->opt.min_trust_region_radius); break;
     case RSBA_STOP_INVALID_STEPS: snprintf(why, sizeof(why), "Number of successive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d", s->opt.max_num_consecutive_invalid_steps); break;
     case RSBA_STOP_INITIAL_FAILURE: snprintf(why, sizeof(why), "Residual and Jacobian evaluation failed."); break;
-    case RSBA_STOP_MAX_TIME: snprintf(why, sizeof(why), "Maximum solver time reached. Total solver time: %e >= %e.", m.minimizer_seconds, s->opt.max_solver_time_in_seconds); break;
+    case RSBA_STOP_MAX_TIME: snprintf(why, sizeof(why), "Maximum solver time reached. Total solver time: %e >= %e.", m.minimizer_seconds + s->setup_seconds, s->opt.max_solver_time_in_seconds); break;   // (the value out_of_time() tests: Ceres counts the preprocessor's time)
     default: break;
   }
   hipDeviceProp_t prop; memset(&prop, 0, sizeof(prop));
@@ -2701,7 +2744,7 @@ void rsba_solver_destroy(rsba_solver* s) {
     (void)hipFree(s->mc_trace);
   } else if (s && s->mc_trace) {
     // diagnostic: per workgroup and panel, microseconds since the kernel's first stamp
-    std::vector<long long> h(8 * 16 * 8);
+    std::vector<long long> h(kMcTraceWords);
     if (hipMemcpy(h.data(), s->mc_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
       long long t0 = 0; for (long long v : h) if (v && (!t0 || v < t0)) t0 = v;
       for (int w = 0; w < s->chol_wgs; ++w) for (int p = 0; p < s->nc / 32; ++p) {

@@ -171,6 +171,21 @@ def load_nocontract(build=True):
     return _VARIANT
 
 
+_WIDE = None
+
+
+def load_wide(build=True):
+    """THE REFEREE (oracle/Makefile: liboracle_wide.so, -DRSBA_ORACLE_WIDE): the point model's linear solve in long double.  Not the
+    reference's arithmetic; used only by oracle_spread.referee."""
+    global _WIDE
+    if _WIDE is None:
+        so = os.path.join(ORACLE_DIR, "liboracle_wide.so")
+        if build:
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle_wide.so"])
+        _WIDE = Oracle(so)
+    return _WIDE
+
+
 def load(build=True):
     global _ORACLE
     if _ORACLE is None:

@@ -78,7 +78,8 @@ def spread(oracle, prob, optkw, ref=None):
     _, ss_ref = oracle.points_cost(prob, params, huber_delta=hd)
     # first iterate whose trust-region radius exceeds RADIUS_CAP (column 6 of the log: the radius after the step); -1: none
     big = np.nonzero(log[:, 6] > RADIUS_CAP)[0]
-    out = dict(same_trajectory=True, raw=0.0, aligned=0.0, final_cost=0.0, rms=0.0, part=-1, radius_iter=int(big[0]) if len(big) else -1, first3=0.0)
+    out = dict(same_trajectory=True, raw=0.0, aligned=0.0, final_cost=0.0, rms=0.0, part=-1, radius_iter=int(big[0]) if len(big) else -1, first3=0.0,
+               logs=[log] + [la for _, _, la in runs])   # (the three executions' iteration logs: oracle_spread.referee)
     for a, sa, la in runs:
         same = (sa.termination == s.termination and sa.stop_reason == s.stop_reason and sa.num_iterations == s.num_iterations and
                 np.array_equal(la[:, 7], log[:, 7]))
@@ -110,6 +111,46 @@ def spread(oracle, prob, optkw, ref=None):
 # equal to 1.6e-13 — pinned in tests/test_gpu_fuzz.py.)
 RADIUS_CAP = 1e13
 FIRST3_CEILING = 1e-10   # no first-three-iterates bar above this, whatever the oracle's own spread
+
+# THE REFEREE RULE (round 6) for the first-three-iterates bar where the ceiling above is BELOW the checker's own noise.  When the
+# oracle's own three executions differ on the first three iterates' costs by more than a tenth of the ceiling (`first3 > 1e-11`:
+# points seen by two cameras, nearly singular 3 x 3 point blocks whose inverse amplifies the last bits of the very first solve),
+# the comparison "implementation against oracle" measures the sum of two rounding errors of the same size and can neither pass nor
+# indict anybody (round 5: sweep 400 / seed 777, case 224 — 1.6e-10 from the oracle, whose own executions are 1.67e-10 apart).  Such a
+# case goes to the referee: the same trust-region loop with the LINEAR SOLVE in long double (oracle/ba_oracle.hpp, RSBA_ORACLE_WIDE:
+# point-block inverses, Schur sums, dense LLT, back-substitution; 11 more bits).  Measured against IT,
+#     d_impl   = the implementation's distance on the first three iterates' costs,
+#     d_oracle = the largest distance of the oracle's three double-precision executions,
+# the implementation passes iff  d_impl <= max(1e-12, REFEREE_FACTOR x d_oracle): it solves the step as exactly as the double-precision
+# restatement of the reference does, which is all a double-precision implementation can be asked for.  No ceiling is needed: both
+# sides are measured against the same, better answer.  Only iterates the referee shares with every execution count (same accept /
+# reject decisions so far).  The class is counted, and tests/test_gpu_fuzz.py asserts it stays rare.
+REFEREE_TRIGGER = 0.1 * FIRST3_CEILING
+REFEREE_FACTOR = 3.0
+
+
+def needs_referee(sp):
+    return sp.get("first3", 0.0) > REFEREE_TRIGGER
+
+
+def referee(oracle, prob, optkw, log_impl, logs_oracle):
+    """(d_impl, d_oracle, iterates compared): distances on the first three iterates' costs to the long-double referee's, in units
+    of cost_tolerance(., ., 1) like `first3`.  logs_oracle: the iteration logs of the oracle's double-precision executions."""
+    wide = oracle_lib.load_wide()
+    _, sw, lw = wide.solve_points(prob, wide.options(**optkw))
+    N = prob["N"]
+
+    def dist(log):
+        d, n = 0.0, 0
+        for j in range(1, min(len(log), len(lw), 4)):
+            if not np.array_equal(log[:j + 1, 7], lw[:j + 1, 7]):
+                break
+            d = max(d, abs(log[j, 1] - lw[j, 1]) / cost_tolerance(abs(lw[j, 1]), N, 1.0))
+            n = j
+        return d, n
+    d_impl, n_impl = dist(log_impl)
+    ds = [dist(l) for l in logs_oracle]
+    return d_impl, max(d for d, _ in ds), min([n_impl] + [n for _, n in ds])
 
 
 def bars(sp, n_obs):

@@ -58,6 +58,9 @@ def test_sweep_is_mostly_held_to_the_baseline_bars():
     relaxed = [i for i, r in SEEN.items() if r["bars"]["first3"] > 1e-12]
     assert len(relaxed) <= len(CASES) // 20, relaxed
     assert all(r["bars"]["first3"] <= 1e-10 for r in SEEN.values())
+    # ... and THE REFEREE RULE (oracle_spread.py) decides at most one case in fifty
+    refereed = [i for i, r in SEEN.items() if r.get("referee") is not None]
+    assert len(refereed) <= max(1, len(CASES) // 50), refereed
     # no sensitive case without a robust loss and none with more than six views per point: the phenomenon is the one described
     for i in sens:
         c = CASES[i]

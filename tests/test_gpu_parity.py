@@ -418,6 +418,38 @@ def test_pipeline_stall_falls_back_to_sequential_schedule(oracle, capfd, who, ca
     assert np.array_equal(got, ref) and np.array_equal(log, log_ref) and s.num_iterations == s_ref.num_iterations
 
 
+def test_double_fault_with_the_border_ends_in_the_one_workgroup_factorisation_for_good(oracle, capfd):
+    """RSBA_TEST_STALL=4: the first pipelined step stalls, and its sequential repeat reports a stalled
+    multi-workgroup factorisation too.  With the border (40 cameras) the Schur work list's stages are permuted (2 Bg + 1 of them),
+    which the one-workgroup factorisation's gates do not describe: the solver must drop the border AND stay sequential — re-enabled,
+    the pipelined schedule would factor panels whose border rows are still being accumulated, silently.  The one-workgroup kernel
+    rounds differently from the diagonal-chain kernel: the bar is the oracle's, not bitwise equality."""
+    prob = syn.make_problem(40, 3000, 9, seed=77)
+    o_ref = oracle.options()
+    ref, s_ref, log_ref = oracle.solve_points(prob, o_ref)
+    os.environ["RSBA_TEST_STALL"] = "4"
+    p = capi.Problem.points(prob)
+    sv = capi.Solver(p, capi.default_options())
+    try:
+        before = sv.schedule_info()
+        s = sv.run()
+        sv.download()
+        log = sv.iterations()
+        got = p.params.copy()
+        after = sv.schedule_info()
+    finally:
+        del os.environ["RSBA_TEST_STALL"]
+        sv.close()
+        p.close()
+    err = capfd.readouterr().err
+    assert err.count("pipelined solve stalled") == 1 and err.count("multi-workgroup Cholesky stalled") == 1, err
+    assert before["schedule"] == "pipelined" and before["chol_workgroups"] == 7
+    assert after["schedule"] == "sequential" and after["chol_workgroups"] == 1 and after["stalls"] == 2 and after["fallbacks"] >= 1
+    assert s.num_iterations == s_ref.num_iterations and np.array_equal(log[:, 7], log_ref[:, 7])
+    assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
+    assert _block_rel(got, ref, prob["C"]) < 1e-6
+
+
 def test_file_driven_reprojection_check_matches_reference_numbers(oracle):
     """reprojection_check.cpp:5-101 from the committed files: 6-digit point3d.txt, R/t from Camera_Transform.xml,
     float32 corners.  The hongo numbers are the ones the oracle's restatement of that text path gives

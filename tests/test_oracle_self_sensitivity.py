@@ -10,6 +10,7 @@ spread instead of a number the reference algorithm itself does not meet.
 import numpy as np
 
 import fuzz_cases
+import oracle_lib
 import oracle_spread
 from realsensecalibration_amd import synthetic as syn
 
@@ -61,3 +62,39 @@ def test_reversed_points_is_the_same_problem(oracle):
     b, _ = oracle.points_cost(q, q["params"])
     assert abs(a - b) < 1e-12 * a
     assert np.array_equal(oracle_spread.unreverse(q["params"], 5), prob["params"])
+
+
+def test_the_referee_decides_the_case_whose_bar_was_below_the_oracles_own_noise(oracle):
+    """Sweep 400 / seed 777, case 224 (32 cameras, every point seen by TWO of them, Huber 2.5): the oracle's three double-precision
+    executions are 1.7e-10 apart on the first three iterates' costs — above the first-three-iterates ceiling of 1e-10, which
+    therefore could neither pass nor indict an implementation (round 5 recorded the HIP path at 1.6e-10, left standing).  THE REFEREE
+    RULE (oracle_spread.py): against the same trust-region loop with the linear solve in long double (liboracle_wide.so), the oracle's
+    main execution is 1.4e-10 off and its two variants ~3e-11 — the spread is the main execution's own rounding error, and the bar for
+    an implementation is three times that distance."""
+    c = fuzz_cases.cases(400, 777)[224]
+    assert (c["C"], c["k"], c["loss"]) == (32, 2, "huber")
+    prob = syn.make_problem(c["C"], c["P"], c["k"], seed=c["seed"], outlier_frac=0.05)
+    hd = c["scale"]
+    sp = oracle_spread.spread(oracle, prob, dict(huber_delta=hd))
+    assert 1e-10 < sp["first3"] < 1e-9 and oracle_spread.needs_referee(sp)
+    ds = [oracle_spread.referee(oracle, prob, dict(huber_delta=hd), log, sp["logs"]) for log in sp["logs"]]
+    assert all(n == 3 for _, _, n in ds), "the referee takes the same three decisions as every execution"
+    d_or = ds[0][1]
+    assert 5e-11 < d_or < 5e-10 and abs(max(d for d, _, _ in ds) - d_or) < 1e-15
+    assert min(d for d, _, _ in ds) < 0.5 * d_or, "two of the three executions are much closer to the long-double solve than the third"
+    # the long-double solve is the same algorithm: every iterate it shares with the oracle agrees to 1e-9
+    wide = oracle_lib.load_wide()
+    _, _, lw = wide.solve_points(prob, wide.options(huber_delta=hd))
+    assert np.abs(lw[:4, 1] - sp["logs"][0][:4, 1]).max() < 1e-9 * lw[0, 1]
+
+
+def test_the_referee_build_is_the_oracle_on_a_well_conditioned_problem(oracle):
+    """liboracle_wide.so differs from the oracle in the precision of the linear solve only: on a problem with eight views per point
+    both take the same decisions and every iterate's cost agrees to 1e-12."""
+    prob = syn.make_problem(8, 400, 8, seed=21)
+    wide = oracle_lib.load_wide()
+    a, sa, la = oracle.solve_points(prob, oracle.options())
+    b, sb, lb = wide.solve_points(prob, wide.options())
+    assert sa.num_iterations == sb.num_iterations and np.array_equal(la[:, 7], lb[:, 7])
+    assert np.abs(la[:, 1] - lb[:, 1]).max() < 1e-12 * la[0, 1]
+    assert oracle_spread.block_rel(a, b, prob["C"]) < 1e-8
