@@ -5,7 +5,8 @@ equations — no Schur complement, no dual numbers, no line of oracle/ or of the
 Why: the reference commits no output for its only point-model input (Common/Correspondence/two_cam_data.txt;
 Test1_BundleAdjustment/main.cpp:56-87 writes none), so oracle/ba_oracle.hpp's point model and losses were pinned only
 transitively (same LM driver as the marker-chain model that IS pinned by the reference's committed XML).  This script is
-SURVEY.md Appendix B's replay — the one that reproduced hongo/Camera_Transform.xml to 7e-16 — extended to the point functor:
+SURVEY.md Appendix B's replay — the one that reproduces hongo/Camera_Transform.xml to 7e-16: mc_solve below, checked by
+tests/test_point_model_replay.py::test_replay_reproduces_the_references_xml since round 6 — extended to the point functor:
 
   residual     Test1_BundleAdjustment/bundle_adjustmenter.cpp:122-141: p = AngleAxisRotatePoint(cam[0:3], X) + cam[3:6],
                r = (fx p0/p2 + ppx - u, fy p1/p2 + ppy - v); AngleAxisRotatePoint as ceres/rotation.h (both branches, the test on
@@ -18,7 +19,8 @@ SURVEY.md Appendix B's replay — the one that reproduced hongo/Camera_Transform
 
 Output: tests/golden/point_model_<case>.json — the inputs (so that the fixture is self-contained), every iterate's cost /
 gradient / step norm / radius / accepted flag, the termination, and the final parameters.  tests/test_point_model_replay.py
-holds the oracle (CPU) and the HIP path (-m gpu) to them.  Regenerate: `python tools/replay_point_model.py` (seconds).
+holds the oracle (CPU) and the HIP path (-m gpu) to them.  Regenerate: `python tools/replay_point_model.py [case names]` (a minute: the
+two 40- / 72-camera cases of round 6 hold dense 4800 x 1140 Jacobians).
 """
 import json
 import os
@@ -98,6 +100,8 @@ def loss(prob, s):
 
 
 def evaluate(x, prob, with_jacobian):
+    if prob.get("model") == "marker_chain":
+        return mc_evaluate(x, prob, with_jacobian)
     r = residuals(x.astype(complex), prob).real
     s = r[0::2] ** 2 + r[1::2] ** 2
     rho, rho1 = loss(prob, s)
@@ -187,6 +191,110 @@ def minimise(prob, max_num_iterations=50, function_tolerance=1e-6, gradient_tole
         rows.append(row)
 
 
+# ------------------------------------------------------------------ the marker-chain model (round 6)
+# Main_Calibration/bundle_adjustment.h:56-343 — the four functors are ONE chain with blocks left out:
+#   corner (-h,+h,0) (+h,+h,0) (+h,-h,0) (-h,-h,0)                          :77-89
+#   p = R(marker) corner + t_marker      skipped by the *BaseMarker functors    :97-100   (marker_idx == 0; Test2's variant always applies it)
+#   p = R(time) p + t_time                                                       :103-106
+#   p = R(camera) p + t_camera           skipped by the BaseCamera* functors     :109-112  (camera_idx == 0)
+#   r = (fx p0 / p2 + ppx - u, fy p1 / p2 + ppy - v) per corner                  :114-121
+# wired per observation by camera_idx == 0 / marker_idx == 0 (bundle_adjustment_manager.cpp:26-87); the blocks no residual names
+# (camera 0, and marker 0 in Main's wiring) are not in the problem.  Parameters [C cameras | T times | M markers] x 6 as
+# BALProblem lays them out (bundle_adjustment.cpp:64-87).  This is SURVEY.md Appendix B's replay, committed: the sentence "the same
+# replay reproduces the reference's XML" is now a test (tests/test_point_model_replay.py::test_replay_reproduces_the_references_xml).
+def mc_parse(path):
+    """correspondence.txt as BALProblem::loadFile reads it (bundle_adjustment.cpp:132-187): every token whitespace-separated, the
+    count rows' leading time id discarded."""
+    tok = open(path).read().split()
+    T, C, M, N = (int(v) for v in tok[:4])
+    q = 4 + T * (1 + C)
+    rows = np.array(tok[q:q + 11 * N], float).reshape(N, 11)
+    q += 11 * N
+    params = np.array(tok[q:q + 6 * (C + T + M)], float)
+    return dict(T=T, C=C, M=M, N=N, t=rows[:, 0].astype(int), c=rows[:, 1].astype(int), m=rows[:, 2].astype(int), obs=rows[:, 3:].copy(), params=params)
+
+
+def mc_problem(path, serials, marker_side, marker0_is_free):
+    """marker0_is_free: Test2_BundleAdjustment's variant (bundle_adjustmenter.cpp:217-366) — two functors only, the marker transform
+    always applied, marker 0 a block like any other."""
+    mc = mc_parse(path)
+    C, T, M = mc["C"], mc["T"], mc["M"]
+    used = np.zeros(C + T + M, bool)
+    used[mc["c"][mc["c"] != 0]] = True
+    used[C + mc["t"]] = True
+    mm = mc["m"] if marker0_is_free else mc["m"][mc["m"] != 0]
+    used[C + T + mm] = True
+    free = np.flatnonzero(np.repeat(used, 6))
+    intr = np.stack([read_intrinsics(sn) for sn in serials])
+    return dict(mc, model="marker_chain", intr=intr, h=marker_side / 2.0, marker0_is_free=marker0_is_free, free=free, full=mc["params"].copy(),
+                params=mc["params"][free].copy())
+
+
+def mc_residuals(xfree, prob):
+    C, T, N, h = prob["C"], prob["T"], prob["N"], prob["h"]
+    full = prob["full"].astype(complex)
+    full[prob["free"]] = xfree
+    blk = full.reshape(-1, 6)
+    corners = np.array([[-h, h, 0.0], [h, h, 0.0], [h, -h, 0.0], [-h, -h, 0.0]], complex)
+    p = np.tile(corners, (N, 1))                                   # (4 N, 3), observation-major, corner-major
+    ci, ti, mi = (np.repeat(prob[k], 4) for k in ("c", "t", "m"))
+    mar, tim, cam = blk[C + T + mi], blk[C + ti], blk[ci]
+    with_marker = np.ones(4 * N, bool) if prob["marker0_is_free"] else mi != 0
+    p = np.where(with_marker[:, None], rotate(mar[:, :3], p) + mar[:, 3:], p)
+    p = rotate(tim[:, :3], p) + tim[:, 3:]
+    p = np.where((ci != 0)[:, None], rotate(cam[:, :3], p) + cam[:, 3:], p)
+    K = prob["intr"][ci]
+    obs = prob["obs"].reshape(-1, 2)
+    u = K[:, 0] * p[:, 0] / p[:, 2] + K[:, 2] - obs[:, 0]
+    v = K[:, 1] * p[:, 1] / p[:, 2] + K[:, 3] - obs[:, 1]
+    return np.stack([u, v], axis=1).reshape(-1)
+
+
+def mc_evaluate(x, prob, with_jacobian):
+    r = mc_residuals(x.astype(complex), prob).real
+    cost = 0.5 * float(r @ r)
+    if not with_jacobian:
+        return cost, None, None, float(r @ r)
+    hstep = 1e-30
+    J = np.zeros((r.size, x.size))
+    for k in range(x.size):
+        xx = x.astype(complex)
+        xx[k] += 1j * hstep
+        J[:, k] = mc_residuals(xx, prob).imag / hstep
+    return cost, r, J, float(r @ r)
+
+
+def rodrigues(w):
+    """cv::Rodrigues, rvec -> R (bundle_adjustment_manager.cpp:118-121)."""
+    th = np.linalg.norm(w)
+    if th < EPS:
+        return np.eye(3)
+    k = w / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * Kx
+
+
+def mc_solve(which):
+    """'hongo' (Main_Calibration: my_const.h:9,15) or 'test2' (Test2_BundleAdjustment; marker side inferred from test2/point3d.txt's corner
+    spacing) -> (all C + T + M blocks after the solve, summary, iteration rows, the problem)."""
+    if which == "hongo":
+        prob = mc_problem(os.path.join(GOLDEN, "hongo", "correspondence.txt"), ["821312061029", "816612062327", "821212062536", "821212061326"], 0.0148, False)
+    else:
+        prob = mc_problem(os.path.join(GOLDEN, "test2", "correspondence_test.txt"), ["819612072493", "825312072048"], 0.048, True)
+    x, summary, rows = minimise(prob)
+    full = prob["full"].copy()
+    full[prob["free"]] = x
+    return full.reshape(-1, 6), summary, rows, prob
+
+
+def read_xml_matrices(path):
+    txt = open(path).read()
+    out = {}
+    for m in re.finditer(r"<(\w+) type_id=\"opencv-matrix\">\s*<rows>(\d+)</rows>\s*<cols>(\d+)</cols>\s*<dt>\w+</dt>\s*<data>(.*?)</data>", txt, re.S):
+        out[m.group(1)] = np.array(m.group(4).split(), float).reshape(int(m.group(2)), int(m.group(3)))
+    return out
+
+
 # ------------------------------------------------------------------ cases
 def read_intrinsics(serial):
     txt = open(os.path.join(GOLDEN, "intrinsics", "%s.xml" % serial)).read()
@@ -248,12 +356,28 @@ CASES = [
     lambda: synthetic("sparse_views", 12, 90, 5, 3),                                     # config 3's shape: a subset of the cameras per point
     lambda: synthetic("huber_outliers", 12, 90, 6, 5, 0.05, "huber", 1.0),               # config 5's: 5 % outliers, Huber delta = 1 px
     lambda: synthetic("cauchy_outliers", 10, 70, 6, 6, 0.05, "cauchy", 2.0),
+    # round 6: the code paths the benchmark runs, not only the one-workgroup ones — 33 .. 64 cameras: the pipelined schedule, three camera
+    # groups, the last one as the factorisation's border; more than 64: sparse pair segments and the tiled factorisation, with Huber
+    lambda: synthetic("border_40cams", 40, 300, 8, 7),
+    lambda: synthetic("tiles_72cams_huber", 72, 200, 9, 8, 0.05, "huber", 1.0),
 ]
 
 
 def main():
+    for which in ("hongo", "test2"):
+        blocks, summary, rows, prob = mc_solve(which)
+        xml = read_xml_matrices(os.path.join(GOLDEN, which, "Camera_Transform.xml"))
+        err = 0.0
+        for c in range(prob["C"]):
+            R = xml["R%d" % c]
+            err = max(err, np.abs((rodrigues(blocks[c, :3]) if R.shape == (3, 3) else blocks[c, :3].reshape(3, 1)) - R).max(), np.abs(blocks[c, 3:] - xml["t%d" % c][:, 0]).max())
+        print("%-16s marker-chain model: %d iterations, %s (%s), cost %.9e -> %.9e; the reference's committed Camera_Transform.xml reproduced to %.1e" % (
+            which, len(rows) - 1, summary["termination"], summary["reason"], summary["initial_cost"], summary["final_cost"], err))
+    only = sys.argv[1:]
     for make in CASES:
         prob = make()
+        if only and prob["name"] not in only:
+            continue
         x, summary, rows = minimise(prob)
         fx = dict(name=prob["name"], C=int(prob["C"]), P=int(prob["P"]), N=int(prob["N"]), loss=prob.get("loss", "none"), loss_scale=float(prob.get("loss_scale", 0.0)),
                   cam_idx=[int(v) for v in prob["cam_idx"]], pt_idx=[int(v) for v in prob["pt_idx"]], obs=[float(v) for v in prob["obs"]],
