@@ -98,8 +98,9 @@ typedef struct rsba_options {
                                         once per iteration IN FRONT OF the iteration limit and for the first time right behind
                                         iteration 0, against minimiser + set-up (preprocessor) time, as TrustRegionMinimizer's
                                         FinalizeIterationAndCheckIfMinimizerCanContinue does -> NO_CONVERGENCE, RSBA_STOP_MAX_TIME;
-                                        a budget of 0 returns the start with no step taken.  One rank only: several ranks would each read their own clock and part
-                                        (rsba_solver_create returns RSBA_ERR_UNSUPPORTED for a finite limit with world_size > 1).
+                                        a budget of 0 returns the start with no step taken.  Several ranks (round 6): RANK 0's clock decides for all of them —
+                                        what it says when a step is launched is all-reduced with that step's candidate scalars, so every rank
+                                        stops on the same iteration, one step behind the clock.
                                         Solver::Options::use_nonmonotonic_steps has no field: the reference leaves it false, and the
                                         device-side step decision (DecideStep) implements the monotonic rule only. */
 } rsba_options;

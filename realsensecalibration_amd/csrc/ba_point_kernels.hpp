@@ -62,7 +62,9 @@ enum {
   RES_WAIT_TIMEOUT = 11, // pipelined solve only: 1.0 when the back-substitution gave up waiting for the solve
   // the trust-region decision as the device took it for the damping kernel queued behind the step (LmNext below)
   RES_DEC_GO = 12, RES_DEC_ACCEPT = 13, RES_DEC_RADIUS = 14,
-  RES_SIZE = 16
+  RES_TIME_UP = 15,      // several ranks + max_solver_time_in_seconds: != 0 when RANK 0's clock had run out as it launched this step (summed with the
+                         // candidate scalars: every rank stops on the same iteration)
+  RES_SIZE = 24          // (the last word is the sequence number the host polls)
 };
 
 __device__ __forceinline__ double WaveSum(double v) {
@@ -1392,7 +1394,7 @@ __global__ void k_publish_result(const double* __restrict__ small_red, double* _
   if (blockIdx.x != 0) return;
   if (threadIdx.x == 0) {
     PublishResult(small_red, res);
-    if (stall_summed) res[RES_STALL] = small_red[5];
+    if (stall_summed) { res[RES_STALL] = small_red[5]; res[RES_TIME_UP] = small_red[6]; }
     if (lm.dec != nullptr) {
       double acc, nr;
       DecideStep(lm, res[RES_COST_X], res[RES_COST_C], res[RES_MCC], res[RES_STEP2], res[RES_CHOL_OK], &acc, &nr);

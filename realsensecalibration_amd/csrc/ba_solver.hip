@@ -187,6 +187,11 @@ struct rsba_solver {
                              // step stalls as with 1, and its sequential repeat reports a stalled multi-workgroup factorisation once
                              // (the one-workgroup fallback; later steps are NOT forced sequential, so the re-enable logic is what runs)
   bool test_seq_stall_fired = false;
+  // max_solver_time_in_seconds with several ranks: every rank its own clock would let the ranks part (one stops, the others hang in a
+  // collective).  Rank 0's clock decides: what it says when it LAUNCHES a step rides in small_red[6] through that step's all-reduce of the
+  // candidate scalars (the other ranks add 0), and every rank reads the same RES_TIME_UP behind the step (MinimizeLoop).
+  bool share_clock = false;
+  double time_up = 0.0;
   bool pipeline_off = false; // the one-workgroup fallback was taken with a bordered work list (or any other state the pipelined schedule's
                              // gates do not describe): the solver stays sequential for good
   int step_tag = 0;
@@ -2074,6 +2079,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     }
     // the candidate's sums and the stall flags — on the main stream, right behind the kernel that formed them — then the
     // result block, the decision and the post to the host
+    if (s->share_clock) k_set_double<<<1, 1, 0, st>>>(s->small_red + 6, s->time_up);   // (rank 0's "out of time" word, MinimizeLoop)
     COMMCHK(s->comm->SumDoubles(s->small_red, 8, st));
     k_publish_result<<<1, 64, 0, st>>>(s->small_red, s->res, s->res_host, s->res_seq + 1.0, 1, s->trace, lm_publish);
     if (s->dec_step) queue_damping();
@@ -2318,9 +2324,13 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
   // the preprocessor's (here: the upload, setup_seconds), tested in front of the iteration limit — and for the first time right
   // behind iteration 0, so that a budget of zero ends the run with no step taken, as Ceres does
   const auto t_loop0 = std::chrono::steady_clock::now();
-  auto out_of_time = [&]() {
+  auto clock_says = [&]() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count() + s->setup_seconds >= o.max_solver_time_in_seconds;
   };
+  // Several ranks: RANK 0's clock, as of the launch of the latest step, all-reduced with that step's candidate scalars (RES_TIME_UP) —
+  // the same answer on every rank, one step behind the clock (a limit is a request to stop soon, not a deadline)
+  s->share_clock = s->comm && s->comm->nranks() > 1 && o.max_solver_time_in_seconds < 1e9;
+  auto out_of_time = [&]() { return s->share_clock ? s->res_host[RES_TIME_UP] != 0.0 : clock_says(); };
   for (;;) {
     // checks of FinalizeIterationAndCheckIfMinimizerCanContinue for the previous iteration
     if (!first) {
@@ -2341,6 +2351,7 @@ static int MinimizeLoop(rsba_solver* s, rsba_summary* sum, StepFn step, AcceptFn
     s->lm_decrease_factor = decrease_factor;
     // (another step may follow this one unless it reaches the iteration limit: PointsStep may launch its head ahead)
     s->ahead_ok = (first ? 1 : s->iters.back().iteration + 1) < o.max_num_iterations;
+    if (s->share_clock) s->time_up = (o.rank == 0 && clock_says()) ? 1.0 : 0.0;
     int rc = step(radius, first);
     if (rc != RSBA_OK) return rc;
     const double* r = s->res_host;
@@ -2462,7 +2473,6 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
   if (o) opt = *o; else rsba_options_default(&opt);
   if (opt.world_size > 1 && (!opt.comm_unique_id || opt.rank < 0 || opt.rank >= opt.world_size)) return RSBA_ERR_ARG;
   if (opt.world_size > 1 && p->model != RSBA_MODEL_POINTS) return RSBA_ERR_UNSUPPORTED;  // marker-chain: replicas only
-  if (opt.world_size > 1 && opt.max_solver_time_in_seconds < 1e9) return RSBA_ERR_UNSUPPORTED;  // (every rank its own clock: the ranks would part)
   if (!(opt.max_solver_time_in_seconds >= 0.0)) return RSBA_ERR_ARG;
   const auto t0 = std::chrono::steady_clock::now();
   rsba_solver* s = new rsba_solver();

@@ -187,3 +187,21 @@ def test_config5_full_size_in_eight_shards(oracle):
     shards = _shards(C, P, k, seed, 8, outl)
     ranks = _sharded_solve_matches_oracle(oracle, whole, shards, huber=huber, max_num_iterations=3, **FORCED)
     assert ranks[0][1].num_iterations == 3
+
+
+def test_max_solver_time_with_several_ranks_stops_every_rank_on_the_same_iteration():
+    """Solver::Options::max_solver_time_in_seconds with world_size > 1 (round 6; refused until then): rank 0's clock, as of the launch
+    of a step, rides through that step's all-reduce of the candidate scalars (RES_TIME_UP), so every rank takes the same decision.
+    A budget of zero: every rank returns the start untouched after iteration 0 (NO_CONVERGENCE, 'maximum solver time'), as one rank
+    does (tests/test_gpu_parity.py::test_max_solver_time_ends_the_run_like_ceres); a generous budget changes nothing, bit for bit."""
+    C, P, k, world = 24, 3000, 8, 3
+    shards = _shards(C, P, k, 17, world)
+    free = capi.solve_points_sharded_loopback(shards, dict(max_num_iterations=6, **FORCED))
+    zero = capi.solve_points_sharded_loopback(shards, dict(max_num_iterations=6, max_solver_time_in_seconds=0.0, **FORCED))
+    for r, (p, s, log, nranks) in enumerate(zero):
+        assert nranks == world
+        assert (s.num_iterations, s.termination_type, s.stop_reason) == (0, capi.NO_CONVERGENCE, 8), (r, s.num_iterations, s.stop_reason)
+        assert np.array_equal(p, shards[r]["params"]) and s.final_cost == s.initial_cost
+    ample = capi.solve_points_sharded_loopback(shards, dict(max_num_iterations=6, max_solver_time_in_seconds=1e6, **FORCED))
+    for (p, s, log, _), (q, t, log2, _) in zip(ample, free):
+        assert s.num_iterations == t.num_iterations == 6 and np.array_equal(p, q) and np.array_equal(log[:, :8], log2[:, :8])

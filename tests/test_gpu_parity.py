@@ -306,15 +306,20 @@ def test_max_solver_time_ends_the_run_like_ceres():
     Main_Calibration/bundle_adjustment_manager.cpp:90-92): TrustRegionMinimizer tests it in FRONT of the iteration limit and for
     the first time right behind iteration 0 (FinalizeIterationAndCheckIfMinimizerCanContinue), against minimiser + preprocessor
     time — a run whose budget is 0 s returns its start with NO step taken, NO_CONVERGENCE and the 'Maximum solver time reached'
-    line in the report, even when the iteration limit is reached at the same moment; the default changes nothing; several
-    ranks refuse a finite limit (each would read its own clock)."""
+    line in the report, even when the iteration limit is reached at the same moment; the default changes nothing.  (Several ranks:
+    rank 0's clock decides for all, tests/test_gpu_loopback.py::test_max_solver_time_with_several_ranks_stops_every_rank_on_the_same_iteration.)"""
     prob = syn.make_problem(24, 2500, 8, seed=78)
     problem = capi.Problem.points(prob)
     fixed = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0)
     sv = capi.Solver(problem, capi.default_options(max_num_iterations=20, max_solver_time_in_seconds=0.0, **fixed))
     s = sv.run()
     assert (s.termination_type, s.stop_reason, s.num_iterations) == (capi.NO_CONVERGENCE, 8, 0)
-    assert s.final_cost == s.initial_cost and "Maximum solver time reached" in sv.full_report()
+    rep = sv.full_report()
+    assert s.final_cost == s.initial_cost and "Maximum solver time reached" in rep
+    # (ADVICE round 5: the printed left-hand side is the value the test compares — minimiser + set-up time — and so never below the limit)
+    import re
+    m = re.search(r"Total solver time: (\S+) >= (\S+?)\.?\s", rep + " ")
+    assert m and float(m.group(1)) >= float(m.group(2).rstrip(".")), rep
     sv.download()
     assert np.array_equal(problem.params, prob["params"]), "a zero budget must leave the start untouched"
     sv.close()
