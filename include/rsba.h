@@ -172,6 +172,11 @@ int rsba_problem_create_marker_chain(int32_t model, int32_t num_cameras, int32_t
  * §8f rank 4): the camera keeps its value, has no columns in the linear system and does not count in the norms of the
  * convergence tests.  Fixing one camera removes the gauge freedom of a free network. */
 int rsba_problem_set_camera_constant(rsba_problem* p, int32_t camera_idx, int32_t constant);
+/* ... on a POINT block (round 6): the point keeps its value, is not eliminated (no block in the Schur complement, no step), its
+ * observations still count in the cost and in their cameras' blocks, and it is left out of the norms of the convergence tests —
+ * Ceres removes a constant block from the program.  The tiled Schur kernel only (schur_impl != 0; rsba_solver_create returns
+ * RSBA_ERR_UNSUPPORTED with the atomic kernel, also when duplicate observations select it). */
+int rsba_problem_set_point_constant(rsba_problem* p, int32_t point_idx, int32_t constant);
 
 /* Test1 file "two_cam_data.txt": `C P`, P rows `cam pt u v` (one observation per point,
  * bundle_adjustmenter.cpp:62-64), C x (rvec row, tvec row), P rows xyz.  Also accepts the extended

@@ -182,6 +182,7 @@ struct Options {
   // such parameters have no Jacobian columns (the model zeroes them) and are left out of |x| and |step|.
   const unsigned char* constant_parameter = nullptr;
   const unsigned char* constant_camera = nullptr;   // point model: per camera
+  const unsigned char* constant_point = nullptr;    // point model: per point (Problem::SetParameterBlockConstant on a point block)
 };
 
 enum Termination { CONVERGENCE = 0, NO_CONVERGENCE = 1, FAILURE = 2 };
@@ -782,6 +783,7 @@ class PointSchurModel {
         PointReprojectionError<J9>(cam, pt, p_.intrinsics[c], p_.observations[2 * i], p_.observations[2 * i + 1], jr);
         for (int r = 0; r < 2; ++r) { res[r] = jr[r].a; for (int k = 0; k < 6; ++k) jc[6 * r + k] = jr[r].v[k]; for (int k = 0; k < 3; ++k) jp[3 * r + k] = jr[r].v[6 + k]; }
         if (opt_.constant_camera && opt_.constant_camera[c]) for (int k = 0; k < 12; ++k) jc[k] = 0.0;   // constant block: no columns
+        if (opt_.constant_point && opt_.constant_point[j]) for (int k = 0; k < 6; ++k) jp[k] = 0.0;
       }
       if (!std::isfinite(res[0]) || !std::isfinite(res[1])) { bad |= 1; continue; }
       const double s = res[0] * res[0] + res[1] * res[1];

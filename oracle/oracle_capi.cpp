@@ -228,6 +228,26 @@ int oracle_solve_points_constant(int C, int P, int64_t N, const int* camera_idx,
   return s.termination;
 }
 
+// ... camera AND point blocks (either mask may be null).
+int oracle_solve_points_constant_blocks(int C, int P, int64_t N, const int* camera_idx, const int* point_idx, const double* observations,
+                                        double* params, const double* intrinsics4, const unsigned char* constant_camera,
+                                        const unsigned char* constant_point, const OracleOptions* oopt, OracleSummary* out, double* iter_log, int max_log) {
+  std::vector<Intrinsics> K;
+  PointProblem p = MakePoint(C, P, N, camera_idx, point_idx, observations, intrinsics4, K);
+  Options opt = ToOptions(oopt);
+  std::vector<unsigned char> cp((size_t)6 * C + (size_t)3 * P, 0);
+  if (constant_camera) for (int c = 0; c < C; ++c) if (constant_camera[c]) for (int k = 0; k < 6; ++k) cp[6 * c + k] = 1;
+  if (constant_point) for (int j = 0; j < P; ++j) if (constant_point[j]) for (int k = 0; k < 3; ++k) cp[(size_t)6 * C + 3 * (size_t)j + k] = 1;
+  opt.constant_camera = constant_camera; opt.constant_point = constant_point; opt.constant_parameter = cp.data();
+  PointSchurModel model(p, opt);
+  Summary s;
+  const auto t0 = std::chrono::steady_clock::now();
+  TrustRegionMinimize(model, opt, params, &s);
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  FillSummary(s, sec, out, iter_log, max_log);
+  return s.termination;
+}
+
 // Cost 1/2 sum rho(|r|^2) at params (operator()<double>), and sum of squared raw residuals for the RMS metric.
 void oracle_points_cost(int C, int P, int64_t N, const int* camera_idx, const int* point_idx, const double* observations,
                         const double* params, const double* intrinsics4, double huber_delta, int num_threads,

@@ -500,17 +500,6 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     if (wave == 0) (void)DiagFactorInverseCall((lds_double*)Pre, RSBA_PB, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane);
     __syncthreads();
   }
-  // Every iteration but a run's first: the column scales are the ones iteration 0 fixed (scale_c, written by an earlier launch) — read
-  // BEFORE the wait for the first stage instead of behind it (round 6: one dependent round trip to memory, 2 - 3 us beside the Schur
-  // kernel, off the chain from the first stage's flag to the first panel)
-#ifndef RSBA_EARLY_SCALE
-#define RSBA_EARLY_SCALE 1
-#endif
-  const bool early_scale = RSBA_EARLY_SCALE && staged && !ip.first;
-  if (early_scale) {
-    for (int i = tid; i < n; i += nt) scl[i] = i < nreal ? scale_c[i] : 1.0;
-    if (w == 0 && tid == 0) __hip_atomic_store(chol_ok, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   // pipelined first iteration: the Jacobi scale needs the whole damping diagonal
   if (gate.ready != nullptr && ip.first && !staged) {
     for (int g = 0; g * gate.cols < nreal; ++g)
@@ -519,7 +508,7 @@ k_reduced_system_solve_diag(int C, double* __restrict__ red, RedLayout L, double
     if (ip.first && !WaitReady(gate.all_diag, gate.tag, w == 0 ? gate.waited : nullptr, gate.budget)) stalled = true;   // every workgroup: the scales
     if (!stalled && w == 0 && !WaitReady(gate.ready + 1, gate.tag, gate.waited, gate.budget)) stalled = true;   // workgroup 0 starts with S(0, 0)
   }
-  if (!stalled && !early_scale) {
+  if (!stalled) {
     for (int i = tid; i < n; i += nt) {
       double sc = 1.0;
       if (i < nreal) {

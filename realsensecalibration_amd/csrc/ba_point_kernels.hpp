@@ -43,7 +43,23 @@ struct IterParams {
   int first;           // 1: iteration 0 -> compute and store the Jacobi scales
   int jacobi_scaling;
   const double* cam_free = nullptr;   // per camera 1.0 / 0.0 (constant block: SetParameterBlockConstant); nullptr: all free
+  const unsigned char* pt_const = nullptr;   // per point (the solver's internal order) != 0: constant block; nullptr: all free
 };
+// The linearisation record of a CONSTANT point block (Problem::SetParameterBlockConstant on a point, round 6): Ceres removes the block
+// from the program — no columns, no step.  Here its record says "infinitely stiff, no gradient": V = kConstPointStiffness I, g_p = 0,
+// so that every consumer of the record that forms (V + D)^-1 (g_p + ...) — the back-substitution kernels, untouched by this — gets a step
+// of ~1e-200 x (a few thousand): X + step == X exactly, and its share of the model cost change is what the cameras' steps alone give.
+// The kernels that WRITE damped blocks (k_point_pass, k_point_damp) set the inverse block and V^-1 g_p to exact zeros for such a point and
+// leave it out of |x|, max |g| and the failed-block count.
+#define RSBA_CONST_POINT_STIFFNESS 1e200
+__global__ void __launch_bounds__(256) k_fix_const_lin(int P, const unsigned char* __restrict__ pt_const, double* __restrict__ lin, int lin_stride) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < P; j += gridDim.x * blockDim.x) {
+    if (pt_const[j] == 0) continue;
+    double* ln = lin + (size_t)j * lin_stride;
+    ln[0] = RSBA_CONST_POINT_STIFFNESS; ln[1] = 0.0; ln[2] = 0.0; ln[3] = RSBA_CONST_POINT_STIFFNESS; ln[4] = 0.0; ln[5] = RSBA_CONST_POINT_STIFFNESS;
+    ln[6] = 0.0; ln[7] = 0.0; ln[8] = 0.0;
+  }
+}
 
 
 // Result block the host reads back once per iteration (and RCCL reduces in part).

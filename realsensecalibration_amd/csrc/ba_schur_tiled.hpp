@@ -256,6 +256,8 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
       gp[0] += jp[0] * r[0] + jp[3] * r[1]; gp[1] += jp[1] * r[0] + jp[4] * r[1]; gp[2] += jp[2] * r[0] + jp[5] * r[1];
     }
     cost += cost_j;
+    const bool konst = ip.pt_const != nullptr && ip.pt_const[j] != 0;   // a constant point block (k_fix_const_lin, ba_point_kernels.hpp)
+    if (konst) { V[0] = RSBA_CONST_POINT_STIFFNESS; V[1] = 0.0; V[2] = 0.0; V[3] = RSBA_CONST_POINT_STIFFNESS; V[4] = 0.0; V[5] = RSBA_CONST_POINT_STIFFNESS; gp[0] = 0.0; gp[1] = 0.0; gp[2] = 0.0; }
     {
       // the linearisation of the point, kept: a rejected step damps it again with the smaller radius (k_point_damp)
       double* ln = lin + (size_t)j * RSBA_LIN_STRIDE;
@@ -271,10 +273,10 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
     if (ip.first) { scale_p[3 * (size_t)j] = sp[0]; scale_p[3 * (size_t)j + 1] = sp[1]; scale_p[3 * (size_t)j + 2] = sp[2]; }
     double Vi[6];
     const bool ok = PointBlockInverse(V, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, ip.radius, Vi);
-    if (!ok) {
+    if (!ok || konst) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) Vi[i] = 0.0;
-      if (any) fail += 1.0;
+      if (any && !konst) fail += 1.0;
     }
     double y[3];
     Sym3MulVec(Vi, gp, y);
@@ -283,7 +285,7 @@ k_point_pass(int C, int P, ObsSliced obs, const double* __restrict__ camc_g, con
 #pragma unroll
     for (int i = 0; i < 6; ++i) pd[3 + i] = Vi[i];
     pd[9] = y[0]; pd[10] = y[1]; pd[11] = y[2];
-    xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+    if (!konst) xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
     gmax = fmax(gmax, fmax(fabs(gp[0]), fmax(fabs(gp[1]), fabs(gp[2]))));
   }
   __shared__ double s[4][256];
@@ -333,12 +335,14 @@ k_point_damp(int P, const double* pts_x, const double* __restrict__ scale_p, con
     double sp[3] = {1.0, 1.0, 1.0};
     if (ip.jacobi_scaling) { sp[0] = scale_p[3 * (size_t)j]; sp[1] = scale_p[3 * (size_t)j + 1]; sp[2] = scale_p[3 * (size_t)j + 2]; }
     const bool any = V[0] != 0.0 || V[3] != 0.0 || V[5] != 0.0;   // a point with observations has a non-zero block
+    const bool konst = ip.pt_const != nullptr && ip.pt_const[j] != 0;   // a constant point block: no step, not in the norms (k_fix_const_lin)
+    if (konst) { gp[0] = 0.0; gp[1] = 0.0; gp[2] = 0.0; }
     double Vi[6];
     const bool ok = PointBlockInverse(V, sp, ip.min_lm_diagonal, ip.max_lm_diagonal, ip.radius, Vi);
-    if (!ok) {
+    if (!ok || konst) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) Vi[i] = 0.0;
-      if (any) fail += 1.0;
+      if (any && !konst) fail += 1.0;
     }
     double y[3];
     Sym3MulVec(Vi, gp, y);
@@ -347,7 +351,7 @@ k_point_damp(int P, const double* pts_x, const double* __restrict__ scale_p, con
 #pragma unroll
     for (int i = 0; i < 6; ++i) pd[3 + i] = Vi[i];
     pd[9] = y[0]; pd[10] = y[1]; pd[11] = y[2];
-    xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+    if (!konst) xn += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
     gmax = fmax(gmax, fmax(fabs(gp[0]), fmax(fabs(gp[1]), fabs(gp[2]))));
   }
   __shared__ double s[4][256];

@@ -285,6 +285,7 @@ struct rsba_solver {
   int *obs_cam = nullptr, *pt_ptr = nullptr;
   double *cam[2] = {nullptr, nullptr}, *pts[2] = {nullptr, nullptr}, *camc[2] = {nullptr, nullptr};
   double* cam_free = nullptr;   // [C] 1.0 / 0.0: constant cameras (nullptr when there are none)
+  unsigned char* pt_const = nullptr;   // [P] != 0: constant point blocks, in the solver's internal point order (nullptr: none)
   double *cam0 = nullptr, *pts0 = nullptr;  // uploaded initial state (rsba_solver_run restarts from it)
   double *scale_c = nullptr, *scale_p = nullptr;
   double *W = nullptr;     // working copy of the reduced system for the multi-launch Cholesky (nc > RSBA_CHOL_MAXN)
@@ -881,7 +882,7 @@ static void FreeSolver(rsba_solver* s) {
   s->timer.Reset();
   void* ptrs[] = {s->obs_u, s->obs_v, s->intr, s->obs_cam, s->pt_ptr, s->sl_row_ptr, s->sl_cam, s->sl_uv, s->cam[0], s->cam[1], s->pts[0], s->pts[1], s->camc[0], s->camc[1],
                   s->cam0, s->pts0, s->scale_c, s->scale_p, s->red, s->A, s->W, s->chol_ok, s->S_copy, s->rhs_copy, s->dcam, s->block_scal,
-                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_backup, s->red_tri, s->cam_free, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_map, s->tc_hand, s->tc_xs, s->tc_ys};
+                  s->block_part, s->small_red, s->gmax, s->res, s->dec, s->cam_backup, s->red_tri, s->cam_free, s->pt_const, s->mc_flags, s->mc_dg, s->tc_flags, s->tc_map, s->tc_hand, s->tc_xs, s->tc_ys};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->tiled.Free();
   s->marker.Free();
@@ -1100,6 +1101,11 @@ static int UploadPoints(rsba_solver* s) {
     for (int j = 0; j < P && !dup; ++j) for (int q = ptr[j] + 1; q < ptr[j + 1]; ++q) if (cam[q] == cam[q - 1]) { dup = true; break; }
     if (dup) s->opt.schur_impl = 0;
   }
+  const bool any_const_point = std::find(p.point_constant.begin(), p.point_constant.end(), (uint8_t)1) != p.point_constant.end();
+  if (any_const_point && s->opt.schur_impl == 0) {
+    fprintf(stderr, "rsba: constant point blocks need the tiled Schur kernel (schur_impl != 0, no duplicate observations)\n");
+    return RSBA_ERR_UNSUPPORTED;
+  }
   if (s->opt.schur_impl != 0) {
     if (getenv("RSBA_TRACE") && atoi(getenv("RSBA_TRACE")) == 2 && s->nc > RSBA_CHOL_MAXN) {
       if (hipMalloc((void**)&s->wg_trace, 3 * 65536 * sizeof(long long)) != hipSuccess) return RSBA_ERR_HIP;   // (the block timeline alone)
@@ -1208,6 +1214,14 @@ static int UploadPoints(rsba_solver* s) {
     const double* src = p.parameters.data() + 6 * C;
     for (int jn = 0; jn < P; ++jn) { const size_t o = 3 * (size_t)s->pt_perm[jn]; xp[3 * (size_t)jn] = src[o]; xp[3 * (size_t)jn + 1] = src[o + 1]; xp[3 * (size_t)jn + 2] = src[o + 2]; }
     HIPCHK(hipMemcpy(s->pts0, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (any_const_point) {
+    // constant point blocks, in the internal point order; they need the kept linearisation (k_fix_const_lin, ba_point_kernels.hpp)
+    if (!s->fused_lin) { fprintf(stderr, "rsba: constant point blocks need the kept point linearisation (RSBA_FUSED_LIN=0 is set)\n"); return RSBA_ERR_UNSUPPORTED; }
+    std::vector<unsigned char> pc(P, 0);
+    for (int jn = 0; jn < P; ++jn) { const int j = s->pt_perm.empty() ? jn : s->pt_perm[jn]; pc[jn] = j < (int)p.point_constant.size() && p.point_constant[j] ? 1 : 0; }
+    if ((rc = DevAlloc(&s->pt_const, (size_t)P))) return rc;
+    HIPCHK(hipMemcpy(s->pt_const, pc.data(), (size_t)P, hipMemcpyHostToDevice));
   }
   // launch geometry: fixed grids (deterministic second-stage reductions depend only on these)
   s->grid_lin = std::max(1, std::min((P + 3) / 4, 2048));
@@ -1581,6 +1595,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
   hipStream_t st = s->stream;
   IterParams ip = MakeIterParams(s->opt, radius, first);
   ip.cam_free = s->cam_free;
+  ip.pt_const = s->pt_const;
   KernelTimer& T = s->timer;
 
   if (s->trace) s->host_t[0] = std::chrono::steady_clock::now();
@@ -2015,6 +2030,10 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
     if (fused) s->tiled.lin_valid = true;
   }
   T.End(st);
+  // constant point blocks: the candidate's linearisation records the back-substitution has just written say "infinitely stiff, no
+  // gradient" again before anybody reads them (k_fix_const_lin, ba_point_kernels.hpp); the damping kernels know the blocks themselves
+  if (s->pt_const != nullptr && s->tiled.lin2[c] != nullptr)
+    k_fix_const_lin<<<std::max(1, std::min((P + 255) / 256, 1024)), 256, 0, st>>>(P, s->pt_const, s->tiled.lin2[c], RSBA_LIN_STRIDE);
   auto queue_damping = [&]() {
     // the damping kernel of the NEXT step, on the device's decision (LmNext)
     TiledSchur& ts = s->tiled;
@@ -2235,6 +2254,7 @@ static int PointsGradient(rsba_solver* s, double radius) {
   hipStream_t st = s->stream;
   IterParams ip = MakeIterParams(s->opt, radius, false);
   ip.cam_free = s->cam_free;
+  ip.pt_const = s->pt_const;
   KernelTimer& T = s->timer;
   T.NextStep();
   { const int rcd = DrainAhead(s); if (rcd != RSBA_OK) return rcd; }
@@ -2652,7 +2672,9 @@ int rsba_solver_full_report(const rsba_solver* s, char* buf, int32_t capacity) {
     int nconst = 0;
     for (uint8_t c : p.camera_constant) nconst += c ? 1 : 0;
     blocks0 = (long long)p.num_cameras + p.num_points; params0 = 6LL * p.num_cameras + 3LL * p.num_points;
-    blocks1 = blocks0 - nconst; params1 = params0 - 6LL * nconst;
+    int nconst_pt = 0;
+    for (uint8_t c : p.point_constant) nconst_pt += c ? 1 : 0;
+    blocks1 = blocks0 - nconst - nconst_pt; params1 = params0 - 6LL * nconst - 3LL * nconst_pt;
     rblocks = p.num_observations; residuals = 2 * rblocks;
   } else {
     const int nb = p.num_cameras + p.num_times + p.num_markers;

@@ -75,6 +75,13 @@ int rsba_problem_set_camera_constant(rsba_problem* p, int32_t camera_idx, int32_
   p->camera_constant[camera_idx] = constant ? 1 : 0;
   return RSBA_OK;
 }
+int rsba_problem_set_point_constant(rsba_problem* p, int32_t point_idx, int32_t constant) {
+  if (!p || point_idx < 0 || point_idx >= p->num_points) return RSBA_ERR_ARG;
+  if (p->model != RSBA_MODEL_POINTS) return RSBA_ERR_UNSUPPORTED;
+  if (p->point_constant.empty()) p->point_constant.assign(p->num_points, 0);
+  p->point_constant[point_idx] = constant ? 1 : 0;
+  return RSBA_OK;
+}
 void rsba_problem_free(rsba_problem* p) { delete p; }
 
 int rsba_base_pose_from_marker_detection(const double* marker_from_camera, const double* marker_from_base, double* base_from_camera) {

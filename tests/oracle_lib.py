@@ -125,6 +125,19 @@ class Oracle:
                                               dp(params), dp(prob["intr"]), mask.ctypes.data_as(C.c_void_p), C.byref(o), C.byref(s), dp(log), max_log)
         return params, s, log[: s.num_iterations + 1]
 
+    def solve_points_constant_blocks(self, prob, constant_cameras=(), constant_points=(), opts=None, max_log=64):
+        """Problem::SetParameterBlockConstant on camera and / or point blocks."""
+        params = prob["params"].copy()
+        s = OracleSummary()
+        log = np.zeros((max_log, 8))
+        o = opts or self.options()
+        cm = np.zeros(prob["C"], np.uint8); cm[list(constant_cameras)] = 1
+        pm = np.zeros(prob["P"], np.uint8); pm[list(constant_points)] = 1
+        self.lib.oracle_solve_points_constant_blocks(prob["C"], prob["P"], C.c_int64(prob["N"]), ip(prob["cam_idx"]), ip(prob["pt_idx"]), dp(prob["obs"]),
+                                                     dp(params), dp(prob["intr"]), cm.ctypes.data_as(C.c_void_p), pm.ctypes.data_as(C.c_void_p),
+                                                     C.byref(o), C.byref(s), dp(log), max_log)
+        return params, s, log[: s.num_iterations + 1]
+
     def points_cost(self, prob, params, huber_delta=0.0, num_threads=1):
         cost, ss = C.c_double(), C.c_double()
         self.lib.oracle_points_cost(prob["C"], prob["P"], C.c_int64(prob["N"]), ip(prob["cam_idx"]), ip(prob["pt_idx"]), dp(prob["obs"]),

@@ -100,7 +100,15 @@ def test_replay_reproduces_the_references_xml(which, iterations, final_cost):
 def test_oracle_matches_the_numpy_replay(oracle, path):
     fx, prob = _load(path)
     hd = -fx["loss_scale"] if fx["loss"] == "cauchy" else (fx["loss_scale"] if fx["loss"] == "huber" else 0.0)
-    params, s, log = oracle.solve_points(prob, oracle.options(huber_delta=hd))
+    if fx.get("constant_cameras") or fx.get("constant_points"):
+        params, s, log = oracle.solve_points_constant_blocks(prob, fx.get("constant_cameras", []), fx.get("constant_points", []), oracle.options(huber_delta=hd))
+        C0 = fx["C"]
+        for c in fx.get("constant_cameras", []):
+            assert np.array_equal(params[6 * c:6 * c + 6], prob["params"][6 * c:6 * c + 6])
+        for j in fx.get("constant_points", []):
+            assert np.array_equal(params[6 * C0 + 3 * j:6 * C0 + 3 * j + 3], prob["params"][6 * C0 + 3 * j:6 * C0 + 3 * j + 3])
+    else:
+        params, s, log = oracle.solve_points(prob, oracle.options(huber_delta=hd))
     _check(fx, prob, params, s.termination, s.stop_reason, s.num_iterations, log, s.final_cost)
 
 
@@ -113,5 +121,31 @@ def test_hip_path_matches_the_numpy_replay(path, impl):
     assert capi.load().rsba_device_count() > 0, "GPU tests need a HIP device; the product has no CPU path"
     fx, prob = _load(path)
     o = capi.default_options(schur_impl=impl, huber_delta=fx["loss_scale"] if fx["loss"] != "none" else 0.0, loss_type=1 if fx["loss"] == "cauchy" else 0)
-    params, s, log = capi.solve_points(prob, o)
+    if fx.get("constant_cameras") or fx.get("constant_points"):
+        # Problem::SetParameterBlockConstant on camera and point blocks (round 6): rsba_problem_set_camera_constant / _set_point_constant
+        p = capi.Problem.points(prob)
+        for c in fx.get("constant_cameras", []):
+            p.set_camera_constant(c)
+        for j in fx.get("constant_points", []):
+            p.set_point_constant(j)
+        if impl == 0 and fx.get("constant_points"):
+            with pytest.raises(capi.RsbaError):   # constant POINT blocks: the tiled kernel only
+                capi.Solver(p, o)
+            p.close()
+            return
+        sv = capi.Solver(p, o)
+        try:
+            s = sv.run()
+            sv.download()
+            log, params = sv.iterations(), p.params.copy()
+        finally:
+            sv.close()
+            p.close()
+        C0 = fx["C"]
+        for c in fx.get("constant_cameras", []):
+            assert np.array_equal(params[6 * c:6 * c + 6], prob["params"][6 * c:6 * c + 6]), "a constant camera moved"
+        for j in fx.get("constant_points", []):
+            assert np.array_equal(params[6 * C0 + 3 * j:6 * C0 + 3 * j + 3], prob["params"][6 * C0 + 3 * j:6 * C0 + 3 * j + 3]), "a constant point moved"
+    else:
+        params, s, log = capi.solve_points(prob, o)
     _check(fx, prob, params, s.termination_type, s.stop_reason, s.num_iterations, log, s.final_cost)

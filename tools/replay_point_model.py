@@ -110,6 +110,8 @@ def evaluate(x, prob, with_jacobian):
         return cost, None, None, float(np.sum(s))
     sq = np.repeat(np.sqrt(rho1), 2)   # corrector with rho'' <= 0 (Huber, Cauchy): alpha = 0, both scaled by sqrt(rho')
     J = jacobian(x, prob) * sq[:, None]
+    if prob.get("const_params") is not None:
+        J[:, prob["const_params"]] = 0.0   # Problem::SetParameterBlockConstant: the block has no columns (Ceres removes it from the program)
     return cost, r * sq, J, float(np.sum(s))
 
 
@@ -167,7 +169,8 @@ def minimise(prob, max_num_iterations=50, function_tolerance=1e-6, gradient_tole
         xc = x + delta
         cand, _, _, cand_sumsq = evaluate(xc, prob, False)
         row["step_norm"] = float(np.linalg.norm(delta))
-        if row["step_norm"] <= parameter_tolerance * (np.linalg.norm(x) + parameter_tolerance):
+        xn = np.linalg.norm(x if prob.get("const_params") is None else np.delete(x, prob["const_params"]))   # (|x| over the blocks in the program)
+        if row["step_norm"] <= parameter_tolerance * (xn + parameter_tolerance):
             rows.append(row)
             return x, dict(out, termination="CONVERGENCE", reason="parameter", final_cost=cost, final_sumsq=sumsq), rows
         row["cost_change"] = cost - cand
@@ -350,6 +353,14 @@ def synthetic(name, C, P, k, seed, outlier_frac=0.0, loss_kind="none", loss_scal
     return prob
 
 
+def with_constant_blocks(prob, cameras, points):
+    C = prob["C"]
+    idx = [6 * c + k for c in cameras for k in range(6)] + [6 * C + 3 * j + k for j in points for k in range(3)]
+    prob["const_params"] = np.array(sorted(idx), int)
+    prob["constant_cameras"], prob["constant_points"] = list(cameras), list(points)
+    return prob
+
+
 CASES = [
     lambda: case_two_cam(),
     lambda: synthetic("cfg2_small", 8, 60, 8, 2),                                        # BASELINE config 2's shape: every camera sees every point
@@ -358,6 +369,7 @@ CASES = [
     lambda: synthetic("cauchy_outliers", 10, 70, 6, 6, 0.05, "cauchy", 2.0),
     # round 6: the code paths the benchmark runs, not only the one-workgroup ones — 33 .. 64 cameras: the pipelined schedule, three camera
     # groups, the last one as the factorisation's border; more than 64: sparse pair segments and the tiled factorisation, with Huber
+    lambda: with_constant_blocks(synthetic("constant_blocks", 12, 90, 5, 9), cameras=[0, 7], points=[3, 17, 40, 89]),   # round 6: SetParameterBlockConstant
     lambda: synthetic("border_40cams", 40, 300, 8, 7),
     lambda: synthetic("tiles_72cams_huber", 72, 200, 9, 8, 0.05, "huber", 1.0),
 ]
@@ -382,6 +394,7 @@ def main():
         fx = dict(name=prob["name"], C=int(prob["C"]), P=int(prob["P"]), N=int(prob["N"]), loss=prob.get("loss", "none"), loss_scale=float(prob.get("loss_scale", 0.0)),
                   cam_idx=[int(v) for v in prob["cam_idx"]], pt_idx=[int(v) for v in prob["pt_idx"]], obs=[float(v) for v in prob["obs"]],
                   intr=[float(v) for v in prob["intr"]], params=[float(v) for v in prob["params"]],
+                  constant_cameras=[int(v) for v in prob.get("constant_cameras", [])], constant_points=[int(v) for v in prob.get("constant_points", [])],
                   expected=dict(summary=summary, iterations=rows, final_params=[float(v) for v in x]),
                   generator="tools/replay_point_model.py (numpy %s): complex-step Jacobians, dense normal equations, SURVEY.md Appendix A.2" % np.__version__)
         path = os.path.join(GOLDEN, "point_model_%s.json" % prob["name"])
