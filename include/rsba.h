@@ -177,6 +177,12 @@ int rsba_problem_set_camera_constant(rsba_problem* p, int32_t camera_idx, int32_
  * Ceres removes a constant block from the program.  The tiled Schur kernel only (schur_impl != 0; rsba_solver_create returns
  * RSBA_ERR_UNSUPPORTED with the atomic kernel, also when duplicate observations select it). */
 int rsba_problem_set_point_constant(rsba_problem* p, int32_t point_idx, int32_t constant);
+/* ceres::Problem::SetParameterBlockConstant(values) as the reference would call it — with the block's place in the parameter array
+ * (`parameter_offset` = values - parameters_: a multiple of 6 for a pose block, 6 C + 3 j for point j of the point model).  Point model: the
+ * two calls above.  Marker-chain models (round 6): any camera / time / marker block of [C | T | M] (bundle_adjustment.cpp:64-87) — the
+ * block keeps its transform in every residual that names it and leaves the program; the solve then runs the dense path (the
+ * time-eliminating one does not know constant blocks). */
+int rsba_problem_set_parameter_block_constant(rsba_problem* p, int64_t parameter_offset, int32_t constant);
 
 /* Test1 file "two_cam_data.txt": `C P`, P rows `cam pt u v` (one observation per point,
  * bundle_adjustmenter.cpp:62-64), C x (rvec row, tvec row), P rows xyz.  Also accepts the extended

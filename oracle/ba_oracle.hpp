@@ -412,6 +412,7 @@ struct MarkerChainProblem {
   const double* observations = nullptr;   // 8 per observation
   const Intrinsics* intrinsics = nullptr;  // per camera index
   double marker_side = 0;
+  const unsigned char* constant_block = nullptr;   // per block [C | T | M]: Problem::SetParameterBlockConstant — applied, not a parameter
   // parameter layout [C cameras | T times | M markers] x 6 (bundle_adjustment.cpp:64-87)
   int num_blocks() const { return C + T + M; }
   bool uses_camera(int i) const { return camera_idx[i] != 0; }
@@ -432,6 +433,8 @@ class MarkerChainModel {
       used[p.time_block(i)] = 1;
       if (p.uses_marker(i)) used[p.marker_block(i)] = 1;
     }
+    // a constant block keeps its transform in every residual that names it and leaves the program (no columns, not in the norms)
+    if (p.constant_block) for (int b = 0; b < p.num_blocks(); ++b) if (p.constant_block[b]) used[b] = 0;
     for (int b = 0; b < p.num_blocks(); ++b) if (used[b]) { block_to_active_[b] = (int)active_blocks_.size(); active_blocks_.push_back(b); }
     n_ = 6 * (int)active_blocks_.size();
     m_ = 8 * p.N;
@@ -457,24 +460,27 @@ class MarkerChainModel {
       const Intrinsics& K = p_.intrinsics[p_.camera_idx[i]];
       const double h = p_.marker_side / 2;
       double res[8];
+      // (a block that is in the residual but not in the program — constant — takes its values from the full array)
+      const double* pc = uc ? (bc >= 0 ? x + 6 * bc : &full_[6 * p_.camera_block(i)]) : nullptr;
+      const double* pt = bt >= 0 ? x + 6 * bt : &full_[6 * p_.time_block(i)];
+      const double* pm = um ? (bm >= 0 ? x + 6 * bm : &full_[6 * p_.marker_block(i)]) : nullptr;
       if (!with_jacobian) {
-        MarkerChainReprojectionError<double>(uc ? x + 6 * bc : nullptr, x + 6 * bt, um ? x + 6 * bm : nullptr, h, K,
-                                             p_.observations + 8 * i, res);
+        MarkerChainReprojectionError<double>(pc, pt, pm, h, K, p_.observations + 8 * i, res);
       } else {
         J18 cam[6], tim[6], mar[6], jr[8];
         for (int k = 0; k < 6; ++k) {
-          if (uc) cam[k] = J18(x[6 * bc + k], k);
-          tim[k] = J18(x[6 * bt + k], 6 + k);
-          if (um) mar[k] = J18(x[6 * bm + k], 12 + k);
+          if (uc) cam[k] = bc >= 0 ? J18(pc[k], k) : J18(pc[k]);
+          tim[k] = bt >= 0 ? J18(pt[k], 6 + k) : J18(pt[k]);
+          if (um) mar[k] = bm >= 0 ? J18(pm[k], 12 + k) : J18(pm[k]);
         }
         MarkerChainReprojectionError<J18>(uc ? cam : nullptr, tim, um ? mar : nullptr, h, K, p_.observations + 8 * i, jr);
         for (int r = 0; r < 8; ++r) {
           res[r] = jr[r].a;
           double* row = &J_[(size_t)(8 * i + r) * n_];
           for (int k = 0; k < 6; ++k) {
-            if (uc) row[6 * bc + k] = jr[r].v[k];
-            row[6 * bt + k] = jr[r].v[6 + k];
-            if (um) row[6 * bm + k] = jr[r].v[12 + k];
+            if (uc && bc >= 0) row[6 * bc + k] = jr[r].v[k];
+            if (bt >= 0) row[6 * bt + k] = jr[r].v[6 + k];
+            if (um && bm >= 0) row[6 * bm + k] = jr[r].v[12 + k];
           }
         }
       }

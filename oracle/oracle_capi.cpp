@@ -160,6 +160,31 @@ int oracle_solve_marker_chain(int variant, int T, int C, int M, int N, const int
   return s.termination;
 }
 
+// oracle_solve_marker_chain (dense model) with some blocks held constant: mask over the C + T + M blocks.
+int oracle_solve_marker_chain_constant(int variant, int T, int C, int M, int N, const int* time_idx, const int* camera_idx,
+                                       const int* marker_idx, const double* observations, double* params, const double* intrinsics4,
+                                       double marker_side, const unsigned char* constant_block, const OracleOptions* oopt,
+                                       OracleSummary* out, double* iter_log, int max_log) {
+  MarkerChainProblem p;
+  p.variant = variant; p.T = T; p.C = C; p.M = M; p.N = N;
+  p.time_idx = time_idx; p.camera_idx = camera_idx; p.marker_idx = marker_idx; p.observations = observations;
+  std::vector<Intrinsics> K(C);
+  for (int c = 0; c < C; ++c) K[c] = Intrinsics{intrinsics4[4 * c], intrinsics4[4 * c + 1], intrinsics4[4 * c + 2], intrinsics4[4 * c + 3]};
+  p.intrinsics = K.data(); p.marker_side = marker_side; p.constant_block = constant_block;
+  Summary s;
+  std::vector<double> full(6 * p.num_blocks());
+  MarkerChainModel model(p, params);
+  std::vector<double> x(model.num_parameters());
+  model.GetActive(x.data());
+  const auto t0 = std::chrono::steady_clock::now();
+  TrustRegionMinimize(model, ToOptions(oopt), x.data(), &s);
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  model.Scatter(x.data(), full.data());
+  std::memcpy(params, full.data(), sizeof(double) * full.size());
+  FillSummary(s, sec, out, iter_log, max_log);
+  return s.termination;
+}
+
 double oracle_marker_chain_cost(int variant, int T, int C, int M, int N, const int* time_idx, const int* camera_idx,
                                 const int* marker_idx, const double* observations, const double* params,
                                 const double* intrinsics4, double marker_side) {

@@ -27,7 +27,7 @@ EXPORTS = [
     "rsba_solver_destroy", "rsba_points_linearize_and_step", "rsba_points_linearize_payload", "rsba_comm_unique_id", "rsba_comm_loopback_id", "rsba_read_intrinsics_xml",
     "rsba_write_outputs", "rsba_reprojection_error", "rsba_reprojection_check_files",
     "rsba_base_pose_from_marker_detection", "rsba_marker_pose_in_camera", "rsba_marker_corners_in_camera", "rsba_solve_pnp_epnp",
-    "rsba_problem_initial_camera_poses", "rsba_problem_set_camera_constant", "rsba_problem_set_point_constant", "rsba_solver_full_report", "rsba_solver_configure_run",
+    "rsba_problem_initial_camera_poses", "rsba_problem_set_camera_constant", "rsba_problem_set_point_constant", "rsba_problem_set_parameter_block_constant", "rsba_solver_full_report", "rsba_solver_configure_run",
     "rsba_solver_comm_nranks", "rsba_solver_schedule_info", "rsba_comm_shm_id", "rsba_comm_finalize",
 ]
 
@@ -139,6 +139,7 @@ def load():
     lib.rsba_problem_initial_camera_poses.argtypes = [C.c_void_p]
     lib.rsba_problem_set_camera_constant.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.rsba_problem_set_point_constant.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.rsba_problem_set_parameter_block_constant.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     _LIB = lib
     return lib
 
@@ -244,6 +245,9 @@ class Problem:
 
     def set_point_constant(self, point_idx, constant=True):
         _chk(load().rsba_problem_set_point_constant(self.h, point_idx, 1 if constant else 0), "rsba_problem_set_point_constant")
+
+    def set_parameter_block_constant(self, parameter_offset, constant=True):
+        _chk(load().rsba_problem_set_parameter_block_constant(self.h, parameter_offset, 1 if constant else 0), "rsba_problem_set_parameter_block_constant")
 
     def initial_camera_poses(self):
         _chk(load().rsba_problem_initial_camera_poses(self.h), "rsba_problem_initial_camera_poses")

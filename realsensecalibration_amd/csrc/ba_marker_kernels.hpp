@@ -276,6 +276,9 @@ struct MarkerDevice {
     const int nblocks = p.num_cameras + p.num_times + p.num_markers;
     std::vector<char> used(nblocks, 0);
     for (int i = 0; i < N; ++i) { if (p.uses_camera(i)) used[p.camera_block(i)] = 1; used[p.time_block(i)] = 1; if (p.uses_marker(i)) used[p.marker_block(i)] = 1; }
+    // a constant block (rsba_problem_set_parameter_block_constant) keeps its transform in every residual that names it (full_*) and has no
+    // columns (act_* = -1): it is not in the program, as Ceres has it
+    for (int b = 0; b < nblocks && b < (int)p.block_constant.size(); ++b) if (p.block_constant[b]) used[b] = 0;
     std::vector<int> act(nblocks, -1), a2f;
     int na = 0;
     for (int b = 0; b < nblocks; ++b) if (used[b]) { act[b] = 6 * na++; for (int q = 0; q < 6; ++q) a2f.push_back(6 * b + q); }

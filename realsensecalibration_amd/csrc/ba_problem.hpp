@@ -27,6 +27,7 @@ struct rsba_problem {
   std::vector<double> intrinsics;     // 4 per camera: fx, fy, ppx, ppy
   std::vector<uint8_t> camera_constant;  // point model: 1 = problem.SetParameterBlockConstant(camera); empty = none
   std::vector<uint8_t> point_constant;   // point model: the same for point blocks (round 6)
+  std::vector<uint8_t> block_constant;   // marker-chain models: per block of [C cameras | T times | M markers] (round 6); empty = none
 
   int64_t num_parameters() const { return (int64_t)parameters.size(); }
   int obs_dim() const { return model == RSBA_MODEL_POINTS ? 2 : 8; }

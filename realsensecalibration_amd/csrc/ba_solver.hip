@@ -2527,7 +2527,8 @@ int rsba_solver_create(rsba_problem* p, const rsba_options* o, rsba_solver** out
     rc = rsba::UploadPoints(s);
     if (rc == RSBA_OK && s->tiled.tree_error) s->tiled.error_flag = reinterpret_cast<int*>(s->res_host + RES_SIZE + 4);   // (zeroed above)
   } else {
-    s->eliminate_times = rsba::MarkerSchurDevice::Wanted(*p, opt.schur_impl);
+    const bool any_const_block = std::find(p->block_constant.begin(), p->block_constant.end(), (uint8_t)1) != p->block_constant.end();
+    s->eliminate_times = !any_const_block && rsba::MarkerSchurDevice::Wanted(*p, opt.schur_impl);   // (constant blocks: the dense path)
     rc = s->eliminate_times ? s->marker_schur.Upload(*p) : s->marker.Upload(*p);
     if (s->eliminate_times && rc == RSBA_ERR_UNSUPPORTED) {
       // duplicate detections, no camera / marker block at all, or a time wider than the kernel's LDS: the dense path is general
@@ -2685,8 +2686,10 @@ int rsba_solver_full_report(const rsba_solver* s, char* buf, int32_t capacity) {
       if (p.uses_marker(i)) used[p.marker_block(i)] = 1;
     }
     int nu = 0; for (char u : used) nu += u;
-    // blocks no residual touches never enter the ceres::Problem (camera 0 / marker 0 of the reference's wiring)
-    blocks0 = blocks1 = nu; params0 = params1 = 6LL * nu;
+    int nconst = 0;
+    for (int b = 0; b < nb && b < (int)p.block_constant.size(); ++b) nconst += (used[b] && p.block_constant[b]) ? 1 : 0;
+    // blocks no residual touches never enter the ceres::Problem (camera 0 / marker 0 of the reference's wiring); constant ones leave the reduced program
+    blocks0 = nu; params0 = 6LL * nu; blocks1 = nu - nconst; params1 = 6LL * (nu - nconst);
     rblocks = p.num_observations; residuals = 8 * rblocks;
   }
   static const char* kTerm[] = {"CONVERGENCE", "NO_CONVERGENCE", "FAILURE"};

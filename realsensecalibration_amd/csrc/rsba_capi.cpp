@@ -82,6 +82,19 @@ int rsba_problem_set_point_constant(rsba_problem* p, int32_t point_idx, int32_t 
   p->point_constant[point_idx] = constant ? 1 : 0;
   return RSBA_OK;
 }
+int rsba_problem_set_parameter_block_constant(rsba_problem* p, int64_t parameter_offset, int32_t constant) {
+  if (!p || parameter_offset < 0 || parameter_offset >= (int64_t)p->parameters.size()) return RSBA_ERR_ARG;
+  if (p->model == RSBA_MODEL_POINTS) {
+    const int64_t cam_end = 6LL * p->num_cameras;
+    if (parameter_offset < cam_end) return parameter_offset % 6 ? RSBA_ERR_ARG : rsba_problem_set_camera_constant(p, (int32_t)(parameter_offset / 6), constant);
+    return (parameter_offset - cam_end) % 3 ? RSBA_ERR_ARG : rsba_problem_set_point_constant(p, (int32_t)((parameter_offset - cam_end) / 3), constant);
+  }
+  if (parameter_offset % 6) return RSBA_ERR_ARG;
+  const size_t nblocks = (size_t)p->num_cameras + p->num_times + p->num_markers;
+  if (p->block_constant.empty()) p->block_constant.assign(nblocks, 0);
+  p->block_constant[(size_t)(parameter_offset / 6)] = constant ? 1 : 0;
+  return RSBA_OK;
+}
 void rsba_problem_free(rsba_problem* p) { delete p; }
 
 int rsba_base_pose_from_marker_detection(const double* marker_from_camera, const double* marker_from_base, double* base_from_camera) {

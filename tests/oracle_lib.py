@@ -94,6 +94,19 @@ class Oracle:
                                            C.c_double(marker_side), C.byref(o), C.byref(s), dp(log), max_log)
         return params, s, log[: s.num_iterations + 1]
 
+    def solve_marker_chain_constant(self, prob, variant, marker_side, intr, constant_blocks, opts=None, max_log=64):
+        """constant_blocks: indices into the [C cameras | T times | M markers] block array."""
+        params = prob["params"].copy()
+        s = OracleSummary()
+        log = np.zeros((max_log, 8))
+        o = opts or self.options()
+        mask = np.zeros(prob["C"] + prob["T"] + prob["M"], np.uint8)
+        mask[list(constant_blocks)] = 1
+        self.lib.oracle_solve_marker_chain_constant(variant, prob["T"], prob["C"], prob["M"], prob["N"], ip(prob["t"]), ip(prob["c"]),
+                                                    ip(prob["m"]), dp(prob["obs"]), dp(params), dp(np.ascontiguousarray(intr, float)),
+                                                    C.c_double(marker_side), mask.ctypes.data_as(C.c_void_p), C.byref(o), C.byref(s), dp(log), max_log)
+        return params, s, log[: s.num_iterations + 1]
+
     def marker_chain_cost(self, prob, variant, marker_side, intr, params):
         return self.lib.oracle_marker_chain_cost(variant, prob["T"], prob["C"], prob["M"], prob["N"], ip(prob["t"]), ip(prob["c"]),
                                                  ip(prob["m"]), dp(prob["obs"]), dp(np.ascontiguousarray(params, float)),

@@ -843,11 +843,50 @@ def test_constant_points_match_oracle(oracle, shape, const_cams, huber):
 
 
 def test_constant_camera_is_refused_for_the_marker_chain_model():
+    """rsba_problem_set_camera_constant is the point model's call; the marker-chain models take
+    rsba_problem_set_parameter_block_constant (below)."""
     prob = syn.make_marker_chain(3, 10, 4, seed=2)
     p = capi.Problem.marker_chain(prob)
     with pytest.raises(capi.RsbaError):
         p.set_camera_constant(1)
     p.close()
+
+
+def test_constant_blocks_of_the_marker_chain_model_match_oracle(oracle):
+    """rsba_problem_set_parameter_block_constant on the committed hongo input (camera 2, time 3, marker 5: one block of every kind) and
+    on a synthetic rig large enough that the time-eliminating path would be chosen — constant blocks select the dense path.  The oracle's
+    constant handling is itself held to the numpy replay (tests/test_oracle_golden.py)."""
+    intr = ol.read_intrinsics(ol.SERIALS_MAIN)
+    prob = ol.read_correspondence(os.path.join(G, "hongo", "correspondence.txt"))
+    Cn, Tn = prob["C"], prob["T"]
+    const = [2, Cn + 3, Cn + Tn + 5]
+    ref, s_ref, _ = oracle.solve_marker_chain_constant(prob, 0, ol.MARKER_SIDE_MAIN, intr, const)
+    p = capi.Problem.correspondence(os.path.join(G, "hongo", "correspondence.txt"), capi.MODEL_MARKER_CHAIN, ol.MARKER_SIDE_MAIN, intr)
+    for b in const:
+        p.set_parameter_block_constant(6 * b)
+    with pytest.raises(capi.RsbaError):
+        p.set_parameter_block_constant(6 * 2 + 1)   # not the start of a block
+    s = p.solve()
+    got = p.params.copy()
+    p.close()
+    assert s.num_iterations == s_ref.num_iterations and abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
+    for b in const:
+        assert np.array_equal(got[6 * b:6 * b + 6], prob["params"][6 * b:6 * b + 6])
+    assert np.abs(got - ref).max() < 1e-7 * max(1.0, np.abs(ref).max())
+    # a rig with 72 + blocks (more than 384 parameters: the time elimination would be the automatic choice)
+    rig = syn.make_marker_chain(4, 60, 8, seed=5)
+    const2 = [1, rig["C"] + 7, rig["C"] + rig["T"] + 3]
+    ref2, s2_ref, _ = oracle.solve_marker_chain_constant(rig, 0, rig["marker_side"], rig["intr"], const2)
+    p2 = capi.Problem.marker_chain(rig)
+    for b in const2:
+        p2.set_parameter_block_constant(6 * b)
+    s2 = p2.solve()
+    got2 = p2.params.copy()
+    p2.close()
+    assert s2.num_iterations == s2_ref.num_iterations and abs(s2.final_cost - s2_ref.final_cost) < 1e-9 * max(s2_ref.final_cost, 1e-12)
+    for b in const2:
+        assert np.array_equal(got2[6 * b:6 * b + 6], rig["params"][6 * b:6 * b + 6])
+    assert np.abs(got2 - ref2).max() < 1e-6 * max(1.0, np.abs(ref2).max())
 
 
 def test_full_report_of_the_committed_problem():

@@ -155,3 +155,28 @@ def test_sparse_marker_chain_oracle_on_a_synthetic_rig(oracle):
     prob = syn.make_marker_chain(6, 60, 9, seed=4)
     intr = prob["intr"].reshape(-1, 4)
     _sparse_against_dense_and_xml(oracle, prob, 0, prob["marker_side"], intr)
+
+
+def test_constant_blocks_of_the_marker_chain_model_match_the_numpy_replay(oracle):
+    """Problem::SetParameterBlockConstant on blocks of the marker-chain model (round 6): camera 2, time 3 and marker 5 of the
+    committed hongo input keep their file values — applied in every residual that names them, no columns, not in the norms.  The
+    oracle (MarkerChainProblem::constant_block) against the independent numpy replay (tools/replay_point_model.py: complex-step
+    Jacobians, dense normal equations; the same replay reproduces the reference's XML with every block free): same iteration count,
+    final cost to 1e-10, parameters to 1e-9."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("replay_point_model", os.path.join(ol.ROOT, "tools", "replay_point_model.py"))
+    rp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rp)
+    prob = ol.read_correspondence(os.path.join(G, "hongo", "correspondence.txt"))
+    intr = ol.read_intrinsics(ol.SERIALS_MAIN)
+    C, T = prob["C"], prob["T"]
+    const = [2, C + 3, C + T + 5]
+    params, s, log = oracle.solve_marker_chain_constant(prob, 0, ol.MARKER_SIDE_MAIN, intr, const)
+    blocks, summary, rows, _ = rp.mc_solve("hongo", constant_blocks=const)
+    assert s.num_iterations == len(rows) - 1 and summary["termination"] == "CONVERGENCE"
+    assert abs(s.final_cost - summary["final_cost"]) < 1e-10 * summary["final_cost"]
+    assert np.abs(params.reshape(-1, 6) - blocks).max() < 1e-9
+    for b in const:
+        assert np.array_equal(params[6 * b:6 * b + 6], prob["params"][6 * b:6 * b + 6])
+    free, s_free, _ = oracle.solve_marker_chain(prob, 0, ol.MARKER_SIDE_MAIN, intr)
+    assert s.final_cost > s_free.final_cost * (1 + 1e-6), "holding blocks at their initial guess must cost something"

@@ -217,7 +217,7 @@ def mc_parse(path):
     return dict(T=T, C=C, M=M, N=N, t=rows[:, 0].astype(int), c=rows[:, 1].astype(int), m=rows[:, 2].astype(int), obs=rows[:, 3:].copy(), params=params)
 
 
-def mc_problem(path, serials, marker_side, marker0_is_free):
+def mc_problem(path, serials, marker_side, marker0_is_free, constant_blocks=()):
     """marker0_is_free: Test2_BundleAdjustment's variant (bundle_adjustmenter.cpp:217-366) — two functors only, the marker transform
     always applied, marker 0 a block like any other."""
     mc = mc_parse(path)
@@ -227,6 +227,7 @@ def mc_problem(path, serials, marker_side, marker0_is_free):
     used[C + mc["t"]] = True
     mm = mc["m"] if marker0_is_free else mc["m"][mc["m"] != 0]
     used[C + T + mm] = True
+    used[list(constant_blocks)] = False   # Problem::SetParameterBlockConstant: applied in the residuals, not in the program
     free = np.flatnonzero(np.repeat(used, 6))
     intr = np.stack([read_intrinsics(sn) for sn in serials])
     return dict(mc, model="marker_chain", intr=intr, h=marker_side / 2.0, marker0_is_free=marker0_is_free, free=free, full=mc["params"].copy(),
@@ -277,13 +278,13 @@ def rodrigues(w):
     return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * Kx
 
 
-def mc_solve(which):
+def mc_solve(which, constant_blocks=()):
     """'hongo' (Main_Calibration: my_const.h:9,15) or 'test2' (Test2_BundleAdjustment; marker side inferred from test2/point3d.txt's corner
     spacing) -> (all C + T + M blocks after the solve, summary, iteration rows, the problem)."""
     if which == "hongo":
-        prob = mc_problem(os.path.join(GOLDEN, "hongo", "correspondence.txt"), ["821312061029", "816612062327", "821212062536", "821212061326"], 0.0148, False)
+        prob = mc_problem(os.path.join(GOLDEN, "hongo", "correspondence.txt"), ["821312061029", "816612062327", "821212062536", "821212061326"], 0.0148, False, constant_blocks)
     else:
-        prob = mc_problem(os.path.join(GOLDEN, "test2", "correspondence_test.txt"), ["819612072493", "825312072048"], 0.048, True)
+        prob = mc_problem(os.path.join(GOLDEN, "test2", "correspondence_test.txt"), ["819612072493", "825312072048"], 0.048, True, constant_blocks)
     x, summary, rows = minimise(prob)
     full = prob["full"].copy()
     full[prob["free"]] = x
