@@ -15,7 +15,8 @@ What runs, in this order, on ONE solver (same buffers, streams, communicator):
   2. N > 1 only: a 2-iteration PREFLIGHT whose iteration logs are compared bit for bit across the ranks (a mismatch ends the job
      with a non-zero exit; a stalled in-kernel wait selects the sequential multi-GPU schedule, and the line says so),
   3. the per-kernel pass: K iterations with HIP events around every launch (untimed; fills "kernels"),
-  4. untimed filler up to --preload iterations in all, then a DIAGNOSTIC timed region of K iterations: "ms_per_step_steady",
+  4. untimed filler up to --preload iterations in all, then a DIAGNOSTIC timed region of K iterations: "ms_per_step_steady", and a run
+     of 2 K iterations beside it: what a RUN costs beyond its steps, "run_overhead_us" = t_K - K (t_2K - t_K) / K,
   5. W warm-up iterations, then THE timed region: exactly K iterations — "ms_per_step", and `value` is quoted on it; "warmup" = W.
 Round 4 quoted `value` on (4) and reported "warmup": 80 for a command that said 5; now the region the command line describes is
 the last thing that runs and the one the headline is quoted on, and everything in front of it is listed ("untimed_iterations_before").
@@ -255,6 +256,7 @@ def main():
         raise SystemExit("communicator spans %d rank(s), --gpus %d" % (rccl_nranks, args.gpus))
     # diagnostic region ("ms_per_step_steady"): filler up to --preload untimed iterations in all, then K timed
     elapsed_steady = None
+    run_overhead_us = None
     preload = 0
     if args.preload > 0:
         preload = max(0, args.preload - ran_before)
@@ -265,6 +267,18 @@ def main():
             ran_before += preload
         _, elapsed_steady = timed_run()
         ran_before += args.steps
+        # what a RUN costs beyond its steps (the first step's full point pass, the gradient at the last accepted point, reset and
+        # synchronisation, the call): a run of 2 K steps against the run of K just timed — step = (t_2K - t_K) / K, overhead = t_K - K step
+        sv_k.configure_run(2 * args.steps, 0 if args.no_events else 2)
+        sync()
+        t0 = time.perf_counter()
+        s2 = sv_k.run()
+        sync()
+        elapsed_2k = max_over_ranks(time.perf_counter() - t0)
+        assert s2.num_iterations == 2 * args.steps, (s2.num_iterations, 2 * args.steps)
+        ran_before += 2 * args.steps
+        step_s = (elapsed_2k - elapsed_steady) / args.steps
+        run_overhead_us = 1e6 * (elapsed_steady - args.steps * step_s)
     # THE region the command line describes: W warm-up iterations, then exactly K timed ones — the last thing that runs.
     # A line that names a schedule must have run it: a stalled in-kernel wait inside the region (a step repeated sequentially after its
     # 0.5 s budget) or a fallback taken there makes the region worthless — one rank: it is run again (at most twice more) on the same
@@ -314,6 +328,8 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "untimed_iterations_before": ran_before,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "ms_per_step_steady": (1e3 * elapsed_steady / args.steps) if elapsed_steady is not None else None,
+        "run_overhead_us": run_overhead_us,   # per RUN, beyond its steps (from a K- and a 2 K-step run in front of the timed region): ms_per_step carries run_overhead_us / K of it
+        "ms_per_step_without_run_overhead": (1e3 * elapsed / args.steps - 1e-3 * run_overhead_us / args.steps) if run_overhead_us is not None else None,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d cams x %d points, %d observations (%d views/point), point model <2,6,3>, "
                                "DENSE_SCHUR-equivalent; %d points per GPU" % (args.config, C, P_total, N_total, k, P_rank),
