@@ -296,6 +296,12 @@ class Solver:
         return np.array([[a.iteration, a.cost, a.cost_change, a.gradient_max_norm, a.step_norm, a.relative_decrease,
                           a.trust_region_radius, a.step_is_valid + 2 * a.step_is_successful] for a in arr[:n]])
 
+    def iteration_times(self, cap=256):
+        """iteration_time_in_seconds of the latest run's rows (row 0: the evaluation at the start), as the host observed them."""
+        arr = (Iteration * cap)()
+        n = load().rsba_solver_iterations(self.h, arr, cap)
+        return np.array([a.iteration_time_in_seconds for a in arr[:n]])
+
     def kernel_stats(self, cap=32):
         arr = (KernelStat * cap)()
         n = load().rsba_solver_kernel_stats(self.h, arr, cap)

@@ -1245,7 +1245,15 @@ static int UploadPoints(rsba_solver* s) {
 #else
     const bool want_diag = true;   // (the round-robin kernel, RSBA_CHOL_DIAG=0, exists in -DRSBA_EXPERIMENTAL builds only)
 #endif
-    const int want = e ? atoi(e) : (want_diag ? 6 : 4);
+    // (the last camera group as a border — three camera groups or more, the tiled Schur kernel, one rank; RSBA_BORDER=0: every camera group
+    //  through the diagonal-chain kernel — leaves that kernel nine panels instead of twelve at 64 cameras: ONE diagonal and THREE row
+    //  workgroups then (round 6; six alternating runs on one box: 0.3452 - 0.3470 ms per step against 0.3489 - 0.3513 with five row
+    //  workgroups, the driver's twenty-step command 0.3485 against 0.3527; 5: 0.3478 - 0.3483, 7 / 8: 0.351 - 0.353 — every workgroup of
+    //  the factorisation holds a CU's whole LDS for the length of the step, and the row workgroups' traffic shares the Schur kernel's paths))
+    static const bool border_env = !(getenv("RSBA_BORDER") && atoi(getenv("RSBA_BORDER")) == 0);
+    const int ngroups_c = (C + RSBA_TG - 1) / RSBA_TG;
+    const bool border_ok = border_env && want_diag && !s->comm && ngroups_c >= 3;
+    const int want = e ? atoi(e) : (want_diag ? (border_ok ? 3 : 6) : 4);
     if (want > 1 && s->opt.schur_impl != 0 && s->nc >= 6 * RSBA_PB && s->nc <= RSBA_CHOL_MAXN) {
       s->chol_wgs = std::min(want, want_diag ? 8 : RSBA_MC_MAXG);
       if ((rc = DevAlloc(&s->mc_flags, 64))) return rc;
@@ -1253,7 +1261,8 @@ static int UploadPoints(rsba_solver* s) {
       // RSBA_CHOL_DIAG=0: round-robin kernel.  A row workgroup of the diagonal-chain kernel keeps the look-ahead sums of at
       // most four blocks
       const int np_d = MultiCholPadded(s->nc) / RSBA_PB;
-      s->chol_diag = want_diag && s->chol_wgs >= 2 && (np_d - 2 + s->chol_wgs - 2) / (s->chol_wgs - 1) <= 4;
+      const int np_rule = border_ok ? 3 * (ngroups_c - 1) : np_d;   // panels of the system the diagonal-chain kernel factors (the border's workgroup has the rest)
+      s->chol_diag = want_diag && s->chol_wgs >= 2 && (np_rule - 2 + s->chol_wgs - 2) / (s->chol_wgs - 1) <= 4;
 #ifdef RSBA_EXPERIMENTAL
       if (!s->chol_diag) s->chol_wgs = std::min(s->chol_wgs, RSBA_MC_MAXG);
 #else
@@ -1262,9 +1271,7 @@ static int UploadPoints(rsba_solver* s) {
       if (s->chol_diag && (rc = DevAlloc(&s->mc_dg, (size_t)2 * (np_d + 1) * 1024))) return rc;   // look-ahead sums | blocks as handed over
       {
         // the last camera group as a border: three camera groups or more, the tiled Schur kernel, one rank
-        static const bool border_env = !(getenv("RSBA_BORDER") && atoi(getenv("RSBA_BORDER")) == 0);   // (RSBA_BORDER=0: all camera groups through the diagonal-chain kernel)
-        const int ngroups = (C + RSBA_TG - 1) / RSBA_TG;
-        if (border_env && s->chol_diag && !s->comm && ngroups >= 3) s->border_cols = 6 * RSBA_TG * (ngroups - 1);
+        if (border_ok && s->chol_diag) s->border_cols = 6 * RSBA_TG * (ngroups_c - 1);
       }
       HIPCHK(hipFuncSetAttribute((const void*)k_reduced_system_solve_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(std::max(DiagCholLdsDoubles(s->nc), BorderLdsDoubles(s->nc)) * sizeof(double))));
