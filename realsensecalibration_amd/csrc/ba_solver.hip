@@ -372,7 +372,10 @@ static int PairSegmentsPerTile(int C, int P, bool staged) {
   // chunk and 98 points) is a staging round trip and a barrier for a handful of hits per lane: segments of WHOLE chunks —
   // as many chunks as the target length is nearest to.  64 cameras x 125k points (a rank's shard of config 4): 245 segments of one
   // chunk instead of 205 of 9.5 words, 0.437 against 0.471 ms per iteration (round 4); 100k points: 7.6 words, unchanged.
-  if (!getenv("RSBA_SEG_PER_CU") && !SparsePairSegments(C, staged) && nW > RSBA_CW * ns) {
+  // (round 6: also when the target length is only NEAR a chunk — three quarters of one or more: at 100k points the target was 7.6 words,
+  //  205 ragged segments a tile, each staging a chunk's buffers for 488 points; 196 of exactly one chunk: 0.3398 - 0.3409 ms per step
+  //  against 0.3431 - 0.3445, two alternating runs each, RSBA_SEG_TARGET=6 against the default on one box)
+  if (!getenv("RSBA_SEG_PER_CU") && !SparsePairSegments(C, staged) && 4 * (long)nW > 3L * RSBA_CW * ns) {
     const int k = std::max(1, (int)std::lround((double)nW / ns / RSBA_CW));
     ns = std::max(1, (nW + RSBA_CW * k - 1) / (RSBA_CW * k));
   }
@@ -597,7 +600,8 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     const bool self = tab[3 * t + 2] != 0;
     const int nW = (P + 63) / 64;  // mask words that hold points
     // (more than 64 cameras: at most 16 self segments per tile — two reduction groups, no reducer workgroups)
-    const int ns_self = std::max(1, std::min((2 * cus + ngroups - 1) / ngroups, nW));
+    static const int self_per_cu = getenv("RSBA_SELF_PER_CU") ? std::max(1, atoi(getenv("RSBA_SELF_PER_CU"))) : 2;   // (lab knob: self segments of all tiles per CU)
+    const int ns_self = std::max(1, std::min((self_per_cu * cus + ngroups - 1) / ngroups, nW));
     const int ns = self ? (6 * C > RSBA_CHOL_MAXN ? std::min(ns_self, 16) : ns_self) : PairSegmentsPerTile(C, P, staged);
     const std::vector<int> bound = SegmentBounds(nW, ns, self ? 1.0 : PairSegmentTaper(C, staged));
     for (int i = 0; i < ns; ++i) {
@@ -615,7 +619,8 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       // group whose last segment ends late in its stage is what the stage's flag waits for
       // (measured at 64 cameras x 100k points, ms per iteration: groups of 8: 0.411, 6: 0.408, 5: 0.407, 4: 0.406, 3: 0.412, 2: 0.428
       //  — the reducers then read twice the group sums and fall behind)
-      const int GRP = 6 * C > RSBA_CHOL_MAXN ? RSBA_GRP : RSBA_GRP_SMALL;
+      static const int grp_env = getenv("RSBA_GRP_SIZE") ? std::max(1, atoi(getenv("RSBA_GRP_SIZE"))) : 0;   // (lab knob: segments per reduction group)
+      const int GRP = grp_env ? grp_env : (6 * C > RSBA_CHOL_MAXN ? RSBA_GRP : RSBA_GRP_SMALL);
       const int s0 = tsp[t], ns_t = tsp[t + 1] - tsp[t], g0 = ngrp;
       std::vector<int> gsize;
       {
@@ -1992,7 +1997,8 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       //  workgroups: 2 x CUs - 0 / 8 / 14 / 16 / 32: 0.3506 - 0.3516 / 0.3470 - 0.3482 / 0.3491 / 0.3486 - 0.3493 / 0.3465 - 0.3482 ms per
       //  step — nothing beyond the run-to-run spread but the full grid, which is slower)
       // (more than 128 cameras: the tables alone are 80 KB, one workgroup per CU)
-      grid_bs = std::max(1, std::min(C <= 128 ? 2 * DeviceCUs() - 16 : DeviceCUs() - 8, (P + 63) / 64));
+      static const int bs_spare = getenv("RSBA_BS_SPARE") ? atoi(getenv("RSBA_BS_SPARE")) : 16;   // (lab knob: workgroups fewer than the chip holds)
+      grid_bs = std::max(1, std::min(C <= 128 ? 2 * DeviceCUs() - bs_spare : DeviceCUs() - 8, (P + 63) / 64));
       FusedLin fl = fl0b;
       // single GPU: the workgroup that completes the result block takes the step's decision as well, and the damping
       // kernel of the NEXT step is queued right here, behind this kernel, on that decision (LmNext; RSBA_DECIDED_DAMP=0:

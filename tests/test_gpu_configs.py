@@ -337,6 +337,6 @@ def test_diagonal_and_round_robin_cholesky(oracle, C, P, k, huber, diag, monkeyp
     assert abs(s_got.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost
     assert np.array_equal(got, again) and np.array_equal(log_got, log_again)
     monkeypatch.setenv("RSBA_PIPELINE", "0")
-    monkeypatch.setenv("RSBA_SEG_PER_CU", "8")
+    monkeypatch.setenv("RSBA_SEG_TARGET", "8")   # (the pipelined default, through the same whole-chunk rounding)
     seq, s_seq, log_seq = capi.solve_points(prob, capi.default_options(huber_delta=huber))
     assert np.array_equal(got, seq) and np.array_equal(log_got, log_seq)

@@ -368,12 +368,12 @@ def test_pipelined_solve_matches_oracle_and_sequential_schedule(oracle, C, P, k,
     prob = syn.make_problem(C, P, k, seed=300 + C, outlier_frac=0.05 if huber else 0.0)
     got, s, log, _ = _compare_solve(oracle, prob, 1, huber=huber)
     os.environ["RSBA_PIPELINE"] = "0"
-    os.environ["RSBA_SEG_PER_CU"] = "8"   # the pipelined default: same segments, same summation order
+    os.environ["RSBA_SEG_TARGET"] = "8"   # the pipelined default (eight per CU through the whole-chunk rounding): same segments, same summation order
     try:
         seq, s_seq, log_seq = capi.solve_points(prob, capi.default_options(schur_impl=1, huber_delta=huber))
     finally:
         del os.environ["RSBA_PIPELINE"]
-        del os.environ["RSBA_SEG_PER_CU"]
+        del os.environ["RSBA_SEG_TARGET"]
     assert np.array_equal(got, seq) and np.array_equal(log, log_seq) and s.final_cost == s_seq.final_cost
     again, s2, log2 = capi.solve_points(prob, capi.default_options(schur_impl=1, huber_delta=huber))
     assert np.array_equal(got, again) and np.array_equal(log, log2)
@@ -568,7 +568,7 @@ def test_config3_full_size_properties():
     s2 = sv2.run()
     log2 = sv2.iterations()
     os.environ["RSBA_PIPELINE"] = "0"
-    os.environ["RSBA_SEG_PER_CU"] = "8"
+    os.environ["RSBA_SEG_TARGET"] = "8"
     try:
         sv3 = capi.Solver(problem, capi.default_options())
         s3 = sv3.run()
@@ -576,7 +576,7 @@ def test_config3_full_size_properties():
         sv3.close()
     finally:
         del os.environ["RSBA_PIPELINE"]
-        del os.environ["RSBA_SEG_PER_CU"]
+        del os.environ["RSBA_SEG_TARGET"]
     assert np.array_equal(log, log2) and s.final_cost == s2.final_cost
     assert np.array_equal(log, log3) and s.final_cost == s3.final_cost
     sv2.download()                                                        # the solution becomes the problem's start
@@ -929,12 +929,12 @@ def test_multi_workgroup_cholesky_matches_oracle_and_single_workgroup(oracle, C,
         assert so.num_iterations == s.num_iterations
         assert np.abs(other - got).max() < 1e-9 * max(1.0, np.abs(got).max()), g
     os.environ["RSBA_PIPELINE"] = "0"
-    os.environ["RSBA_SEG_PER_CU"] = "8"
+    os.environ["RSBA_SEG_TARGET"] = "8"
     try:
         seq, s_seq, log_seq = capi.solve_points(prob)
     finally:
         del os.environ["RSBA_PIPELINE"]
-        del os.environ["RSBA_SEG_PER_CU"]
+        del os.environ["RSBA_SEG_TARGET"]
     assert np.array_equal(got, seq) and np.array_equal(log, log_seq)
 
 
