@@ -338,6 +338,15 @@ static std::vector<int> SegmentBounds(int nW, int ns, double taper = 1.0) {
   // length): 1.  Above 64 cameras (sparse pair segments, handed out by point range: the last ranges are the short ones)
   // the launch is 2.6 rounds of ~110 us blocks deep and its tail was 100 us long: 4 (419 -> 385 us at the config-5 shard).
   std::vector<int> bound(ns + 1, 0);
+  if (taper == 1.0 && ns >= 1) {
+    // as many segments as whole runs of k chunks give (PairSegmentsPerTile's and the self segments' rounding): cut exactly there — an even
+    // split of the words (1563 words into 196: 7.97 each) drifts off the chunk boundaries, and a segment that straddles one stages two chunks
+    const int k = std::max(1, (int)std::lround((double)nW / ns / RSBA_CW));
+    if ((nW + RSBA_CW * k - 1) / (RSBA_CW * k) == ns) {
+      for (int i = 0; i <= ns; ++i) bound[i] = std::min(nW, i * RSBA_CW * k);
+      return bound;
+    }
+  }
   const double hi = 2.0 * taper / (taper + 1.0), lo = 2.0 - hi;
   double cum = 0.0;
   for (int i = 0; i < ns; ++i) { cum += ns > 1 ? hi - (hi - lo) * i / (ns - 1) : 1.0; bound[i + 1] = (int)std::llround(nW * cum / ns); }
@@ -601,7 +610,15 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     const int nW = (P + 63) / 64;  // mask words that hold points
     // (more than 64 cameras: at most 16 self segments per tile — two reduction groups, no reducer workgroups)
     static const int self_per_cu = getenv("RSBA_SELF_PER_CU") ? std::max(1, atoi(getenv("RSBA_SELF_PER_CU"))) : 2;   // (lab knob: self segments of all tiles per CU)
-    const int ns_self = std::max(1, std::min((self_per_cu * cus + ngroups - 1) / ngroups, nW));
+    static const int self_segs_env = getenv("RSBA_SELF_SEGS") ? std::max(1, atoi(getenv("RSBA_SELF_SEGS"))) : 0;       // (lab knob: ... per tile)
+    int ns_self = std::max(1, std::min(self_segs_env ? self_segs_env : (self_per_cu * cus + ngroups - 1) / ngroups, nW));
+    // (round 6: the self segments too in WHOLE chunks where their target length is three quarters of a chunk or more — they walk the chunk
+    //  buffers like the pair segments do.  100k points: 98 segments of two chunks a tile instead of 128 of 12.2 words, 0.3357 - 0.3383 ms per
+    //  step against 0.3423; 66 of three 0.3377 - 0.3395, 196 of one 0.3475 - 0.3493 — two alternating runs each on one box)
+    if (!self_segs_env && !SparsePairSegments(C, staged) && 4 * (long)nW > 3L * RSBA_CW * ns_self) {
+      const int k = std::max(1, (int)std::lround((double)nW / ns_self / RSBA_CW));
+      ns_self = std::max(1, (nW + RSBA_CW * k - 1) / (RSBA_CW * k));
+    }
     const int ns = self ? (6 * C > RSBA_CHOL_MAXN ? std::min(ns_self, 16) : ns_self) : PairSegmentsPerTile(C, P, staged);
     const std::vector<int> bound = SegmentBounds(nW, ns, self ? 1.0 : PairSegmentTaper(C, staged));
     for (int i = 0; i < ns; ++i) {
