@@ -913,8 +913,18 @@ k_marker_schur_finish(int nb_time, const double* __restrict__ bp_time, const dou
   }
 }
 
+}  // namespace rsba
+#include "ba_marker_split.hpp"
+namespace rsba {
+
 struct MarkerSchurDevice {
   int N = 0, T = 0, nr = 0, nfull = 0, G = 0, dmax = 0, nb_time = 0;
+  // the split elimination (ba_marker_split.hpp; RSBA_MT_SPLIT=0: k_time_eliminate)
+  bool split = true;
+  int nslots = 0, nx = 0, ncam_cols = 0;
+  int *slot_order = nullptr, *slot_time = nullptr, *sb_ptr = nullptr, *sb_blk = nullptr, *xi_ptr = nullptr, *xi_blk = nullptr, *xi_cc = nullptr, *xi_cm = nullptr, *xc_ptr = nullptr;
+  double *sp = nullptr, *xout = nullptr, *tscal = nullptr;
+  size_t lds_acc = 0;
   bool backsub_wg = false;   // k_time_backsub_wg instead of k_time_backsub_terms
   double* posec_c = nullptr; // pose constants of the candidate's cameras and markers
   double half_side = 0;
@@ -936,7 +946,8 @@ struct MarkerSchurDevice {
 
   void Free() {
     void* ptrs[] = {mo, ts, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ok_flag, obs8, intr, params[0], params[1],
-                    params0, posec, posec_c, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res, tc_flags, tc_hand, tc_map};
+                    params0, posec, posec_c, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res, tc_flags, tc_hand, tc_map,
+                    slot_order, slot_time, sb_ptr, sb_blk, xi_ptr, xi_blk, xi_cc, xi_cm, xc_ptr, sp, xout, tscal};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     mo = nullptr; ts = nullptr;
   }
@@ -1029,6 +1040,12 @@ struct MarkerSchurDevice {
     lds_elim = (size_t)(13 * dmax + 96 + RSBA_MT_TILE * (RSBA_MT_JLD + 9) + (dmax / 6 + 2) * CC_STRIDE) * sizeof(double) + (size_t)(2 * RSBA_MT_TILE + 3 * (dmax / 6 + 1) + 2) * sizeof(int);
     lds_s = lds_elim + (PL.packed() + 3 * (size_t)nr) * sizeof(double) <= 156 * 1024;
     if (lds_s) lds_elim += (PL.packed() + 3 * (size_t)nr) * sizeof(double);
+    split = !(getenv("RSBA_MT_SPLIT") && atoi(getenv("RSBA_MT_SPLIT")) == 0);
+    if (split) {
+      lds_s = AccLdsBytes(dmax, PL.packed() + 3 * (size_t)nr) <= 156 * 1024;
+      lds_acc = AccLdsBytes(dmax, lds_s ? PL.packed() + 3 * (size_t)nr : 0);
+      if (lds_acc > 156 * 1024) return RSBA_ERR_UNSUPPORTED;
+    }
     // Without the LDS accumulators every entry is a read-modify-write in the partial system: few enough workgroups that
     // their partial systems stay in the L2s (8 x 4 MB) then, as many as there are times otherwise (at most 1024).
     // With the sums in LDS a workgroup fills a CU: one chunk per CU (more chunks only add partial systems to write, to
@@ -1052,6 +1069,58 @@ struct MarkerSchurDevice {
       std::vector<int> c2; c2.push_back(0);
       for (int k = 1; k <= G; ++k) if (cptr[k] > c2.back()) c2.push_back(cptr[k]);
       G = (int)c2.size() - 1; cptr = c2;
+    }
+    // the split elimination's tables: a (time, slot)'s residual blocks, the thread order, the camera-marker pairs of every chunk
+    std::vector<int> h_slot_time, h_sb_ptr, h_sb_blk, h_order, h_xi_ptr, h_xi_blk, h_xi_cc, h_xi_cm, h_xc_ptr;
+    if (split) {
+      nslots = (int)scol.size();
+      ncam_cols = 0;
+      for (int b = 0; b < C; ++b) if (used[b]) ncam_cols += 6;
+      h_slot_time.resize(nslots);
+      h_sb_ptr.assign(nslots + 1, 0);
+      for (int t = 0; t < T; ++t) {
+        for (int S = sptr[t]; S < sptr[t + 1]; ++S) h_slot_time[S] = t;
+        for (int k = tptr[t]; k < tptr[t + 1]; ++k) {
+          if (hts[k].slot_cam >= 0) h_sb_ptr[sptr[t] + hts[k].slot_cam + 1]++;
+          if (hts[k].slot_marker >= 0) h_sb_ptr[sptr[t] + hts[k].slot_marker + 1]++;
+        }
+      }
+      for (int S = 0; S < nslots; ++S) h_sb_ptr[S + 1] += h_sb_ptr[S];
+      h_sb_blk.resize(h_sb_ptr[nslots]);
+      {
+        std::vector<int> fill(h_sb_ptr.begin(), h_sb_ptr.end() - 1);
+        for (int t = 0; t < T; ++t)
+          for (int k = tptr[t]; k < tptr[t + 1]; ++k) {
+            if (hts[k].slot_cam >= 0) h_sb_blk[fill[sptr[t] + hts[k].slot_cam]++] = k;
+            if (hts[k].slot_marker >= 0) h_sb_blk[fill[sptr[t] + hts[k].slot_marker]++] = k;
+          }
+      }
+      h_order.resize(nslots);
+      for (int S = 0; S < nslots; ++S) h_order[S] = S;
+      std::stable_sort(h_order.begin(), h_order.end(), [&](int x, int y) {
+        const bool cx = scol[x] < ncam_cols, cy = scol[y] < ncam_cols;
+        if (cx != cy) return cx;
+        return h_sb_ptr[x + 1] - h_sb_ptr[x] > h_sb_ptr[y + 1] - h_sb_ptr[y];
+      });
+      h_xc_ptr.assign(G + 1, 0);
+      h_xi_ptr.push_back(0);
+      for (int g = 0; g < G; ++g) {
+        std::vector<std::pair<std::pair<int, int>, int>> items;   // ((camera column, marker column), residual block)
+        for (int t = cptr[g]; t < cptr[g + 1]; ++t)
+          for (int k = tptr[t]; k < tptr[t + 1]; ++k)
+            if (hts[k].col_cam >= 0 && hts[k].col_marker >= 0) items.push_back({{hts[k].col_cam, hts[k].col_marker}, k});
+        std::stable_sort(items.begin(), items.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        for (size_t i = 0; i < items.size(); ++i) {
+          if (i == 0 || items[i].first != items[i - 1].first) {
+            if (i != 0) h_xi_ptr.push_back((int)h_xi_blk.size());
+            h_xi_cc.push_back(items[i].first.first); h_xi_cm.push_back(items[i].first.second);
+          }
+          h_xi_blk.push_back(items[i].second);
+        }
+        if (!items.empty()) h_xi_ptr.push_back((int)h_xi_blk.size());
+        h_xc_ptr[g + 1] = (int)h_xi_cc.size();
+      }
+      nx = (int)h_xi_cc.size();
     }
     // (k_time_backsub_wg: a corner of a residual block per lane, two per lane at most; wider times take the wavefront-per-time kernel)
     { int widest = 0; for (int t = 0; t < T; ++t) widest = std::max(widest, tptr[t + 1] - tptr[t]); backsub_wg = widest <= 128 /* 4 x 128 corners = 512 lanes */ && !(getenv("RSBA_MT_BACKSUB_WG") && atoi(getenv("RSBA_MT_BACKSUB_WG")) == 0); }
@@ -1078,11 +1147,26 @@ struct MarkerSchurDevice {
         !up(params0, p.parameters.data(), nfull * 8))
       return RSBA_ERR_HIP;
     if (hipMemset(res, 0, RES_SIZE * 8) != hipSuccess) return RSBA_ERR_HIP;
+    if (split) {
+      if (!al((void**)&slot_order, (size_t)nslots * 4) || !al((void**)&slot_time, (size_t)nslots * 4) || !al((void**)&sb_ptr, ((size_t)nslots + 1) * 4) ||
+          !al((void**)&sb_blk, h_sb_blk.size() * 4) || !al((void**)&xi_ptr, ((size_t)nx + 1) * 4) || !al((void**)&xi_blk, h_xi_blk.size() * 4) ||
+          !al((void**)&xi_cc, (size_t)nx * 4) || !al((void**)&xi_cm, (size_t)nx * 4) || !al((void**)&xc_ptr, ((size_t)G + 1) * 4) ||
+          !al((void**)&sp, (size_t)nslots * RSBA_SP_STRIDE * 8) || !al((void**)&xout, (size_t)nx * 36 * 8) || !al((void**)&tscal, 4 * (size_t)T * 8))
+        return RSBA_ERR_HIP;
+      if (!up(slot_order, h_order.data(), (size_t)nslots * 4) || !up(slot_time, h_slot_time.data(), (size_t)nslots * 4) ||
+          !up(sb_ptr, h_sb_ptr.data(), ((size_t)nslots + 1) * 4) || !up(sb_blk, h_sb_blk.data(), h_sb_blk.size() * 4) ||
+          !up(xi_ptr, h_xi_ptr.data(), ((size_t)nx + 1) * 4) || !up(xi_blk, h_xi_blk.data(), h_xi_blk.size() * 4) ||
+          !up(xi_cc, h_xi_cc.data(), (size_t)nx * 4) || !up(xi_cm, h_xi_cm.data(), (size_t)nx * 4) || !up(xc_ptr, h_xc_ptr.data(), ((size_t)G + 1) * 4))
+        return RSBA_ERR_HIP;
+      if (lds_acc > 48 * 1024 &&
+          hipFuncSetAttribute(lds_s ? (const void*)k_mc_accumulate<true> : (const void*)k_mc_accumulate<false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc) != hipSuccess) return RSBA_ERR_HIP;
+    }
     if (backsub_wg) {
       const size_t lds_bw = (size_t)(dmax / 6 + 1) * (CC_STRIDE + 12 + 6) * sizeof(double);
       if (lds_bw > 48 * 1024 && hipFuncSetAttribute((const void*)k_time_backsub_wg<2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bw) != hipSuccess) return RSBA_ERR_HIP;
     }
-    if (lds_elim > 48 * 1024 &&
+    if (!split && lds_elim > 48 * 1024 &&
         hipFuncSetAttribute(lds_s ? (const void*)k_time_eliminate<true> : (const void*)k_time_eliminate<false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_elim) != hipSuccess) return RSBA_ERR_HIP;
     if (nr <= RSBA_CHOL_MAXN) {
@@ -1139,11 +1223,33 @@ struct MarkerSchurDevice {
     k_pose_constants<<<(nfull / 6 + 255) / 256, 256, 0, st>>>(nfull / 6, params[x], posec);
     Tm.End(st);
     ElimArgs ea{nr, dmax, (int)N, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ts, mo, obs8, intr, posec, half_side, params[x], scale_t, tdata, part, ip};
-    Tm.Begin("k_time_eliminate", st);
-    if (lds_s) k_time_eliminate<true><<<G, RSBA_MT_THREADS, lds_elim, st>>>(ea);
-    else k_time_eliminate<false><<<G, RSBA_MT_THREADS, lds_elim, st>>>(ea);
-    Tm.End(st);
-    if (!chk("k_time_eliminate")) return RSBA_ERR_HIP;
+    if (split) {
+      SplitArgs sa{nslots, T, nx, ncam_cols, slot_order, slot_time, slot_col, sb_ptr, sb_blk, time_ptr, time_full, col_full, ts, mo, obs8, intr, posec, half_side,
+                   xi_ptr, xi_blk, xi_cc, xi_cm, sp, xout};
+      Tm.Begin("k_mc_slot_products", st);
+      k_mc_slot_products<<<(nslots + 255) / 256, 256, 0, st>>>(sa);
+      Tm.End(st);
+      Tm.Begin("k_mc_time_products", st);
+      k_mc_time_products<<<(T + 3) / 4, 256, 0, st>>>(sa, ip, params[x], scale_t, tdata, tscal);
+      Tm.End(st);
+      if (nx > 0) {
+        Tm.Begin("k_mc_cross", st);
+        k_mc_cross<<<(nx + 255) / 256, 256, 0, st>>>(sa);
+        Tm.End(st);
+      }
+      AccArgs aa{nr, dmax, chunk_ptr, slot_ptr, slot_col, sp, tdata, tscal, xc_ptr, xi_cc, xi_cm, xout, part};
+      Tm.Begin("k_mc_accumulate", st);
+      if (lds_s) k_mc_accumulate<true><<<G, RSBA_MT_THREADS, lds_acc, st>>>(aa);
+      else k_mc_accumulate<false><<<G, RSBA_MT_THREADS, lds_acc, st>>>(aa);
+      Tm.End(st);
+      if (!chk("split elimination")) return RSBA_ERR_HIP;
+    } else {
+      Tm.Begin("k_time_eliminate", st);
+      if (lds_s) k_time_eliminate<true><<<G, RSBA_MT_THREADS, lds_elim, st>>>(ea);
+      else k_time_eliminate<false><<<G, RSBA_MT_THREADS, lds_elim, st>>>(ea);
+      Tm.End(st);
+      if (!chk("k_time_eliminate")) return RSBA_ERR_HIP;
+    }
     Tm.Begin("k_marker_reduce", st);
     k_marker_reduce<<<(unsigned)((PartLayout{nr}.size() + 63) / 64), 512, 0, st>>>(nr, G, part, red);
     Tm.End(st);
