@@ -925,6 +925,13 @@ struct MarkerSchurDevice {
   int *slot_order = nullptr, *slot_time = nullptr, *sb_ptr = nullptr, *sb_blk = nullptr, *xi_ptr = nullptr, *xi_blk = nullptr, *xi_cc = nullptr, *xi_cm = nullptr, *xc_ptr = nullptr;
   double *sp = nullptr, *xout = nullptr, *tscal = nullptr;
   size_t lds_acc = 0;
+  bool split_backsub = false;   // k_mc_time_step + k_mc_candidate instead of k_time_backsub_wg / _terms
+  int* blk_time = nullptr;
+  int ncand_wg = 0;
+  int acc_tiles = 0;   // > 0: k_mc_accumulate_mfma with that many tiles a wavefront
+  int acc_tb = 2;      // ... and times per step (three tiles a wavefront; eight: one)
+  hipStream_t fork_s[2] = {nullptr, nullptr};   // the three product kernels side by side
+  hipEvent_t fork_ev[3] = {nullptr, nullptr, nullptr};
   bool backsub_wg = false;   // k_time_backsub_wg instead of k_time_backsub_terms
   double* posec_c = nullptr; // pose constants of the candidate's cameras and markers
   double half_side = 0;
@@ -947,9 +954,11 @@ struct MarkerSchurDevice {
   void Free() {
     void* ptrs[] = {mo, ts, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ok_flag, obs8, intr, params[0], params[1],
                     params0, posec, posec_c, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res, tc_flags, tc_hand, tc_map,
-                    slot_order, slot_time, sb_ptr, sb_blk, xi_ptr, xi_blk, xi_cc, xi_cm, xc_ptr, sp, xout, tscal};
+                    slot_order, slot_time, sb_ptr, sb_blk, xi_ptr, xi_blk, xi_cc, xi_cm, xc_ptr, sp, xout, tscal, blk_time};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     mo = nullptr; ts = nullptr;
+    for (auto& q : fork_s) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
+    for (auto& q : fork_ev) if (q) { (void)hipEventDestroy(q); q = nullptr; }
   }
 
   // true when the problem should take this path (schur_impl: 0 never, 1 when the dense system outgrows one workgroup, 2 always)
@@ -1042,8 +1051,17 @@ struct MarkerSchurDevice {
     if (lds_s) lds_elim += (PL.packed() + 3 * (size_t)nr) * sizeof(double);
     split = !(getenv("RSBA_MT_SPLIT") && atoi(getenv("RSBA_MT_SPLIT")) == 0);
     if (split) {
-      lds_s = AccLdsBytes(dmax, PL.packed() + 3 * (size_t)nr) <= 156 * 1024;
-      lds_acc = AccLdsBytes(dmax, lds_s ? PL.packed() + 3 * (size_t)nr : 0);
+      const int per_wave = (AccMfmaTiles(nr) + 15) / 16;
+      acc_tiles = (per_wave <= 8 && !(getenv("RSBA_MT_ACC_MFMA") && atoi(getenv("RSBA_MT_ACC_MFMA")) == 0)) ? (per_wave <= 3 ? 3 : 8) : 0;
+      if (acc_tiles > 0) {
+        lds_s = true;   // (the chunk's sums never touch memory before the end: one chunk per CU, as with the sums in LDS)
+        if (getenv("RSBA_MT_ACC_TB")) acc_tb = atoi(getenv("RSBA_MT_ACC_TB")) >= 2 ? 2 : 1;
+        if (acc_tiles == 8) acc_tb = 1;
+        lds_acc = AccMfmaLdsBytes(nr, acc_tb);
+      } else {
+        lds_s = AccLdsBytes(dmax, PL.packed() + 3 * (size_t)nr) <= 156 * 1024;
+        lds_acc = AccLdsBytes(dmax, lds_s ? PL.packed() + 3 * (size_t)nr : 0);
+      }
       if (lds_acc > 156 * 1024) return RSBA_ERR_UNSUPPORTED;
     }
     // Without the LDS accumulators every entry is a read-modify-write in the partial system: few enough workgroups that
@@ -1125,6 +1143,8 @@ struct MarkerSchurDevice {
     // (k_time_backsub_wg: a corner of a residual block per lane, two per lane at most; wider times take the wavefront-per-time kernel)
     { int widest = 0; for (int t = 0; t < T; ++t) widest = std::max(widest, tptr[t + 1] - tptr[t]); backsub_wg = widest <= 128 /* 4 x 128 corners = 512 lanes */ && !(getenv("RSBA_MT_BACKSUB_WG") && atoi(getenv("RSBA_MT_BACKSUB_WG")) == 0); }
     nb_time = backsub_wg ? T : (T + 3) / 4;
+    split_backsub = split && !(getenv("RSBA_MT_SPLIT_BACKSUB") && atoi(getenv("RSBA_MT_SPLIT_BACKSUB")) == 0);
+    if (split_backsub) { ncand_wg = (N + 255) / 256; nb_time = T + ncand_wg; }
     auto al = [](void** q, size_t bytes) { return hipMalloc(q, std::max<size_t>(bytes, 8)) == hipSuccess; };
     const size_t nA = (size_t)(nr + 2) * nr;
     if (!al((void**)&mo, N * sizeof(MarkerObs)) || !al((void**)&ts, N * sizeof(TimeSlots)) || !al((void**)&chunk_ptr, (G + 1) * 4) ||
@@ -1153,14 +1173,25 @@ struct MarkerSchurDevice {
           !al((void**)&xi_cc, (size_t)nx * 4) || !al((void**)&xi_cm, (size_t)nx * 4) || !al((void**)&xc_ptr, ((size_t)G + 1) * 4) ||
           !al((void**)&sp, (size_t)nslots * RSBA_SP_STRIDE * 8) || !al((void**)&xout, (size_t)nx * 36 * 8) || !al((void**)&tscal, 4 * (size_t)T * 8))
         return RSBA_ERR_HIP;
+      if (split_backsub) {
+        std::vector<int> h_bt(N);
+        for (int t = 0; t < T; ++t) for (int k = tptr[t]; k < tptr[t + 1]; ++k) h_bt[k] = t;
+        if (!al((void**)&blk_time, (size_t)N * 4) || !up(blk_time, h_bt.data(), (size_t)N * 4)) return RSBA_ERR_HIP;
+      }
       if (!up(slot_order, h_order.data(), (size_t)nslots * 4) || !up(slot_time, h_slot_time.data(), (size_t)nslots * 4) ||
           !up(sb_ptr, h_sb_ptr.data(), ((size_t)nslots + 1) * 4) || !up(sb_blk, h_sb_blk.data(), h_sb_blk.size() * 4) ||
           !up(xi_ptr, h_xi_ptr.data(), ((size_t)nx + 1) * 4) || !up(xi_blk, h_xi_blk.data(), h_xi_blk.size() * 4) ||
           !up(xi_cc, h_xi_cc.data(), (size_t)nx * 4) || !up(xi_cm, h_xi_cm.data(), (size_t)nx * 4) || !up(xc_ptr, h_xc_ptr.data(), ((size_t)G + 1) * 4))
         return RSBA_ERR_HIP;
-      if (lds_acc > 48 * 1024 &&
-          hipFuncSetAttribute(lds_s ? (const void*)k_mc_accumulate<true> : (const void*)k_mc_accumulate<false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc) != hipSuccess) return RSBA_ERR_HIP;
+      const void* kacc = acc_tiles == 3 ? (acc_tb == 2 ? (const void*)k_mc_accumulate_mfma<3, 2> : (const void*)k_mc_accumulate_mfma<3, 1>) : acc_tiles == 8 ? (const void*)k_mc_accumulate_mfma<8, 1>
+                         : lds_s ? (const void*)k_mc_accumulate<true> : (const void*)k_mc_accumulate<false>;
+      if (lds_acc > 48 * 1024 && hipFuncSetAttribute(kacc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc) != hipSuccess) return RSBA_ERR_HIP;
+      if (!(getenv("RSBA_MT_FORK") && atoi(getenv("RSBA_MT_FORK")) == 0)) {
+        bool ok = true;
+        for (auto& q : fork_s) ok = ok && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess;
+        for (auto& q : fork_ev) ok = ok && hipEventCreateWithFlags(&q, hipEventDisableTiming) == hipSuccess;
+        if (!ok) return RSBA_ERR_HIP;
+      }
     }
     if (backsub_wg) {
       const size_t lds_bw = (size_t)(dmax / 6 + 1) * (CC_STRIDE + 12 + 6) * sizeof(double);
@@ -1226,20 +1257,35 @@ struct MarkerSchurDevice {
     if (split) {
       SplitArgs sa{nslots, T, nx, ncam_cols, slot_order, slot_time, slot_col, sb_ptr, sb_blk, time_ptr, time_full, col_full, ts, mo, obs8, intr, posec, half_side,
                    xi_ptr, xi_blk, xi_cc, xi_cm, sp, xout};
+      // the three product kernels are independent and none fills the chip: side by side on three streams (one after the other
+      // when every kernel is timed)
+      const bool fork = fork_s[0] != nullptr && !Tm.enabled();
+      hipStream_t s_time = fork ? fork_s[0] : st, s_cross = fork ? fork_s[1] : st;
+      if (fork) {
+        if (hipEventRecord(fork_ev[0], st) != hipSuccess || hipStreamWaitEvent(s_time, fork_ev[0], 0) != hipSuccess ||
+            hipStreamWaitEvent(s_cross, fork_ev[0], 0) != hipSuccess) return RSBA_ERR_HIP;
+      }
       Tm.Begin("k_mc_slot_products", st);
       k_mc_slot_products<<<(nslots + 255) / 256, 256, 0, st>>>(sa);
       Tm.End(st);
       Tm.Begin("k_mc_time_products", st);
-      k_mc_time_products<<<(T + 3) / 4, 256, 0, st>>>(sa, ip, params[x], scale_t, tdata, tscal);
+      k_mc_time_products<<<(T + 3) / 4, 256, 0, s_time>>>(sa, ip, params[x], scale_t, tdata, tscal);
       Tm.End(st);
       if (nx > 0) {
         Tm.Begin("k_mc_cross", st);
-        k_mc_cross<<<(nx + 255) / 256, 256, 0, st>>>(sa);
+        k_mc_cross<<<(nx + 255) / 256, 256, 0, s_cross>>>(sa);
         Tm.End(st);
+      }
+      if (fork) {
+        if (hipEventRecord(fork_ev[1], s_time) != hipSuccess || hipEventRecord(fork_ev[2], s_cross) != hipSuccess ||
+            hipStreamWaitEvent(st, fork_ev[1], 0) != hipSuccess || hipStreamWaitEvent(st, fork_ev[2], 0) != hipSuccess) return RSBA_ERR_HIP;
       }
       AccArgs aa{nr, dmax, chunk_ptr, slot_ptr, slot_col, sp, tdata, tscal, xc_ptr, xi_cc, xi_cm, xout, part};
       Tm.Begin("k_mc_accumulate", st);
-      if (lds_s) k_mc_accumulate<true><<<G, RSBA_MT_THREADS, lds_acc, st>>>(aa);
+      if (acc_tiles == 3 && acc_tb == 2) k_mc_accumulate_mfma<3, 2><<<G, RSBA_MT_THREADS, lds_acc, st>>>(aa);
+      else if (acc_tiles == 3) k_mc_accumulate_mfma<3, 1><<<G, RSBA_MT_THREADS, lds_acc, st>>>(aa);
+      else if (acc_tiles == 8) k_mc_accumulate_mfma<8, 1><<<G, RSBA_MT_THREADS, lds_acc, st>>>(aa);
+      else if (lds_s) k_mc_accumulate<true><<<G, RSBA_MT_THREADS, lds_acc, st>>>(aa);
       else k_mc_accumulate<false><<<G, RSBA_MT_THREADS, lds_acc, st>>>(aa);
       Tm.End(st);
       if (!chk("split elimination")) return RSBA_ERR_HIP;
@@ -1285,7 +1331,11 @@ struct MarkerSchurDevice {
     }
     if (!chk("reduced solve")) return RSBA_ERR_HIP;
     Tm.Begin("k_time_backsub_terms", st);
-    if (backsub_wg) {
+    if (split_backsub) {
+      k_pose_constants_reduced<<<(nr / 6 + 63) / 64, 64, 0, st>>>(nr / 6, col_full, params[c], posec_c);
+      k_mc_time_step<<<(8 * T + 255) / 256, 256, 0, st>>>(T, slot_ptr, slot_col, time_full, sp, tdata, delta_r, params[x], params[c], delta_t, posec_c, bp_time);
+      k_mc_candidate<<<ncand_wg, 256, 0, st>>>(N, T, ts, mo, obs8, intr, half_side, posec, posec_c, delta_r, delta_t, blk_time, bp_time);
+    } else if (backsub_wg) {
       k_pose_constants_reduced<<<(nr / 6 + 63) / 64, 64, 0, st>>>(nr / 6, col_full, params[c], posec_c);
       const size_t lds_bw = (size_t)(dmax / 6 + 1) * (CC_STRIDE + 12 + 6) * sizeof(double);   // the shot's tables (k_time_backsub_wg)
       k_time_backsub_wg<2, 256><<<T, 256, lds_bw, st>>>(T, time_ptr, time_full, ts, mo, obs8, intr, half_side, posec, posec_c, tdata, delta_r, params[x],

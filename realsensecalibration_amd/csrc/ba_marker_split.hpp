@@ -436,4 +436,318 @@ __global__ void __launch_bounds__(RSBA_MT_THREADS) k_mc_accumulate(AccArgs a) {
   if (tid == 0) { P[RL.scal() + 0] = cost; P[RL.scal() + 1] = xn2; P[RL.scal() + 2] = fail; P[RL.scal() + 3] = gmax; }
 }
 
+// k_mc_accumulate for reduced systems of up to 240 columns: W'Y on the matrix cores, the chunk's sum of it in the wavefronts' registers.
+// The VALU form above reads 10 LDS words per entry of a time's block of W'Y and adds every entry into the chunk's sum in LDS (6 us a
+// time at 22 slots: LDS-bound).  Here a time's W goes into a dense 8 x nrp strip in GLOBAL reduced columns (absent slots: zeros; row 6:
+// g_s, which meets a zero row of Y; row 7: zeros), Y = E W likewise, and every 16 x 16 tile of the lower triangle belongs to one
+// wavefront for the whole chunk: two v_mfma_f64_16x16x4_f64 per tile and time, operands straight from the strips, the sum never leaves
+// the accumulators.  U_ss, g_s and -W'E g_t have their own small sums in LDS (added by the owner of a COLUMN, time after time: the
+// slot that holds a column changes from time to time); at the end  S = U_ss + U_cm - sum W'Y  is put together in the partial system.
+// kTB times per step, two barriers a step: [Y = E W, the small sums, zero the other strips] | [MFMA, the next step's records into the
+// other strips] — the records' trip from memory (~2 us, the whole of a one-time step) is paid once per kTB times.
+typedef double d4_acc __attribute__((ext_vector_type(4)));
+__host__ __device__ inline int AccMfmaTiles(int nr) { const int nt = (nr + 15) / 16; return nt * (nt + 1) / 2; }
+__host__ __device__ inline size_t AccMfmaLdsBytes(int nr, int tb) {
+  const int nrp = ((nr + 15) / 16) * 16;
+  return (size_t)(3 * tb * 8 * nrp + 2 * tb * 48 + 2 * tb * 4 + 2 * tb * (nr / 6) * 21 + 2 * nr + (nr / 6) * 21) * sizeof(double);
+}
+
+template <int kTiles /* tiles a wavefront owns at most */, int kTB /* times per step */>
+__global__ void __launch_bounds__(RSBA_MT_THREADS) k_mc_accumulate_mfma(AccArgs a) {
+  constexpr int kPf = 3;   // record doubles of one time a thread fetches ahead: at most 40 slots (240 columns) x 64 / 1024 threads
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nr = a.nr;
+  const int nt = (nr + 15) / 16, nrp = 16 * nt, ntiles = nt * (nt + 1) / 2, strip = 8 * nrp, nub = (nr / 6) * 21;
+  const PartLayout RL{nr};
+  double* Wg = lds;                         // [2][kTB][8][nrp]
+  double* Yg = Wg + 2 * kTB * strip;        // [kTB][8][nrp]
+  double* Ev = Yg + kTB * strip;            // [2][kTB][48]: E | g_t | E g_t
+  double* Ts = Ev + 2 * kTB * 48;           // [2][kTB][4]: the times' scalars
+  double* Ug = Ts + 2 * kTB * 4;            // [2][kTB][nr / 6][21]: U_ss by reduced block
+  double* gacc = Ug + 2 * kTB * nub;        // [nr] sum of g_s
+  double* cacc = gacc + nr;                 // [nr] -sum W'E g_t
+  double* Uacc = cacc + nr;                 // [nr / 6][21] sum of U_ss
+  double* P = a.part + (size_t)blockIdx.x * RL.size();
+  for (int e = tid; e < 3 * kTB * strip; e += RSBA_MT_THREADS) Wg[e] = 0.0;   // (rows 6, 7 of Y and row 7 of every strip stay zero)
+  for (int e = tid; e < 2 * kTB * nub + 2 * nr + nub; e += RSBA_MT_THREADS) Ug[e] = 0.0;
+  double cost = 0.0, xn2 = 0.0, gmax = 0.0, fail = 0.0;
+  // the wavefront's tiles: t = wave + 16 u -> (ti >= tj)
+  int ti[kTiles], tj[kTiles];
+  d4_acc acc[kTiles];
+#pragma unroll
+  for (int u = 0; u < kTiles; ++u) {
+    const int tl = wave + 16 * u;
+    int r = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
+    while (r * (r + 1) / 2 > tl) --r;
+    while ((r + 1) * (r + 2) / 2 <= tl) ++r;
+    ti[u] = __builtin_amdgcn_readfirstlane(tl < ntiles ? r : -1); tj[u] = __builtin_amdgcn_readfirstlane(tl - r * (r + 1) / 2);   // (wave-uniform: scalar registers)
+    acc[u] = d4_acc{0.0, 0.0, 0.0, 0.0};
+  }
+  const int t0 = a.chunk_ptr[blockIdx.x], t1 = a.chunk_ptr[blockIdx.x + 1], nstep = (t1 - t0 + kTB - 1) / kTB;
+  double pf[kTB][kPf], pe = 0.0, psv = 0.0;
+  int pcs[kTB][kPf], pns[kTB];
+  auto issue = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < kTB; ++j) {
+      const int t = t0 + b * kTB + j;
+      const int s0 = t < t1 ? a.slot_ptr[t] : 0;
+      pns[j] = t < t1 ? a.slot_ptr[t + 1] - s0 : 0;
+      const double* src = a.sp + (size_t)s0 * RSBA_SP_STRIDE;
+#pragma unroll
+      for (int u = 0; u < kPf; ++u) {
+        const int e = tid + RSBA_MT_THREADS * u;
+        const bool in = e < pns[j] * RSBA_SP_STRIDE;
+        pf[j][u] = in ? src[e] : 0.0;
+        pcs[j][u] = in ? a.slot_col[s0 + (e >> 6)] : 0;
+      }
+    }
+    if (tid < 48 * kTB) { const int j = tid / 48, t = t0 + b * kTB + j; pe = t < t1 ? a.tdata[(size_t)t * 48 + (tid - 48 * j)] : 0.0; }
+    if (tid < 4 * kTB) { const int t = t0 + b * kTB + (tid >> 2); psv = t < t1 ? a.tscal[4 * (size_t)t + (tid & 3)] : 0.0; }
+  };
+  // the fetched records into the strips of `par` (zeroed a phase ago): every (time, slot, entry) has one owner
+  auto commit = [&](int par) {
+#pragma unroll
+    for (int j = 0; j < kTB; ++j) {
+      double* Wp = Wg + (size_t)(par * kTB + j) * strip;
+      double* Up = Ug + (size_t)(par * kTB + j) * nub;
+#pragma unroll
+      for (int u = 0; u < kPf; ++u) {
+        const int e = tid + RSBA_MT_THREADS * u;
+        if (e < pns[j] * RSBA_SP_STRIDE) {
+          const int i = e & 63, col = pcs[j][u];
+          if (i < 36) { const int x = i / 6; Wp[x * nrp + col + (i - 6 * x)] = pf[j][u]; }
+          else if (i < 42) Wp[6 * nrp + col + i - 36] = pf[j][u];
+          else if (i < 63) Up[(col / 6) * 21 + i - 42] = pf[j][u];
+        }
+      }
+    }
+    if (tid < 48 * kTB) Ev[par * kTB * 48 + tid] = pe;
+    if (tid < 4 * kTB) Ts[par * kTB * 4 + tid] = psv;
+  };
+  __syncthreads();
+  if (nstep > 0) { issue(0); commit(0); }
+  __syncthreads();
+  const int mi = lane & 15, mk = lane >> 4;
+  for (int b = 0; b < nstep; ++b) {
+    const int par = b & 1;
+    const double* Wb = Wg + (size_t)par * kTB * strip;
+    double* Wo = Wg + (size_t)(1 - par) * kTB * strip;
+    const double* Eb = Ev + par * kTB * 48;
+    if (b + 1 < nstep) issue(b + 1);
+    for (int e = tid; e < kTB * 6 * nrp; e += RSBA_MT_THREADS) {
+      const int j = e / (6 * nrp), r = e - j * 6 * nrp, x = r / nrp, col = r - x * nrp;
+      const double* Wp = Wb + (size_t)j * strip;
+      const double* E = Eb + 48 * j;
+      double sum = 0.0;
+#pragma unroll
+      for (int y = 0; y < 6; ++y) sum += E[6 * x + y] * Wp[y * nrp + col];
+      Yg[(size_t)j * strip + r] = sum;
+    }
+    for (int e = tid; e < kTB * 7 * nrp; e += RSBA_MT_THREADS) { const int j = e / (7 * nrp); Wo[(size_t)j * strip + (e - j * 7 * nrp)] = 0.0; }
+    for (int e = tid; e < kTB * nub; e += RSBA_MT_THREADS) Ug[(size_t)(1 - par) * kTB * nub + e] = 0.0;
+    for (int col = tid; col < nr; col += RSBA_MT_THREADS) {
+      double g = gacc[col], c = cacc[col];
+#pragma unroll
+      for (int j = 0; j < kTB; ++j) {
+        const double* Wp = Wb + (size_t)j * strip;
+        const double* E = Eb + 48 * j;
+        double wc = 0.0;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) wc += Wp[x * nrp + col] * E[42 + x];
+        g += Wp[6 * nrp + col];
+        c -= wc;
+      }
+      gacc[col] = g; cacc[col] = c;
+    }
+    for (int e = tid; e < nub; e += RSBA_MT_THREADS) {
+      double u = Uacc[e];
+#pragma unroll
+      for (int j = 0; j < kTB; ++j) u += Ug[(size_t)(par * kTB + j) * nub + e];
+      Uacc[e] = u;
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int j = 0; j < kTB; ++j) { const double* q = Ts + (par * kTB + j) * 4; cost += q[0]; xn2 += q[1]; fail += q[2]; gmax = fmax(gmax, q[3]); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kTiles; ++u) {
+      if (ti[u] < 0) continue;
+#pragma unroll
+      for (int j = 0; j < kTB; ++j) {
+        const double* Wp = Wb + (size_t)j * strip;
+        const double* Yp = Yg + (size_t)j * strip;
+        const double a0 = Wp[mk * nrp + 16 * ti[u] + mi], b0 = Yp[mk * nrp + 16 * tj[u] + mi];
+        const double a1 = Wp[(4 + mk) * nrp + 16 * ti[u] + mi], b1 = Yp[(4 + mk) * nrp + 16 * tj[u] + mi];
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[u], 0, 0, 0);
+      }
+      if (kTiles > 3) __builtin_amdgcn_sched_barrier(0);   // (else all eight tiles' operands are fetched first: 64 registers beside the 64 accumulators)
+    }
+    if (b + 1 < nstep) commit(1 - par);
+    __syncthreads();
+  }
+  // the partial system: S = -sum W'Y from the accumulators (D[row = mk + 4 tt][column = mi]), then U_ss and U_cm on top
+  for (size_t e = RL.packed() + 3 * (size_t)nr + tid; e < RL.size(); e += RSBA_MT_THREADS) P[e] = 0.0;
+#pragma unroll
+  for (int u = 0; u < kTiles; ++u) {
+    if (ti[u] < 0) continue;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int gr = 16 * ti[u] + mk + 4 * tt, gc = 16 * tj[u] + mi;
+      if (gr < nr && gc <= gr) P[RL.S() + (size_t)gr * (gr + 1) / 2 + gc] = -acc[u][tt];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int e = tid; e < nub; e += RSBA_MT_THREADS) {
+    const int bq = e / 21, tri = e - 21 * bq;
+    int rq = (int)((sqrtf(8.0f * (float)tri + 1.0f) - 1.0f) * 0.5f);
+    while (rq * (rq + 1) / 2 > tri) --rq;
+    while ((rq + 1) * (rq + 2) / 2 <= tri) ++rq;
+    const int cq = tri - rq * (rq + 1) / 2, gr = 6 * bq + rq, gc = 6 * bq + cq;
+    P[RL.S() + (size_t)gr * (gr + 1) / 2 + gc] += Uacc[e];
+    if (rq == cq) P[RL.diagU() + gr] = Uacc[e];
+  }
+  for (int e = tid; e < nr; e += RSBA_MT_THREADS) { P[RL.gc() + e] = gacc[e]; P[RL.corr() + e] = cacc[e]; }
+  {
+    const int x0 = a.xc_ptr[blockIdx.x], x1 = a.xc_ptr[blockIdx.x + 1];
+    for (int e = tid; e < 36 * (x1 - x0); e += RSBA_MT_THREADS) {
+      const int it = x0 + e / 36, q = e - 36 * (e / 36), qm = q / 6, qc = q - 6 * qm;
+      const int gr = a.xi_cm[it] + qm, gc = a.xi_cc[it] + qc;
+      P[RL.S() + (size_t)gr * (gr + 1) / 2 + gc] += a.xout[(size_t)it * 36 + q];
+    }
+  }
+  if (tid == 0) { P[RL.scal() + 0] = cost; P[RL.scal() + 1] = xn2; P[RL.scal() + 2] = fail; P[RL.scal() + 3] = gmax; }
+}
+
+// The back-substitution of the time blocks, split the same way (k_time_backsub_wg: a workgroup per time, three barriers, 128 us).
+//   k_mc_time_step   eight lanes per time: W_t delta_r = sum over the time's slots of W_s delta_s from the slots' RECORDS (no Jacobian),
+//                    delta_t = -E (g_t + W_t delta_r), the candidate pose and its rotation matrix (-> posec_c), |delta_t|^2, |x_t + delta_t|^2
+//   k_mc_candidate   thread per residual block: its rows once more for the model cost change -(J d).(r + J d / 2), the candidate's corners
+//                    through the candidate's rotation matrices; a workgroup's sums in a fixed order -> one entry of bp_time
+// bp_time: [T] (|delta_t|^2, |x_t + delta_t|^2, 0, 0), then one entry per workgroup of k_mc_candidate (0, 0, model cost change, sum r_c^2).
+__global__ void __launch_bounds__(256) k_mc_time_step(int T, const int* __restrict__ slot_ptr, const int* __restrict__ slot_col, const int* __restrict__ time_full,
+                                                      const double* __restrict__ sp, const double* __restrict__ tdata, const double* __restrict__ delta_r,
+                                                      const double* __restrict__ params_x, double* __restrict__ params_c, double* __restrict__ delta_t,
+                                                      double* __restrict__ posec_c, double* __restrict__ bp_time) {
+  const int g = blockIdx.x * 256 + threadIdx.x, t = g >> 3, l = g & 7;
+  if (t >= T) return;   // (whole groups of eight lanes)
+  double h[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  const int s0 = slot_ptr[t], s1 = slot_ptr[t + 1];
+  for (int S = s0 + l; S < s1; S += 8) {
+    const double* rec = sp + (size_t)S * RSBA_SP_STRIDE;
+    const double* d = delta_r + slot_col[S];
+    double dd[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dd[q] = d[q];
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) h[x] = fma(rec[6 * x + q], dd[q], h[x]);
+  }
+#pragma unroll
+  for (int x = 0; x < 6; ++x) {
+    h[x] += __shfl_xor(h[x], 1, 8); h[x] += __shfl_xor(h[x], 2, 8); h[x] += __shfl_xor(h[x], 4, 8);
+  }
+  if (l != 0) return;
+  const double* td = tdata + (size_t)t * 48;
+  const int tf = time_full[t];
+  double hh[6], tc[6], d2 = 0.0, xc2 = 0.0;
+#pragma unroll
+  for (int x = 0; x < 6; ++x) hh[x] = h[x] + td[36 + x];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double sum = 0.0;
+#pragma unroll
+    for (int y = 0; y < 6; ++y) sum += td[6 * a + y] * hh[y];
+    const double d = -sum;
+    tc[a] = params_x[tf + a] + d;
+    delta_t[6 * t + a] = d;
+    params_c[tf + a] = tc[a];
+    d2 += d * d; xc2 += tc[a] * tc[a];
+  }
+  const double zero4[4] = {0.0, 0.0, 0.0, 0.0};
+  double cct[CC_STRIDE];
+  CameraConstants(tc, zero4, cct);
+  double* pc = posec_c + (size_t)(tf / 6) * CC_STRIDE;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) pc[CC_R + q] = cct[CC_R + q];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) pc[CC_T + q] = cct[CC_T + q];
+  bp_time[4 * (size_t)t] = d2; bp_time[4 * (size_t)t + 1] = xc2; bp_time[4 * (size_t)t + 2] = 0.0; bp_time[4 * (size_t)t + 3] = 0.0;
+}
+
+__global__ void __launch_bounds__(256) k_mc_candidate(int N, int T, const TimeSlots* __restrict__ ts, const MarkerObs* __restrict__ mo, const double* __restrict__ obs8,
+                                                      const double* __restrict__ intr, double half_side, const double* __restrict__ posec,
+                                                      const double* __restrict__ posec_c, const double* __restrict__ delta_r, const double* __restrict__ delta_t,
+                                                      const int* __restrict__ blk_time, double* __restrict__ bp_time) {
+  __shared__ double s_w[4][2];
+  const int k = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double mcc = 0.0, cc = 0.0;
+  if (k < N) {
+    const TimeSlots s = ts[k];
+    const MarkerObs o = mo[k];
+    const PoseC cam = LoadPose<true>(posec, o.full_cam >= 0 ? o.full_cam / 6 : -1);
+    const PoseC tim = LoadPose<true>(posec, o.full_time / 6);
+    const PoseC mar = LoadPose<true>(posec, o.full_marker >= 0 ? o.full_marker / 6 : -1);
+    const PoseC ccam = LoadPose<false>(posec_c, o.full_cam >= 0 ? o.full_cam / 6 : -1);
+    const PoseC ctim = LoadPose<false>(posec_c, o.full_time / 6);
+    const PoseC cmar = LoadPose<false>(posec_c, o.full_marker >= 0 ? o.full_marker / 6 : -1);
+    double dl[18];
+    const int t = blk_time[k];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+      dl[x] = s.col_cam >= 0 ? delta_r[s.col_cam + x] : 0.0;
+      dl[6 + x] = delta_t[6 * t + x];
+      dl[12 + x] = s.col_marker >= 0 ? delta_r[s.col_marker + x] : 0.0;
+    }
+    const double* in = intr + 4 * s.camera;
+    const double fx = in[0], fy = in[1], ppx = in[2], ppy = in[3];
+    const double* ob = obs8 + 8 * (size_t)k;
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+      const double cx = CornerX(c, half_side), cy = CornerY(c, half_side), u = ob[2 * c], v = ob[2 * c + 1];
+      double r[2], Jc[2][6], Jt[2][6], Jm[2][6];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Jc[i][q] = 0.0;   // (an absent camera transform: CornerRows leaves the block alone)
+      CornerRows<true, true, true>(cam, tim, mar, fx, fy, ppx, ppy, cx, cy, u, v, r, Jc, Jt, Jm);
+      // (an absent marker transform: its block is formed from the stand-in pose's constants and meets dl[12..17] = 0)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        double m = 0.0;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) m += Jc[i][x] * dl[x];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) m += Jt[i][x] * dl[6 + x];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) m += Jm[i][x] * dl[12 + x];
+        mcc -= m * (r[i] + 0.5 * m);
+      }
+      // the candidate's corner through the candidate's transforms (rotation matrices: k_pose_constants_reduced, k_mc_time_step)
+      double pt[3] = {cx, cy, 0.0};
+      auto apply = [&](const PoseC& p) {
+        const double a0 = p.R[0] * pt[0] + p.R[1] * pt[1] + p.R[2] * pt[2], a1 = p.R[3] * pt[0] + p.R[4] * pt[1] + p.R[5] * pt[2], a2 = p.R[6] * pt[0] + p.R[7] * pt[1] + p.R[8] * pt[2];
+        pt[0] = a0 + p.T[0]; pt[1] = a1 + p.T[1]; pt[2] = a2 + p.T[2];
+      };
+      if (cmar.on) apply(cmar);
+      apply(ctim);
+      if (ccam.on) apply(ccam);
+      const double r0 = fx * pt[0] / pt[2] + ppx - u, r1 = fy * pt[1] / pt[2] + ppy - v;
+      cc += r0 * r0 + r1 * r1;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { mcc += __shfl_down(mcc, off, 64); cc += __shfl_down(cc, off, 64); }
+  if (lane == 0) { s_w[wave][0] = mcc; s_w[wave][1] = cc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* out = bp_time + 4 * ((size_t)T + blockIdx.x);
+    out[0] = 0.0; out[1] = 0.0;
+    out[2] = ((s_w[0][0] + s_w[1][0]) + s_w[2][0]) + s_w[3][0];
+    out[3] = ((s_w[0][1] + s_w[1][1]) + s_w[2][1]) + s_w[3][1];
+  }
+}
+
 }  // namespace rsba

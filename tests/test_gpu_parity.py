@@ -647,8 +647,14 @@ def _solve_marker_chain_both(oracle, prob, schur_impl, model=capi.MODEL_MARKER_C
     return ref, s_ref, got, s
 
 
-@pytest.mark.parametrize("shape", [(4, 40, 6), (8, 120, 12), (3, 300, 4)])
-def test_marker_chain_time_elimination_matches_oracle(oracle, shape):
+@pytest.mark.parametrize("env", [{}, {"RSBA_MT_ACC_MFMA": "0"}, {"RSBA_MT_FORK": "0"}, {"RSBA_MT_SPLIT": "0"}], ids=["default", "valu-accumulate", "one-stream", "k_time_eliminate"])
+@pytest.mark.parametrize("shape", [(4, 40, 6), (8, 120, 12), (3, 300, 4), (12, 40, 20)])
+def test_marker_chain_time_elimination_matches_oracle(oracle, shape, env, monkeypatch):
+    """The split elimination (csrc/ba_marker_split.hpp, round 6) in its variants — the chunk's sum of W'Y on the matrix cores in the
+    wavefronts' registers (up to 144 reduced columns: three tiles a wavefront; up to 240: eight — the (12, 40, 20) shape, 180 columns),
+    the VALU accumulation in LDS (wider systems; forced here), the three product kernels on one stream — and round 4's k_time_eliminate."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     C_, T_, M_ = shape
     prob = syn.make_marker_chain(C_, T_, M_, seed=sum(shape))
     ref, s_ref, got, s = _solve_marker_chain_both(oracle, prob, 2)
@@ -704,12 +710,15 @@ def test_marker_chain_chunk_count_does_not_change_the_answer(oracle, chunks):
     assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("wg", ["0", "1"])
-def test_marker_chain_both_back_substitution_kernels_match_the_oracle(oracle, wg):
-    """The shots' back-substitution: a workgroup per shot with a corner of a residual block per lane (k_time_backsub_wg, shots of
-    at most 128 residual blocks) or a wavefront per shot (k_time_backsub_terms, any width; RSBA_MT_BACKSUB_WG=0 forces it).  Both
+@pytest.mark.parametrize("wg", ["0", "1", "split"])
+def test_marker_chain_both_back_substitution_kernels_match_the_oracle(oracle, wg, monkeypatch):
+    """The shots' back-substitution: round 6's split form (k_mc_time_step from the slots' records + k_mc_candidate, a thread per
+    residual block: the default), a workgroup per shot with a corner of a residual block per lane (k_time_backsub_wg, shots of
+    at most 128 residual blocks) or a wavefront per shot (k_time_backsub_terms, any width; RSBA_MT_BACKSUB_WG=0 forces it).  All
     against the oracle, on a shape with all cameras x markers in a shot (96 residual blocks) and on one with few."""
-    os.environ["RSBA_MT_BACKSUB_WG"] = wg
+    if wg != "split":
+        monkeypatch.setenv("RSBA_MT_SPLIT_BACKSUB", "0")
+    os.environ["RSBA_MT_BACKSUB_WG"] = "1" if wg == "split" else wg
     try:
         for shape, seed in (((8, 60, 12), 5), ((3, 200, 4), 9)):
             prob = syn.make_marker_chain(*shape, seed=seed)

@@ -21,6 +21,8 @@ out = {}
 for mode in (0, 1):
     s = capi.Solver(p, capi.default_options(profile_kernels=mode))
     s.run()            # warm-up: code objects, allocations
+    for _ in range(int(os.environ.get("MC_RUNS", "3")) - 1):   # (the kernel statistics include the warm-up's first launches: amortised)
+        s.run()
     sm = s.run()
     if mode == 0:
         out.update({"cameras": C_, "times": T_, "markers": M_, "residual_blocks": int(prob["N"]), "generate_s": round(gen, 2),
@@ -31,7 +33,7 @@ for mode in (0, 1):
         out["kernels_us"] = {k: round(1e3 * ms / n, 1) for k, (n, ms) in s.kernel_stats().items()}
     s.download()
     s.close()
-# roofline entry of the dominant kernel (k_time_eliminate): ALGORITHMIC work per LM iteration.  Per residual block (8 residuals, a camera,
+# roofline entry of the elimination of the time blocks: ALGORITHMIC work per LM iteration.  Per residual block (8 residuals, a camera,
 # a time and a marker block of 6: J is 8 x 18) the normal-equation products J'J / J'r restricted to what the elimination needs —
 # V += Jt'Jt (8 x 21 unique), g_t (8 x 6), W_c = Jt'Jc and W_m = Jt'Jm (8 x 36 each), U_cc, U_mm (8 x 21 each), U_cm (8 x 36),
 # g_c, g_m (8 x 6 each): 1512 multiply-adds where all three blocks are parameters (camera 0 / marker 0 are not: those rows drop
@@ -48,13 +50,20 @@ f_per_time = np.bincount((np.concatenate([fc, fm]) // 4096).astype(np.int64), mi
 fma += float(np.sum((6 * f_per_time) ** 2 / 2 * 6 + 6 ** 3 / 3))
 flops = 2.0 * fma
 nbytes = 76.0 * prob["N"] + 96.0 * T_
-if "kernels_us" in out and "k_time_eliminate" in out["kernels_us"]:
-    us = out["kernels_us"]["k_time_eliminate"]
-    out["roofline"] = {"kernel": "k_time_eliminate", "avg_launch_us": us, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
+# the elimination of the time blocks: round 6's split kernels (csrc/ba_marker_split.hpp; timed one after the other here — in a run
+# that is not profiled the three product kernels share the chip on three streams), or round 4's k_time_eliminate (RSBA_MT_SPLIT=0)
+SPLIT = ["k_mc_slot_products", "k_mc_time_products", "k_mc_cross", "k_mc_accumulate"]
+ku = out.get("kernels_us", {})
+parts = {k: ku[k] for k in SPLIT if k in ku} or ({"k_time_eliminate": ku["k_time_eliminate"]} if "k_time_eliminate" in ku else {})
+if parts:
+    us = sum(parts.values())
+    # the split kernels form a residual block's Jacobian rows 2.7 times instead of once: NOT counted — algorithmic work only
+    out["roofline"] = {"kernel": "+".join(parts), "kernels_us": parts, "avg_launch_us": round(us, 1), "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
                        "flops_per_residual_block": flops / prob["N"], "bytes_per_residual_block": nbytes / prob["N"],
                        "achieved_TFLOPs": flops / (us * 1e-6) / 1e12, "frac_of_fp64_peak_78.6": flops / (us * 1e-6) / 1e12 / 78.6,
                        "achieved_GBps": nbytes / (us * 1e-6) / 1e9, "frac_of_hbm_8000": nbytes / (us * 1e-6) / 1e9 / 8000.0,
-                       "bound": "neither roof: a latency chain of five barriers per 32-block tile inside one workgroup per chunk of shots (HISTORY.md round 4)"}
+                       "bound": ("fp64 VALU issue of threads that own their sums (one wavefront a SIMD at 334 registers), then two barriers a time in the accumulation" if len(parts) > 1 else
+                                 "neither roof: a latency chain of five barriers per 32-block tile inside one workgroup per chunk of shots (HISTORY.md round 4)")}
 err = np.abs(p.params - prob["truth"]).reshape(-1, 6)
 out["max_abs_error_vs_truth"] = float(err.max())
 print(json.dumps(out))
