@@ -1055,7 +1055,6 @@ struct MarkerSchurDevice {
       acc_tiles = (per_wave <= 8 && !(getenv("RSBA_MT_ACC_MFMA") && atoi(getenv("RSBA_MT_ACC_MFMA")) == 0)) ? (per_wave <= 3 ? 3 : 8) : 0;
       if (acc_tiles > 0) {
         lds_s = true;   // (the chunk's sums never touch memory before the end: one chunk per CU, as with the sums in LDS)
-        if (getenv("RSBA_MT_ACC_TB")) acc_tb = atoi(getenv("RSBA_MT_ACC_TB")) >= 2 ? 2 : 1;
         if (acc_tiles == 8) acc_tb = 1;
         lds_acc = AccMfmaLdsBytes(nr, acc_tb);
       } else {

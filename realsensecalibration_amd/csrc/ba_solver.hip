@@ -609,13 +609,11 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
     const bool self = tab[3 * t + 2] != 0;
     const int nW = (P + 63) / 64;  // mask words that hold points
     // (more than 64 cameras: at most 16 self segments per tile — two reduction groups, no reducer workgroups)
-    static const int self_per_cu = getenv("RSBA_SELF_PER_CU") ? std::max(1, atoi(getenv("RSBA_SELF_PER_CU"))) : 2;   // (lab knob: self segments of all tiles per CU)
-    static const int self_segs_env = getenv("RSBA_SELF_SEGS") ? std::max(1, atoi(getenv("RSBA_SELF_SEGS"))) : 0;       // (lab knob: ... per tile)
-    int ns_self = std::max(1, std::min(self_segs_env ? self_segs_env : (self_per_cu * cus + ngroups - 1) / ngroups, nW));
+    int ns_self = std::max(1, std::min((2 * cus + ngroups - 1) / ngroups, nW));   // (two self segments per CU over all tiles: the target before the rounding below)
     // (round 6: the self segments too in WHOLE chunks where their target length is three quarters of a chunk or more — they walk the chunk
     //  buffers like the pair segments do.  100k points: 98 segments of two chunks a tile instead of 128 of 12.2 words, 0.3357 - 0.3383 ms per
     //  step against 0.3423; 66 of three 0.3377 - 0.3395, 196 of one 0.3475 - 0.3493 — two alternating runs each on one box)
-    if (!self_segs_env && !SparsePairSegments(C, staged) && 4 * (long)nW > 3L * RSBA_CW * ns_self) {
+    if (!SparsePairSegments(C, staged) && 4 * (long)nW > 3L * RSBA_CW * ns_self) {
       const int k = std::max(1, (int)std::lround((double)nW / ns_self / RSBA_CW));
       ns_self = std::max(1, (nW + RSBA_CW * k - 1) / (RSBA_CW * k));
     }
@@ -636,8 +634,8 @@ int TiledSchur::Build(int C_, int P_, const std::vector<int>& pt_ptr, const std:
       // group whose last segment ends late in its stage is what the stage's flag waits for
       // (measured at 64 cameras x 100k points, ms per iteration: groups of 8: 0.411, 6: 0.408, 5: 0.407, 4: 0.406, 3: 0.412, 2: 0.428
       //  — the reducers then read twice the group sums and fall behind)
-      static const int grp_env = getenv("RSBA_GRP_SIZE") ? std::max(1, atoi(getenv("RSBA_GRP_SIZE"))) : 0;   // (lab knob: segments per reduction group)
-      const int GRP = grp_env ? grp_env : (6 * C > RSBA_CHOL_MAXN ? RSBA_GRP : RSBA_GRP_SMALL);
+      // (round 6, beside three factorisation workgroups: 3 and 8 no different from 4 — HISTORY.md)
+      const int GRP = 6 * C > RSBA_CHOL_MAXN ? RSBA_GRP : RSBA_GRP_SMALL;
       const int s0 = tsp[t], ns_t = tsp[t + 1] - tsp[t], g0 = ngrp;
       std::vector<int> gsize;
       {
@@ -2014,8 +2012,7 @@ static int PointsStep(rsba_solver* s, double radius, bool first, bool keep_syste
       //  workgroups: 2 x CUs - 0 / 8 / 14 / 16 / 32: 0.3506 - 0.3516 / 0.3470 - 0.3482 / 0.3491 / 0.3486 - 0.3493 / 0.3465 - 0.3482 ms per
       //  step — nothing beyond the run-to-run spread but the full grid, which is slower)
       // (more than 128 cameras: the tables alone are 80 KB, one workgroup per CU)
-      static const int bs_spare = getenv("RSBA_BS_SPARE") ? atoi(getenv("RSBA_BS_SPARE")) : 16;   // (lab knob: workgroups fewer than the chip holds)
-      grid_bs = std::max(1, std::min(C <= 128 ? 2 * DeviceCUs() - bs_spare : DeviceCUs() - 8, (P + 63) / 64));
+      grid_bs = std::max(1, std::min(C <= 128 ? 2 * DeviceCUs() - 16 : DeviceCUs() - 8, (P + 63) / 64));   // (round 6, four factorisation workgroups: 0 / 8 / 16 / 32 fewer no different)
       FusedLin fl = fl0b;
       // single GPU: the workgroup that completes the result block takes the step's decision as well, and the damping
       // kernel of the NEXT step is queued right here, behind this kernel, on that decision (LmNext; RSBA_DECIDED_DAMP=0:
