@@ -921,8 +921,10 @@ struct MarkerSchurDevice {
   int N = 0, T = 0, nr = 0, nfull = 0, G = 0, dmax = 0, nb_time = 0;
   // the split elimination (ba_marker_split.hpp; RSBA_MT_SPLIT=0: k_time_eliminate)
   bool split = true;
-  int nslots = 0, nx = 0, ncam_cols = 0;
-  int *slot_order = nullptr, *slot_time = nullptr, *sb_ptr = nullptr, *sb_blk = nullptr, *xi_ptr = nullptr, *xi_blk = nullptr, *xi_cc = nullptr, *xi_cm = nullptr, *xc_ptr = nullptr;
+  int nslots = 0, nx = 0, ncam_cols = 0, nx_threads = 0;
+  int* x_order = nullptr;
+  int4 *sb_blk = nullptr, *xi_blk = nullptr;
+  int *slot_order = nullptr, *slot_time = nullptr, *sb_ptr = nullptr, *xi_ptr = nullptr, *xi_cc = nullptr, *xi_cm = nullptr, *xc_ptr = nullptr;
   double *sp = nullptr, *xout = nullptr, *tscal = nullptr;
   size_t lds_acc = 0;
   bool split_backsub = false;   // k_mc_time_step + k_mc_candidate instead of k_time_backsub_wg / _terms
@@ -954,7 +956,7 @@ struct MarkerSchurDevice {
   void Free() {
     void* ptrs[] = {mo, ts, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ok_flag, obs8, intr, params[0], params[1],
                     params0, posec, posec_c, ss_x, scale_t, scale_r, tdata, part, red, A, Wm, delta_r, delta_t, bp_time, solve_out, res, tc_flags, tc_hand, tc_map,
-                    slot_order, slot_time, sb_ptr, sb_blk, xi_ptr, xi_blk, xi_cc, xi_cm, xc_ptr, sp, xout, tscal, blk_time};
+                    slot_order, slot_time, sb_ptr, sb_blk, xi_ptr, xi_blk, xi_cc, xi_cm, xc_ptr, sp, xout, tscal, blk_time, x_order};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     mo = nullptr; ts = nullptr;
     for (auto& q : fork_s) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
@@ -1088,7 +1090,10 @@ struct MarkerSchurDevice {
       G = (int)c2.size() - 1; cptr = c2;
     }
     // the split elimination's tables: a (time, slot)'s residual blocks, the thread order, the camera-marker pairs of every chunk
-    std::vector<int> h_slot_time, h_sb_ptr, h_sb_blk, h_order, h_xi_ptr, h_xi_blk, h_xi_cc, h_xi_cm, h_xc_ptr;
+    std::vector<int> h_slot_time, h_sb_ptr, h_order, h_xi_ptr, h_xi_cc, h_xi_cm, h_xc_ptr, h_xorder;
+    std::vector<int4> h_sb_blk, h_xi_blk;
+    auto pose_of_col = [&](int col) { return col >= 0 ? cf[col] / 6 : -1; };   // reduced column -> pose in the parameter array
+    const int kShareFrom = 10;   // an item of k_mc_cross with this many residual blocks or more runs on two neighbouring lanes
     if (split) {
       nslots = (int)scol.size();
       ncam_cols = 0;
@@ -1108,8 +1113,8 @@ struct MarkerSchurDevice {
         std::vector<int> fill(h_sb_ptr.begin(), h_sb_ptr.end() - 1);
         for (int t = 0; t < T; ++t)
           for (int k = tptr[t]; k < tptr[t + 1]; ++k) {
-            if (hts[k].slot_cam >= 0) h_sb_blk[fill[sptr[t] + hts[k].slot_cam]++] = k;
-            if (hts[k].slot_marker >= 0) h_sb_blk[fill[sptr[t] + hts[k].slot_marker]++] = k;
+            if (hts[k].slot_cam >= 0) h_sb_blk[fill[sptr[t] + hts[k].slot_cam]++] = int4{k, pose_of_col(hts[k].col_marker), hts[k].camera, 0};
+            if (hts[k].slot_marker >= 0) h_sb_blk[fill[sptr[t] + hts[k].slot_marker]++] = int4{k, pose_of_col(hts[k].col_cam), hts[k].camera, 0};
           }
       }
       h_order.resize(nslots);
@@ -1132,12 +1137,21 @@ struct MarkerSchurDevice {
             if (i != 0) h_xi_ptr.push_back((int)h_xi_blk.size());
             h_xi_cc.push_back(items[i].first.first); h_xi_cm.push_back(items[i].first.second);
           }
-          h_xi_blk.push_back(items[i].second);
+          h_xi_blk.push_back(int4{items[i].second, hmo[items[i].second].full_time / 6, hts[items[i].second].camera, 0});
         }
         if (!items.empty()) h_xi_ptr.push_back((int)h_xi_blk.size());
         h_xc_ptr[g + 1] = (int)h_xi_cc.size();
       }
       nx = (int)h_xi_cc.size();
+      {
+        std::vector<int> ord(nx);
+        for (int it = 0; it < nx; ++it) ord[it] = it;
+        auto len = [&](int it) { return h_xi_ptr[it + 1] - h_xi_ptr[it]; };
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return len(x) > len(y); });
+        for (int it : ord) if (len(it) >= kShareFrom) { h_xorder.push_back(4 * it + 2); h_xorder.push_back(4 * it + 3); }
+        for (int it : ord) if (len(it) < kShareFrom) h_xorder.push_back(4 * it);
+        nx_threads = (int)h_xorder.size();
+      }
     }
     // (k_time_backsub_wg: a corner of a residual block per lane, two per lane at most; wider times take the wavefront-per-time kernel)
     { int widest = 0; for (int t = 0; t < T; ++t) widest = std::max(widest, tptr[t + 1] - tptr[t]); backsub_wg = widest <= 128 /* 4 x 128 corners = 512 lanes */ && !(getenv("RSBA_MT_BACKSUB_WG") && atoi(getenv("RSBA_MT_BACKSUB_WG")) == 0); }
@@ -1167,8 +1181,8 @@ struct MarkerSchurDevice {
       return RSBA_ERR_HIP;
     if (hipMemset(res, 0, RES_SIZE * 8) != hipSuccess) return RSBA_ERR_HIP;
     if (split) {
-      if (!al((void**)&slot_order, (size_t)nslots * 4) || !al((void**)&slot_time, (size_t)nslots * 4) || !al((void**)&sb_ptr, ((size_t)nslots + 1) * 4) ||
-          !al((void**)&sb_blk, h_sb_blk.size() * 4) || !al((void**)&xi_ptr, ((size_t)nx + 1) * 4) || !al((void**)&xi_blk, h_xi_blk.size() * 4) ||
+      if (!al((void**)&slot_order, (size_t)nslots * 4) || !al((void**)&x_order, (size_t)nx_threads * 4) || !al((void**)&slot_time, (size_t)nslots * 4) || !al((void**)&sb_ptr, ((size_t)nslots + 1) * 4) ||
+          !al((void**)&sb_blk, h_sb_blk.size() * sizeof(int4)) || !al((void**)&xi_ptr, ((size_t)nx + 1) * 4) || !al((void**)&xi_blk, h_xi_blk.size() * sizeof(int4)) ||
           !al((void**)&xi_cc, (size_t)nx * 4) || !al((void**)&xi_cm, (size_t)nx * 4) || !al((void**)&xc_ptr, ((size_t)G + 1) * 4) ||
           !al((void**)&sp, (size_t)nslots * RSBA_SP_STRIDE * 8) || !al((void**)&xout, (size_t)nx * 36 * 8) || !al((void**)&tscal, 4 * (size_t)T * 8))
         return RSBA_ERR_HIP;
@@ -1177,9 +1191,9 @@ struct MarkerSchurDevice {
         for (int t = 0; t < T; ++t) for (int k = tptr[t]; k < tptr[t + 1]; ++k) h_bt[k] = t;
         if (!al((void**)&blk_time, (size_t)N * 4) || !up(blk_time, h_bt.data(), (size_t)N * 4)) return RSBA_ERR_HIP;
       }
-      if (!up(slot_order, h_order.data(), (size_t)nslots * 4) || !up(slot_time, h_slot_time.data(), (size_t)nslots * 4) ||
-          !up(sb_ptr, h_sb_ptr.data(), ((size_t)nslots + 1) * 4) || !up(sb_blk, h_sb_blk.data(), h_sb_blk.size() * 4) ||
-          !up(xi_ptr, h_xi_ptr.data(), ((size_t)nx + 1) * 4) || !up(xi_blk, h_xi_blk.data(), h_xi_blk.size() * 4) ||
+      if (!up(slot_order, h_order.data(), (size_t)nslots * 4) || !up(x_order, h_xorder.data(), (size_t)nx_threads * 4) || !up(slot_time, h_slot_time.data(), (size_t)nslots * 4) ||
+          !up(sb_ptr, h_sb_ptr.data(), ((size_t)nslots + 1) * 4) || !up(sb_blk, h_sb_blk.data(), h_sb_blk.size() * sizeof(int4)) ||
+          !up(xi_ptr, h_xi_ptr.data(), ((size_t)nx + 1) * 4) || !up(xi_blk, h_xi_blk.data(), h_xi_blk.size() * sizeof(int4)) ||
           !up(xi_cc, h_xi_cc.data(), (size_t)nx * 4) || !up(xi_cm, h_xi_cm.data(), (size_t)nx * 4) || !up(xc_ptr, h_xc_ptr.data(), ((size_t)G + 1) * 4))
         return RSBA_ERR_HIP;
       const void* kacc = acc_tiles == 3 ? (acc_tb == 2 ? (const void*)k_mc_accumulate_mfma<3, 2> : (const void*)k_mc_accumulate_mfma<3, 1>) : acc_tiles == 8 ? (const void*)k_mc_accumulate_mfma<8, 1>
@@ -1254,7 +1268,7 @@ struct MarkerSchurDevice {
     Tm.End(st);
     ElimArgs ea{nr, dmax, (int)N, chunk_ptr, time_ptr, slot_ptr, slot_col, time_full, col_full, ts, mo, obs8, intr, posec, half_side, params[x], scale_t, tdata, part, ip};
     if (split) {
-      SplitArgs sa{nslots, T, nx, ncam_cols, slot_order, slot_time, slot_col, sb_ptr, sb_blk, time_ptr, time_full, col_full, ts, mo, obs8, intr, posec, half_side,
+      SplitArgs sa{nslots, T, nx, ncam_cols, nx_threads, slot_order, x_order, slot_time, slot_col, sb_ptr, sb_blk, time_ptr, time_full, col_full, ts, mo, obs8, intr, posec, half_side,
                    xi_ptr, xi_blk, xi_cc, xi_cm, sp, xout};
       // the three product kernels are independent and none fills the chip: side by side on three streams (one after the other
       // when every kernel is timed)
@@ -1272,7 +1286,7 @@ struct MarkerSchurDevice {
       Tm.End(st);
       if (nx > 0) {
         Tm.Begin("k_mc_cross", st);
-        k_mc_cross<<<(nx + 255) / 256, 256, 0, s_cross>>>(sa);
+        k_mc_cross<<<(nx_threads + 255) / 256, 256, 0, s_cross>>>(sa);
         Tm.End(st);
       }
       if (fork) {

@@ -21,6 +21,17 @@
 
 namespace rsba {
 
+// corners of a residual block formed side by side in the product kernels' loops (they run one wavefront a SIMD: the registers are there,
+// what is missing is independent work between dependent instructions)
+#ifndef RSBA_MC_UNROLL_SLOT
+#define RSBA_MC_UNROLL_SLOT 1
+#endif
+#ifndef RSBA_MC_UNROLL_CROSS
+#define RSBA_MC_UNROLL_CROSS 2
+#endif
+#ifndef RSBA_MC_UNROLL_CAND
+#define RSBA_MC_UNROLL_CAND 1
+#endif
 #define RSBA_SP_STRIDE 64   // doubles of a (time, slot) record: W (time row x, slot column q at 6 x + q: 36) | g_s (6) | U_ss lower triangle (21) | pad
 #define RSBA_SP_LDS 65      // its stride in LDS
 
@@ -101,11 +112,13 @@ __device__ __forceinline__ double CornerY(int k, double hs) { return k < 2 ? hs 
 
 struct SplitArgs {
   int nslots, T, nx, ncam_cols;
+  int nx_threads;                       // entries of x_order
   const int* __restrict__ slot_order;   // [nslots] thread -> slot: camera slots first, the longest lists first inside a role (a wavefront's lanes run alike)
+  const int* __restrict__ x_order;      // [nx_threads] thread -> 4 item + 2 (the item's list is shared by this lane and its neighbour) + part, of k_mc_cross
   const int* __restrict__ slot_time;    // [nslots]
   const int* __restrict__ slot_col;     // [nslots] first reduced column
   const int* __restrict__ sb_ptr;       // [nslots + 1] the slot's residual blocks ...
-  const int* __restrict__ sb_blk;       // ... in block (= time, then file) order
+  const int4* __restrict__ sb_blk;      // ... in block (= time, then file) order: {residual block, the OTHER block's pose (-1: none), the detecting camera (intrinsics), 0}
   const int* __restrict__ time_ptr;     // [T + 1]
   const int* __restrict__ time_full;    // [T]
   const int* __restrict__ col_full;     // [nr]
@@ -116,7 +129,7 @@ struct SplitArgs {
   const double* __restrict__ posec;
   double half_side;
   const int* __restrict__ xi_ptr;       // [nx + 1] residual blocks of a (chunk, camera column, marker column) item
-  const int* __restrict__ xi_blk;
+  const int4* __restrict__ xi_blk;      // {residual block, the time's pose, the detecting camera, 0}
   const int* __restrict__ xi_cc;        // [nx] camera column, [nx] marker column
   const int* __restrict__ xi_cm;
   double* __restrict__ sp;              // [nslots][RSBA_SP_STRIDE]
@@ -133,19 +146,40 @@ __device__ __forceinline__ void SlotProducts(const SplitArgs& a, int S, const Po
 #pragma unroll
   for (int i = 0; i < 21; ++i) U[i] = 0.0;
   const double hs = a.half_side;
-  for (int e = a.sb_ptr[S]; e < a.sb_ptr[S + 1]; ++e) {
-    const int k = a.sb_blk[e];
-    const TimeSlots s = a.ts[k];
-    const int oc = kCam ? s.col_marker : s.col_cam;
-    const PoseC oth = LoadPose<false>(a.posec, oc >= 0 ? a.col_full[oc] / 6 : -1);
-    const double* in = a.intr + 4 * s.camera;
-    const double fx = in[0], fy = in[1], ppx = in[2], ppy = in[3];
-    const double* ob = a.obs8 + 8 * (size_t)k;
-#pragma unroll 1
+  // What a residual block's rows need from memory — the other block's pose, the observed corners, the intrinsics — is asked for ONE ENTRY AHEAD,
+  // and the entry's own record two ahead: as block -> slots -> column -> pose -> constants it was four dependent trips to memory per entry, on one
+  // wavefront a SIMD with nothing to run meanwhile (5 us an entry; the arithmetic is 1.2).
+  struct Fetched { PoseC oth; double ob[8], in[4]; };
+  auto fetch = [&](const int4 r, Fetched& f) {
+    f.oth = LoadPose<false>(a.posec, r.y);
+    const double* ob = a.obs8 + 8 * (size_t)r.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.ob[i] = ob[i];
+    const double* in = a.intr + 4 * r.z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.in[i] = in[i];
+  };
+  int e = a.sb_ptr[S];
+  const int e1 = a.sb_ptr[S + 1];
+  const int4 none = {0, -1, 0, 0};
+  int4 r1 = e < e1 ? a.sb_blk[e] : none;
+  Fetched cur;
+  fetch(r1, cur);
+  r1 = e + 1 < e1 ? a.sb_blk[e + 1] : none;
+  for (; e < e1; ++e) {
+    const int4 r2 = e + 2 < e1 ? a.sb_blk[e + 2] : none;
+    Fetched nxt;
+    fetch(r1, nxt);
+    const PoseC& oth = cur.oth;
+    const double fx = cur.in[0], fy = cur.in[1], ppx = cur.in[2], ppy = cur.in[3];
+#pragma unroll RSBA_MC_UNROLL_SLOT
     for (int c = 0; c < 4; ++c) {
+      // (the corner's pixels by selects: an index into the fetched array that is not a constant puts the whole record into private memory)
+      const double ou = c == 0 ? cur.ob[0] : (c == 1 ? cur.ob[2] : (c == 2 ? cur.ob[4] : cur.ob[6]));
+      const double ov = c == 0 ? cur.ob[1] : (c == 1 ? cur.ob[3] : (c == 2 ? cur.ob[5] : cur.ob[7]));
       double r[2], Jo[2][6], Jt[2][6];
-      if (kCam) CornerRows<true, true, false>(own, tim, oth, fx, fy, ppx, ppy, CornerX(c, hs), CornerY(c, hs), ob[2 * c], ob[2 * c + 1], r, Jo, Jt, nullptr);
-      else CornerRows<false, true, true>(oth, tim, own, fx, fy, ppx, ppy, CornerX(c, hs), CornerY(c, hs), ob[2 * c], ob[2 * c + 1], r, nullptr, Jt, Jo);
+      if (kCam) CornerRows<true, true, false>(own, tim, oth, fx, fy, ppx, ppy, CornerX(c, hs), CornerY(c, hs), ou, ov, r, Jo, Jt, nullptr);
+      else CornerRows<false, true, true>(oth, tim, own, fx, fy, ppx, ppy, CornerX(c, hs), CornerY(c, hs), ou, ov, r, nullptr, Jt, Jo);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -160,6 +194,8 @@ __device__ __forceinline__ void SlotProducts(const SplitArgs& a, int S, const Po
           for (int p = 0; p <= q; ++p) U[q * (q + 1) / 2 + p] = fma(Jo[i][q], Jo[i][p], U[q * (q + 1) / 2 + p]);
       }
     }
+    cur = nxt;
+    r1 = r2;
   }
   double* out = a.sp + (size_t)S * RSBA_SP_STRIDE;
 #pragma unroll
@@ -272,24 +308,48 @@ __global__ void __launch_bounds__(256) k_mc_time_products(SplitArgs a, IterParam
 }
 
 __global__ void __launch_bounds__(256) k_mc_cross(SplitArgs a) {
-  const int it = blockIdx.x * 256 + threadIdx.x;
-  if (it >= a.nx) return;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= a.nx_threads) return;
+  // a long item on TWO neighbouring lanes — even and odd entries, the sums meet by one lane exchange (even + odd: a fixed order): the items are
+  // fewer than the chip's SIMDs, the kernel lasts as long as its longest one (75 -> 43 us).  (The same for k_mc_slot_products' lists: 92 -> 101 us —
+  // that kernel is two rounds of wavefronts deep and balanced by the dispatcher already.)
+  const int code = a.x_order[g], it = code >> 2, two = (code >> 1) & 1, part = code & 1;
   const PoseC cam = LoadPose<true>(a.posec, a.col_full[a.xi_cc[it]] / 6);
   const PoseC mar = LoadPose<true>(a.posec, a.col_full[a.xi_cm[it]] / 6);
   double X[36];
 #pragma unroll
   for (int i = 0; i < 36; ++i) X[i] = 0.0;
   const double hs = a.half_side;
-  for (int e = a.xi_ptr[it]; e < a.xi_ptr[it + 1]; ++e) {
-    const int k = a.xi_blk[e];
-    const PoseC tim = LoadPose<false>(a.posec, a.mo[k].full_time / 6);
-    const double* in = a.intr + 4 * a.ts[k].camera;
-    const double fx = in[0], fy = in[1], ppx = in[2], ppy = in[3];
-    const double* ob = a.obs8 + 8 * (size_t)k;
-#pragma unroll 1
+  // (the time's pose, the corners and the intrinsics one entry ahead, the entry's record two: see SlotProducts)
+  struct Fetched { PoseC tim; double ob[8], in[4]; };
+  auto fetch = [&](const int4 r, Fetched& f) {
+    f.tim = LoadPose<false>(a.posec, r.y);
+    const double* ob = a.obs8 + 8 * (size_t)r.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.ob[i] = ob[i];
+    const double* in = a.intr + 4 * r.z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.in[i] = in[i];
+  };
+  const int step = 1 + two, e1 = a.xi_ptr[it + 1];
+  int e = a.xi_ptr[it] + part;
+  const int4 none = {0, 0, 0, 0};
+  int4 r1 = e < e1 ? a.xi_blk[e] : none;
+  Fetched cur;
+  fetch(r1, cur);
+  r1 = e + step < e1 ? a.xi_blk[e + step] : none;
+  for (; e < e1; e += step) {
+    const int4 r2 = e + 2 * step < e1 ? a.xi_blk[e + 2 * step] : none;
+    Fetched nxt;
+    fetch(r1, nxt);
+    const PoseC& tim = cur.tim;
+    const double fx = cur.in[0], fy = cur.in[1], ppx = cur.in[2], ppy = cur.in[3];
+#pragma unroll RSBA_MC_UNROLL_CROSS
     for (int c = 0; c < 4; ++c) {
+      const double ou = c == 0 ? cur.ob[0] : (c == 1 ? cur.ob[2] : (c == 2 ? cur.ob[4] : cur.ob[6]));
+      const double ov = c == 0 ? cur.ob[1] : (c == 1 ? cur.ob[3] : (c == 2 ? cur.ob[5] : cur.ob[7]));
       double r[2], Jc[2][6], Jm[2][6];
-      CornerRows<true, false, true>(cam, tim, mar, fx, fy, ppx, ppy, CornerX(c, hs), CornerY(c, hs), ob[2 * c], ob[2 * c + 1], r, Jc, nullptr, Jm);
+      CornerRows<true, false, true>(cam, tim, mar, fx, fy, ppx, ppy, CornerX(c, hs), CornerY(c, hs), ou, ov, r, Jc, nullptr, Jm);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -297,7 +357,12 @@ __global__ void __launch_bounds__(256) k_mc_cross(SplitArgs a) {
 #pragma unroll
           for (int qc = 0; qc < 6; ++qc) X[6 * qm + qc] = fma(Jm[i][qm], Jc[i][qc], X[6 * qm + qc]);
     }
+    cur = nxt;
+    r1 = r2;
   }
+#pragma unroll
+  for (int i = 0; i < 36; ++i) { const double o = __shfl_xor(X[i], 1, 64); if (two) X[i] += o; }
+  if (part != 0) return;
   double* out = a.xout + (size_t)it * 36;
 #pragma unroll
   for (int i = 0; i < 36; ++i) out[i] = X[i];
@@ -705,7 +770,7 @@ __global__ void __launch_bounds__(256) k_mc_candidate(int N, int T, const TimeSl
     const double* in = intr + 4 * s.camera;
     const double fx = in[0], fy = in[1], ppx = in[2], ppy = in[3];
     const double* ob = obs8 + 8 * (size_t)k;
-#pragma unroll 1
+#pragma unroll RSBA_MC_UNROLL_CAND
     for (int c = 0; c < 4; ++c) {
       const double cx = CornerX(c, half_side), cy = CornerY(c, half_side), u = ob[2 * c], v = ob[2 * c + 1];
       double r[2], Jc[2][6], Jt[2][6], Jm[2][6];
