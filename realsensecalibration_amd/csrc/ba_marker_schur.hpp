@@ -1051,6 +1051,7 @@ struct MarkerSchurDevice {
     lds_elim = (size_t)(13 * dmax + 96 + RSBA_MT_TILE * (RSBA_MT_JLD + 9) + (dmax / 6 + 2) * CC_STRIDE) * sizeof(double) + (size_t)(2 * RSBA_MT_TILE + 3 * (dmax / 6 + 1) + 2) * sizeof(int);
     lds_s = lds_elim + (PL.packed() + 3 * (size_t)nr) * sizeof(double) <= 156 * 1024;
     if (lds_s) lds_elim += (PL.packed() + 3 * (size_t)nr) * sizeof(double);
+    const bool lds_s_elim = lds_s;   // (k_time_eliminate's own choice, should the split kernels not take the problem)
     split = !(getenv("RSBA_MT_SPLIT") && atoi(getenv("RSBA_MT_SPLIT")) == 0);
     if (split) {
       const int per_wave = (AccMfmaTiles(nr) + 15) / 16;
@@ -1063,7 +1064,11 @@ struct MarkerSchurDevice {
         lds_s = AccLdsBytes(dmax, PL.packed() + 3 * (size_t)nr) <= 156 * 1024;
         lds_acc = AccLdsBytes(dmax, lds_s ? PL.packed() + 3 * (size_t)nr : 0);
       }
-      if (lds_acc > 156 * 1024) return RSBA_ERR_UNSUPPORTED;
+      if (lds_acc > 156 * 1024) {
+        // times that touch more blocks than the accumulation's double-buffered records hold in LDS (~110 of the 170 the model allows):
+        // round 4's kernel, which stages 32 residual blocks at a time whatever the width
+        split = false; acc_tiles = 0; lds_s = lds_s_elim;
+      }
     }
     // Without the LDS accumulators every entry is a read-modify-write in the partial system: few enough workgroups that
     // their partial systems stay in the L2s (8 x 4 MB) then, as many as there are times otherwise (at most 1024).

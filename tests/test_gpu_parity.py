@@ -760,6 +760,19 @@ def test_marker_chain_large_reduced_system(oracle):
     assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
 
 
+def test_marker_chain_times_wider_than_the_split_kernels_hold(oracle):
+    """A shot that touches more camera / marker blocks than the split accumulation's double-buffered records fit in LDS (~110 of the 170 the
+    model allows): the library takes round 4's k_time_eliminate for it (32 residual blocks staged at a time, whatever the width) — 60 cameras
+    x 60 markers all seen in every shot (118 blocks, 3 481 residual blocks a shot: the split kernels with the chunk sums in memory), 62 x 62
+    (122 blocks: k_time_eliminate)."""
+    for C_, T_, M_ in ((60, 5, 60), (62, 4, 62)):
+        prob = syn.make_marker_chain(C_, T_, M_, seed=21, keep=1.0)
+        ref, s_ref, got, s = _solve_marker_chain_both(oracle, prob, 2)
+        assert s.num_iterations == s_ref.num_iterations, (C_, M_)
+        assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost, (C_, M_)
+        assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()), (C_, M_)
+
+
 def test_golden_fixtures_through_time_elimination(oracle, tmp_path):
     """The committed hongo / test2 inputs with schur_impl = 2: same iteration counts and the reference's own outputs."""
     intr = ol.read_intrinsics(ol.SERIALS_MAIN)
