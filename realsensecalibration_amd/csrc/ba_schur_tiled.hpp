@@ -990,6 +990,7 @@ __device__ __forceinline__ void PairSegmentSparse(const SchurArgs& a, const Schu
   unsigned e0 = RSBA_HIT_NONE, e1 = 0, e2 = 0, f0 = RSBA_HIT_NONE, f1 = 0, f2 = 0;
   if (ntrip > 0) { e0 = hl[0]; e1 = hl[1]; e2 = hl[2]; }
   if (ntrip > 1) { f0 = hl[3 * 64]; f1 = hl[3 * 64 + 1]; f2 = hl[3 * 64 + 2]; }
+  bool fv = ntrip > 1;   // (f holds a trip of the list: wave-uniform)
   // camera constants of the tile's 32 cameras: two values per thread
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -1024,12 +1025,14 @@ __device__ __forceinline__ void PairSegmentSparse(const SchurArgs& a, const Schu
     const double sqa = sqn[0], sqb = sqn[1];
     // the next trip's records (its entries came in during the previous trip) and the entries after that go out before this
     // trip's arithmetic
-    e0 = f0; e1 = f1; e2 = f2;
-    if (n + 2 < ntrip) {
-      const unsigned* __restrict__ hn = hl + 3 * 64 * (size_t)(n + 2);
+    // (the entries' load is UNCONDITIONAL — past the list's end the last trip's again, told apart by fv when it is rotated in a trip later:
+    //  under `if (n + 2 < ntrip)` the compiler rotated f1 / f2 inside the branch and waited for the load it had just issued — vmcnt(0) right
+    //  behind it, a trip to memory exposed in every trip of the loop, the entries "two ahead" in name only)
+    e0 = fv ? f0 : RSBA_HIT_NONE; e1 = f1; e2 = f2;
+    {
+      const unsigned* __restrict__ hn = hl + 3 * 64 * (size_t)min(n + 2, ntrip - 1);
       f0 = hn[0]; f1 = hn[1]; f2 = hn[2];
-    } else {
-      f0 = RSBA_HIT_NONE;
+      fv = n + 2 < ntrip;
     }
     if (e0 != RSBA_HIT_NONE) fetch(e0, e1, e2);
     if (!hit) continue;
