@@ -1352,7 +1352,13 @@ struct MarkerSchurDevice {
     if (split_backsub) {
       k_pose_constants_reduced<<<(nr / 6 + 63) / 64, 64, 0, st>>>(nr / 6, col_full, params[c], posec_c);
       k_mc_time_step<<<(8 * T + 255) / 256, 256, 0, st>>>(T, slot_ptr, slot_col, time_full, sp, tdata, delta_r, params[x], params[c], delta_t, posec_c, bp_time);
-      k_mc_candidate<<<ncand_wg, 256, 0, st>>>(N, T, ts, mo, obs8, intr, half_side, posec, posec_c, delta_r, delta_t, blk_time, bp_time);
+      // the two halves of the candidate's evaluation side by side (one after the other when every kernel is timed)
+      const bool fork2 = fork_s[0] != nullptr && !Tm.enabled();
+      hipStream_t s_cost = fork2 ? fork_s[0] : st;
+      if (fork2 && (hipEventRecord(fork_ev[0], st) != hipSuccess || hipStreamWaitEvent(s_cost, fork_ev[0], 0) != hipSuccess)) return RSBA_ERR_HIP;
+      k_mc_candidate<0><<<ncand_wg, 256, 0, st>>>(N, T, ts, mo, obs8, intr, half_side, posec, posec_c, delta_r, delta_t, blk_time, bp_time);
+      k_mc_candidate<1><<<ncand_wg, 256, 0, s_cost>>>(N, T, ts, mo, obs8, intr, half_side, posec, posec_c, delta_r, delta_t, blk_time, bp_time);
+      if (fork2 && (hipEventRecord(fork_ev[1], s_cost) != hipSuccess || hipStreamWaitEvent(st, fork_ev[1], 0) != hipSuccess)) return RSBA_ERR_HIP;
     } else if (backsub_wg) {
       k_pose_constants_reduced<<<(nr / 6 + 63) / 64, 64, 0, st>>>(nr / 6, col_full, params[c], posec_c);
       const size_t lds_bw = (size_t)(dmax / 6 + 1) * (CC_STRIDE + 12 + 6) * sizeof(double);   // the shot's tables (k_time_backsub_wg)

@@ -743,75 +743,85 @@ __global__ void __launch_bounds__(256) k_mc_time_step(int T, const int* __restri
   bp_time[4 * (size_t)t] = d2; bp_time[4 * (size_t)t + 1] = xc2; bp_time[4 * (size_t)t + 2] = 0.0; bp_time[4 * (size_t)t + 3] = 0.0;
 }
 
+// kPart 0: the model cost change (the block's rows at x: 340 registers, one wavefront a SIMD); 1: the candidate's residuals (rotation
+// matrices and translations only: four wavefronts a SIMD) — two launches side by side instead of one kernel with the registers of both.
+template <int kPart>
 __global__ void __launch_bounds__(256) k_mc_candidate(int N, int T, const TimeSlots* __restrict__ ts, const MarkerObs* __restrict__ mo, const double* __restrict__ obs8,
                                                       const double* __restrict__ intr, double half_side, const double* __restrict__ posec,
                                                       const double* __restrict__ posec_c, const double* __restrict__ delta_r, const double* __restrict__ delta_t,
                                                       const int* __restrict__ blk_time, double* __restrict__ bp_time) {
-  __shared__ double s_w[4][2];
+  __shared__ double s_w[4];
   const int k = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double mcc = 0.0, cc = 0.0;
+  double sum = 0.0;
   if (k < N) {
     const TimeSlots s = ts[k];
     const MarkerObs o = mo[k];
-    const PoseC cam = LoadPose<true>(posec, o.full_cam >= 0 ? o.full_cam / 6 : -1);
-    const PoseC tim = LoadPose<true>(posec, o.full_time / 6);
-    const PoseC mar = LoadPose<true>(posec, o.full_marker >= 0 ? o.full_marker / 6 : -1);
-    const PoseC ccam = LoadPose<false>(posec_c, o.full_cam >= 0 ? o.full_cam / 6 : -1);
-    const PoseC ctim = LoadPose<false>(posec_c, o.full_time / 6);
-    const PoseC cmar = LoadPose<false>(posec_c, o.full_marker >= 0 ? o.full_marker / 6 : -1);
-    double dl[18];
-    const int t = blk_time[k];
-#pragma unroll
-    for (int x = 0; x < 6; ++x) {
-      dl[x] = s.col_cam >= 0 ? delta_r[s.col_cam + x] : 0.0;
-      dl[6 + x] = delta_t[6 * t + x];
-      dl[12 + x] = s.col_marker >= 0 ? delta_r[s.col_marker + x] : 0.0;
-    }
     const double* in = intr + 4 * s.camera;
     const double fx = in[0], fy = in[1], ppx = in[2], ppy = in[3];
     const double* ob = obs8 + 8 * (size_t)k;
-#pragma unroll RSBA_MC_UNROLL_CAND
-    for (int c = 0; c < 4; ++c) {
-      const double cx = CornerX(c, half_side), cy = CornerY(c, half_side), u = ob[2 * c], v = ob[2 * c + 1];
-      double r[2], Jc[2][6], Jt[2][6], Jm[2][6];
+    if (kPart == 0) {
+      const PoseC cam = LoadPose<true>(posec, o.full_cam >= 0 ? o.full_cam / 6 : -1);
+      const PoseC tim = LoadPose<true>(posec, o.full_time / 6);
+      const PoseC mar = LoadPose<true>(posec, o.full_marker >= 0 ? o.full_marker / 6 : -1);
+      double dl[18];
+      const int t = blk_time[k];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 6; ++q) Jc[i][q] = 0.0;   // (an absent camera transform: CornerRows leaves the block alone)
-      CornerRows<true, true, true>(cam, tim, mar, fx, fy, ppx, ppy, cx, cy, u, v, r, Jc, Jt, Jm);
-      // (an absent marker transform: its block is formed from the stand-in pose's constants and meets dl[12..17] = 0)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        double m = 0.0;
-#pragma unroll
-        for (int x = 0; x < 6; ++x) m += Jc[i][x] * dl[x];
-#pragma unroll
-        for (int x = 0; x < 6; ++x) m += Jt[i][x] * dl[6 + x];
-#pragma unroll
-        for (int x = 0; x < 6; ++x) m += Jm[i][x] * dl[12 + x];
-        mcc -= m * (r[i] + 0.5 * m);
+      for (int x = 0; x < 6; ++x) {
+        dl[x] = s.col_cam >= 0 ? delta_r[s.col_cam + x] : 0.0;
+        dl[6 + x] = delta_t[6 * t + x];
+        dl[12 + x] = s.col_marker >= 0 ? delta_r[s.col_marker + x] : 0.0;
       }
-      // the candidate's corner through the candidate's transforms (rotation matrices: k_pose_constants_reduced, k_mc_time_step)
-      double pt[3] = {cx, cy, 0.0};
-      auto apply = [&](const PoseC& p) {
-        const double a0 = p.R[0] * pt[0] + p.R[1] * pt[1] + p.R[2] * pt[2], a1 = p.R[3] * pt[0] + p.R[4] * pt[1] + p.R[5] * pt[2], a2 = p.R[6] * pt[0] + p.R[7] * pt[1] + p.R[8] * pt[2];
-        pt[0] = a0 + p.T[0]; pt[1] = a1 + p.T[1]; pt[2] = a2 + p.T[2];
-      };
-      if (cmar.on) apply(cmar);
-      apply(ctim);
-      if (ccam.on) apply(ccam);
-      const double r0 = fx * pt[0] / pt[2] + ppx - u, r1 = fy * pt[1] / pt[2] + ppy - v;
-      cc += r0 * r0 + r1 * r1;
+#pragma unroll RSBA_MC_UNROLL_CAND
+      for (int c = 0; c < 4; ++c) {
+        const double cx = CornerX(c, half_side), cy = CornerY(c, half_side), u = ob[2 * c], v = ob[2 * c + 1];
+        double r[2], Jc[2][6], Jt[2][6], Jm[2][6];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 6; ++q) Jc[i][q] = 0.0;   // (an absent camera transform: CornerRows leaves the block alone)
+        CornerRows<true, true, true>(cam, tim, mar, fx, fy, ppx, ppy, cx, cy, u, v, r, Jc, Jt, Jm);
+        // (an absent marker transform: its block is formed from the stand-in pose's constants and meets dl[12..17] = 0)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          double m = 0.0;
+#pragma unroll
+          for (int x = 0; x < 6; ++x) m += Jc[i][x] * dl[x];
+#pragma unroll
+          for (int x = 0; x < 6; ++x) m += Jt[i][x] * dl[6 + x];
+#pragma unroll
+          for (int x = 0; x < 6; ++x) m += Jm[i][x] * dl[12 + x];
+          sum -= m * (r[i] + 0.5 * m);
+        }
+      }
+    } else {
+      // the candidate's corners through the candidate's transforms (rotation matrices: k_pose_constants_reduced, k_mc_time_step)
+      const PoseC ccam = LoadPose<false>(posec_c, o.full_cam >= 0 ? o.full_cam / 6 : -1);
+      const PoseC ctim = LoadPose<false>(posec_c, o.full_time / 6);
+      const PoseC cmar = LoadPose<false>(posec_c, o.full_marker >= 0 ? o.full_marker / 6 : -1);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double u = ob[2 * c], v = ob[2 * c + 1];
+        double pt[3] = {CornerX(c, half_side), CornerY(c, half_side), 0.0};
+        auto apply = [&](const PoseC& p) {
+          const double a0 = p.R[0] * pt[0] + p.R[1] * pt[1] + p.R[2] * pt[2], a1 = p.R[3] * pt[0] + p.R[4] * pt[1] + p.R[5] * pt[2], a2 = p.R[6] * pt[0] + p.R[7] * pt[1] + p.R[8] * pt[2];
+          pt[0] = a0 + p.T[0]; pt[1] = a1 + p.T[1]; pt[2] = a2 + p.T[2];
+        };
+        if (cmar.on) apply(cmar);
+        apply(ctim);
+        if (ccam.on) apply(ccam);
+        const double r0 = fx * pt[0] / pt[2] + ppx - u, r1 = fy * pt[1] / pt[2] + ppy - v;
+        sum += r0 * r0 + r1 * r1;
+      }
     }
   }
-  for (int off = 32; off > 0; off >>= 1) { mcc += __shfl_down(mcc, off, 64); cc += __shfl_down(cc, off, 64); }
-  if (lane == 0) { s_w[wave][0] = mcc; s_w[wave][1] = cc; }
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if (lane == 0) s_w[wave] = sum;
   __syncthreads();
   if (threadIdx.x == 0) {
     double* out = bp_time + 4 * ((size_t)T + blockIdx.x);
-    out[0] = 0.0; out[1] = 0.0;
-    out[2] = ((s_w[0][0] + s_w[1][0]) + s_w[2][0]) + s_w[3][0];
-    out[3] = ((s_w[0][1] + s_w[1][1]) + s_w[2][1]) + s_w[3][1];
+    const double tot = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+    if (kPart == 0) { out[0] = 0.0; out[1] = 0.0; out[2] = tot; }
+    else out[3] = tot;
   }
 }
 
