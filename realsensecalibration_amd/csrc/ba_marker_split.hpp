@@ -593,22 +593,32 @@ __global__ void __launch_bounds__(RSBA_MT_THREADS) k_mc_accumulate_mfma(AccArgs 
   if (nstep > 0) { issue(0); commit(0); }
   __syncthreads();
   const int mi = lane & 15, mk = lane >> 4;
+  int yx[2], ycol[2];   // this thread's entries of Y = E W: 6 x nrp <= 1440 entries, two a thread at most
+#pragma unroll
+  for (int u = 0; u < 2; ++u) { const int e = tid + RSBA_MT_THREADS * u; yx[u] = e < 6 * nrp ? e / nrp : -1; ycol[u] = e - max(yx[u], 0) * nrp; }
   for (int b = 0; b < nstep; ++b) {
     const int par = b & 1;
     const double* Wb = Wg + (size_t)par * kTB * strip;
     double* Wo = Wg + (size_t)(1 - par) * kTB * strip;
     const double* Eb = Ev + par * kTB * 48;
     if (b + 1 < nstep) issue(b + 1);
-    for (int e = tid; e < kTB * 6 * nrp; e += RSBA_MT_THREADS) {
-      const int j = e / (6 * nrp), r = e - j * 6 * nrp, x = r / nrp, col = r - x * nrp;
-      const double* Wp = Wb + (size_t)j * strip;
-      const double* E = Eb + 48 * j;
-      double sum = 0.0;
+    // (a thread's entries (x, column) of Y are the same in every step: found once, in front of the loop — two integer divisions per
+    //  entry and step were a third of this phase's instructions)
 #pragma unroll
-      for (int y = 0; y < 6; ++y) sum += E[6 * x + y] * Wp[y * nrp + col];
-      Yg[(size_t)j * strip + r] = sum;
+    for (int u = 0; u < 2; ++u) {
+      if (yx[u] >= 0) {
+#pragma unroll
+        for (int j = 0; j < kTB; ++j) {
+          const double* Wp = Wb + (size_t)j * strip;
+          const double* E = Eb + 48 * j + 6 * yx[u];
+          double sum = 0.0;
+#pragma unroll
+          for (int y = 0; y < 6; ++y) sum += E[y] * Wp[y * nrp + ycol[u]];
+          Yg[(size_t)j * strip + yx[u] * nrp + ycol[u]] = sum;
+        }
+      }
     }
-    for (int e = tid; e < kTB * 7 * nrp; e += RSBA_MT_THREADS) { const int j = e / (7 * nrp); Wo[(size_t)j * strip + (e - j * 7 * nrp)] = 0.0; }
+    for (int e = tid; e < kTB * strip; e += RSBA_MT_THREADS) Wo[e] = 0.0;   // (whole strips: row 7 is zero already)
     for (int e = tid; e < kTB * nub; e += RSBA_MT_THREADS) Ug[(size_t)(1 - par) * kTB * nub + e] = 0.0;
     for (int col = tid; col < nr; col += RSBA_MT_THREADS) {
       double g = gacc[col], c = cacc[col];
