@@ -560,6 +560,207 @@ k_marker_reduced_solve(int nr, const double* __restrict__ red, double* __restric
   ReducedStepEpilogue(nr, red, RL, scale_r, ysol, col_full, params_x, params_c, delta_r, out, s_ok > 0, lds);
 }
 
+// k_marker_reduced_solve for systems of up to 160 columns (26 camera + marker blocks: the 8 x 5000 x 16 benchmark has 132) with the WHOLE
+// lower triangle in LDS.  CholeskySolvePanelLDS keeps a panel there and the matrix in memory: per 32-column panel the panel comes
+// in, the strip of L to its left comes in, the panel goes back out — three dependent trips to memory around 7 us of factorisation,
+// 12 us a panel, 77 us for the five of 132 columns (a quarter of the iteration once the elimination was split, ba_marker_split.hpp).
+// Here the lower triangle lies in LDS as five column panels of 33-double rows (the right-hand side rides along as every panel's last
+// row; padding columns are identity), loaded once; right-looking: per panel DiagFactorInverse (one wavefront), X = rows T' and the
+// trailing panels' updates on the matrix cores, T kept where L_pp was; then L' x = y from LDS.  Nothing goes to memory but x.
+// Same scaling and damping as PanelSource's (ba_cholesky.hpp); fixed orders: bitwise reproducible.
+#define RSBA_MRS_MAXP 5
+__host__ __device__ inline size_t MarkerSolveLdsDoubles(int nr) {
+  const int np = (nr + RSBA_PB - 1) / RSBA_PB, npad = RSBA_PB * np;
+  size_t rows = 0;
+  for (int p = 0; p < np; ++p) rows += (size_t)(npad + 1 - RSBA_PB * p);
+  return rows * RSBA_PLD + 2 * RSBA_PB * RSBA_PLD + RSBA_PB + 2 * (size_t)npad;   // panels (>= 2048 doubles: the epilogue's scratch, once they are done with) | T | Lt | invd | scl | y, then x
+}
+__global__ void __launch_bounds__(512)
+k_marker_reduced_solve_lds(int nr, const double* __restrict__ red, double* __restrict__ A, double* __restrict__ scale_r,
+                           const int* __restrict__ col_full, const double* __restrict__ params_x, double* __restrict__ params_c,
+                           double* __restrict__ delta_r, double* __restrict__ out, IterParams ip) {
+  extern __shared__ double lds[];
+  const RedLayout RL{nr};
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nt >> 6, mi = lane & 15, kk = lane >> 4;
+  const int np = (nr + RSBA_PB - 1) / RSBA_PB, npad = RSBA_PB * np;
+  __shared__ int s_ok;
+  __shared__ double s_red[8][4];
+  int poff[RSBA_MRS_MAXP + 1];   // panel p: rows 32 p .. npad (the right-hand side) of its 32 columns
+  poff[0] = 0;
+#pragma unroll
+  for (int p = 0; p < RSBA_MRS_MAXP; ++p) poff[p + 1] = poff[p] + (npad + 1 - RSBA_PB * p) * RSBA_PLD;
+  double* T = lds + poff[np];
+  double* Lt = T + RSBA_PB * RSBA_PLD;
+  double* invd = Lt + RSBA_PB * RSBA_PLD;
+  double* scl = invd + RSBA_PB;        // npad
+  double* yv = scl + npad;             // npad: the damping diagonal while the panels are filled, then y, then x
+  double* tmp32 = invd;                // (the back-substitution's 32 doubles: the inverse pivots are done with by then)
+  if (tid == 0) s_ok = 1;
+  // ---- everything the kernel reads from memory, asked for in ONE go: the thread's entry of the vectors (nr <= 160 < 512: one each),
+  // then its entries of S — element e = tid + 512 u of panel p's (rows x 32) block, at most eleven a panel.  (Entry by entry under
+  // their branches the loads were 30 dependent trips to memory a thread: 15 us of the kernel's 78.)
+  const bool mine = tid < nr;
+  const double my_du = mine ? red[RL.diagU() + tid] : 0.0, my_gc = mine ? red[RL.gc() + tid] : 0.0, my_corr = mine ? red[RL.corr() + tid] : 0.0;
+  const double my_sc_old = (mine && !ip.first) ? scale_r[tid] : 1.0;
+  const int my_cf = mine ? col_full[tid] : 0;
+  constexpr int kMaxE = (RSBA_PB * RSBA_MRS_MAXP + 1 + 15) / 16;   // 11
+  double sv[RSBA_MRS_MAXP][kMaxE];
+#pragma unroll
+  for (int p = 0; p < RSBA_MRS_MAXP; ++p) {
+#pragma unroll
+    for (int u = 0; u < kMaxE; ++u) {
+      sv[p][u] = 0.0;
+      if (u < kMaxE - 2 * p) {   // (panel p has 161 - 32 p rows at most: 11, 9, 7, 5, 3 elements a thread)
+        const int kb = RSBA_PB * p, e = tid + u * nt, gi = kb + (e >> 5), gj = kb + (e & 31);
+        if (p < np && gi < nr && gj < nr) sv[p][u] = red[RL.S() + (size_t)gi * nr + gj];
+      }
+    }
+  }
+  const double my_x = mine ? params_x[my_cf] : 0.0;
+  if (tid < npad) {
+    double sc = 1.0;
+    if (mine) { sc = ip.first ? (ip.jacobi_scaling ? 1.0 / (1.0 + sqrt(my_du)) : 1.0) : my_sc_old; if (ip.first) scale_r[tid] = sc; }
+    scl[tid] = sc;
+    yv[tid] = my_du;
+  }
+  __syncthreads();
+  const double inv_radius = 1.0 / ip.radius;
+#pragma unroll
+  for (int p = 0; p < RSBA_MRS_MAXP; ++p) {
+    if (p < np) {
+      const int kb = RSBA_PB * p, R = npad + 1 - kb;
+      double* Pan = lds + poff[p];
+#pragma unroll
+      for (int u = 0; u < kMaxE; ++u) {
+        const int e = tid + u * nt;
+        if (u < kMaxE - 2 * p && e < R * RSBA_PB) {
+          const int r = e >> 5, c = e & 31, gi = kb + r, gj = kb + c;
+          double v;
+          if (gi == npad) v = 0.0;   // (the right-hand side: below)
+          else if (gi >= nr || gj >= nr) v = gi == gj ? 1.0 : 0.0;
+          else {
+            v = sv[p][u] * (scl[gi] * scl[gj]);
+            if (gi == gj) v += fmin(fmax(scl[gi] * scl[gi] * yv[gi], ip.min_lm_diagonal), ip.max_lm_diagonal) * inv_radius;
+          }
+          Pan[r * RSBA_PLD + c] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();   // (the damping diagonal in yv has been read)
+  if (mine) { const int p = tid >> 5; (lds + poff[p])[(npad - RSBA_PB * p) * RSBA_PLD + (tid & 31)] = scl[tid] * (my_gc + my_corr); }   // s_j (g_j + corr_j): the panel's last row
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < RSBA_MRS_MAXP; ++p) {
+    if (p >= np) break;
+    const int R = npad + 1 - RSBA_PB * p;   // rows of the panel, the right-hand side's included
+    double* Pan = lds + poff[p];
+    if (wave == 0 && !DiagFactorInverseCall((lds_double*)Pan, RSBA_PB, (lds_double*)T, (lds_double*)Lt, (lds_double*)invd, lane) && lane == 0) s_ok = 0;
+    __syncthreads();
+    // X = rows T' for the rows below the diagonal block (CholeskySolvePanelLDS, step 4)
+    {
+      const int nrb = (R - RSBA_PB + 15) >> 4;
+      for (int rb = wave; rb < nrb; rb += nwave) {
+        const int prow = RSBA_PB + rb * 16 + mi;
+        d4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int qs = 0; qs < RSBA_PB; qs += 4) {
+          const double a = prow < R ? Pan[prow * RSBA_PLD + qs + kk] : 0.0;
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[mi * RSBA_PLD + qs + kk], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[(16 + mi) * RSBA_PLD + qs + kk], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();   // all of this block's rows are read before any is overwritten
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int r = RSBA_PB + rb * 16 + kk + 4 * tt;
+          if (r < R) { Pan[r * RSBA_PLD + mi] = acc0[tt]; Pan[r * RSBA_PLD + 16 + mi] = acc1[tt]; }
+        }
+      }
+    }
+    __syncthreads();
+    // T_p takes L_pp's place (the back-substitution wants T_p and the blocks below; L_pp itself is done with)
+    for (int e = tid; e < RSBA_PB * RSBA_PB; e += nt) Pan[(e >> 5) * RSBA_PLD + (e & 31)] = T[(e >> 5) * RSBA_PLD + (e & 31)];
+    // the trailing panels: (i, j) -= sum_k L(i, k) L(j, k) over this panel's columns k — 16 x 16 tiles, both operands from this panel
+    {
+      int tile0 = 0;
+#pragma unroll
+      for (int q = 1; q < RSBA_MRS_MAXP; ++q) {
+        if (q <= p || q >= np) continue;
+        const int Rq = npad + 1 - RSBA_PB * q, nrt = (Rq + 15) >> 4;     // rows of panel q, its 16-row tiles (two column tiles each)
+        double* Pq = lds + poff[q];
+        const int roff = RSBA_PB * (q - p);                                 // panel q's row 0 / column block inside panel p
+        const int m = tile0 & (nwave - 1);
+        for (int t = wave - m + (wave < m ? nwave : 0); t < 2 * nrt; t += nwave) {   // (tile tile0 + t is wavefront (tile0 + t) mod 8's)
+          const int rt = t >> 1, ct = t & 1;
+          const int prow = roff + 16 * rt + mi;
+          d4_t acc = {0, 0, 0, 0};
+#pragma unroll
+          for (int qs = 0; qs < RSBA_PB; qs += 4) {
+            const double a = prow < R ? Pan[prow * RSBA_PLD + qs + kk] : 0.0;
+            const double b = Pan[(roff + 16 * ct + mi) * RSBA_PLD + qs + kk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) {
+            const int r = 16 * rt + kk + 4 * tt;
+            if (r < Rq) Pq[r * RSBA_PLD + 16 * ct + mi] -= acc[tt];
+          }
+        }
+        tile0 += 2 * nrt;
+      }
+    }
+    __syncthreads();
+  }
+  // y (the panels' last rows) and L' x = y, block by block from the last: one wavefront, lane (c, h) half of a column's terms
+  if (wave == 0) {
+    const int c = lane & 31, h = lane >> 5;
+    for (int p = 0; p < np; ++p) if (lane < RSBA_PB) yv[RSBA_PB * p + lane] = (lds + poff[p])[(npad - RSBA_PB * p) * RSBA_PLD + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int p = np - 1; p >= 0; --p) {
+      const double* Pan = lds + poff[p];
+      // t = y_p - sum over the rows below of L(row, 32 p + c) x(row)
+      double t = 0.0;
+      const int nbelow = npad - RSBA_PB * (p + 1);
+      for (int r = h; r < nbelow; r += 2) t = fma(Pan[(RSBA_PB + r) * RSBA_PLD + c], yv[RSBA_PB * (p + 1) + r], t);
+      t += __shfl_xor(t, 32, 64);
+      const double tv = yv[RSBA_PB * p + c] - t;
+      __builtin_amdgcn_wave_barrier();
+      if (lane < RSBA_PB) tmp32[lane] = tv;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // x_p = T_p' t  (T_p lies where L_pp was: T[i][c], i >= c)
+      double x = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x = fma(Pan[(16 * h + k) * RSBA_PLD + c], tmp32[16 * h + k], x);
+      x += __shfl_xor(x, 32, 64);
+      __builtin_amdgcn_wave_barrier();
+      if (lane < RSBA_PB) yv[RSBA_PB * p + lane] = x;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  __syncthreads();
+  // the step of the reduced blocks and its norms (ReducedStepEpilogue's arithmetic on what this thread already holds; the lanes by
+  // butterfly, the wavefronts in order: one barrier instead of a tree of eleven)
+  double d2 = 0.0, x2 = 0.0, xc2 = 0.0, gm = 0.0;
+  if (mine) {
+    const double dd = -scl[tid] * yv[tid], xc = my_x + dd;
+    delta_r[tid] = dd;
+    params_c[my_cf] = xc;
+    d2 = dd * dd; x2 = my_x * my_x; xc2 = xc * xc; gm = fabs(my_gc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    d2 += __shfl_xor(d2, off, 64); x2 += __shfl_xor(x2, off, 64); xc2 += __shfl_xor(xc2, off, 64); gm = fmax(gm, __shfl_xor(gm, off, 64));
+  }
+  if (lane == 0) { s_red[wave][0] = d2; s_red[wave][1] = x2; s_red[wave][2] = xc2; s_red[wave][3] = gm; }
+  __syncthreads();
+  if (tid == 0) {
+    double t4[4] = {s_red[0][0], s_red[0][1], s_red[0][2], s_red[0][3]};
+    for (int w8 = 1; w8 < nwave; ++w8) { t4[0] += s_red[w8][0]; t4[1] += s_red[w8][1]; t4[2] += s_red[w8][2]; t4[3] = fmax(t4[3], s_red[w8][3]); }
+    out[0] = t4[0]; out[1] = t4[1]; out[2] = t4[2]; out[3] = t4[3]; out[4] = s_ok > 0 ? 1.0 : 0.0;
+  }
+  (void)A;
+}
+
 __global__ void __launch_bounds__(1024)
 k_marker_chol_finish(int nr, const double* __restrict__ red, double* __restrict__ F, const double* __restrict__ scale_r,
                      const int* __restrict__ col_full, const double* __restrict__ params_x, double* __restrict__ params_c,
@@ -927,6 +1128,7 @@ struct MarkerSchurDevice {
   int *slot_order = nullptr, *slot_time = nullptr, *sb_ptr = nullptr, *xi_ptr = nullptr, *xi_cc = nullptr, *xi_cm = nullptr, *xc_ptr = nullptr;
   double *sp = nullptr, *xout = nullptr, *tscal = nullptr;
   size_t lds_acc = 0;
+  bool solve_lds = false;       // k_marker_reduced_solve_lds (the whole triangle in LDS: up to 160 reduced columns)
   bool split_backsub = false;   // k_mc_time_step + k_mc_candidate instead of k_time_backsub_wg / _terms
   int* blk_time = nullptr;
   int ncand_wg = 0;
@@ -1222,6 +1424,9 @@ struct MarkerSchurDevice {
       const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(nr)) * sizeof(double);
       if (lds_c > 48 * 1024 &&
           hipFuncSetAttribute((const void*)k_marker_reduced_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return RSBA_ERR_HIP;
+      solve_lds = nr <= RSBA_PB * RSBA_MRS_MAXP && MarkerSolveLdsDoubles(nr) * sizeof(double) <= 156 * 1024 && !(getenv("RSBA_MT_SOLVE_LDS") && atoi(getenv("RSBA_MT_SOLVE_LDS")) == 0);
+      if (getenv("RSBA_DEBUG")) fprintf(stderr, "rsba: marker reduced system %d columns, solve in LDS: %d (%zu bytes)\n", nr, (int)solve_lds, MarkerSolveLdsDoubles(nr) * sizeof(double));
+      if (solve_lds && hipFuncSetAttribute((const void*)k_marker_reduced_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MarkerSolveLdsDoubles(nr) * sizeof(double))) != hipSuccess) return RSBA_ERR_HIP;
     } else {
       if (hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CholStepLdsDoubles() * sizeof(double))) != hipSuccess)
         return RSBA_ERR_HIP;
@@ -1320,7 +1525,8 @@ struct MarkerSchurDevice {
     if (nr <= RSBA_CHOL_MAXN) {
       const size_t lds_c = std::max((size_t)4 * 1024, CholeskyLdsDoubles(nr)) * sizeof(double);
       Tm.Begin("k_marker_reduced_solve", st);
-      k_marker_reduced_solve<<<1, 512, lds_c, st>>>(nr, red, A, scale_r, col_full, params[x], params[c], delta_r, solve_out, ip);
+      if (solve_lds) k_marker_reduced_solve_lds<<<1, 512, MarkerSolveLdsDoubles(nr) * sizeof(double), st>>>(nr, red, A, scale_r, col_full, params[x], params[c], delta_r, solve_out, ip);
+      else k_marker_reduced_solve<<<1, 512, lds_c, st>>>(nr, red, A, scale_r, col_full, params[x], params[c], delta_r, solve_out, ip);
       Tm.End(st);
     } else {
       Tm.Begin("k_sys_build", st);
