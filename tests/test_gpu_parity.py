@@ -647,12 +647,14 @@ def _solve_marker_chain_both(oracle, prob, schur_impl, model=capi.MODEL_MARKER_C
     return ref, s_ref, got, s
 
 
-@pytest.mark.parametrize("env", [{}, {"RSBA_MT_ACC_MFMA": "0"}, {"RSBA_MT_FORK": "0"}, {"RSBA_MT_SPLIT": "0"}], ids=["default", "valu-accumulate", "one-stream", "k_time_eliminate"])
+@pytest.mark.parametrize("env", [{}, {"RSBA_MT_ACC_MFMA": "0"}, {"RSBA_MT_FORK": "0"}, {"RSBA_MT_SPLIT": "0"}, {"RSBA_MT_SOLVE_LDS": "0"}],
+                         ids=["default", "valu-accumulate", "one-stream", "k_time_eliminate", "panel-solver"])
 @pytest.mark.parametrize("shape", [(4, 40, 6), (8, 120, 12), (3, 300, 4), (12, 40, 20)])
 def test_marker_chain_time_elimination_matches_oracle(oracle, shape, env, monkeypatch):
     """The split elimination (csrc/ba_marker_split.hpp, round 6) in its variants — the chunk's sum of W'Y on the matrix cores in the
     wavefronts' registers (up to 144 reduced columns: three tiles a wavefront; up to 240: eight — the (12, 40, 20) shape, 180 columns),
-    the VALU accumulation in LDS (wider systems; forced here), the three product kernels on one stream — and round 4's k_time_eliminate."""
+    the VALU accumulation in LDS (wider systems; forced here), the three product kernels on one stream — and round 4's k_time_eliminate; the
+    reduced solve with the whole triangle in LDS (up to 160 columns: 48, 108, 30 here; 180 takes the panel solver) or the panel solver forced."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     C_, T_, M_ = shape
