@@ -1087,17 +1087,31 @@ k_time_backsub_wg(int T, const int* __restrict__ time_ptr, const int* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256)
+// (1024 threads, an entry = 32 bytes in two 16-byte loads, four entries in flight a thread, the lanes by butterfly and the sixteen
+//  wavefronts in order: 256 threads walking 27 entries each, one dependent trip to memory after the other, and a tree of eight
+//  barriers were 11 us for 200 KB)
+__global__ void __launch_bounds__(1024)
 k_marker_schur_finish(int nb_time, const double* __restrict__ bp_time, const double* __restrict__ red_scal,
                       const double* __restrict__ solve_out, double* __restrict__ res) {
-  __shared__ double s[4][256];
-  const int tid = threadIdx.x;
+  __shared__ double s[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double v[4] = {0, 0, 0, 0};
-  for (int b = tid; b < nb_time; b += 256) for (int k = 0; k < 4; ++k) v[k] += bp_time[4 * b + k];
-  for (int k = 0; k < 4; ++k) s[k][tid] = v[k];
+  const double2* __restrict__ bp2 = reinterpret_cast<const double2*>(bp_time);
+  for (int b0 = tid; b0 < nb_time; b0 += 4 * 1024) {
+    double2 lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int b = min(b0 + 1024 * u, nb_time - 1); lo[u] = bp2[2 * b]; hi[u] = bp2[2 * b + 1]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (b0 + 1024 * u < nb_time) { v[0] += lo[u].x; v[1] += lo[u].y; v[2] += hi[u].x; v[3] += hi[u].y; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += __shfl_xor(v[k], off, 64);
+  if (lane == 0) for (int k = 0; k < 4; ++k) s[k][wave] = v[k];
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) { if (tid < off) for (int k = 0; k < 4; ++k) s[k][tid] += s[k][tid + off]; __syncthreads(); }
   if (tid == 0) {
+    for (int k = 0; k < 4; ++k) { double t = s[k][0]; for (int w = 1; w < 16; ++w) t += s[k][w]; s[k][0] = t; }
     res[RES_COST_X] = 0.5 * red_scal[0];
     res[RES_GMAX] = fmax(red_scal[3], solve_out[3]);
     res[RES_XNORM2] = red_scal[1] + solve_out[1];
@@ -1576,7 +1590,7 @@ struct MarkerSchurDevice {
     }
     Tm.End(st);
     Tm.Begin("k_marker_schur_finish", st);
-    k_marker_schur_finish<<<1, 256, 0, st>>>(nb_time, bp_time, red + RL.scal(), solve_out, res);
+    k_marker_schur_finish<<<1, 1024, 0, st>>>(nb_time, bp_time, red + RL.scal(), solve_out, res);
     Tm.End(st);
     if (!chk("k_marker_schur_finish")) return RSBA_ERR_HIP;
     if (hipMemcpyAsync(res_host, res, RES_SIZE * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return RSBA_ERR_HIP;
