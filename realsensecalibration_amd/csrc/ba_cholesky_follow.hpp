@@ -1,10 +1,12 @@
-// LAB (round 6): DiagFactorInverse's factorisation with FOLLOWER rows — the rows of the blocks below a 32 x 32 diagonal block take the
-// factoring wavefront's own steps (scale column j, subtract l_ij l_cj) and end as X = A L11^-T, without the inverse of L11 and the
-// product with it.  Set A: 32 rows in the lanes 32..63 (which DiagFactorInverse leaves to shadow the lanes 0..31); set B: 32 more rows
-// in a second set of registers of the lanes 0..31.  tools/lab/follow_bench.hip measures it against DiagFactorInverse / DiagFactorOnly
-// (+ TrsmRowsQuad); HISTORY.md round 6 has the numbers and why the product does not use it.
+// DiagFactorInverse's factorisation (ba_cholesky.hpp) with FOLLOWER rows — the rows of the blocks below a 32 x 32 diagonal block take the
+// factoring wavefront's own steps (scale column j, subtract l_ij l_cj) and end as X = A L11^-T, without the inverse of L11 and without a
+// substitution behind the factorisation.  Set A: 32 rows in the lanes 32..63 (which DiagFactorInverse leaves to shadow the lanes 0..31);
+// set B: 32 more rows in a second set of registers of the lanes 0..31.  Alone on a CU (tools/lab/follow_bench.hip, profiles/r06_follow_bench.txt):
+// factor alone 4.81 us, + 32 follower rows 5.32, + 64: 6.83; factor then TrsmRowsQuad of 32 rows by two wavefronts 6.31.  Used by the
+// tiled factorisation's diagonal tiles for their own rows 32..63 (ba_cholesky_tiles.hpp, round 6); in the border's workgroup of the
+// 64-camera kernel it was slower (the substitution it replaces ran beside the next pivot chain there: HISTORY.md).
 #pragma once
-#include "../../realsensecalibration_amd/csrc/ba_cholesky.hpp"
+#include "ba_cholesky.hpp"
 namespace rsba {
 template <bool kSetB>
 __device__ __forceinline__ bool DiagFactorFollow(double* __restrict__ Pan, double* __restrict__ T, double* __restrict__ Lt, double* __restrict__ invd,
@@ -173,10 +175,10 @@ __device__ __forceinline__ bool DiagFactorFollow(double* __restrict__ Pan, doubl
       return __builtin_amdgcn_ballot_w64(piv && (!(ilv > 0.0) || !(ilv <= DBL_MAX))) == 0;
 }
 
-__device__ __noinline__ bool DiagFactorFollowACall(lds_double* Pan, lds_double* T, lds_double* Lt, lds_double* invd, lds_double* FolA, int lane) {
+static __device__ __noinline__ bool DiagFactorFollowACall(lds_double* Pan, lds_double* T, lds_double* Lt, lds_double* invd, lds_double* FolA, int lane) {
   return DiagFactorFollow<false>((double*)Pan, (double*)T, (double*)Lt, (double*)invd, (double*)FolA, nullptr, lane);
 }
-__device__ __noinline__ bool DiagFactorFollowABCall(lds_double* Pan, lds_double* T, lds_double* Lt, lds_double* invd, lds_double* FolA, lds_double* FolB, int lane) {
+static __device__ __noinline__ bool DiagFactorFollowABCall(lds_double* Pan, lds_double* T, lds_double* Lt, lds_double* invd, lds_double* FolA, lds_double* FolB, int lane) {
   return DiagFactorFollow<true>((double*)Pan, (double*)T, (double*)Lt, (double*)invd, (double*)FolA, (double*)FolB, lane);
 }
 }  // namespace rsba

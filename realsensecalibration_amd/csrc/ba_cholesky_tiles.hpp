@@ -23,6 +23,7 @@
 #include <vector>
 #include "ba_cholesky_large.hpp"
 #include "ba_cholesky_multi.hpp"
+#include "ba_cholesky_follow.hpp"
 
 namespace rsba {
 
@@ -386,9 +387,13 @@ static __device__ __noinline__ bool DiagTileColumn(const TileCtx& c, lds_double*
     double* ivx = L.invd + 32 * hf;
     TileStamp(f, J, hf ? 6 : 2);
     for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) { const int r = e >> 5, cc = e & 31; L.Pan[r * RSBA_PLD + cc] = L.Tl[(lc + r) * RSBA_TL + lc + cc]; }
+    // (first half: the tile's rows 32..63 of these columns FOLLOW the factorisation — lanes 32..63 of the factoring wavefront, DiagFactorFollow —
+    //  and are X when it returns: no substitution behind it, 2.8 us of every tile column's 18.5)
+    if (hf == 0) { for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) { const int r = e >> 5, cc = e & 31; L.XI[(32 + r) * RSBA_PLD + cc] = L.Tl[(32 + r) * RSBA_TL + cc]; } }
     __syncthreads();
     if (wave == 0) {
-      const bool good = DiagFactorOnlyCall((lds_double*)L.Pan, RSBA_PB, (lds_double*)Tscr, (lds_double*)Ltx, (lds_double*)ivx, lane);   // (inlined here: slower, 546 vs 520 us)
+      const bool good = hf == 0 ? DiagFactorFollowACall((lds_double*)L.Pan, (lds_double*)Tscr, (lds_double*)Ltx, (lds_double*)ivx, (lds_double*)(L.XI + 32 * RSBA_PLD), lane)
+                                : DiagFactorOnlyCall((lds_double*)L.Pan, RSBA_PB, (lds_double*)Tscr, (lds_double*)Ltx, (lds_double*)ivx, lane);   // (inlined here: slower, 546 vs 520 us)
       if (lane == 0) L.flags[0] = good ? 1 : 0;
     } else if (wave == 1 && hf == 1) {
       // the first block's inverse, its place in F, the first half's flags (every wavefront's stores of L11 and X were
@@ -431,7 +436,6 @@ static __device__ __noinline__ bool DiagTileColumn(const TileCtx& c, lds_double*
       for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) {
         const double v = DenseLtT(Ltx, ivx, e);
         if (wanted) StoreShared(&hs[e], v);
-        if (hf == 0) L.T[(e >> 5) * RSBA_PLD + (e & 31)] = v;
       }
     }
     for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) {
@@ -452,9 +456,7 @@ static __device__ __noinline__ bool DiagTileColumn(const TileCtx& c, lds_double*
       TileStamp(f, J, 8);
       break;
     }
-    __syncthreads();                                 // L11 transposed is in T
-    TrsmRowsQuad(L.Tl + 32 * RSBA_TL, RSBA_TL, L.T, L.XI + 32 * RSBA_PLD, tid, 32);   // (wavefronts 0 and 1)
-    for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) L.XI[(e >> 5) * RSBA_PLD + (e & 31)] = 0.0;   // rows above the block: no X
+    for (int e = tid; e < RSBA_PB * RSBA_PB; e += 256) L.XI[(e >> 5) * RSBA_PLD + (e & 31)] = 0.0;   // rows above the block: no X (rows 32..63: the followers')
     if (tid == 0) L.flags[2] = 0;
     __syncthreads();
     // X (XI rows 32..63) leaves from registers of the wavefronts 2 and 3 in the second half: nothing waits for its stores here

@@ -1,4 +1,4 @@
-// Micro-benchmark + check of the follower factorisation (tools/lab/factor_follow.hpp) against the product's routines:
+// Micro-benchmark + check of the follower factorisation (csrc/ba_cholesky_follow.hpp) against the product's routines:
 //   V0  DiagFactorInverseCall (factor + inverse)                     V1  DiagFactorOnlyCall (factor alone)
 //   V2  DiagFactorFollowACall (factor + 32 follower rows)            V3  DiagFactorFollowABCall (factor + 64 follower rows)
 //   V4  DiagFactorOnlyCall + TrsmRowsQuad of 32 rows by wavefronts 0, 1 (what the tiled factorisation does for its rows 32..63)
@@ -8,7 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <vector>
-#include "factor_follow.hpp"
+#include "../../realsensecalibration_amd/csrc/ba_cholesky_follow.hpp"
 
 using namespace rsba;
 
