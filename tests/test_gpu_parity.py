@@ -762,6 +762,19 @@ def test_marker_chain_large_reduced_system(oracle):
     assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_marker_chain_random_shapes_match_the_oracle(oracle, seed):
+    """Twelve seeded random shapes of the marker-chain model through the time elimination (round 6: the split kernels) — cameras, shots,
+    markers, visibility and noise drawn as tools/fuzz_marker_chain.py draws them (120 more: profiles/r06_fuzz_marker_chain_120_seed2026.txt)."""
+    rng = np.random.default_rng([seed, 0x3C])
+    C_, M_, T_ = int(rng.integers(2, 14)), int(rng.integers(2, 22)), int(rng.integers(3, 160))
+    prob = syn.make_marker_chain(C_, T_, M_, seed=int(rng.integers(1, 1 << 30)), keep=float(rng.uniform(0.35, 1.0)), noise_px=float(rng.choice([0.05, 0.3, 1.0])))
+    ref, s_ref, got, s = _solve_marker_chain_both(oracle, prob, 2)
+    assert (s.num_iterations, s.num_successful_steps) == (s_ref.num_iterations, s_ref.num_successful_steps), (C_, T_, M_)
+    assert abs(s.final_cost - s_ref.final_cost) < 1e-9 * s_ref.final_cost, (C_, T_, M_)
+    assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()), (C_, T_, M_)
+
+
 def test_marker_chain_times_wider_than_the_split_kernels_hold(oracle):
     """A shot that touches more camera / marker blocks than the split accumulation's double-buffered records fit in LDS (~110 of the 170 the
     model allows): the library takes round 4's k_time_eliminate for it (32 residual blocks staged at a time, whatever the width) — 60 cameras
